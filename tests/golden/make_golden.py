@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Generate the committed golden vectors by running the UNMODIFIED reference on CPU.
+
+Run in the build container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Outputs tests/golden/*.npz: inputs + reference outputs (energy f64, forces/charges f32,
+stress) and a few model intermediates, all for the synthetic weights of
+aimnetcentral_amd.synth (seed recorded in each file together with the state-dict digest).
+The reference is driven through its public API only:
+  AIMNet2Calculator(model_path, device="cpu", deterministic=True, needs_dispersion=False)
+(calculator.py:147-165, eval :879-947) - deterministic=True routes DSF through the in-tree
+torch twin lr.py:559-615, which the reference's own tests pin to the nvalchemiops kernel
+(tests/test_calculator.py:373-428).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+
+import _refshim  # noqa: E402
+
+_refshim.install()
+
+import torch  # noqa: E402
+
+from aimnet.calculators import AIMNet2Calculator  # noqa: E402
+from aimnet.models.base import load_model  # noqa: E402
+
+from aimnetcentral_amd import synth, workloads  # noqa: E402
+
+SEED = 0
+torch.set_num_threads(8)
+
+
+def make_calc(path: str) -> AIMNet2Calculator:
+    return AIMNet2Calculator(path, device="cpu", deterministic=True, needs_dispersion=False)
+
+
+def read_taxol() -> tuple[np.ndarray, np.ndarray]:
+    sym = {"H": 1, "C": 6, "N": 7, "O": 8}
+    with open(os.path.join(_refshim.REFERENCE_ROOT, "examples", "taxol.xyz")) as f:
+        n = int(f.readline())
+        f.readline()
+        rows = [f.readline().split() for _ in range(n)]
+    numbers = np.array([sym[r[0]] for r in rows], dtype=np.int64)
+    coord = np.array([[float(x) for x in r[1:4]] for r in rows], dtype=np.float64)
+    return coord, numbers
+
+
+def capture_intermediates(calc: AIMNet2Calculator, data: dict) -> dict[str, np.ndarray]:
+    """Model-level intermediates via forward hooks on the reference modules."""
+    model = calc.model
+    store: dict[str, np.ndarray] = {}
+    handles = []
+
+    def hook_mlp(i):
+        def fn(mod, inp, out):
+            store[f"mlp{i}_in"] = inp[0].detach().numpy().copy()
+            store[f"mlp{i}_out"] = out.detach().numpy().copy()
+
+        return fn
+
+    for i, m in enumerate(model.mlps):
+        handles.append(m.register_forward_hook(hook_mlp(i)))
+
+    def hook_aev(mod, inp, out):
+        store["d_ij"] = out["d_ij"].detach().numpy().copy()
+
+    handles.append(model.aev.register_forward_hook(hook_aev))
+    out = calc(data, forces=True)
+    for h in handles:
+        h.remove()
+    return store, out
+
+
+def to_np(out: dict) -> dict[str, np.ndarray]:
+    return {k: v.detach().cpu().numpy() for k, v in out.items()}
+
+
+def main() -> None:
+    art = synth.synthetic_artifact(SEED)
+    digest = synth.state_dict_digest({k: v.numpy() for k, v in art["state_dict"].items()})
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "aimnet2_synth.pt")
+    torch.save(art, path)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model, meta = load_model(path)  # must load cleanly through the reference loader
+    assert meta["coulomb_mode"] == "sr_embedded" and meta["needs_coulomb"]
+    meta_common = {"weights_seed": np.int64(SEED), "weights_digest": np.array(digest)}
+
+    # ---- G1: taxol, config 1 -------------------------------------------------------------
+    coord, numbers = read_taxol()
+    calc = make_calc(path)
+    data = {"coord": coord.astype(np.float32), "numbers": numbers, "charge": 0.0}
+    inter, out = capture_intermediates(calc, data)
+    o = to_np(out)
+    # per-atom intermediates kept small: pass-0/1/2 MLP outputs of the first 8 atoms + all d_ij sums
+    np.savez_compressed(
+        os.path.join(HERE, "taxol.npz"),
+        coord=coord.astype(np.float32), numbers=numbers, charge=np.float32(0.0),
+        energy=o["energy"], forces=o["forces"], charges=o["charges"],
+        mlp0_in_head=inter["mlp0_in"][:8], mlp0_out_head=inter["mlp0_out"][:8],
+        mlp1_in_head=inter["mlp1_in"][:8], mlp1_out_head=inter["mlp1_out"][:8],
+        mlp2_in_head=inter["mlp2_in"][:8], mlp2_out_head=inter["mlp2_out"][:8],
+        nnb=np.int64((inter["d_ij"].shape[1])),
+        **meta_common,
+    )
+    print("taxol  E=%.6f  |F|max=%.4f  q[:4]=%s" % (o["energy"][0], np.abs(o["forces"]).max(), o["charges"][:4]))
+
+    # ---- G2: ragged flat batch with charged molecules ------------------------------------
+    c, z, mol, q = workloads.random_batch(5, 9, 30, seed=11)
+    q = np.array([0.0, 1.0, -1.0, 0.0, 2.0], dtype=np.float32)
+    calc = make_calc(path)
+    out = to_np(calc({"coord": c, "numbers": z, "mol_idx": mol, "charge": q}, forces=True))
+    np.savez_compressed(os.path.join(HERE, "batch5.npz"), coord=c, numbers=z, mol_idx=mol, charge=q,
+                        energy=out["energy"], forces=out["forces"], charges=out["charges"], **meta_common)
+    print("batch5 E=", out["energy"])
+
+    # same molecules one by one (batched-vs-individual invariant, test_calculator.py:1052-1217)
+    e_single = []
+    for m in range(5):
+        sel = mol == m
+        calc = make_calc(path)
+        r = to_np(calc({"coord": c[sel], "numbers": z[sel], "charge": q[m]}, forces=True))
+        e_single.append(r["energy"][0])
+    print("batch5 single-vs-batch dE=", np.array(e_single) - out["energy"])
+
+    # ---- G3: periodic allose cell, DSF 15 A (config 3 shape at 96 atoms), forces + stress --
+    pc, pz, cell = workloads.glucose_cell()
+    calc = make_calc(path)
+    calc.set_lrcoulomb_method("dsf")
+    out = to_np(calc({"coord": pc.astype(np.float32), "numbers": pz, "charge": 0.0,
+                      "cell": cell.astype(np.float32)}, forces=True, stress=True))
+    np.savez_compressed(os.path.join(HERE, "pbc96_dsf15.npz"), coord=pc.astype(np.float32), numbers=pz,
+                        charge=np.float32(0.0), cell=cell.astype(np.float32), dsf_rc=np.float64(15.0),
+                        dsf_alpha=np.float64(0.2), energy=out["energy"], forces=out["forces"],
+                        charges=out["charges"], stress=out["stress"], **meta_common)
+    print("pbc96 dsf15 E=%.6f stress=%s" % (out["energy"][0], out["stress"].ravel()[:3]))
+
+    # ---- G4: same cell, atoms displaced out of the box (wrap test), DSF 8 A / alpha 0.25,
+    #          non-periodic c axis ----------------------------------------------------------
+    rng = np.random.Generator(np.random.PCG64(4))
+    shift_cells = rng.integers(-2, 3, size=(pc.shape[0], 3)).astype(np.float64)
+    pc2 = pc + shift_cells @ cell + rng.standard_normal(pc.shape) * 0.02
+    calc = make_calc(path)
+    calc.set_lrcoulomb_method("dsf", cutoff=8.0, dsf_alpha=0.25)
+    out = to_np(calc({"coord": pc2.astype(np.float32), "numbers": pz, "charge": 0.0,
+                      "cell": cell.astype(np.float32)}, forces=True, stress=True))
+    np.savez_compressed(os.path.join(HERE, "pbc96_dsf8_wrapped.npz"), coord=pc2.astype(np.float32), numbers=pz,
+                        charge=np.float32(0.0), cell=cell.astype(np.float32), dsf_rc=np.float64(8.0),
+                        dsf_alpha=np.float64(0.25), energy=out["energy"], forces=out["forces"],
+                        charges=out["charges"], stress=out["stress"], **meta_common)
+    print("pbc96 dsf8 E=%.6f" % out["energy"][0])
+
+    # ---- G5: two periodic systems in one flat batch with (B,3,3) cells ---------------------
+    cell_b = cell * np.array([[1.02], [0.98], [1.01]])
+    frac = pc @ np.linalg.inv(cell)
+    pcb = frac @ cell_b
+    cc = np.concatenate([pc, pcb]).astype(np.float32)
+    zz = np.concatenate([pz, pz])
+    mm = np.concatenate([np.zeros(96, dtype=np.int64), np.ones(96, dtype=np.int64)])
+    cells = np.stack([cell, cell_b]).astype(np.float32)
+    calc = make_calc(path)
+    calc.set_lrcoulomb_method("dsf", cutoff=9.0)
+    out = to_np(calc({"coord": cc, "numbers": zz, "mol_idx": mm, "charge": np.zeros(2, dtype=np.float32),
+                      "cell": cells}, forces=True, stress=True))
+    np.savez_compressed(os.path.join(HERE, "pbc2x96_dsf9.npz"), coord=cc, numbers=zz, mol_idx=mm,
+                        charge=np.zeros(2, dtype=np.float32), cell=cells, dsf_rc=np.float64(9.0),
+                        dsf_alpha=np.float64(0.2), energy=out["energy"], forces=out["forces"],
+                        charges=out["charges"], stress=out["stress"], **meta_common)
+    print("pbc2x96 E=", out["energy"])
+
+    # ---- G6: edge cases the reference tests (test_calculator.py:1422-1471) -----------------
+    edge = {}
+    calc = make_calc(path)
+    r = to_np(calc({"coord": np.zeros((1, 3), dtype=np.float32), "numbers": np.array([8]), "charge": 0.0}, forces=True))
+    edge.update(single_energy=r["energy"], single_forces=r["forces"], single_charges=r["charges"])
+    water = np.array([[0.0, 0.0, 0.1173], [0.0, 0.7572, -0.4692], [0.0, -0.7572, -0.4692]], dtype=np.float32)
+    calc = make_calc(path)
+    r = to_np(calc({"coord": water, "numbers": np.array([8, 1, 1]), "charge": 3.0}, forces=True))
+    edge.update(water3_coord=water, water3_energy=r["energy"], water3_forces=r["forces"], water3_charges=r["charges"])
+    close = np.array([[0.0, 0.0, 0.0], [0.1, 0.0, 0.0], [1.5, 0.3, 0.0]], dtype=np.float32)
+    calc = make_calc(path)
+    r = to_np(calc({"coord": close, "numbers": np.array([6, 1, 1]), "charge": 0.0}, forces=True))
+    edge.update(close_coord=close, close_energy=r["energy"], close_forces=r["forces"], close_charges=r["charges"])
+    np.savez_compressed(os.path.join(HERE, "edge.npz"), **edge, **meta_common)
+    print("edge single E=%.6f water3 E=%.6f close E=%.6f" % (edge["single_energy"][0], edge["water3_energy"][0], edge["close_energy"][0]))
+
+    # ---- G7: 3D (B,N,3) batch of equal-size molecules (CPU flattens it, calculator.py:1495) -
+    rng = np.random.Generator(np.random.PCG64(21))
+    mols = [workloads.random_organic(14, rng) for _ in range(3)]
+    c3 = np.stack([m[0] for m in mols]).astype(np.float32)
+    z3 = np.stack([m[1] for m in mols])
+    calc = make_calc(path)
+    out = to_np(calc({"coord": c3, "numbers": z3, "charge": np.zeros(3, dtype=np.float32)}, forces=True))
+    np.savez_compressed(os.path.join(HERE, "dense3x14.npz"), coord=c3, numbers=z3, charge=np.zeros(3, dtype=np.float32),
+                        energy=out["energy"], forces=out["forces"], charges=out["charges"], **meta_common)
+    print("dense3x14 E=", out["energy"], out["forces"].shape)
+
+
+if __name__ == "__main__":
+    main()

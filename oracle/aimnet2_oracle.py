@@ -1,0 +1,366 @@
+"""ORACLE - test infrastructure only.  CPU restatement of the reference AIMNet2 energy/force path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this file;
+the product (aimnetcentral_amd/) never does and fails loudly when its HIP library is missing.
+
+Parity status: PINNED - tests/test_oracle_golden.py checks this file against the golden
+vectors in tests/golden/*.npz, which were produced by the unmodified reference
+(tests/golden/make_golden.py) in the build container.
+
+It restates, op for op, the PyTorch eager sequence of the reference (all paths relative to
+/root/reference/aimnet):
+  * flat "mode 1" layout with a trailing padding atom and sentinel neighbour index N
+    (calculators/calculator.py:1521-1710 make_nbmat/pad_input, nbops.py:61-133 calc_masks)
+  * ops.calc_distances ops.py:37-66, cosine_cutoff :82-85, exp_cutoff :88-90, exp_expand :93-96
+  * AEVSV._calc_aev modules/aev.py:94-110, ConvSV.forward aev.py:156-189
+  * AIMNet2.forward models/aimnet2.py:141-187 (_update_q :122-139), ops.nse ops.py:99-145
+  * Output/AtomicShift/AtomicSum modules/core.py:71-132, SRCoulomb lr.py:986-1032 (_calc_coulomb_sr :21-62)
+  * LRCoulomb.coul_simple lr.py:311-331, _coul_dsf_torch lr.py:559-615
+  * derivatives: calculators/derivatives.py:47-146 (autograd forces; row-vector strain stress)
+Forces/stress come from torch.autograd exactly as in the reference; oracle/aimnet2_analytic.py
+holds the hand-derived backward that the HIP kernels implement and is itself checked against
+this file.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any
+
+import numpy as np
+import torch
+from torch import Tensor
+
+HARTREE = 27.211386024367243
+BOHR = 0.5291772105638411
+COULOMB_FACTOR = 0.5 * HARTREE * BOHR
+
+
+# --------------------------------------------------------------------------------------------
+# neighbour list (brute force; the reference delegates to nvalchemiops, un-vendored, 0.4.0)
+# --------------------------------------------------------------------------------------------
+def wrap_into_cell(coord: np.ndarray, cell: np.ndarray, mol_idx: np.ndarray, pbc: np.ndarray) -> np.ndarray:
+    """neighbors.py:331-381 move_coord_to_cell: fractional % 1 on periodic axes (fp32 like the reference)."""
+    c = torch.as_tensor(coord, dtype=torch.float32)
+    cells = torch.as_tensor(cell, dtype=torch.float32)
+    if cells.ndim == 2:
+        cells = cells.unsqueeze(0)
+    pb = torch.as_tensor(pbc, dtype=torch.bool)
+    if pb.ndim == 1:
+        pb = pb.unsqueeze(0).expand(cells.shape[0], -1)
+    m = torch.as_tensor(mol_idx, dtype=torch.long)
+    if cells.shape[0] == 1:
+        inv = torch.linalg.inv(cells[0])
+        f = c @ inv
+        f = torch.where(pb[0], f % 1, f)
+        return (f @ cells[0]).numpy()
+    inv = torch.linalg.inv(cells)
+    f = torch.bmm(c.unsqueeze(1), inv[m]).squeeze(1)
+    f = torch.where(pb[m], f % 1, f)
+    return torch.bmm(f.unsqueeze(1), cells[m]).squeeze(1).numpy()
+
+
+def neighbor_list(coord, cutoff: float, mol_idx, cell=None, pbc=None):
+    """Full neighbour matrix: returns (nbmat (N+1, M) int64 with sentinel N incl. padding row,
+    shifts (N+1, M, 3) float32 or None).  Rows real-first; same-molecule pairs only."""
+    pos = np.asarray(coord, dtype=np.float64)
+    n = pos.shape[0]
+    mol = np.asarray(mol_idx, dtype=np.int64)
+    rows: list[list[tuple[int, int, int, int]]] = [[] for _ in range(n)]
+    if cell is None:
+        if math.isinf(cutoff):
+            ok = mol[:, None] == mol[None, :]
+        else:
+            d2 = ((pos[:, None, :] - pos[None, :, :]) ** 2).sum(-1)
+            ok = (d2 < cutoff * cutoff) & (mol[:, None] == mol[None, :])
+        np.fill_diagonal(ok, False)
+        for i in range(n):
+            rows[i] = [(int(j), 0, 0, 0) for j in np.nonzero(ok[i])[0]]
+    else:
+        cells = np.asarray(cell, dtype=np.float64)
+        if cells.ndim == 2:
+            cells = cells[None]
+        pb = np.ones((cells.shape[0], 3), dtype=bool) if pbc is None else np.asarray(pbc, dtype=bool)
+        if pb.ndim == 1:
+            pb = np.broadcast_to(pb, (cells.shape[0], 3))
+        for s in range(cells.shape[0]):
+            idx = np.nonzero(mol == s)[0]
+            if idx.size == 0:
+                continue
+            c = cells[s]
+            vol = abs(np.linalg.det(c))
+            nimg = []
+            for k in range(3):
+                h = vol / np.linalg.norm(np.cross(c[(k + 1) % 3], c[(k + 2) % 3]))
+                nimg.append(int(math.ceil(cutoff / h)) if pb[s, k] else 0)
+            p = pos[idx]
+            for sx in range(-nimg[0], nimg[0] + 1):
+                for sy in range(-nimg[1], nimg[1] + 1):
+                    for sz in range(-nimg[2], nimg[2] + 1):
+                        off = sx * c[0] + sy * c[1] + sz * c[2]
+                        d2 = ((p[None, :, :] + off - p[:, None, :]) ** 2).sum(-1)
+                        ok = d2 < cutoff * cutoff
+                        if sx == 0 and sy == 0 and sz == 0:
+                            np.fill_diagonal(ok, False)
+                        ii, jj = np.nonzero(ok)
+                        for a, b in zip(ii.tolist(), jj.tolist()):
+                            rows[int(idx[a])].append((int(idx[b]), sx, sy, sz))
+    m = max(1, max(len(r) for r in rows))
+    nbmat = np.full((n + 1, m), n, dtype=np.int64)
+    shifts = np.zeros((n + 1, m, 3), dtype=np.float32)
+    for i, r in enumerate(rows):
+        for k, (j, sx, sy, sz) in enumerate(r):
+            nbmat[i, k] = j
+            shifts[i, k] = (sx, sy, sz)
+    return nbmat, (shifts if cell is not None else None)
+
+
+# --------------------------------------------------------------------------------------------
+# model
+# --------------------------------------------------------------------------------------------
+class OracleModel:
+    """Weights of one AIMNet2 core model (state-dict keys as in SURVEY.md 2.1)."""
+
+    def __init__(self, state_dict: dict[str, Any], dtype: torch.dtype = torch.float32):
+        self.dtype = dtype
+        sd = {k: torch.as_tensor(np.asarray(v)) for k, v in state_dict.items()}
+        f = lambda k: sd[k].to(dtype)  # noqa: E731
+        self.rc = f("aev.rc_s")
+        self.eta = f("aev.eta_s")
+        self.shifts = f("aev.shifts_s")
+        self.afv = f("afv.weight")
+        self.agh_a = f("conv_a.agh")
+        self.agh_q = f("conv_q.agh")
+        self.mlps: list[list[tuple[Tensor, Tensor]]] = []
+        p = 0
+        while f"mlps.{p}.0.weight" in sd:
+            layers, li = [], 0
+            while f"mlps.{p}.{2 * li}.weight" in sd:
+                layers.append((f(f"mlps.{p}.{2 * li}.weight"), f(f"mlps.{p}.{2 * li}.bias")))
+                li += 1
+            self.mlps.append(layers)
+            p += 1
+        self.head = []
+        li = 0
+        while f"outputs.energy_mlp.mlp.{2 * li}.weight" in sd:
+            self.head.append((f(f"outputs.energy_mlp.mlp.{2 * li}.weight"), f(f"outputs.energy_mlp.mlp.{2 * li}.bias")))
+            li += 1
+        self.sae = sd["outputs.atomic_shift.shifts.weight"].to(torch.float64).squeeze(-1)
+        self.sr_rc = f("outputs.srcoulomb.rc") if "outputs.srcoulomb.rc" in sd else torch.tensor(4.6, dtype=dtype)
+        self.A = self.agh_a.shape[0]
+        self.G = self.agh_a.shape[1]
+
+
+def _gelu(x: Tensor) -> Tensor:
+    return torch.nn.functional.gelu(x)  # exact erf form (core.py:27, torch.nn.GELU default)
+
+
+def _mlp(x: Tensor, layers, last_linear: bool) -> Tensor:
+    for i, (w, b) in enumerate(layers):
+        x = torch.nn.functional.linear(x, w, b)
+        if not (last_linear and i == len(layers) - 1):
+            x = _gelu(x)
+    return x
+
+
+def _distances(coord_p: Tensor, nbmat: Tensor, shifts, cell, mol_idx_p: Tensor):
+    """ops.calc_distances for mode 1 (ops.py:37-66): masked pairs get r=(1,1,1)."""
+    n = coord_p.shape[0] - 1
+    coord_j = coord_p.index_select(0, nbmat.flatten()).unflatten(0, nbmat.shape)
+    if shifts is not None:
+        if cell.ndim == 2:
+            off = shifts @ cell
+        else:
+            off = torch.einsum("nmd,ndh->nmh", shifts, cell[mol_idx_p])
+        coord_j = coord_j + off
+    r = coord_j - coord_p.unsqueeze(1)
+    mask = nbmat == n
+    r = r.masked_fill(mask.unsqueeze(-1), 1.0)
+    d = torch.linalg.vector_norm(r, ord=2, dim=-1)
+    return d, r, mask
+
+
+def _cosine_cutoff(d: Tensor, rc: Tensor) -> Tensor:
+    return 0.5 * (torch.cos(d.clamp(min=torch.full_like(rc, 1e-6), max=rc) * (math.pi / rc)) + 1.0)
+
+
+def _exp_cutoff(d: Tensor, rc: Tensor) -> Tensor:
+    return torch.exp(-1.0 / (1.0 - (d / rc).clamp(0, 1.0 - 1e-6).pow(2))) / 0.36787944117144233
+
+
+def _mol_sum(x: Tensor, mol_idx_p: Tensor, n_mol: int) -> Tensor:
+    if x.ndim == 1:
+        res = torch.zeros(n_mol, dtype=x.dtype)
+        return res.scatter_add_(0, mol_idx_p, x)
+    res = torch.zeros(n_mol, x.shape[1], dtype=x.dtype)
+    return res.scatter_add_(0, mol_idx_p.unsqueeze(-1).expand(-1, x.shape[1]), x)
+
+
+def _conv(a: Tensor, g_sv: Tensor, nbmat: Tensor, agh: Tensor, d2: bool) -> Tensor:
+    a_j = a.index_select(0, nbmat.flatten()).unflatten(0, nbmat.shape)
+    if d2:
+        avf_sv = torch.einsum("...mag,...mgd->...agd", a_j, g_sv)
+    else:
+        avf_sv = torch.einsum("...ma,...mgd->...agd", a_j, g_sv)
+    avf_s, avf_v = avf_sv.split([1, 3], dim=-1)
+    avf_v = torch.einsum("agh,...agd->...ahd", agh, avf_v).pow(2).sum(-1)
+    return torch.cat([avf_s.squeeze(-1).flatten(-2, -1), avf_v.flatten(-2, -1)], dim=-1)
+
+
+def evaluate(
+    model: OracleModel,
+    coord,
+    numbers,
+    charge,
+    mol_idx=None,
+    cell=None,
+    pbc=None,
+    coulomb: str = "simple",
+    dsf_rc: float = 15.0,
+    dsf_alpha: float = 0.2,
+    forces: bool = True,
+    stress: bool = False,
+    return_intermediates: bool = False,
+    nbmat=None,
+    shifts=None,
+    nbmat_lr=None,
+    shifts_lr=None,
+) -> dict[str, np.ndarray]:
+    """One AIMNet2Calculator.eval on a flat (N,3) system (calculator.py:879-947) with external
+    Coulomb `coulomb` in {"simple","dsf","none"} and sr_embedded SRCoulomb subtraction."""
+    dt = model.dtype
+    coord_np = np.asarray(coord, dtype=np.float32)
+    n = coord_np.shape[0]
+    numbers = np.asarray(numbers, dtype=np.int64)
+    mol = np.zeros(n, dtype=np.int64) if mol_idx is None else np.asarray(mol_idx, dtype=np.int64)
+    charge_t = torch.as_tensor(np.atleast_1d(np.asarray(charge, dtype=np.float32))).to(dt)
+    n_mol = charge_t.shape[0]
+    cell_t = None
+    if cell is not None:
+        pbc_np = np.ones(3, dtype=bool) if pbc is None else np.asarray(pbc, dtype=bool)
+        coord_np = wrap_into_cell(coord_np, np.asarray(cell, dtype=np.float32), mol, pbc_np)
+        cell_t = torch.as_tensor(np.asarray(cell, dtype=np.float32)).to(dt)
+    else:
+        pbc_np = None
+    if nbmat is None:
+        nbmat, shifts = neighbor_list(coord_np, float(model.rc), mol, cell, pbc_np)
+    if coulomb == "simple" and cell is None:
+        if nbmat_lr is None:
+            nbmat_lr, shifts_lr = neighbor_list(coord_np, math.inf, mol)
+    elif coulomb == "dsf" or (coulomb == "simple" and cell is not None):
+        coulomb = "dsf"
+        if nbmat_lr is None:
+            nbmat_lr, shifts_lr = neighbor_list(coord_np, dsf_rc, mol, cell, pbc_np)
+    nb = torch.as_tensor(nbmat)
+    sh = None if shifts is None else torch.as_tensor(shifts).to(dt)
+
+    # pad_input: padding atom row (coord 0, Z 0, mol_idx = last) calculator.py:1704-1710
+    coord_p = torch.cat([torch.as_tensor(coord_np).to(dt), torch.zeros(1, 3, dtype=dt)], dim=0)
+    numbers_p = torch.cat([torch.as_tensor(numbers), torch.zeros(1, dtype=torch.long)])
+    mol_p = torch.cat([torch.as_tensor(mol), torch.as_tensor(mol[-1:])])
+
+    coord_p.requires_grad_(forces or stress)
+    x = coord_p
+    cell_x = cell_t
+    scaling = None
+    if stress:
+        assert cell_t is not None
+        if cell_t.ndim == 2:
+            scaling = torch.eye(3, dtype=dt, requires_grad=True)
+            x = coord_p @ scaling
+            cell_x = cell_t @ scaling
+        else:
+            scaling = torch.eye(3, dtype=dt).unsqueeze(0).repeat(cell_t.shape[0], 1, 1).requires_grad_(True)
+            x = (coord_p.unsqueeze(1) @ scaling[mol_p]).squeeze(1)
+            cell_x = cell_t @ scaling
+
+    inter: dict[str, Tensor] = {}
+    a = model.afv[numbers_p].unflatten(-1, (model.A, model.G))
+    d_ij, r_ij, mask = _distances(x, nb, sh, cell_x, mol_p)
+    fc = _cosine_cutoff(d_ij, model.rc).masked_fill(mask, 0.0)
+    gs = torch.exp(-model.eta * (d_ij.unsqueeze(-1) - model.shifts) ** 2) * fc.unsqueeze(-1)
+    u = r_ij / d_ij.unsqueeze(-1)
+    g_sv = torch.cat([gs.unsqueeze(-1), gs.unsqueeze(-1) * u.unsqueeze(-2)], dim=-1)
+    inter["d_ij"] = d_ij
+
+    q = None
+    Q = charge_t.unsqueeze(-1)
+    npass = len(model.mlps)
+    for ip, layers in enumerate(model.mlps):
+        _in = torch.cat([a.flatten(-2, -1), _conv(a, g_sv, nb, model.agh_a, True)], dim=-1)
+        if ip > 0:
+            _in = torch.cat([_in, q, _conv(q, g_sv, nb, model.agh_q, False)], dim=-1)
+        inter[f"mlp{ip}_in"] = _in
+        out = _mlp(_in, layers, last_linear=(ip == 0))
+        out = torch.cat([out[:-1], torch.zeros_like(out[:1])], dim=0)  # mask_i_ on padding row
+        inter[f"mlp{ip}_out"] = out
+        if ip < npass - 1:
+            _q, _f, da = out.split([1, 1, out.shape[-1] - 2], dim=-1)
+            qr = q + _q if ip > 0 else _q
+            f = _f.pow(2)
+            F = _mol_sum(f, mol_p, n_mol) + 1.0e-6
+            Qu = _mol_sum(qr, mol_p, n_mol)
+            dQ = Q - Qu
+            q = qr + f / F[mol_p] * dQ[mol_p]
+            a = a + da.view_as(a)
+            inter[f"q{ip}"] = q.squeeze(-1)
+        else:
+            aim = out
+    charges = q.squeeze(-1)
+    inter["aim"] = aim
+
+    e_at = _mlp(aim, model.head, last_linear=True).squeeze(-1)
+    e_at = torch.cat([e_at[:-1], torch.zeros_like(e_at[:1])])
+    inter["e_atom"] = e_at
+    e_at64 = e_at + model.sae[numbers_p]  # fp32 + fp64 -> fp64 (core.py:95)
+    energy = _mol_sum(e_at64, mol_p, n_mol)
+
+    def pair_sum(e_ij: Tensor) -> Tensor:
+        return COULOMB_FACTOR * _mol_sum(e_ij.sum(-1, dtype=torch.float64), mol_p, n_mol)
+
+    # embedded SRCoulomb: energy -= E_sr (lr.py:1020-1032)
+    q_i, q_j = charges.unsqueeze(1), charges[nb]
+    e_sr = (_exp_cutoff(d_ij, model.sr_rc) * q_i * q_j / d_ij).masked_fill(mask, 0.0)
+    energy = energy.double() - pair_sum(e_sr)
+
+    if coulomb != "none":
+        nbl = torch.as_tensor(nbmat_lr)
+        shl = None if shifts_lr is None else torch.as_tensor(shifts_lr).to(dt)
+        d_lr, _, mask_lr = _distances(x, nbl, shl, cell_x, mol_p)
+        q_jl = charges[nbl]
+        if coulomb == "simple":
+            e_lr = (q_i * q_jl / d_lr).masked_fill(mask_lr, 0.0)
+            energy = energy + pair_sum(e_lr)
+        else:
+            al = d_lr.new_tensor(dsf_alpha)
+            rc = d_lr.new_tensor(dsf_rc)
+            erfc_rc = torch.erfc(al * rc)
+            shift_val = erfc_rc / rc
+            slope = erfc_rc / rc.pow(2) + d_lr.new_tensor(2.0 * dsf_alpha / math.sqrt(math.pi)) * torch.exp(-(al**2) * rc**2) / rc
+            e_pair = torch.erfc(al * d_lr) / d_lr - shift_val + (d_lr - rc) * slope
+            e_lr = (q_i * q_jl * e_pair * (d_lr < rc).to(dt)).masked_fill(mask_lr, 0.0)
+            energy = energy + pair_sum(e_lr)
+            self_coeff = -(shift_val / 2.0 + d_lr.new_tensor(dsf_alpha / math.sqrt(math.pi)))
+            q_self = torch.cat([charges[:-1], torch.zeros_like(charges[:1])])
+            energy = energy + 2.0 * COULOMB_FACTOR * _mol_sum((self_coeff * q_self.pow(2)).double(), mol_p, n_mol)
+
+    res: dict[str, np.ndarray] = {"energy": energy.detach().numpy().copy(), "charges": charges[:-1].detach().numpy().copy()}
+    if forces or stress:
+        wrt = [coord_p] + ([scaling] if stress else [])
+        grads = torch.autograd.grad(energy.sum(), wrt)
+        if forces:
+            res["forces"] = (-grads[0][:-1]).detach().numpy().copy()
+        if stress:
+            dedc = grads[1]
+            cell0 = cell_t.detach()
+            vol = torch.linalg.det(cell0).abs()
+            if cell0.ndim == 3:
+                vol = vol.unsqueeze(-1).unsqueeze(-1)
+            res["stress"] = (dedc / vol).detach().numpy().copy()
+    if return_intermediates:
+        res["nbmat"] = np.asarray(nbmat)
+        if shifts is not None:
+            res["shifts"] = np.asarray(shifts)
+        res["coord_wrapped"] = coord_np
+        for k, v in inter.items():
+            res["_" + k] = v.detach().numpy().copy()
+    return res

@@ -1,0 +1,150 @@
+"""ctypes binding of libaimnet_hip.so (C ABI in include/aimnet_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C aimnetcentral_amd/csrc`.
+There is NO fallback: if the shared object is missing or fails to load, every product entry
+point raises `HipLibraryError` - the engine never silently routes through PyTorch or the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from functools import lru_cache
+
+MAX_PASS, MAX_LAYERS, MAX_SHIFTS = 4, 6, 32
+FORCES, STRESS = 1, 2
+COULOMB_NONE, COULOMB_SIMPLE, COULOMB_DSF = 0, 1, 2
+E_INVALID, E_HIP, E_WORKSPACE = -1, -2, -3
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaimnet_hip.so")
+
+# every symbol include/aimnet_hip.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTED_SYMBOLS = (
+    "aimnet_abi_version",
+    "aimnet_engine_create",
+    "aimnet_engine_destroy",
+    "aimnet_last_error",
+    "aimnet_engine_workspace_bytes",
+    "aimnet_engine_eval",
+    "aimnet_engine_debug_view",
+    "aimnet_neighbor_list",
+    "aimnet_neighbor_list_workspace_bytes",
+    "aimnet_conv_sv_2d_sp_fwd",
+    "aimnet_conv_sv_2d_sp_bwd",
+)
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class Arch(C.Structure):
+    _fields_ = [
+        ("nfeature", C.c_int32),
+        ("nshifts", C.c_int32),
+        ("ncomb_v", C.c_int32),
+        ("n_pass", C.c_int32),
+        ("n_layers", C.c_int32 * MAX_PASS),
+        ("layer_dims", (C.c_int32 * (MAX_LAYERS + 1)) * MAX_PASS),
+        ("last_linear", C.c_int32 * MAX_PASS),
+        ("head_n_layers", C.c_int32),
+        ("head_dims", C.c_int32 * (MAX_LAYERS + 1)),
+        ("rc", C.c_float),
+        ("eta", C.c_float),
+        ("shifts", C.c_float * MAX_SHIFTS),
+        ("sr_coulomb", C.c_int32),
+        ("sr_envelope", C.c_int32),
+        ("sr_rc", C.c_float),
+    ]
+
+
+class Weights(C.Structure):
+    _fields_ = [
+        ("afv", C.c_void_p),
+        ("agh_a", C.c_void_p),
+        ("agh_q", C.c_void_p),
+        ("mlp_w", (C.c_void_p * MAX_LAYERS) * MAX_PASS),
+        ("mlp_b", (C.c_void_p * MAX_LAYERS) * MAX_PASS),
+        ("head_w", C.c_void_p * MAX_LAYERS),
+        ("head_b", C.c_void_p * MAX_LAYERS),
+        ("sae", C.c_void_p),
+    ]
+
+
+class Inputs(C.Structure):
+    _fields_ = [
+        ("n_atoms", C.c_int32),
+        ("n_mol", C.c_int32),
+        ("coord", C.c_void_p),
+        ("numbers", C.c_void_p),
+        ("mol_idx", C.c_void_p),
+        ("charge", C.c_void_p),
+        ("cell", C.c_void_p),
+        ("n_cell", C.c_int32),
+        ("pbc", C.c_int32 * 3),
+    ]
+
+
+class EvalOptions(C.Structure):
+    _fields_ = [
+        ("flags", C.c_uint32),
+        ("coulomb", C.c_int32),
+        ("dsf_rc", C.c_float),
+        ("dsf_alpha", C.c_float),
+        ("max_nb", C.c_int32),
+        ("max_nb_lr", C.c_int32),
+    ]
+
+
+class Outputs(C.Structure):
+    _fields_ = [
+        ("energy", C.c_void_p),
+        ("charges", C.c_void_p),
+        ("forces", C.c_void_p),
+        ("stress", C.c_void_p),
+        ("status", C.c_void_p),
+    ]
+
+
+@lru_cache(maxsize=1)
+def load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C aimnetcentral_amd/csrc`). The HIP engine has no CPU/PyTorch fallback."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:  # missing ROCm runtime etc.
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+    vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
+    lib.aimnet_abi_version.restype = C.c_int
+    lib.aimnet_last_error.restype = C.c_char_p
+    lib.aimnet_engine_create.restype = C.c_int
+    lib.aimnet_engine_create.argtypes = [C.POINTER(Arch), C.POINTER(Weights), C.c_int, C.POINTER(vp)]
+    lib.aimnet_engine_destroy.restype = None
+    lib.aimnet_engine_destroy.argtypes = [vp]
+    lib.aimnet_engine_workspace_bytes.restype = sz
+    lib.aimnet_engine_workspace_bytes.argtypes = [vp, i32, i32, i32, C.POINTER(EvalOptions)]
+    lib.aimnet_engine_eval.restype = C.c_int
+    lib.aimnet_engine_eval.argtypes = [vp, C.POINTER(Inputs), C.POINTER(EvalOptions), C.POINTER(Outputs), vp, sz, vp]
+    lib.aimnet_engine_debug_view.restype = C.c_int
+    lib.aimnet_engine_debug_view.argtypes = [vp, C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(i32), C.POINTER(i32)]
+    lib.aimnet_neighbor_list_workspace_bytes.restype = sz
+    lib.aimnet_neighbor_list_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.aimnet_neighbor_list.restype = C.c_int
+    lib.aimnet_neighbor_list.argtypes = [vp, vp, i32, i32, vp, i32, C.POINTER(i32 * 3), C.c_float, i32, i32, vp, vp, vp,
+                                         vp, vp, vp, sz, vp]
+    lib.aimnet_conv_sv_2d_sp_fwd.restype = C.c_int
+    lib.aimnet_conv_sv_2d_sp_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.aimnet_conv_sv_2d_sp_bwd.restype = C.c_int
+    lib.aimnet_conv_sv_2d_sp_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    return lib
+
+
+def last_error() -> str:
+    return load().aimnet_last_error().decode(errors="replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise HipLibraryError(f"{what} failed with code {rc}: {last_error()}")

@@ -1,0 +1,384 @@
+"""AIMNet2Calculator - host-side mirror of the reference calculator API over the HIP engine.
+
+Same constructor signature, input keys, layouts, validation rules, warnings and output shapes as
+aimnet/calculators/calculator.py:40-947 of the reference.  Everything between
+`prepare_input` and `process_output` (neighbour lists, model, Coulomb, derivatives;
+calculator.py:917-936) runs in libaimnet_hip.so; this file only normalises inputs and reshapes
+outputs.  Torch tensors are device buffers, nothing here is differentiated by autograd.
+
+Deliberate deviations, all loud:
+  * no CPU device and no torch fallback - constructing without a ROCm GPU raises HipLibraryError;
+  * inputs carrying requires_grad raise (the reference keeps the autograd graph, :1458-1461);
+  * hessian / hessian_vector_product, Ewald / PME, external DFT-D3, NSE (2-channel) models,
+    torch.compile and training mode raise NotImplementedError (SURVEY.md 8f "next" rows).
+"""
+from __future__ import annotations
+
+import math
+import os
+import warnings
+from collections.abc import Collection
+from types import MappingProxyType
+from typing import Any, ClassVar
+
+import numpy as np
+
+from . import loader
+from ._lib import HipLibraryError
+from .engine import HipEngine, ModelSpec
+
+
+class AIMNet2Calculator:
+    keys_in: ClassVar[dict[str, str]] = {"coord": "float32", "numbers": "int32", "charge": "float32"}
+    keys_in_optional: ClassVar[dict[str, str]] = {
+        "mult": "float32", "mol_idx": "int32", "nbmat": "int32", "nbmat_lr": "int32", "nb_pad_mask": "bool",
+        "nb_pad_mask_lr": "bool", "shifts": "float32", "shifts_lr": "float32", "cell": "float32", "pbc": "bool",
+    }
+    keys_out: ClassVar[list[str]] = ["energy", "charges", "spin_charges", "forces", "hessian", "stress"]
+    atom_feature_keys: ClassVar[list[str]] = ["coord", "numbers", "charges", "spin_charges", "forces"]
+    _constructed_families: ClassVar[set[str]] = set()
+
+    def __init__(
+        self,
+        model: str | ModelSpec = "aimnet2",
+        nb_threshold: int = 120,
+        needs_coulomb: bool | None = None,
+        needs_dispersion: bool | None = None,
+        device: str | None = None,
+        compile_model: bool = False,
+        compile_kwargs: dict | None = None,
+        cache_static: bool = False,
+        train: bool = False,
+        deterministic: bool = False,
+        ensemble_member: int = 0,
+        revision: str | None = None,
+        token: str | None = None,
+        *,
+        model_import_paths: Collection[str] | None = None,
+        model_import_mode: str = "extend",
+    ):
+        import torch
+
+        if device is None:
+            device = "cuda"  # reference: cuda if available else cpu (:167-169); there is no cpu engine here
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise HipLibraryError(f"device={device!r}: the native engine runs on MI355X GPUs only (no CPU path)")
+        if train:
+            raise NotImplementedError("train=True: the native engine is inference only")
+        if compile_model:
+            warnings.warn("compile_model=True has no effect: the native engine does not use torch.compile", stacklevel=2)
+        self._was_compiled = False
+        self.nb_threshold = nb_threshold
+        self.cache_static = bool(cache_static)
+        self._deterministic = bool(deterministic)  # the engine is always deterministic (no atomics)
+        self._train = False
+
+        if isinstance(model, ModelSpec):
+            spec = model
+        elif isinstance(model, str):
+            spec = self._resolve(model, model_import_paths, model_import_mode)
+        else:
+            raise TypeError("model must be a path to a v2 artifact, a registry name or a ModelSpec "
+                            "(raw nn.Module inputs cannot run on the native engine)")
+        self.spec = spec
+        metadata = spec.metadata or None
+        self._metadata = metadata
+        self.cutoff = float(metadata["cutoff"]) if metadata and "cutoff" in metadata else float(spec.rc)
+
+        final_needs_coulomb = needs_coulomb if needs_coulomb is not None else bool((metadata or {}).get("needs_coulomb", False))
+        final_needs_dispersion = needs_dispersion if needs_dispersion is not None else bool((metadata or {}).get("needs_dispersion", False))
+        if metadata is not None:
+            loader.validate_runtime_metadata(metadata, needs_coulomb=final_needs_coulomb, needs_dispersion=final_needs_dispersion)
+        if final_needs_dispersion:
+            raise NotImplementedError(
+                "external DFT-D3 is not implemented by the native engine yet (SURVEY.md 8f next-1); "
+                "construct with needs_dispersion=False to evaluate without dispersion")
+        self.external_dftd3 = None
+        self._default_dsf_cutoff = 15.0
+        self._dftd3_cutoff = 15.0
+        # external Coulomb state (LRCoulomb attributes the reference exposes, lr.py:285-300)
+        self.external_coulomb = None
+        self._coulomb_method: str | None = None
+        self._coulomb_cutoff: float | None = None
+        self._dsf_alpha, self._dsf_rc = 0.2, 15.0
+        if final_needs_coulomb:
+            sr_embedded = (metadata or {}).get("coulomb_mode") == "sr_embedded"
+            if not sr_embedded:
+                raise NotImplementedError("external Coulomb with subtract_sr=True (model without embedded SRCoulomb) is not implemented")
+            self.external_coulomb = _ExternalCoulombState(self)
+            self._coulomb_method = "simple"
+            self._coulomb_cutoff = float("inf")
+        self.cutoff_lr: float | None = self._coulomb_cutoff
+        self.lr = self.external_coulomb is not None or bool((metadata or {}).get("has_embedded_lr", False))
+
+        self.engine = HipEngine(spec, dev)
+        self.device = str(self.engine.device)
+        self._batch: int | None = None
+        self._max_mol_size = 0
+        self._mult_ignored_checked = False
+        self._species_cache: tuple[int, Any] | None = None
+        family = (metadata or {}).get("family")
+        self._maybe_warn_family_mix(family)
+
+    # ---- model resolution ----------------------------------------------------------------------
+    @staticmethod
+    def _resolve(model: str, paths, mode) -> ModelSpec:
+        if os.path.isfile(model):
+            return loader.load_model(model, model_import_paths=paths, model_import_mode=mode)[0]
+        cache = os.environ.get("AIMNET_CACHE_DIR", os.path.join(os.path.expanduser("~"), ".cache", "aimnet"))
+        for cand in (os.path.join(cache, model), os.path.join(cache, model + ".pt")):
+            if os.path.isfile(cand):
+                return loader.load_model(cand, model_import_paths=paths, model_import_mode=mode)[0]
+        raise FileNotFoundError(
+            f"model {model!r} is neither a file nor present in the model cache {cache!r}; registry downloads "
+            "need network access and are not performed by the native engine - pass a local v2 .pt path")
+
+    @classmethod
+    def from_legacy_jit(cls, path: str, **kw):
+        raise NotImplementedError("legacy TorchScript (.jpt) models cannot run on the native HIP engine")
+
+    def __call__(self, *args, **kwargs):
+        return self.eval(*args, **kwargs)
+
+    # ---- properties ------------------------------------------------------------------------------
+    @property
+    def metadata(self):
+        return MappingProxyType(self._metadata) if self._metadata is not None else None
+
+    @property
+    def model(self):
+        return self.spec
+
+    @property
+    def has_external_coulomb(self) -> bool:
+        return self.external_coulomb is not None
+
+    @property
+    def has_external_dftd3(self) -> bool:
+        return False
+
+    @property
+    def is_nse(self) -> bool:
+        return False
+
+    @property
+    def coulomb_method(self) -> str | None:
+        return self._coulomb_method if self.external_coulomb is not None else None
+
+    @property
+    def coulomb_cutoff(self) -> float | None:
+        return self._coulomb_cutoff
+
+    @property
+    def dftd3_cutoff(self) -> float:
+        return self._dftd3_cutoff
+
+    def _maybe_warn_family_mix(self, family):
+        if family is None:
+            return
+        already = family in self._constructed_families
+        self._constructed_families.add(family)
+        if not already and len(self._constructed_families) > 1:
+            warnings.warn(
+                f"AIMNet2Calculator instances from different families have been constructed in this process: "
+                f"{sorted(self._constructed_families)}. Do not mix or compare energies across families.",
+                UserWarning, stacklevel=3)
+
+    def _maybe_warn_mult_ignored(self, data) -> None:
+        if self._mult_ignored_checked:
+            return
+        mult = data.get("mult")
+        if mult is None:
+            return
+        import torch
+
+        m = torch.as_tensor(mult).detach().cpu()
+        if bool((m != 1).any()):
+            self._mult_ignored_checked = True
+            warnings.warn(
+                f"Input mult={m.flatten().tolist()} is ignored: this model is closed-shell "
+                f"(num_charge_channels=1) and does not use spin multiplicity.", UserWarning, stacklevel=3)
+
+    # ---- Coulomb setters (calculator.py:638-783) -----------------------------------------------------
+    def set_lrcoulomb_method(self, method: str, cutoff: float = 15.0, dsf_alpha: float = 0.2, ewald_accuracy: float = 1e-6):
+        if method not in ("simple", "dsf", "ewald", "pme"):
+            raise ValueError(f"Invalid method: {method}")
+        if self.external_coulomb is None:
+            if (self._metadata or {}).get("coulomb_mode", "none") != "none" and not (self._metadata or {}).get("needs_coulomb", False):
+                warnings.warn("Model has embedded Coulomb module (legacy format). set_lrcoulomb_method() only affects "
+                              "external Coulomb modules.", stacklevel=2)
+            return
+        if method in ("ewald", "pme"):
+            raise NotImplementedError(f"Coulomb method {method!r} is not implemented by the native engine (use 'dsf')")
+        self._coulomb_method = method
+        if method == "dsf":
+            self._dsf_alpha, self._dsf_rc = float(dsf_alpha), float(cutoff)
+            self._coulomb_cutoff = float(cutoff)
+        else:
+            self._coulomb_cutoff = float("inf")
+        self.cutoff_lr = self._coulomb_cutoff
+
+    def set_lr_cutoff(self, cutoff: float) -> None:
+        self._coulomb_cutoff = cutoff
+        if self._coulomb_method == "dsf":
+            self._dsf_rc = float(cutoff)
+        self._dftd3_cutoff = cutoff
+        self.cutoff_lr = cutoff
+
+    def set_dftd3_cutoff(self, cutoff: float | None = None, smoothing_fraction: float | None = None) -> None:
+        self._dftd3_cutoff = 15.0 if cutoff is None else cutoff
+
+    # ---- validation (calculator.py:785-851) ------------------------------------------------------------
+    def _validate_species_and_charge(self, data) -> None:
+        import torch
+
+        if "numbers" not in data:
+            return
+        meta = self._metadata or {}
+        impl = meta.get("implemented_species") or []
+        if impl:
+            numbers = data["numbers"]
+            key = (id(numbers), getattr(numbers, "_version", None)) if isinstance(numbers, torch.Tensor) else None
+            if key is None or self._species_cache != key:
+                seen = {int(z) for z in torch.as_tensor(numbers).flatten().tolist() if int(z) > 0}
+                unsupported = sorted(seen - set(impl))
+                if unsupported:
+                    raise ValueError(
+                        f"Atomic numbers {unsupported} are not in this model's implemented_species {sorted(impl)}. "
+                        f"This model was trained on a restricted element set; passing other elements yields undefined "
+                        f"output. Pass validate_species=False to bypass.")
+                self._species_cache = key
+        if meta.get("supports_charged_systems") is False:
+            ch = torch.as_tensor(data.get("charge", 0.0))
+            if ch.numel() > 0 and float(ch.abs().max().item()) > 1e-6:
+                bad = ch[ch.abs() > 1e-6].flatten().tolist()
+                raise ValueError(f"This model does not support net-charged systems (got non-zero charge(s) {bad}). "
+                                 f"Pass validate_species=False to bypass.")
+
+    # ---- evaluation ------------------------------------------------------------------------------------
+    def to_input_tensors(self, data: dict[str, Any]) -> dict[str, Any]:
+        import torch
+
+        ret = {}
+        dt = {"float32": torch.float32, "int32": torch.int32, "bool": torch.bool}
+        for k, d in self.keys_in.items():
+            if k not in data:
+                raise KeyError(f"Missing key {k} in the input data")
+            if isinstance(data[k], torch.Tensor) and data[k].requires_grad:
+                raise NotImplementedError(f"input {k!r} requires grad: the native engine does not build autograd graphs")
+            ret[k] = torch.as_tensor(data[k], device=self.device, dtype=dt[d]).detach()
+        for k, d in self.keys_in_optional.items():
+            if k in data and data[k] is not None:
+                ret[k] = torch.as_tensor(data[k], device=self.device, dtype=dt[d]).detach()
+        for k, v in ret.items():
+            if v.ndim == 0:
+                ret[k] = v.unsqueeze(0)
+        return ret
+
+    def eval(self, data: dict[str, Any], forces=False, stress=False, hessian=False, *, validate_species: bool = True) -> dict[str, Any]:
+        import torch
+
+        if validate_species:
+            self._validate_species_and_charge(data)
+        self._maybe_warn_mult_ignored(data)
+        if hessian:
+            raise NotImplementedError("hessian=True is not implemented by the native engine yet (SURVEY.md 8f next-4)")
+        d = self.to_input_tensors(data)
+        for k in ("nbmat", "nbmat_lr", "shifts", "shifts_lr"):
+            if k in d:
+                raise NotImplementedError(f"caller-supplied {k!r} is not supported: the engine builds its own neighbour lists")
+        coord, numbers, charge = d["coord"], d["numbers"], d["charge"]
+        cell = d.get("cell")
+        pbc = d.get("pbc")
+        if stress and cell is None:
+            raise AssertionError("Stress calculation requires cell")
+        # ---- layout (mol_flatten, calculator.py:1475-1511): the engine is always flat ---------------
+        pad_mask = None
+        self._batch = None
+        if coord.ndim == 3:
+            B, N = coord.shape[:2]
+            self._batch = B
+            if numbers.ndim != 2 or numbers.shape[0] != B:
+                raise ValueError("numbers must have shape (B, N) for 3D coord input")
+            real = (numbers > 0).flatten()
+            mol_idx = torch.arange(B, device=self.device, dtype=torch.int32).repeat_interleave(N)
+            coord_f, numbers_f = coord.flatten(0, 1), numbers.flatten()
+            if not bool(real.all()):
+                pad_mask = real
+                coord_f, numbers_f, mol_idx = coord_f[real], numbers_f[real], mol_idx[real]
+            self._max_mol_size = N
+        elif coord.ndim == 2:
+            coord_f, numbers_f = coord, numbers
+            mol_idx = d.get("mol_idx")
+            if mol_idx is None:
+                mol_idx = torch.zeros(coord.shape[0], dtype=torch.int32, device=self.device)
+        else:
+            raise ValueError(f"coord must be (N,3) or (B,N,3), got {tuple(coord.shape)}")
+        n_mol = charge.shape[0]
+        method, restore = self._coulomb_method, None
+        if cell is not None and method == "simple":
+            warnings.warn("Switching to DSF Coulomb for PBC for this evaluation; "
+                          "call set_lrcoulomb_method() to select a periodic method persistently.", stacklevel=2)
+            restore = (self._coulomb_method, self._coulomb_cutoff, self.cutoff_lr, self._dsf_alpha, self._dsf_rc)
+            self.set_lrcoulomb_method("dsf")
+            method = "dsf"
+        try:
+            pbc3 = (True, True, True)
+            if pbc is not None:
+                p = pbc.detach().cpu().numpy().astype(bool)
+                if p.ndim == 2:
+                    if not (p == p[0]).all():
+                        raise NotImplementedError("per-system pbc flags are not supported by the native engine")
+                    p = p[0]
+                if p.shape != (3,):
+                    raise ValueError("pbc must have shape (3,) or (B, 3)")
+                pbc3 = tuple(bool(x) for x in p)
+            res = self.engine.eval(
+                coord_f, numbers_f, mol_idx, charge, cell=cell, pbc=pbc3, forces=bool(forces), stress=bool(stress),
+                coulomb=method or "none", dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha)
+        finally:
+            if restore is not None:
+                (self._coulomb_method, self._coulomb_cutoff, self.cutoff_lr, self._dsf_alpha, self._dsf_rc) = restore
+        # ---- process_output: un-flatten (calculator.py:1240-1245,1513-1519) -------------------------
+        out: dict[str, Any] = {"energy": res["energy"], "charges": res["charges"]}
+        if forces:
+            out["forces"] = res["forces"]
+        if stress:
+            out["stress"] = res["stress"]
+        if self._batch is not None:
+            B = self._batch
+            for k in ("charges", "forces"):
+                if k in out:
+                    v = out[k]
+                    if pad_mask is not None:
+                        full = torch.zeros((pad_mask.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+                        full[pad_mask] = v
+                        v = full
+                    out[k] = v.view(B, -1, *v.shape[1:])
+        assert n_mol == out["energy"].shape[0]
+        return out
+
+    def hessian_vector_product(self, data, vectors, **kw):
+        raise NotImplementedError("hessian_vector_product is not implemented by the native engine yet (SURVEY.md 8f next-4)")
+
+
+class _ExternalCoulombState:
+    """Stand-in exposing the attributes callers read off `calc.external_coulomb` (lr.py:285-300)."""
+
+    def __init__(self, calc: AIMNet2Calculator):
+        self._calc = calc
+
+    @property
+    def method(self):
+        return self._calc._coulomb_method
+
+    @property
+    def dsf_alpha(self):
+        return self._calc._dsf_alpha
+
+    @property
+    def dsf_rc(self):
+        return self._calc._dsf_rc
+
+    subtract_sr = False

@@ -1,0 +1,646 @@
+// conv.hip - pair geometry, AEV radial basis and the ConvSV gather-contract kernels (fwd + bwd).
+//
+// Reference semantics (paths relative to /root/reference/aimnet):
+//   pair_geom   ops.calc_distances ops.py:37-66 (r = x_j + s.C - x_i, d, u = r/d)
+//   radial basis AEVSV._calc_aev modules/aev.py:94-110: gs_g = exp(-eta (d-s_g)^2) * 0.5 (cos(pi d/rc)+1)
+//   conv_fwd    ConvSV.forward aev.py:156-189 == Warp kernel kernels/conv_sv_2d_sp_wp.py:90-112 plus the
+//               agh contraction + square-sum, for conv_a (d2features) and conv_q in one launch;
+//               also assembles the MLP input row of aimnet2.py:108-120,163-164
+//   conv_bwd    Warp backward_a / backward_g kernels conv_sv_2d_sp_wp.py:115-164 fused with the AEV
+//               backward, in CENTRE-MAJOR form: the neighbour matrix is full and exactly symmetric, so
+//               every scatter into j is rewritten as a gather at i with u_ji = -u_ij (SURVEY.md App. A
+//               step 4; oracle/aimnet2_analytic.py is the executable specification) - deterministic,
+//               no atomics, and g_sv (N,M,16,4) is never materialised (recomputed from (u,d) in LDS).
+//
+// Mapping: one wave per centre atom, 4 atoms per 256-thread block, persistent grid-stride blocks.
+// Lane l owns feature a = l>>2 and the four shifts g = 4*(l&3)..+3, i.e. the 16 B at a_j[4l..4l+3]:
+// a neighbour's 1 KiB feature row is one coalesced dwordx4 wave load.  Neighbours are processed in
+// chunks of 64 whose (j, u, d) and radial basis tables are staged in LDS once per chunk (16 exp
+// per pair in total instead of per lane).
+#include "common.h"
+#include "kernels.h"
+
+namespace aimnet {
+
+constexpr int A_ = 16, G_ = 16, H_ = 12;
+constexpr int NF = A_ * G_;         // 256
+constexpr int NV = A_ * H_;         // 192
+constexpr int APB = 4;              // atoms (waves) per block
+constexpr float PI_F = 3.14159265358979323846f;
+
+// ------------------------------------------------------------------------------------------------
+__global__ void pair_geom_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
+                                 const float* __restrict__ cell, int n_cell, const int* __restrict__ nb_idx,
+                                 const int* __restrict__ nb_shift, const int* __restrict__ nb_cnt, int cap, int n_atoms,
+                                 float4* __restrict__ pg) {
+  const int i = blockIdx.x * APB + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const int cnt = nb_cnt[i];
+  const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2];
+  const float* c = cell ? cell + (n_cell == 1 ? 0 : (size_t)mol_idx[i] * 9) : nullptr;
+  for (int m = lane; m < cnt; m += 64) {
+    const size_t p = (size_t)i * cap + m;
+    const int j = nb_idx[p];
+    float rx = xw[3 * j] - xi, ry = xw[3 * j + 1] - yi, rz = xw[3 * j + 2] - zi;
+    if (c) {
+      int sx, sy, sz;
+      unpack_shift(nb_shift[p], sx, sy, sz);
+      rx += sx * c[0] + sy * c[3] + sz * c[6];
+      ry += sx * c[1] + sy * c[4] + sz * c[7];
+      rz += sx * c[2] + sy * c[5] + sz * c[8];
+    }
+    const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+    const float inv = 1.0f / d;
+    pg[p] = make_float4(rx * inv, ry * inv, rz * inv, d);
+  }
+}
+
+int launch_pair_geom(hipStream_t s, const float* xw, const int* mol_idx, const float* cell, int n_cell,
+                     const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, int n_atoms, float4* pg) {
+  hipLaunchKernelGGL(pair_geom_kernel, dim3(ceil_div(n_atoms, APB)), dim3(256), 0, s, xw, mol_idx, cell, n_cell, nb_idx,
+                     nb_shift, nb_cnt, cap, n_atoms, pg);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void embed_kernel(const float* __restrict__ afv, const int* __restrict__ numbers, int n_atoms,
+                             float* __restrict__ a0) {
+  const int i = blockIdx.x * APB + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const int z = min(63, max(0, numbers[i]));
+  reinterpret_cast<float4*>(a0 + (size_t)i * NF)[lane] = reinterpret_cast<const float4*>(afv + (size_t)z * NF)[lane];
+}
+
+int launch_embed(hipStream_t s, const float* afv, const int* numbers, int n_atoms, float* a0) {
+  hipLaunchKernelGGL(embed_kernel, dim3(ceil_div(n_atoms, APB)), dim3(256), 0, s, afv, numbers, n_atoms, a0);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// radial basis value (and optionally d/dd) for one (pair, shift)
+__device__ __forceinline__ float basis_fc(const BasisParams& bp, float d, float& dfc) {
+  const float dc = fminf(fmaxf(d, 1e-6f), bp.rc);
+  const float w = PI_F / bp.rc;
+  float sn, cs;
+  sincosf(dc * w, &sn, &cs);
+  dfc = (d > 1e-6f && d < bp.rc) ? -0.5f * w * sn : 0.0f;
+  return 0.5f * (cs + 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-wave LDS scratch of the forward kernel
+struct FwdWaveLds {
+  float gs[64][G_];   // radial basis of the current chunk
+  float4 ud[64];      // (ux, uy, uz, d)
+  int j[64];
+  float qj[64];
+};
+
+template <bool HAS_Q>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__ a, const float* __restrict__ q,
+                                                      const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
+                                                      const float4* __restrict__ pg, int cap,
+                                                      const float* __restrict__ agh_a, const float* __restrict__ agh_q,
+                                                      BasisParams bp, float* __restrict__ x, int ldx,
+                                                      float* __restrict__ Vsave, float* __restrict__ Vqsave, int n_atoms) {
+  __shared__ __attribute__((aligned(16))) FwdWaveLds wl[APB];
+  __shared__ float s_agh[A_ * G_ * H_];
+  __shared__ float s_aghq[G_ * H_];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < A_ * G_ * H_; k += 256) s_agh[k] = agh_a[k];
+  if (HAS_Q)
+    for (int k = threadIdx.x; k < G_ * H_; k += 256) s_aghq[k] = agh_q[k];
+  __syncthreads();
+  FwdWaveLds& L = wl[wid];
+  const int g4 = (lane & 3) * 4;
+
+  for (int i0 = blockIdx.x * APB; i0 < n_atoms; i0 += gridDim.x * APB) {
+    const int i = i0 + wid;
+    const bool live = i < n_atoms;
+    const int cnt = live ? nb_cnt[i] : 0;
+    int cmax = cnt;  // block-uniform trip count so that __syncthreads() is legal
+#pragma unroll
+    for (int w = 0; w < APB; ++w) {
+      const int iw = i0 + w;
+      cmax = max(cmax, iw < n_atoms ? nb_cnt[iw] : 0);
+    }
+    float acc[4][4];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[gi][c] = 0.0f;
+    float accq = 0.0f;
+
+    for (int c0 = 0; c0 < cmax; c0 += 64) {
+      const int nch = max(0, min(64, cnt - c0));
+      __syncthreads();  // previous chunk fully consumed
+      if (lane < nch) {
+        const size_t p = (size_t)i * cap + c0 + lane;
+        const int j = nb_idx[p];
+        L.j[lane] = j;
+        L.ud[lane] = pg[p];
+        if (HAS_Q) L.qj[lane] = q[j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int e = lane + 64 * t;
+        const int mm = e >> 4, g = e & 15;
+        float v = 0.0f;
+        if (mm < nch) {
+          const float d = L.ud[mm].w;
+          float dfc;
+          const float fc = basis_fc(bp, d, dfc);
+          const float dd = d - bp.shifts[g];
+          v = expf(-bp.eta * dd * dd) * fc;
+        }
+        L.gs[mm][g] = v;
+      }
+      __syncthreads();
+      for (int mm = 0; mm < nch; ++mm) {
+        const int j = L.j[mm];
+        const float4 av = reinterpret_cast<const float4*>(a + (size_t)j * NF)[lane];
+        const float4 gv = *reinterpret_cast<const float4*>(&L.gs[mm][g4]);
+        const float4 u = L.ud[mm];
+        const float t0 = av.x * gv.x, t1 = av.y * gv.y, t2 = av.z * gv.z, t3 = av.w * gv.w;
+        acc[0][0] += t0; acc[0][1] += t0 * u.x; acc[0][2] += t0 * u.y; acc[0][3] += t0 * u.z;
+        acc[1][0] += t1; acc[1][1] += t1 * u.x; acc[1][2] += t1 * u.y; acc[1][3] += t1 * u.z;
+        acc[2][0] += t2; acc[2][1] += t2 * u.x; acc[2][2] += t2 * u.y; acc[2][3] += t2 * u.z;
+        acc[3][0] += t3; acc[3][1] += t3 * u.x; acc[3][2] += t3 * u.y; acc[3][3] += t3 * u.z;
+        if (HAS_Q) {
+          const int c = lane & 3;
+          const float uc = (c == 0) ? 1.0f : (c == 1 ? u.x : (c == 2 ? u.y : u.z));
+          accq += L.qj[mm] * L.gs[mm][lane >> 2] * uc;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- epilogue: agh contraction + square-sum, assemble the MLP input row -----------------
+    float* sv = &L.gs[0][0];  // reuse: sv[(a*16+g)*3 + k], 768 floats; svq at 768.. (48 floats)
+    if (live) {
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        const int f = lane * 4 + gi;
+        sv[f * 3 + 0] = acc[gi][1];
+        sv[f * 3 + 1] = acc[gi][2];
+        sv[f * 3 + 2] = acc[gi][3];
+      }
+      if (HAS_Q && (lane & 3) != 0) sv[768 + (lane >> 2) * 3 + (lane & 3) - 1] = accq;
+      float* xr = x + (size_t)i * ldx;
+      reinterpret_cast<float4*>(xr)[lane] = reinterpret_cast<const float4*>(a + (size_t)i * NF)[lane];
+      reinterpret_cast<float4*>(xr + NF)[lane] = make_float4(acc[0][0], acc[1][0], acc[2][0], acc[3][0]);
+    }
+    __syncthreads();
+    if (live) {
+      float* xr = x + (size_t)i * ldx;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int o = lane + 64 * t;  // (a, h) = (o / 12, o % 12)
+        const int aa = o / H_, hh = o % H_;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < G_; ++g) {
+          const float w = s_agh[(aa * G_ + g) * H_ + hh];
+          const float* s3 = &sv[(aa * G_ + g) * 3];
+          v0 += w * s3[0];
+          v1 += w * s3[1];
+          v2 += w * s3[2];
+        }
+        float* vs = Vsave + (size_t)i * (NV * 3) + o * 3;
+        vs[0] = v0; vs[1] = v1; vs[2] = v2;
+        xr[2 * NF + o] = v0 * v0 + v1 * v1 + v2 * v2;
+      }
+      if (HAS_Q) {
+        const int c0 = 2 * NF + NV;  // 704
+        if (lane == 0) xr[c0] = q[i];
+        if ((lane & 3) == 0) xr[c0 + 1 + (lane >> 2)] = accq;
+        if (lane < H_) {
+          float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+          for (int g = 0; g < G_; ++g) {
+            const float w = s_aghq[g * H_ + lane];
+            v0 += w * sv[768 + g * 3 + 0];
+            v1 += w * sv[768 + g * 3 + 1];
+            v2 += w * sv[768 + g * 3 + 2];
+          }
+          float* vs = Vqsave + (size_t)i * (H_ * 3) + lane * 3;
+          vs[0] = v0; vs[1] = v1; vs[2] = v2;
+          xr[c0 + 1 + G_ + lane] = v0 * v0 + v1 * v1 + v2 * v2;
+        }
+        const int used = c0 + 1 + G_ + H_;  // 733
+        if (lane < ldx - used) xr[used + lane] = 0.0f;  // zero the K padding of the GEMM operand
+      } else {
+        const int used = 2 * NF + NV;
+        if (lane < ldx - used) xr[used + lane] = 0.0f;
+      }
+    }
+  }
+}
+
+int launch_conv_fwd(hipStream_t s, bool has_q, const float* a, const float* q, const int* nb_idx, const int* nb_cnt,
+                    const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp, float* x,
+                    int ldx, float* Vsave, float* Vqsave, int n_atoms) {
+  const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
+  if (has_q)
+    hipLaunchKernelGGL(conv_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, a, q, nb_idx, nb_cnt, pg, cap, agh_a, agh_q, bp,
+                       x, ldx, Vsave, Vqsave, n_atoms);
+  else
+    hipLaunchKernelGGL(conv_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, a, q, nb_idx, nb_cnt, pg, cap, agh_a, agh_q, bp,
+                       x, ldx, Vsave, Vqsave, n_atoms);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// unconcat: adjoint of the MLP input row -> adjoint of the conv sums:
+//   Sbar[a,g,0] = xbar[256 + a*16+g];  Sbar[a,g,1+k] = sum_h agh[a,g,h] * 2 V[a,h,k] xbar[512 + a*12+h]
+template <bool HAS_Q>
+__global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__ xbar, int ldx,
+                                                      const float* __restrict__ Vsave, const float* __restrict__ Vqsave,
+                                                      const float* __restrict__ agh_a, const float* __restrict__ agh_q,
+                                                      float* __restrict__ Sbar, float* __restrict__ Sqbar, int n_atoms) {
+  __shared__ float s_agh[A_ * G_ * H_];
+  __shared__ float s_aghq[G_ * H_];
+  __shared__ float s_vb[APB][NV * 3 + H_ * 3];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < A_ * G_ * H_; k += 256) s_agh[k] = agh_a[k];
+  if (HAS_Q)
+    for (int k = threadIdx.x; k < G_ * H_; k += 256) s_aghq[k] = agh_q[k];
+  float* vb = s_vb[wid];
+  for (int i0 = blockIdx.x * APB; i0 < n_atoms; i0 += gridDim.x * APB) {
+    const int i = i0 + wid;
+    const bool live = i < n_atoms;
+    __syncthreads();
+    if (live) {
+      const float* xr = xbar + (size_t)i * ldx;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int o = lane + 64 * t;
+        const float f = 2.0f * xr[2 * NF + o];
+        const float* vs = Vsave + (size_t)i * (NV * 3) + o * 3;
+        vb[o * 3 + 0] = f * vs[0];
+        vb[o * 3 + 1] = f * vs[1];
+        vb[o * 3 + 2] = f * vs[2];
+      }
+      if (HAS_Q && lane < H_) {
+        const float f = 2.0f * xr[2 * NF + NV + 1 + G_ + lane];
+        const float* vs = Vqsave + (size_t)i * (H_ * 3) + lane * 3;
+        vb[NV * 3 + lane * 3 + 0] = f * vs[0];
+        vb[NV * 3 + lane * 3 + 1] = f * vs[1];
+        vb[NV * 3 + lane * 3 + 2] = f * vs[2];
+      }
+    }
+    __syncthreads();
+    if (live) {
+      const float* xr = xbar + (size_t)i * ldx;
+      const int aa = lane >> 2;
+      const float4 s0 = reinterpret_cast<const float4*>(xr + NF)[lane];
+      const float s0v[4] = {s0.x, s0.y, s0.z, s0.w};
+      float4* out = reinterpret_cast<float4*>(Sbar + (size_t)i * (NF * 4)) + lane * 4;
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        const int g = (lane & 3) * 4 + gi;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int h = 0; h < H_; ++h) {
+          const float w = s_agh[(aa * G_ + g) * H_ + h];
+          const float* v3 = &vb[(aa * H_ + h) * 3];
+          v0 += w * v3[0];
+          v1 += w * v3[1];
+          v2 += w * v3[2];
+        }
+        out[gi] = make_float4(s0v[gi], v0, v1, v2);
+      }
+      if (HAS_Q) {
+        const int g = lane >> 2, c = lane & 3;
+        float v;
+        if (c == 0) {
+          v = xr[2 * NF + NV + 1 + g];
+        } else {
+          v = 0.f;
+#pragma unroll
+          for (int h = 0; h < H_; ++h) v += s_aghq[g * H_ + h] * vb[NV * 3 + h * 3 + c - 1];
+        }
+        Sqbar[(size_t)i * (G_ * 4) + lane] = v;
+      }
+    }
+  }
+}
+
+int launch_unconcat(hipStream_t s, bool has_q, const float* xbar, int ldx, const float* Vsave, const float* Vqsave,
+                    const float* agh_a, const float* agh_q, float* Sbar, float* Sqbar, int n_atoms) {
+  const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
+  if (has_q)
+    hipLaunchKernelGGL(unconcat_kernel<true>, dim3(grid), dim3(256), 0, s, xbar, ldx, Vsave, Vqsave, agh_a, agh_q, Sbar,
+                       Sqbar, n_atoms);
+  else
+    hipLaunchKernelGGL(unconcat_kernel<false>, dim3(grid), dim3(256), 0, s, xbar, ldx, Vsave, Vqsave, agh_a, agh_q, Sbar,
+                       Sqbar, n_atoms);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct BwdWaveLds {
+  float gs[64][G_];
+  float dgs[64][G_];
+  float4 ud[64];
+  int j[64];
+  float qj[64];
+};
+
+// per-lane linear map (dbar, ubar) -> rbar = dbar*u + (ubar - (ubar.u) u)/d
+__device__ __forceinline__ void rbar_of(float db, float ub0, float ub1, float ub2, const float4& u, float inv_d,
+                                        float& r0, float& r1, float& r2) {
+  const float dot = ub0 * u.x + ub1 * u.y + ub2 * u.z;
+  r0 = db * u.x + (ub0 - dot * u.x) * inv_d;
+  r1 = db * u.y + (ub1 - dot * u.y) * inv_d;
+  r2 = db * u.z + (ub2 - dot * u.z) * inv_d;
+}
+
+template <bool HAS_Q, bool NEED_ABAR, bool STRESS>
+__global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__ a, const float* __restrict__ q,
+                                                      const float* __restrict__ Sbar, const float* __restrict__ Sqbar,
+                                                      const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
+                                                      const float4* __restrict__ pg, int cap, BasisParams bp,
+                                                      const float* __restrict__ xbar, int ldx,
+                                                      const float* __restrict__ abar_in, float* __restrict__ abar_out,
+                                                      const float* __restrict__ qbar_in, float* __restrict__ qbar_out,
+                                                      float* __restrict__ fgrad, float* __restrict__ virial_atom,
+                                                      int n_atoms) {
+  __shared__ __attribute__((aligned(16))) BwdWaveLds wl[APB];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  BwdWaveLds& L = wl[wid];
+  const int g4 = (lane & 3) * 4;
+  const int qg = lane >> 2, qc = lane & 3;
+
+  for (int i0 = blockIdx.x * APB; i0 < n_atoms; i0 += gridDim.x * APB) {
+    const int i = i0 + wid;
+    const bool live = i < n_atoms;
+    const int cnt = live ? nb_cnt[i] : 0;
+    int cmax = cnt;
+#pragma unroll
+    for (int w = 0; w < APB; ++w) {
+      const int iw = i0 + w;
+      cmax = max(cmax, iw < n_atoms ? nb_cnt[iw] : 0);
+    }
+    // centre atom's own rows
+    float ai[4] = {0, 0, 0, 0};
+    float Si[4][4];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Si[gi][c] = 0.0f;
+    float qi = 0.0f, Sqi = 0.0f;
+    if (live) {
+      const float4 t = reinterpret_cast<const float4*>(a + (size_t)i * NF)[lane];
+      ai[0] = t.x; ai[1] = t.y; ai[2] = t.z; ai[3] = t.w;
+      const float4* sp = reinterpret_cast<const float4*>(Sbar + (size_t)i * (NF * 4)) + lane * 4;
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        const float4 v = sp[gi];
+        Si[gi][0] = v.x; Si[gi][1] = v.y; Si[gi][2] = v.z; Si[gi][3] = v.w;
+      }
+      if (HAS_Q) {
+        qi = q[i];
+        Sqi = Sqbar[(size_t)i * (G_ * 4) + lane];
+      }
+    }
+    float ab[4] = {0, 0, 0, 0};
+    float xa0 = 0.f, xa1 = 0.f, xa2 = 0.f;  // per-lane partial of dE/dx_i
+    float qacc = 0.0f;
+    float W[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) W[k] = 0.0f;
+
+    for (int c0 = 0; c0 < cmax; c0 += 64) {
+      const int nch = max(0, min(64, cnt - c0));
+      __syncthreads();
+      if (lane < nch) {
+        const size_t p = (size_t)i * cap + c0 + lane;
+        const int j = nb_idx[p];
+        L.j[lane] = j;
+        L.ud[lane] = pg[p];
+        if (HAS_Q) L.qj[lane] = q[j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int e = lane + 64 * t;
+        const int mm = e >> 4, g = e & 15;
+        float v = 0.0f, dv = 0.0f;
+        if (mm < nch) {
+          const float d = L.ud[mm].w;
+          float dfc;
+          const float fc = basis_fc(bp, d, dfc);
+          const float dd = d - bp.shifts[g];
+          const float Gg = expf(-bp.eta * dd * dd);
+          v = Gg * fc;
+          dv = Gg * (dfc - 2.0f * bp.eta * dd * fc);
+        }
+        L.gs[mm][g] = v;
+        L.dgs[mm][g] = dv;
+      }
+      __syncthreads();
+      for (int mm = 0; mm < nch; ++mm) {
+        const int j = L.j[mm];
+        const float4 ajv = reinterpret_cast<const float4*>(a + (size_t)j * NF)[lane];
+        const float4* sp = reinterpret_cast<const float4*>(Sbar + (size_t)j * (NF * 4)) + lane * 4;
+        const float4 sj0 = sp[0], sj1 = sp[1], sj2 = sp[2], sj3 = sp[3];
+        const float4 gv = *reinterpret_cast<const float4*>(&L.gs[mm][g4]);
+        const float4 dgv = *reinterpret_cast<const float4*>(&L.dgs[mm][g4]);
+        const float4 u = L.ud[mm];
+        const float inv_d = 1.0f / u.w;
+        const float aj[4] = {ajv.x, ajv.y, ajv.z, ajv.w};
+        const float gsv[4] = {gv.x, gv.y, gv.z, gv.w};
+        const float dg[4] = {dgv.x, dgv.y, dgv.z, dgv.w};
+        const float Sj[4][4] = {{sj0.x, sj0.y, sj0.z, sj0.w}, {sj1.x, sj1.y, sj1.z, sj1.w},
+                                {sj2.x, sj2.y, sj2.z, sj2.w}, {sj3.x, sj3.y, sj3.z, sj3.w}};
+        float dij = 0.f, uij0 = 0.f, uij1 = 0.f, uij2 = 0.f;
+        float dji = 0.f, uji0 = 0.f, uji1 = 0.f, uji2 = 0.f;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+          const float Pp = Sj[gi][0] - (u.x * Sj[gi][1] + u.y * Sj[gi][2] + u.z * Sj[gi][3]);
+          const float P = Si[gi][0] + (u.x * Si[gi][1] + u.y * Si[gi][2] + u.z * Si[gi][3]);
+          if (NEED_ABAR) ab[gi] += gsv[gi] * Pp;
+          dij += aj[gi] * P * dg[gi];
+          const float t = gsv[gi] * aj[gi];
+          uij0 += t * Si[gi][1]; uij1 += t * Si[gi][2]; uij2 += t * Si[gi][3];
+          dji += ai[gi] * Pp * dg[gi];
+          const float tp = gsv[gi] * ai[gi];
+          uji0 += tp * Sj[gi][1]; uji1 += tp * Sj[gi][2]; uji2 += tp * Sj[gi][3];
+        }
+        if (HAS_Q) {
+          // lane (g, c) of the charge convolution: Sq[g,c] = sum_m q_j gs_g (1,u)_c
+          const float sqj = Sqbar[(size_t)j * (G_ * 4) + lane];
+          const float gq = L.gs[mm][qg], dgq = L.dgs[mm][qg];
+          const float uc = (qc == 0) ? 1.0f : (qc == 1 ? u.x : (qc == 2 ? u.y : u.z));
+          const float qj = L.qj[mm];
+          const float sgn = (qc == 0) ? 1.0f : -1.0f;  // (1, -u) for the reverse pair
+          qacc += gq * sqj * uc * sgn;
+          dij += qj * Sqi * uc * dgq;
+          dji += qi * sqj * uc * sgn * dgq;
+          const float vij = qj * gq * Sqi, vji = qi * gq * sqj;
+          if (qc == 1) { uij0 += vij; uji0 += vji; }
+          if (qc == 2) { uij1 += vij; uji1 += vji; }
+          if (qc == 3) { uij2 += vij; uji2 += vji; }
+        }
+        float r0, r1, r2, s0, s1, s2;
+        rbar_of(dij, uij0, uij1, uij2, u, inv_d, r0, r1, r2);  // dE/dr_ij   (r_ij = x_j - x_i)
+        const float4 um = make_float4(-u.x, -u.y, -u.z, u.w);
+        rbar_of(dji, uji0, uji1, uji2, um, inv_d, s0, s1, s2);  // dE/dr_ji   (r_ji = x_i - x_j)
+        xa0 += s0 - r0; xa1 += s1 - r1; xa2 += s2 - r2;
+        if (STRESS) {
+          const float rx = u.x * u.w, ry = u.y * u.w, rz = u.z * u.w;
+          W[0] += rx * r0; W[1] += rx * r1; W[2] += rx * r2;
+          W[3] += ry * r0; W[4] += ry * r1; W[5] += ry * r2;
+          W[6] += rz * r0; W[7] += rz * r1; W[8] += rz * r2;
+        }
+      }
+    }
+    // ---- epilogue ---------------------------------------------------------------------------
+    xa0 = wave_sum(xa0); xa1 = wave_sum(xa1); xa2 = wave_sum(xa2);
+    if (HAS_Q) qacc = wave_sum(qacc);
+    if (STRESS) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) W[k] = wave_sum(W[k]);
+    }
+    if (live) {
+      if (NEED_ABAR) {
+        const float4 xb = reinterpret_cast<const float4*>(xbar + (size_t)i * ldx)[lane];
+        float4 o = make_float4(ab[0] + xb.x, ab[1] + xb.y, ab[2] + xb.z, ab[3] + xb.w);
+        if (abar_in) {
+          const float4 p = reinterpret_cast<const float4*>(abar_in + (size_t)i * NF)[lane];
+          o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+        }
+        reinterpret_cast<float4*>(abar_out + (size_t)i * NF)[lane] = o;
+      }
+      if (lane == 0) {
+        fgrad[3 * i + 0] += xa0;
+        fgrad[3 * i + 1] += xa1;
+        fgrad[3 * i + 2] += xa2;
+        if (HAS_Q) qbar_out[i] = qbar_in[i] + xbar[(size_t)i * ldx + 2 * NF + NV] + qacc;
+      }
+      if (STRESS && lane < 9) {
+        float v = W[0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) v = (lane == k) ? W[k] : v;
+        virial_atom[(size_t)i * 9 + lane] += v;
+      }
+    }
+  }
+}
+
+int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, const float* a, const float* q,
+                    const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
+                    int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
+                    const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms) {
+  const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
+#define AIMNET_BWD(HQ, NA, ST)                                                                                        \
+  hipLaunchKernelGGL((conv_bwd_kernel<HQ, NA, ST>), dim3(grid), dim3(256), 0, s, a, q, Sbar, Sqbar, nb_idx, nb_cnt, pg, \
+                     cap, bp, xbar, ldx, abar_in, abar_out, qbar_in, qbar_out, fgrad, virial_atom, n_atoms)
+  if (has_q) {
+    if (need_abar) {
+      if (stress) AIMNET_BWD(true, true, true); else AIMNET_BWD(true, true, false);
+    } else {
+      if (stress) AIMNET_BWD(true, false, true); else AIMNET_BWD(true, false, false);
+    }
+  } else {
+    if (need_abar) {
+      if (stress) AIMNET_BWD(false, true, true); else AIMNET_BWD(false, true, false);
+    } else {
+      if (stress) AIMNET_BWD(false, false, true); else AIMNET_BWD(false, false, false);
+    }
+  }
+#undef AIMNET_BWD
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone op with the exact contract of torch.ops.aimnet.conv_sv_2d_sp_fwd / _bwd
+// (conv_sv_2d_sp_wp.py:252-340): generic (A, G) with A*G a multiple of 4, materialised g (B,M,G,4),
+// sentinel index B-1, rows packed real-first (early exit at the first sentinel), padding row zero.
+__global__ void conv_sv_fwd_kernel(const float* __restrict__ a, const int* __restrict__ idx, const float4* __restrict__ g,
+                                   float4* __restrict__ out, int B, int A, int G, int M) {
+  const int b = blockIdx.x;
+  const int AG = A * G;
+  for (int f = threadIdx.x; f < AG; f += blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b < B - 1) {
+      const int gg = f % G;
+      for (int m = 0; m < M; ++m) {
+        const int j = idx[(size_t)b * M + m];
+        if (j >= B - 1) break;
+        const float av = a[(size_t)j * AG + f];
+        const float4 gv = g[((size_t)b * M + m) * G + gg];
+        acc.x += av * gv.x; acc.y += av * gv.y; acc.z += av * gv.z; acc.w += av * gv.w;
+      }
+    }
+    out[(size_t)b * AG + f] = acc;
+  }
+}
+
+int launch_conv_sv_fwd(hipStream_t s, const float* a, const int* idx, const float* g, float* out, int B, int A, int G,
+                       int M) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(conv_sv_fwd_kernel, dim3(B), dim3(256), 0, s, a, idx, (const float4*)g, (float4*)out, B, A, G, M);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// grad_g[b,m,g,:] = sum_a a[idx[b,m],a,g] * grad_out[b,a,g,:]
+__global__ void conv_sv_bwd_g_kernel(const float4* __restrict__ grad_out, const float* __restrict__ a,
+                                     const int* __restrict__ idx, float4* __restrict__ grad_g, int B, int A, int G, int M) {
+  const int b = blockIdx.x;
+  for (int e = threadIdx.x; e < M * G; e += blockDim.x) {
+    const int m = e / G, gg = e % G;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int j = idx[(size_t)b * M + m];
+    if (b < B - 1 && j < B - 1) {
+      for (int aa = 0; aa < A; ++aa) {
+        const float av = a[((size_t)j * A + aa) * G + gg];
+        const float4 go = grad_out[((size_t)b * A + aa) * G + gg];
+        acc.x += av * go.x; acc.y += av * go.y; acc.z += av * go.z; acc.w += av * go.w;
+      }
+    }
+    grad_g[((size_t)b * M + m) * G + gg] = acc;
+  }
+}
+
+// grad_a[j,a,g] += <grad_out[b,a,g,:], g[b,m,g,:]> for j = idx[b,m]: the op contract allows an
+// arbitrary (non-symmetric) idx, so this stand-alone form scatters with atomics like the Warp
+// kernel (conv_sv_2d_sp_wp.py:115-136); the engine itself never uses it (centre-major gather).
+__global__ void conv_sv_bwd_a_kernel(const float4* __restrict__ grad_out, const int* __restrict__ idx,
+                                     const float4* __restrict__ g, float* __restrict__ grad_a, int B, int A, int G, int M) {
+  const int b = blockIdx.x;
+  if (b >= B - 1) return;
+  const int AG = A * G;
+  for (int f = threadIdx.x; f < AG; f += blockDim.x) {
+    const int gg = f % G;
+    const float4 go = grad_out[(size_t)b * AG + f];
+    for (int m = 0; m < M; ++m) {
+      const int j = idx[(size_t)b * M + m];
+      if (j >= B - 1) break;
+      const float4 gv = g[((size_t)b * M + m) * G + gg];
+      atomicAdd(&grad_a[(size_t)j * AG + f], go.x * gv.x + go.y * gv.y + go.z * gv.z + go.w * gv.w);
+    }
+  }
+}
+
+int launch_conv_sv_bwd(hipStream_t s, const float* grad_out, const float* a, const int* idx, const float* g,
+                       float* grad_a, float* grad_g, int B, int A, int G, int M) {
+  if (B <= 0) return 0;
+  AIMNET_HIP_CHECK(hipMemsetAsync(grad_a, 0, (size_t)B * A * G * sizeof(float), s));
+  hipLaunchKernelGGL(conv_sv_bwd_g_kernel, dim3(B), dim3(256), 0, s, (const float4*)grad_out, a, idx, (float4*)grad_g, B, A,
+                     G, M);
+  AIMNET_LAUNCH_CHECK();
+  hipLaunchKernelGGL(conv_sv_bwd_a_kernel, dim3(B), dim3(256), 0, s, (const float4*)grad_out, idx, (const float4*)g, grad_a,
+                     B, A, G, M);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace aimnet

@@ -1,0 +1,550 @@
+// engine.hip - C ABI, device weight store, workspace layout and the launch sequence of one
+// AIMNet2 energy(+force, +virial) evaluation.  See include/aimnet_hip.h for the boundary and
+// DESIGN.md for the data layout; oracle/aimnet2_analytic.py is the executable specification of
+// the order of operations below.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/aimnet_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace aimnet {
+
+static thread_local char g_err[512] = "";
+void set_last_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static inline int pad32(int n) { return (n + 31) / 32 * 32; }
+
+struct Layer {
+  int n_in, n_out, k_in, k_out;  // real and padded (multiple of 32) sizes
+  float* w;                      // [k_out][k_in]  forward operand  (Bt of  H = X . W^T)
+  float* wt;                     // [k_in][k_out]  backward operand (Bt of dX = dZ . W)
+  float* b;                      // [k_out]
+};
+
+struct View {
+  size_t off, n_elem;
+  int elem_size, row_stride;
+};
+
+}  // namespace aimnet
+
+using namespace aimnet;
+
+struct aimnet_engine {
+  aimnet_arch arch;
+  int device;
+  std::vector<void*> allocs;
+  float *afv, *agh_a, *agh_q;
+  double* sae;
+  std::vector<Layer> mlp[AIMNET_MAX_PASS];
+  std::vector<Layer> head;
+  float* head_w_last;  // [k] last head layer as a vector
+  float* head_b_last;  // [1]
+  BasisParams bp;
+  std::map<std::string, View> views;
+};
+
+namespace {
+
+template <typename T>
+int dev_upload(aimnet_engine* e, const T* host, size_t n, T** out) {
+  void* p = nullptr;
+  AIMNET_HIP_CHECK(hipMalloc(&p, n * sizeof(T)));
+  e->allocs.push_back(p);
+  AIMNET_HIP_CHECK(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+  *out = (T*)p;
+  return 0;
+}
+
+int upload_layer(aimnet_engine* e, const float* w, const float* b, int n_in, int n_out, Layer* L) {
+  L->n_in = n_in;
+  L->n_out = n_out;
+  L->k_in = pad32(n_in);
+  L->k_out = pad32(n_out);
+  std::vector<float> wp((size_t)L->k_out * L->k_in, 0.0f), wtp((size_t)L->k_in * L->k_out, 0.0f), bp(L->k_out, 0.0f);
+  for (int o = 0; o < n_out; ++o) {
+    bp[o] = b[o];
+    for (int i = 0; i < n_in; ++i) {
+      const float v = w[(size_t)o * n_in + i];
+      wp[(size_t)o * L->k_in + i] = v;
+      wtp[(size_t)i * L->k_out + o] = v;
+    }
+  }
+  int rc;
+  if ((rc = dev_upload(e, wp.data(), wp.size(), &L->w))) return rc;
+  if ((rc = dev_upload(e, wtp.data(), wtp.size(), &L->wt))) return rc;
+  if ((rc = dev_upload(e, bp.data(), bp.size(), &L->b))) return rc;
+  return 0;
+}
+
+// ---- workspace layout ---------------------------------------------------------------------------
+struct Carver {
+  char* base;
+  size_t off = 0;
+  std::map<std::string, View>* views = nullptr;
+  template <typename T>
+  T* take(size_t n, const char* name = nullptr, int row_stride = 0) {
+    off = align_up(off, 256);
+    T* p = base ? (T*)(base + off) : nullptr;
+    if (name && views) (*views)[name] = View{off, n, (int)sizeof(T), row_stride};
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct Workspace {
+  NlistBuffers nl;
+  int *nb_idx, *nb_shift, *nb_cnt;
+  int *lr_idx, *lr_shift, *lr_cnt;
+  float4* pg;
+  float* a[AIMNET_MAX_PASS];       // features entering pass p
+  float* q[AIMNET_MAX_PASS];       // charges after pass p (p < n_pass-1)
+  float* x[AIMNET_MAX_PASS];       // MLP input rows
+  float* V[AIMNET_MAX_PASS];
+  float* Vq[AIMNET_MAX_PASS];
+  float* H[AIMNET_MAX_PASS][AIMNET_MAX_LAYERS];
+  float* D[AIMNET_MAX_PASS][AIMNET_MAX_LAYERS];
+  float* Fm[AIMNET_MAX_PASS];
+  float* Dm[AIMNET_MAX_PASS];
+  float* hH[AIMNET_MAX_LAYERS];
+  float* hD[AIMNET_MAX_LAYERS];
+  float* e_atom;
+  double* ecoul;
+  float *qbar, *fgrad, *virial_atom, *abar, *Wbar;
+  float *zb0, *zb1;  // ping-pong adjoint buffers (N x max padded width)
+  float *Sbar, *Sqbar;
+  size_t total;
+};
+
+int max_width(const aimnet_engine* e) {
+  int w = 32;
+  for (int p = 0; p < e->arch.n_pass; ++p)
+    for (const Layer& L : e->mlp[p]) w = std::max(w, std::max(L.k_in, L.k_out));
+  for (const Layer& L : e->head) w = std::max(w, std::max(L.k_in, L.k_out));
+  return w;
+}
+
+void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options* opt, char* base, Workspace& W,
+            std::map<std::string, View>* views) {
+  Carver c{base, 0, views};
+  const int np = e->arch.n_pass;
+  const bool grad = (opt->flags & (AIMNET_FORCES | AIMNET_STRESS)) != 0;
+  const size_t n = (size_t)N;
+  char* nl_base = c.take<char>(nlist_scratch_bytes(N, n_mol));
+  if (base) nlist_carve(W.nl, nl_base, N, n_mol);
+  if (views)  // the wrapped coordinates sit at a fixed position inside the nlist scratch
+    (*views)["xw"] = View{(size_t)(nl_base - base) + nlist_xw_offset(n_mol), n * 3, 4, 3};
+  const int cap = std::max(1, opt->max_nb), cap_lr = std::max(0, opt->max_nb_lr);
+  W.nb_idx = c.take<int>(n * cap, "nb_idx", cap);
+  W.nb_shift = c.take<int>(n * cap, "nb_shift", cap);
+  W.nb_cnt = c.take<int>(n, "nb_cnt", 1);
+  W.lr_idx = c.take<int>(n * cap_lr, "lr_idx", cap_lr);
+  W.lr_shift = c.take<int>(n * cap_lr, "lr_shift", cap_lr);
+  W.lr_cnt = c.take<int>(n, "lr_cnt", 1);
+  W.pg = c.take<float4>(n * cap, "pair_geom", cap);
+  char name[32];
+  for (int p = 0; p < np; ++p) {
+    snprintf(name, sizeof name, "a%d", p);
+    W.a[p] = c.take<float>(n * 256, name, 256);
+    snprintf(name, sizeof name, "q%d", p);
+    W.q[p] = c.take<float>(n, name, 1);
+    const int ldx = e->mlp[p][0].k_in;
+    snprintf(name, sizeof name, "x%d", p);
+    W.x[p] = c.take<float>(n * ldx, name, ldx);
+    W.V[p] = c.take<float>(n * 576);
+    W.Vq[p] = c.take<float>(n * 36);
+    for (size_t l = 0; l < e->mlp[p].size(); ++l) {
+      const int ld = e->mlp[p][l].k_out;
+      snprintf(name, sizeof name, "h%d_%d", p, (int)l);
+      W.H[p][l] = c.take<float>(n * ld, name, ld);
+      W.D[p][l] = grad ? c.take<float>(n * ld) : nullptr;
+    }
+    W.Fm[p] = c.take<float>(n_mol);
+    W.Dm[p] = c.take<float>(n_mol);
+  }
+  for (size_t l = 0; l + 1 < e->head.size(); ++l) {
+    const int ld = e->head[l].k_out;
+    W.hH[l] = c.take<float>(n * ld);
+    W.hD[l] = grad ? c.take<float>(n * ld) : nullptr;
+  }
+  W.e_atom = c.take<float>(n, "e_atom", 1);
+  W.ecoul = c.take<double>(n, "ecoul", 1);
+  W.qbar = c.take<float>(n, "qbar", 1);
+  W.fgrad = c.take<float>(n * 3, "fgrad", 3);
+  W.virial_atom = c.take<float>(n * 9);
+  W.Wbar = c.take<float>(n_mol);
+  if (grad) {
+    const int mw = max_width(e);
+    W.abar = c.take<float>(n * 256, "abar", 256);
+    W.zb0 = c.take<float>(n * mw, "zb0", mw);
+    W.zb1 = c.take<float>(n * mw, "zb1", mw);
+    W.Sbar = c.take<float>(n * 1024, "Sbar", 1024);
+    W.Sqbar = c.take<float>(n * 64, "Sqbar", 64);
+  } else {
+    W.abar = W.zb0 = W.zb1 = W.Sbar = W.Sqbar = nullptr;
+  }
+  W.total = align_up(c.off, 256);
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int aimnet_abi_version(void) { return AIMNET_ABI_VERSION; }
+
+const char* aimnet_last_error(void) { return g_err; }
+
+int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int device, aimnet_engine** out) {
+  if (!arch || !w || !out) return AIMNET_E_INVALID;
+  if (arch->nfeature != 16 || arch->nshifts != 16 || arch->ncomb_v != 12) {
+    set_last_error("unsupported architecture: kernels are specialised for nfeature=16, nshifts=16, ncomb_v=12 (got %d,%d,%d)",
+                   arch->nfeature, arch->nshifts, arch->ncomb_v);
+    return AIMNET_E_INVALID;
+  }
+  if (arch->n_pass < 2 || arch->n_pass > AIMNET_MAX_PASS || arch->head_n_layers < 2 || arch->head_n_layers > AIMNET_MAX_LAYERS) {
+    set_last_error("unsupported architecture: n_pass=%d head layers=%d", arch->n_pass, arch->head_n_layers);
+    return AIMNET_E_INVALID;
+  }
+  AIMNET_HIP_CHECK(hipSetDevice(device));
+  aimnet_engine* e = new aimnet_engine();
+  e->arch = *arch;
+  e->device = device;
+  int rc = 0;
+  const int AG = 256;
+  if ((rc = dev_upload(e, w->afv, (size_t)64 * AG, &e->afv))) goto fail;
+  if ((rc = dev_upload(e, w->agh_a, (size_t)16 * 16 * 12, &e->agh_a))) goto fail;
+  if ((rc = dev_upload(e, w->agh_q, (size_t)16 * 12, &e->agh_q))) goto fail;
+  if ((rc = dev_upload(e, w->sae, (size_t)64, &e->sae))) goto fail;
+  for (int p = 0; p < arch->n_pass; ++p) {
+    const int nl = arch->n_layers[p];
+    if (nl < 1 || nl > AIMNET_MAX_LAYERS) { rc = AIMNET_E_INVALID; set_last_error("bad n_layers[%d]=%d", p, nl); goto fail; }
+    const int n_in_expect = (p == 0) ? 704 : 733;
+    const int n_out_expect = (p < arch->n_pass - 1) ? 258 : arch->layer_dims[p][nl];
+    if (arch->layer_dims[p][0] != n_in_expect || arch->layer_dims[p][nl] != n_out_expect) {
+      rc = AIMNET_E_INVALID;
+      set_last_error("pass %d MLP dims %d->%d do not match the feature layout (%d->%d)", p, arch->layer_dims[p][0],
+                     arch->layer_dims[p][nl], n_in_expect, n_out_expect);
+      goto fail;
+    }
+    for (int l = 0; l < nl; ++l) {
+      Layer L;
+      if ((rc = upload_layer(e, w->mlp_w[p][l], w->mlp_b[p][l], arch->layer_dims[p][l], arch->layer_dims[p][l + 1], &L))) goto fail;
+      e->mlp[p].push_back(L);
+    }
+  }
+  if (arch->head_dims[0] != arch->layer_dims[arch->n_pass - 1][arch->n_layers[arch->n_pass - 1]] ||
+      arch->head_dims[arch->head_n_layers] != 1) {
+    rc = AIMNET_E_INVALID;
+    set_last_error("energy head dims do not chain from the last MLP / do not end in 1");
+    goto fail;
+  }
+  for (int l = 0; l + 1 < arch->head_n_layers; ++l) {
+    Layer L;
+    if ((rc = upload_layer(e, w->head_w[l], w->head_b[l], arch->head_dims[l], arch->head_dims[l + 1], &L))) goto fail;
+    e->head.push_back(L);
+  }
+  {
+    const int l = arch->head_n_layers - 1;
+    Layer L{};  // vector form of the final (k -> 1) layer
+    L.n_in = arch->head_dims[l];
+    L.n_out = 1;
+    L.k_in = pad32(L.n_in);
+    L.k_out = 1;
+    e->head.push_back(L);
+    if ((rc = dev_upload(e, w->head_w[l], (size_t)L.n_in, &e->head_w_last))) goto fail;
+    if ((rc = dev_upload(e, w->head_b[l], (size_t)1, &e->head_b_last))) goto fail;
+  }
+  e->bp.rc = arch->rc;
+  e->bp.eta = arch->eta;
+  for (int g = 0; g < 16; ++g) e->bp.shifts[g] = arch->shifts[g];
+  if ((rc = gemm_set_attributes())) goto fail;
+  *out = e;
+  return AIMNET_OK;
+fail:
+  aimnet_engine_destroy(e);
+  return rc;
+}
+
+void aimnet_engine_destroy(aimnet_engine* e) {
+  if (!e) return;
+  for (void* p : e->allocs) (void)hipFree(p);
+  delete e;
+}
+
+size_t aimnet_engine_workspace_bytes(const aimnet_engine* e, int32_t n_atoms, int32_t n_mol, int32_t n_cell,
+                                     const aimnet_eval_options* opt) {
+  (void)n_cell;
+  if (!e || !opt || n_atoms <= 0 || n_mol <= 0) return 0;
+  Workspace W;
+  layout(e, n_atoms, n_mol, opt, nullptr, W, nullptr);
+  return W.total;
+}
+
+int aimnet_engine_debug_view(const aimnet_engine* e, const char* name, size_t* byte_offset, size_t* n_elem,
+                             int32_t* elem_size, int32_t* row_stride) {
+  if (!e || !name) return AIMNET_E_INVALID;
+  auto it = e->views.find(name);
+  if (it == e->views.end()) return AIMNET_E_INVALID;
+  if (byte_offset) *byte_offset = it->second.off;
+  if (n_elem) *n_elem = it->second.n_elem;
+  if (elem_size) *elem_size = it->second.elem_size;
+  if (row_stride) *row_stride = it->second.row_stride;
+  return AIMNET_OK;
+}
+
+#define RC(call)            \
+  do {                      \
+    int _rc = (call);       \
+    if (_rc) return _rc;    \
+  } while (0)
+
+int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_eval_options* opt,
+                       const aimnet_outputs* out, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!e || !in || !opt || !out || !workspace) return AIMNET_E_INVALID;
+  const int N = in->n_atoms, n_mol = in->n_mol;
+  if (N <= 0 || n_mol <= 0 || !in->coord || !in->numbers || !in->mol_idx || !in->charge || !out->energy ||
+      !out->charges || !out->status) {
+    set_last_error("eval: null or empty input/output");
+    return AIMNET_E_INVALID;
+  }
+  const bool want_f = (opt->flags & AIMNET_FORCES) != 0, want_s = (opt->flags & AIMNET_STRESS) != 0;
+  const bool grad = want_f || want_s;
+  const bool pbc = in->cell != nullptr;
+  if (want_s && (!pbc || !out->stress)) {
+    set_last_error("eval: stress requires a cell and a stress buffer");
+    return AIMNET_E_INVALID;
+  }
+  if (want_f && !out->forces) {
+    set_last_error("eval: forces requested without a forces buffer");
+    return AIMNET_E_INVALID;
+  }
+  if (pbc && !(in->n_cell == 1 || in->n_cell == n_mol)) {
+    set_last_error("eval: n_cell must be 1 or n_mol");
+    return AIMNET_E_INVALID;
+  }
+  int coulomb = opt->coulomb;
+  if (coulomb == AIMNET_COULOMB_DSF && opt->max_nb_lr <= 0) {
+    set_last_error("eval: DSF Coulomb needs max_nb_lr > 0");
+    return AIMNET_E_INVALID;
+  }
+  if (coulomb == AIMNET_COULOMB_SIMPLE && pbc) {
+    set_last_error("eval: 'simple' Coulomb is undefined for periodic input (host must switch to DSF, calculator.py:1044)");
+    return AIMNET_E_INVALID;
+  }
+  hipStream_t s = (hipStream_t)hip_stream;
+  AIMNET_HIP_CHECK(hipSetDevice(e->device));
+  Workspace W;
+  e->views.clear();
+  layout(e, N, n_mol, opt, (char*)workspace, W, &e->views);
+  if (W.total > workspace_bytes) {
+    set_last_error("eval: workspace too small (%zu < %zu)", workspace_bytes, W.total);
+    return AIMNET_E_WORKSPACE;
+  }
+  const aimnet_arch& ar = e->arch;
+  const int np = ar.n_pass;
+  const int cap = std::max(1, opt->max_nb), cap_lr = std::max(0, opt->max_nb_lr);
+  const int n_cell = pbc ? in->n_cell : 0;
+
+  // ---- neighbour lists + pair geometry ------------------------------------------------------
+  AIMNET_HIP_CHECK(hipMemsetAsync(out->status, 0, 8 * sizeof(int), s));
+  RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start));
+  RC(launch_wrap(s, in->coord, in->mol_idx, N, n_mol, in->cell, n_cell, in->pbc, W.nl));
+  RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, ar.rc, 1, cap, N, 0, W.nl, W.nb_idx, W.nb_shift,
+                  W.nb_cnt, out->status + 0, out->status + 2));
+  if (coulomb == AIMNET_COULOMB_DSF)
+    RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, opt->dsf_rc, 2, cap_lr, N, 0, W.nl, W.lr_idx,
+                    W.lr_shift, W.lr_cnt, out->status + 1, out->status + 3));
+  RC(launch_pair_geom(s, W.nl.xw, in->mol_idx, in->cell, n_cell, W.nb_idx, W.nb_shift, W.nb_cnt, cap, N, W.pg));
+
+  // ---- forward --------------------------------------------------------------------------------
+  RC(launch_embed(s, e->afv, in->numbers, N, W.a[0]));
+  for (int p = 0; p < np; ++p) {
+    const std::vector<Layer>& Ls = e->mlp[p];
+    const int nl = (int)Ls.size();
+    RC(launch_conv_fwd(s, p > 0, W.a[p], p > 0 ? W.q[p - 1] : nullptr, W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q,
+                       e->bp, W.x[p], Ls[0].k_in, W.V[p], W.Vq[p], N));
+    const float* hin = W.x[p];
+    int ld_in = Ls[0].k_in;
+    for (int l = 0; l < nl; ++l) {
+      const bool linear = (l == nl - 1) && ar.last_linear[p];
+      RC(launch_gemm_nt(s, linear ? EPI_BIAS : EPI_BIAS_GELU, hin, ld_in, Ls[l].w, Ls[l].k_in, N, Ls[l].k_out, Ls[l].k_in,
+                        Ls[l].b, W.H[p][l], linear ? nullptr : W.D[p][l], Ls[l].k_out));
+      hin = W.H[p][l];
+      ld_in = Ls[l].k_out;
+    }
+    if (p < np - 1) {
+      RC(launch_nse_fwd(s, W.H[p][nl - 1], Ls[nl - 1].k_out, p > 0 ? W.q[p - 1] : nullptr, W.nl.mol_start, in->charge,
+                        n_mol, W.q[p], W.Fm[p], W.Dm[p]));
+      RC(launch_update_a(s, W.a[p], W.H[p][nl - 1], Ls[nl - 1].k_out, N, W.a[p + 1]));
+    }
+  }
+  const float* q_fin = W.q[np - 2];
+  {
+    const int nlp = (int)e->mlp[np - 1].size();
+    const float* hin = W.H[np - 1][nlp - 1];
+    int ld_in = e->mlp[np - 1][nlp - 1].k_out;
+    const int nh = (int)e->head.size();
+    for (int l = 0; l + 1 < nh; ++l) {
+      const Layer& L = e->head[l];
+      RC(launch_gemm_nt(s, EPI_BIAS_GELU, hin, ld_in, L.w, L.k_in, N, L.k_out, L.k_in, L.b, W.hH[l], W.hD[l], L.k_out));
+      hin = W.hH[l];
+      ld_in = L.k_out;
+    }
+    RC(launch_head_last(s, hin, ld_in, e->head_w_last, e->head_b_last, e->head[nh - 1].n_in, N, W.e_atom));
+  }
+
+  // ---- Coulomb: energies, and the seeds of qbar / dE/dx / virial -------------------------------
+  CoulombParams cp;
+  cp.factor = (float)(0.5 * 27.211386024367243 * 0.5291772105638411);
+  cp.sr_rc = ar.sr_rc;
+  cp.sr_envelope = ar.sr_envelope;
+  cp.dsf_rc = opt->dsf_rc;
+  cp.dsf_alpha = opt->dsf_alpha;
+  RC(launch_coulomb_sr(s, grad, want_s, ar.sr_coulomb != 0, q_fin, W.nb_idx, W.nb_cnt, W.pg, cap, cp, N, W.ecoul, W.qbar,
+                       W.fgrad, W.virial_atom));
+  if (coulomb == AIMNET_COULOMB_SIMPLE)
+    RC(launch_coulomb_simple(s, grad, q_fin, W.nl.xw, in->mol_idx, W.nl.mol_start, cp, N, W.ecoul, W.qbar, W.fgrad));
+  else if (coulomb == AIMNET_COULOMB_DSF)
+    RC(launch_coulomb_dsf(s, grad, want_s, q_fin, W.nl.xw, in->mol_idx, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt,
+                          cap_lr, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));
+  RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, out->energy));
+  RC(launch_copy_f32(s, q_fin, out->charges, (size_t)N));
+  if (!grad) return AIMNET_OK;
+
+  // ---- backward -------------------------------------------------------------------------------
+  float* zcur = W.zb0;
+  float* znext = W.zb1;
+  {
+    const int nh = (int)e->head.size();
+    // seed: d e / d z_{nh-2} = w_last * GELU'(z)
+    const Layer& Lp = e->head[nh - 2];
+    RC(launch_head_seed(s, e->head_w_last, W.hD[nh - 2], Lp.k_out, Lp.n_out, N, zcur));
+    int ld = Lp.k_out;
+    for (int l = nh - 2; l >= 0; --l) {
+      const Layer& L = e->head[l];
+      float* dprev;
+      if (l > 0) dprev = W.hD[l - 1];
+      else dprev = W.D[np - 1][e->mlp[np - 1].size() - 1];  // aim = GELU(z_last) of the last MLP
+      RC(launch_gemm_nt(s, dprev ? EPI_MUL : EPI_NONE, zcur, ld, L.wt, L.k_out, N, L.k_in, L.k_out, nullptr, znext, dprev,
+                        L.k_in));
+      std::swap(zcur, znext);
+      ld = L.k_in;
+    }
+  }
+  for (int p = np - 1; p >= 0; --p) {
+    const std::vector<Layer>& Ls = e->mlp[p];
+    const int nl = (int)Ls.size();
+    int ld = Ls[nl - 1].k_out;  // zcur = adjoint of the last layer's pre-activation (GELU' already applied)
+    for (int l = nl - 1; l >= 0; --l) {
+      const Layer& L = Ls[l];
+      if (l > 0)
+        RC(launch_gemm_nt(s, EPI_MUL, zcur, ld, L.wt, L.k_out, N, L.k_in, L.k_out, nullptr, znext, W.D[p][l - 1], L.k_in));
+      else
+        RC(launch_gemm_nt(s, EPI_NONE, zcur, ld, L.wt, L.k_out, N, L.k_in, L.k_out, nullptr, znext, nullptr, L.k_in));
+      std::swap(zcur, znext);
+      ld = L.k_in;
+    }
+    // zcur = xbar_p  (N x k_in of the first layer)
+    RC(launch_unconcat(s, p > 0, zcur, ld, W.V[p], W.Vq[p], e->agh_a, e->agh_q, W.Sbar, W.Sqbar, N));
+    RC(launch_conv_bwd(s, p > 0, p > 0, want_s, W.a[p], p > 0 ? W.q[p - 1] : nullptr, W.Sbar, W.Sqbar, W.nb_idx, W.nb_cnt,
+                       W.pg, cap, e->bp, zcur, ld, (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, W.fgrad,
+                       W.virial_atom, N));
+    if (p == 0) break;
+    // NSE adjoint of pass p-1, then the adjoint of its MLP output
+    const std::vector<Layer>& Lq = e->mlp[p - 1];
+    const int nlq = (int)Lq.size();
+    const float* y = W.H[p - 1][nlq - 1];
+    const int ldy = Lq[nlq - 1].k_out;
+    RC(launch_nse_bwd_reduce(s, W.qbar, y, ldy, W.Fm[p - 1], W.nl.mol_start, n_mol, W.Wbar));
+    RC(launch_build_zbar(s, W.qbar, W.abar, y, ldy, ar.last_linear[p - 1] ? nullptr : W.D[p - 1][nlq - 1], W.Fm[p - 1],
+                         W.Dm[p - 1], W.Wbar, in->mol_idx, N, 256, p - 1 > 0, znext, W.qbar));
+    std::swap(zcur, znext);
+  }
+  RC(launch_finalize(s, W.fgrad, W.virial_atom, W.nl.mol_start, in->cell, n_cell, n_mol, N, want_f ? out->forces : nullptr,
+                     want_s ? out->stress : nullptr));
+  return AIMNET_OK;
+}
+
+// ---- stand-alone entry points --------------------------------------------------------------------
+size_t aimnet_neighbor_list_workspace_bytes(int32_t n_atoms, int32_t n_mol, int32_t max_nb) {
+  if (n_atoms <= 0 || n_mol <= 0 || max_nb <= 0) return 0;
+  return align_up(nlist_scratch_bytes(n_atoms, n_mol), 256) + align_up((size_t)n_atoms * (size_t)max_nb * sizeof(int), 256);
+}
+
+__global__ void expand_shifts_kernel(const int* __restrict__ code, size_t n, int* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  int sx, sy, sz;
+  unpack_shift(code[e], sx, sy, sz);
+  out[3 * e] = sx;
+  out[3 * e + 1] = sy;
+  out[3 * e + 2] = sz;
+}
+
+int aimnet_neighbor_list(const float* coord, const int32_t* mol_idx, int32_t n_atoms, int32_t n_mol,
+                         const float* cell, int32_t n_cell, const int32_t pbc[3], float cutoff, int32_t max_nb,
+                         int32_t fill_value, int32_t* nbmat, int32_t* shifts, int32_t* num_nb, int32_t* status,
+                         float* coord_wrapped, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!coord || !mol_idx || !nbmat || !num_nb || !status || !workspace || n_atoms <= 0 || n_mol <= 0 || max_nb <= 0)
+    return AIMNET_E_INVALID;
+  if (cell && !shifts) {
+    set_last_error("neighbor_list: periodic input needs a shifts buffer");
+    return AIMNET_E_INVALID;
+  }
+  if (cell && !(n_cell == 1 || n_cell == n_mol)) {
+    set_last_error("neighbor_list: n_cell must be 1 or n_mol");
+    return AIMNET_E_INVALID;
+  }
+  const size_t need = aimnet_neighbor_list_workspace_bytes(n_atoms, n_mol, max_nb);
+  if (workspace_bytes < need) {
+    set_last_error("neighbor_list: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return AIMNET_E_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)hip_stream;
+  NlistBuffers nl;
+  nlist_carve(nl, (char*)workspace, n_atoms, n_mol);
+  int* codes = (int*)((char*)workspace + align_up(nlist_scratch_bytes(n_atoms, n_mol), 256));
+  const int pz[3] = {1, 1, 1};
+  const int* pb = pbc ? pbc : pz;
+  AIMNET_HIP_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(int), s));
+  RC(launch_mol_start(s, mol_idx, n_atoms, n_mol, nl.mol_start));
+  RC(launch_wrap(s, coord, mol_idx, n_atoms, n_mol, cell, cell ? n_cell : 0, pb, nl));
+  RC(launch_nlist(s, n_atoms, n_mol, mol_idx, cell, cell ? n_cell : 0, pb, cutoff, 1, max_nb, fill_value, 1, nl, nbmat,
+                  codes, num_nb, status + 0, status + 1));
+  if (cell) {
+    const size_t n_pairs = (size_t)n_atoms * max_nb;
+    hipLaunchKernelGGL(expand_shifts_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, codes, n_pairs, shifts);
+    AIMNET_LAUNCH_CHECK();
+  }
+  if (coord_wrapped)
+    AIMNET_HIP_CHECK(hipMemcpyAsync(coord_wrapped, nl.xw, (size_t)n_atoms * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return AIMNET_OK;
+}
+
+int aimnet_conv_sv_2d_sp_fwd(const float* a, const int32_t* idx, const float* g, float* out, int32_t B, int32_t A,
+                             int32_t G, int32_t M, void* hip_stream) {
+  if (!a || !idx || !g || !out || B < 0 || A <= 0 || G <= 0 || M <= 0) return AIMNET_E_INVALID;
+  return launch_conv_sv_fwd((hipStream_t)hip_stream, a, idx, g, out, B, A, G, M);
+}
+
+int aimnet_conv_sv_2d_sp_bwd(const float* grad_out, const float* a, const int32_t* idx, const float* g,
+                             float* grad_a, float* grad_g, int32_t B, int32_t A, int32_t G, int32_t M,
+                             void* hip_stream) {
+  if (!grad_out || !a || !idx || !g || !grad_a || !grad_g || B < 0 || A <= 0 || G <= 0 || M <= 0) return AIMNET_E_INVALID;
+  return launch_conv_sv_bwd((hipStream_t)hip_stream, grad_out, a, idx, g, grad_a, grad_g, B, A, G, M);
+}
+
+}  // extern "C"

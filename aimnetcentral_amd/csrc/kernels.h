@@ -1,0 +1,102 @@
+// kernels.h - host-side launchers of the gfx950 kernels (one .hip file per family).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace aimnet {
+
+// ---- gemm.hip ---------------------------------------------------------------------------------
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL = 3 };
+// C[M,N] = A[M,K] . Bt[N,K]^T with fused epilogue.  K % 32 == 0, lda/ldb % 4 == 0.
+//   EPI_BIAS_GELU: C = gelu(acc + bias), D = gelu'(acc + bias) (D may be NULL)
+//   EPI_MUL:       C = acc * D
+int launch_gemm_nt(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N,
+                   int K, const float* bias, float* C, float* D, int ldc);
+int gemm_set_attributes();
+
+// ---- nlist.hip --------------------------------------------------------------------------------
+struct NlistBuffers {      // all device pointers, carved from the caller's workspace
+  int* mol_start;          // [n_mol + 1]
+  float* xw;               // [n_atoms, 3] coordinates wrapped into the cell (== coord when non-periodic)
+  void* sys;               // [n_mol] NlistSystem
+  int* atom_bin;           // [n_atoms]
+  int* bin_count;          // [max_bins + 1]
+  int* bin_start;          // [max_bins + 1]
+  int* bin_fill;           // [max_bins]
+  int* sorted_tmp;         // [n_atoms]
+  int* sorted;             // [n_atoms]
+};
+size_t nlist_scratch_bytes(int n_atoms, int n_mol);
+size_t nlist_xw_offset(int n_mol);  // byte offset of NlistBuffers::xw inside the scratch
+void nlist_carve(NlistBuffers& b, char* base, int n_atoms, int n_mol);
+int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start);
+// wrap coordinates (periodic) or copy them (non-periodic) into b.xw
+int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
+                int n_cell, const int pbc[3], NlistBuffers& b);
+// build one full neighbour matrix for `cutoff` from b.xw; rows real-first; entries beyond the row
+// count are set to `fill_value` when fill_rows != 0; status[0] = max count (atomicMax), status[1] = overflow
+int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, const float* cell, int n_cell,
+                 const int pbc[3], float cutoff, int bin_sub, int cap, int fill_value, int fill_rows,
+                 NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf);
+
+// ---- conv.hip ---------------------------------------------------------------------------------
+struct BasisParams {  // radial basis of AEVSV (aev.py:66-81), passed by value
+  float rc, eta;
+  float shifts[16];
+};
+int launch_pair_geom(hipStream_t s, const float* xw, const int* mol_idx, const float* cell, int n_cell,
+                     const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, int n_atoms, float4* pg);
+int launch_embed(hipStream_t s, const float* afv, const int* numbers, int n_atoms, float* a0);
+int launch_conv_fwd(hipStream_t s, bool has_q, const float* a, const float* q, const int* nb_idx, const int* nb_cnt,
+                    const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp, float* x,
+                    int ldx, float* Vsave, float* Vqsave, int n_atoms);
+int launch_unconcat(hipStream_t s, bool has_q, const float* xbar, int ldx, const float* Vsave, const float* Vqsave,
+                    const float* agh_a, const float* agh_q, float* Sbar, float* Sqbar, int n_atoms);
+int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, const float* a, const float* q,
+                    const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
+                    int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
+                    const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms);
+// stand-alone reference-op forms (conv_sv_2d_sp_wp.py:90-164)
+int launch_conv_sv_fwd(hipStream_t s, const float* a, const int* idx, const float* g, float* out, int B, int A, int G,
+                       int M);
+int launch_conv_sv_bwd(hipStream_t s, const float* grad_out, const float* a, const int* idx, const float* g,
+                       float* grad_a, float* grad_g, int B, int A, int G, int M);
+
+// ---- model.hip --------------------------------------------------------------------------------
+int launch_nse_fwd(hipStream_t s, const float* y, int ldy, const float* q_prev, const int* mol_start,
+                   const float* charge, int n_mol, float* q_new, float* Fm, float* Dm);
+int launch_update_a(hipStream_t s, const float* a, const float* y, int ldy, int n_atoms, float* a_new);
+int launch_head_last(hipStream_t s, const float* h, int ldh, const float* w, const float* b, int k, int n_atoms,
+                     float* e_atom);
+int launch_head_seed(hipStream_t s, const float* w, const float* d, int ldd, int k, int n_atoms, float* zbar);
+int launch_energy_reduce(hipStream_t s, const float* e_atom, const double* ecoul, const int* numbers,
+                         const double* sae, const int* mol_start, int n_mol, double* energy);
+struct CoulombParams {
+  float factor;      // 1/2 Hartree Bohr
+  float sr_rc;       // exp / cosine envelope radius (SRCoulomb)
+  int sr_envelope;   // 0 exp, 1 cosine
+  float dsf_rc, dsf_alpha;
+};
+// embedded SRCoulomb subtraction over the rc list (sets ecoul/qbar/fgrad/virial_atom)
+int launch_coulomb_sr(hipStream_t s, bool grad, bool stress, bool enabled, const float* q, const int* nb_idx,
+                      const int* nb_cnt, const float4* pg, int cap, CoulombParams cp, int n_atoms, double* ecoul,
+                      float* qbar, float* fgrad, float* virial_atom);
+int launch_coulomb_simple(hipStream_t s, bool grad, const float* q, const float* xw, const int* mol_idx,
+                          const int* mol_start, CoulombParams cp, int n_atoms, double* ecoul, float* qbar,
+                          float* fgrad);
+int launch_coulomb_dsf(hipStream_t s, bool grad, bool stress, const float* q, const float* xw, const int* mol_idx,
+                       const float* cell, int n_cell, const int* nb_idx, const int* nb_shift, const int* nb_cnt,
+                       int cap, CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad,
+                       float* virial_atom);
+int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, const float* Fm,
+                          const int* mol_start, int n_mol, float* Wbar);
+int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
+                      const float* Fm, const float* Dm, const float* Wbar, const int* mol_idx, int n_atoms, int n_feat,
+                      bool carry_q, float* zbar, float* qbar_next);
+int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
+                    const float* cell, int n_cell, int n_mol, int n_atoms, float* forces, float* stress);
+int launch_copy_f32(hipStream_t s, const float* src, float* dst, size_t n);
+
+}  // namespace aimnet

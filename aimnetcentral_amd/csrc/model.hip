@@ -1,0 +1,474 @@
+// model.hip - the small per-atom / per-molecule kernels around the GEMMs and convolutions.
+//
+// Reference semantics (paths relative to /root/reference/aimnet):
+//   nse_fwd         ops.nse ops.py:99-145 + AIMNet2._update_q models/aimnet2.py:122-139
+//   energy_reduce   AtomicShift + AtomicSum modules/core.py:71-111 (fp64 SAE, fp64 molecule sums)
+//   coulomb_sr      SRCoulomb / _calc_coulomb_sr modules/lr.py:21-62,986-1032 (exp_cutoff ops.py:88-90)
+//   coulomb_simple  LRCoulomb.coul_simple lr.py:311-331
+//   coulomb_dsf     LRCoulomb._coul_dsf_torch lr.py:559-615
+//   nse_bwd / build_zbar   adjoint of ops.nse
+//   finalize        forces = -dE/dx, stress = (dE/deps)/|det C| calculators/derivatives.py:118-137
+// Per-molecule reductions run one block per molecule in a fixed tree order (deterministic); pair
+// energies are accumulated in fp64 exactly where the reference does (lr.py:61,326,602,611).
+#include "common.h"
+#include "kernels.h"
+
+namespace aimnet {
+
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* sh) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  T r = 0;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int w = 0; w < nw; ++w) r += sh[w];
+  return r;
+}
+
+// ---- NSE forward -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nse_fwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ q_prev,
+                                                     const int* __restrict__ mol_start, const float* __restrict__ charge,
+                                                     float* __restrict__ q_new, float* __restrict__ Fm,
+                                                     float* __restrict__ Dm) {
+  __shared__ float sh[4];
+  const int m = blockIdx.x;
+  const int i0 = mol_start[m], i1 = mol_start[m + 1];
+  float sf = 0.f, sq = 0.f;
+  for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const float ft = y[(size_t)i * ldy + 1];
+    sf += ft * ft;
+    sq += (q_prev ? q_prev[i] : 0.0f) + y[(size_t)i * ldy];
+  }
+  const float F = block_sum(sf, sh) + 1.0e-6f;
+  const float D = charge[m] - block_sum(sq, sh);
+  if (threadIdx.x == 0) {
+    Fm[m] = F;
+    Dm[m] = D;
+  }
+  for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const float ft = y[(size_t)i * ldy + 1];
+    const float qr = (q_prev ? q_prev[i] : 0.0f) + y[(size_t)i * ldy];
+    q_new[i] = qr + (ft * ft) / F * D;
+  }
+}
+
+int launch_nse_fwd(hipStream_t s, const float* y, int ldy, const float* q_prev, const int* mol_start,
+                   const float* charge, int n_mol, float* q_new, float* Fm, float* Dm) {
+  hipLaunchKernelGGL(nse_fwd_kernel, dim3(n_mol), dim3(256), 0, s, y, ldy, q_prev, mol_start, charge, q_new, Fm, Dm);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void update_a_kernel(const float* __restrict__ a, const float* __restrict__ y, int ldy, int n_atoms,
+                                float* __restrict__ a_new) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)n_atoms * 256) return;
+  const size_t i = e >> 8;
+  const int k = (int)(e & 255);
+  a_new[e] = a[e] + y[i * ldy + 2 + k];
+}
+
+int launch_update_a(hipStream_t s, const float* a, const float* y, int ldy, int n_atoms, float* a_new) {
+  const size_t n = (size_t)n_atoms * 256;
+  hipLaunchKernelGGL(update_a_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, y, ldy, n_atoms, a_new);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- energy head last layer (k -> 1) and its adjoint seed ---------------------------------------
+__global__ void head_last_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ w,
+                                 const float* __restrict__ b, int k, int n_atoms, float* __restrict__ e_atom) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  float acc = 0.f;
+  for (int c = lane; c < k; c += 64) acc += h[(size_t)i * ldh + c] * w[c];
+  acc = wave_sum(acc);
+  if (lane == 0) e_atom[i] = acc + b[0];
+}
+
+int launch_head_last(hipStream_t s, const float* h, int ldh, const float* w, const float* b, int k, int n_atoms,
+                     float* e_atom) {
+  hipLaunchKernelGGL(head_last_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, h, ldh, w, b, k, n_atoms, e_atom);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void head_seed_kernel(const float* __restrict__ w, const float* __restrict__ d, int ldd, int k, int n_atoms,
+                                 float* __restrict__ zbar) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)n_atoms * ldd) return;
+  const int c = (int)(e % ldd);
+  zbar[e] = (c < k) ? w[c] * d[e] : 0.0f;
+}
+
+int launch_head_seed(hipStream_t s, const float* w, const float* d, int ldd, int k, int n_atoms, float* zbar) {
+  const size_t n = (size_t)n_atoms * ldd;
+  hipLaunchKernelGGL(head_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, d, ldd, k, n_atoms, zbar);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void energy_reduce_kernel(const float* __restrict__ e_atom,
+                                                           const double* __restrict__ ecoul,
+                                                           const int* __restrict__ numbers,
+                                                           const double* __restrict__ sae,
+                                                           const int* __restrict__ mol_start, double* __restrict__ energy) {
+  __shared__ double sh[4];
+  const int m = blockIdx.x;
+  const int i0 = mol_start[m], i1 = mol_start[m + 1];
+  double acc = 0.0;
+  for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const int z = min(63, max(0, numbers[i]));
+    acc += (double)e_atom[i] + sae[z] + ecoul[i];
+  }
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) energy[m] = r;
+}
+
+int launch_energy_reduce(hipStream_t s, const float* e_atom, const double* ecoul, const int* numbers,
+                         const double* sae, const int* mol_start, int n_mol, double* energy) {
+  hipLaunchKernelGGL(energy_reduce_kernel, dim3(n_mol), dim3(256), 0, s, e_atom, ecoul, numbers, sae, mol_start, energy);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- Coulomb pair kernels: one wave per centre atom, lanes over neighbours ------------------------
+// Common tail: E_i = sign k sum_m w q_i q_j (fp64 sum of fp32 pair terms), and for the full symmetric
+// list  dE/dq_i = sign 2k sum_m w q_j ,  dE/dx_i = -sign 2k sum_m w' q_i q_j u_im ,
+// dE/deps_ab += sign k sum_m w' q_i q_j r_a u_b  (ordered pairs, each once).
+struct PairAcc {
+  double e = 0.0;
+  float qb = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f;
+  float W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+template <bool GRAD, bool STRESS>
+__device__ __forceinline__ void pair_add(PairAcc& A, float w, float dw, float qi, float qj, float ux, float uy, float uz,
+                                         float d) {
+  const float qq = qi * qj;
+  A.e += (double)(w * qq);
+  if (GRAD) {
+    A.qb += w * qj;
+    const float t = dw * qq;
+    A.f0 += t * ux;
+    A.f1 += t * uy;
+    A.f2 += t * uz;
+    if (STRESS) {
+      const float rx = ux * d, ry = uy * d, rz = uz * d;
+      A.W[0] += rx * t * ux; A.W[1] += rx * t * uy; A.W[2] += rx * t * uz;
+      A.W[3] += ry * t * ux; A.W[4] += ry * t * uy; A.W[5] += ry * t * uz;
+      A.W[6] += rz * t * ux; A.W[7] += rz * t * uy; A.W[8] += rz * t * uz;
+    }
+  }
+}
+
+template <bool GRAD, bool STRESS, bool ACCUM>
+__device__ __forceinline__ void pair_store(PairAcc& A, int i, int lane, float sign_k, double e_extra, float qb_extra,
+                                           double* ecoul, float* qbar, float* fgrad, float* virial_atom) {
+  const double e = wave_sum(A.e);
+  float qb = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f;
+  if (GRAD) {
+    qb = wave_sum(A.qb);
+    f0 = wave_sum(A.f0);
+    f1 = wave_sum(A.f1);
+    f2 = wave_sum(A.f2);
+    if (STRESS) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) A.W[k] = wave_sum(A.W[k]);
+    }
+  }
+  if (lane == 0) {
+    const double ev = (double)sign_k * e + e_extra;
+    ecoul[i] = ACCUM ? ecoul[i] + ev : ev;
+    if (GRAD) {
+      const float qv = 2.0f * sign_k * qb + qb_extra;
+      qbar[i] = ACCUM ? qbar[i] + qv : qv;
+      const float g0 = -2.0f * sign_k * f0, g1 = -2.0f * sign_k * f1, g2 = -2.0f * sign_k * f2;
+      fgrad[3 * i + 0] = ACCUM ? fgrad[3 * i + 0] + g0 : g0;
+      fgrad[3 * i + 1] = ACCUM ? fgrad[3 * i + 1] + g1 : g1;
+      fgrad[3 * i + 2] = ACCUM ? fgrad[3 * i + 2] + g2 : g2;
+    }
+  }
+  if (GRAD && STRESS && lane < 9) {
+    float v = A.W[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) v = (lane == k) ? A.W[k] : v;
+    v *= sign_k;
+    virial_atom[(size_t)i * 9 + lane] = ACCUM ? virial_atom[(size_t)i * 9 + lane] + v : v;
+  }
+}
+
+// embedded short-range Coulomb, SUBTRACTED (sign -1); also initialises the adjoint buffers
+template <bool GRAD, bool STRESS>
+__global__ __launch_bounds__(256) void coulomb_sr_kernel(bool enabled, const float* __restrict__ q,
+                                                        const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
+                                                        const float4* __restrict__ pg, int cap, CoulombParams cp,
+                                                        int n_atoms, double* __restrict__ ecoul, float* __restrict__ qbar,
+                                                        float* __restrict__ fgrad, float* __restrict__ virial_atom) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  PairAcc A;
+  if (enabled) {
+    const int cnt = nb_cnt[i];
+    const float qi = q[i];
+    for (int m = lane; m < cnt; m += 64) {
+      const size_t p = (size_t)i * cap + m;
+      const float4 u = pg[p];
+      const float d = u.w;
+      float fc, dfc;
+      if (cp.sr_envelope == 0) {
+        const float tr = d / cp.sr_rc;
+        const float t = fminf(fmaxf(tr, 0.0f), 1.0f - 1e-6f);
+        const float om = 1.0f - t * t;
+        fc = expf(-1.0f / om) / 0.36787944117144233f;
+        dfc = (tr < 1.0f - 1e-6f) ? fc * (-2.0f * t / (om * om)) / cp.sr_rc : 0.0f;
+      } else {
+        const float dc = fminf(fmaxf(d, 1e-6f), cp.sr_rc);
+        const float w = 3.14159265358979323846f / cp.sr_rc;
+        fc = 0.5f * (cosf(dc * w) + 1.0f);
+        dfc = (d > 1e-6f && d < cp.sr_rc) ? -0.5f * w * sinf(dc * w) : 0.0f;
+      }
+      const float inv = 1.0f / d;
+      pair_add<GRAD, STRESS>(A, fc * inv, dfc * inv - fc * inv * inv, qi, q[nb_idx[p]], u.x, u.y, u.z, d);
+    }
+  }
+  pair_store<GRAD, STRESS, false>(A, i, lane, -cp.factor, 0.0, 0.0f, ecoul, qbar, fgrad, virial_atom);
+}
+
+int launch_coulomb_sr(hipStream_t s, bool grad, bool stress, bool enabled, const float* q, const int* nb_idx,
+                      const int* nb_cnt, const float4* pg, int cap, CoulombParams cp, int n_atoms, double* ecoul,
+                      float* qbar, float* fgrad, float* virial_atom) {
+  dim3 grid(ceil_div(n_atoms, 4)), block(256);
+  if (grad && stress)
+    hipLaunchKernelGGL((coulomb_sr_kernel<true, true>), grid, block, 0, s, enabled, q, nb_idx, nb_cnt, pg, cap, cp, n_atoms,
+                       ecoul, qbar, fgrad, virial_atom);
+  else if (grad)
+    hipLaunchKernelGGL((coulomb_sr_kernel<true, false>), grid, block, 0, s, enabled, q, nb_idx, nb_cnt, pg, cap, cp, n_atoms,
+                       ecoul, qbar, fgrad, virial_atom);
+  else
+    hipLaunchKernelGGL((coulomb_sr_kernel<false, false>), grid, block, 0, s, enabled, q, nb_idx, nb_cnt, pg, cap, cp,
+                       n_atoms, ecoul, qbar, fgrad, virial_atom);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// "simple": every other atom of the same molecule, w = 1/d
+template <bool GRAD>
+__global__ __launch_bounds__(256) void coulomb_simple_kernel(const float* __restrict__ q, const float* __restrict__ xw,
+                                                            const int* __restrict__ mol_idx,
+                                                            const int* __restrict__ mol_start, CoulombParams cp,
+                                                            int n_atoms, double* __restrict__ ecoul,
+                                                            float* __restrict__ qbar, float* __restrict__ fgrad) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const int m = mol_idx[i];
+  const int j0 = mol_start[m], j1 = mol_start[m + 1];
+  const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2], qi = q[i];
+  PairAcc A;
+  for (int j = j0 + lane; j < j1; j += 64) {
+    if (j == i) continue;
+    const float rx = xw[3 * j] - xi, ry = xw[3 * j + 1] - yi, rz = xw[3 * j + 2] - zi;
+    const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+    const float inv = 1.0f / d;
+    pair_add<GRAD, false>(A, inv, -inv * inv, qi, q[j], rx * inv, ry * inv, rz * inv, d);
+  }
+  pair_store<GRAD, false, true>(A, i, lane, cp.factor, 0.0, 0.0f, ecoul, qbar, fgrad, nullptr);
+}
+
+int launch_coulomb_simple(hipStream_t s, bool grad, const float* q, const float* xw, const int* mol_idx,
+                          const int* mol_start, CoulombParams cp, int n_atoms, double* ecoul, float* qbar,
+                          float* fgrad) {
+  dim3 grid(ceil_div(n_atoms, 4)), block(256);
+  if (grad)
+    hipLaunchKernelGGL(coulomb_simple_kernel<true>, grid, block, 0, s, q, xw, mol_idx, mol_start, cp, n_atoms, ecoul, qbar,
+                       fgrad);
+  else
+    hipLaunchKernelGGL(coulomb_simple_kernel<false>, grid, block, 0, s, q, xw, mol_idx, mol_start, cp, n_atoms, ecoul, qbar,
+                       fgrad);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// DSF over the long-range neighbour matrix, plus the self term -2k (erfc(a Rc)/(2 Rc) + a/sqrt(pi)) q_i^2
+template <bool GRAD, bool STRESS>
+__global__ __launch_bounds__(256) void coulomb_dsf_kernel(const float* __restrict__ q, const float* __restrict__ xw,
+                                                         const int* __restrict__ mol_idx, const float* __restrict__ cell,
+                                                         int n_cell, const int* __restrict__ nb_idx,
+                                                         const int* __restrict__ nb_shift, const int* __restrict__ nb_cnt,
+                                                         int cap, CoulombParams cp, int n_atoms,
+                                                         double* __restrict__ ecoul, float* __restrict__ qbar,
+                                                         float* __restrict__ fgrad, float* __restrict__ virial_atom) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const float al = cp.dsf_alpha, Rc = cp.dsf_rc;
+  const float two_a_sqrtpi = 2.0f * al * 0.56418958354775629f;
+  const float erfc_rc = erfcf(al * Rc);
+  const float sv = erfc_rc / Rc;
+  const float slope = erfc_rc / (Rc * Rc) + two_a_sqrtpi * expf(-al * al * Rc * Rc) / Rc;
+  const float* c = cell ? cell + (n_cell == 1 ? 0 : (size_t)mol_idx[i] * 9) : nullptr;
+  const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2], qi = q[i];
+  const int cnt = nb_cnt[i];
+  PairAcc A;
+  for (int m = lane; m < cnt; m += 64) {
+    const size_t p = (size_t)i * cap + m;
+    const int j = nb_idx[p];
+    float rx = xw[3 * j] - xi, ry = xw[3 * j + 1] - yi, rz = xw[3 * j + 2] - zi;
+    if (c) {
+      int sx, sy, sz;
+      unpack_shift(nb_shift[p], sx, sy, sz);
+      rx += sx * c[0] + sy * c[3] + sz * c[6];
+      ry += sx * c[1] + sy * c[4] + sz * c[7];
+      rz += sx * c[2] + sy * c[5] + sz * c[8];
+    }
+    const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+    if (!(d < Rc)) continue;
+    const float inv = 1.0f / d;
+    const float ec = erfcf(al * d);
+    const float w = ec * inv - sv + (d - Rc) * slope;
+    const float dw = -ec * inv * inv - two_a_sqrtpi * expf(-al * al * d * d) * inv + slope;
+    pair_add<GRAD, STRESS>(A, w, dw, qi, q[j], rx * inv, ry * inv, rz * inv, d);
+  }
+  const float cs = -(sv * 0.5f + al * 0.56418958354775629f);
+  const double e_self = 2.0 * (double)cp.factor * (double)(cs * qi * qi);
+  const float qb_self = 4.0f * cp.factor * cs * qi;
+  pair_store<GRAD, STRESS, true>(A, i, lane, cp.factor, e_self, qb_self, ecoul, qbar, fgrad, virial_atom);
+}
+
+int launch_coulomb_dsf(hipStream_t s, bool grad, bool stress, const float* q, const float* xw, const int* mol_idx,
+                       const float* cell, int n_cell, const int* nb_idx, const int* nb_shift, const int* nb_cnt,
+                       int cap, CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad,
+                       float* virial_atom) {
+  dim3 grid(ceil_div(n_atoms, 4)), block(256);
+  if (grad && stress)
+    hipLaunchKernelGGL((coulomb_dsf_kernel<true, true>), grid, block, 0, s, q, xw, mol_idx, cell, n_cell, nb_idx, nb_shift,
+                       nb_cnt, cap, cp, n_atoms, ecoul, qbar, fgrad, virial_atom);
+  else if (grad)
+    hipLaunchKernelGGL((coulomb_dsf_kernel<true, false>), grid, block, 0, s, q, xw, mol_idx, cell, n_cell, nb_idx, nb_shift,
+                       nb_cnt, cap, cp, n_atoms, ecoul, qbar, fgrad, virial_atom);
+  else
+    hipLaunchKernelGGL((coulomb_dsf_kernel<false, false>), grid, block, 0, s, q, xw, mol_idx, cell, n_cell, nb_idx, nb_shift,
+                       nb_cnt, cap, cp, n_atoms, ecoul, qbar, fgrad, virial_atom);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- NSE backward --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nse_bwd_reduce_kernel(const float* __restrict__ qbar, const float* __restrict__ y,
+                                                            int ldy, const float* __restrict__ Fm,
+                                                            const int* __restrict__ mol_start, float* __restrict__ Wbar) {
+  __shared__ float sh[4];
+  const int m = blockIdx.x;
+  const int i0 = mol_start[m], i1 = mol_start[m + 1];
+  float acc = 0.f;
+  for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const float ft = y[(size_t)i * ldy + 1];
+    acc += qbar[i] * (ft * ft);
+  }
+  const float r = block_sum(acc, sh);
+  if (threadIdx.x == 0) Wbar[m] = r / Fm[m];
+}
+
+int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, const float* Fm,
+                          const int* mol_start, int n_mol, float* Wbar) {
+  hipLaunchKernelGGL(nse_bwd_reduce_kernel, dim3(n_mol), dim3(256), 0, s, qbar, y, ldy, Fm, mol_start, Wbar);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// zbar[i] = adjoint of the LAST linear layer's pre-activation of this pass' MLP:
+//   ybar = [q~bar, f~bar, delta_a bar(n_feat)], times GELU'(z_last) when the MLP ends with GELU.
+__global__ void build_zbar_kernel(const float* __restrict__ qbar, const float* __restrict__ abar,
+                                  const float* __restrict__ y, int ldy, const float* __restrict__ dlast,
+                                  const float* __restrict__ Fm, const float* __restrict__ Dm,
+                                  const float* __restrict__ Wbar, const int* __restrict__ mol_idx, int n_atoms, int n_feat,
+                                  int carry_q, float* __restrict__ zbar, float* __restrict__ qbar_next) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const int m = mol_idx[i];
+  const float qr = qbar[i] - Wbar[m];
+  const float ft = y[(size_t)i * ldy + 1];
+  const float ftb = 2.0f * ft * (Dm[m] / Fm[m]) * qr;
+  float* zr = zbar + (size_t)i * ldy;
+  const float* dr = dlast ? dlast + (size_t)i * ldy : nullptr;
+  for (int c = lane; c < ldy; c += 64) {
+    float v;
+    if (c == 0) v = qr;
+    else if (c == 1) v = ftb;
+    else if (c < 2 + n_feat) v = abar[(size_t)i * n_feat + c - 2];
+    else v = 0.0f;
+    if (dr && c < 2 + n_feat) v *= dr[c];
+    zr[c] = v;
+  }
+  if (lane == 0) qbar_next[i] = carry_q ? qr : 0.0f;
+}
+
+int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
+                      const float* Fm, const float* Dm, const float* Wbar, const int* mol_idx, int n_atoms, int n_feat,
+                      bool carry_q, float* zbar, float* qbar_next) {
+  hipLaunchKernelGGL(build_zbar_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, qbar, abar, y, ldy, dlast, Fm, Dm, Wbar,
+                     mol_idx, n_atoms, n_feat, carry_q ? 1 : 0, zbar, qbar_next);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- outputs -------------------------------------------------------------------------------------
+__global__ void forces_kernel(const float* __restrict__ fgrad, int n3, float* __restrict__ forces) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n3) forces[e] = -fgrad[e];
+}
+
+__global__ __launch_bounds__(256) void stress_kernel(const float* __restrict__ virial_atom,
+                                                    const int* __restrict__ mol_start, const float* __restrict__ cell,
+                                                    int n_cell, int n_mol, float* __restrict__ stress) {
+  __shared__ double sh[4];
+  // one block per output system; a single shared cell (n_cell == 1) sums over all molecules
+  const int sidx = blockIdx.x;
+  const int i0 = (n_cell == 1) ? mol_start[0] : mol_start[sidx];
+  const int i1 = (n_cell == 1) ? mol_start[n_mol] : mol_start[sidx + 1];
+  const float* c = cell + (size_t)sidx * 9;
+  const double det = (double)c[0] * ((double)c[4] * c[8] - (double)c[5] * c[7]) -
+                     (double)c[1] * ((double)c[3] * c[8] - (double)c[5] * c[6]) +
+                     (double)c[2] * ((double)c[3] * c[7] - (double)c[4] * c[6]);
+  const double vol = fabs(det);
+  for (int k = 0; k < 9; ++k) {
+    double acc = 0.0;
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) acc += (double)virial_atom[(size_t)i * 9 + k];
+    const double r = block_sum(acc, sh);
+    if (threadIdx.x == 0) stress[(size_t)sidx * 9 + k] = (float)(r / vol);
+  }
+}
+
+int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
+                    const float* cell, int n_cell, int n_mol, int n_atoms, float* forces, float* stress) {
+  if (forces) {
+    hipLaunchKernelGGL(forces_kernel, dim3(ceil_div(3 * n_atoms, 256)), dim3(256), 0, s, fgrad, 3 * n_atoms, forces);
+    AIMNET_LAUNCH_CHECK();
+  }
+  if (stress && cell) {
+    hipLaunchKernelGGL(stress_kernel, dim3(n_cell), dim3(256), 0, s, virial_atom, mol_start, cell, n_cell, n_mol, stress);
+    AIMNET_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+__global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) dst[e] = src[e];
+}
+
+int launch_copy_f32(hipStream_t s, const float* src, float* dst, size_t n) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace aimnet

@@ -1,0 +1,419 @@
+// nlist.hip - full (both-direction) neighbour matrices on gfx950.
+//
+// Replaces nvalchemiops.torch.neighbors.neighbor_list as the reference calls it
+// (aimnet/calculators/neighbors.py:106-125: half_fill=False, same-batch pairs only, rows packed
+// real-first, integer PBC shifts, overflow reported) and move_coord_to_cell (neighbors.py:331-381).
+//
+//   non-periodic : one wave per atom scans its own molecule (atoms of a molecule are contiguous).
+//   periodic     : per-system cell list.  bins along lattice axis k are slabs of the fractional
+//                  coordinate, at least cutoff/bin_sub thick in perpendicular distance; the search
+//                  range R_k = ceil(cutoff / slab thickness) also covers cells smaller than the
+//                  cutoff (several images of the same atom, self images included).
+// Pair vectors are always formed as (x_j - x_i) + s.C so that (i,j,s) and (j,i,-s) evaluate to
+// exactly opposite vectors: the list is exactly symmetric, which the centre-major backward relies on.
+// Row order is deterministic: bins are traversed in a fixed order and each bin is sorted by atom id.
+#include "common.h"
+#include "kernels.h"
+
+namespace aimnet {
+
+struct NlistSystem {
+  float c[9];    // cell row vectors
+  float inv[9];  // inverse: frac = x . inv
+  float h[3];    // perpendicular heights
+  int per[3];
+  int nb[3];
+  int R[3];
+  int bin_offset;
+  int n_bins;
+};
+
+size_t nlist_scratch_bytes(int n_atoms, int n_mol) {
+  const size_t max_bins = (size_t)n_atoms + 8 * (size_t)n_mol + 8;
+  size_t b = 0;
+  b += align_up((size_t)(n_mol + 1) * sizeof(int), 256);
+  b += align_up((size_t)n_atoms * 3 * sizeof(float), 256);
+  b += align_up((size_t)n_mol * sizeof(NlistSystem), 256);
+  b += align_up((size_t)n_atoms * sizeof(int), 256);        // atom_bin
+  b += 3 * align_up((max_bins + 1) * sizeof(int), 256);     // count, start, fill
+  b += 2 * align_up((size_t)n_atoms * sizeof(int), 256);    // sorted_tmp, sorted
+  return b;
+}
+
+size_t nlist_xw_offset(int n_mol) { return align_up((size_t)(n_mol + 1) * sizeof(int), 256); }
+
+void nlist_carve(NlistBuffers& b, char* p, int n_atoms, int n_mol) {
+  const size_t max_bins = (size_t)n_atoms + 8 * (size_t)n_mol + 8;
+  auto take = [&](size_t bytes) {
+    char* r = p;
+    p += align_up(bytes, 256);
+    return r;
+  };
+  b.mol_start = (int*)take((size_t)(n_mol + 1) * sizeof(int));
+  b.xw = (float*)take((size_t)n_atoms * 3 * sizeof(float));
+  b.sys = (void*)take((size_t)n_mol * sizeof(NlistSystem));
+  b.atom_bin = (int*)take((size_t)n_atoms * sizeof(int));
+  b.bin_count = (int*)take((max_bins + 1) * sizeof(int));
+  b.bin_start = (int*)take((max_bins + 1) * sizeof(int));
+  b.bin_fill = (int*)take((max_bins + 1) * sizeof(int));
+  b.sorted_tmp = (int*)take((size_t)n_atoms * sizeof(int));
+  b.sorted = (int*)take((size_t)n_atoms * sizeof(int));
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void mol_start_kernel(const int* __restrict__ mol_idx, int n_atoms, int n_mol, int* __restrict__ mol_start) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  const int prev = (i == 0) ? -1 : mol_idx[i - 1];
+  const int cur = mol_idx[i];
+  for (int m = prev + 1; m <= cur && m <= n_mol; ++m) mol_start[m] = i;
+  if (i == n_atoms - 1)
+    for (int m = cur + 1; m <= n_mol; ++m) mol_start[m] = n_atoms;
+}
+
+int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start) {
+  hipLaunchKernelGGL(mol_start_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, mol_idx, n_atoms, n_mol, mol_start);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void cell_setup_kernel(const float* __restrict__ cell, int n_cell, int n_mol, int p0, int p1, int p2,
+                                  NlistSystem* __restrict__ sys) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_mol) return;
+  const float* c = cell + (n_cell == 1 ? 0 : (size_t)s * 9);
+  NlistSystem S;
+  double m[9];
+  for (int k = 0; k < 9; ++k) {
+    S.c[k] = c[k];
+    m[k] = c[k];
+  }
+  const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+                     m[2] * (m[3] * m[7] - m[4] * m[6]);
+  const double id = 1.0 / det;
+  double inv[9];
+  inv[0] = (m[4] * m[8] - m[5] * m[7]) * id;
+  inv[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+  inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+  inv[3] = (m[5] * m[6] - m[3] * m[8]) * id;
+  inv[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+  inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  inv[6] = (m[3] * m[7] - m[4] * m[6]) * id;
+  inv[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+  inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+  for (int k = 0; k < 9; ++k) S.inv[k] = (float)inv[k];
+  for (int k = 0; k < 3; ++k) {
+    const double* a1 = m + 3 * ((k + 1) % 3);
+    const double* a2 = m + 3 * ((k + 2) % 3);
+    const double cx = a1[1] * a2[2] - a1[2] * a2[1];
+    const double cy = a1[2] * a2[0] - a1[0] * a2[2];
+    const double cz = a1[0] * a2[1] - a1[1] * a2[0];
+    S.h[k] = (float)(fabs(det) / sqrt(cx * cx + cy * cy + cz * cz));
+    S.nb[k] = 1;
+    S.R[k] = 0;
+  }
+  S.per[0] = p0;
+  S.per[1] = p1;
+  S.per[2] = p2;
+  S.bin_offset = 0;
+  S.n_bins = 1;
+  sys[s] = S;
+}
+
+__global__ void wrap_kernel(const float* __restrict__ coord, const int* __restrict__ mol_idx, int n_atoms,
+                            const NlistSystem* __restrict__ sys, float* __restrict__ xw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  const float x = coord[3 * i], y = coord[3 * i + 1], z = coord[3 * i + 2];
+  if (sys == nullptr) {
+    xw[3 * i] = x;
+    xw[3 * i + 1] = y;
+    xw[3 * i + 2] = z;
+    return;
+  }
+  const NlistSystem& S = sys[mol_idx[i]];
+  float f[3];
+  for (int k = 0; k < 3; ++k) {
+    f[k] = x * S.inv[k] + y * S.inv[3 + k] + z * S.inv[6 + k];
+    if (S.per[k]) {
+      f[k] -= floorf(f[k]);
+      if (f[k] >= 1.0f) f[k] = 0.0f;
+    }
+  }
+  for (int k = 0; k < 3; ++k) xw[3 * i + k] = f[0] * S.c[k] + f[1] * S.c[3 + k] + f[2] * S.c[6 + k];
+}
+
+int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
+                int n_cell, const int pbc[3], NlistBuffers& b) {
+  NlistSystem* sys = nullptr;
+  if (cell != nullptr) {
+    sys = (NlistSystem*)b.sys;
+    hipLaunchKernelGGL(cell_setup_kernel, dim3(ceil_div(n_mol, 64)), dim3(64), 0, s, cell, n_cell, n_mol, pbc[0], pbc[1],
+                       pbc[2], sys);
+    AIMNET_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(wrap_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, coord, mol_idx, n_atoms, sys, b.xw);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// non-periodic: one wave per atom, lanes over the atoms of the same molecule
+__global__ __launch_bounds__(256) void nlist_brute_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
+                                                         const int* __restrict__ mol_start, int n_atoms, float cutoff2,
+                                                         int cap, int fill_value, int fill_rows, int* __restrict__ nb_idx,
+                                                         int* __restrict__ nb_cnt, int* __restrict__ status_max,
+                                                         int* __restrict__ status_ovf) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int m = mol_idx[i];
+  const int j0 = mol_start[m], j1 = mol_start[m + 1];
+  const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2];
+  int* row = nb_idx + (size_t)i * cap;
+  int count = 0;
+  for (int base = j0; base < j1; base += 64) {
+    const int j = base + lane;
+    bool ok = false;
+    if (j < j1 && j != i) {
+      const float dx = xw[3 * j] - xi, dy = xw[3 * j + 1] - yi, dz = xw[3 * j + 2] - zi;
+      ok = (dx * dx + dy * dy + dz * dz) < cutoff2;
+    }
+    const unsigned long long mask = __ballot(ok);
+    const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+    if (ok && pos < cap) row[pos] = j;
+    count += __popcll(mask);
+  }
+  if (fill_rows)
+    for (int p = min(count, cap) + lane; p < cap; p += 64) row[p] = fill_value;
+  if (lane == 0) {
+    nb_cnt[i] = min(count, cap);
+    atomicMax(status_max, count);
+    if (count > cap) atomicMax(status_ovf, 1);
+  }
+}
+
+// periodic: choose the bin grid of every system for this cutoff, then a serial prefix of bin offsets
+__global__ void bins_setup_kernel(NlistSystem* __restrict__ sys, const int* __restrict__ mol_start, int n_mol,
+                                  float cutoff, int bin_sub) {
+  const float w = cutoff / (float)bin_sub;
+  for (int s = threadIdx.x; s < n_mol; s += blockDim.x) {
+    NlistSystem S = sys[s];
+    const int ns = mol_start[s + 1] - mol_start[s];
+    const long cap_bins = (long)ns + 8;
+    int nb[3];
+    for (int k = 0; k < 3; ++k) nb[k] = max(1, min(1024, (int)floorf(S.h[k] / w)));
+    while ((long)nb[0] * nb[1] * nb[2] > cap_bins) {
+      const float f = cbrtf((float)cap_bins / (float)((long)nb[0] * nb[1] * nb[2]));
+      int big = 0;
+      for (int k = 0; k < 3; ++k) {
+        const int t = max(1, (int)floorf(nb[k] * f));
+        if (nb[k] > nb[big]) big = k;
+        nb[k] = t;
+      }
+      if ((long)nb[0] * nb[1] * nb[2] > cap_bins && nb[big] > 1) nb[big] -= 1;
+    }
+    for (int k = 0; k < 3; ++k) {
+      S.nb[k] = nb[k];
+      const float thick = S.h[k] / (float)nb[k];
+      int R = (int)ceilf(cutoff / thick);
+      if (!S.per[k]) R = min(R, nb[k] - 1);
+      S.R[k] = min(R, 120);
+    }
+    S.n_bins = nb[0] * nb[1] * nb[2];
+    sys[s] = S;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int off = 0;
+    for (int s = 0; s < n_mol; ++s) {
+      sys[s].bin_offset = off;
+      off += sys[s].n_bins;
+    }
+  }
+}
+
+__device__ __forceinline__ int bin_of(const NlistSystem& S, float x, float y, float z, int b[3]) {
+  for (int k = 0; k < 3; ++k) {
+    const float f = x * S.inv[k] + y * S.inv[3 + k] + z * S.inv[6 + k];
+    b[k] = max(0, min(S.nb[k] - 1, (int)floorf(f * (float)S.nb[k])));
+  }
+  return S.bin_offset + (b[0] * S.nb[1] + b[1]) * S.nb[2] + b[2];
+}
+
+__global__ void bin_count_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx, int n_atoms,
+                                 const NlistSystem* __restrict__ sys, int* __restrict__ atom_bin,
+                                 int* __restrict__ bin_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  int b[3];
+  const int bin = bin_of(sys[mol_idx[i]], xw[3 * i], xw[3 * i + 1], xw[3 * i + 2], b);
+  atom_bin[i] = bin;
+  atomicAdd(&bin_count[bin], 1);
+}
+
+// single-block exclusive scan (n <= a few million): each thread owns a contiguous chunk
+__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ in, int* __restrict__ out, int n) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int chunk = (n + 1023) / 1024;
+  const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
+  int s = 0;
+  for (int k = lo; k < hi; ++k) s += in[k];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = (t == 0) ? 0 : part[t - 1];
+  for (int k = lo; k < hi; ++k) {
+    out[k] = run;
+    run += in[k];
+  }
+  if (t == 1023) out[n] = part[1023];
+}
+
+__global__ void bin_fill_kernel(const int* __restrict__ atom_bin, const int* __restrict__ bin_start, int n_atoms,
+                                int* __restrict__ bin_fill, int* __restrict__ sorted_tmp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  const int bin = atom_bin[i];
+  const int p = atomicAdd(&bin_fill[bin], 1);
+  sorted_tmp[bin_start[bin] + p] = i;
+}
+
+// order every bin by atom id (rank by counting; bins hold tens of atoms): one wave per bin
+__global__ __launch_bounds__(256) void bin_sort_kernel(const int* __restrict__ bin_start, int n_bins,
+                                                      const int* __restrict__ sorted_tmp, int* __restrict__ sorted) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= n_bins) return;
+  const int s0 = bin_start[b], n = bin_start[b + 1] - s0;
+  for (int e = lane; e < n; e += 64) {
+    const int v = sorted_tmp[s0 + e];
+    int rank = 0;
+    for (int f = 0; f < n; ++f) rank += (sorted_tmp[s0 + f] < v) ? 1 : 0;
+    sorted[s0 + rank] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
+                                                        const NlistSystem* __restrict__ sys,
+                                                        const int* __restrict__ bin_start, const int* __restrict__ sorted,
+                                                        int n_atoms, float cutoff2, int cap, int fill_value,
+                                                        int fill_rows, int* __restrict__ nb_idx,
+                                                        int* __restrict__ nb_shift, int* __restrict__ nb_cnt,
+                                                        int* __restrict__ status_max, int* __restrict__ status_ovf) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const NlistSystem& S = sys[mol_idx[i]];
+  const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2];
+  int bi[3];
+  bin_of(S, xi, yi, zi, bi);
+  int* row = nb_idx + (size_t)i * cap;
+  int* rsh = nb_shift + (size_t)i * cap;
+  int count = 0;
+  for (int dx = -S.R[0]; dx <= S.R[0]; ++dx) {
+    int bx = bi[0] + dx, sx = 0;
+    if (S.per[0]) {
+      sx = (bx >= 0) ? bx / S.nb[0] : -((-bx + S.nb[0] - 1) / S.nb[0]);
+      bx -= sx * S.nb[0];
+    } else if (bx < 0 || bx >= S.nb[0]) {
+      continue;
+    }
+    for (int dy = -S.R[1]; dy <= S.R[1]; ++dy) {
+      int by = bi[1] + dy, sy = 0;
+      if (S.per[1]) {
+        sy = (by >= 0) ? by / S.nb[1] : -((-by + S.nb[1] - 1) / S.nb[1]);
+        by -= sy * S.nb[1];
+      } else if (by < 0 || by >= S.nb[1]) {
+        continue;
+      }
+      for (int dz = -S.R[2]; dz <= S.R[2]; ++dz) {
+        int bz = bi[2] + dz, sz = 0;
+        if (S.per[2]) {
+          sz = (bz >= 0) ? bz / S.nb[2] : -((-bz + S.nb[2] - 1) / S.nb[2]);
+          bz -= sz * S.nb[2];
+        } else if (bz < 0 || bz >= S.nb[2]) {
+          continue;
+        }
+        const int bin = S.bin_offset + (bx * S.nb[1] + by) * S.nb[2] + bz;
+        const float ox = sx * S.c[0] + sy * S.c[3] + sz * S.c[6];
+        const float oy = sx * S.c[1] + sy * S.c[4] + sz * S.c[7];
+        const float oz = sx * S.c[2] + sy * S.c[5] + sz * S.c[8];
+        const bool self_image = (sx == 0 && sy == 0 && sz == 0);
+        const int code = pack_shift(sx, sy, sz);
+        const int s0 = bin_start[bin], s1 = bin_start[bin + 1];
+        for (int base = s0; base < s1; base += 64) {
+          const int e = base + lane;
+          bool ok = false;
+          int j = 0;
+          if (e < s1) {
+            j = sorted[e];
+            const float rx = (xw[3 * j] - xi) + ox, ry = (xw[3 * j + 1] - yi) + oy, rz = (xw[3 * j + 2] - zi) + oz;
+            ok = (rx * rx + ry * ry + rz * rz) < cutoff2 && !(self_image && j == i);
+          }
+          const unsigned long long mask = __ballot(ok);
+          const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+          if (ok && pos < cap) {
+            row[pos] = j;
+            rsh[pos] = code;
+          }
+          count += __popcll(mask);
+        }
+      }
+    }
+  }
+  if (fill_rows)
+    for (int p = min(count, cap) + lane; p < cap; p += 64) {
+      row[p] = fill_value;
+      rsh[p] = 0;
+    }
+  if (lane == 0) {
+    nb_cnt[i] = min(count, cap);
+    atomicMax(status_max, count);
+    if (count > cap) atomicMax(status_ovf, 1);
+  }
+}
+
+int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, const float* cell, int n_cell,
+                 const int pbc[3], float cutoff, int bin_sub, int cap, int fill_value, int fill_rows,
+                 NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf) {
+  (void)n_cell;
+  (void)pbc;
+  const float c2 = cutoff * cutoff;
+  if (cell == nullptr) {
+    hipLaunchKernelGGL(nlist_brute_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, b.mol_start, n_atoms,
+                       c2, cap, fill_value, fill_rows, nb_idx, nb_cnt, status_max, status_ovf);
+    AIMNET_LAUNCH_CHECK();
+    return 0;
+  }
+  NlistSystem* sys = (NlistSystem*)b.sys;
+  const int max_bins = n_atoms + 8 * n_mol + 8;
+  hipLaunchKernelGGL(bins_setup_kernel, dim3(1), dim3(256), 0, s, sys, b.mol_start, n_mol, cutoff, bin_sub);
+  AIMNET_LAUNCH_CHECK();
+  AIMNET_HIP_CHECK(hipMemsetAsync(b.bin_count, 0, (size_t)(max_bins + 1) * sizeof(int), s));
+  AIMNET_HIP_CHECK(hipMemsetAsync(b.bin_fill, 0, (size_t)(max_bins + 1) * sizeof(int), s));
+  hipLaunchKernelGGL(bin_count_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.xw, mol_idx, n_atoms, sys,
+                     b.atom_bin, b.bin_count);
+  AIMNET_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, b.bin_count, b.bin_start, max_bins);
+  AIMNET_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bin_fill_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.atom_bin, b.bin_start, n_atoms,
+                     b.bin_fill, b.sorted_tmp);
+  AIMNET_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bin_sort_kernel, dim3(ceil_div(max_bins, 4)), dim3(256), 0, s, b.bin_start, max_bins, b.sorted_tmp,
+                     b.sorted);
+  AIMNET_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nlist_cell_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, sys, b.bin_start,
+                     b.sorted, n_atoms, c2, cap, fill_value, fill_rows, nb_idx, nb_shift, nb_cnt, status_max, status_ovf);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace aimnet

@@ -1,0 +1,298 @@
+"""HipEngine: thin Python owner of one `aimnet_engine` handle (include/aimnet_hip.h).
+
+PyTorch-ROCm tensors are used purely as device buffers (`data_ptr()`), the HIP stream is torch's
+current stream; there is no autograd and no torch compute on the hot path.  One engine per
+device; not re-entrant (same contract as the reference calculator, calculator.py:283-328).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Any
+
+import numpy as np
+
+from . import _lib
+
+_DTYPES = {4: "float32", 8: "float64"}
+_INT_VIEWS = {"nb_idx", "nb_shift", "nb_cnt", "lr_idx", "lr_shift", "lr_cnt"}
+
+
+def _round16(n: int) -> int:
+    return ((int(n) + 15) // 16) * 16
+
+
+@dataclass
+class ModelSpec:
+    """Architecture + host weights of one AIMNet2 core model (built by loader.py / synth.py)."""
+
+    nfeature: int
+    nshifts: int
+    ncomb_v: int
+    mlp_dims: list[list[int]]          # per pass: [n_in, hidden..., n_out]
+    last_linear: list[bool]
+    head_dims: list[int]
+    rc: float
+    eta: float
+    shifts: list[float]
+    sr_coulomb: bool
+    sr_envelope: str
+    sr_rc: float
+    weights: dict[str, np.ndarray] = field(repr=False, default_factory=dict)  # state-dict keys
+    metadata: dict[str, Any] = field(default_factory=dict)
+
+
+class HipEngine:
+    def __init__(self, spec: ModelSpec, device: str | int = 0):
+        import torch
+
+        self.spec = spec
+        self.lib = _lib.load()  # raises HipLibraryError when the .so is missing: no fallback
+        if not torch.cuda.is_available():
+            raise _lib.HipLibraryError("HipEngine needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if self.device.type != "cuda":
+            raise _lib.HipLibraryError(f"HipEngine device must be a GPU, got {self.device}")
+        self.dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._keep: list[np.ndarray] = []
+        arch = _lib.Arch()
+        arch.nfeature, arch.nshifts, arch.ncomb_v = spec.nfeature, spec.nshifts, spec.ncomb_v
+        arch.n_pass = len(spec.mlp_dims)
+        for p, dims in enumerate(spec.mlp_dims):
+            arch.n_layers[p] = len(dims) - 1
+            for k, d in enumerate(dims):
+                arch.layer_dims[p][k] = d
+            arch.last_linear[p] = 1 if spec.last_linear[p] else 0
+        arch.head_n_layers = len(spec.head_dims) - 1
+        for k, d in enumerate(spec.head_dims):
+            arch.head_dims[k] = d
+        arch.rc, arch.eta = float(spec.rc), float(spec.eta)
+        for g, s in enumerate(spec.shifts):
+            arch.shifts[g] = float(s)
+        arch.sr_coulomb = 1 if spec.sr_coulomb else 0
+        arch.sr_envelope = 0 if spec.sr_envelope == "exp" else 1
+        arch.sr_rc = float(spec.sr_rc)
+
+        w = _lib.Weights()
+        sd = spec.weights
+
+        def ptr(key: str, dtype=np.float32) -> int:
+            a = np.ascontiguousarray(np.asarray(sd[key]), dtype=dtype)
+            self._keep.append(a)
+            return a.ctypes.data
+
+        w.afv, w.agh_a, w.agh_q = ptr("afv.weight"), ptr("conv_a.agh"), ptr("conv_q.agh")
+        for p, dims in enumerate(spec.mlp_dims):
+            for layer in range(len(dims) - 1):
+                w.mlp_w[p][layer] = ptr(f"mlps.{p}.{2 * layer}.weight")
+                w.mlp_b[p][layer] = ptr(f"mlps.{p}.{2 * layer}.bias")
+        for layer in range(len(spec.head_dims) - 1):
+            w.head_w[layer] = ptr(f"outputs.energy_mlp.mlp.{2 * layer}.weight")
+            w.head_b[layer] = ptr(f"outputs.energy_mlp.mlp.{2 * layer}.bias")
+        w.sae = ptr("outputs.atomic_shift.shifts.weight", np.float64)
+        handle = C.c_void_p()
+        _lib.check(self.lib.aimnet_engine_create(C.byref(arch), C.byref(w), self.dev_index, C.byref(handle)), "aimnet_engine_create")
+        self._h = handle
+        self._keep.clear()  # weights are on the device now
+        self._ws = None
+        # AdaptiveNeighborList policy (neighbors.py:49-63): density 0.2 -> 112 @ 5 A, 2832 @ 15 A
+        self.max_nb = _round16(int(0.2 * 4.0 / 3.0 * math.pi * spec.rc**3))
+        self._max_nb_lr: dict[float, int] = {}
+        self.last_status: np.ndarray | None = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self.lib.aimnet_engine_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ------------------------------------------------------------------------------------------
+    def _lr_capacity(self, rc: float) -> int:
+        if rc not in self._max_nb_lr:
+            self._max_nb_lr[rc] = _round16(int(0.2 * 4.0 / 3.0 * math.pi * rc**3))
+        return self._max_nb_lr[rc]
+
+    def eval(
+        self,
+        coord,
+        numbers,
+        mol_idx,
+        charge,
+        cell=None,
+        pbc=(True, True, True),
+        forces: bool = False,
+        stress: bool = False,
+        coulomb: str = "simple",
+        dsf_rc: float = 15.0,
+        dsf_alpha: float = 0.2,
+        sync: bool = True,
+    ) -> dict[str, Any]:
+        """One evaluation on device tensors (coord f32 [N,3], numbers/mol_idx i32 [N], charge f32
+        [n_mol], cell f32 [3,3]|[n_mol,3,3]).  Returns device tensors; retries with x1.5 row
+        capacity on neighbour overflow (neighbors.py:127-130)."""
+        import torch
+
+        dev = self.device
+        coord = coord.to(device=dev, dtype=torch.float32).contiguous()
+        numbers = numbers.to(device=dev, dtype=torch.int32).contiguous()
+        mol_idx = mol_idx.to(device=dev, dtype=torch.int32).contiguous()
+        charge = charge.to(device=dev, dtype=torch.float32).contiguous()
+        n, n_mol = coord.shape[0], charge.shape[0]
+        n_cell = 0
+        if cell is not None:
+            cell = cell.to(device=dev, dtype=torch.float32).contiguous()
+            n_cell = 1 if cell.ndim == 2 else cell.shape[0]
+        method = {"none": _lib.COULOMB_NONE, "simple": _lib.COULOMB_SIMPLE, "dsf": _lib.COULOMB_DSF}[coulomb]
+        energy = torch.empty(n_mol, dtype=torch.float64, device=dev)
+        charges = torch.empty(n, dtype=torch.float32, device=dev)
+        f_out = torch.empty(n, 3, dtype=torch.float32, device=dev) if forces else None
+        s_out = torch.empty(max(n_cell, 1), 3, 3, dtype=torch.float32, device=dev) if stress else None
+        status = torch.zeros(8, dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        while True:
+            opt = _lib.EvalOptions()
+            opt.flags = (_lib.FORCES if forces else 0) | (_lib.STRESS if stress else 0)
+            opt.coulomb = method
+            opt.dsf_rc, opt.dsf_alpha = float(dsf_rc), float(dsf_alpha)
+            opt.max_nb = self.max_nb
+            opt.max_nb_lr = self._lr_capacity(float(dsf_rc)) if method == _lib.COULOMB_DSF else 0
+            need = int(self.lib.aimnet_engine_workspace_bytes(self._h, n, n_mol, n_cell, C.byref(opt)))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = None
+                self._ws = torch.empty(int(need * 1.1) + 4096, dtype=torch.uint8, device=dev)
+            inp = _lib.Inputs()
+            inp.n_atoms, inp.n_mol = n, n_mol
+            inp.coord, inp.numbers, inp.mol_idx, inp.charge = coord.data_ptr(), numbers.data_ptr(), mol_idx.data_ptr(), charge.data_ptr()
+            inp.cell = cell.data_ptr() if cell is not None else None
+            inp.n_cell = n_cell
+            for k in range(3):
+                inp.pbc[k] = 1 if bool(pbc[k]) else 0
+            out = _lib.Outputs()
+            out.energy, out.charges = energy.data_ptr(), charges.data_ptr()
+            out.forces = f_out.data_ptr() if f_out is not None else None
+            out.stress = s_out.data_ptr() if s_out is not None else None
+            out.status = status.data_ptr()
+            with torch.cuda.device(dev):
+                rc = self.lib.aimnet_engine_eval(self._h, C.byref(inp), C.byref(opt), C.byref(out), self._ws.data_ptr(),
+                                                 self._ws.numel(), stream)
+            _lib.check(rc, "aimnet_engine_eval")
+            if not sync:
+                break
+            st = status.cpu().numpy()  # the one D2H sync of a step (the reference has one per list, neighbors.py:133)
+            self.last_status = st
+            retry = False
+            if st[2]:
+                self.max_nb = _round16(int(max(self.max_nb * 1.5, st[0])))
+                retry = True
+            if st[3]:
+                self._max_nb_lr[float(dsf_rc)] = _round16(int(max(opt.max_nb_lr * 1.5, st[1])))
+                retry = True
+            if not retry:
+                break
+        res: dict[str, Any] = {"energy": energy, "charges": charges}
+        if forces:
+            res["forces"] = f_out
+        if stress:
+            res["stress"] = s_out[0] if (cell is not None and cell.ndim == 2) else s_out
+        return res
+
+    # ------------------------------------------------------------------------------------------
+    def debug_view(self, name: str):
+        """Intermediate of the last eval as a torch tensor view into the workspace (tests only)."""
+        import torch
+
+        off, n_elem = C.c_size_t(), C.c_size_t()
+        esz, stride = C.c_int32(), C.c_int32()
+        rc = self.lib.aimnet_engine_debug_view(self._h, name.encode(), C.byref(off), C.byref(n_elem), C.byref(esz), C.byref(stride))
+        if rc != 0:
+            raise KeyError(name)
+        raw = self._ws[off.value : off.value + n_elem.value * esz.value]
+        if name in _INT_VIEWS:
+            t = raw.view(torch.int32)
+        elif esz.value == 16:
+            t = raw.view(torch.float32)
+        else:
+            t = raw.view(getattr(torch, _DTYPES[esz.value]))
+        if stride.value > 1:
+            per = stride.value * (4 if esz.value == 16 else 1)
+            t = t.view(-1, per)
+        return t
+
+
+# ---- stand-alone op wrappers (parity tests of the reference operator boundaries) ------------------
+def neighbor_list(coord, cutoff: float, mol_idx=None, cell=None, pbc=(True, True, True), max_nb: int = 128, fill_value=None):
+    """nvalchemiops-contract neighbour list on the GPU: returns (nbmat i32 [N,max_nb], num_nb i32 [N],
+    shifts i32 [N,max_nb,3] | None, coord_wrapped f32 [N,3], status (max_count, overflow))."""
+    import torch
+
+    lib = _lib.load()
+    dev = coord.device
+    coord = coord.to(torch.float32).contiguous()
+    n = coord.shape[0]
+    if mol_idx is None:
+        mol_idx = torch.zeros(n, dtype=torch.int32, device=dev)
+    mol_idx = mol_idx.to(device=dev, dtype=torch.int32).contiguous()
+    n_mol = int(mol_idx.max().item()) + 1
+    fill = n if fill_value is None else int(fill_value)
+    n_cell = 0
+    if cell is not None:
+        cell = cell.to(device=dev, dtype=torch.float32).contiguous()
+        n_cell = 1 if cell.ndim == 2 else cell.shape[0]
+    nbmat = torch.empty(n, max_nb, dtype=torch.int32, device=dev)
+    shifts = torch.empty(n, max_nb, 3, dtype=torch.int32, device=dev) if cell is not None else None
+    num = torch.empty(n, dtype=torch.int32, device=dev)
+    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    xw = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    nbytes = int(lib.aimnet_neighbor_list_workspace_bytes(n, n_mol, max_nb))
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    p3 = (C.c_int32 * 3)(*[1 if bool(b) else 0 for b in pbc])
+    with torch.cuda.device(dev):
+        rc = lib.aimnet_neighbor_list(coord.data_ptr(), mol_idx.data_ptr(), n, n_mol, cell.data_ptr() if cell is not None else None,
+                                      n_cell, C.byref(p3), float(cutoff), int(max_nb), fill, nbmat.data_ptr(),
+                                      shifts.data_ptr() if shifts is not None else None, num.data_ptr(), status.data_ptr(),
+                                      xw.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "aimnet_neighbor_list")
+    st = status.cpu().numpy()
+    return nbmat, num, shifts, xw, (int(st[0]), int(st[1]))
+
+
+def conv_sv_2d_sp_fwd(a, idx, g):
+    """torch.ops.aimnet.conv_sv_2d_sp_fwd contract (conv_sv_2d_sp_wp.py:252-275)."""
+    import torch
+
+    lib = _lib.load()
+    B, A, G = a.shape
+    M = idx.shape[1]
+    a = a.to(torch.float32).contiguous()
+    idx = idx.to(torch.int32).contiguous()
+    g = g.to(torch.float32).contiguous()
+    out = torch.empty(B, A, G, 4, dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        rc = lib.aimnet_conv_sv_2d_sp_fwd(a.data_ptr(), idx.data_ptr(), g.data_ptr(), out.data_ptr(), B, A, G, M,
+                                          torch.cuda.current_stream(a.device).cuda_stream)
+    _lib.check(rc, "aimnet_conv_sv_2d_sp_fwd")
+    return out
+
+
+def conv_sv_2d_sp_bwd(grad_out, a, idx, g):
+    """torch.ops.aimnet.conv_sv_2d_sp_bwd contract (conv_sv_2d_sp_wp.py:285-340): (grad_a, grad_g)."""
+    import torch
+
+    lib = _lib.load()
+    B, A, G = a.shape
+    M = idx.shape[1]
+    grad_out = grad_out.to(torch.float32).contiguous()
+    a = a.to(torch.float32).contiguous()
+    idx = idx.to(torch.int32).contiguous()
+    g = g.to(torch.float32).contiguous()
+    grad_a = torch.empty_like(a)
+    grad_g = torch.empty_like(g)
+    with torch.cuda.device(a.device):
+        rc = lib.aimnet_conv_sv_2d_sp_bwd(grad_out.data_ptr(), a.data_ptr(), idx.data_ptr(), g.data_ptr(), grad_a.data_ptr(),
+                                          grad_g.data_ptr(), B, A, G, M, torch.cuda.current_stream(a.device).cuda_stream)
+    _lib.check(rc, "aimnet_conv_sv_2d_sp_bwd")
+    return grad_a, grad_g

@@ -1,0 +1,163 @@
+/*
+ * aimnet_hip.h - C ABI of libaimnet_hip.so: the MI355X (gfx950) native AIMNet2 energy / force /
+ * virial engine.  Plain pointers and sizes only; all buffers are DEVICE pointers owned by the
+ * caller (the Python host allocates them as torch tensors), the library never allocates in the
+ * hot path and never frees caller memory.  Every call is asynchronous on the given HIP stream.
+ *
+ * Each entry point replaces one boundary of the reference (paths relative to /root/reference):
+ *
+ *   aimnet_engine_eval            <- the span `data = self.model(data)` .. `get_derivatives`
+ *                                    of AIMNet2Calculator.eval, aimnet/calculators/calculator.py:917-936,
+ *                                    plus make_nbmat :1521-1702 and move_coord_to_cell neighbors.py:331
+ *   aimnet_neighbor_list          <- nvalchemiops.torch.neighbors.neighbor_list as called in
+ *                                    aimnet/calculators/neighbors.py:106-125 (full list, packed
+ *                                    real-first, fill_value padding, integer shifts, overflow report)
+ *   aimnet_conv_sv_2d_sp_fwd/bwd  <- torch.ops.aimnet.conv_sv_2d_sp_fwd / _bwd,
+ *                                    aimnet/kernels/conv_sv_2d_sp_wp.py:252-340 (Warp kernels :90-164)
+ *   aimnet_engine_create          <- "state_dict -> module on device" of aimnet/models/base.py:65-89
+ *
+ * Errors: functions return 0 on success or a negative AIMNET_E_* code; no exceptions cross the
+ * ABI.  Neighbour overflow is reported asynchronously through the `status` words (the host grows
+ * the row capacity x1.5 and retries, mirroring AdaptiveNeighborList, neighbors.py:127-130).
+ */
+#ifndef AIMNET_HIP_H
+#define AIMNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIMNET_ABI_VERSION 1
+
+#define AIMNET_OK 0
+#define AIMNET_E_INVALID (-1)   /* bad argument / unsupported architecture */
+#define AIMNET_E_HIP (-2)       /* a HIP runtime call failed; see aimnet_last_error */
+#define AIMNET_E_WORKSPACE (-3) /* workspace too small */
+
+#define AIMNET_MAX_PASS 4
+#define AIMNET_MAX_LAYERS 6
+#define AIMNET_MAX_SHIFTS 32
+
+/* flags for aimnet_eval_options.flags */
+#define AIMNET_FORCES 1u
+#define AIMNET_STRESS 2u
+
+/* Coulomb method of the external LRCoulomb module (aimnet/modules/lr.py:928-983) */
+#define AIMNET_COULOMB_NONE 0
+#define AIMNET_COULOMB_SIMPLE 1 /* all pairs inside a molecule, lr.py:311-331 */
+#define AIMNET_COULOMB_DSF 2    /* damped shifted force, lr.py:559-615 */
+
+/* Architecture of one AIMNet2 core model (aimnet/models/aimnet2.py:12-106 hyper-parameters). */
+typedef struct aimnet_arch {
+  int32_t nfeature;  /* A, 16 */
+  int32_t nshifts;   /* G, 16 */
+  int32_t ncomb_v;   /* H, 12 */
+  int32_t n_pass;    /* number of message-passing MLPs, 3 */
+  int32_t n_layers[AIMNET_MAX_PASS];                       /* linear layers per pass MLP */
+  int32_t layer_dims[AIMNET_MAX_PASS][AIMNET_MAX_LAYERS + 1]; /* n_in, hidden..., n_out */
+  int32_t last_linear[AIMNET_MAX_PASS];                    /* 1: no GELU after the last layer */
+  int32_t head_n_layers;                                   /* energy head, last layer linear */
+  int32_t head_dims[AIMNET_MAX_LAYERS + 1];
+  float rc;                         /* aev.rc_s */
+  float eta;                        /* aev.eta_s */
+  float shifts[AIMNET_MAX_SHIFTS];  /* aev.shifts_s */
+  int32_t sr_coulomb;               /* 1: embedded SRCoulomb subtraction (lr.py:986-1032) */
+  int32_t sr_envelope;              /* 0 exp (ops.py:88), 1 cosine (ops.py:82) */
+  float sr_rc;                      /* 4.6 */
+} aimnet_arch;
+
+/* Host pointers to the fp32 weights, copied to the device once at create time.
+ * mlp_w[p][l] is torch Linear.weight [out, in] row-major, mlp_b[p][l] the bias [out]. */
+typedef struct aimnet_weights {
+  const float* afv;     /* [64, A*G] embedding; rows of unsupported Z may be NaN */
+  const float* agh_a;   /* [A, G, H] */
+  const float* agh_q;   /* [G, H] */
+  const float* mlp_w[AIMNET_MAX_PASS][AIMNET_MAX_LAYERS];
+  const float* mlp_b[AIMNET_MAX_PASS][AIMNET_MAX_LAYERS];
+  const float* head_w[AIMNET_MAX_LAYERS];
+  const float* head_b[AIMNET_MAX_LAYERS];
+  const double* sae;    /* [64] fp64 atomic shifts (core.py:71-97, utils.py:369-376) */
+} aimnet_weights;
+
+typedef struct aimnet_engine aimnet_engine;
+
+/* Device inputs of one evaluation.  Flat layout: atoms of a molecule are contiguous and
+ * mol_idx is non-decreasing (the reference assumes the same, nbops.py:346). */
+typedef struct aimnet_inputs {
+  int32_t n_atoms;
+  int32_t n_mol;
+  const float* coord;      /* [n_atoms, 3] */
+  const int32_t* numbers;  /* [n_atoms] */
+  const int32_t* mol_idx;  /* [n_atoms] */
+  const float* charge;     /* [n_mol] total molecular charge */
+  const float* cell;       /* [n_cell, 3, 3] row vectors, or NULL (non-periodic) */
+  int32_t n_cell;          /* 0, 1 (shared) or n_mol */
+  int32_t pbc[3];          /* periodic axes (used when cell != NULL) */
+} aimnet_inputs;
+
+typedef struct aimnet_eval_options {
+  uint32_t flags;          /* AIMNET_FORCES | AIMNET_STRESS */
+  int32_t coulomb;         /* AIMNET_COULOMB_* */
+  float dsf_rc;            /* 15.0 */
+  float dsf_alpha;         /* 0.2 */
+  int32_t max_nb;          /* row capacity of the short-range (rc) neighbour matrix */
+  int32_t max_nb_lr;       /* row capacity of the DSF neighbour matrix (0 if unused) */
+} aimnet_eval_options;
+
+typedef struct aimnet_outputs {
+  double* energy;   /* [n_mol] eV, fp64 like the reference */
+  float* charges;   /* [n_atoms] */
+  float* forces;    /* [n_atoms, 3] or NULL */
+  float* stress;    /* [max(n_cell,1), 3, 3] or NULL */
+  int32_t* status;  /* [8]: 0 max neighbours found (rc list), 1 same for the LR list,
+                              2 overflow flag rc list, 3 overflow flag LR list, 4.. reserved */
+} aimnet_outputs;
+
+int aimnet_abi_version(void);
+
+int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int device, aimnet_engine** out);
+void aimnet_engine_destroy(aimnet_engine* e);
+const char* aimnet_last_error(void);
+
+/* Bytes of scratch `aimnet_engine_eval` needs for the given problem size. */
+size_t aimnet_engine_workspace_bytes(const aimnet_engine* e, int32_t n_atoms, int32_t n_mol, int32_t n_cell,
+                                     const aimnet_eval_options* opt);
+
+/* One energy(+forces, +stress) evaluation.  `workspace` must stay alive until the stream has
+ * drained; it also holds the intermediates that aimnet_engine_debug_view exposes. */
+int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_eval_options* opt,
+                       const aimnet_outputs* out, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Test hook: byte offset / element count / element size of a named intermediate inside the
+ * workspace of the LAST eval (e.g. "nb_idx", "nb_cnt", "pair_geom", "x0", "y1", "q0", "aim",
+ * "e_atom", "xbar0").  Returns AIMNET_E_INVALID for unknown names. */
+int aimnet_engine_debug_view(const aimnet_engine* e, const char* name, size_t* byte_offset, size_t* n_elem,
+                             int32_t* elem_size, int32_t* row_stride);
+
+/* Stand-alone neighbour list with the nvalchemiops contract.  nbmat [n_atoms, max_nb] int32 is
+ * filled with `fill_value` beyond each row's count; shifts [n_atoms, max_nb, 3] int32 may be NULL
+ * when cell == NULL; num_nb [n_atoms] int32; status [2] = {max count, overflow flag}. */
+int aimnet_neighbor_list(const float* coord, const int32_t* mol_idx, int32_t n_atoms, int32_t n_mol,
+                         const float* cell, int32_t n_cell, const int32_t pbc[3], float cutoff, int32_t max_nb,
+                         int32_t fill_value, int32_t* nbmat, int32_t* shifts, int32_t* num_nb, int32_t* status,
+                         float* coord_wrapped, void* workspace, size_t workspace_bytes, void* hip_stream);
+size_t aimnet_neighbor_list_workspace_bytes(int32_t n_atoms, int32_t n_mol, int32_t max_nb);
+
+/* conv_sv_2d_sp forward: out[b,a,g,0:4] = sum_{m: idx[b,m] < B-1} a[idx[b,m],a,g] * g[b,m,g,0:4],
+ * rows packed real-first, last row (b = B-1) is padding and comes out zero.
+ * a [B,A,G] f32, idx [B,M] i32, g [B,M,G,4] f32, out [B,A,G,4] f32. */
+int aimnet_conv_sv_2d_sp_fwd(const float* a, const int32_t* idx, const float* g, float* out, int32_t B, int32_t A,
+                             int32_t G, int32_t M, void* hip_stream);
+/* backward: grad_a[j,a,g] = sum_{(b,m): idx[b,m]=j} <grad_out[b,a,g,:], g[b,m,g,:]>   (zero-initialised here)
+ *           grad_g[b,m,g,:] = sum_a a[idx[b,m],a,g] * grad_out[b,a,g,:]  (zero for padded slots) */
+int aimnet_conv_sv_2d_sp_bwd(const float* grad_out, const float* a, const int32_t* idx, const float* g,
+                             float* grad_a, float* grad_g, int32_t B, int32_t A, int32_t G, int32_t M,
+                             void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIMNET_HIP_H */

@@ -14,6 +14,7 @@ MAX_PASS, MAX_LAYERS, MAX_SHIFTS = 4, 6, 32
 FORCES, STRESS = 1, 2
 COULOMB_NONE, COULOMB_SIMPLE, COULOMB_DSF = 0, 1, 2
 E_INVALID, E_HIP, E_WORKSPACE = -1, -2, -3
+PROF_FAMILIES = ("nlist", "geom", "conv_fwd", "gemm", "pointwise", "coulomb", "unconcat", "conv_bwd", "other")
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaimnet_hip.so")
 
@@ -26,6 +27,8 @@ EXPORTED_SYMBOLS = (
     "aimnet_engine_workspace_bytes",
     "aimnet_engine_eval",
     "aimnet_engine_debug_view",
+    "aimnet_engine_set_profiling",
+    "aimnet_engine_profile_read",
     "aimnet_neighbor_list",
     "aimnet_neighbor_list_workspace_bytes",
     "aimnet_conv_sv_2d_sp_fwd",
@@ -129,6 +132,10 @@ def load() -> C.CDLL:
     lib.aimnet_engine_eval.argtypes = [vp, C.POINTER(Inputs), C.POINTER(EvalOptions), C.POINTER(Outputs), vp, sz, vp]
     lib.aimnet_engine_debug_view.restype = C.c_int
     lib.aimnet_engine_debug_view.argtypes = [vp, C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(i32), C.POINTER(i32)]
+    lib.aimnet_engine_set_profiling.restype = C.c_int
+    lib.aimnet_engine_set_profiling.argtypes = [vp, C.c_int]
+    lib.aimnet_engine_profile_read.restype = C.c_int
+    lib.aimnet_engine_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.c_int]
     lib.aimnet_neighbor_list_workspace_bytes.restype = sz
     lib.aimnet_neighbor_list_workspace_bytes.argtypes = [i32, i32, i32]
     lib.aimnet_neighbor_list.restype = C.c_int

@@ -54,9 +54,35 @@ struct aimnet_engine {
   float* head_b_last;  // [1]
   BasisParams bp;
   std::map<std::string, View> views;
+  // optional HIP-event profiling: one event per change of kernel family on the eval stream
+  int prof_level = 0;  // 0 off, 1 GEMM vs everything else, 2 every family
+  std::vector<hipEvent_t> prof_ev;
+  std::vector<int> prof_fam;
+  size_t prof_used = 0;
+  int prof_last = -2;
 };
 
 namespace {
+
+enum { FAM_NLIST = 0, FAM_GEOM, FAM_CONV_FWD, FAM_GEMM, FAM_POINTWISE, FAM_COULOMB, FAM_UNCONCAT, FAM_CONV_BWD, FAM_OTHER, FAM_COUNT };
+
+// mark "kernels launched from here on belong to family `fam`" (fam < 0 closes the last interval)
+int prof_mark(aimnet_engine* e, hipStream_t s, int fam) {
+  if (e->prof_level == 0) return 0;
+  if (e->prof_level == 1 && fam >= 0) fam = (fam == FAM_GEMM) ? FAM_GEMM : FAM_OTHER;
+  if (fam == e->prof_last) return 0;
+  if (e->prof_used == e->prof_ev.size()) {
+    hipEvent_t ev;
+    AIMNET_HIP_CHECK(hipEventCreate(&ev));
+    e->prof_ev.push_back(ev);
+    e->prof_fam.push_back(0);
+  }
+  AIMNET_HIP_CHECK(hipEventRecord(e->prof_ev[e->prof_used], s));
+  e->prof_fam[e->prof_used] = fam;
+  e->prof_used++;
+  e->prof_last = fam;
+  return 0;
+}
 
 template <typename T>
 int dev_upload(aimnet_engine* e, const T* host, size_t n, T** out) {
@@ -281,7 +307,34 @@ fail:
 void aimnet_engine_destroy(aimnet_engine* e) {
   if (!e) return;
   for (void* p : e->allocs) (void)hipFree(p);
+  for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
   delete e;
+}
+
+int aimnet_engine_set_profiling(aimnet_engine* e, int level) {
+  if (!e || level < 0 || level > 2) return AIMNET_E_INVALID;
+  e->prof_level = level;
+  e->prof_used = 0;
+  e->prof_last = -2;
+  return AIMNET_OK;
+}
+
+int aimnet_engine_profile_read(aimnet_engine* e, double* ms, int n_families, int reset) {
+  if (!e || !ms || n_families < FAM_COUNT) return AIMNET_E_INVALID;
+  for (int k = 0; k < n_families; ++k) ms[k] = 0.0;
+  if (e->prof_used > 0) AIMNET_HIP_CHECK(hipEventSynchronize(e->prof_ev[e->prof_used - 1]));
+  for (size_t k = 0; k + 1 < e->prof_used; ++k) {
+    const int fam = e->prof_fam[k];
+    if (fam < 0) continue;  // gap between two evals
+    float t = 0.f;
+    AIMNET_HIP_CHECK(hipEventElapsedTime(&t, e->prof_ev[k], e->prof_ev[k + 1]));
+    ms[fam] += (double)t;
+  }
+  if (reset) {
+    e->prof_used = 0;
+    e->prof_last = -2;
+  }
+  return AIMNET_OK;
 }
 
 size_t aimnet_engine_workspace_bytes(const aimnet_engine* e, int32_t n_atoms, int32_t n_mol, int32_t n_cell,
@@ -359,6 +412,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const int n_cell = pbc ? in->n_cell : 0;
 
   // ---- neighbour lists + pair geometry ------------------------------------------------------
+  RC(prof_mark(e, s, FAM_NLIST));
   AIMNET_HIP_CHECK(hipMemsetAsync(out->status, 0, 8 * sizeof(int), s));
   RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start));
   RC(launch_wrap(s, in->coord, in->mol_idx, N, n_mol, in->cell, n_cell, in->pbc, W.nl));
@@ -367,6 +421,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   if (coulomb == AIMNET_COULOMB_DSF)
     RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, opt->dsf_rc, 2, cap_lr, N, 0, W.nl, W.lr_idx,
                     W.lr_shift, W.lr_cnt, out->status + 1, out->status + 3));
+  RC(prof_mark(e, s, FAM_GEOM));
   RC(launch_pair_geom(s, W.nl.xw, in->mol_idx, in->cell, n_cell, W.nb_idx, W.nb_shift, W.nb_cnt, cap, N, W.pg));
 
   // ---- forward --------------------------------------------------------------------------------
@@ -374,10 +429,12 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   for (int p = 0; p < np; ++p) {
     const std::vector<Layer>& Ls = e->mlp[p];
     const int nl = (int)Ls.size();
+    RC(prof_mark(e, s, FAM_CONV_FWD));
     RC(launch_conv_fwd(s, p > 0, W.a[p], p > 0 ? W.q[p - 1] : nullptr, W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q,
                        e->bp, W.x[p], Ls[0].k_in, W.V[p], W.Vq[p], N));
     const float* hin = W.x[p];
     int ld_in = Ls[0].k_in;
+    RC(prof_mark(e, s, FAM_GEMM));
     for (int l = 0; l < nl; ++l) {
       const bool linear = (l == nl - 1) && ar.last_linear[p];
       RC(launch_gemm_nt(s, linear ? EPI_BIAS : EPI_BIAS_GELU, hin, ld_in, Ls[l].w, Ls[l].k_in, N, Ls[l].k_out, Ls[l].k_in,
@@ -386,6 +443,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       ld_in = Ls[l].k_out;
     }
     if (p < np - 1) {
+      RC(prof_mark(e, s, FAM_POINTWISE));
       RC(launch_nse_fwd(s, W.H[p][nl - 1], Ls[nl - 1].k_out, p > 0 ? W.q[p - 1] : nullptr, W.nl.mol_start, in->charge,
                         n_mol, W.q[p], W.Fm[p], W.Dm[p]));
       RC(launch_update_a(s, W.a[p], W.H[p][nl - 1], Ls[nl - 1].k_out, N, W.a[p + 1]));
@@ -397,12 +455,14 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const float* hin = W.H[np - 1][nlp - 1];
     int ld_in = e->mlp[np - 1][nlp - 1].k_out;
     const int nh = (int)e->head.size();
+    RC(prof_mark(e, s, FAM_GEMM));
     for (int l = 0; l + 1 < nh; ++l) {
       const Layer& L = e->head[l];
       RC(launch_gemm_nt(s, EPI_BIAS_GELU, hin, ld_in, L.w, L.k_in, N, L.k_out, L.k_in, L.b, W.hH[l], W.hD[l], L.k_out));
       hin = W.hH[l];
       ld_in = L.k_out;
     }
+    RC(prof_mark(e, s, FAM_POINTWISE));
     RC(launch_head_last(s, hin, ld_in, e->head_w_last, e->head_b_last, e->head[nh - 1].n_in, N, W.e_atom));
   }
 
@@ -413,6 +473,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   cp.sr_envelope = ar.sr_envelope;
   cp.dsf_rc = opt->dsf_rc;
   cp.dsf_alpha = opt->dsf_alpha;
+  RC(prof_mark(e, s, FAM_COULOMB));
   RC(launch_coulomb_sr(s, grad, want_s, ar.sr_coulomb != 0, q_fin, W.nb_idx, W.nb_cnt, W.pg, cap, cp, N, W.ecoul, W.qbar,
                        W.fgrad, W.virial_atom));
   if (coulomb == AIMNET_COULOMB_SIMPLE)
@@ -420,9 +481,13 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   else if (coulomb == AIMNET_COULOMB_DSF)
     RC(launch_coulomb_dsf(s, grad, want_s, q_fin, W.nl.xw, in->mol_idx, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt,
                           cap_lr, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));
+  RC(prof_mark(e, s, FAM_POINTWISE));
   RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, out->energy));
   RC(launch_copy_f32(s, q_fin, out->charges, (size_t)N));
-  if (!grad) return AIMNET_OK;
+  if (!grad) {
+    RC(prof_mark(e, s, -1));
+    return AIMNET_OK;
+  }
 
   // ---- backward -------------------------------------------------------------------------------
   float* zcur = W.zb0;
@@ -433,6 +498,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const Layer& Lp = e->head[nh - 2];
     RC(launch_head_seed(s, e->head_w_last, W.hD[nh - 2], Lp.k_out, Lp.n_out, N, zcur));
     int ld = Lp.k_out;
+    RC(prof_mark(e, s, FAM_GEMM));
     for (int l = nh - 2; l >= 0; --l) {
       const Layer& L = e->head[l];
       float* dprev;
@@ -448,6 +514,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const std::vector<Layer>& Ls = e->mlp[p];
     const int nl = (int)Ls.size();
     int ld = Ls[nl - 1].k_out;  // zcur = adjoint of the last layer's pre-activation (GELU' already applied)
+    RC(prof_mark(e, s, FAM_GEMM));
     for (int l = nl - 1; l >= 0; --l) {
       const Layer& L = Ls[l];
       if (l > 0)
@@ -458,7 +525,9 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       ld = L.k_in;
     }
     // zcur = xbar_p  (N x k_in of the first layer)
+    RC(prof_mark(e, s, FAM_UNCONCAT));
     RC(launch_unconcat(s, p > 0, zcur, ld, W.V[p], W.Vq[p], e->agh_a, e->agh_q, W.Sbar, W.Sqbar, N));
+    RC(prof_mark(e, s, FAM_CONV_BWD));
     RC(launch_conv_bwd(s, p > 0, p > 0, want_s, W.a[p], p > 0 ? W.q[p - 1] : nullptr, W.Sbar, W.Sqbar, W.nb_idx, W.nb_cnt,
                        W.pg, cap, e->bp, zcur, ld, (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, W.fgrad,
                        W.virial_atom, N));
@@ -468,13 +537,16 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const int nlq = (int)Lq.size();
     const float* y = W.H[p - 1][nlq - 1];
     const int ldy = Lq[nlq - 1].k_out;
+    RC(prof_mark(e, s, FAM_POINTWISE));
     RC(launch_nse_bwd_reduce(s, W.qbar, y, ldy, W.Fm[p - 1], W.nl.mol_start, n_mol, W.Wbar));
     RC(launch_build_zbar(s, W.qbar, W.abar, y, ldy, ar.last_linear[p - 1] ? nullptr : W.D[p - 1][nlq - 1], W.Fm[p - 1],
                          W.Dm[p - 1], W.Wbar, in->mol_idx, N, 256, p - 1 > 0, znext, W.qbar));
     std::swap(zcur, znext);
   }
+  RC(prof_mark(e, s, FAM_POINTWISE));
   RC(launch_finalize(s, W.fgrad, W.virial_atom, W.nl.mol_start, in->cell, n_cell, n_mol, N, want_f ? out->forces : nullptr,
                      want_s ? out->stress : nullptr));
+  RC(prof_mark(e, s, -1));
   return AIMNET_OK;
 }
 

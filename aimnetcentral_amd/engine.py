@@ -201,6 +201,26 @@ class HipEngine:
         return res
 
     # ------------------------------------------------------------------------------------------
+    def set_profiling(self, level: int) -> None:
+        """0 off, 1 GEMM-vs-rest, 2 per kernel family (HIP events on the eval stream)."""
+        _lib.check(self.lib.aimnet_engine_set_profiling(self._h, int(level)), "aimnet_engine_set_profiling")
+
+    def read_profile(self, reset: bool = True) -> dict[str, float]:
+        """Milliseconds per kernel family accumulated since the last reset."""
+        buf = (C.c_double * len(_lib.PROF_FAMILIES))()
+        _lib.check(self.lib.aimnet_engine_profile_read(self._h, buf, len(_lib.PROF_FAMILIES), 1 if reset else 0), "aimnet_engine_profile_read")
+        return {k: float(buf[i]) for i, k in enumerate(_lib.PROF_FAMILIES)}
+
+    def gemm_flops_per_atom(self, backward: bool = True) -> float:
+        """Algorithmic (unpadded) FLOPs per atom of all GEMM launches of one eval: 2 MACs forward,
+        plus the input-gradient GEMMs of the backward; the k->1 head layer is a dot kernel."""
+        macs = 0
+        for dims in self.spec.mlp_dims:
+            macs += sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+        hd = self.spec.head_dims
+        macs += sum(hd[i] * hd[i + 1] for i in range(len(hd) - 2))
+        return 2.0 * macs * (2 if backward else 1)
+
     def debug_view(self, name: str):
         """Intermediate of the last eval as a torch tensor view into the workspace (tests only)."""
         import torch

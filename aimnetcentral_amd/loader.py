@@ -371,7 +371,8 @@ def spec_from_config(config: Mapping[str, Any], state_dict: Mapping[str, Any], m
         sr_rc = float(np.asarray(state_dict["outputs.srcoulomb.rc"].detach().cpu().numpy() if hasattr(state_dict["outputs.srcoulomb.rc"], "detach") else state_dict["outputs.srcoulomb.rc"]))
     spec = ModelSpec(
         nfeature=A, nshifts=G, ncomb_v=H, mlp_dims=mlp_dims, last_linear=last_linear, head_dims=head_dims,
-        rc=float(w["aev.rc_s"]), eta=float(w["aev.eta_s"]), shifts=[float(s) for s in w["aev.shifts_s"]],
+        rc=float(w["aev.rc_s"].reshape(-1)[0]), eta=float(w["aev.eta_s"].reshape(-1)[0]),
+        shifts=[float(s) for s in w["aev.shifts_s"]],
         sr_coulomb=sr_coulomb, sr_envelope=sr_env, sr_rc=sr_rc, weights=w, metadata=dict(metadata),
     )
     return spec

@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""bench.py - atoms*steps/s of AIMNet2 energy+forces(+stress) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload pbc10k|md1024|batch256|taxol]
+
+A "step" is one full evaluation of the hot path (neighbour lists rebuilt, 3 message passing
+passes, energy head, Coulomb, analytic force/virial backward) on inputs already resident in HBM.
+
+Default workload (BASELINE.json configs[2], the configuration the north-star target is quoted
+on): the 2019828.cif allose crystal, (7,3,5) supercell = 10 080 atoms, periodic, DSF Coulomb
+(Rc 15 A, alpha 0.2), energy + forces + stress, synthetic weights (seed 0) of the real aimnet2
+architecture.  With --gpus N every rank evaluates its own independent frame (batch sharding,
+weak scaling) and the per-frame energies are all-gathered over RCCL each step; --workload md1024
+is BASELINE configs[4] (1024 frames x 50 atoms, 128 frames per GPU).
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the eval stream
+around the dominant kernel family (the fp32-MFMA GEMMs): algorithmic GEMM FLOPs per step /
+GEMM milliseconds per step against the 157.3 TFLOP/s fp32-matrix peak.  `cpu_baseline` times
+the oracle (torch-CPU eager restatement of the reference op sequence, kind "port") on the host
+cores on a bounded sample of the same workload, rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+
+
+def build_workload(name: str, rank: int, world: int):
+    """Returns dict(coord, numbers, mol_idx, charge, cell|None, coulomb, stress, frames, label)."""
+    from aimnetcentral_amd import dist as adist
+    from aimnetcentral_amd import workloads
+
+    if name == "pbc10k":
+        c, z, cell = workloads.glucose_supercell((7, 3, 5))
+        rng = np.random.Generator(np.random.PCG64(1000 + rank))
+        c = c + rng.standard_normal(c.shape) * 0.02  # independent thermal-like jitter per frame
+        return dict(coord=c.astype(np.float32), numbers=z, mol_idx=np.zeros(len(z), dtype=np.int64),
+                    charge=np.zeros(1, dtype=np.float32), cell=cell.astype(np.float32), coulomb="dsf", stress=True,
+                    frames=1, label="aimnet2 periodic: 2019828.cif (7,3,5) supercell 10080 atoms, DSF 15A, E+F+stress")
+    if name in ("md1024", "batch256"):
+        if name == "md1024":
+            n_frames, lo, hi, seed = 128 * world, 50, 50, 5
+        else:
+            n_frames, lo, hi, seed = 256 * world, 20, 60, 2
+        c, z, mol, q = workloads.random_batch(n_frames, lo, hi, seed)
+        sizes = np.bincount(mol, minlength=n_frames)
+        a, b = adist.shard_frames(sizes, world)[rank]
+        c, z, mol, q = adist.local_batch(c, z, mol, q, a, b)
+        label = ("aimnet2 MD: 1024 frames x 50 atoms, 128 frames/GPU" if name == "md1024"
+                 else "aimnet2 batched: 256 organics of 20-60 atoms per GPU")
+        return dict(coord=c, numbers=z, mol_idx=mol, charge=q, cell=None, coulomb="simple", stress=False,
+                    frames=b - a, label=label + ", simple Coulomb, E+F")
+    if name == "taxol":
+        g = np.load(os.path.join(ROOT, "tests", "golden", "taxol.npz"))
+        return dict(coord=g["coord"], numbers=g["numbers"], mol_idx=np.zeros(len(g["numbers"]), dtype=np.int64),
+                    charge=np.zeros(1, dtype=np.float32), cell=None, coulomb="simple", stress=False, frames=1,
+                    label="aimnet2 on taxol (113 atoms), simple Coulomb, E+F")
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(workload: str, budget_s: float = 20.0):
+    """Oracle (kind 'port') on the host cores, bounded sample of the same workload."""
+    import torch
+
+    from aimnetcentral_amd import synth, workloads
+    from oracle import aimnet2_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    om = O.OracleModel(synth.synthetic_state_dict(0), torch.float32)
+    if workload == "pbc10k":
+        c, z, cell = workloads.glucose_supercell((2, 2, 1))  # 384 atoms of the same crystal
+        mol = np.zeros(len(z), dtype=np.int64)
+        xw = O.wrap_into_cell(c.astype(np.float32), cell.astype(np.float32), mol, np.ones(3, dtype=bool))
+        nb, sh = O.neighbor_list(xw, 5.0, mol, cell, np.ones(3, dtype=bool))
+        nbl, shl = O.neighbor_list(xw, 15.0, mol, cell, np.ones(3, dtype=bool))
+        kw = dict(coord=xw, numbers=z, charge=np.zeros(1, np.float32), mol_idx=mol, cell=cell.astype(np.float32),
+                  coulomb="dsf", stress=True, nbmat=nb, shifts=sh, nbmat_lr=nbl, shifts_lr=shl)
+        sample = "2019828.cif (2,2,1) supercell, 384 atoms, DSF 15A, E+F+stress, neighbour lists prebuilt (not timed)"
+    else:
+        c, z, mol, q = workloads.random_batch(16, 50, 50, 5)
+        nb, _ = O.neighbor_list(c, 5.0, mol)
+        nbl, _ = O.neighbor_list(c, float("inf"), mol)
+        kw = dict(coord=c, numbers=z, charge=q, mol_idx=mol, coulomb="simple", nbmat=nb, nbmat_lr=nbl)
+        sample = "16 frames x 50 atoms, simple Coulomb, E+F, neighbour lists prebuilt (not timed)"
+    n_atoms = len(kw["numbers"])
+    O.evaluate(om, **kw)  # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        O.evaluate(om, **kw)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or reps >= 50:
+            break
+    return {"value": n_atoms * reps / dt, "unit": "atoms*steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": sample + f"; {reps} evals in {dt:.1f} s, torch {torch.__version__} CPU eager"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="pbc10k")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-family time table to stderr")
+    args = ap.parse_args()
+
+    import torch
+
+    from aimnetcentral_amd import dist as adist
+    from aimnetcentral_amd import loader
+    from aimnetcentral_amd.engine import HipEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if args.gpus > 1 and not distributed:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    wl = build_workload(args.workload, rank, world)
+    eng = HipEngine(loader.synthetic_spec(0), dev)
+    t = {k: torch.from_numpy(np.ascontiguousarray(wl[k])).to(dev) for k in ("coord", "numbers", "mol_idx", "charge")}
+    cell = torch.from_numpy(wl["cell"]).to(dev) if wl["cell"] is not None else None
+    n_atoms = int(t["coord"].shape[0])
+    frames = int(wl["frames"])
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def step():
+        res = eng.eval(t["coord"], t["numbers"], t["mol_idx"], t["charge"], cell=cell, forces=True, stress=wl["stress"],
+                       coulomb=wl["coulomb"])
+        if distributed:
+            return adist.all_gather_energies(res["energy"], [frames] * world)
+        return res["energy"]
+
+    for _ in range(args.warmup):
+        step()
+    eng.set_profiling(1)  # HIP events at GEMM <-> rest boundaries only
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        e_all = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.read_profile()
+    eng.set_profiling(0)
+    if distributed:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        na = torch.tensor([n_atoms], dtype=torch.int64, device=dev)
+        dist.all_reduce(na)
+        total_atoms = int(na.item())
+    else:
+        total_atoms = n_atoms
+    assert bool(torch.isfinite(e_all).all()), "non-finite energies"
+
+    if args.breakdown and rank == 0:
+        eng.set_profiling(2)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize(dev)
+        fam = eng.read_profile()
+        eng.set_profiling(0)
+        tot = sum(fam.values())
+        print("per-family ms/step: " + "  ".join(f"{k}={v / 5:.3f}" for k, v in fam.items()) + f"  total={tot / 5:.3f}", file=sys.stderr)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_atoms * args.steps / elapsed
+        gemm_ms = prof["gemm"] / args.steps
+        flops_step = eng.gemm_flops_per_atom(True) * n_atoms
+        achieved = flops_step / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        out = {
+            "metric": "atoms*steps/sec (energy+forces)",
+            "value": value,
+            "unit": "atoms*steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (seeded weights of the real aimnet2 architecture; crystal from 2019828.cif + 0.02 A jitter)",
+            "config": {"workload": wl["label"], "atoms_per_gpu": n_atoms, "frames_per_gpu": frames,
+                       "parallelism": f"batch-shard x{world} (independent frames, RCCL all-gather of energies)" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "kernel": "gemm_nt_kernel (fp32 MFMA MLP GEMMs, all launches of a step)",
+                         "gemm_ms_per_step": gemm_ms, "other_ms_per_step": prof["other"] / args.steps,
+                         "algorithmic_flop_per_step": flops_step},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -137,6 +137,15 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
 int aimnet_engine_debug_view(const aimnet_engine* e, const char* name, size_t* byte_offset, size_t* n_elem,
                              int32_t* elem_size, int32_t* row_stride);
 
+/* Optional HIP-event profiling on the eval stream (no reference counterpart; the reference documents
+ * a manual torch.cuda.synchronize + perf_counter recipe, docs/tutorials/performance.md:183-238).
+ * level 0 off, 1 = {GEMM, everything else}, 2 = every kernel family.  profile_read sums the elapsed
+ * milliseconds per family since the last reset into ms[AIMNET_PROF_FAMILIES]; family order:
+ * nlist, geom, conv_fwd, gemm, pointwise, coulomb, unconcat, conv_bwd, other. */
+#define AIMNET_PROF_FAMILIES 9
+int aimnet_engine_set_profiling(aimnet_engine* e, int level);
+int aimnet_engine_profile_read(aimnet_engine* e, double* ms, int n_families, int reset);
+
 /* Stand-alone neighbour list with the nvalchemiops contract.  nbmat [n_atoms, max_nb] int32 is
  * filled with `fill_value` beyond each row's count; shifts [n_atoms, max_nb, 3] int32 may be NULL
  * when cell == NULL; num_nb [n_atoms] int32; status [2] = {max count, overflow flag}. */

@@ -61,56 +61,58 @@ def wrap_into_cell(coord: np.ndarray, cell: np.ndarray, mol_idx: np.ndarray, pbc
 
 def neighbor_list(coord, cutoff: float, mol_idx, cell=None, pbc=None):
     """Full neighbour matrix: returns (nbmat (N+1, M) int64 with sentinel N incl. padding row,
-    shifts (N+1, M, 3) float32 or None).  Rows real-first; same-molecule pairs only."""
+    shifts (N+1, M, 3) float32 or None).  Rows real-first; same-molecule pairs only.
+    Brute force over images in fp64, vectorised per image; row order = (image, j) ascending."""
     pos = np.asarray(coord, dtype=np.float64)
     n = pos.shape[0]
     mol = np.asarray(mol_idx, dtype=np.int64)
-    rows: list[list[tuple[int, int, int, int]]] = [[] for _ in range(n)]
-    if cell is None:
-        if math.isinf(cutoff):
-            ok = mol[:, None] == mol[None, :]
-        else:
-            d2 = ((pos[:, None, :] - pos[None, :, :]) ** 2).sum(-1)
-            ok = (d2 < cutoff * cutoff) & (mol[:, None] == mol[None, :])
-        np.fill_diagonal(ok, False)
-        for i in range(n):
-            rows[i] = [(int(j), 0, 0, 0) for j in np.nonzero(ok[i])[0]]
-    else:
+    ii_all, jj_all, sh_all = [], [], []
+    starts = np.concatenate([[0], np.nonzero(np.diff(mol))[0] + 1, [n]])
+    for a, b in zip(starts[:-1], starts[1:]):  # molecules are contiguous (sorted mol_idx)
+        p = pos[a:b]
+        if cell is None:
+            if math.isinf(cutoff):
+                ok = np.ones((b - a, b - a), dtype=bool)
+            else:
+                ok = ((p[:, None, :] - p[None, :, :]) ** 2).sum(-1) < cutoff * cutoff
+            np.fill_diagonal(ok, False)
+            i, j = np.nonzero(ok)
+            ii_all.append(i + a)
+            jj_all.append(j + a)
+            sh_all.append(np.zeros((i.size, 3), dtype=np.int64))
+            continue
         cells = np.asarray(cell, dtype=np.float64)
-        if cells.ndim == 2:
-            cells = cells[None]
-        pb = np.ones((cells.shape[0], 3), dtype=bool) if pbc is None else np.asarray(pbc, dtype=bool)
-        if pb.ndim == 1:
-            pb = np.broadcast_to(pb, (cells.shape[0], 3))
-        for s in range(cells.shape[0]):
-            idx = np.nonzero(mol == s)[0]
-            if idx.size == 0:
-                continue
-            c = cells[s]
-            vol = abs(np.linalg.det(c))
-            nimg = []
-            for k in range(3):
-                h = vol / np.linalg.norm(np.cross(c[(k + 1) % 3], c[(k + 2) % 3]))
-                nimg.append(int(math.ceil(cutoff / h)) if pb[s, k] else 0)
-            p = pos[idx]
-            for sx in range(-nimg[0], nimg[0] + 1):
-                for sy in range(-nimg[1], nimg[1] + 1):
-                    for sz in range(-nimg[2], nimg[2] + 1):
-                        off = sx * c[0] + sy * c[1] + sz * c[2]
-                        d2 = ((p[None, :, :] + off - p[:, None, :]) ** 2).sum(-1)
-                        ok = d2 < cutoff * cutoff
-                        if sx == 0 and sy == 0 and sz == 0:
-                            np.fill_diagonal(ok, False)
-                        ii, jj = np.nonzero(ok)
-                        for a, b in zip(ii.tolist(), jj.tolist()):
-                            rows[int(idx[a])].append((int(idx[b]), sx, sy, sz))
-    m = max(1, max(len(r) for r in rows))
+        c = cells if cells.ndim == 2 else cells[mol[a]]
+        pb = np.ones(3, dtype=bool) if pbc is None else np.asarray(pbc, dtype=bool).reshape(-1, 3)[0]
+        vol = abs(np.linalg.det(c))
+        nimg = []
+        for k in range(3):
+            h = vol / np.linalg.norm(np.cross(c[(k + 1) % 3], c[(k + 2) % 3]))
+            nimg.append(int(math.ceil(cutoff / h)) if pb[k] else 0)
+        for sx in range(-nimg[0], nimg[0] + 1):
+            for sy in range(-nimg[1], nimg[1] + 1):
+                for sz in range(-nimg[2], nimg[2] + 1):
+                    off = sx * c[0] + sy * c[1] + sz * c[2]
+                    ok = ((p[None, :, :] + off - p[:, None, :]) ** 2).sum(-1) < cutoff * cutoff
+                    if sx == 0 and sy == 0 and sz == 0:
+                        np.fill_diagonal(ok, False)
+                    i, j = np.nonzero(ok)
+                    ii_all.append(i + a)
+                    jj_all.append(j + a)
+                    sh_all.append(np.broadcast_to(np.array([sx, sy, sz]), (i.size, 3)))
+    ii = np.concatenate(ii_all) if ii_all else np.zeros(0, dtype=np.int64)
+    jj = np.concatenate(jj_all) if jj_all else np.zeros(0, dtype=np.int64)
+    sh = np.concatenate(sh_all) if sh_all else np.zeros((0, 3), dtype=np.int64)
+    order = np.argsort(ii, kind="stable")
+    ii, jj, sh = ii[order], jj[order], sh[order]
+    counts = np.bincount(ii, minlength=n)
+    m = max(1, int(counts.max()) if counts.size else 1)
+    first = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    slot = np.arange(ii.size) - first[ii]
     nbmat = np.full((n + 1, m), n, dtype=np.int64)
     shifts = np.zeros((n + 1, m, 3), dtype=np.float32)
-    for i, r in enumerate(rows):
-        for k, (j, sx, sy, sz) in enumerate(r):
-            nbmat[i, k] = j
-            shifts[i, k] = (sx, sy, sz)
+    nbmat[ii, slot] = jj
+    shifts[ii, slot] = sh
     return nbmat, (shifts if cell is not None else None)
 
 

@@ -1,0 +1,156 @@
+"""Stand-alone C-ABI operators against the reference operator contracts."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from aimnetcentral_amd import engine as E
+from aimnetcentral_amd import workloads
+from oracle import aimnet2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def reference_conv_sv_2d_sp_einsum(a, idx, g):
+    """Masked einsum semantics the reference pins its Warp kernel to (tests/test_conv_sv_2d_sp.py:73-101)."""
+    B, M = idx.shape
+    valid = (idx < B - 1).unsqueeze(-1).unsqueeze(-1)
+    a_sel = a.index_select(0, idx.clamp(0, B - 1).flatten()).unflatten(0, (B, M))
+    out = torch.einsum("bmag,bmgd->bagd", a_sel, g * valid)
+    out[-1] = 0
+    return out
+
+
+def make_idx(B, M, n_real, gen):
+    idx = torch.full((B, M), B - 1, dtype=torch.int64)
+    for b in range(B):
+        n = int(torch.randint(0, min(n_real, M) + 1, (1,), generator=gen))
+        idx[b, :n] = torch.randint(0, B - 1, (n,), generator=gen)
+    return idx
+
+
+@pytest.mark.parametrize("B,A,G,M", [(8, 16, 12, 10), (113, 16, 16, 62), (33, 4, 8, 5), (2, 16, 16, 1)])
+def test_conv_sv_fwd_bwd_match_einsum_reference(B, A, G, M):
+    gen = torch.Generator().manual_seed(B * 1000 + M)
+    a = torch.randn(B, A, G, generator=gen)
+    g = torch.randn(B, M, G, 4, generator=gen)
+    idx = make_idx(B, M, M, gen)
+    dev = torch.device("cuda:0")
+    out = E.conv_sv_2d_sp_fwd(a.to(dev), idx.to(dev), g.to(dev)).cpu()
+    ref = reference_conv_sv_2d_sp_einsum(a, idx, g)
+    torch.testing.assert_close(out, ref, atol=1e-5, rtol=1e-4)  # test_conv_sv_2d_sp.py:158
+    assert (out[-1] == 0).all()
+    # backward against autograd of the einsum reference (test_conv_sv_2d_sp.py:186-192)
+    a_r, g_r = a.clone().requires_grad_(True), g.clone().requires_grad_(True)
+    go = torch.randn(B, A, G, 4, generator=gen)
+    go[-1] = 0
+    reference_conv_sv_2d_sp_einsum(a_r, idx, g_r).backward(go)
+    ga, gg = E.conv_sv_2d_sp_bwd(go.to(dev), a.to(dev), idx.to(dev), g.to(dev))
+    torch.testing.assert_close(ga.cpu(), a_r.grad, atol=1e-4, rtol=1e-3)
+    torch.testing.assert_close(gg.cpu(), g_r.grad, atol=1e-4, rtol=1e-3)
+
+
+def test_conv_sv_padding_counts():
+    """rows with 0, partial and full neighbour counts (test_conv_sv_2d_sp.py:294-318)."""
+    B, A, G, M = 6, 16, 16, 4
+    gen = torch.Generator().manual_seed(7)
+    a, g = torch.randn(B, A, G, generator=gen), torch.randn(B, M, G, 4, generator=gen)
+    idx = torch.full((B, M), B - 1, dtype=torch.int64)
+    idx[1, :1] = 0
+    idx[2, :2] = torch.tensor([3, 1])
+    idx[3, :4] = torch.tensor([0, 1, 2, 4])
+    dev = torch.device("cuda:0")
+    out = E.conv_sv_2d_sp_fwd(a.to(dev), idx.to(dev), g.to(dev)).cpu()
+    assert (out[0] == 0).all() and (out[4] == 0).all() and (out[5] == 0).all()
+    torch.testing.assert_close(out, reference_conv_sv_2d_sp_einsum(a, idx, g), atol=1e-5, rtol=1e-4)
+
+
+def rows_as_sets(nbmat, num, shifts=None):
+    out = []
+    nb = nbmat.cpu().numpy()
+    cnt = num.cpu().numpy()
+    sh = shifts.cpu().numpy() if shifts is not None else None
+    for i in range(nb.shape[0]):
+        if sh is None:
+            out.append(sorted((int(j), 0, 0, 0) for j in nb[i, : cnt[i]]))
+        else:
+            out.append(sorted((int(j), int(s[0]), int(s[1]), int(s[2])) for j, s in zip(nb[i, : cnt[i]], sh[i, : cnt[i]])))
+    return out
+
+
+def oracle_sets(nbmat, shifts, n):
+    out = []
+    for i in range(n):
+        v = nbmat[i] < n
+        if shifts is None:
+            out.append(sorted((int(j), 0, 0, 0) for j in nbmat[i][v]))
+        else:
+            out.append(sorted((int(j), int(s[0]), int(s[1]), int(s[2])) for j, s in zip(nbmat[i][v], shifts[i][v])))
+    return out
+
+
+def test_neighbor_list_nonperiodic_batch_as_sets():
+    """neighbour rows compared as SETS per atom, as the reference does (test_calculator_gpu.py:181-184)."""
+    c, z, mol, q = workloads.random_batch(7, 5, 70, seed=9)
+    dev = torch.device("cuda:0")
+    nb, num, sh, xw, (mx, ovf) = E.neighbor_list(torch.from_numpy(c).to(dev), 5.0, torch.from_numpy(mol).to(dev), max_nb=96)
+    ref, _ = O.neighbor_list(c, 5.0, mol)
+    assert ovf == 0 and sh is None
+    assert rows_as_sets(nb, num) == oracle_sets(ref, None, len(z))
+    assert mx == (ref[:-1] < len(z)).sum(1).max()
+    # packed real-first + fill_value padding (conv_sv_2d_sp_wp.py:630-636)
+    nbn, cnt = nb.cpu().numpy(), num.cpu().numpy()
+    for i in range(len(z)):
+        assert (nbn[i, cnt[i]:] == len(z)).all() and (nbn[i, : cnt[i]] < len(z)).all()
+    # symmetry of the full list
+    pairs = {(i, j) for i, r in enumerate(rows_as_sets(nb, num)) for (j, *_s) in r}
+    assert all((j, i) in pairs for (i, j) in pairs)
+
+
+@pytest.mark.parametrize("cutoff,pbc", [(5.0, (True, True, True)), (9.0, (True, True, True)), (6.0, (True, False, True))])
+def test_neighbor_list_periodic_small_cell_as_sets(cutoff, pbc):
+    """96-atom monoclinic cell, a = 4.98 A < cutoff: several images of the same atom and self images."""
+    c, z, cell = workloads.glucose_cell()
+    rng = np.random.default_rng(1)
+    c = c + rng.integers(-2, 3, size=(96, 3)) @ cell  # atoms outside the box: exercises wrapping
+    mol = np.zeros(96, dtype=np.int64)
+    dev = torch.device("cuda:0")
+    nb, num, sh, xw, (mx, ovf) = E.neighbor_list(torch.from_numpy(c.astype(np.float32)).to(dev), cutoff,
+                                                 torch.from_numpy(mol).to(dev), cell=torch.from_numpy(cell.astype(np.float32)).to(dev),
+                                                 pbc=pbc, max_nb=640)
+    assert ovf == 0
+    pb = np.array(pbc)
+    xw_ref = O.wrap_into_cell(c.astype(np.float32), cell.astype(np.float32), mol, pb)
+    assert np.abs(xw.cpu().numpy() - xw_ref).max() < 5e-5
+    ref, rsh = O.neighbor_list(xw.cpu().numpy(), cutoff, mol, cell, pb)
+    got, want = rows_as_sets(nb, num, sh), oracle_sets(ref, rsh, 96)
+    # pairs within 1e-4 A of the cutoff may legitimately differ between fp32 (GPU) and fp64 (oracle)
+    diff = sum(len(set(a) ^ set(b)) for a, b in zip(got, want))
+    assert diff <= 2, f"{diff} differing pairs"
+    # exact symmetry (i,j,s) <-> (j,i,-s)
+    allp = {(i, j, sx, sy, sz) for i, r in enumerate(got) for (j, sx, sy, sz) in r}
+    assert all((j, i, -sx, -sy, -sz) in allp for (i, j, sx, sy, sz) in allp)
+
+
+def test_neighbor_list_overflow_reported():
+    c, z, mol, q = workloads.random_batch(1, 60, 60, seed=2)
+    dev = torch.device("cuda:0")
+    nb, num, sh, xw, (mx, ovf) = E.neighbor_list(torch.from_numpy(c).to(dev), 5.0, max_nb=8)
+    assert ovf == 1 and mx > 8 and int(num.max()) == 8
+
+
+def test_neighbor_list_batched_cells():
+    c, z, cell = workloads.glucose_cell()
+    cell2 = cell * np.array([[1.03], [0.97], [1.0]])
+    c2 = (c @ np.linalg.inv(cell)) @ cell2
+    cc = np.concatenate([c, c2]).astype(np.float32)
+    mol = np.repeat(np.arange(2), 96)
+    cells = np.stack([cell, cell2]).astype(np.float32)
+    dev = torch.device("cuda:0")
+    nb, num, sh, xw, (mx, ovf) = E.neighbor_list(torch.from_numpy(cc).to(dev), 5.0, torch.from_numpy(mol).to(dev),
+                                                 cell=torch.from_numpy(cells).to(dev), max_nb=128)
+    ref, rsh = O.neighbor_list(xw.cpu().numpy(), 5.0, mol, cells, np.ones(3, bool))
+    got, want = rows_as_sets(nb, num, sh), oracle_sets(ref, rsh, 192)
+    assert sum(len(set(a) ^ set(b)) for a, b in zip(got, want)) <= 2
+    assert all(j < 96 for r in got[:96] for (j, *_x) in r) and all(j >= 96 for r in got[96:] for (j, *_x) in r)

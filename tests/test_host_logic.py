@@ -1,0 +1,167 @@
+"""Host-side calculator logic (layouts, validation, warnings, Coulomb switching) with a recording
+fake in place of the HIP engine - the reference does the same with TinyLegacyModel /
+RecordingExternalCoulomb fakes (tests/test_calculator.py:15-196).  CPU only."""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from aimnetcentral_amd import calculator as calc_mod
+from aimnetcentral_amd import loader, workloads
+
+
+class FakeEngine:
+    """Records eval() calls and returns recognisable tensors; stands in for HipEngine."""
+
+    def __init__(self, spec, device):
+        self.spec, self.device, self.calls = spec, torch.device("cpu"), []
+
+    def eval(self, coord, numbers, mol_idx, charge, cell=None, pbc=(True, True, True), forces=False, stress=False,
+             coulomb="simple", dsf_rc=15.0, dsf_alpha=0.2, sync=True):
+        self.calls.append(dict(n=coord.shape[0], n_mol=charge.shape[0], coulomb=coulomb, dsf_rc=dsf_rc, dsf_alpha=dsf_alpha,
+                               pbc=pbc, cell=None if cell is None else tuple(cell.shape), mol_idx=mol_idx.clone(),
+                               numbers=numbers.clone()))
+        n = coord.shape[0]
+        out = {"energy": torch.arange(charge.shape[0], dtype=torch.float64), "charges": torch.arange(n, dtype=torch.float32) + 1}
+        if forces:
+            out["forces"] = torch.ones(n, 3) * (torch.arange(n, dtype=torch.float32) + 1).unsqueeze(-1)
+        if stress:
+            out["stress"] = torch.zeros(3, 3) if cell is not None and cell.ndim == 2 else torch.zeros(charge.shape[0], 3, 3)
+        return out
+
+
+@pytest.fixture()
+def calc(monkeypatch):
+    monkeypatch.setattr(calc_mod, "HipEngine", FakeEngine)
+    monkeypatch.setattr(torch, "as_tensor", _as_tensor_cpu(torch.as_tensor))
+    c = calc_mod.AIMNet2Calculator(loader.synthetic_spec(0), device="cuda")
+    c.device = "cpu"
+    return c
+
+
+def _as_tensor_cpu(orig):
+    def f(data, dtype=None, device=None):
+        return orig(data, dtype=dtype, device="cpu")
+
+    return f
+
+
+WATER = dict(coord=[[0.0, 0.0, 0.1173], [0.0, 0.7572, -0.4692], [0.0, -0.7572, -0.4692]], numbers=[8, 1, 1], charge=0.0)
+
+
+def test_cpu_device_is_refused():
+    from aimnetcentral_amd import HipLibraryError
+
+    with pytest.raises(HipLibraryError):
+        calc_mod.AIMNet2Calculator(loader.synthetic_spec(0), device="cpu")
+
+
+def test_missing_keys_raise_keyerror(calc):
+    for k in ("coord", "numbers", "charge"):
+        d = dict(WATER)
+        d.pop(k)
+        with pytest.raises(KeyError, match=f"Missing key {k} in the input data"):
+            calc(d, validate_species=False)
+
+
+def test_flat_single_molecule(calc):
+    out = calc(WATER, forces=True)
+    call = calc.engine.calls[-1]
+    assert call["n"] == 3 and call["n_mol"] == 1 and call["coulomb"] == "simple" and call["cell"] is None
+    assert out["energy"].shape == (1,) and out["energy"].dtype == torch.float64
+    assert out["charges"].shape == (3,) and out["forces"].shape == (3, 3)
+    assert set(out) == {"energy", "charges", "forces"}
+
+
+def test_dense_padded_batch_is_compacted_and_restored(calc):
+    c, z, mol, q = workloads.random_batch(3, 4, 7, seed=1)
+    cp, zp = workloads.pad_batch(c, z, mol, 3)
+    out = calc({"coord": cp, "numbers": zp, "charge": q}, forces=True)
+    call = calc.engine.calls[-1]
+    assert call["n"] == len(z) and call["n_mol"] == 3
+    assert torch.equal(call["mol_idx"].long(), torch.from_numpy(mol))
+    assert torch.equal(call["numbers"].long(), torch.from_numpy(z))
+    B, N = zp.shape
+    assert out["forces"].shape == (B, N, 3) and out["charges"].shape == (B, N)
+    pad = torch.from_numpy(zp == 0)
+    assert (out["charges"][pad] == 0).all() and (out["forces"][pad] == 0).all()
+    assert (out["charges"][~pad] > 0).all()
+
+
+def test_species_and_charge_validation(calc):
+    bad = dict(WATER, numbers=[8, 1, 2])
+    with pytest.raises(ValueError, match=r"Atomic numbers \[2\]"):
+        calc(bad)
+    calc(bad, validate_species=False)
+    calc._metadata["supports_charged_systems"] = False
+    with pytest.raises(ValueError, match="net-charged"):
+        calc(dict(WATER, charge=1.0))
+    calc(dict(WATER, charge=1.0), validate_species=False)
+
+
+def test_mult_warning_once(calc):
+    with pytest.warns(UserWarning, match="mult"):
+        calc(dict(WATER, mult=2.0))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        calc(dict(WATER, mult=2.0))
+
+
+def test_pbc_switches_to_dsf_for_one_eval_and_restores(calc):
+    cell = np.eye(3, dtype=np.float32) * 12.0
+    with pytest.warns(UserWarning, match="Switching to DSF Coulomb for PBC"):
+        out = calc(dict(WATER, cell=cell), forces=True, stress=True)
+    call = calc.engine.calls[-1]
+    assert call["coulomb"] == "dsf" and call["dsf_rc"] == 15.0 and call["cell"] == (3, 3)
+    assert out["stress"].shape == (3, 3)
+    assert calc.coulomb_method == "simple" and calc.coulomb_cutoff == float("inf")
+    calc.set_lrcoulomb_method("dsf", cutoff=9.0, dsf_alpha=0.25)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        calc(dict(WATER, cell=cell), forces=True)
+    call = calc.engine.calls[-1]
+    assert call["dsf_rc"] == 9.0 and call["dsf_alpha"] == 0.25 and calc.coulomb_method == "dsf"
+
+
+def test_setters_and_unsupported_paths(calc):
+    with pytest.raises(ValueError, match="Invalid method"):
+        calc.set_lrcoulomb_method("nope")
+    with pytest.raises(NotImplementedError):
+        calc.set_lrcoulomb_method("ewald")
+    with pytest.raises(AssertionError):
+        calc(WATER, stress=True)
+    with pytest.raises(NotImplementedError):
+        calc(WATER, hessian=True)
+    with pytest.raises(NotImplementedError):
+        calc.hessian_vector_product(WATER, torch.zeros(3, 3))
+    x = torch.tensor(WATER["coord"], requires_grad=True)
+    with pytest.raises(NotImplementedError, match="requires grad"):
+        calc(dict(WATER, coord=x))
+    assert calc.has_external_coulomb and not calc.has_external_dftd3 and not calc.is_nse
+    assert calc.cutoff == 5.0 and calc.metadata["coulomb_mode"] == "sr_embedded"
+    with pytest.raises(TypeError):
+        calc.metadata["cutoff"] = 1.0
+
+
+def test_dispersion_request_is_loud(monkeypatch):
+    monkeypatch.setattr(calc_mod, "HipEngine", FakeEngine)
+    spec = loader.synthetic_spec(0)
+    spec.metadata = dict(spec.metadata, needs_dispersion=True, d3_params={"s8": 0.39, "a1": 0.57, "a2": 3.1, "s6": 1.0})
+    with pytest.raises(NotImplementedError, match="DFT-D3"):
+        calc_mod.AIMNet2Calculator(spec, device="cuda")
+    calc_mod.AIMNet2Calculator(spec, device="cuda", needs_dispersion=False)
+
+
+def test_workloads_are_deterministic_and_sized():
+    c, z, cell = workloads.glucose_supercell((7, 3, 5))
+    assert c.shape == (10080, 3) and sorted(set(z.tolist())) == [1, 6, 8]
+    assert abs(abs(np.linalg.det(cell)) - 739.36 * 105) / (739.36 * 105) < 1e-3
+    c1 = workloads.random_batch(4, 20, 60, seed=2)
+    c2 = workloads.random_batch(4, 20, 60, seed=2)
+    assert all(np.array_equal(a, b) for a, b in zip(c1, c2))
+    d = np.linalg.norm(c1[0][:, None] - c1[0][None], axis=-1) + np.eye(len(c1[0])) * 9
+    same = c1[2][:, None] == c1[2][None]
+    assert d[same].min() >= 0.9

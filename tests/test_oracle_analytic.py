@@ -1,0 +1,56 @@
+"""The hand-derived analytic backward (the specification of the HIP kernels) against the autograd
+oracle, in fp64 where both must agree to round-off."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import aimnet2_analytic as AN
+from oracle import aimnet2_oracle as O
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("batch5", {}),
+    ("pbc96_dsf8_wrapped", {"coulomb": "dsf", "dsf_rc": 8.0, "dsf_alpha": 0.25}),
+    ("pbc2x96_dsf9", {"coulomb": "dsf", "dsf_rc": 9.0, "dsf_alpha": 0.2}),
+])
+def test_analytic_matches_autograd_fp64(oracle64, name, kw):
+    g = golden(name)
+    mol = g["mol_idx"] if "mol_idx" in g.files else np.zeros(len(g["numbers"]), dtype=np.int64)
+    cell = g["cell"] if "cell" in g.files else None
+    ref = O.evaluate(oracle64, g["coord"], g["numbers"], g["charge"], mol, cell=cell, stress=cell is not None,
+                     return_intermediates=True, **kw)
+    xw = ref["coord_wrapped"]
+    if cell is None:
+        nbl, shl = O.neighbor_list(xw, float("inf"), mol)
+        coul = "simple"
+    else:
+        nbl, shl = O.neighbor_list(xw, kw["dsf_rc"], mol, cell, np.ones(3, bool))
+        coul = "dsf"
+    a = AN.evaluate(oracle64, xw, g["numbers"], g["charge"], mol, ref["nbmat"], ref.get("shifts"), cell, coulomb=coul,
+                    nbmat_lr=nbl, shifts_lr=shl, stress=cell is not None,
+                    **{k: v for k, v in kw.items() if k != "coulomb"})
+    assert np.abs(a["energy"] - ref["energy"]).max() < 1e-9
+    assert np.abs(a["charges"] - ref["charges"]).max() < 1e-12
+    assert np.abs(a["forces"] - ref["forces"]).max() < 1e-10
+    if cell is not None:
+        assert np.abs(a["stress"] - ref["stress"]).max() < 1e-12
+
+
+def test_forces_are_energy_gradient_fd(oracle64):
+    """central finite difference of the fp64 oracle energy (the reference's own FD check is
+    tests/test_pbc.py:1054-1107 at 5e-2; fp64 lets us be much tighter)."""
+    g = golden("batch5")
+    sel = g["mol_idx"] == 0
+    c, z = g["coord"][sel].astype(np.float64), g["numbers"][sel]
+    r0 = O.evaluate(oracle64, c, z, 0.0)
+    h = 1e-4
+    for (i, k) in [(0, 0), (3, 1), (5, 2)]:
+        cp, cm = c.copy(), c.copy()
+        cp[i, k] += h
+        cm[i, k] -= h
+        ep = O.evaluate(oracle64, cp.astype(np.float32).astype(np.float64), z, 0.0, forces=False)["energy"][0]
+        em = O.evaluate(oracle64, cm.astype(np.float32).astype(np.float64), z, 0.0, forces=False)["energy"][0]
+        hp = float(cp.astype(np.float32)[i, k]) - float(cm.astype(np.float32)[i, k])
+        assert abs(-(ep - em) / hp - r0["forces"][i, k]) < 5e-4

@@ -1,0 +1,98 @@
+"""The oracle (oracle/aimnet2_oracle.py) against golden vectors produced by the UNMODIFIED
+reference (tests/golden/make_golden.py).  This is what pins the oracle; CPU only."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from conftest import CHARGE_ATOL, STRESS_ATOL, assert_forces_close, energy_tol, golden
+from oracle import aimnet2_oracle as O
+
+
+def _mol(g):
+    return g["mol_idx"] if "mol_idx" in g.files else np.zeros(len(g["numbers"]), dtype=np.int64)
+
+
+def _check(res, g, sizes):
+    assert np.abs(res["energy"] - g["energy"]).max() <= energy_tol(sizes)
+    assert_forces_close(res["forces"], g["forces"])
+    assert np.abs(res["charges"] - g["charges"]).max() <= CHARGE_ATOL
+    if "stress" in g.files:
+        assert np.abs(res["stress"] - g["stress"]).max() <= STRESS_ATOL
+
+
+def test_weights_digest(synth_sd):
+    from aimnetcentral_amd import synth
+
+    g = golden("taxol")
+    assert synth.state_dict_digest(synth_sd) == str(g["weights_digest"]), "synthetic weights differ from the golden run"
+
+
+def test_taxol_config1(oracle32):
+    g = golden("taxol")
+    res = O.evaluate(oracle32, g["coord"], g["numbers"], g["charge"], return_intermediates=True)
+    _check(res, g, 113)
+    # bit-level agreement of the charge path and of the reference's own intermediates
+    assert np.abs(res["charges"] - g["charges"]).max() < 1e-6
+    for p in range(3):
+        assert np.abs(res[f"_mlp{p}_out"][:8] - g[f"mlp{p}_out_head"]).max() < 2e-5
+    assert res["nbmat"].shape[1] == int(g["nnb"])
+
+
+def test_ragged_charged_batch(oracle32):
+    g = golden("batch5")
+    res = O.evaluate(oracle32, g["coord"], g["numbers"], g["charge"], g["mol_idx"])
+    _check(res, g, np.bincount(g["mol_idx"]))
+    # charge conservation per molecule (ops.nse)
+    tot = np.zeros(5)
+    np.add.at(tot, g["mol_idx"], res["charges"])
+    assert np.abs(tot - g["charge"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("name", ["pbc96_dsf15", "pbc96_dsf8_wrapped", "pbc2x96_dsf9"])
+def test_periodic_dsf_stress(oracle32, name):
+    g = golden(name)
+    res = O.evaluate(oracle32, g["coord"], g["numbers"], g["charge"], _mol(g), cell=g["cell"], coulomb="dsf",
+                     dsf_rc=float(g["dsf_rc"]), dsf_alpha=float(g["dsf_alpha"]), stress=True)
+    _check(res, g, 96)
+
+
+def test_edge_cases(oracle32):
+    g = golden("edge")
+    r = O.evaluate(oracle32, np.zeros((1, 3), np.float32), np.array([8]), 0.0)
+    assert abs(r["energy"][0] - g["single_energy"][0]) < 1e-5 and np.abs(r["forces"]).max() == 0.0
+    r = O.evaluate(oracle32, g["water3_coord"], np.array([8, 1, 1]), 3.0)
+    assert abs(r["energy"][0] - g["water3_energy"][0]) < 1e-5
+    assert_forces_close(r["forces"], g["water3_forces"])
+    assert abs(r["charges"].sum() - 3.0) < 1e-5
+    r = O.evaluate(oracle32, g["close_coord"], np.array([6, 1, 1]), 0.0)
+    assert np.isfinite(r["forces"]).all()
+    assert abs(r["energy"][0] - g["close_energy"][0]) < 1e-4
+    assert_forces_close(r["forces"], g["close_forces"])
+
+
+def test_dense_batch_flattened(oracle32):
+    g = golden("dense3x14")
+    B, N = g["numbers"].shape
+    mol = np.repeat(np.arange(B), N)
+    res = O.evaluate(oracle32, g["coord"].reshape(-1, 3), g["numbers"].reshape(-1), g["charge"], mol)
+    assert np.abs(res["energy"] - g["energy"]).max() <= energy_tol(N)
+    assert_forces_close(res["forces"].reshape(B, N, 3), g["forces"])
+
+
+def test_reference_known_answer_distances():
+    """REF_DIJ_SUM / REF_DIJ_01 of the reference's tests/test_torch_version_numerics.py:16-17
+    (water, dense mode: all ordered pairs incl. the masked diagonal r=(1,1,1))."""
+    import torch
+
+    coord = torch.tensor([[0.0, 0.0, 0.1173], [0.0, 0.7572, -0.4692], [0.0, -0.7572, -0.4692]])
+    r = coord.unsqueeze(0) - coord.unsqueeze(1)
+    r = r.masked_fill(torch.eye(3, dtype=torch.bool).unsqueeze(-1), 1.0)
+    d = torch.linalg.vector_norm(r, dim=-1)
+    assert d.double().sum().item() == pytest.approx(12.056054711341858, rel=1e-12)
+    assert d[0, 1].double().item() == pytest.approx(0.9577755928039551, rel=1e-12)
+    # the same numbers through the oracle's mode-1 distance routine
+    nb, _ = O.neighbor_list(coord.numpy(), float("inf"), np.zeros(3, dtype=np.int64))
+    cp = torch.cat([coord, torch.zeros(1, 3)])
+    dd, _, mask = O._distances(cp, torch.as_tensor(nb), None, None, torch.zeros(4, dtype=torch.long))
+    assert dd[0][~mask[0]].double().min().item() == pytest.approx(0.9577755928039551, rel=1e-6)

@@ -1,0 +1,163 @@
+"""AIMNet2ASE - ASE calculator adapter over the native AIMNet2Calculator.
+
+Observable contract of aimnet/calculators/aimnet2ase.py:35-274 of the reference:
+implemented_properties, species check in set_atoms, atoms.info["charge"] precedence and cache
+invalidation, non-periodic systems passed as a 3-D batch of one, periodic systems flat with
+cell + pbc, results {energy (float), charges, dipole_moment (sum q r on the host), forces?, stress?}.
+Pure host code; needs `ase` at run time (absent in the build image -> a minimal stand-in base class
+with the same `calculate/reset/check_state` protocol is used so that the adapter stays testable
+with any Atoms-like object exposing numbers, positions, cell, pbc, info).
+"""
+from __future__ import annotations
+
+from typing import ClassVar
+
+import numpy as np
+
+try:  # pragma: no cover - ase is an optional extra
+    from ase.calculators.calculator import Calculator, PropertyNotImplementedError, all_changes
+    HAVE_ASE = True
+except ImportError:
+    HAVE_ASE = False
+    all_changes = ["positions", "numbers", "cell", "pbc", "initial_charges", "initial_magmoms", "info"]
+
+    class PropertyNotImplementedError(NotImplementedError):
+        pass
+
+    class Calculator:
+        """Smallest subset of ase.calculators.calculator.Calculator the adapter relies on."""
+
+        def __init__(self, *a, **k):
+            self.results = {}
+            self.atoms = None
+
+        def reset(self):
+            self.results = {}
+
+        def check_state(self, atoms, tol=1e-15):
+            old = self.atoms
+            if old is None:
+                return list(all_changes)
+            changes = []
+            if len(old.numbers) != len(atoms.numbers) or (np.asarray(old.numbers) != np.asarray(atoms.numbers)).any():
+                changes.append("numbers")
+            elif np.abs(np.asarray(old.positions) - np.asarray(atoms.positions)).max(initial=0.0) > tol:
+                changes.append("positions")
+            return changes
+
+        def calculate(self, atoms=None, properties=None, system_changes=None):
+            if atoms is not None:
+                self.atoms = _copy_atoms(atoms)
+
+
+def _copy_atoms(atoms):
+    return atoms.copy() if hasattr(atoms, "copy") else atoms
+
+
+def _cell_array(atoms):
+    cell = getattr(atoms, "cell", None)
+    if cell is None:
+        return None
+    return np.asarray(cell.array if hasattr(cell, "array") else cell, dtype=np.float64)
+
+
+class AIMNet2ASE(Calculator):
+    implemented_properties: ClassVar[list[str]] = ["energy", "forces", "free_energy", "charges", "stress", "dipole_moment"]
+
+    def __init__(self, base_calc="aimnet2", charge=0, mult=1, validate_species: bool = True):
+        from .calculator import AIMNet2Calculator
+
+        super().__init__()
+        if isinstance(base_calc, str):
+            base_calc = AIMNet2Calculator(base_calc)
+        self.base_calc = base_calc
+        self.validate_species = validate_species
+        self.reset()
+        self.charge = charge
+        self.mult = mult
+        meta = base_calc.metadata
+        species = meta.get("implemented_species") if meta is not None else None
+        self.implemented_species = np.array(species, dtype=np.int64) if species else None
+
+    def reset(self):
+        super().reset()
+        self._numbers = None
+
+    def set_atoms(self, atoms):
+        if self.implemented_species is not None and not np.isin(atoms.numbers, self.implemented_species).all():
+            raise ValueError("Some species are not implemented in the AIMNet2Calculator")
+        self.reset()
+        self.atoms = atoms
+
+    def check_state(self, atoms, tol=1e-15):
+        state = super().check_state(atoms, tol=tol)
+        if (not state) and getattr(self, "atoms", None) is not None:
+            if getattr(self.atoms, "info", {}).get("charge") != getattr(atoms, "info", {}).get("charge"):
+                state.append("info")
+        return state
+
+    def set_charge(self, charge):
+        self.charge = charge
+
+    def set_mult(self, mult):
+        self.mult = mult
+
+    def _charge_from_info(self, atoms):
+        charge = getattr(atoms, "info", {}).get("charge")
+        if charge is not None and charge != self.charge:
+            self.charge = charge
+
+    def get_dipole_moment(self, atoms=None):
+        atoms = self.atoms if atoms is None else atoms
+        return np.sum(np.asarray(self.results["charges"])[:, None] * np.asarray(atoms.positions), axis=0)
+
+    def get_spin_charges(self, atoms=None):
+        raise PropertyNotImplementedError("spin_charges is not available. Use an NSE model.")
+
+    def get_hessian(self, atoms=None):
+        atoms = getattr(self, "atoms", None) if atoms is None else atoms
+        if atoms is None:
+            raise PropertyNotImplementedError("get_hessian() requires an attached Atoms object or an explicit argument.")
+        if np.asarray(atoms.pbc).any():
+            raise PropertyNotImplementedError("Hessian for periodic systems is not supported by AIMNet2ASE.get_hessian().")
+        self._charge_from_info(atoms)
+        res = self.base_calc({"coord": np.asarray(atoms.positions, dtype=np.float32), "numbers": np.asarray(atoms.numbers),
+                              "charge": float(self.charge), "mult": float(self.mult)}, forces=True, hessian=True,
+                             validate_species=self.validate_species)
+        H = res["hessian"].detach()
+        n = H.shape[0]
+        return H.reshape(n * 3, n * 3).cpu().numpy()
+
+    def calculate(self, atoms=None, properties=None, system_changes=all_changes):
+        if properties is None:
+            properties = ["energy"]
+        super().calculate(atoms, properties, system_changes)
+        self._charge_from_info(self.atoms)
+        pbc = np.asarray(self.atoms.pbc, dtype=bool)
+        cell = _cell_array(self.atoms) if pbc.any() else None
+        coord = np.asarray(self.atoms.positions, dtype=np.float32)
+        numbers = np.asarray(self.atoms.numbers)
+        data = {"coord": coord, "numbers": numbers, "charge": np.float32(self.charge), "mult": np.float32(self.mult)}
+        batched = cell is None
+        if batched:  # non-periodic: a 3-D batch of one (aimnet2ase.py:248-251)
+            data = {"coord": coord[None], "numbers": numbers[None], "charge": np.array([self.charge], np.float32),
+                    "mult": np.array([self.mult], np.float32)}
+        else:
+            data["cell"] = cell.astype(np.float32)
+            data["pbc"] = pbc
+        out = self.base_calc(data, forces="forces" in properties, stress="stress" in properties,
+                             validate_species=self.validate_species)
+        res = {}
+        for k, v in out.items():
+            v = v.detach().cpu().numpy()
+            if batched and k in ("charges", "forces"):
+                v = v[0]
+            res[k] = v
+        self.results["energy"] = float(np.asarray(res["energy"]).reshape(-1)[0])
+        self.results["free_energy"] = self.results["energy"]
+        self.results["charges"] = res["charges"]
+        self.results["dipole_moment"] = self.get_dipole_moment(self.atoms)
+        if "forces" in properties:
+            self.results["forces"] = res["forces"]
+        if "stress" in properties:
+            self.results["stress"] = res["stress"]

@@ -165,3 +165,38 @@ def test_workloads_are_deterministic_and_sized():
     d = np.linalg.norm(c1[0][:, None] - c1[0][None], axis=-1) + np.eye(len(c1[0])) * 9
     same = c1[2][:, None] == c1[2][None]
     assert d[same].min() >= 0.9
+
+
+class _Atoms:
+    def __init__(self, numbers, positions, cell=None, pbc=(False, False, False), info=None):
+        self.numbers, self.positions = np.asarray(numbers), np.asarray(positions, dtype=float)
+        self.cell, self.pbc, self.info = cell, np.asarray(pbc), dict(info or {})
+
+    def copy(self):
+        return _Atoms(self.numbers.copy(), self.positions.copy(), None if self.cell is None else np.array(self.cell), self.pbc.copy(), self.info)
+
+    def __len__(self):
+        return len(self.numbers)
+
+
+def test_ase_adapter_contract(calc):
+    from aimnetcentral_amd.aimnet2ase import AIMNet2ASE
+
+    ase_calc = AIMNet2ASE(calc, charge=0)
+    atoms = _Atoms(WATER["numbers"], WATER["coord"], info={"charge": 1})
+    ase_calc.calculate(atoms, properties=["energy", "forces"])
+    call = calc.engine.calls[-1]
+    assert call["n"] == 3 and call["n_mol"] == 1 and call["cell"] is None
+    assert ase_calc.charge == 1  # atoms.info["charge"] wins (aimnet2ase.py:112-135)
+    r = ase_calc.results
+    assert isinstance(r["energy"], float) and r["forces"].shape == (3, 3) and r["charges"].shape == (3,)
+    assert np.allclose(r["dipole_moment"], (r["charges"][:, None] * atoms.positions).sum(0))
+    assert "stress" not in r
+    with pytest.raises(ValueError, match="not implemented"):
+        ase_calc.set_atoms(_Atoms([8, 1, 2], WATER["coord"]))
+    # periodic: flat input with cell + pbc, DSF auto-switch warning from the calculator
+    patoms = _Atoms(WATER["numbers"], WATER["coord"], cell=np.eye(3) * 12.0, pbc=(True, True, True))
+    with pytest.warns(UserWarning, match="Switching to DSF"):
+        ase_calc.calculate(patoms, properties=["energy", "forces", "stress"])
+    assert calc.engine.calls[-1]["cell"] == (3, 3) and ase_calc.results["stress"].shape == (3, 3)
+    assert sorted(AIMNet2ASE.implemented_properties) == sorted(["energy", "forces", "free_energy", "charges", "stress", "dipole_moment"])

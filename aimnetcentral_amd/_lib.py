@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "aimnet_engine_debug_view",
     "aimnet_engine_set_profiling",
     "aimnet_engine_profile_read",
+    "aimnet_debug_gemm",
     "aimnet_neighbor_list",
     "aimnet_neighbor_list_workspace_bytes",
     "aimnet_conv_sv_2d_sp_fwd",
@@ -136,6 +137,8 @@ def load() -> C.CDLL:
     lib.aimnet_engine_set_profiling.argtypes = [vp, C.c_int]
     lib.aimnet_engine_profile_read.restype = C.c_int
     lib.aimnet_engine_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.c_int]
+    lib.aimnet_debug_gemm.restype = C.c_int
+    lib.aimnet_debug_gemm.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
     lib.aimnet_neighbor_list_workspace_bytes.restype = sz
     lib.aimnet_neighbor_list_workspace_bytes.argtypes = [i32, i32, i32]
     lib.aimnet_neighbor_list.restype = C.c_int

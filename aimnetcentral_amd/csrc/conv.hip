@@ -98,8 +98,12 @@ struct FwdWaveLds {
   float qj[64];
 };
 
+// `row_of` (may be NULL): feature row of atom j inside `a`.  Pass 0 gathers straight from the
+// embedding table (a = afv, row_of = atomic numbers): the whole "feature table" is then a few KiB
+// that live in L1 instead of a 1 KiB-per-pair trip to L2 / Infinity Cache.
 template <bool HAS_Q>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__ a, const float* __restrict__ q,
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
+                                                      const float* __restrict__ q,
                                                       const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
                                                       const float4* __restrict__ pg, int cap,
                                                       const float* __restrict__ agh_a, const float* __restrict__ agh_q,
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
       if (lane < nch) {
         const size_t p = (size_t)i * cap + c0 + lane;
         const int j = nb_idx[p];
-        L.j[lane] = j;
+        L.j[lane] = row_of ? min(63, max(0, row_of[j])) : j;
         L.ud[lane] = pg[p];
         if (HAS_Q) L.qj[lane] = q[j];
       }
@@ -189,7 +193,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
       }
       if (HAS_Q && (lane & 3) != 0) sv[768 + (lane >> 2) * 3 + (lane & 3) - 1] = accq;
       float* xr = x + (size_t)i * ldx;
-      reinterpret_cast<float4*>(xr)[lane] = reinterpret_cast<const float4*>(a + (size_t)i * NF)[lane];
+      const int ri = row_of ? min(63, max(0, row_of[i])) : i;
+      reinterpret_cast<float4*>(xr)[lane] = reinterpret_cast<const float4*>(a + (size_t)ri * NF)[lane];
       reinterpret_cast<float4*>(xr + NF)[lane] = make_float4(acc[0][0], acc[1][0], acc[2][0], acc[3][0]);
     }
     __syncthreads();
@@ -239,16 +244,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
   }
 }
 
-int launch_conv_fwd(hipStream_t s, bool has_q, const float* a, const float* q, const int* nb_idx, const int* nb_cnt,
-                    const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp, float* x,
-                    int ldx, float* Vsave, float* Vqsave, int n_atoms) {
+int launch_conv_fwd(hipStream_t s, bool has_q, const float* a, const int* row_of, const float* q, const int* nb_idx,
+                    const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
+                    float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms) {
   const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
   if (has_q)
-    hipLaunchKernelGGL(conv_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, a, q, nb_idx, nb_cnt, pg, cap, agh_a, agh_q, bp,
-                       x, ldx, Vsave, Vqsave, n_atoms);
+    hipLaunchKernelGGL(conv_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a,
+                       agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms);
   else
-    hipLaunchKernelGGL(conv_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, a, q, nb_idx, nb_cnt, pg, cap, agh_a, agh_q, bp,
-                       x, ldx, Vsave, Vqsave, n_atoms);
+    hipLaunchKernelGGL(conv_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a,
+                       agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

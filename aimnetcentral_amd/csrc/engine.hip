@@ -149,6 +149,8 @@ struct Workspace {
   float* e_atom;
   double* ecoul;
   float *qbar, *fgrad, *virial_atom, *abar, *Wbar;
+  double* part;  // per-(system, slice) partial sums of the molecule reductions
+  int S;         // slices per molecule
   float *zb0, *zb1;  // ping-pong adjoint buffers (N x max padded width)
   float *Sbar, *Sqbar;
   size_t total;
@@ -211,6 +213,8 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   W.fgrad = c.take<float>(n * 3, "fgrad", 3);
   W.virial_atom = c.take<float>(n * 9);
   W.Wbar = c.take<float>(n_mol);
+  W.S = std::min(128, std::max(1, (N / std::max(1, n_mol) + 511) / 512));
+  W.part = c.take<double>((size_t)n_mol * W.S * 9);
   if (grad) {
     const int mw = max_width(e);
     W.abar = c.take<float>(n * 256, "abar", 256);
@@ -430,8 +434,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const std::vector<Layer>& Ls = e->mlp[p];
     const int nl = (int)Ls.size();
     RC(prof_mark(e, s, FAM_CONV_FWD));
-    RC(launch_conv_fwd(s, p > 0, W.a[p], p > 0 ? W.q[p - 1] : nullptr, W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q,
-                       e->bp, W.x[p], Ls[0].k_in, W.V[p], W.Vq[p], N));
+    RC(launch_conv_fwd(s, p > 0, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr, p > 0 ? W.q[p - 1] : nullptr,
+                       W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q, e->bp, W.x[p], Ls[0].k_in, W.V[p], W.Vq[p], N));
     const float* hin = W.x[p];
     int ld_in = Ls[0].k_in;
     RC(prof_mark(e, s, FAM_GEMM));
@@ -445,7 +449,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     if (p < np - 1) {
       RC(prof_mark(e, s, FAM_POINTWISE));
       RC(launch_nse_fwd(s, W.H[p][nl - 1], Ls[nl - 1].k_out, p > 0 ? W.q[p - 1] : nullptr, W.nl.mol_start, in->charge,
-                        n_mol, W.q[p], W.Fm[p], W.Dm[p]));
+                        n_mol, W.S, (float*)W.part, W.q[p], W.Fm[p], W.Dm[p]));
       RC(launch_update_a(s, W.a[p], W.H[p][nl - 1], Ls[nl - 1].k_out, N, W.a[p + 1]));
     }
   }
@@ -482,7 +486,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     RC(launch_coulomb_dsf(s, grad, want_s, q_fin, W.nl.xw, in->mol_idx, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt,
                           cap_lr, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));
   RC(prof_mark(e, s, FAM_POINTWISE));
-  RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, out->energy));
+  RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, W.S, W.part, out->energy));
   RC(launch_copy_f32(s, q_fin, out->charges, (size_t)N));
   if (!grad) {
     RC(prof_mark(e, s, -1));
@@ -538,14 +542,14 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const float* y = W.H[p - 1][nlq - 1];
     const int ldy = Lq[nlq - 1].k_out;
     RC(prof_mark(e, s, FAM_POINTWISE));
-    RC(launch_nse_bwd_reduce(s, W.qbar, y, ldy, W.Fm[p - 1], W.nl.mol_start, n_mol, W.Wbar));
+    RC(launch_nse_bwd_reduce(s, W.qbar, y, ldy, W.Fm[p - 1], W.nl.mol_start, n_mol, W.S, (float*)W.part, W.Wbar));
     RC(launch_build_zbar(s, W.qbar, W.abar, y, ldy, ar.last_linear[p - 1] ? nullptr : W.D[p - 1][nlq - 1], W.Fm[p - 1],
                          W.Dm[p - 1], W.Wbar, in->mol_idx, N, 256, p - 1 > 0, znext, W.qbar));
     std::swap(zcur, znext);
   }
   RC(prof_mark(e, s, FAM_POINTWISE));
-  RC(launch_finalize(s, W.fgrad, W.virial_atom, W.nl.mol_start, in->cell, n_cell, n_mol, N, want_f ? out->forces : nullptr,
-                     want_s ? out->stress : nullptr));
+  RC(launch_finalize(s, W.fgrad, W.virial_atom, W.nl.mol_start, in->cell, n_cell, n_mol, N, W.S, W.part,
+                     want_f ? out->forces : nullptr, want_s ? out->stress : nullptr));
   RC(prof_mark(e, s, -1));
   return AIMNET_OK;
 }
@@ -604,6 +608,17 @@ int aimnet_neighbor_list(const float* coord, const int32_t* mol_idx, int32_t n_a
   if (coord_wrapped)
     AIMNET_HIP_CHECK(hipMemcpyAsync(coord_wrapped, nl.xw, (size_t)n_atoms * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
   return AIMNET_OK;
+}
+
+int aimnet_debug_gemm(int cfg, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
+                      const float* bias, float* C, float* D, int ldc, void* hip_stream) {
+  static bool attr = false;
+  if (!attr) {
+    int rc = gemm_set_attributes();
+    if (rc) return rc;
+    attr = true;
+  }
+  return launch_gemm_nt_cfg((hipStream_t)hip_stream, cfg, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
 }
 
 int aimnet_conv_sv_2d_sp_fwd(const float* a, const int32_t* idx, const float* g, float* out, int32_t B, int32_t A,

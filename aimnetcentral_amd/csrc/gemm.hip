@@ -10,13 +10,15 @@
 // xf32/TF32.  v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf chain at the fp32 vector peak
 // (157 TFLOP/s, MI355X_MICROARCH.md) and leaves the VALU free for the GELU epilogue.
 //
-// Tiling: 128x128x32 block tile, 256 threads = 2x2 waves, each wave 64x64 = 2x2 MFMA tiles of
-// 32x32 (64 accumulator VGPRs).  Both tiles are staged global -> VGPR -> LDS (padded rows, 36
+// Tiling: BM x BN x 32 block tile (64x64 or 128x128, see the kernel), 256 threads = 2x2 waves of
+// 32x32 MFMA tiles.  Both tiles are staged global -> VGPR -> LDS (padded rows, 36
 // floats, so the ds_read_b128 fragment reads are conflict free) with a 2-deep LDS ring: the
 // global loads of tile k+1 are in flight under the 64 MFMAs of tile k, one barrier per K tile.
 // K mapping inside an 8-wide k block: lane half h = lane>>5 owns k = 4h..4h+3, so one b128 read
 // feeds four consecutive MFMAs for A and for B alike (the MFMA only needs A and B to agree on
 // which k a lane half carries).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -24,13 +26,21 @@ namespace aimnet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = BK + 4;
+constexpr int BK = 32, LDS_LD = BK + 4;
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict__ A, int lda,
-                                                        const float* __restrict__ Bt, int ldb, int M, int N, int K,
-                                                        const float* __restrict__ bias, float* __restrict__ C,
-                                                        float* __restrict__ D, int ldc) {
+// BM x BN block tile, 256 threads = 2x2 waves, each wave (BM/2) x (BN/2) = MI x NI MFMA tiles of 32x32.
+//   64 x 64  : 1 MFMA tile per wave, 36 KiB LDS -> 4 blocks/CU.  Fine-grained: with M ~ 10^4 rows a layer
+//              has ~10^3 tiles, so the 256 CUs stay evenly loaded (a 128x128 grid of 316 tiles ran as
+//              "2 rounds" at 62 % utilisation, profiles/r1a).
+//   128 x 128: 2x2 MFMA tiles per wave, 72 KiB LDS -> 2 blocks/CU.  Half the L2->LDS traffic per FLOP;
+//              chosen when there are enough tiles to fill the chip many times over.
+template <int EPI, int BM, int BN>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_nt_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb, int M, int N, int K,
+    const float* __restrict__ bias, float* __restrict__ C, float* __restrict__ D, int ldc) {
+  constexpr int MI = BM / 64, NI = BN / 64;   // MFMA tiles per wave along M / N
+  constexpr int LA = BM / 32, LB = BN / 32;   // float4 staging loads per thread per K tile
+  constexpr int KB = BK / 8;                  // 8-wide k blocks per K tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                         // [2][BM][LDS_LD]
   float* Bs = smem + 2 * BM * LDS_LD;       // [2][BN][LDS_LD]
@@ -53,86 +63,119 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
   const int tile_n = wg % tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  float4 ra[4], rb[4];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int idx = tid + 256 * r;
-      const int row = idx >> 3, c4 = (idx & 7) << 2;
-      const int gm = m0 + row, gn = n0 + row;
-      ra[r] = (gm < M) ? *reinterpret_cast<const float4*>(A + (size_t)gm * lda + k0 + c4) : make_float4(0, 0, 0, 0);
-      rb[r] = (gn < N) ? *reinterpret_cast<const float4*>(Bt + (size_t)gn * ldb + k0 + c4) : make_float4(0, 0, 0, 0);
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int idx = tid + 256 * r;
-      const int row = idx >> 3, c4 = (idx & 7) << 2;
-      *reinterpret_cast<float4*>(As + (buf * BM + row) * LDS_LD + c4) = ra[r];
-      *reinterpret_cast<float4*>(Bs + (buf * BN + row) * LDS_LD + c4) = rb[r];
-    }
-  };
+  // staging: thread t moves float4 #t, #t+256, ... of each [rows][32] tile; rows past M / N are clamped
+  // (loaded, never stored) so the loads issue branch-free.  The staging registers are NAMED scalars
+  // (ra0..ra3 / rb0..rb3, guarded by if constexpr): as arrays hipcc kept them in scratch memory
+  // (scratch_store right behind every global_load, -45 % throughput).
+  const int srow = tid >> 3, sc4 = (tid & 7) << 2;
+  const float* const ga0 = A + (size_t)min(m0 + srow, M - 1) * lda + sc4;
+  const float* const ga1 = A + (size_t)min(m0 + srow + 32, M - 1) * lda + sc4;
+  const float* const ga2 = A + (size_t)min(m0 + srow + 64, M - 1) * lda + sc4;
+  const float* const ga3 = A + (size_t)min(m0 + srow + 96, M - 1) * lda + sc4;
+  const float* const gb0 = Bt + (size_t)min(n0 + srow, N - 1) * ldb + sc4;
+  const float* const gb1 = Bt + (size_t)min(n0 + srow + 32, N - 1) * ldb + sc4;
+  const float* const gb2 = Bt + (size_t)min(n0 + srow + 64, N - 1) * ldb + sc4;
+  const float* const gb3 = Bt + (size_t)min(n0 + srow + 96, N - 1) * ldb + sc4;
+  float* const sa = As + srow * LDS_LD + sc4;
+  float* const sb = Bs + srow * LDS_LD + sc4;
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+#define AIMNET_GLOAD(k0)                                                   \
+  do {                                                                     \
+    ra0 = *reinterpret_cast<const float4*>(ga0 + (k0));                    \
+    ra1 = *reinterpret_cast<const float4*>(ga1 + (k0));                    \
+    if constexpr (LA > 2) {                                                \
+      ra2 = *reinterpret_cast<const float4*>(ga2 + (k0));                  \
+      ra3 = *reinterpret_cast<const float4*>(ga3 + (k0));                  \
+    }                                                                      \
+    rb0 = *reinterpret_cast<const float4*>(gb0 + (k0));                    \
+    rb1 = *reinterpret_cast<const float4*>(gb1 + (k0));                    \
+    if constexpr (LB > 2) {                                                \
+      rb2 = *reinterpret_cast<const float4*>(gb2 + (k0));                  \
+      rb3 = *reinterpret_cast<const float4*>(gb3 + (k0));                  \
+    }                                                                      \
+  } while (0)
+#define AIMNET_LSTORE(buf)                                                                  \
+  do {                                                                                      \
+    *reinterpret_cast<float4*>(sa + ((buf)*BM) * LDS_LD) = ra0;                             \
+    *reinterpret_cast<float4*>(sa + ((buf)*BM + 32) * LDS_LD) = ra1;                        \
+    if constexpr (LA > 2) {                                                                 \
+      *reinterpret_cast<float4*>(sa + ((buf)*BM + 64) * LDS_LD) = ra2;                      \
+      *reinterpret_cast<float4*>(sa + ((buf)*BM + 96) * LDS_LD) = ra3;                      \
+    }                                                                                       \
+    *reinterpret_cast<float4*>(sb + ((buf)*BN) * LDS_LD) = rb0;                             \
+    *reinterpret_cast<float4*>(sb + ((buf)*BN + 32) * LDS_LD) = rb1;                        \
+    if constexpr (LB > 2) {                                                                 \
+      *reinterpret_cast<float4*>(sb + ((buf)*BN + 64) * LDS_LD) = rb2;                      \
+      *reinterpret_cast<float4*>(sb + ((buf)*BN + 96) * LDS_LD) = rb3;                      \
+    }                                                                                       \
+  } while (0)
+
+  AIMNET_GLOAD(0);
+  AIMNET_LSTORE(0);
+  __syncthreads();
 
   const int nk = K / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
-    const float* a_base = As + (buf * BM + wr * 64 + li) * LDS_LD + 4 * lh;
-    const float* b_base = Bs + (buf * BN + wc * 64 + li) * LDS_LD + 4 * lh;
+    const bool more = kt + 1 < nk;
+    if (more) AIMNET_GLOAD((kt + 1) * BK);
+    const float* a_base = As + (buf * BM + wr * (BM / 2) + li) * LDS_LD + 4 * lh;
+    const float* b_base = Bs + (buf * BN + wc * (BN / 2) + li) * LDS_LD + 4 * lh;
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      const float4 a0 = *reinterpret_cast<const float4*>(a_base + kk * 8);
-      const float4 a1 = *reinterpret_cast<const float4*>(a_base + 32 * LDS_LD + kk * 8);
-      const float4 b0 = *reinterpret_cast<const float4*>(b_base + kk * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(b_base + 32 * LDS_LD + kk * 8);
-      const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-      const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+    for (int kk = 0; kk < KB; ++kk) {
+      float4 af[MI], bf[NI];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv0[t], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv1[t], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv0[t], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv1[t], acc[1][1], 0, 0, 0);
-      }
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
     }
-    if (kt + 1 < nk) lstore(buf ^ 1);
+    if (more) AIMNET_LSTORE(buf ^ 1);
     __syncthreads();
   }
+#undef AIMNET_GLOAD
+#undef AIMNET_LSTORE
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n0 + wc * 64 + ni * 32 + li;
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = n0 + wc * (BN / 2) + ni * 32 + li;
       if (col >= N) continue;
-      float bv = 0.0f;
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bv = bias[col];
+      float bvv = 0.0f;
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bvv = bias[col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = m0 + wr * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row >= M) continue;
         const size_t o = (size_t)row * ldc + col;
         float v = acc[mi][ni][r];
         if (EPI == EPI_NONE) {
           C[o] = v;
         } else if (EPI == EPI_BIAS) {
-          C[o] = v + bv;
+          C[o] = v + bvv;
         } else if (EPI == EPI_BIAS_GELU) {
           float h, d;
-          gelu_and_grad(v + bv, h, d);
+          gelu_and_grad(v + bvv, h, d);
           C[o] = h;
           if (D) D[o] = d;
         } else {  // EPI_MUL: chain rule through the previous layer's GELU, D holds GELU'(z)
@@ -143,28 +186,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
   }
 }
 
-int launch_gemm_nt(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N,
-                   int K, const float* bias, float* C, float* D, int ldc) {
-  if (M <= 0) return 0;
-  if (K % BK != 0 || (lda & 3) || (ldb & 3)) {
-    set_last_error("gemm: K=%d must be a multiple of %d and lda/ldb multiples of 4", K, BK);
-    return -1;
-  }
+template <int BM, int BN>
+static int launch_cfg(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
+                      const float* bias, float* C, float* D, int ldc) {
   const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
-  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+  static const size_t pad = getenv("AIMNET_GEMM_LDS_PAD") ? (size_t)atoi(getenv("AIMNET_GEMM_LDS_PAD")) : 0;  // occupancy probe
+  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float) + pad;
   dim3 grid(tiles), block(256);
   switch (epi) {
     case EPI_NONE:
-      hipLaunchKernelGGL(gemm_nt_kernel<EPI_NONE>, grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, BM, BN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
       break;
     case EPI_BIAS:
-      hipLaunchKernelGGL(gemm_nt_kernel<EPI_BIAS>, grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_kernel<EPI_BIAS, BM, BN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
       break;
     case EPI_BIAS_GELU:
-      hipLaunchKernelGGL(gemm_nt_kernel<EPI_BIAS_GELU>, grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_kernel<EPI_BIAS_GELU, BM, BN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
       break;
     case EPI_MUL:
-      hipLaunchKernelGGL(gemm_nt_kernel<EPI_MUL>, grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_kernel<EPI_MUL, BM, BN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
       break;
     default:
       set_last_error("gemm: bad epilogue %d", epi);
@@ -174,13 +214,52 @@ int launch_gemm_nt(hipStream_t stream, int epi, const float* A, int lda, const f
   return 0;
 }
 
+static int g_force_tile = 0;  // 0 auto; 64, 128, 12864 (128x64), 64128 (64x128) from AIMNET_GEMM_TILE for A/B runs
+
+int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N,
+                       int K, const float* bias, float* C, float* D, int ldc) {
+  if (M <= 0) return 0;
+  if (K % BK != 0 || (lda & 3) || (ldb & 3)) {
+    set_last_error("gemm: K=%d must be a multiple of %d and lda/ldb multiples of 4", K, BK);
+    return -1;
+  }
+  if (cfg == 0) cfg = g_force_tile;
+  if (cfg == 0) {
+    // 128x128 tiles only when they alone would fill the 256 CUs (2 blocks each) ~8 times over
+    const long big_tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
+    cfg = big_tiles >= 4096 ? 128 : 64;
+  }
+  switch (cfg) {
+    case 128: return launch_cfg<128, 128>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    case 12864: return launch_cfg<128, 64>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    case 64128: return launch_cfg<64, 128>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    default: return launch_cfg<64, 64>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+  }
+}
+
+int launch_gemm_nt(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N,
+                   int K, const float* bias, float* C, float* D, int ldc) {
+  return launch_gemm_nt_cfg(stream, 0, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+}
+
+template <int BM, int BN>
+static int set_attr() {
+  const int lds = 160 * 1024;
+  AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_NONE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_BIAS, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_BIAS_GELU, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_MUL, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  return 0;
+}
+
 int gemm_set_attributes() {
-  // 72 KiB of dynamic LDS per block exceeds the 64 KiB default cap.
-  const int lds = 2 * (BM + BN) * LDS_LD * (int)sizeof(float);
-  AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  const char* env = getenv("AIMNET_GEMM_TILE");
+  g_force_tile = env ? atoi(env) : 0;
+  int rc;
+  if ((rc = set_attr<64, 64>())) return rc;
+  if ((rc = set_attr<128, 64>())) return rc;
+  if ((rc = set_attr<64, 128>())) return rc;
+  if ((rc = set_attr<128, 128>())) return rc;  // 72 KiB of dynamic LDS exceeds the 64 KiB default cap
   return 0;
 }
 

@@ -14,6 +14,8 @@ enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL = 3 };
 //   EPI_MUL:       C = acc * D
 int launch_gemm_nt(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N,
                    int K, const float* bias, float* C, float* D, int ldc);
+int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N,
+                       int K, const float* bias, float* C, float* D, int ldc);
 int gemm_set_attributes();
 
 // ---- nlist.hip --------------------------------------------------------------------------------
@@ -49,9 +51,9 @@ struct BasisParams {  // radial basis of AEVSV (aev.py:66-81), passed by value
 int launch_pair_geom(hipStream_t s, const float* xw, const int* mol_idx, const float* cell, int n_cell,
                      const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, int n_atoms, float4* pg);
 int launch_embed(hipStream_t s, const float* afv, const int* numbers, int n_atoms, float* a0);
-int launch_conv_fwd(hipStream_t s, bool has_q, const float* a, const float* q, const int* nb_idx, const int* nb_cnt,
-                    const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp, float* x,
-                    int ldx, float* Vsave, float* Vqsave, int n_atoms);
+int launch_conv_fwd(hipStream_t s, bool has_q, const float* a, const int* row_of, const float* q, const int* nb_idx,
+                    const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
+                    float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms);
 int launch_unconcat(hipStream_t s, bool has_q, const float* xbar, int ldx, const float* Vsave, const float* Vqsave,
                     const float* agh_a, const float* agh_q, float* Sbar, float* Sqbar, int n_atoms);
 int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, const float* a, const float* q,
@@ -65,14 +67,15 @@ int launch_conv_sv_bwd(hipStream_t s, const float* grad_out, const float* a, con
                        float* grad_a, float* grad_g, int B, int A, int G, int M);
 
 // ---- model.hip --------------------------------------------------------------------------------
+// S = slices (blocks) per molecule for the per-molecule reductions; `part` = scratch [n_sys * S * 9] doubles
 int launch_nse_fwd(hipStream_t s, const float* y, int ldy, const float* q_prev, const int* mol_start,
-                   const float* charge, int n_mol, float* q_new, float* Fm, float* Dm);
+                   const float* charge, int n_mol, int S, float* part, float* q_new, float* Fm, float* Dm);
 int launch_update_a(hipStream_t s, const float* a, const float* y, int ldy, int n_atoms, float* a_new);
 int launch_head_last(hipStream_t s, const float* h, int ldh, const float* w, const float* b, int k, int n_atoms,
                      float* e_atom);
 int launch_head_seed(hipStream_t s, const float* w, const float* d, int ldd, int k, int n_atoms, float* zbar);
 int launch_energy_reduce(hipStream_t s, const float* e_atom, const double* ecoul, const int* numbers,
-                         const double* sae, const int* mol_start, int n_mol, double* energy);
+                         const double* sae, const int* mol_start, int n_mol, int S, double* part, double* energy);
 struct CoulombParams {
   float factor;      // 1/2 Hartree Bohr
   float sr_rc;       // exp / cosine envelope radius (SRCoulomb)
@@ -91,12 +94,13 @@ int launch_coulomb_dsf(hipStream_t s, bool grad, bool stress, const float* q, co
                        int cap, CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad,
                        float* virial_atom);
 int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, const float* Fm,
-                          const int* mol_start, int n_mol, float* Wbar);
+                          const int* mol_start, int n_mol, int S, float* part, float* Wbar);
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
                       const float* Fm, const float* Dm, const float* Wbar, const int* mol_idx, int n_atoms, int n_feat,
                       bool carry_q, float* zbar, float* qbar_next);
 int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
-                    const float* cell, int n_cell, int n_mol, int n_atoms, float* forces, float* stress);
+                    const float* cell, int n_cell, int n_mol, int n_atoms, int S, double* part, float* forces,
+                    float* stress);
 int launch_copy_f32(hipStream_t s, const float* src, float* dst, size_t n);
 
 }  // namespace aimnet

@@ -55,9 +55,81 @@ __global__ __launch_bounds__(256) void nse_fwd_kernel(const float* __restrict__ 
   }
 }
 
+// Sliced variants for large molecules: S blocks per molecule write partial sums in a fixed layout,
+// every consumer adds the S partials in slice order -> still deterministic, but a 10k-atom
+// molecule is reduced by S blocks instead of one.
+__device__ __forceinline__ void slice_bounds(const int* __restrict__ mol_start, int m, int s, int S, int& lo, int& hi) {
+  const int i0 = mol_start[m], i1 = mol_start[m + 1];
+  const int L = (i1 - i0 + S - 1) / S;
+  lo = min(i1, i0 + s * L);
+  hi = min(i1, lo + L);
+}
+
+__global__ __launch_bounds__(256) void nse_fwd_partial_kernel(const float* __restrict__ y, int ldy,
+                                                             const float* __restrict__ q_prev,
+                                                             const int* __restrict__ mol_start, int S,
+                                                             float* __restrict__ part) {
+  __shared__ float sh[4];
+  const int m = blockIdx.y, sl = blockIdx.x;
+  int lo, hi;
+  slice_bounds(mol_start, m, sl, S, lo, hi);
+  float sf = 0.f, sq = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const float ft = y[(size_t)i * ldy + 1];
+    sf += ft * ft;
+    sq += (q_prev ? q_prev[i] : 0.0f) + y[(size_t)i * ldy];
+  }
+  sf = block_sum(sf, sh);
+  sq = block_sum(sq, sh);
+  if (threadIdx.x == 0) {
+    part[((size_t)m * S + sl) * 2 + 0] = sf;
+    part[((size_t)m * S + sl) * 2 + 1] = sq;
+  }
+}
+
+__global__ __launch_bounds__(256) void nse_fwd_apply_kernel(const float* __restrict__ y, int ldy,
+                                                           const float* __restrict__ q_prev,
+                                                           const int* __restrict__ mol_start,
+                                                           const float* __restrict__ charge, int S,
+                                                           const float* __restrict__ part, float* __restrict__ q_new,
+                                                           float* __restrict__ Fm, float* __restrict__ Dm) {
+  __shared__ float shFD[2];
+  const int m = blockIdx.y, sl = blockIdx.x;
+  if (threadIdx.x == 0) {
+    float sf = 0.f, sq = 0.f;
+    for (int k = 0; k < S; ++k) {
+      sf += part[((size_t)m * S + k) * 2 + 0];
+      sq += part[((size_t)m * S + k) * 2 + 1];
+    }
+    shFD[0] = sf + 1.0e-6f;
+    shFD[1] = charge[m] - sq;
+    if (sl == 0) {
+      Fm[m] = shFD[0];
+      Dm[m] = shFD[1];
+    }
+  }
+  __syncthreads();
+  const float F = shFD[0], D = shFD[1];
+  int lo, hi;
+  slice_bounds(mol_start, m, sl, S, lo, hi);
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const float ft = y[(size_t)i * ldy + 1];
+    const float qr = (q_prev ? q_prev[i] : 0.0f) + y[(size_t)i * ldy];
+    q_new[i] = qr + (ft * ft) / F * D;
+  }
+}
+
 int launch_nse_fwd(hipStream_t s, const float* y, int ldy, const float* q_prev, const int* mol_start,
-                   const float* charge, int n_mol, float* q_new, float* Fm, float* Dm) {
-  hipLaunchKernelGGL(nse_fwd_kernel, dim3(n_mol), dim3(256), 0, s, y, ldy, q_prev, mol_start, charge, q_new, Fm, Dm);
+                   const float* charge, int n_mol, int S, float* part, float* q_new, float* Fm, float* Dm) {
+  if (S <= 1) {
+    hipLaunchKernelGGL(nse_fwd_kernel, dim3(n_mol), dim3(256), 0, s, y, ldy, q_prev, mol_start, charge, q_new, Fm, Dm);
+    AIMNET_LAUNCH_CHECK();
+    return 0;
+  }
+  hipLaunchKernelGGL(nse_fwd_partial_kernel, dim3(S, n_mol), dim3(256), 0, s, y, ldy, q_prev, mol_start, S, part);
+  AIMNET_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nse_fwd_apply_kernel, dim3(S, n_mol), dim3(256), 0, s, y, ldy, q_prev, mol_start, charge, S, part, q_new,
+                     Fm, Dm);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }
@@ -112,27 +184,43 @@ int launch_head_seed(hipStream_t s, const float* w, const float* d, int ldd, int
   return 0;
 }
 
-__global__ __launch_bounds__(256) void energy_reduce_kernel(const float* __restrict__ e_atom,
-                                                           const double* __restrict__ ecoul,
-                                                           const int* __restrict__ numbers,
-                                                           const double* __restrict__ sae,
-                                                           const int* __restrict__ mol_start, double* __restrict__ energy) {
+__global__ __launch_bounds__(256) void energy_partial_kernel(const float* __restrict__ e_atom,
+                                                            const double* __restrict__ ecoul,
+                                                            const int* __restrict__ numbers,
+                                                            const double* __restrict__ sae,
+                                                            const int* __restrict__ mol_start, int S,
+                                                            double* __restrict__ part) {
   __shared__ double sh[4];
-  const int m = blockIdx.x;
-  const int i0 = mol_start[m], i1 = mol_start[m + 1];
+  const int m = blockIdx.y, sl = blockIdx.x;
+  int lo, hi;
+  slice_bounds(mol_start, m, sl, S, lo, hi);
   double acc = 0.0;
-  for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const int z = min(63, max(0, numbers[i]));
     acc += (double)e_atom[i] + sae[z] + ecoul[i];
   }
   const double r = block_sum(acc, sh);
-  if (threadIdx.x == 0) energy[m] = r;
+  if (threadIdx.x == 0) part[(size_t)m * S + sl] = r;
+}
+
+__global__ void energy_finish_kernel(const double* __restrict__ part, int S, int n_mol, double* __restrict__ energy) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_mol) return;
+  double r = 0.0;
+  for (int k = 0; k < S; ++k) r += part[(size_t)m * S + k];
+  energy[m] = r;
 }
 
 int launch_energy_reduce(hipStream_t s, const float* e_atom, const double* ecoul, const int* numbers,
-                         const double* sae, const int* mol_start, int n_mol, double* energy) {
-  hipLaunchKernelGGL(energy_reduce_kernel, dim3(n_mol), dim3(256), 0, s, e_atom, ecoul, numbers, sae, mol_start, energy);
+                         const double* sae, const int* mol_start, int n_mol, int S, double* part, double* energy) {
+  S = S < 1 ? 1 : S;
+  hipLaunchKernelGGL(energy_partial_kernel, dim3(S, n_mol), dim3(256), 0, s, e_atom, ecoul, numbers, sae, mol_start, S,
+                     S == 1 ? energy : part);
   AIMNET_LAUNCH_CHECK();
+  if (S > 1) {
+    hipLaunchKernelGGL(energy_finish_kernel, dim3(ceil_div(n_mol, 64)), dim3(64), 0, s, part, S, n_mol, energy);
+    AIMNET_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -360,24 +448,37 @@ int launch_coulomb_dsf(hipStream_t s, bool grad, bool stress, const float* q, co
 }
 
 // ---- NSE backward --------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nse_bwd_reduce_kernel(const float* __restrict__ qbar, const float* __restrict__ y,
-                                                            int ldy, const float* __restrict__ Fm,
-                                                            const int* __restrict__ mol_start, float* __restrict__ Wbar) {
+__global__ __launch_bounds__(256) void nse_bwd_partial_kernel(const float* __restrict__ qbar, const float* __restrict__ y,
+                                                             int ldy, const int* __restrict__ mol_start, int S,
+                                                             float* __restrict__ part) {
   __shared__ float sh[4];
-  const int m = blockIdx.x;
-  const int i0 = mol_start[m], i1 = mol_start[m + 1];
+  const int m = blockIdx.y, sl = blockIdx.x;
+  int lo, hi;
+  slice_bounds(mol_start, m, sl, S, lo, hi);
   float acc = 0.f;
-  for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const float ft = y[(size_t)i * ldy + 1];
     acc += qbar[i] * (ft * ft);
   }
   const float r = block_sum(acc, sh);
-  if (threadIdx.x == 0) Wbar[m] = r / Fm[m];
+  if (threadIdx.x == 0) part[(size_t)m * S + sl] = r;
+}
+
+__global__ void nse_bwd_finish_kernel(const float* __restrict__ part, int S, int n_mol, const float* __restrict__ Fm,
+                                      float* __restrict__ Wbar) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_mol) return;
+  float r = 0.f;
+  for (int k = 0; k < S; ++k) r += part[(size_t)m * S + k];
+  Wbar[m] = r / Fm[m];
 }
 
 int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, const float* Fm,
-                          const int* mol_start, int n_mol, float* Wbar) {
-  hipLaunchKernelGGL(nse_bwd_reduce_kernel, dim3(n_mol), dim3(256), 0, s, qbar, y, ldy, Fm, mol_start, Wbar);
+                          const int* mol_start, int n_mol, int S, float* part, float* Wbar) {
+  S = S < 1 ? 1 : S;
+  hipLaunchKernelGGL(nse_bwd_partial_kernel, dim3(S, n_mol), dim3(256), 0, s, qbar, y, ldy, mol_start, S, part);
+  AIMNET_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nse_bwd_finish_kernel, dim3(ceil_div(n_mol, 64)), dim3(64), 0, s, part, S, n_mol, Fm, Wbar);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }
@@ -425,35 +526,50 @@ __global__ void forces_kernel(const float* __restrict__ fgrad, int n3, float* __
   if (e < n3) forces[e] = -fgrad[e];
 }
 
-__global__ __launch_bounds__(256) void stress_kernel(const float* __restrict__ virial_atom,
-                                                    const int* __restrict__ mol_start, const float* __restrict__ cell,
-                                                    int n_cell, int n_mol, float* __restrict__ stress) {
+// stage 1: 9 partial sums per (system, slice); a single shared cell (n_cell == 1) spans all molecules
+__global__ __launch_bounds__(256) void stress_partial_kernel(const float* __restrict__ virial_atom,
+                                                            const int* __restrict__ mol_start, int n_cell, int n_mol,
+                                                            int S, double* __restrict__ part) {
   __shared__ double sh[4];
-  // one block per output system; a single shared cell (n_cell == 1) sums over all molecules
-  const int sidx = blockIdx.x;
+  const int sidx = blockIdx.y, sl = blockIdx.x;
   const int i0 = (n_cell == 1) ? mol_start[0] : mol_start[sidx];
   const int i1 = (n_cell == 1) ? mol_start[n_mol] : mol_start[sidx + 1];
+  const int L = (i1 - i0 + S - 1) / S;
+  const int lo = min(i1, i0 + sl * L), hi = min(i1, lo + L);
+  for (int k = 0; k < 9; ++k) {
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += (double)virial_atom[(size_t)i * 9 + k];
+    const double r = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[((size_t)sidx * S + sl) * 9 + k] = r;
+  }
+}
+
+__global__ void stress_finish_kernel(const double* __restrict__ part, int S, int n_cell, const float* __restrict__ cell,
+                                     float* __restrict__ stress) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_cell * 9) return;
+  const int sidx = e / 9, k = e % 9;
   const float* c = cell + (size_t)sidx * 9;
   const double det = (double)c[0] * ((double)c[4] * c[8] - (double)c[5] * c[7]) -
                      (double)c[1] * ((double)c[3] * c[8] - (double)c[5] * c[6]) +
                      (double)c[2] * ((double)c[3] * c[7] - (double)c[4] * c[6]);
-  const double vol = fabs(det);
-  for (int k = 0; k < 9; ++k) {
-    double acc = 0.0;
-    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) acc += (double)virial_atom[(size_t)i * 9 + k];
-    const double r = block_sum(acc, sh);
-    if (threadIdx.x == 0) stress[(size_t)sidx * 9 + k] = (float)(r / vol);
-  }
+  double r = 0.0;
+  for (int s = 0; s < S; ++s) r += part[((size_t)sidx * S + s) * 9 + k];
+  stress[e] = (float)(r / fabs(det));
 }
 
 int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
-                    const float* cell, int n_cell, int n_mol, int n_atoms, float* forces, float* stress) {
+                    const float* cell, int n_cell, int n_mol, int n_atoms, int S, double* part, float* forces,
+                    float* stress) {
   if (forces) {
     hipLaunchKernelGGL(forces_kernel, dim3(ceil_div(3 * n_atoms, 256)), dim3(256), 0, s, fgrad, 3 * n_atoms, forces);
     AIMNET_LAUNCH_CHECK();
   }
   if (stress && cell) {
-    hipLaunchKernelGGL(stress_kernel, dim3(n_cell), dim3(256), 0, s, virial_atom, mol_start, cell, n_cell, n_mol, stress);
+    S = S < 1 ? 1 : S;
+    hipLaunchKernelGGL(stress_partial_kernel, dim3(S, n_cell), dim3(256), 0, s, virial_atom, mol_start, n_cell, n_mol, S, part);
+    AIMNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(stress_finish_kernel, dim3(ceil_div(n_cell * 9, 64)), dim3(64), 0, s, part, S, n_cell, cell, stress);
     AIMNET_LAUNCH_CHECK();
   }
   return 0;

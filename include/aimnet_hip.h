@@ -146,6 +146,11 @@ int aimnet_engine_debug_view(const aimnet_engine* e, const char* name, size_t* b
 int aimnet_engine_set_profiling(aimnet_engine* e, int level);
 int aimnet_engine_profile_read(aimnet_engine* e, double* ms, int n_families, int reset);
 
+/* Test / tuning hook for the fp32 MFMA GEMM of the MLP stack: C[M,N] = A[M,K] . Bt[N,K]^T with epilogue
+ * epi (0 none, 1 +bias, 2 gelu(+bias) with D = gelu', 3 C = acc * D); K % 32 == 0; cfg 0 = automatic tile. */
+int aimnet_debug_gemm(int cfg, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
+                      const float* bias, float* C, float* D, int ldc, void* hip_stream);
+
 /* Stand-alone neighbour list with the nvalchemiops contract.  nbmat [n_atoms, max_nb] int32 is
  * filled with `fill_value` beyond each row's count; shifts [n_atoms, max_nb, 3] int32 may be NULL
  * when cell == NULL; num_nb [n_atoms] int32; status [2] = {max count, overflow flag}. */

@@ -17,6 +17,8 @@
 // a neighbour's 1 KiB feature row is one coalesced dwordx4 wave load.  Neighbours are processed in
 // chunks of 64 whose (j, u, d) and radial basis tables are staged in LDS once per chunk (16 exp
 // per pair in total instead of per lane).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -79,6 +81,24 @@ int launch_embed(hipStream_t s, const float* afv, const int* numbers, int n_atom
   return 0;
 }
 
+// Persistent-loop atom assignment.  Hardware places block b on XCD b % 8 (observed; speed only): give
+// each XCD one CONTIGUOUS range of atoms, processed in order, so that when the input is spatially
+// ordered (crystals, MD frames) the neighbour rows an XCD gathers were mostly produced / recently
+// touched by the same XCD and hit its private 4 MiB L2 instead of the Infinity Cache.
+struct AtomLoop {
+  int first, last, step;  // atoms [first, last) in steps of `step`
+};
+__device__ __forceinline__ AtomLoop atom_loop(int n_atoms, int apb) {
+  const int nb = gridDim.x, b = blockIdx.x;
+  if (nb < 8) return AtomLoop{b * apb, n_atoms, nb * apb};
+  const int xcd = b & 7, slot = b >> 3;
+  const int per = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0);          // blocks resident on this XCD: slot = 0..per-1
+  const int nblk = (n_atoms + apb - 1) / apb;                    // atom blocks in total
+  const int chunk = (nblk + 7) >> 3;                             // atom blocks per XCD
+  const int lo = xcd * chunk, hi = min(nblk, lo + chunk);
+  return AtomLoop{(lo + slot) * apb, hi * apb < n_atoms ? hi * apb : n_atoms, per * apb};
+}
+
 // radial basis value (and optionally d/dd) for one (pair, shift)
 __device__ __forceinline__ float basis_fc(const BasisParams& bp, float d, float& dfc) {
   const float dc = fminf(fmaxf(d, 1e-6f), bp.rc);
@@ -95,7 +115,8 @@ struct FwdWaveLds {
   float gs[64][G_];   // radial basis of the current chunk
   float4 ud[64];      // (ux, uy, uz, d)
   int j[64];
-  float qj[64];
+  float fc[64];       // cutoff envelope fc(d) of the chunk (one sincos per pair)
+  float qj[64];       // neighbour charges
 };
 
 // `row_of` (may be NULL): feature row of atom j inside `a`.  Pass 0 gathers straight from the
@@ -120,15 +141,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
   FwdWaveLds& L = wl[wid];
   const int g4 = (lane & 3) * 4;
 
-  for (int i0 = blockIdx.x * APB; i0 < n_atoms; i0 += gridDim.x * APB) {
+  const AtomLoop al = atom_loop(n_atoms, APB);
+  for (int i0 = al.first; i0 < al.last; i0 += al.step) {
     const int i = i0 + wid;
-    const bool live = i < n_atoms;
+    const bool live = i < al.last;
     const int cnt = live ? nb_cnt[i] : 0;
     int cmax = cnt;  // block-uniform trip count so that __syncthreads() is legal
 #pragma unroll
     for (int w = 0; w < APB; ++w) {
       const int iw = i0 + w;
-      cmax = max(cmax, iw < n_atoms ? nb_cnt[iw] : 0);
+      cmax = max(cmax, iw < al.last ? nb_cnt[iw] : 0);
     }
     float acc[4][4];
 #pragma unroll
@@ -144,7 +166,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
         const size_t p = (size_t)i * cap + c0 + lane;
         const int j = nb_idx[p];
         L.j[lane] = row_of ? min(63, max(0, row_of[j])) : j;
-        L.ud[lane] = pg[p];
+        const float4 ud = pg[p];
+        L.ud[lane] = ud;
+        float dfc;
+        L.fc[lane] = basis_fc(bp, ud.w, dfc);
         if (HAS_Q) L.qj[lane] = q[j];
       }
       __syncthreads();
@@ -154,11 +179,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
         const int mm = e >> 4, g = e & 15;
         float v = 0.0f;
         if (mm < nch) {
-          const float d = L.ud[mm].w;
-          float dfc;
-          const float fc = basis_fc(bp, d, dfc);
-          const float dd = d - bp.shifts[g];
-          v = expf(-bp.eta * dd * dd) * fc;
+          const float dd = L.ud[mm].w - bp.shifts[g];
+          v = expf(-bp.eta * dd * dd) * L.fc[mm];
         }
         L.gs[mm][g] = v;
       }
@@ -274,9 +296,10 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
   if (HAS_Q)
     for (int k = threadIdx.x; k < G_ * H_; k += 256) s_aghq[k] = agh_q[k];
   float* vb = s_vb[wid];
-  for (int i0 = blockIdx.x * APB; i0 < n_atoms; i0 += gridDim.x * APB) {
+  const AtomLoop al = atom_loop(n_atoms, APB);
+  for (int i0 = al.first; i0 < al.last; i0 += al.step) {
     const int i = i0 + wid;
-    const bool live = i < n_atoms;
+    const bool live = i < al.last;
     __syncthreads();
     if (live) {
       const float* xr = xbar + (size_t)i * ldx;
@@ -352,8 +375,10 @@ struct BwdWaveLds {
   float gs[64][G_];
   float dgs[64][G_];
   float4 ud[64];
-  int j[64];
+  int j[64];      // neighbour atom
+  int jr[64];     // its feature row (atomic number in pass 0)
   float qj[64];
+  float fc[64], dfc[64];
 };
 
 // per-lane linear map (dbar, ubar) -> rbar = dbar*u + (ubar - (ubar.u) u)/d
@@ -366,7 +391,8 @@ __device__ __forceinline__ void rbar_of(float db, float ub0, float ub1, float ub
 }
 
 template <bool HAS_Q, bool NEED_ABAR, bool STRESS>
-__global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__ a, const float* __restrict__ q,
+__global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
+                                                      const float* __restrict__ q,
                                                       const float* __restrict__ Sbar, const float* __restrict__ Sqbar,
                                                       const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
                                                       const float4* __restrict__ pg, int cap, BasisParams bp,
@@ -374,22 +400,23 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
                                                       const float* __restrict__ abar_in, float* __restrict__ abar_out,
                                                       const float* __restrict__ qbar_in, float* __restrict__ qbar_out,
                                                       float* __restrict__ fgrad, float* __restrict__ virial_atom,
-                                                      int n_atoms) {
+                                                      int n_atoms, int dbg) {
   __shared__ __attribute__((aligned(16))) BwdWaveLds wl[APB];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   BwdWaveLds& L = wl[wid];
   const int g4 = (lane & 3) * 4;
   const int qg = lane >> 2, qc = lane & 3;
 
-  for (int i0 = blockIdx.x * APB; i0 < n_atoms; i0 += gridDim.x * APB) {
+  const AtomLoop al = atom_loop(n_atoms, APB);
+  for (int i0 = al.first; i0 < al.last; i0 += al.step) {
     const int i = i0 + wid;
-    const bool live = i < n_atoms;
+    const bool live = i < al.last;
     const int cnt = live ? nb_cnt[i] : 0;
     int cmax = cnt;
 #pragma unroll
     for (int w = 0; w < APB; ++w) {
       const int iw = i0 + w;
-      cmax = max(cmax, iw < n_atoms ? nb_cnt[iw] : 0);
+      cmax = max(cmax, iw < al.last ? nb_cnt[iw] : 0);
     }
     // centre atom's own rows
     float ai[4] = {0, 0, 0, 0};
@@ -399,8 +426,10 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
 #pragma unroll
       for (int c = 0; c < 4; ++c) Si[gi][c] = 0.0f;
     float qi = 0.0f, Sqi = 0.0f;
+    int ri = 0;
     if (live) {
-      const float4 t = reinterpret_cast<const float4*>(a + (size_t)i * NF)[lane];
+      ri = row_of ? min(63, max(0, row_of[i])) : i;
+      const float4 t = reinterpret_cast<const float4*>(a + (size_t)ri * NF)[lane];
       ai[0] = t.x; ai[1] = t.y; ai[2] = t.z; ai[3] = t.w;
       const float4* sp = reinterpret_cast<const float4*>(Sbar + (size_t)i * (NF * 4)) + lane * 4;
 #pragma unroll
@@ -427,7 +456,12 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
         const size_t p = (size_t)i * cap + c0 + lane;
         const int j = nb_idx[p];
         L.j[lane] = j;
-        L.ud[lane] = pg[p];
+        L.jr[lane] = row_of ? min(63, max(0, row_of[j])) : j;
+        const float4 ud = pg[p];
+        L.ud[lane] = ud;
+        float dfc;
+        L.fc[lane] = basis_fc(bp, ud.w, dfc);  // one sincos per pair, not per (pair, shift)
+        L.dfc[lane] = dfc;
         if (HAS_Q) L.qj[lane] = q[j];
       }
       __syncthreads();
@@ -437,10 +471,8 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
         const int mm = e >> 4, g = e & 15;
         float v = 0.0f, dv = 0.0f;
         if (mm < nch) {
-          const float d = L.ud[mm].w;
-          float dfc;
-          const float fc = basis_fc(bp, d, dfc);
-          const float dd = d - bp.shifts[g];
+          const float fc = L.fc[mm], dfc = L.dfc[mm];
+          const float dd = L.ud[mm].w - bp.shifts[g];
           const float Gg = expf(-bp.eta * dd * dd);
           v = Gg * fc;
           dv = Gg * (dfc - 2.0f * bp.eta * dd * fc);
@@ -450,8 +482,8 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
       }
       __syncthreads();
       for (int mm = 0; mm < nch; ++mm) {
-        const int j = L.j[mm];
-        const float4 ajv = reinterpret_cast<const float4*>(a + (size_t)j * NF)[lane];
+        const int j = (dbg & 1) ? i : L.j[mm];  // dbg bit0 (ablation only): perfect gather locality
+        const float4 ajv = reinterpret_cast<const float4*>(a + (size_t)((dbg & 1) ? ri : L.jr[mm]) * NF)[lane];
         const float4* sp = reinterpret_cast<const float4*>(Sbar + (size_t)j * (NF * 4)) + lane * 4;
         const float4 sj0 = sp[0], sj1 = sp[1], sj2 = sp[2], sj3 = sp[3];
         const float4 gv = *reinterpret_cast<const float4*>(&L.gs[mm][g4]);
@@ -538,14 +570,15 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
   }
 }
 
-int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, const float* a, const float* q,
-                    const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
+int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, const float* a, const int* row_of,
+                    const float* q, const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
                     int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
                     const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms) {
   const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
+  static const int dbg = getenv("AIMNET_CONV_DBG") ? atoi(getenv("AIMNET_CONV_DBG")) : 0;  // ablation switch, tests only
 #define AIMNET_BWD(HQ, NA, ST)                                                                                        \
-  hipLaunchKernelGGL((conv_bwd_kernel<HQ, NA, ST>), dim3(grid), dim3(256), 0, s, a, q, Sbar, Sqbar, nb_idx, nb_cnt, pg, \
-                     cap, bp, xbar, ldx, abar_in, abar_out, qbar_in, qbar_out, fgrad, virial_atom, n_atoms)
+  hipLaunchKernelGGL((conv_bwd_kernel<HQ, NA, ST>), dim3(grid), dim3(256), 0, s, a, row_of, q, Sbar, Sqbar, nb_idx, nb_cnt, pg, \
+                     cap, bp, xbar, ldx, abar_in, abar_out, qbar_in, qbar_out, fgrad, virial_atom, n_atoms, dbg)
   if (has_q) {
     if (need_abar) {
       if (stress) AIMNET_BWD(true, true, true); else AIMNET_BWD(true, true, false);

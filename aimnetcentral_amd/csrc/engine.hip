@@ -423,7 +423,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, ar.rc, 1, cap, N, 0, W.nl, W.nb_idx, W.nb_shift,
                   W.nb_cnt, out->status + 0, out->status + 2));
   if (coulomb == AIMNET_COULOMB_DSF)
-    RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, opt->dsf_rc, 2, cap_lr, N, 0, W.nl, W.lr_idx,
+    RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, opt->dsf_rc, 3, cap_lr, N, 0, W.nl, W.lr_idx,
                     W.lr_shift, W.lr_cnt, out->status + 1, out->status + 3));
   RC(prof_mark(e, s, FAM_GEOM));
   RC(launch_pair_geom(s, W.nl.xw, in->mol_idx, in->cell, n_cell, W.nb_idx, W.nb_shift, W.nb_cnt, cap, N, W.pg));
@@ -532,7 +532,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     RC(prof_mark(e, s, FAM_UNCONCAT));
     RC(launch_unconcat(s, p > 0, zcur, ld, W.V[p], W.Vq[p], e->agh_a, e->agh_q, W.Sbar, W.Sqbar, N));
     RC(prof_mark(e, s, FAM_CONV_BWD));
-    RC(launch_conv_bwd(s, p > 0, p > 0, want_s, W.a[p], p > 0 ? W.q[p - 1] : nullptr, W.Sbar, W.Sqbar, W.nb_idx, W.nb_cnt,
+    RC(launch_conv_bwd(s, p > 0, p > 0, want_s, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr,
+                       p > 0 ? W.q[p - 1] : nullptr, W.Sbar, W.Sqbar, W.nb_idx, W.nb_cnt,
                        W.pg, cap, e->bp, zcur, ld, (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, W.fgrad,
                        W.virial_atom, N));
     if (p == 0) break;

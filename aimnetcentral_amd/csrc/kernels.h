@@ -29,6 +29,7 @@ struct NlistBuffers {      // all device pointers, carved from the caller's work
   int* bin_fill;           // [max_bins]
   int* sorted_tmp;         // [n_atoms]
   int* sorted;             // [n_atoms]
+  float4* xs;              // [n_atoms] bin-ordered (x, y, z, atom id)
 };
 size_t nlist_scratch_bytes(int n_atoms, int n_mol);
 size_t nlist_xw_offset(int n_mol);  // byte offset of NlistBuffers::xw inside the scratch
@@ -56,8 +57,8 @@ int launch_conv_fwd(hipStream_t s, bool has_q, const float* a, const int* row_of
                     float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms);
 int launch_unconcat(hipStream_t s, bool has_q, const float* xbar, int ldx, const float* Vsave, const float* Vqsave,
                     const float* agh_a, const float* agh_q, float* Sbar, float* Sqbar, int n_atoms);
-int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, const float* a, const float* q,
-                    const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
+int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, const float* a, const int* row_of,
+                    const float* q, const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
                     int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
                     const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms);
 // stand-alone reference-op forms (conv_sv_2d_sp_wp.py:90-164)

@@ -37,6 +37,7 @@ size_t nlist_scratch_bytes(int n_atoms, int n_mol) {
   b += align_up((size_t)n_atoms * sizeof(int), 256);        // atom_bin
   b += 3 * align_up((max_bins + 1) * sizeof(int), 256);     // count, start, fill
   b += 2 * align_up((size_t)n_atoms * sizeof(int), 256);    // sorted_tmp, sorted
+  b += align_up((size_t)n_atoms * sizeof(float4), 256);     // xs: bin-ordered (x, y, z, atom id)
   return b;
 }
 
@@ -58,6 +59,7 @@ void nlist_carve(NlistBuffers& b, char* p, int n_atoms, int n_mol) {
   b.bin_fill = (int*)take((max_bins + 1) * sizeof(int));
   b.sorted_tmp = (int*)take((size_t)n_atoms * sizeof(int));
   b.sorted = (int*)take((size_t)n_atoms * sizeof(int));
+  b.xs = (float4*)take((size_t)n_atoms * sizeof(float4));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -189,7 +191,9 @@ __global__ __launch_bounds__(256) void nlist_brute_kernel(const float* __restric
     for (int p = min(count, cap) + lane; p < cap; p += 64) row[p] = fill_value;
   if (lane == 0) {
     nb_cnt[i] = min(count, cap);
-    atomicMax(status_max, count);
+    // 10^4 same-address atomics serialise at ~12 ns each (>100 us per list): atomicMax is monotonic, so
+    // skip it whenever a (possibly stale) relaxed read already shows a value >= ours
+    if (count > __hip_atomic_load(status_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(status_max, count);
     if (count > cap) atomicMax(status_ovf, 1);
   }
 }
@@ -287,8 +291,11 @@ __global__ void bin_fill_kernel(const int* __restrict__ atom_bin, const int* __r
 }
 
 // order every bin by atom id (rank by counting; bins hold tens of atoms): one wave per bin
+// also emits the bin-ordered coordinate stream xs[k] = (x, y, z, atom id): the row builder then reads
+// its candidates as ONE coalesced 16-byte load per lane instead of an index load + 3 scattered dwords
 __global__ __launch_bounds__(256) void bin_sort_kernel(const int* __restrict__ bin_start, int n_bins,
-                                                      const int* __restrict__ sorted_tmp, int* __restrict__ sorted) {
+                                                      const int* __restrict__ sorted_tmp, const float* __restrict__ xw,
+                                                      int* __restrict__ sorted, float4* __restrict__ xs) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= n_bins) return;
@@ -298,12 +305,13 @@ __global__ __launch_bounds__(256) void bin_sort_kernel(const int* __restrict__ b
     int rank = 0;
     for (int f = 0; f < n; ++f) rank += (sorted_tmp[s0 + f] < v) ? 1 : 0;
     sorted[s0 + rank] = v;
+    xs[s0 + rank] = make_float4(xw[3 * v], xw[3 * v + 1], xw[3 * v + 2], __int_as_float(v));
   }
 }
 
 __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
                                                         const NlistSystem* __restrict__ sys,
-                                                        const int* __restrict__ bin_start, const int* __restrict__ sorted,
+                                                        const int* __restrict__ bin_start, const float4* __restrict__ xs,
                                                         int n_atoms, float cutoff2, int cap, int fill_value,
                                                         int fill_rows, int* __restrict__ nb_idx,
                                                         int* __restrict__ nb_shift, int* __restrict__ nb_cnt,
@@ -318,6 +326,7 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
   int* row = nb_idx + (size_t)i * cap;
   int* rsh = nb_shift + (size_t)i * cap;
   int count = 0;
+  const int nb2 = S.nb[2];
   for (int dx = -S.R[0]; dx <= S.R[0]; ++dx) {
     int bx = bi[0] + dx, sx = 0;
     if (S.per[0]) {
@@ -334,28 +343,31 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
       } else if (by < 0 || by >= S.nb[1]) {
         continue;
       }
-      for (int dz = -S.R[2]; dz <= S.R[2]; ++dz) {
-        int bz = bi[2] + dz, sz = 0;
-        if (S.per[2]) {
-          sz = (bz >= 0) ? bz / S.nb[2] : -((-bz + S.nb[2] - 1) / S.nb[2]);
-          bz -= sz * S.nb[2];
-        } else if (bz < 0 || bz >= S.nb[2]) {
-          continue;
-        }
-        const int bin = S.bin_offset + (bx * S.nb[1] + by) * S.nb[2] + bz;
+      // bins along z are contiguous in memory: walk whole runs [z0, z1] that share one lattice shift sz
+      const int zlo = bi[2] - S.R[2], zhi = bi[2] + S.R[2];
+      int sz_lo = 0, sz_hi = 0;
+      if (S.per[2]) {
+        sz_lo = (zlo >= 0) ? zlo / nb2 : -((-zlo + nb2 - 1) / nb2);
+        sz_hi = (zhi >= 0) ? zhi / nb2 : -((-zhi + nb2 - 1) / nb2);
+      }
+      const int row_bin = S.bin_offset + (bx * S.nb[1] + by) * nb2;
+      for (int sz = sz_lo; sz <= sz_hi; ++sz) {
+        const int z0 = max(zlo, sz * nb2) - sz * nb2, z1 = min(zhi, sz * nb2 + nb2 - 1) - sz * nb2;
+        if (z1 < z0) continue;
         const float ox = sx * S.c[0] + sy * S.c[3] + sz * S.c[6];
         const float oy = sx * S.c[1] + sy * S.c[4] + sz * S.c[7];
         const float oz = sx * S.c[2] + sy * S.c[5] + sz * S.c[8];
         const bool self_image = (sx == 0 && sy == 0 && sz == 0);
         const int code = pack_shift(sx, sy, sz);
-        const int s0 = bin_start[bin], s1 = bin_start[bin + 1];
+        const int s0 = bin_start[row_bin + z0], s1 = bin_start[row_bin + z1 + 1];
         for (int base = s0; base < s1; base += 64) {
           const int e = base + lane;
           bool ok = false;
           int j = 0;
           if (e < s1) {
-            j = sorted[e];
-            const float rx = (xw[3 * j] - xi) + ox, ry = (xw[3 * j + 1] - yi) + oy, rz = (xw[3 * j + 2] - zi) + oz;
+            const float4 c = xs[e];
+            j = __float_as_int(c.w);
+            const float rx = (c.x - xi) + ox, ry = (c.y - yi) + oy, rz = (c.z - zi) + oz;
             ok = (rx * rx + ry * ry + rz * rz) < cutoff2 && !(self_image && j == i);
           }
           const unsigned long long mask = __ballot(ok);
@@ -376,7 +388,9 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
     }
   if (lane == 0) {
     nb_cnt[i] = min(count, cap);
-    atomicMax(status_max, count);
+    // 10^4 same-address atomics serialise at ~12 ns each (>100 us per list): atomicMax is monotonic, so
+    // skip it whenever a (possibly stale) relaxed read already shows a value >= ours
+    if (count > __hip_atomic_load(status_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(status_max, count);
     if (count > cap) atomicMax(status_ovf, 1);
   }
 }
@@ -407,11 +421,11 @@ int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, cons
   hipLaunchKernelGGL(bin_fill_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.atom_bin, b.bin_start, n_atoms,
                      b.bin_fill, b.sorted_tmp);
   AIMNET_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bin_sort_kernel, dim3(ceil_div(max_bins, 4)), dim3(256), 0, s, b.bin_start, max_bins, b.sorted_tmp,
-                     b.sorted);
+  hipLaunchKernelGGL(bin_sort_kernel, dim3(ceil_div(max_bins, 4)), dim3(256), 0, s, b.bin_start, max_bins, b.sorted_tmp, b.xw,
+                     b.sorted, b.xs);
   AIMNET_LAUNCH_CHECK();
   hipLaunchKernelGGL(nlist_cell_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, sys, b.bin_start,
-                     b.sorted, n_atoms, c2, cap, fill_value, fill_rows, nb_idx, nb_shift, nb_cnt, status_max, status_ovf);
+                     b.xs, n_atoms, c2, cap, fill_value, fill_rows, nb_idx, nb_shift, nb_cnt, status_max, status_ovf);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

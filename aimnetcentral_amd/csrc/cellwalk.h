@@ -1,0 +1,111 @@
+// cellwalk.h - per-system cell grid and the wave-per-atom walk over neighbouring bins, shared by the
+// neighbour-list builder (nlist.hip) and the list-free DSF Coulomb kernel (model.hip).
+#pragma once
+
+#include "common.h"
+
+namespace aimnet {
+
+struct NlistSystem {
+  float c[9];    // cell row vectors
+  float inv[9];  // inverse: frac = x . inv
+  float h[3];    // perpendicular heights
+  int per[3];
+  int nb[3];     // bins per lattice axis (slabs of the fractional coordinate)
+  int bin_offset;
+  int n_bins;
+};
+
+__device__ __forceinline__ int bin_of(const NlistSystem& S, float x, float y, float z, int b[3]) {
+  for (int k = 0; k < 3; ++k) {
+    const float f = x * S.inv[k] + y * S.inv[3 + k] + z * S.inv[6 + k];
+    b[k] = max(0, min(S.nb[k] - 1, (int)floorf(f * (float)S.nb[k])));
+  }
+  return S.bin_offset + (b[0] * S.nb[1] + b[1]) * S.nb[2] + b[2];
+}
+
+// Visit every (neighbour image) candidate of atom i (one wave per atom) whose bin lies within the
+// search range of `cutoff`.  f(j, rx, ry, rz, ok, code) is called convergently by all 64 lanes once
+// per 64-candidate chunk; ok = candidate exists, |r| < cutoff and it is not the atom itself; r is
+// formed as (x_j - x_i) + s.C so that (i,j,s) and (j,i,-s) see exactly opposite vectors.
+// Everything that steers the walk is wave-uniform -> SGPRs, scalar branches, no integer division.
+template <class F>
+__device__ __forceinline__ void cell_walk(const NlistSystem& S, int i, float xi, float yi, float zi, float cutoff,
+                                          const int* __restrict__ bin_start, const float4* __restrict__ xs, int lane,
+                                          F&& f) {
+  int bv[3];
+  bin_of(S, xi, yi, zi, bv);
+  auto U = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto UF = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+  const int nb0 = U(S.nb[0]), nb1 = U(S.nb[1]), nb2 = U(S.nb[2]);
+  const int p0 = U(S.per[0]), p1 = U(S.per[1]), p2 = U(S.per[2]);
+  // search radius in bins: slab thickness = h_k / nb_k
+  int R0 = (int)ceilf(cutoff * (float)nb0 / UF(S.h[0])), R1 = (int)ceilf(cutoff * (float)nb1 / UF(S.h[1])),
+      R2 = (int)ceilf(cutoff * (float)nb2 / UF(S.h[2]));
+  R0 = U(min(120, p0 ? R0 : min(R0, nb0 - 1)));
+  R1 = U(min(120, p1 ? R1 : min(R1, nb1 - 1)));
+  R2 = U(min(120, p2 ? R2 : min(R2, nb2 - 1)));
+  const int b0 = U(bv[0]), b1 = U(bv[1]), b2 = U(bv[2]);
+  const int boff = U(S.bin_offset);
+  const float cutoff2 = cutoff * cutoff;
+  float c[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) c[k] = UF(S.c[k]);
+  for (int dx = -R0; dx <= R0; ++dx) {
+    int bx = b0 + dx, sx = 0;
+    if (p0) {
+      while (bx < 0) { bx += nb0; --sx; }
+      while (bx >= nb0) { bx -= nb0; ++sx; }
+    } else if (bx < 0 || bx >= nb0) {
+      continue;
+    }
+    for (int dy = -R1; dy <= R1; ++dy) {
+      int by = b1 + dy, sy = 0;
+      if (p1) {
+        while (by < 0) { by += nb1; --sy; }
+        while (by >= nb1) { by -= nb1; ++sy; }
+      } else if (by < 0 || by >= nb1) {
+        continue;
+      }
+      // bins along z are contiguous in memory: walk whole runs [z0, z1] that share one lattice shift sz
+      const int zlo = b2 - R2, zhi = b2 + R2;
+      int sz_lo = 0, sz_hi = 0;
+      if (p2) {
+        int t = zlo;
+        while (t < 0) { t += nb2; --sz_lo; }
+        while (t >= nb2) { t -= nb2; ++sz_lo; }
+        t = zhi;
+        while (t < 0) { t += nb2; --sz_hi; }
+        while (t >= nb2) { t -= nb2; ++sz_hi; }
+      }
+      const int row_bin = boff + (bx * nb1 + by) * nb2;
+      for (int sz = sz_lo; sz <= sz_hi; ++sz) {
+        const int z0 = max(zlo, sz * nb2) - sz * nb2, z1 = min(zhi, sz * nb2 + nb2 - 1) - sz * nb2;
+        if (z1 < z0) continue;
+        const float ox = sx * c[0] + sy * c[3] + sz * c[6];
+        const float oy = sx * c[1] + sy * c[4] + sz * c[7];
+        const float oz = sx * c[2] + sy * c[5] + sz * c[8];
+        const bool self_image = (sx == 0 && sy == 0 && sz == 0);
+        const int code = pack_shift(sx, sy, sz);
+        const int s0 = bin_start[row_bin + z0], s1 = bin_start[row_bin + z1 + 1];
+        for (int base = s0; base < s1; base += 64) {
+          const int e = base + lane;
+          bool ok = false;
+          int j = 0;
+          float rx = 0.f, ry = 0.f, rz = 0.f;
+          if (e < s1) {
+            const float4 cj = xs[e];
+            j = __float_as_int(cj.w);
+            rx = (cj.x - xi) + ox;
+            ry = (cj.y - yi) + oy;
+            rz = (cj.z - zi) + oz;
+            ok = (rx * rx + ry * ry + rz * rz) < cutoff2 && !(self_image && j == i);
+          }
+          f(j, rx, ry, rz, ok, code);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace aimnet

@@ -393,8 +393,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     return AIMNET_E_INVALID;
   }
   int coulomb = opt->coulomb;
-  if (coulomb == AIMNET_COULOMB_DSF && opt->max_nb_lr <= 0) {
-    set_last_error("eval: DSF Coulomb needs max_nb_lr > 0");
+  if (coulomb == AIMNET_COULOMB_DSF && !pbc && opt->max_nb_lr <= 0) {
+    set_last_error("eval: non-periodic DSF Coulomb needs max_nb_lr > 0 (periodic DSF walks the cell grid, no list)");
     return AIMNET_E_INVALID;
   }
   if (coulomb == AIMNET_COULOMB_SIMPLE && pbc) {
@@ -420,10 +420,10 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   AIMNET_HIP_CHECK(hipMemsetAsync(out->status, 0, 8 * sizeof(int), s));
   RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start));
   RC(launch_wrap(s, in->coord, in->mol_idx, N, n_mol, in->cell, n_cell, in->pbc, W.nl));
-  RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, ar.rc, 1, cap, N, 0, W.nl, W.nb_idx, W.nb_shift,
+  RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, ar.rc, ar.rc, cap, N, 0, W.nl, W.nb_idx, W.nb_shift,
                   W.nb_cnt, out->status + 0, out->status + 2));
-  if (coulomb == AIMNET_COULOMB_DSF)
-    RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, opt->dsf_rc, 3, cap_lr, N, 0, W.nl, W.lr_idx,
+  if (coulomb == AIMNET_COULOMB_DSF && !pbc)  // periodic DSF needs no list: it walks the short-range cell grid
+    RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, opt->dsf_rc, -1.0f, cap_lr, N, 0, W.nl, W.lr_idx,
                     W.lr_shift, W.lr_cnt, out->status + 1, out->status + 3));
   RC(prof_mark(e, s, FAM_GEOM));
   RC(launch_pair_geom(s, W.nl.xw, in->mol_idx, in->cell, n_cell, W.nb_idx, W.nb_shift, W.nb_cnt, cap, N, W.pg));
@@ -482,6 +482,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
                        W.fgrad, W.virial_atom));
   if (coulomb == AIMNET_COULOMB_SIMPLE)
     RC(launch_coulomb_simple(s, grad, q_fin, W.nl.xw, in->mol_idx, W.nl.mol_start, cp, N, W.ecoul, W.qbar, W.fgrad));
+  else if (coulomb == AIMNET_COULOMB_DSF && pbc)
+    RC(launch_coulomb_dsf_walk(s, grad, want_s, q_fin, in->mol_idx, W.nl, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));
   else if (coulomb == AIMNET_COULOMB_DSF)
     RC(launch_coulomb_dsf(s, grad, want_s, q_fin, W.nl.xw, in->mol_idx, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt,
                           cap_lr, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));
@@ -599,7 +601,7 @@ int aimnet_neighbor_list(const float* coord, const int32_t* mol_idx, int32_t n_a
   AIMNET_HIP_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(int), s));
   RC(launch_mol_start(s, mol_idx, n_atoms, n_mol, nl.mol_start));
   RC(launch_wrap(s, coord, mol_idx, n_atoms, n_mol, cell, cell ? n_cell : 0, pb, nl));
-  RC(launch_nlist(s, n_atoms, n_mol, mol_idx, cell, cell ? n_cell : 0, pb, cutoff, 1, max_nb, fill_value, 1, nl, nbmat,
+  RC(launch_nlist(s, n_atoms, n_mol, mol_idx, cell, cell ? n_cell : 0, pb, cutoff, cutoff, max_nb, fill_value, 1, nl, nbmat,
                   codes, num_nb, status + 0, status + 1));
   if (cell) {
     const size_t n_pairs = (size_t)n_atoms * max_nb;

@@ -40,9 +40,11 @@ int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_ato
                 int n_cell, const int pbc[3], NlistBuffers& b);
 // build one full neighbour matrix for `cutoff` from b.xw; rows real-first; entries beyond the row
 // count are set to `fill_value` when fill_rows != 0; status[0] = max count (atomicMax), status[1] = overflow
+// bin_width > 0: (re)bin the periodic systems into slabs >= bin_width thick first; <= 0: reuse the last bins
 int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, const float* cell, int n_cell,
-                 const int pbc[3], float cutoff, int bin_sub, int cap, int fill_value, int fill_rows,
+                 const int pbc[3], float cutoff, float bin_width, int cap, int fill_value, int fill_rows,
                  NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf);
+int launch_bins(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, float width, NlistBuffers& b);
 
 // ---- conv.hip ---------------------------------------------------------------------------------
 struct BasisParams {  // radial basis of AEVSV (aev.py:66-81), passed by value
@@ -94,6 +96,9 @@ int launch_coulomb_dsf(hipStream_t s, bool grad, bool stress, const float* q, co
                        const float* cell, int n_cell, const int* nb_idx, const int* nb_shift, const int* nb_cnt,
                        int cap, CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad,
                        float* virial_atom);
+// periodic DSF straight from the cell grid of the last launch_bins (no neighbour matrix)
+int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, NlistBuffers& b,
+                            CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom);
 int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, const float* Fm,
                           const int* mol_start, int n_mol, int S, float* part, float* Wbar);
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,

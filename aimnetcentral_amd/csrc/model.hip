@@ -10,6 +10,7 @@
 //   finalize        forces = -dE/dx, stress = (dE/deps)/|det C| calculators/derivatives.py:118-137
 // Per-molecule reductions run one block per molecule in a fixed tree order (deterministic); pair
 // energies are accumulated in fp64 exactly where the reference does (lr.py:61,326,602,611).
+#include "cellwalk.h"
 #include "common.h"
 #include "kernels.h"
 
@@ -443,6 +444,63 @@ int launch_coulomb_dsf(hipStream_t s, bool grad, bool stress, const float* q, co
   else
     hipLaunchKernelGGL((coulomb_dsf_kernel<false, false>), grid, block, 0, s, q, xw, mol_idx, cell, n_cell, nb_idx, nb_shift,
                        nb_cnt, cap, cp, n_atoms, ecoul, qbar, fgrad, virial_atom);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// periodic DSF without a neighbour matrix: the wave walks the bins of the short-range cell grid out to
+// Rc and accumulates the pair terms directly (no 8 B x ~1800 per atom list write + re-read, no row
+// capacity / overflow handling for the long-range cutoff)
+template <bool GRAD, bool STRESS>
+__global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __restrict__ q, const float* __restrict__ xw,
+                                                              const int* __restrict__ mol_idx,
+                                                              const NlistSystem* __restrict__ sys,
+                                                              const int* __restrict__ bin_start,
+                                                              const float4* __restrict__ xs, CoulombParams cp, int n_atoms,
+                                                              double* __restrict__ ecoul, float* __restrict__ qbar,
+                                                              float* __restrict__ fgrad, float* __restrict__ virial_atom) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const float al = cp.dsf_alpha, Rc = cp.dsf_rc;
+  const float two_a_sqrtpi = 2.0f * al * 0.56418958354775629f;
+  const float erfc_rc = erfcf(al * Rc);
+  const float sv = erfc_rc / Rc;
+  const float slope = erfc_rc / (Rc * Rc) + two_a_sqrtpi * expf(-al * al * Rc * Rc) / Rc;
+  const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2], qi = q[i];
+  PairAcc A;
+  cell_walk(sys[mol_idx[i]], i, xi, yi, zi, Rc, bin_start, xs, lane,
+            [&](int j, float rx, float ry, float rz, bool ok, int) {
+              if (ok) {
+                const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+                if (d < Rc) {
+                  const float inv = 1.0f / d;
+                  const float ec = erfcf(al * d);
+                  const float w = ec * inv - sv + (d - Rc) * slope;
+                  const float dw = -ec * inv * inv - two_a_sqrtpi * expf(-al * al * d * d) * inv + slope;
+                  pair_add<GRAD, STRESS>(A, w, dw, qi, q[j], rx * inv, ry * inv, rz * inv, d);
+                }
+              }
+            });
+  const float cs = -(sv * 0.5f + al * 0.56418958354775629f);
+  const double e_self = 2.0 * (double)cp.factor * (double)(cs * qi * qi);
+  const float qb_self = 4.0f * cp.factor * cs * qi;
+  pair_store<GRAD, STRESS, true>(A, i, lane, cp.factor, e_self, qb_self, ecoul, qbar, fgrad, virial_atom);
+}
+
+int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, NlistBuffers& b,
+                            CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom) {
+  dim3 grid(ceil_div(n_atoms, 4)), block(256);
+  const NlistSystem* sys = (const NlistSystem*)b.sys;
+  if (grad && stress)
+    hipLaunchKernelGGL((coulomb_dsf_walk_kernel<true, true>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, b.xs, cp,
+                       n_atoms, ecoul, qbar, fgrad, virial_atom);
+  else if (grad)
+    hipLaunchKernelGGL((coulomb_dsf_walk_kernel<true, false>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, b.xs, cp,
+                       n_atoms, ecoul, qbar, fgrad, virial_atom);
+  else
+    hipLaunchKernelGGL((coulomb_dsf_walk_kernel<false, false>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, b.xs, cp,
+                       n_atoms, ecoul, qbar, fgrad, virial_atom);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

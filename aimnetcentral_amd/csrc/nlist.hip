@@ -12,21 +12,11 @@
 // Pair vectors are always formed as (x_j - x_i) + s.C so that (i,j,s) and (j,i,-s) evaluate to
 // exactly opposite vectors: the list is exactly symmetric, which the centre-major backward relies on.
 // Row order is deterministic: bins are traversed in a fixed order and each bin is sorted by atom id.
+#include "cellwalk.h"
 #include "common.h"
 #include "kernels.h"
 
 namespace aimnet {
-
-struct NlistSystem {
-  float c[9];    // cell row vectors
-  float inv[9];  // inverse: frac = x . inv
-  float h[3];    // perpendicular heights
-  int per[3];
-  int nb[3];
-  int R[3];
-  int bin_offset;
-  int n_bins;
-};
 
 size_t nlist_scratch_bytes(int n_atoms, int n_mol) {
   const size_t max_bins = (size_t)n_atoms + 8 * (size_t)n_mol + 8;
@@ -113,7 +103,6 @@ __global__ void cell_setup_kernel(const float* __restrict__ cell, int n_cell, in
     const double cz = a1[0] * a2[1] - a1[1] * a2[0];
     S.h[k] = (float)(fabs(det) / sqrt(cx * cx + cy * cy + cz * cz));
     S.nb[k] = 1;
-    S.R[k] = 0;
   }
   S.per[0] = p0;
   S.per[1] = p1;
@@ -200,8 +189,7 @@ __global__ __launch_bounds__(256) void nlist_brute_kernel(const float* __restric
 
 // periodic: choose the bin grid of every system for this cutoff, then a serial prefix of bin offsets
 __global__ void bins_setup_kernel(NlistSystem* __restrict__ sys, const int* __restrict__ mol_start, int n_mol,
-                                  float cutoff, int bin_sub) {
-  const float w = cutoff / (float)bin_sub;
+                                  float w) {
   for (int s = threadIdx.x; s < n_mol; s += blockDim.x) {
     NlistSystem S = sys[s];
     const int ns = mol_start[s + 1] - mol_start[s];
@@ -218,13 +206,7 @@ __global__ void bins_setup_kernel(NlistSystem* __restrict__ sys, const int* __re
       }
       if ((long)nb[0] * nb[1] * nb[2] > cap_bins && nb[big] > 1) nb[big] -= 1;
     }
-    for (int k = 0; k < 3; ++k) {
-      S.nb[k] = nb[k];
-      const float thick = S.h[k] / (float)nb[k];
-      int R = (int)ceilf(cutoff / thick);
-      if (!S.per[k]) R = min(R, nb[k] - 1);
-      S.R[k] = min(R, 120);
-    }
+    for (int k = 0; k < 3; ++k) S.nb[k] = nb[k];
     S.n_bins = nb[0] * nb[1] * nb[2];
     sys[s] = S;
   }
@@ -236,14 +218,6 @@ __global__ void bins_setup_kernel(NlistSystem* __restrict__ sys, const int* __re
       off += sys[s].n_bins;
     }
   }
-}
-
-__device__ __forceinline__ int bin_of(const NlistSystem& S, float x, float y, float z, int b[3]) {
-  for (int k = 0; k < 3; ++k) {
-    const float f = x * S.inv[k] + y * S.inv[3 + k] + z * S.inv[6 + k];
-    b[k] = max(0, min(S.nb[k] - 1, (int)floorf(f * (float)S.nb[k])));
-  }
-  return S.bin_offset + (b[0] * S.nb[1] + b[1]) * S.nb[2] + b[2];
 }
 
 __global__ void bin_count_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx, int n_atoms,
@@ -312,75 +286,27 @@ __global__ __launch_bounds__(256) void bin_sort_kernel(const int* __restrict__ b
 __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
                                                         const NlistSystem* __restrict__ sys,
                                                         const int* __restrict__ bin_start, const float4* __restrict__ xs,
-                                                        int n_atoms, float cutoff2, int cap, int fill_value,
+                                                        int n_atoms, float cutoff, int cap, int fill_value,
                                                         int fill_rows, int* __restrict__ nb_idx,
                                                         int* __restrict__ nb_shift, int* __restrict__ nb_cnt,
                                                         int* __restrict__ status_max, int* __restrict__ status_ovf) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
-  const NlistSystem& S = sys[mol_idx[i]];
   const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2];
-  int bi[3];
-  bin_of(S, xi, yi, zi, bi);
   int* row = nb_idx + (size_t)i * cap;
   int* rsh = nb_shift + (size_t)i * cap;
   int count = 0;
-  const int nb2 = S.nb[2];
-  for (int dx = -S.R[0]; dx <= S.R[0]; ++dx) {
-    int bx = bi[0] + dx, sx = 0;
-    if (S.per[0]) {
-      sx = (bx >= 0) ? bx / S.nb[0] : -((-bx + S.nb[0] - 1) / S.nb[0]);
-      bx -= sx * S.nb[0];
-    } else if (bx < 0 || bx >= S.nb[0]) {
-      continue;
-    }
-    for (int dy = -S.R[1]; dy <= S.R[1]; ++dy) {
-      int by = bi[1] + dy, sy = 0;
-      if (S.per[1]) {
-        sy = (by >= 0) ? by / S.nb[1] : -((-by + S.nb[1] - 1) / S.nb[1]);
-        by -= sy * S.nb[1];
-      } else if (by < 0 || by >= S.nb[1]) {
-        continue;
-      }
-      // bins along z are contiguous in memory: walk whole runs [z0, z1] that share one lattice shift sz
-      const int zlo = bi[2] - S.R[2], zhi = bi[2] + S.R[2];
-      int sz_lo = 0, sz_hi = 0;
-      if (S.per[2]) {
-        sz_lo = (zlo >= 0) ? zlo / nb2 : -((-zlo + nb2 - 1) / nb2);
-        sz_hi = (zhi >= 0) ? zhi / nb2 : -((-zhi + nb2 - 1) / nb2);
-      }
-      const int row_bin = S.bin_offset + (bx * S.nb[1] + by) * nb2;
-      for (int sz = sz_lo; sz <= sz_hi; ++sz) {
-        const int z0 = max(zlo, sz * nb2) - sz * nb2, z1 = min(zhi, sz * nb2 + nb2 - 1) - sz * nb2;
-        if (z1 < z0) continue;
-        const float ox = sx * S.c[0] + sy * S.c[3] + sz * S.c[6];
-        const float oy = sx * S.c[1] + sy * S.c[4] + sz * S.c[7];
-        const float oz = sx * S.c[2] + sy * S.c[5] + sz * S.c[8];
-        const bool self_image = (sx == 0 && sy == 0 && sz == 0);
-        const int code = pack_shift(sx, sy, sz);
-        const int s0 = bin_start[row_bin + z0], s1 = bin_start[row_bin + z1 + 1];
-        for (int base = s0; base < s1; base += 64) {
-          const int e = base + lane;
-          bool ok = false;
-          int j = 0;
-          if (e < s1) {
-            const float4 c = xs[e];
-            j = __float_as_int(c.w);
-            const float rx = (c.x - xi) + ox, ry = (c.y - yi) + oy, rz = (c.z - zi) + oz;
-            ok = (rx * rx + ry * ry + rz * rz) < cutoff2 && !(self_image && j == i);
-          }
-          const unsigned long long mask = __ballot(ok);
-          const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
-          if (ok && pos < cap) {
-            row[pos] = j;
-            rsh[pos] = code;
-          }
-          count += __popcll(mask);
-        }
-      }
-    }
-  }
+  cell_walk(sys[mol_idx[i]], i, xi, yi, zi, cutoff, bin_start, xs, lane,
+            [&](int j, float, float, float, bool ok, int code) {
+              const unsigned long long mask = __ballot(ok);
+              const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+              if (ok && pos < cap) {
+                row[pos] = j;
+                rsh[pos] = code;
+              }
+              count += __popcll(mask);
+            });
   if (fill_rows)
     for (int p = min(count, cap) + lane; p < cap; p += 64) {
       row[p] = fill_value;
@@ -395,23 +321,13 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
   }
 }
 
-int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, const float* cell, int n_cell,
-                 const int pbc[3], float cutoff, int bin_sub, int cap, int fill_value, int fill_rows,
-                 NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf) {
-  (void)n_cell;
-  (void)pbc;
-  const float c2 = cutoff * cutoff;
-  if (cell == nullptr) {
-    hipLaunchKernelGGL(nlist_brute_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, b.mol_start, n_atoms,
-                       c2, cap, fill_value, fill_rows, nb_idx, nb_cnt, status_max, status_ovf);
-    AIMNET_LAUNCH_CHECK();
-    return 0;
-  }
+// bin all atoms of every periodic system into slabs >= `width` thick (count, scan, fill, per-bin sort)
+int launch_bins(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, float width, NlistBuffers& b) {
   NlistSystem* sys = (NlistSystem*)b.sys;
   const int max_bins = n_atoms + 8 * n_mol + 8;
-  hipLaunchKernelGGL(bins_setup_kernel, dim3(1), dim3(256), 0, s, sys, b.mol_start, n_mol, cutoff, bin_sub);
+  hipLaunchKernelGGL(bins_setup_kernel, dim3(1), dim3(256), 0, s, sys, b.mol_start, n_mol, width);
   AIMNET_LAUNCH_CHECK();
-  AIMNET_HIP_CHECK(hipMemsetAsync(b.bin_count, 0, (size_t)(max_bins + 1) * sizeof(int), s));
+  AIMNET_HIP_CHECK(hipMemsetAsync(b.bin_count, 0, (size_t)(max_bins + 1) * sizeof(int) * 1, s));
   AIMNET_HIP_CHECK(hipMemsetAsync(b.bin_fill, 0, (size_t)(max_bins + 1) * sizeof(int), s));
   hipLaunchKernelGGL(bin_count_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.xw, mol_idx, n_atoms, sys,
                      b.atom_bin, b.bin_count);
@@ -424,8 +340,27 @@ int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, cons
   hipLaunchKernelGGL(bin_sort_kernel, dim3(ceil_div(max_bins, 4)), dim3(256), 0, s, b.bin_start, max_bins, b.sorted_tmp, b.xw,
                      b.sorted, b.xs);
   AIMNET_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nlist_cell_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, sys, b.bin_start,
-                     b.xs, n_atoms, c2, cap, fill_value, fill_rows, nb_idx, nb_shift, nb_cnt, status_max, status_ovf);
+  return 0;
+}
+
+int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, const float* cell, int n_cell,
+                 const int pbc[3], float cutoff, float bin_width, int cap, int fill_value, int fill_rows,
+                 NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf) {
+  (void)n_cell;
+  (void)pbc;
+  if (cell == nullptr) {
+    hipLaunchKernelGGL(nlist_brute_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, b.mol_start, n_atoms,
+                       cutoff * cutoff, cap, fill_value, fill_rows, nb_idx, nb_cnt, status_max, status_ovf);
+    AIMNET_LAUNCH_CHECK();
+    return 0;
+  }
+  if (bin_width > 0.0f) {  // bin_width <= 0: reuse the bins of the previous call
+    int rc = launch_bins(s, n_atoms, n_mol, mol_idx, bin_width, b);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(nlist_cell_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, (NlistSystem*)b.sys,
+                     b.bin_start, b.xs, n_atoms, cutoff, cap, fill_value, fill_rows, nb_idx, nb_shift, nb_cnt, status_max,
+                     status_ovf);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

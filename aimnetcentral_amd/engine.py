@@ -159,7 +159,8 @@ class HipEngine:
             opt.coulomb = method
             opt.dsf_rc, opt.dsf_alpha = float(dsf_rc), float(dsf_alpha)
             opt.max_nb = self.max_nb
-            opt.max_nb_lr = self._lr_capacity(float(dsf_rc)) if method == _lib.COULOMB_DSF else 0
+            # periodic DSF walks the cell grid (no list); only non-periodic DSF materialises a long-range list
+            opt.max_nb_lr = self._lr_capacity(float(dsf_rc)) if (method == _lib.COULOMB_DSF and cell is None) else 0
             need = int(self.lib.aimnet_engine_workspace_bytes(self._h, n, n_mol, n_cell, C.byref(opt)))
             if self._ws is None or self._ws.numel() < need:
                 self._ws = None

@@ -28,7 +28,17 @@ constexpr int A_ = 16, G_ = 16, H_ = 12;
 constexpr int NF = A_ * G_;         // 256
 constexpr int NV = A_ * H_;         // 192
 constexpr int APB = 4;              // atoms (waves) per block
+constexpr int CH = 64;              // neighbours staged in LDS per chunk (32 doubled the resident waves: no gain)
 constexpr float PI_F = 3.14159265358979323846f;
+
+// 2-wide float vectors: LLVM lowers their arithmetic to v_pk_{mul,add,fma}_f32 (2 FMAs per issue slot)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) {
+  f2 r;
+  r.x = a;
+  r.y = b;
+  return r;
+}
 
 // ------------------------------------------------------------------------------------------------
 __global__ void pair_geom_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
@@ -112,11 +122,11 @@ __device__ __forceinline__ float basis_fc(const BasisParams& bp, float d, float&
 // ------------------------------------------------------------------------------------------------
 // per-wave LDS scratch of the forward kernel
 struct FwdWaveLds {
-  float gs[64][G_];   // radial basis of the current chunk
-  float4 ud[64];      // (ux, uy, uz, d)
-  int j[64];
-  float fc[64];       // cutoff envelope fc(d) of the chunk (one sincos per pair)
-  float qj[64];       // neighbour charges
+  float gs[64][G_];   // radial basis of the current chunk (first CH rows); reused as 816-float epilogue scratch
+  float4 ud[CH];      // (ux, uy, uz, d)
+  int j[CH];
+  float fc[CH];       // cutoff envelope fc(d) of the chunk (one sincos per pair)
+  float qj[CH];       // neighbour charges
 };
 
 // `row_of` (may be NULL): feature row of atom j inside `a`.  Pass 0 gathers straight from the
@@ -152,15 +162,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
       const int iw = i0 + w;
       cmax = max(cmax, iw < al.last ? nb_cnt[iw] : 0);
     }
-    float acc[4][4];
+    f2 acc[4][2];  // [component c][shift pair]: 2-wide vectors -> v_pk_fma_f32
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[gi][c] = 0.0f;
+    for (int c = 0; c < 4; ++c) acc[c][0] = acc[c][1] = mk2(0.f, 0.f);
     float accq = 0.0f;
 
-    for (int c0 = 0; c0 < cmax; c0 += 64) {
-      const int nch = max(0, min(64, cnt - c0));
+    for (int c0 = 0; c0 < cmax; c0 += CH) {
+      const int nch = max(0, min(CH, cnt - c0));
       __syncthreads();  // previous chunk fully consumed
       if (lane < nch) {
         const size_t p = (size_t)i * cap + c0 + lane;
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
       }
       __syncthreads();
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
+      for (int t = 0; t < CH * G_ / 64; ++t) {
         const int e = lane + 64 * t;
         const int mm = e >> 4, g = e & 15;
         float v = 0.0f;
@@ -186,15 +194,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
       }
       __syncthreads();
       for (int mm = 0; mm < nch; ++mm) {
-        const int j = L.j[mm];
+        const int j = __builtin_amdgcn_readfirstlane(L.j[mm]);  // wave-uniform row -> scalar address
         const float4 av = reinterpret_cast<const float4*>(a + (size_t)j * NF)[lane];
         const float4 gv = *reinterpret_cast<const float4*>(&L.gs[mm][g4]);
         const float4 u = L.ud[mm];
-        const float t0 = av.x * gv.x, t1 = av.y * gv.y, t2 = av.z * gv.z, t3 = av.w * gv.w;
-        acc[0][0] += t0; acc[0][1] += t0 * u.x; acc[0][2] += t0 * u.y; acc[0][3] += t0 * u.z;
-        acc[1][0] += t1; acc[1][1] += t1 * u.x; acc[1][2] += t1 * u.y; acc[1][3] += t1 * u.z;
-        acc[2][0] += t2; acc[2][1] += t2 * u.x; acc[2][2] += t2 * u.y; acc[2][3] += t2 * u.z;
-        acc[3][0] += t3; acc[3][1] += t3 * u.x; acc[3][2] += t3 * u.y; acc[3][3] += t3 * u.z;
+        const f2 t0 = mk2(av.x, av.y) * mk2(gv.x, gv.y), t1 = mk2(av.z, av.w) * mk2(gv.z, gv.w);
+        acc[0][0] += t0;       acc[0][1] += t1;
+        acc[1][0] += t0 * u.x; acc[1][1] += t1 * u.x;
+        acc[2][0] += t0 * u.y; acc[2][1] += t1 * u.y;
+        acc[3][0] += t0 * u.z; acc[3][1] += t1 * u.z;
         if (HAS_Q) {
           const int c = lane & 3;
           const float uc = (c == 0) ? 1.0f : (c == 1 ? u.x : (c == 2 ? u.y : u.z));
@@ -209,15 +217,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
 #pragma unroll
       for (int gi = 0; gi < 4; ++gi) {
         const int f = lane * 4 + gi;
-        sv[f * 3 + 0] = acc[gi][1];
-        sv[f * 3 + 1] = acc[gi][2];
-        sv[f * 3 + 2] = acc[gi][3];
+        sv[f * 3 + 0] = acc[1][gi >> 1][gi & 1];
+        sv[f * 3 + 1] = acc[2][gi >> 1][gi & 1];
+        sv[f * 3 + 2] = acc[3][gi >> 1][gi & 1];
       }
       if (HAS_Q && (lane & 3) != 0) sv[768 + (lane >> 2) * 3 + (lane & 3) - 1] = accq;
       float* xr = x + (size_t)i * ldx;
       const int ri = row_of ? min(63, max(0, row_of[i])) : i;
       reinterpret_cast<float4*>(xr)[lane] = reinterpret_cast<const float4*>(a + (size_t)ri * NF)[lane];
-      reinterpret_cast<float4*>(xr + NF)[lane] = make_float4(acc[0][0], acc[1][0], acc[2][0], acc[3][0]);
+      reinterpret_cast<float4*>(xr + NF)[lane] = make_float4(acc[0][0].x, acc[0][0].y, acc[0][1].x, acc[0][1].y);
     }
     __syncthreads();
     if (live) {
@@ -325,8 +333,11 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
       const float* xr = xbar + (size_t)i * ldx;
       const int aa = lane >> 2;
       const float4 s0 = reinterpret_cast<const float4*>(xr + NF)[lane];
-      const float s0v[4] = {s0.x, s0.y, s0.z, s0.w};
+      // Sbar row layout: the lane's 16 floats are stored COMPONENT-major, [c][gi] (c = 0 scalar, 1..3
+      // vector; gi = the lane's 4 shifts), so that conv_bwd's float4 loads are (gi 0..3) of one
+      // component and all its arithmetic packs into v_pk_* pairs over gi without register shuffles
       float4* out = reinterpret_cast<float4*>(Sbar + (size_t)i * (NF * 4)) + lane * 4;
+      float vv[3][4];
 #pragma unroll
       for (int gi = 0; gi < 4; ++gi) {
         const int g = (lane & 3) * 4 + gi;
@@ -339,8 +350,12 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
           v1 += w * v3[1];
           v2 += w * v3[2];
         }
-        out[gi] = make_float4(s0v[gi], v0, v1, v2);
+        vv[0][gi] = v0; vv[1][gi] = v1; vv[2][gi] = v2;
       }
+      out[0] = s0;
+      out[1] = make_float4(vv[0][0], vv[0][1], vv[0][2], vv[0][3]);
+      out[2] = make_float4(vv[1][0], vv[1][1], vv[1][2], vv[1][3]);
+      out[3] = make_float4(vv[2][0], vv[2][1], vv[2][2], vv[2][3]);
       if (HAS_Q) {
         const int g = lane >> 2, c = lane & 3;
         float v;
@@ -372,13 +387,13 @@ int launch_unconcat(hipStream_t s, bool has_q, const float* xbar, int ldx, const
 
 // ------------------------------------------------------------------------------------------------
 struct BwdWaveLds {
-  float gs[64][G_];
-  float dgs[64][G_];
-  float4 ud[64];
-  int j[64];      // neighbour atom
-  int jr[64];     // its feature row (atomic number in pass 0)
-  float qj[64];
-  float fc[64], dfc[64];
+  float gs[CH][G_];
+  float dgs[CH][G_];
+  float4 ud[CH];
+  int j[CH];      // neighbour atom
+  int jr[CH];     // its feature row (atomic number in pass 0)
+  float qj[CH];
+  float fc[CH], dfc[CH];
 };
 
 // per-lane linear map (dbar, ubar) -> rbar = dbar*u + (ubar - (ubar.u) u)/d
@@ -406,6 +421,9 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
   BwdWaveLds& L = wl[wid];
   const int g4 = (lane & 3) * 4;
   const int qg = lane >> 2, qc = lane & 3;
+  const float qm0 = qc == 0 ? 1.f : 0.f, qm1 = qc == 1 ? 1.f : 0.f, qm2 = qc == 2 ? 1.f : 0.f, qm3 = qc == 3 ? 1.f : 0.f;
+  const float qsgn = qc == 0 ? 1.f : -1.f;
+  (void)dbg;
 
   const AtomLoop al = atom_loop(n_atoms, APB);
   for (int i0 = al.first; i0 < al.last; i0 += al.step) {
@@ -419,38 +437,38 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
       cmax = max(cmax, iw < al.last ? nb_cnt[iw] : 0);
     }
     // centre atom's own rows
-    float ai[4] = {0, 0, 0, 0};
-    float Si[4][4];
+    // [half]: gi pair (0,1) / (2,3);  Si[c][half]: component c of the centre's Sbar row
+    f2 ai[2] = {mk2(0.f, 0.f), mk2(0.f, 0.f)};
+    f2 Si[4][2];
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) Si[gi][c] = 0.0f;
+    for (int c = 0; c < 4; ++c) Si[c][0] = Si[c][1] = mk2(0.f, 0.f);
     float qi = 0.0f, Sqi = 0.0f;
-    int ri = 0;
     if (live) {
-      ri = row_of ? min(63, max(0, row_of[i])) : i;
+      const int ri = row_of ? min(63, max(0, row_of[i])) : i;
       const float4 t = reinterpret_cast<const float4*>(a + (size_t)ri * NF)[lane];
-      ai[0] = t.x; ai[1] = t.y; ai[2] = t.z; ai[3] = t.w;
+      ai[0] = mk2(t.x, t.y);
+      ai[1] = mk2(t.z, t.w);
       const float4* sp = reinterpret_cast<const float4*>(Sbar + (size_t)i * (NF * 4)) + lane * 4;
 #pragma unroll
-      for (int gi = 0; gi < 4; ++gi) {
-        const float4 v = sp[gi];
-        Si[gi][0] = v.x; Si[gi][1] = v.y; Si[gi][2] = v.z; Si[gi][3] = v.w;
+      for (int c = 0; c < 4; ++c) {
+        const float4 v = sp[c];
+        Si[c][0] = mk2(v.x, v.y);
+        Si[c][1] = mk2(v.z, v.w);
       }
       if (HAS_Q) {
         qi = q[i];
         Sqi = Sqbar[(size_t)i * (G_ * 4) + lane];
       }
     }
-    float ab[4] = {0, 0, 0, 0};
+    f2 ab[2] = {mk2(0.f, 0.f), mk2(0.f, 0.f)};
     float xa0 = 0.f, xa1 = 0.f, xa2 = 0.f;  // per-lane partial of dE/dx_i
     float qacc = 0.0f;
     float W[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) W[k] = 0.0f;
 
-    for (int c0 = 0; c0 < cmax; c0 += 64) {
-      const int nch = max(0, min(64, cnt - c0));
+    for (int c0 = 0; c0 < cmax; c0 += CH) {
+      const int nch = max(0, min(CH, cnt - c0));
       __syncthreads();
       if (lane < nch) {
         const size_t p = (size_t)i * cap + c0 + lane;
@@ -466,7 +484,7 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
       }
       __syncthreads();
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
+      for (int t = 0; t < CH * G_ / 64; ++t) {
         const int e = lane + 64 * t;
         const int mm = e >> 4, g = e & 15;
         float v = 0.0f, dv = 0.0f;
@@ -481,59 +499,83 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
         L.dgs[mm][g] = dv;
       }
       __syncthreads();
+      // software pipeline: the 80 B per lane of neighbour mm+1 are requested before neighbour mm is
+      // consumed, so the L2 / Infinity-Cache latency of the gather hides under ~110 VALU instructions
+      float4 n_aj, n_s0, n_s1, n_s2, n_s3;
+      float n_sq = 0.f;
+      {
+        // neighbour ids are wave-uniform: readfirstlane moves them to SGPRs, so the row addresses are
+        // scalar (saddr-form global loads, no per-lane 64-bit address arithmetic on the VALU)
+        const int jn = __builtin_amdgcn_readfirstlane(nch > 0 ? L.j[0] : 0);
+        const int jrn = __builtin_amdgcn_readfirstlane(nch > 0 ? L.jr[0] : 0);
+        n_aj = reinterpret_cast<const float4*>(a + (size_t)jrn * NF)[lane];
+        const float4* spn = reinterpret_cast<const float4*>(Sbar + (size_t)jn * (NF * 4)) + lane * 4;
+        n_s0 = spn[0]; n_s1 = spn[1]; n_s2 = spn[2]; n_s3 = spn[3];
+        if (HAS_Q) n_sq = Sqbar[(size_t)jn * (G_ * 4) + lane];
+      }
       for (int mm = 0; mm < nch; ++mm) {
-        const int j = (dbg & 1) ? i : L.j[mm];  // dbg bit0 (ablation only): perfect gather locality
-        const float4 ajv = reinterpret_cast<const float4*>(a + (size_t)((dbg & 1) ? ri : L.jr[mm]) * NF)[lane];
-        const float4* sp = reinterpret_cast<const float4*>(Sbar + (size_t)j * (NF * 4)) + lane * 4;
-        const float4 sj0 = sp[0], sj1 = sp[1], sj2 = sp[2], sj3 = sp[3];
+        const float4 ajv = n_aj, sj0 = n_s0, sj1 = n_s1, sj2 = n_s2, sj3 = n_s3;
+        const float sqj_cur = n_sq;
+        {
+          const int mn = min(mm + 1, nch - 1);
+          const int jn = __builtin_amdgcn_readfirstlane(L.j[mn]), jrn = __builtin_amdgcn_readfirstlane(L.jr[mn]);
+          n_aj = reinterpret_cast<const float4*>(a + (size_t)jrn * NF)[lane];
+          const float4* spn = reinterpret_cast<const float4*>(Sbar + (size_t)jn * (NF * 4)) + lane * 4;
+          n_s0 = spn[0]; n_s1 = spn[1]; n_s2 = spn[2]; n_s3 = spn[3];
+          if (HAS_Q) n_sq = Sqbar[(size_t)jn * (G_ * 4) + lane];
+        }
         const float4 gv = *reinterpret_cast<const float4*>(&L.gs[mm][g4]);
         const float4 dgv = *reinterpret_cast<const float4*>(&L.dgs[mm][g4]);
         const float4 u = L.ud[mm];
-        const float inv_d = 1.0f / u.w;
-        const float aj[4] = {ajv.x, ajv.y, ajv.z, ajv.w};
-        const float gsv[4] = {gv.x, gv.y, gv.z, gv.w};
-        const float dg[4] = {dgv.x, dgv.y, dgv.z, dgv.w};
-        const float Sj[4][4] = {{sj0.x, sj0.y, sj0.z, sj0.w}, {sj1.x, sj1.y, sj1.z, sj1.w},
-                                {sj2.x, sj2.y, sj2.z, sj2.w}, {sj3.x, sj3.y, sj3.z, sj3.w}};
-        float dij = 0.f, uij0 = 0.f, uij1 = 0.f, uij2 = 0.f;
-        float dji = 0.f, uji0 = 0.f, uji1 = 0.f, uji2 = 0.f;
+        const float inv_d = __builtin_amdgcn_rcpf(u.w);
+        // Both directions of the pair enter dE/dx_i only through the COMBINED adjoints
+        //   D = dbar_ij + dbar_ji,  U = ubar_ji - ubar_ij      (u_ji = -u_ij):
+        //   dE/dx_i += rbar_ji - rbar_ij = -D u + (U - (U.u) u) / d
+        // and the virial of the two ordered pairs is -1/2 r_ij (x) (rbar_ji - rbar_ij).
+        // All of it in 2-wide vectors over the lane's shift pairs (v_pk_* instructions).
+        const f2 aj[2] = {mk2(ajv.x, ajv.y), mk2(ajv.z, ajv.w)};
+        const f2 gsv[2] = {mk2(gv.x, gv.y), mk2(gv.z, gv.w)};
+        const f2 dg[2] = {mk2(dgv.x, dgv.y), mk2(dgv.z, dgv.w)};
+        const f2 Sj[4][2] = {{mk2(sj0.x, sj0.y), mk2(sj0.z, sj0.w)}, {mk2(sj1.x, sj1.y), mk2(sj1.z, sj1.w)},
+                             {mk2(sj2.x, sj2.y), mk2(sj2.z, sj2.w)}, {mk2(sj3.x, sj3.y), mk2(sj3.z, sj3.w)}};
+        f2 Dv = mk2(0.f, 0.f), U0v = mk2(0.f, 0.f), U1v = mk2(0.f, 0.f), U2v = mk2(0.f, 0.f);
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi) {
-          const float Pp = Sj[gi][0] - (u.x * Sj[gi][1] + u.y * Sj[gi][2] + u.z * Sj[gi][3]);
-          const float P = Si[gi][0] + (u.x * Si[gi][1] + u.y * Si[gi][2] + u.z * Si[gi][3]);
-          if (NEED_ABAR) ab[gi] += gsv[gi] * Pp;
-          dij += aj[gi] * P * dg[gi];
-          const float t = gsv[gi] * aj[gi];
-          uij0 += t * Si[gi][1]; uij1 += t * Si[gi][2]; uij2 += t * Si[gi][3];
-          dji += ai[gi] * Pp * dg[gi];
-          const float tp = gsv[gi] * ai[gi];
-          uji0 += tp * Sj[gi][1]; uji1 += tp * Sj[gi][2]; uji2 += tp * Sj[gi][3];
+        for (int hf = 0; hf < 2; ++hf) {
+          const f2 Pp = Sj[0][hf] - (u.x * Sj[1][hf] + u.y * Sj[2][hf] + u.z * Sj[3][hf]);
+          const f2 P = Si[0][hf] + (u.x * Si[1][hf] + u.y * Si[2][hf] + u.z * Si[3][hf]);
+          if (NEED_ABAR) ab[hf] += gsv[hf] * Pp;
+          Dv += dg[hf] * (aj[hf] * P + ai[hf] * Pp);
+          const f2 t = gsv[hf] * aj[hf], tp = gsv[hf] * ai[hf];
+          U0v += tp * Sj[1][hf] - t * Si[1][hf];
+          U1v += tp * Sj[2][hf] - t * Si[2][hf];
+          U2v += tp * Sj[3][hf] - t * Si[3][hf];
         }
+        float D = Dv.x + Dv.y, U0 = U0v.x + U0v.y, U1 = U1v.x + U1v.y, U2 = U2v.x + U2v.y;
         if (HAS_Q) {
-          // lane (g, c) of the charge convolution: Sq[g,c] = sum_m q_j gs_g (1,u)_c
-          const float sqj = Sqbar[(size_t)j * (G_ * 4) + lane];
+          // lane (g, c) of the charge convolution Sq[g,c] = sum_m q_j gs_g (1,u)_c, branch-free:
+          // qm0..qm3 are the lane's one-hot component selectors, qsgn = (1,-1,-1,-1)[c] for the reverse pair
+          const float sqj = sqj_cur;
           const float gq = L.gs[mm][qg], dgq = L.dgs[mm][qg];
-          const float uc = (qc == 0) ? 1.0f : (qc == 1 ? u.x : (qc == 2 ? u.y : u.z));
+          const float uc = qm0 + qm1 * u.x + qm2 * u.y + qm3 * u.z;
           const float qj = L.qj[mm];
-          const float sgn = (qc == 0) ? 1.0f : -1.0f;  // (1, -u) for the reverse pair
-          qacc += gq * sqj * uc * sgn;
-          dij += qj * Sqi * uc * dgq;
-          dji += qi * sqj * uc * sgn * dgq;
-          const float vij = qj * gq * Sqi, vji = qi * gq * sqj;
-          if (qc == 1) { uij0 += vij; uji0 += vji; }
-          if (qc == 2) { uij1 += vij; uji1 += vji; }
-          if (qc == 3) { uij2 += vij; uji2 += vji; }
+          const float sj_s = sqj * qsgn;
+          qacc += gq * sj_s * uc;
+          D += dgq * uc * (qj * Sqi + qi * sj_s);
+          const float v = gq * (qi * sqj - qj * Sqi);
+          U0 += qm1 * v;
+          U1 += qm2 * v;
+          U2 += qm3 * v;
         }
-        float r0, r1, r2, s0, s1, s2;
-        rbar_of(dij, uij0, uij1, uij2, u, inv_d, r0, r1, r2);  // dE/dr_ij   (r_ij = x_j - x_i)
-        const float4 um = make_float4(-u.x, -u.y, -u.z, u.w);
-        rbar_of(dji, uji0, uji1, uji2, um, inv_d, s0, s1, s2);  // dE/dr_ji   (r_ji = x_i - x_j)
-        xa0 += s0 - r0; xa1 += s1 - r1; xa2 += s2 - r2;
+        const float dot = U0 * u.x + U1 * u.y + U2 * u.z;
+        const float f0 = (U0 - dot * u.x) * inv_d - D * u.x;
+        const float f1 = (U1 - dot * u.y) * inv_d - D * u.y;
+        const float f2 = (U2 - dot * u.z) * inv_d - D * u.z;
+        xa0 += f0; xa1 += f1; xa2 += f2;
         if (STRESS) {
-          const float rx = u.x * u.w, ry = u.y * u.w, rz = u.z * u.w;
-          W[0] += rx * r0; W[1] += rx * r1; W[2] += rx * r2;
-          W[3] += ry * r0; W[4] += ry * r1; W[5] += ry * r2;
-          W[6] += rz * r0; W[7] += rz * r1; W[8] += rz * r2;
+          const float hx = -0.5f * u.x * u.w, hy = -0.5f * u.y * u.w, hz = -0.5f * u.z * u.w;
+          W[0] += hx * f0; W[1] += hx * f1; W[2] += hx * f2;
+          W[3] += hy * f0; W[4] += hy * f1; W[5] += hy * f2;
+          W[6] += hz * f0; W[7] += hz * f1; W[8] += hz * f2;
         }
       }
     }
@@ -547,7 +589,7 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
     if (live) {
       if (NEED_ABAR) {
         const float4 xb = reinterpret_cast<const float4*>(xbar + (size_t)i * ldx)[lane];
-        float4 o = make_float4(ab[0] + xb.x, ab[1] + xb.y, ab[2] + xb.z, ab[3] + xb.w);
+        float4 o = make_float4(ab[0].x + xb.x, ab[0].y + xb.y, ab[1].x + xb.z, ab[1].y + xb.w);
         if (abar_in) {
           const float4 p = reinterpret_cast<const float4*>(abar_in + (size_t)i * NF)[lane];
           o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;

@@ -179,6 +179,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
         float dfc;
         L.fc[lane] = basis_fc(bp, ud.w, dfc);
         if (HAS_Q) L.qj[lane] = q[j];
+      } else {  // slots past the row end: a valid row with zero weight (the pipelined loop rounds up to 4)
+        L.j[lane] = 0;
+        L.ud[lane] = make_float4(0.f, 0.f, 0.f, 1.f);
+        L.fc[lane] = 0.f;
+        if (HAS_Q) L.qj[lane] = 0.f;
       }
       __syncthreads();
 #pragma unroll
@@ -193,9 +198,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
         L.gs[mm][g] = v;
       }
       __syncthreads();
-      for (int mm = 0; mm < nch; ++mm) {
-        const int j = __builtin_amdgcn_readfirstlane(L.j[mm]);  // wave-uniform row -> scalar address
-        const float4 av = reinterpret_cast<const float4*>(a + (size_t)j * NF)[lane];
+      // 4-deep software pipeline over the neighbour rows: the kernel is latency-bound (25 VALU
+      // instructions per 1 KiB row), so keep four row loads in flight per wave
+      const int qc_f = lane & 3;
+      const float fm0 = qc_f == 0 ? 1.f : 0.f, fm1 = qc_f == 1 ? 1.f : 0.f, fm2 = qc_f == 2 ? 1.f : 0.f,
+                  fm3 = qc_f == 3 ? 1.f : 0.f;
+      auto row = [&](int mm) {
+        const int j = __builtin_amdgcn_readfirstlane(L.j[min(mm, CH - 1)]);  // wave-uniform -> scalar address
+        return reinterpret_cast<const float4*>(a + (size_t)j * NF)[lane];
+      };
+      auto use = [&](int mm, const float4& av) {
         const float4 gv = *reinterpret_cast<const float4*>(&L.gs[mm][g4]);
         const float4 u = L.ud[mm];
         const f2 t0 = mk2(av.x, av.y) * mk2(gv.x, gv.y), t1 = mk2(av.z, av.w) * mk2(gv.z, gv.w);
@@ -203,11 +215,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
         acc[1][0] += t0 * u.x; acc[1][1] += t1 * u.x;
         acc[2][0] += t0 * u.y; acc[2][1] += t1 * u.y;
         acc[3][0] += t0 * u.z; acc[3][1] += t1 * u.z;
-        if (HAS_Q) {
-          const int c = lane & 3;
-          const float uc = (c == 0) ? 1.0f : (c == 1 ? u.x : (c == 2 ? u.y : u.z));
-          accq += L.qj[mm] * L.gs[mm][lane >> 2] * uc;
+        if (HAS_Q) accq += L.qj[mm] * L.gs[mm][lane >> 2] * (fm0 + fm1 * u.x + fm2 * u.y + fm3 * u.z);
+      };
+      const int nch4 = (nch + 3) & ~3;  // rows >= nch have gs = 0 and a valid (clamped) index: harmless
+      float4 r0 = row(0), r1 = row(1), r2 = row(2), r3 = row(3);
+      for (int mm = 0; mm < nch4; mm += 4) {
+        const float4 c0 = r0, c1 = r1, c2 = r2, c3 = r3;
+        if (mm + 4 < nch4) {
+          r0 = row(mm + 4); r1 = row(mm + 5); r2 = row(mm + 6); r3 = row(mm + 7);
         }
+        use(mm, c0); use(mm + 1, c1); use(mm + 2, c2); use(mm + 3, c3);
       }
     }
     __syncthreads();

@@ -34,7 +34,7 @@ constexpr int BK = 32, LDS_LD = BK + 4;
 //              "2 rounds" at 62 % utilisation, profiles/r1a).
 //   128 x 128: 2x2 MFMA tiles per wave, 72 KiB LDS -> 2 blocks/CU.  Half the L2->LDS traffic per FLOP;
 //              chosen when there are enough tiles to fill the chip many times over.
-template <int EPI, int BM, int BN>
+template <int EPI, int BM, int BN, int ABL = 0>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_nt_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb, int M, int N, int K,
     const float* __restrict__ bias, float* __restrict__ C, float* __restrict__ D, int ldc) {
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_nt_k
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     const bool more = kt + 1 < nk;
-    if (more) AIMNET_GLOAD((kt + 1) * BK);
+    if (more && ABL < 1) AIMNET_GLOAD((kt + 1) * BK);
     const float* a_base = As + (buf * BM + wr * (BM / 2) + li) * LDS_LD + 4 * lh;
     const float* b_base = Bs + (buf * BN + wc * (BN / 2) + li) * LDS_LD + 4 * lh;
 #pragma unroll
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_nt_k
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (more) AIMNET_LSTORE(buf ^ 1);
-    __syncthreads();
+    if (more && ABL < 1) AIMNET_LSTORE(buf ^ 1);
+    if (ABL < 2) __syncthreads();
   }
 #undef AIMNET_GLOAD
 #undef AIMNET_LSTORE
@@ -210,6 +210,19 @@ static int launch_cfg(hipStream_t stream, int epi, const float* A, int lda, cons
       set_last_error("gemm: bad epilogue %d", epi);
       return -1;
   }
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// timing-only ablations of the 64x64 kernel (wrong results): 1 = no global->LDS restaging, 2 = also no barrier
+int launch_gemm_ablation(hipStream_t stream, int abl, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
+                         float* C, int ldc) {
+  const int tiles = ceil_div(M, 64) * ceil_div(N, 64);
+  const size_t lds = (size_t)2 * 128 * LDS_LD * sizeof(float);
+  if (abl == 1)
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, 64, 64, 1>), dim3(tiles), dim3(256), lds, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, 64, 64, 2>), dim3(tiles), dim3(256), lds, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

@@ -26,7 +26,7 @@ namespace aimnet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32, LDS_LD = BK + 4;
+constexpr int BK_DEFAULT = 32;
 
 // BM x BN block tile, 256 threads = 2x2 waves, each wave (BM/2) x (BN/2) = MI x NI MFMA tiles of 32x32.
 //   64 x 64  : 1 MFMA tile per wave, 36 KiB LDS -> 4 blocks/CU.  Fine-grained: with M ~ 10^4 rows a layer
@@ -34,13 +34,16 @@ constexpr int BK = 32, LDS_LD = BK + 4;
 //              "2 rounds" at 62 % utilisation, profiles/r1a).
 //   128 x 128: 2x2 MFMA tiles per wave, 72 KiB LDS -> 2 blocks/CU.  Half the L2->LDS traffic per FLOP;
 //              chosen when there are enough tiles to fill the chip many times over.
-template <int EPI, int BM, int BN, int ABL = 0>
-__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_nt_kernel(
+template <int EPI, int BM, int BN, int ABL = 0, int BK = BK_DEFAULT>
+__global__ __launch_bounds__(256, (BM * BN * BK >= 128 * 128 * 32) ? 2 : (BK <= 16 ? 6 : 4)) void gemm_nt_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb, int M, int N, int K,
     const float* __restrict__ bias, float* __restrict__ C, float* __restrict__ D, int ldc) {
+  constexpr int LDS_LD = BK + 4;
   constexpr int MI = BM / 64, NI = BN / 64;   // MFMA tiles per wave along M / N
-  constexpr int LA = BM / 32, LB = BN / 32;   // float4 staging loads per thread per K tile
+  constexpr int RPT = 256 / (BK / 4);         // rows staged per pass of the 256 threads
+  constexpr int LA = BM / RPT, LB = BN / RPT; // float4 staging loads per thread per K tile
   constexpr int KB = BK / 8;                  // 8-wide k blocks per K tile
+  static_assert(LA >= 1 && LA <= 4 && LB >= 1 && LB <= 4, "staging uses up to 4 named registers per operand");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                         // [2][BM][LDS_LD]
   float* Bs = smem + 2 * BM * LDS_LD;       // [2][BN][LDS_LD]
@@ -75,15 +78,15 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_nt_k
   // (loaded, never stored) so the loads issue branch-free.  The staging registers are NAMED scalars
   // (ra0..ra3 / rb0..rb3, guarded by if constexpr): as arrays hipcc kept them in scratch memory
   // (scratch_store right behind every global_load, -45 % throughput).
-  const int srow = tid >> 3, sc4 = (tid & 7) << 2;
+  const int srow = tid / (BK / 4), sc4 = (tid % (BK / 4)) << 2;
   const float* const ga0 = A + (size_t)min(m0 + srow, M - 1) * lda + sc4;
-  const float* const ga1 = A + (size_t)min(m0 + srow + 32, M - 1) * lda + sc4;
-  const float* const ga2 = A + (size_t)min(m0 + srow + 64, M - 1) * lda + sc4;
-  const float* const ga3 = A + (size_t)min(m0 + srow + 96, M - 1) * lda + sc4;
+  const float* const ga1 = A + (size_t)min(m0 + srow + 1 * RPT, M - 1) * lda + sc4;
+  const float* const ga2 = A + (size_t)min(m0 + srow + 2 * RPT, M - 1) * lda + sc4;
+  const float* const ga3 = A + (size_t)min(m0 + srow + 3 * RPT, M - 1) * lda + sc4;
   const float* const gb0 = Bt + (size_t)min(n0 + srow, N - 1) * ldb + sc4;
-  const float* const gb1 = Bt + (size_t)min(n0 + srow + 32, N - 1) * ldb + sc4;
-  const float* const gb2 = Bt + (size_t)min(n0 + srow + 64, N - 1) * ldb + sc4;
-  const float* const gb3 = Bt + (size_t)min(n0 + srow + 96, N - 1) * ldb + sc4;
+  const float* const gb1 = Bt + (size_t)min(n0 + srow + 1 * RPT, N - 1) * ldb + sc4;
+  const float* const gb2 = Bt + (size_t)min(n0 + srow + 2 * RPT, N - 1) * ldb + sc4;
+  const float* const gb3 = Bt + (size_t)min(n0 + srow + 3 * RPT, N - 1) * ldb + sc4;
   float* const sa = As + srow * LDS_LD + sc4;
   float* const sb = Bs + srow * LDS_LD + sc4;
   float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
@@ -92,13 +95,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_nt_k
 #define AIMNET_GLOAD(k0)                                                   \
   do {                                                                     \
     ra0 = *reinterpret_cast<const float4*>(ga0 + (k0));                    \
-    ra1 = *reinterpret_cast<const float4*>(ga1 + (k0));                    \
+    if constexpr (LA > 1) ra1 = *reinterpret_cast<const float4*>(ga1 + (k0)); \
     if constexpr (LA > 2) {                                                \
       ra2 = *reinterpret_cast<const float4*>(ga2 + (k0));                  \
       ra3 = *reinterpret_cast<const float4*>(ga3 + (k0));                  \
     }                                                                      \
     rb0 = *reinterpret_cast<const float4*>(gb0 + (k0));                    \
-    rb1 = *reinterpret_cast<const float4*>(gb1 + (k0));                    \
+    if constexpr (LB > 1) rb1 = *reinterpret_cast<const float4*>(gb1 + (k0)); \
     if constexpr (LB > 2) {                                                \
       rb2 = *reinterpret_cast<const float4*>(gb2 + (k0));                  \
       rb3 = *reinterpret_cast<const float4*>(gb3 + (k0));                  \
@@ -107,16 +110,16 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_nt_k
 #define AIMNET_LSTORE(buf)                                                                  \
   do {                                                                                      \
     *reinterpret_cast<float4*>(sa + ((buf)*BM) * LDS_LD) = ra0;                             \
-    *reinterpret_cast<float4*>(sa + ((buf)*BM + 32) * LDS_LD) = ra1;                        \
+    if constexpr (LA > 1) *reinterpret_cast<float4*>(sa + ((buf)*BM + RPT) * LDS_LD) = ra1; \
     if constexpr (LA > 2) {                                                                 \
-      *reinterpret_cast<float4*>(sa + ((buf)*BM + 64) * LDS_LD) = ra2;                      \
-      *reinterpret_cast<float4*>(sa + ((buf)*BM + 96) * LDS_LD) = ra3;                      \
+      *reinterpret_cast<float4*>(sa + ((buf)*BM + 2 * RPT) * LDS_LD) = ra2;                 \
+      *reinterpret_cast<float4*>(sa + ((buf)*BM + 3 * RPT) * LDS_LD) = ra3;                 \
     }                                                                                       \
     *reinterpret_cast<float4*>(sb + ((buf)*BN) * LDS_LD) = rb0;                             \
-    *reinterpret_cast<float4*>(sb + ((buf)*BN + 32) * LDS_LD) = rb1;                        \
+    if constexpr (LB > 1) *reinterpret_cast<float4*>(sb + ((buf)*BN + RPT) * LDS_LD) = rb1; \
     if constexpr (LB > 2) {                                                                 \
-      *reinterpret_cast<float4*>(sb + ((buf)*BN + 64) * LDS_LD) = rb2;                      \
-      *reinterpret_cast<float4*>(sb + ((buf)*BN + 96) * LDS_LD) = rb3;                      \
+      *reinterpret_cast<float4*>(sb + ((buf)*BN + 2 * RPT) * LDS_LD) = rb2;                 \
+      *reinterpret_cast<float4*>(sb + ((buf)*BN + 3 * RPT) * LDS_LD) = rb3;                 \
     }                                                                                       \
   } while (0)
 
@@ -191,7 +194,7 @@ static int launch_cfg(hipStream_t stream, int epi, const float* A, int lda, cons
                       const float* bias, float* C, float* D, int ldc) {
   const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
   static const size_t pad = getenv("AIMNET_GEMM_LDS_PAD") ? (size_t)atoi(getenv("AIMNET_GEMM_LDS_PAD")) : 0;  // occupancy probe
-  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float) + pad;
+  const size_t lds = (size_t)2 * (BM + BN) * (BK_DEFAULT + 4) * sizeof(float) + pad;
   dim3 grid(tiles), block(256);
   switch (epi) {
     case EPI_NONE:
@@ -218,7 +221,24 @@ static int launch_cfg(hipStream_t stream, int epi, const float* A, int lda, cons
 int launch_gemm_ablation(hipStream_t stream, int abl, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
                          float* C, int ldc) {
   const int tiles = ceil_div(M, 64) * ceil_div(N, 64);
-  const size_t lds = (size_t)2 * 128 * LDS_LD * sizeof(float);
+  const size_t lds = (size_t)2 * 128 * (BK_DEFAULT + 4) * sizeof(float);
+  if (abl == 3) {  // 64x64 tile with BK = 64 (half the barriers, 2 blocks/CU)
+    const size_t l64 = (size_t)2 * 128 * (64 + 4) * sizeof(float);
+    static bool once = false;
+    if (!once) {
+      AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_NONE, 64, 64, 0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      once = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, 64, 64, 0, 64>), dim3(tiles), dim3(256), l64, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
+    AIMNET_LAUNCH_CHECK();
+    return 0;
+  }
+  if (abl == 4) {  // 64x64 tile with BK = 16: 20 KiB LDS -> up to 8 blocks/CU, every tile resident at once
+    const size_t l16 = (size_t)2 * 128 * (16 + 4) * sizeof(float);
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, 64, 64, 0, 16>), dim3(tiles), dim3(256), l16, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
+    AIMNET_LAUNCH_CHECK();
+    return 0;
+  }
   if (abl == 1)
     hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, 64, 64, 1>), dim3(tiles), dim3(256), lds, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
   else
@@ -232,8 +252,8 @@ static int g_force_tile = 0;  // 0 auto; 64, 128, 12864 (128x64), 64128 (64x128)
 int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N,
                        int K, const float* bias, float* C, float* D, int ldc) {
   if (M <= 0) return 0;
-  if (K % BK != 0 || (lda & 3) || (ldb & 3)) {
-    set_last_error("gemm: K=%d must be a multiple of %d and lda/ldb multiples of 4", K, BK);
+  if (K % BK_DEFAULT != 0 || (lda & 3) || (ldb & 3)) {
+    set_last_error("gemm: K=%d must be a multiple of %d and lda/ldb multiples of 4", K, BK_DEFAULT);
     return -1;
   }
   if (cfg == 0) cfg = g_force_tile;

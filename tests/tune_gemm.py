@@ -8,8 +8,8 @@ from aimnetcentral_amd import _lib
 lib = _lib.load()
 dev = torch.device("cuda:0")
 M = int(os.environ.get("M", 10080))
-shapes = [(512, 736), (736, 512)]
-cfgs = [64, 1000, 2000]
+shapes = [(512, 704), (768, 512), (384, 512)]
+cfgs = [64, 3000, 4000]
 EPI = int(os.environ.get("EPI", 2))
 stream = torch.cuda.current_stream(dev).cuda_stream
 for (N, K) in shapes:

@@ -10,6 +10,7 @@ struct NlistSystem {
   float c[9];    // cell row vectors
   float inv[9];  // inverse: frac = x . inv
   float h[3];    // perpendicular heights
+  float lam;     // Gershgorin bound on lambda_max of the Gram matrix of the slab normals (1 = orthogonal cell)
   int per[3];
   int nb[3];     // bins per lattice axis (slabs of the fractional coordinate)
   int bin_offset;
@@ -25,11 +26,13 @@ __device__ __forceinline__ int bin_of(const NlistSystem& S, float x, float y, fl
 }
 
 // Visit every (neighbour image) candidate of atom i (one wave per atom) whose bin lies within the
-// search range of `cutoff`.  f(j, rx, ry, rz, ok, code) is called convergently by all 64 lanes once
-// per 64-candidate chunk; ok = candidate exists, |r| < cutoff and it is not the atom itself; r is
-// formed as (x_j - x_i) + s.C so that (i,j,s) and (j,i,-s) see exactly opposite vectors.
+// search range of `cutoff`.  f(w, rx, ry, rz, ok, code) is called convergently by all 64 lanes once
+// per 64-candidate chunk; w = 4th component of the candidate's stream entry (atom id bits when
+// BY_ID, else a payload such as the charge); ok = candidate exists, |r| < cutoff and it is not the
+// atom itself (BY_ID: id test in the home image; otherwise r != 0); r is formed as
+// (x_j - x_i) + s.C so that (i,j,s) and (j,i,-s) see exactly opposite vectors.
 // Everything that steers the walk is wave-uniform -> SGPRs, scalar branches, no integer division.
-template <class F>
+template <bool BY_ID, class F>
 __device__ __forceinline__ void cell_walk(const NlistSystem& S, int i, float xi, float yi, float zi, float cutoff,
                                           const int* __restrict__ bin_start, const float4* __restrict__ xs, int lane,
                                           F&& f) {
@@ -48,10 +51,17 @@ __device__ __forceinline__ void cell_walk(const NlistSystem& S, int i, float xi,
   const int b0 = U(bv[0]), b1 = U(bv[1]), b2 = U(bv[2]);
   const int boff = U(S.bin_offset);
   const float cutoff2 = cutoff * cutoff;
+  // Bin pruning.  A point in a bin d_k slabs away along axis k is at least g_k = (|d_k|-1) t_k from the
+  // atom along the slab normal n_k; with r.n_k = p_k, |r|^2 = p^T (N N^T)^-1 p >= |p|^2 / lambda_max(N N^T),
+  // so the bin can hold a neighbour only if g_x^2 + g_y^2 + g_z^2 <= lam * cutoff^2 (rigorous for any cell).
+  const float t0 = UF(S.h[0]) / (float)nb0, t1 = UF(S.h[1]) / (float)nb1, t2 = UF(S.h[2]) / (float)nb2;
+  const float lim2 = UF(S.lam) * cutoff2;
   float c[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) c[k] = UF(S.c[k]);
   for (int dx = -R0; dx <= R0; ++dx) {
+    const float gx = (float)max(0, abs(dx) - 1) * t0;
+    if (gx * gx > lim2) continue;
     int bx = b0 + dx, sx = 0;
     if (p0) {
       while (bx < 0) { bx += nb0; --sx; }
@@ -60,6 +70,10 @@ __device__ __forceinline__ void cell_walk(const NlistSystem& S, int i, float xi,
       continue;
     }
     for (int dy = -R1; dy <= R1; ++dy) {
+      const float gy = (float)max(0, abs(dy) - 1) * t1;
+      const float rem = lim2 - gx * gx - gy * gy;
+      if (rem < 0.0f) continue;
+      const int Rz = min(R2, (int)floorf(sqrtf(rem) / t2) + 1);
       int by = b1 + dy, sy = 0;
       if (p1) {
         while (by < 0) { by += nb1; --sy; }
@@ -68,7 +82,7 @@ __device__ __forceinline__ void cell_walk(const NlistSystem& S, int i, float xi,
         continue;
       }
       // bins along z are contiguous in memory: walk whole runs [z0, z1] that share one lattice shift sz
-      const int zlo = b2 - R2, zhi = b2 + R2;
+      const int zlo = b2 - Rz, zhi = b2 + Rz;
       int sz_lo = 0, sz_hi = 0;
       if (p2) {
         int t = zlo;
@@ -91,17 +105,17 @@ __device__ __forceinline__ void cell_walk(const NlistSystem& S, int i, float xi,
         for (int base = s0; base < s1; base += 64) {
           const int e = base + lane;
           bool ok = false;
-          int j = 0;
-          float rx = 0.f, ry = 0.f, rz = 0.f;
+          float w = 0.f, rx = 0.f, ry = 0.f, rz = 0.f;
           if (e < s1) {
             const float4 cj = xs[e];
-            j = __float_as_int(cj.w);
+            w = cj.w;
             rx = (cj.x - xi) + ox;
             ry = (cj.y - yi) + oy;
             rz = (cj.z - zi) + oz;
-            ok = (rx * rx + ry * ry + rz * rz) < cutoff2 && !(self_image && j == i);
+            const float d2 = rx * rx + ry * ry + rz * rz;
+            ok = d2 < cutoff2 && (BY_ID ? !(self_image && __float_as_int(w) == i) : d2 > 0.0f);
           }
-          f(j, rx, ry, rz, ok, code);
+          f(w, rx, ry, rz, ok, code);
         }
       }
     }

@@ -32,6 +32,7 @@ struct NlistBuffers {      // all device pointers, carved from the caller's work
   int* sorted_tmp;         // [n_atoms]
   int* sorted;             // [n_atoms]
   float4* xs;              // [n_atoms] bin-ordered (x, y, z, atom id)
+  void* sorted_tmp_xq;     // [n_atoms] float4 bin-ordered (x, y, z, charge) for the list-free DSF walk
 };
 size_t nlist_scratch_bytes(int n_atoms, int n_mol);
 size_t nlist_xw_offset(int n_mol);  // byte offset of NlistBuffers::xw inside the scratch

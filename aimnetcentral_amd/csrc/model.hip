@@ -456,12 +456,17 @@ __global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __re
                                                               const int* __restrict__ mol_idx,
                                                               const NlistSystem* __restrict__ sys,
                                                               const int* __restrict__ bin_start,
-                                                              const float4* __restrict__ xs, CoulombParams cp, int n_atoms,
+                                                              const float4* __restrict__ xq, CoulombParams cp, int n_atoms,
                                                               double* __restrict__ ecoul, float* __restrict__ qbar,
                                                               float* __restrict__ fgrad, float* __restrict__ virial_atom) {
+  // Only ~1/3 of the candidates the bin walk visits lie inside Rc, while a pair term costs ~150 VALU
+  // instructions (erfc, exp, fp64 energy sum, virial).  So the walk only COMPACTS the hits (r, q_j) into a
+  // per-wave LDS queue, and the expensive math runs on full 64-lane batches popped from that queue.
+  __shared__ float4 queue[4][128];
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
+  float4* Q = queue[threadIdx.x >> 6];
   const float al = cp.dsf_alpha, Rc = cp.dsf_rc;
   const float two_a_sqrtpi = 2.0f * al * 0.56418958354775629f;
   const float erfc_rc = erfcf(al * Rc);
@@ -469,37 +474,65 @@ __global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __re
   const float slope = erfc_rc / (Rc * Rc) + two_a_sqrtpi * expf(-al * al * Rc * Rc) / Rc;
   const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2], qi = q[i];
   PairAcc A;
-  cell_walk(sys[mol_idx[i]], i, xi, yi, zi, Rc, bin_start, xs, lane,
-            [&](int j, float rx, float ry, float rz, bool ok, int) {
-              if (ok) {
-                const float d = sqrtf(rx * rx + ry * ry + rz * rz);
-                if (d < Rc) {
-                  const float inv = 1.0f / d;
-                  const float ec = erfcf(al * d);
-                  const float w = ec * inv - sv + (d - Rc) * slope;
-                  const float dw = -ec * inv * inv - two_a_sqrtpi * expf(-al * al * d * d) * inv + slope;
-                  pair_add<GRAD, STRESS>(A, w, dw, qi, q[j], rx * inv, ry * inv, rz * inv, d);
-                }
-              }
-            });
+  auto pair_term = [&](const float4& e) {
+    const float d = sqrtf(e.x * e.x + e.y * e.y + e.z * e.z);
+    if (d < Rc) {  // the walk tests the squared distance; keep the reference's d < Rc on the rounded root
+      const float inv = 1.0f / d;
+      const float ec = erfcf(al * d);
+      const float w = ec * inv - sv + (d - Rc) * slope;
+      const float dw = -ec * inv * inv - two_a_sqrtpi * expf(-al * al * d * d) * inv + slope;
+      pair_add<GRAD, STRESS>(A, w, dw, qi, e.w, e.x * inv, e.y * inv, e.z * inv, d);
+    }
+  };
+  int qn = 0;  // wave-uniform fill level of the queue
+  cell_walk<false>(sys[mol_idx[i]], i, xi, yi, zi, Rc, bin_start, xq, lane,
+                   [&](float qj, float rx, float ry, float rz, bool ok, int) {
+                     const unsigned long long mask = __ballot(ok);
+                     if (ok) Q[qn + __popcll(mask & ((1ull << lane) - 1ull))] = make_float4(rx, ry, rz, qj);
+                     qn += __popcll(mask);
+                     __atomic_signal_fence(__ATOMIC_SEQ_CST);  // LDS ops of one wave execute in order
+                     if (qn >= 64) {
+                       const float4 e = Q[lane];
+                       const float4 tail = Q[64 + lane];
+                       __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                       qn -= 64;
+                       if (lane < qn) Q[lane] = tail;
+                       __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                       pair_term(e);
+                     }
+                   });
+  if (lane < qn) pair_term(Q[lane]);
   const float cs = -(sv * 0.5f + al * 0.56418958354775629f);
   const double e_self = 2.0 * (double)cp.factor * (double)(cs * qi * qi);
   const float qb_self = 4.0f * cp.factor * cs * qi;
   pair_store<GRAD, STRESS, true>(A, i, lane, cp.factor, e_self, qb_self, ecoul, qbar, fgrad, virial_atom);
 }
 
+// bin-ordered (x, y, z, q) stream: the walk then needs ONE coalesced 16-byte load per candidate and no
+// dependent q[j] gather (the list-free DSF kernel was latency-bound on that second load)
+__global__ void charge_stream_kernel(const float4* __restrict__ xs, const float* __restrict__ q, int n_atoms,
+                                     float4* __restrict__ xq) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_atoms) return;
+  const float4 c = xs[k];
+  xq[k] = make_float4(c.x, c.y, c.z, q[__float_as_int(c.w)]);
+}
+
 int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, NlistBuffers& b,
                             CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom) {
   dim3 grid(ceil_div(n_atoms, 4)), block(256);
   const NlistSystem* sys = (const NlistSystem*)b.sys;
+  float4* xq = (float4*)b.sorted_tmp_xq;
+  hipLaunchKernelGGL(charge_stream_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.xs, q, n_atoms, xq);
+  AIMNET_LAUNCH_CHECK();
   if (grad && stress)
-    hipLaunchKernelGGL((coulomb_dsf_walk_kernel<true, true>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, b.xs, cp,
+    hipLaunchKernelGGL((coulomb_dsf_walk_kernel<true, true>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, xq, cp,
                        n_atoms, ecoul, qbar, fgrad, virial_atom);
   else if (grad)
-    hipLaunchKernelGGL((coulomb_dsf_walk_kernel<true, false>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, b.xs, cp,
+    hipLaunchKernelGGL((coulomb_dsf_walk_kernel<true, false>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, xq, cp,
                        n_atoms, ecoul, qbar, fgrad, virial_atom);
   else
-    hipLaunchKernelGGL((coulomb_dsf_walk_kernel<false, false>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, b.xs, cp,
+    hipLaunchKernelGGL((coulomb_dsf_walk_kernel<false, false>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, xq, cp,
                        n_atoms, ecoul, qbar, fgrad, virial_atom);
   AIMNET_LAUNCH_CHECK();
   return 0;

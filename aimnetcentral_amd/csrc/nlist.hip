@@ -27,7 +27,7 @@ size_t nlist_scratch_bytes(int n_atoms, int n_mol) {
   b += align_up((size_t)n_atoms * sizeof(int), 256);        // atom_bin
   b += 3 * align_up((max_bins + 1) * sizeof(int), 256);     // count, start, fill
   b += 2 * align_up((size_t)n_atoms * sizeof(int), 256);    // sorted_tmp, sorted
-  b += align_up((size_t)n_atoms * sizeof(float4), 256);     // xs: bin-ordered (x, y, z, atom id)
+  b += 2 * align_up((size_t)n_atoms * sizeof(float4), 256); // xs: bin-ordered (x, y, z, atom id); xq: (x, y, z, charge)
   return b;
 }
 
@@ -50,6 +50,7 @@ void nlist_carve(NlistBuffers& b, char* p, int n_atoms, int n_mol) {
   b.sorted_tmp = (int*)take((size_t)n_atoms * sizeof(int));
   b.sorted = (int*)take((size_t)n_atoms * sizeof(int));
   b.xs = (float4*)take((size_t)n_atoms * sizeof(float4));
+  b.sorted_tmp_xq = (void*)take((size_t)n_atoms * sizeof(float4));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -95,15 +96,26 @@ __global__ void cell_setup_kernel(const float* __restrict__ cell, int n_cell, in
   inv[7] = (m[1] * m[6] - m[0] * m[7]) * id;
   inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
   for (int k = 0; k < 9; ++k) S.inv[k] = (float)inv[k];
+  double nrm[3][3];
   for (int k = 0; k < 3; ++k) {
     const double* a1 = m + 3 * ((k + 1) % 3);
     const double* a2 = m + 3 * ((k + 2) % 3);
     const double cx = a1[1] * a2[2] - a1[2] * a2[1];
     const double cy = a1[2] * a2[0] - a1[0] * a2[2];
     const double cz = a1[0] * a2[1] - a1[1] * a2[0];
-    S.h[k] = (float)(fabs(det) / sqrt(cx * cx + cy * cy + cz * cz));
+    const double len = sqrt(cx * cx + cy * cy + cz * cz);
+    S.h[k] = (float)(fabs(det) / len);
+    nrm[k][0] = cx / len; nrm[k][1] = cy / len; nrm[k][2] = cz / len;
     S.nb[k] = 1;
   }
+  double lam = 1.0;  // Gershgorin: lambda_max(N N^T) <= 1 + max_i sum_{j != i} |n_i . n_j|
+  for (int i2 = 0; i2 < 3; ++i2) {
+    double off = 0.0;
+    for (int j2 = 0; j2 < 3; ++j2)
+      if (j2 != i2) off += fabs(nrm[i2][0] * nrm[j2][0] + nrm[i2][1] * nrm[j2][1] + nrm[i2][2] * nrm[j2][2]);
+    lam = fmax(lam, 1.0 + off);
+  }
+  S.lam = (float)(lam * 1.0001);
   S.per[0] = p0;
   S.per[1] = p1;
   S.per[2] = p2;
@@ -297,12 +309,12 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
   int* row = nb_idx + (size_t)i * cap;
   int* rsh = nb_shift + (size_t)i * cap;
   int count = 0;
-  cell_walk(sys[mol_idx[i]], i, xi, yi, zi, cutoff, bin_start, xs, lane,
-            [&](int j, float, float, float, bool ok, int code) {
+  cell_walk<true>(sys[mol_idx[i]], i, xi, yi, zi, cutoff, bin_start, xs, lane,
+            [&](float w, float, float, float, bool ok, int code) {
               const unsigned long long mask = __ballot(ok);
               const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
               if (ok && pos < cap) {
-                row[pos] = j;
+                row[pos] = __float_as_int(w);
                 rsh[pos] = code;
               }
               count += __popcll(mask);

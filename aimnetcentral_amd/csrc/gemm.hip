@@ -25,6 +25,7 @@
 namespace aimnet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK_DEFAULT = 32;
 
@@ -189,6 +190,292 @@ __global__ __launch_bounds__(256, (BM * BN * BK >= 128 * 128 * 32) ? 2 : (BK <= 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2: 64x64x32 tile, operands DMA'd straight into LDS (global_load_lds_dwordx4: no VGPR staging, no
+// ds_write), un-padded rows with the k-chunk XOR-swizzled by (row>>1)&7 on the SOURCE address (the DMA
+// writes lane-linear; cdna_hip_programming.md rule 21) so the b128 fragment reads stay conflict free,
+// 2 stages x 16 KiB = exactly 32 KiB per block -> 5 blocks per CU (160 KiB): the 1264 tiles of a
+// 10 080 x 512 layer are ALL resident at once, every CU carrying 4.94 of them (no partial last wave).
+// Loop: [__syncthreads = vmcnt(0) + barrier] -> DMA tile k+1 into the other stage -> 8 b128 reads +
+// 16 MFMAs on tile k.  One barrier per K tile, loads in flight for a whole iteration.
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int EPI, int ABL = 0, int BK = 32>
+__global__ __launch_bounds__(256, (BK == 16 ? 8 : 5)) void gemm_nt_glds_kernel(const float* __restrict__ A, int lda,
+                                                                             const float* __restrict__ Bt, int ldb, int M,
+                                                                             int N, int K, const float* __restrict__ bias,
+                                                                             float* __restrict__ C, float* __restrict__ D,
+                                                                             int ldc) {
+  constexpr int BM = 64, BN = 64;
+  constexpr int GR = BK / 4;             // 16-byte granules per tile row (8 or 4)
+  constexpr int SH = (BK == 32) ? 1 : 2;  // rows per 64-bank line = 2^SH ; swizzle = (row >> SH) & (GR-1)
+  constexpr int NP = BM * GR / 256;      // DMA passes per operand tile (2 or 1)
+  constexpr int STAGE = (BM + BN) * BK;  // floats per stage: A tile then B tile, each [64 rows][GR granules of 16 B]
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int tiles_n = (N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+  // DMA mapping: wave w, pass t moves LDS granules G = t*256 + w*64 + lane of a tile;
+  // granule G holds row G/GR, k-chunk (G % GR) ^ swz(row)
+  const float* srcA[NP];
+  const float* srcB[NP];
+#pragma unroll
+  for (int t = 0; t < NP; ++t) {
+    const int G = t * 256 + wid * 64 + lane;
+    const int row = G / GR, kc = (G % GR) ^ ((row >> SH) & (GR - 1));
+    srcA[t] = A + (size_t)min(m0 + row, M - 1) * lda + kc * 4;
+    srcB[t] = Bt + (size_t)min(n0 + row, N - 1) * ldb + kc * 4;
+  }
+  auto dma = [&](int stage, int k0) {
+    float* base = smem + stage * STAGE + wid * 64 * 4;
+#pragma unroll
+    for (int t = 0; t < NP; ++t) glds16(srcA[t] + k0, base + t * 256 * 4);
+#pragma unroll
+    for (int t = 0; t < NP; ++t) glds16(srcB[t] + k0, base + BM * BK + t * 256 * 4);
+  };
+  // fragment addressing: row r, k-chunk kc = 2*kk + lh  ->  float offset (r*GR + (kc ^ swz(r))) * 4
+  const int ra = wr * 32 + li, rb = wc * 32 + li;
+  const int sa = (ra >> SH) & (GR - 1), sb = (rb >> SH) & (GR - 1);
+
+  const int nk = K / BK;
+  dma(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (ABL < 2) __syncthreads();  // = s_waitcnt vmcnt(0) (tile kt landed) + barrier (everybody done with the other stage)
+    const float* As = smem + (kt & 1) * STAGE;
+    const float* Bs = As + BM * BK;
+    float4 af[GR / 2], bf[GR / 2];
+#pragma unroll
+    for (int kk = 0; kk < GR / 2; ++kk) {
+      if (ABL < 3) {
+        af[kk] = *reinterpret_cast<const float4*>(As + (ra * GR + ((2 * kk + lh) ^ sa)) * 4);
+        bf[kk] = *reinterpret_cast<const float4*>(Bs + (rb * GR + ((2 * kk + lh) ^ sb)) * 4);
+      } else {
+        af[kk] = make_float4(1.f + kt, 2.f, 3.f, (float)lane);
+        bf[kk] = make_float4(0.5f, (float)kt, 1.5f, 2.5f);
+      }
+    }
+    // the DMA of the NEXT tile is issued after this tile's fragment reads: the compiler conservatively
+    // puts s_waitcnt vmcnt(0) in front of any ds_read that follows a global_load_lds, which in the other
+    // order serialises the load with the reads; here the load flies during the 4*GR MFMAs below.
+    if (kt + 1 < nk && ABL < 1) dma((kt + 1) & 1, (kt + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < GR / 2; ++kk) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].x, bf[kk].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].y, bf[kk].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].z, bf[kk].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].w, bf[kk].w, acc, 0, 0, 0);
+    }
+  }
+
+  const int col = n0 + wc * 32 + li;
+  if (col >= N) return;
+  float bvv = 0.0f;
+  if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bvv = bias[col];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (row >= M) continue;
+    const size_t o = (size_t)row * ldc + col;
+    const float v = acc[r];
+    if (EPI == EPI_NONE) {
+      C[o] = v;
+    } else if (EPI == EPI_BIAS) {
+      C[o] = v + bvv;
+    } else if (EPI == EPI_BIAS_GELU) {
+      float h, d;
+      gelu_and_grad(v + bvv, h, d);
+      C[o] = h;
+      if (D) D[o] = d;
+    } else {
+      C[o] = v * D[o];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// v3: 64x64x16 tiles in an NST-deep LDS ring (8 KiB per stage).  Same DMA + swizzle as v2, but the fragment
+// reads are inline asm: hipcc puts a conservative `s_waitcnt vmcnt(0)` in front of every C++ LDS read that
+// follows a global_load_lds (it cannot prove the DMA target does not alias), which would drain the ring on
+// every K tile.  With asm reads the only vmcnt wait is ours: vmcnt(2*(NST-2)) = "tile kt has landed, the
+// younger tiles may still be in flight".  NST = 3 -> 24 KiB -> 6 blocks/CU; NST = 2 -> 16 KiB -> 8 blocks/CU.
+template <int EPI, int NST, int ABL = 0>
+__global__ __launch_bounds__(256, (NST == 2 ? 8 : 6)) void gemm_nt_ring_kernel(const float* __restrict__ A, int lda,
+                                                                             const float* __restrict__ Bt, int ldb, int M,
+                                                                             int N, int K, const float* __restrict__ bias,
+                                                                             float* __restrict__ C, float* __restrict__ D,
+                                                                             int ldc) {
+  constexpr int BM = 64, BN = 64, BK = 16;
+  constexpr int STAGE = (BM + BN) * BK;        // floats per stage: A tile then B tile, each [64 rows][4 granules of 16 B]
+  constexpr int STAGE_BYTES = STAGE * 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int tiles_n = (N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+  // DMA: wave w moves LDS granules G = w*64 + lane of each operand tile; granule G = row G>>2, k-chunk (G&3) ^ ((row>>2)&3)
+  const int G = wid * 64 + lane;
+  const int grow = G >> 2, gkc = (G & 3) ^ ((grow >> 2) & 3);
+  // ABL 4 (timing only): every block streams the SAME rows -> all DMA traffic is served by the per-CU L1
+  const float* srcA = A + (size_t)min((ABL == 4 ? 0 : m0) + grow, M - 1) * lda + gkc * 4;
+  const float* srcB = Bt + (size_t)min((ABL == 4 ? 0 : n0) + grow, N - 1) * ldb + gkc * 4;
+  auto dma = [&](int stage, int k0) {
+    float* base = smem + stage * STAGE + wid * 64 * 4;
+    glds16(srcA + k0, base);
+    glds16(srcB + k0, base + BM * BK);
+  };
+  // fragment byte addresses inside a stage: row r, k-chunk kc = 2*kk + lh -> (r*4 + (kc ^ ((r>>2)&3))) * 16
+  const int ra = wr * 32 + li, rb = wc * 32 + li;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+  const unsigned aA0 = lds0 + (ra * 4 + ((0 + lh) ^ ((ra >> 2) & 3))) * 16;
+  const unsigned aA1 = lds0 + (ra * 4 + ((2 + lh) ^ ((ra >> 2) & 3))) * 16;
+  const unsigned aB0 = lds0 + BM * BK * 4 + (rb * 4 + ((0 + lh) ^ ((rb >> 2) & 3))) * 16;
+  const unsigned aB1 = lds0 + BM * BK * 4 + (rb * 4 + ((2 + lh) ^ ((rb >> 2) & 3))) * 16;
+
+  const int nk = K / BK;
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) dma(s, s * BK);
+  int st = 0;          // stage of tile kt
+  int sn = NST - 1;    // stage the next DMA goes to
+  for (int kt = 0; kt < nk; ++kt) {
+    if (ABL < 2 || ABL == 4) {
+      if (NST > 2 && kt + NST - 2 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * (NST - 2)));  // vmcnt(2*(NST-2))
+      else __builtin_amdgcn_s_waitcnt(0x0F70);                                              // vmcnt(0)
+      __builtin_amdgcn_s_barrier();  // tile kt visible to all waves; everybody is done reading tile kt-1 (stage sn)
+    }
+    if (kt + NST - 1 < nk && (ABL < 1 || ABL == 4)) dma(sn, (kt + NST - 1) * BK);
+    f32x4 a0, a1, b0, b1;
+    if (ABL < 3 || ABL == 4) {
+      const unsigned so = st * STAGE_BYTES;
+      asm volatile(
+          "ds_read_b128 %0, %4\n\tds_read_b128 %2, %6\n\tds_read_b128 %1, %5\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+          : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
+          : "v"(aA0 + so), "v"(aA1 + so), "v"(aB0 + so), "v"(aB1 + so)
+          : "memory");
+    } else {
+      a0 = f32x4{1.f + kt, 2.f, 3.f, (float)lane}; a1 = a0; b0 = f32x4{0.5f, (float)kt, 1.5f, 2.5f}; b1 = b0;
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[2], b0[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[3], b0[3], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], b1[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], b1[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2], b1[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[3], b1[3], acc, 0, 0, 0);
+    st = (st + 1 == NST) ? 0 : st + 1;
+    sn = (sn + 1 == NST) ? 0 : sn + 1;
+  }
+
+  const int col = n0 + wc * 32 + li;
+  if (col >= N) return;
+  float bvv = 0.0f;
+  if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bvv = bias[col];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (row >= M) continue;
+    const size_t o = (size_t)row * ldc + col;
+    const float v = acc[r];
+    if (EPI == EPI_NONE) {
+      C[o] = v;
+    } else if (EPI == EPI_BIAS) {
+      C[o] = v + bvv;
+    } else if (EPI == EPI_BIAS_GELU) {
+      float h, d;
+      gelu_and_grad(v + bvv, h, d);
+      C[o] = h;
+      if (D) D[o] = d;
+    } else {
+      C[o] = v * D[o];
+    }
+  }
+}
+
+template <int NST, int ABL = 0>
+static int launch_ring(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
+                       const float* bias, float* C, float* D, int ldc) {
+  const int tiles = ceil_div(M, 64) * ceil_div(N, 64);
+  const size_t lds = (size_t)NST * 128 * 16 * sizeof(float);
+  dim3 grid(tiles), block(256);
+  switch (epi) {
+    case EPI_NONE:
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_NONE, NST, ABL>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    case EPI_BIAS:
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_BIAS, NST, ABL>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    case EPI_BIAS_GELU:
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_BIAS_GELU, NST, ABL>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    case EPI_MUL:
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_MUL, NST, ABL>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    default:
+      set_last_error("gemm: bad epilogue %d", epi);
+      return -1;
+  }
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int BK>
+static int launch_glds(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
+                       const float* bias, float* C, float* D, int ldc) {
+  const int tiles = ceil_div(M, 64) * ceil_div(N, 64);
+  const size_t lds = (size_t)2 * 128 * BK * sizeof(float);  // 32 KiB (BK 32: 4 blocks/CU) or 16 KiB (BK 16: 8 blocks/CU)
+  dim3 grid(tiles), block(256);
+  switch (epi) {
+    case EPI_NONE:
+      hipLaunchKernelGGL((gemm_nt_glds_kernel<EPI_NONE, 0, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    case EPI_BIAS:
+      hipLaunchKernelGGL((gemm_nt_glds_kernel<EPI_BIAS, 0, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    case EPI_BIAS_GELU:
+      hipLaunchKernelGGL((gemm_nt_glds_kernel<EPI_BIAS_GELU, 0, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    case EPI_MUL:
+      hipLaunchKernelGGL((gemm_nt_glds_kernel<EPI_MUL, 0, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    default:
+      set_last_error("gemm: bad epilogue %d", epi);
+      return -1;
+  }
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int BM, int BN>
 static int launch_cfg(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
                       const float* bias, float* C, float* D, int ldc) {
@@ -217,6 +504,220 @@ static int launch_cfg(hipStream_t stream, int epi, const float* A, int lda, cons
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// v4 "panel" kernel: 512 threads = WM x WN waves, v_mfma_f32_16x16x4_f32, block tile
+// TM x TN = (16*SM*WM) x (16*SN*WN) with SM*SN accumulator tiles per wave (160x128, 160x192, 128x96 ...).
+// Why: a 64x64 tile streams (64+64)/(64*64) operand floats per MAC through the DMA and the LDS; measured
+// (tests/tune_gemm.py, ABL runs) that traffic - not L2 bandwidth, not the barrier - costs 30 % of the MFMA
+// time.  A 160x128 tile moves 2.2x fewer bytes per MAC, and the strip counts are template parameters so the
+// host can pick the shape whose tile count just fits a whole number of "rounds" of the 256 CUs
+// (10 080 x 512 -> 63 x 4 = 252 tiles of 160x128: one tile per CU, 98 % balanced).
+// Operands are swapped into the MFMA (weights = "A" operand, activations = "B"), which leaves each lane with
+// 4 consecutive output COLUMNS of one row -> dwordx4 epilogue stores / bias / D loads.
+// LDS: NST-deep ring of [TM rows | TN rows] x 16 floats, DMA'd and swizzled like v3 (slot = chunk ^ 3*((row>>3)&1),
+// conflict-free for the 16x16x4 fragment reads, whose b128 lane groups are not contiguous - MI355X_MICROARCH.md LDS).
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int EPI, int SM, int SN, int WM, int WN>
+__global__ __launch_bounds__(512, (SM * SN > 10 ? 2 : 4)) void gemm_nt_panel_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb, int M, int N, int K,
+    const float* __restrict__ bias, float* __restrict__ C, float* __restrict__ D, int ldc) {
+  static_assert(WM * WN == 8, "8 waves");
+  constexpr int NST = 4;
+  constexpr int TM = 16 * SM * WM, TN = 16 * SN * WN, BK = 16;
+  constexpr int STAGE_BYTES = (TM + TN) * BK * 4;
+  constexpr int NGRAN = (TM + TN) * 4;          // 16-byte granules per stage
+  constexpr int NPASS = (NGRAN + 511) / 512;    // DMA wave-instructions per wave per stage (last pass may be partial)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+
+  const int tiles_n = (N + TN - 1) / TN;
+  const int nwg = gridDim.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int m0 = (wg / tiles_n) * TM, n0 = (wg % tiles_n) * TN;
+
+  f32x4 acc[SM][SN];
+#pragma unroll
+  for (int i = 0; i < SM; ++i)
+#pragma unroll
+    for (int j = 0; j < SN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // DMA sources.  Granule G = p*512 + tid of a stage: rows [0,TM) are the activation tile, [TM,TM+TN) the weight tile;
+  // TM*4 is a multiple of 64, so a wave-instruction never straddles the two.
+  const float* src[NPASS];
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int G = min(p * 512 + tid, NGRAN - 1);
+    const int row = G >> 2;
+    const int kc = (G & 3) ^ (3 * ((row >> 3) & 1));
+    src[p] = (row < TM) ? A + (size_t)min(m0 + row, M - 1) * lda + kc * 4
+                        : Bt + (size_t)min(n0 + row - TM, N - 1) * ldb + kc * 4;
+  }
+  // number of passes in which this wave has granules (wave-uniform): NPASS or NPASS-1
+  const bool last_pass = ((NPASS - 1) * 512 + wid * 64) < NGRAN;
+  auto dma = [&](int stage, int k0) {
+    float* base = smem + stage * (STAGE_BYTES / 4) + wid * 64 * 4;
+#pragma unroll
+    for (int p = 0; p < NPASS - 1; ++p) glds16(src[p] + k0, base + p * 512 * 4);
+    if (last_pass) glds16(src[NPASS - 1] + k0, base + (NPASS - 1) * 512 * 4);
+  };
+
+  // fragment byte addresses in stage 0: row r, k-chunk c = lane>>4 -> (r*4 + (c ^ swz(r))) * 16; strip i adds i*1024 B
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+  const int l16 = lane & 15, lc = lane >> 4;
+  const int rA = wm * 16 * SM + l16, rB = wn * 16 * SN + l16;
+  const unsigned adA = lds0 + (rA * 4 + (lc ^ (3 * ((rA >> 3) & 1)))) * 16;
+  const unsigned adB = lds0 + TM * 64 + (rB * 4 + (lc ^ (3 * ((rB >> 3) & 1)))) * 16;
+
+  const int nk = K / BK;
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) dma(s, s * BK);
+  int st = 0, sn = NST - 1;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + NST - 2 < nk) {  // tiles kt+1 .. kt+NST-2 may stay in flight
+      if (last_pass) wait_vmcnt<(NST - 2) * NPASS>();
+      else wait_vmcnt<(NST - 2) * (NPASS - 1)>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();  // tile kt visible to all waves; everybody has finished reading tile kt-1 (stage sn)
+    if (kt + NST - 1 < nk) dma(sn, (kt + NST - 1) * BK);
+
+    const unsigned so = st * STAGE_BYTES;
+    f32x4 fa[SM], fb[SN];
+    {
+      const unsigned pa = adA + so, pb = adB + so;
+      fb[0] = lds_read16<0>(pb);
+      fa[0] = lds_read16<0>(pa);
+      if (SN > 1) fb[1] = lds_read16<1024>(pb);
+      if (SN > 2) fb[2] = lds_read16<2048>(pb);
+      if (SM > 1) fa[1] = lds_read16<1024>(pa);
+      if (SM > 2) fa[2] = lds_read16<2048>(pa);
+      if (SM > 3) fa[3] = lds_read16<3072>(pa);
+      if (SM > 4) fa[4] = lds_read16<4096>(pa);
+    }
+    // one wait that "produces" every fragment, so no MFMA can be scheduled above it
+    if constexpr (SM == 5 && SN == 2)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fb[0]), "+v"(fb[1]));
+    else if constexpr (SM == 5 && SN == 3)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]));
+    else if constexpr (SM == 5 && SN == 1)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fb[0]));
+    else if constexpr (SM == 4 && SN == 2)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]));
+    else if constexpr (SM == 4 && SN == 3)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]));
+    else if constexpr (SM == 3 && SN == 2)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]), "+v"(fb[1]));
+    else if constexpr (SM == 3 && SN == 1)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]));
+    else if constexpr (SM == 2 && SN == 2)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1]));
+    else if constexpr (SM == 2 && SN == 3)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]));
+    else if constexpr (SM == 1 && SN == 3)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]));
+    else if constexpr (SM == 1 && SN == 2)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fb[1]));
+    else
+      static_assert(SM == 0, "add the fragment list for this (SM, SN)");
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][t], fa[i][t], acc[i][j], 0, 0, 0);
+    st = (st + 1 == NST) ? 0 : st + 1;
+    sn = (sn + 1 == NST) ? 0 : sn + 1;
+  }
+
+  // epilogue: acc[i][j][r] = C[m0 + wm*16*SM + 16 i + (lane&15)][n0 + wn*16*SN + 16 j + 4 (lane>>4) + r]
+#pragma unroll
+  for (int j = 0; j < SN; ++j) {
+    const int col = n0 + wn * 16 * SN + 16 * j + 4 * lc;
+    if (col >= N) continue;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+      const int row = m0 + wm * 16 * SM + 16 * i + l16;
+      if (row >= M) continue;
+      const size_t o = (size_t)row * ldc + col;
+      f32x4 v = acc[i][j];
+      if (EPI == EPI_NONE) {
+        *reinterpret_cast<f32x4*>(C + o) = v;
+      } else if (EPI == EPI_BIAS) {
+        *reinterpret_cast<f32x4*>(C + o) = v + bv;
+      } else if (EPI == EPI_BIAS_GELU) {
+        f32x4 h, d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float hh, dd;
+          gelu_and_grad(v[r] + bv[r], hh, dd);
+          h[r] = hh;
+          d[r] = dd;
+        }
+        *reinterpret_cast<f32x4*>(C + o) = h;
+        if (D) *reinterpret_cast<f32x4*>(D + o) = d;
+      } else {
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(D + o);
+        *reinterpret_cast<f32x4*>(C + o) = v * dv;
+      }
+    }
+  }
+}
+
+template <int SM, int SN, int WM, int WN>
+static int launch_panel(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
+                        const float* bias, float* C, float* D, int ldc) {
+  constexpr int TM = 16 * SM * WM, TN = 16 * SN * WN;
+  const int tiles = ceil_div(M, TM) * ceil_div(N, TN);
+  const size_t lds = (size_t)4 * (TM + TN) * 64;
+  static bool attr_done = false;
+  if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in, once per instantiation
+    AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_NONE, SM, SN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_BIAS, SM, SN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_BIAS_GELU, SM, SN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_MUL, SM, SN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  dim3 grid(tiles), block(512);
+  switch (epi) {
+    case EPI_NONE:
+      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_NONE, SM, SN, WM, WN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    case EPI_BIAS:
+      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_BIAS, SM, SN, WM, WN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    case EPI_BIAS_GELU:
+      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_BIAS_GELU, SM, SN, WM, WN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    case EPI_MUL:
+      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_MUL, SM, SN, WM, WN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    default:
+      set_last_error("gemm: bad epilogue %d", epi);
+      return -1;
+  }
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
 // timing-only ablations of the 64x64 kernel (wrong results): 1 = no global->LDS restaging, 2 = also no barrier
 int launch_gemm_ablation(hipStream_t stream, int abl, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
                          float* C, int ldc) {
@@ -230,6 +731,14 @@ int launch_gemm_ablation(hipStream_t stream, int abl, const float* A, int lda, c
       once = true;
     }
     hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, 64, 64, 0, 64>), dim3(tiles), dim3(256), l64, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
+    AIMNET_LAUNCH_CHECK();
+    return 0;
+  }
+  if (abl >= 5) {  // ablations of the DMA kernel: 5 = no DMA in the loop, 6 = also no barrier, 7 = also no LDS reads (pure MFMA)
+    const size_t l2 = (size_t)2 * 128 * 32 * sizeof(float);
+    if (abl == 5) hipLaunchKernelGGL((gemm_nt_glds_kernel<EPI_NONE, 1>), dim3(tiles), dim3(256), l2, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
+    else if (abl == 6) hipLaunchKernelGGL((gemm_nt_glds_kernel<EPI_NONE, 2>), dim3(tiles), dim3(256), l2, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
+    else hipLaunchKernelGGL((gemm_nt_glds_kernel<EPI_NONE, 3>), dim3(tiles), dim3(256), l2, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
     AIMNET_LAUNCH_CHECK();
     return 0;
   }
@@ -249,6 +758,33 @@ int launch_gemm_ablation(hipStream_t stream, int abl, const float* A, int lda, c
 
 static int g_force_tile = 0;  // 0 auto; 64, 128, 12864 (128x64), 64128 (64x128) from AIMNET_GEMM_TILE for A/B runs
 
+// Tile choice.  Every candidate runs the same MFMA rate; what differs is (a) how evenly ceil(M/TM)*ceil(N/TN)
+// tiles load the 256 CUs - the busiest CU carries ceil(tiles/256) tiles of TM*TN MACs per k, padding of M and N
+// included - and (b) the operand bytes streamed per MAC, x = (TM+TN)/(TM*TN), which costs MFMA issue slots
+// through the DMA + LDS-read path.  Fitted to tests/tune_gemm.py on 10 080-row layers (profiles/r1c_gemm_tiles.md):
+// efficiency = 0.9 / (1 + 5x), times 0.88 when a CU holds a single block of <= 10 accumulator tiles per wave
+// (nothing to overlap its barrier with).  The model reproduces the measured ranking on all six MLP shapes.
+struct TileCand { int id, tm, tn, acc_tiles; };
+static const TileCand kTileCands[] = {
+    {152, 160, 128, 10}, {142, 128, 128, 8}, {132, 96, 128, 6}, {122, 64, 128, 4}, {153, 160, 192, 15}, {143, 128, 192, 12},
+    {223, 128, 96, 6},   {213, 64, 96, 3},   {222, 128, 64, 4}, {351, 80, 128, 5}, {331, 48, 128, 3},   {5, 64, 64, 1}};
+static int choose_tile(int M, int N, bool vec_ok) {
+  int best = 5;
+  double best_cost = 1e300;
+  for (const TileCand& c : kTileCands) {
+    if (c.id != 5 && !vec_ok) continue;
+    const long tiles = (long)ceil_div(M, c.tm) * ceil_div(N, c.tn);
+    const long per_cu = (tiles + 255) / 256;
+    const double x = (double)(c.tm + c.tn) / ((double)c.tm * c.tn);
+    double eff = 0.9 / (1.0 + 5.0 * x);
+    if (per_cu == 1 && c.acc_tiles <= 10) eff *= 0.88;
+    if (c.id == 5) eff *= 0.9;  // 4-wave ring kernel: larger fixed cost per tile (profiles/r1c_gemm_tiles.md)
+    const double cost = (double)per_cu * c.tm * c.tn / eff;
+    if (cost < best_cost) { best_cost = cost; best = c.id; }
+  }
+  return best;
+}
+
 int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N,
                        int K, const float* bias, float* C, float* D, int ldc) {
   if (M <= 0) return 0;
@@ -257,12 +793,31 @@ int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int
     return -1;
   }
   if (cfg == 0) cfg = g_force_tile;
-  if (cfg == 0) {
-    // 128x128 tiles only when they alone would fill the 256 CUs (2 blocks each) ~8 times over
-    const long big_tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
-    cfg = big_tiles >= 4096 ? 128 : 64;
-  }
+  if (cfg == 0) cfg = choose_tile(M, N, ((N | ldc) & 3) == 0 && (((size_t)bias | (size_t)C | (size_t)D) & 15) == 0);
   switch (cfg) {
+    case 2: return launch_glds<32>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    case 3: return launch_glds<16>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+#define AIMNET_PANEL_CASE(ID, SM_, SN_, WM_, WN_) \
+    case ID: return launch_panel<SM_, SN_, WM_, WN_>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    // panel kernels: id = 100*arrangement + 10*SM + SN; arrangement 1 = 2x4 waves, 2 = 4x2, 3 = 1x8
+    AIMNET_PANEL_CASE(152, 5, 2, 2, 4)  // 160 x 128
+    AIMNET_PANEL_CASE(142, 4, 2, 2, 4)  // 128 x 128
+    AIMNET_PANEL_CASE(132, 3, 2, 2, 4)  //  96 x 128
+    AIMNET_PANEL_CASE(122, 2, 2, 2, 4)  //  64 x 128
+    AIMNET_PANEL_CASE(153, 5, 3, 2, 4)  // 160 x 192
+    AIMNET_PANEL_CASE(143, 4, 3, 2, 4)  // 128 x 192
+    AIMNET_PANEL_CASE(223, 2, 3, 4, 2)  // 128 x  96
+    AIMNET_PANEL_CASE(213, 1, 3, 4, 2)  //  64 x  96
+    AIMNET_PANEL_CASE(222, 2, 2, 4, 2)  // 128 x  64
+    AIMNET_PANEL_CASE(351, 5, 1, 1, 8)  //  80 x 128
+    AIMNET_PANEL_CASE(331, 3, 1, 1, 8)  //  48 x 128
+#undef AIMNET_PANEL_CASE
+    case 4: return launch_ring<2>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    case 5: return launch_ring<3>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    case 51: return launch_ring<3, 1>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    case 52: return launch_ring<3, 2>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    case 53: return launch_ring<3, 3>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    case 54: return launch_ring<3, 4>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
     case 128: return launch_cfg<128, 128>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
     case 12864: return launch_cfg<128, 64>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
     case 64128: return launch_cfg<64, 128>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);

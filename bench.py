@@ -224,7 +224,7 @@ def main():
                        "parallelism": f"batch-shard x{world} (independent frames, RCCL all-gather of energies)" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
-                         "kernel": "gemm_nt_kernel (fp32 MFMA MLP GEMMs, all launches of a step)",
+                         "kernel": "gemm_nt_panel_kernel (fp32 MFMA MLP GEMMs, all launches of a step)",
                          "gemm_ms_per_step": gemm_ms, "other_ms_per_step": prof["other"] / args.steps,
                          "algorithmic_flop_per_step": flops_step},
         }

@@ -154,3 +154,45 @@ def test_neighbor_list_batched_cells():
     got, want = rows_as_sets(nb, num, sh), oracle_sets(ref, rsh, 192)
     assert sum(len(set(a) ^ set(b)) for a, b in zip(got, want)) <= 2
     assert all(j < 96 for r in got[:96] for (j, *_x) in r) and all(j >= 96 for r in got[96:] for (j, *_x) in r)
+
+
+# ---- MLP GEMM (csrc/gemm.hip): every tile configuration against an fp64 product ---------------------------
+GEMM_CFGS = [0, 5, 3, 64, 152, 142, 132, 122, 153, 143, 223, 213, 222, 351, 331]
+
+
+@pytest.mark.parametrize("cfg", GEMM_CFGS)
+@pytest.mark.parametrize("M,N,K", [(1000, 288, 384), (333, 736, 512), (47, 128, 32)])
+def test_gemm_tiles_match_fp64(cfg, M, N, K):
+    """C = epilogue(A . Bt^T): bias+GELU (with its derivative D), plain, and the backward's multiply-by-D form.
+    Tolerance: fp32 accumulation over K <= 512 terms of O(1) products -> |err| <= 5e-5 (observed ~1e-5)."""
+    from aimnetcentral_amd import _lib
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(1234 + cfg + M)
+    A = torch.randn(M, K, generator=gen).to(dev)
+    Bt = (torch.randn(N, K, generator=gen) * 0.1).to(dev)
+    bias = torch.randn(N, generator=gen).to(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    z = A.double() @ Bt.double().T
+    for epi in (0, 1, 2, 3):
+        Cm = torch.full((M, N), float("nan"), device=dev)
+        D = torch.rand(M, N, generator=gen).to(dev) if epi == 3 else torch.full((M, N), float("nan"), device=dev)
+        D0 = D.clone()
+        rc = lib.aimnet_debug_gemm(cfg, epi, A.data_ptr(), K, Bt.data_ptr(), K, M, N, K, bias.data_ptr(), Cm.data_ptr(),
+                                   D.data_ptr(), N, stream)
+        assert rc == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        if epi == 0:
+            want = z
+        elif epi == 1:
+            want = z + bias.double()
+        elif epi == 2:
+            zb = z + bias.double()
+            cdf = 0.5 * (1 + torch.erf(zb / 2**0.5))
+            want = zb * cdf
+            want_d = cdf + zb * torch.exp(-0.5 * zb * zb) / (2 * torch.pi) ** 0.5
+            assert (D.double() - want_d).abs().max().item() < 5e-5
+        else:
+            want = z * D0.double()
+        assert (Cm.double() - want).abs().max().item() < 5e-5, (cfg, epi)

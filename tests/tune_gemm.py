@@ -8,8 +8,9 @@ from aimnetcentral_amd import _lib
 lib = _lib.load()
 dev = torch.device("cuda:0")
 M = int(os.environ.get("M", 10080))
-shapes = [(512, 704), (768, 512), (384, 512)]
-cfgs = [64, 3000, 4000]
+shapes = [(512, 736), (384, 512), (256, 384), (736, 512), (512, 384), (128, 256)]
+if os.environ.get("ONESHAPE"): shapes = shapes[:1]
+cfgs = [int(c) for c in os.environ.get("CFGS", "64,2,3").split(",")]
 EPI = int(os.environ.get("EPI", 2))
 stream = torch.cuda.current_stream(dev).cuda_stream
 for (N, K) in shapes:

@@ -657,6 +657,269 @@ int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pass-0 backward through SPECIES MOMENTS.
+// In the first pass the neighbour features are rows of the embedding table, a_j = afv[Z_j], so the only
+// per-pair unknown of the contraction sum_{a} a_j[a,g] Sbar_i[a,g,c] is the species of j.  Contract once per
+// atom and species,
+//     T_i[s][g][c] = sum_a Sbar_i[a,g,c] * afv[z(s)][a,g]            (256 B per (atom, species present)),
+// and the combined adjoints of conv_bwd_kernel (same algebra, same sign conventions) collapse to
+//     D   = sum_g dgs_g ( T_i[s_j][g][0] + T_j[s_i][g][0] + u . (T_i[s_j][g][1:4] - T_j[s_i][g][1:4]) )
+//     U_c = sum_g  gs_g ( T_j[s_i][g][c] - T_i[s_j][g][c] ),                     c = 1..3
+// i.e. 64 + 64 floats per pair instead of a 1 KiB feature row and a 4 KiB Sbar row, and 16x fewer FMAs.
+// Exact re-association of the reference sums (Warp backward_g, conv_sv_2d_sp_wp.py:139-164, with the AEV
+// backward of aev.py:94-110); no gradient with respect to a_j is needed because afv is a constant.
+__global__ void species_kernel(const int* __restrict__ numbers, const int* __restrict__ slot_of_z, int n_atoms,
+                               int* __restrict__ aslot, unsigned long long* __restrict__ present_part) {
+  __shared__ unsigned long long s_mask;
+  if (threadIdx.x == 0) s_mask = 0ull;
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long m = 0ull;
+  if (i < n_atoms) {
+    const int sl = slot_of_z[min(63, max(0, numbers[i]))];
+    aslot[i] = sl;
+    m = 1ull << sl;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m |= __shfl_xor(m, off, 64);
+  if ((threadIdx.x & 63) == 0) atomicOr(&s_mask, m);
+  __syncthreads();
+  if (threadIdx.x == 0) present_part[blockIdx.x] = s_mask;
+}
+
+int launch_species(hipStream_t s, const int* numbers, const int* slot_of_z, int n_atoms, int* aslot,
+                   unsigned long long* present_part) {
+  hipLaunchKernelGGL(species_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, numbers, slot_of_z, n_atoms, aslot,
+                     present_part);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// xbar of pass 0 -> Sbar_i (registers/LDS only, never written to HBM) -> T_i[s] for the species present.
+// Stage 1 is unconcat_kernel<false>'s arithmetic (lane = (a, 4 shifts)); stage 2 re-reads the row from LDS with
+// lane = (g, c) and contracts over a.  Row stride 65 keeps both the (a,gq)-major writes and the (g,c)-major reads
+// conflict free.
+__global__ __launch_bounds__(256) void unconcat_p0_kernel(const float* __restrict__ xbar, int ldx,
+                                                         const float* __restrict__ Vsave, const float* __restrict__ agh_a,
+                                                         const float* __restrict__ afv, const int* __restrict__ z_of_slot,
+                                                         int nslots, const unsigned long long* __restrict__ present_part,
+                                                         int n_part, float* __restrict__ T, int n_atoms) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  float* s_agh = dsm;                                  // A*G*H
+  float* s_vb = s_agh + A_ * G_ * H_;                  // [APB][NV*3]
+  float* s_sb = s_vb + APB * NV * 3;                   // [APB][A*65]
+  float* s_afv = s_sb + APB * A_ * 65;                 // [npres][256]
+  __shared__ int s_plist[64];
+  __shared__ int s_npres;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < A_ * G_ * H_; k += 256) s_agh[k] = agh_a[k];
+  if (wid == 0) {
+    unsigned long long m = 0ull;
+    for (int k = lane; k < n_part; k += 64) m |= present_part[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m |= __shfl_xor(m, off, 64);
+    if (lane < nslots && ((m >> lane) & 1ull)) s_plist[__popcll(m & ((1ull << lane) - 1ull))] = lane;
+    if (lane == 0) s_npres = __popcll(m);
+  }
+  __syncthreads();
+  const int npres = s_npres;
+  for (int k = threadIdx.x; k < npres * NF; k += 256) s_afv[k] = afv[(size_t)z_of_slot[s_plist[k >> 8]] * NF + (k & 255)];
+  float* vb = s_vb + wid * (NV * 3);
+  float* sb = s_sb + wid * (A_ * 65);
+  const AtomLoop al = atom_loop(n_atoms, APB);
+  for (int i0 = al.first; i0 < al.last; i0 += al.step) {
+    const int i = i0 + wid;
+    const bool live = i < al.last;
+    __syncthreads();
+    if (live) {
+      const float* xr = xbar + (size_t)i * ldx;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int o = lane + 64 * t;
+        const float f = 2.0f * xr[2 * NF + o];
+        const float* vs = Vsave + (size_t)i * (NV * 3) + o * 3;
+        vb[o * 3 + 0] = f * vs[0];
+        vb[o * 3 + 1] = f * vs[1];
+        vb[o * 3 + 2] = f * vs[2];
+      }
+    }
+    __syncthreads();
+    if (live) {
+      const float* xr = xbar + (size_t)i * ldx;
+      const int aa = lane >> 2, gq = lane & 3;
+      const float4 s0 = reinterpret_cast<const float4*>(xr + NF)[lane];
+      const float s0v[4] = {s0.x, s0.y, s0.z, s0.w};
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        const int g = gq * 4 + gi;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int h = 0; h < H_; ++h) {
+          const float w = s_agh[(aa * G_ + g) * H_ + h];
+          const float* v3 = &vb[(aa * H_ + h) * 3];
+          v0 += w * v3[0];
+          v1 += w * v3[1];
+          v2 += w * v3[2];
+        }
+        float* o = sb + aa * 65 + g * 4;
+        o[0] = s0v[gi]; o[1] = v0; o[2] = v1; o[3] = v2;
+      }
+    }
+    __syncthreads();
+    if (live) {
+      float sr[A_];
+#pragma unroll
+      for (int a = 0; a < A_; ++a) sr[a] = sb[a * 65 + lane];
+      const int g = lane >> 2;
+      for (int k = 0; k < npres; ++k) {
+        const float* av = s_afv + k * NF + g;
+        float t = 0.f;
+#pragma unroll
+        for (int a = 0; a < A_; ++a) t += sr[a] * av[a * G_];
+        T[((size_t)i * nslots + s_plist[k]) * 64 + lane] = t;
+      }
+    }
+  }
+}
+
+int launch_unconcat_p0(hipStream_t s, const float* xbar, int ldx, const float* Vsave, const float* agh_a, const float* afv,
+                       const int* z_of_slot, int nslots, const unsigned long long* present_part, int n_part, float* T,
+                       int n_atoms) {
+  const int grid = min(ceil_div(n_atoms, APB), 256 * 4);
+  const size_t lds = sizeof(float) * ((size_t)A_ * G_ * H_ + APB * NV * 3 + APB * A_ * 65 + (size_t)nslots * NF);
+  static bool attr = false;
+  if (!attr) {
+    AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)unconcat_p0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL(unconcat_p0_kernel, dim3(grid), dim3(256), lds, s, xbar, ldx, Vsave, agh_a, afv, z_of_slot, nslots,
+                     present_part, n_part, T, n_atoms);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+struct P0WaveLds {
+  float4 ud[64];
+  float fc[64], dfc[64];
+  int j[64], sj[64];
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over each aligned group of 16 lanes, result in all 16 (quad xor 1, quad xor 2, row_half_mirror, row_mirror)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;
+}
+
+// One wave per centre atom; 4 neighbours per step, 16 lanes (one per shift g) each: the two 256 B moment blocks of a
+// pair are single coalesced float4 loads, the radial basis is evaluated exactly once per (pair, g).
+template <bool STRESS>
+__global__ __launch_bounds__(256) void conv_bwd_p0_kernel(const float4* __restrict__ T4, int nslots,
+                                                         const int* __restrict__ aslot, const int* __restrict__ nb_idx,
+                                                         const int* __restrict__ nb_cnt, const float4* __restrict__ pg,
+                                                         int cap, BasisParams bp, float* __restrict__ fgrad,
+                                                         float* __restrict__ virial_atom, int n_atoms) {
+  __shared__ __attribute__((aligned(16))) P0WaveLds wl[APB];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  P0WaveLds& L = wl[wid];
+  const int g = lane & 15, pq = lane >> 4;
+  const float shift_g = bp.shifts[g];
+  const AtomLoop al = atom_loop(n_atoms, APB);
+  for (int i0 = al.first; i0 < al.last; i0 += al.step) {
+    const int i = i0 + wid;
+    if (i >= al.last) continue;  // no block barriers below: the LDS staging is private to the wave
+    const int cnt = nb_cnt[i];
+    const int si = aslot[i];
+    const float4* Ti_base = T4 + (size_t)i * nslots * 16 + g;
+    float xa0 = 0.f, xa1 = 0.f, xa2 = 0.f;
+    float W[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) W[k] = 0.0f;
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+      const int nch = min(64, cnt - c0);
+      __builtin_amdgcn_wave_barrier();
+      if (lane < nch) {  // lane = pair: one sincos per pair
+        const size_t p = (size_t)i * cap + c0 + lane;
+        const int j = nb_idx[p];
+        const float4 ud = pg[p];
+        L.j[lane] = j;
+        L.sj[lane] = aslot[j];
+        L.ud[lane] = ud;
+        float dfc;
+        L.fc[lane] = basis_fc(bp, ud.w, dfc);
+        L.dfc[lane] = dfc;
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int m0 = 0; m0 < nch; m0 += 4) {
+        const int m = min(m0 + pq, nch - 1);
+        const bool valid = m0 + pq < nch;
+        const int j = L.j[m], sj = L.sj[m];
+        const float4 u = L.ud[m];
+        const float fc = L.fc[m], dfc = L.dfc[m];
+        const float4 Ti = Ti_base[(size_t)sj * 16];
+        const float4 Tj = T4[((size_t)j * nslots + si) * 16 + g];
+        const float dd = u.w - shift_g;
+        const float Gg = expf(-bp.eta * dd * dd);
+        const float gs = Gg * fc;
+        const float dg = Gg * (dfc - 2.0f * bp.eta * dd * fc);
+        float D = dg * ((Ti.x + Tj.x) + u.x * (Ti.y - Tj.y) + u.y * (Ti.z - Tj.z) + u.z * (Ti.w - Tj.w));
+        float U0 = gs * (Tj.y - Ti.y), U1 = gs * (Tj.z - Ti.z), U2 = gs * (Tj.w - Ti.w);
+        D = row16_sum(D); U0 = row16_sum(U0); U1 = row16_sum(U1); U2 = row16_sum(U2);
+        const float keep = (valid && g == 0) ? 1.0f : 0.0f;
+        const float inv_d = __builtin_amdgcn_rcpf(u.w);
+        const float dot = U0 * u.x + U1 * u.y + U2 * u.z;
+        const float f0 = keep * ((U0 - dot * u.x) * inv_d - D * u.x);
+        const float f1 = keep * ((U1 - dot * u.y) * inv_d - D * u.y);
+        const float f2 = keep * ((U2 - dot * u.z) * inv_d - D * u.z);
+        xa0 += f0; xa1 += f1; xa2 += f2;
+        if (STRESS) {
+          const float hx = -0.5f * u.x * u.w, hy = -0.5f * u.y * u.w, hz = -0.5f * u.z * u.w;
+          W[0] += hx * f0; W[1] += hx * f1; W[2] += hx * f2;
+          W[3] += hy * f0; W[4] += hy * f1; W[5] += hy * f2;
+          W[6] += hz * f0; W[7] += hz * f1; W[8] += hz * f2;
+        }
+      }
+    }
+    xa0 = wave_sum(xa0); xa1 = wave_sum(xa1); xa2 = wave_sum(xa2);
+    if (STRESS) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) W[k] = wave_sum(W[k]);
+    }
+    if (lane == 0) {
+      fgrad[3 * i + 0] += xa0;
+      fgrad[3 * i + 1] += xa1;
+      fgrad[3 * i + 2] += xa2;
+    }
+    if (STRESS && lane < 9) {
+      float v = W[0];
+#pragma unroll
+      for (int k = 1; k < 9; ++k) v = (lane == k) ? W[k] : v;
+      virial_atom[(size_t)i * 9 + lane] += v;
+    }
+  }
+}
+
+int launch_conv_bwd_p0(hipStream_t s, bool stress, const float* T, int nslots, const int* aslot, const int* nb_idx,
+                       const int* nb_cnt, const float4* pg, int cap, BasisParams bp, float* fgrad, float* virial_atom,
+                       int n_atoms) {
+  const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
+  if (stress)
+    hipLaunchKernelGGL(conv_bwd_p0_kernel<true>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(T), nslots, aslot,
+                       nb_idx, nb_cnt, pg, cap, bp, fgrad, virial_atom, n_atoms);
+  else
+    hipLaunchKernelGGL(conv_bwd_p0_kernel<false>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(T), nslots, aslot,
+                       nb_idx, nb_cnt, pg, cap, bp, fgrad, virial_atom, n_atoms);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // stand-alone op with the exact contract of torch.ops.aimnet.conv_sv_2d_sp_fwd / _bwd
 // (conv_sv_2d_sp_wp.py:252-340): generic (A, G) with A*G a multiple of 4, materialised g (B,M,G,4),
 // sentinel index B-1, rows packed real-first (early exit at the first sentinel), padding row zero.

@@ -48,6 +48,11 @@ struct aimnet_engine {
   std::vector<void*> allocs;
   float *afv, *agh_a, *agh_q;
   double* sae;
+  // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
+  // are finite (supported elements); every other Z shares one extra slot that points at its NaN row
+  int *slot_of_z, *z_of_slot;
+  int nslots = 0;
+  bool p0_moments = true;  // AIMNET_P0_MOMENTS=0 keeps the generic conv_bwd for pass 0 (A/B and parity runs)
   std::vector<Layer> mlp[AIMNET_MAX_PASS];
   std::vector<Layer> head;
   float* head_w_last;  // [k] last head layer as a vector
@@ -153,6 +158,9 @@ struct Workspace {
   int S;         // slices per molecule
   float *zb0, *zb1;  // ping-pong adjoint buffers (N x max padded width)
   float *Sbar, *Sqbar;
+  int* aslot;                        // species slot of every atom (pass-0 moments)
+  unsigned long long* present_part;  // per-block masks of the slots present
+  int n_part;
   size_t total;
 };
 
@@ -220,11 +228,15 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
     W.abar = c.take<float>(n * 256, "abar", 256);
     W.zb0 = c.take<float>(n * mw, "zb0", mw);
     W.zb1 = c.take<float>(n * mw, "zb1", mw);
-    W.Sbar = c.take<float>(n * 1024, "Sbar", 1024);
+    // Sbar doubles as the species-moment table T of pass 0 (N x nslots x 64), which outlives no Sbar
+    W.Sbar = c.take<float>(n * std::max(1024, e->nslots * 64), "Sbar", 1024);
     W.Sqbar = c.take<float>(n * 64, "Sqbar", 64);
   } else {
     W.abar = W.zb0 = W.zb1 = W.Sbar = W.Sqbar = nullptr;
   }
+  W.n_part = (N + 255) / 256;
+  W.aslot = c.take<int>(n);
+  W.present_part = c.take<unsigned long long>((size_t)W.n_part);
   W.total = align_up(c.off, 256);
 }
 
@@ -255,6 +267,24 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
   int rc = 0;
   const int AG = 256;
   if ((rc = dev_upload(e, w->afv, (size_t)64 * AG, &e->afv))) goto fail;
+  {
+    int soz[64], zos[64];
+    int ns = 0, bad_row = -1;
+    for (int z = 0; z < 64; ++z) {
+      bool ok = true;
+      for (int k = 0; k < AG; ++k) ok = ok && std::isfinite(w->afv[(size_t)z * AG + k]);
+      if (ok) { soz[z] = ns; zos[ns++] = z; } else { soz[z] = -1; if (bad_row < 0) bad_row = z; }
+    }
+    if (bad_row >= 0) {
+      for (int z = 0; z < 64; ++z) if (soz[z] < 0) soz[z] = ns;
+      zos[ns++] = bad_row;
+    }
+    e->nslots = ns;
+    if ((rc = dev_upload(e, soz, (size_t)64, &e->slot_of_z))) goto fail;
+    if ((rc = dev_upload(e, zos, (size_t)ns, &e->z_of_slot))) goto fail;
+    const char* env = getenv("AIMNET_P0_MOMENTS");
+    if (env) e->p0_moments = atoi(env) != 0;
+  }
   if ((rc = dev_upload(e, w->agh_a, (size_t)16 * 16 * 12, &e->agh_a))) goto fail;
   if ((rc = dev_upload(e, w->agh_q, (size_t)16 * 12, &e->agh_q))) goto fail;
   if ((rc = dev_upload(e, w->sae, (size_t)64, &e->sae))) goto fail;
@@ -430,6 +460,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
 
   // ---- forward --------------------------------------------------------------------------------
   RC(launch_embed(s, e->afv, in->numbers, N, W.a[0]));
+  const bool p0m = e->p0_moments && e->nslots <= 64 && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
+  if (p0m) RC(launch_species(s, in->numbers, e->slot_of_z, N, W.aslot, W.present_part));
   for (int p = 0; p < np; ++p) {
     const std::vector<Layer>& Ls = e->mlp[p];
     const int nl = (int)Ls.size();
@@ -532,6 +564,12 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     }
     // zcur = xbar_p  (N x k_in of the first layer)
     RC(prof_mark(e, s, FAM_UNCONCAT));
+    if (p == 0 && p0m) {
+      RC(launch_unconcat_p0(s, zcur, ld, W.V[0], e->agh_a, e->afv, e->z_of_slot, e->nslots, W.present_part, W.n_part, W.Sbar, N));
+      RC(prof_mark(e, s, FAM_CONV_BWD));
+      RC(launch_conv_bwd_p0(s, want_s, W.Sbar, e->nslots, W.aslot, W.nb_idx, W.nb_cnt, W.pg, cap, e->bp, W.fgrad, W.virial_atom, N));
+      break;
+    }
     RC(launch_unconcat(s, p > 0, zcur, ld, W.V[p], W.Vq[p], e->agh_a, e->agh_q, W.Sbar, W.Sqbar, N));
     RC(prof_mark(e, s, FAM_CONV_BWD));
     RC(launch_conv_bwd(s, p > 0, p > 0, want_s, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr,

@@ -66,6 +66,15 @@ int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, cons
                     const float* q, const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
                     int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
                     const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms);
+// pass-0 backward through species moments (conv.hip)
+int launch_species(hipStream_t s, const int* numbers, const int* slot_of_z, int n_atoms, int* aslot,
+                   unsigned long long* present_part);
+int launch_unconcat_p0(hipStream_t s, const float* xbar, int ldx, const float* Vsave, const float* agh_a, const float* afv,
+                       const int* z_of_slot, int nslots, const unsigned long long* present_part, int n_part, float* T,
+                       int n_atoms);
+int launch_conv_bwd_p0(hipStream_t s, bool stress, const float* T, int nslots, const int* aslot, const int* nb_idx,
+                       const int* nb_cnt, const float4* pg, int cap, BasisParams bp, float* fgrad, float* virial_atom,
+                       int n_atoms);
 // stand-alone reference-op forms (conv_sv_2d_sp_wp.py:90-164)
 int launch_conv_sv_fwd(hipStream_t s, const float* a, const int* idx, const float* g, float* out, int B, int A, int G,
                        int M);

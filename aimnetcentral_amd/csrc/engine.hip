@@ -460,7 +460,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
 
   // ---- forward --------------------------------------------------------------------------------
   RC(launch_embed(s, e->afv, in->numbers, N, W.a[0]));
-  const bool p0m = e->p0_moments && e->nslots <= 64 && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
+  const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
   if (p0m) RC(launch_species(s, in->numbers, e->slot_of_z, N, W.aslot, W.present_part));
   for (int p = 0; p < np; ++p) {
     const std::vector<Layer>& Ls = e->mlp[p];
@@ -557,6 +557,9 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       const Layer& L = Ls[l];
       if (l > 0)
         RC(launch_gemm_nt(s, EPI_MUL, zcur, ld, L.wt, L.k_out, N, L.k_in, L.k_out, nullptr, znext, W.D[p][l - 1], L.k_in));
+      else if (p == 0 && p0m)  // only the conv columns 256.. of xbar_0 are consumed (the embedding is a constant)
+        RC(launch_gemm_nt(s, EPI_NONE, zcur, ld, L.wt + (size_t)256 * L.k_out, L.k_out, N, L.k_in - 256, L.k_out, nullptr,
+                          znext + 256, nullptr, L.k_in));
       else
         RC(launch_gemm_nt(s, EPI_NONE, zcur, ld, L.wt, L.k_out, N, L.k_in, L.k_out, nullptr, znext, nullptr, L.k_in));
       std::swap(zcur, znext);

@@ -220,7 +220,13 @@ class HipEngine:
             macs += sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
         hd = self.spec.head_dims
         macs += sum(hd[i] * hd[i + 1] for i in range(len(hd) - 2))
-        return 2.0 * macs * (2 if backward else 1)
+        total = 2.0 * macs * (2 if backward else 1)
+        if backward:
+            # the pass-0 input gradient with respect to the (constant) embedding block is never formed:
+            # the last backward GEMM of pass 0 has N = 448, not 704 (engine.hip, "only the conv columns")
+            d0 = self.spec.mlp_dims[0]
+            total -= 2.0 * 256 * d0[1]
+        return total
 
     def debug_view(self, name: str):
         """Intermediate of the last eval as a torch tensor view into the workspace (tests only)."""

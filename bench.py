@@ -118,6 +118,17 @@ def cpu_baseline(workload: str, budget_s: float = 12.0):
             "sample": sample + f"; {reps} evals in {dt:.1f} s on {best_nt} of {cores} host threads, torch {torch.__version__} CPU eager"}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC pass of this workload (profiles/r1c_pmc.json:
+    TCC_EA0_RDREQ x 128 B + TCC_EA0_WRREQ x 64 B, the gfx950 correction of MI355X_MICROARCH.md); PMC counters
+    cannot be read from inside the timed process, so this is the last measured value, None for other workloads."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1c_pmc.json")
+    if workload != "pbc10k" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["traffic_bytes_per_launch"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,7 +234,7 @@ def main():
             "config": {"workload": wl["label"], "atoms_per_gpu": n_atoms, "frames_per_gpu": frames,
                        "parallelism": f"batch-shard x{world} (independent frames, RCCL all-gather of energies)" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": pmc_traffic(args.workload),
                          "kernel": "gemm_nt_panel_kernel (fp32 MFMA MLP GEMMs, all launches of a step)",
                          "gemm_ms_per_step": gemm_ms, "other_ms_per_step": prof["other"] / args.steps,
                          "algorithmic_flop_per_step": flops_step},

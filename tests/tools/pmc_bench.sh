@@ -1,0 +1,28 @@
+#!/bin/bash
+# rocprofv3 passes over the default bench (run on the GPU box): kernel trace + two PMC passes, summaries into gpurun_out/$1
+out=$1
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/$out
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$out/trace -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/$out/bench_traced.log 2>&1
+for pass in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum"; do
+  tag=$(echo $pass | cut -d' ' -f1)
+  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/$out/$tag -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/$out/$tag.log 2>&1
+done
+cd $R
+python tests/prof_summary.py $(ls gpurun_out/$out/trace/*/*kernel_trace.csv | head -1) 12 > gpurun_out/$out/kernel_summary.txt
+cp $(ls gpurun_out/$out/trace/*/*kernel_stats.csv | head -1) gpurun_out/$out/kernel_stats.csv
+python - <<PY > gpurun_out/$out/pmc_summary.txt
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in sorted(glob.glob("gpurun_out/$out/*/*/*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].replace("aimnet::", "").replace("void ", "").split("(")[0][:48]
+        a = agg[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+names = sorted({c for k in agg for c in agg[k]})
+print("per-dispatch averages; kernel | " + " | ".join(names))
+for k in sorted(agg, key=lambda k: -agg[k].get("GRBM_GUI_ACTIVE", [0, 1])[0]):
+    print(f"{k:48s} | " + " | ".join(f"{agg[k][c][0] / max(1, agg[k][c][1]):.4g}" if c in agg[k] else "-" for c in names))
+PY
+rm -rf gpurun_out/$out/SQ_VALU_MFMA_BUSY_CYCLES gpurun_out/$out/TCC_EA0_RDREQ_sum gpurun_out/$out/trace
+head -30 gpurun_out/$out/kernel_summary.txt; head -24 gpurun_out/$out/pmc_summary.txt

@@ -662,7 +662,6 @@ int aimnet_debug_gemm(int cfg, int epi, const float* A, int lda, const float* Bt
     if (rc) return rc;
     attr = true;
   }
-  if (cfg >= 1000) return launch_gemm_ablation((hipStream_t)hip_stream, cfg / 1000, A, lda, Bt, ldb, M, N, K, C, ldc);
   return launch_gemm_nt_cfg((hipStream_t)hip_stream, cfg, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
 }
 

@@ -7,16 +7,19 @@
 //
 // Why fp32 MFMA: the reference's parity gate is |dE| < 1e-5 eV, |dF| < 1e-5 + 1e-4|F|
 // (tests/test_calculator_gpu.py:445,464); bf16 inputs cannot hold it, and gfx950 has no
-// xf32/TF32.  v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf chain at the fp32 vector peak
-// (157 TFLOP/s, MI355X_MICROARCH.md) and leaves the VALU free for the GELU epilogue.
+// xf32/TF32.  v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32 multiply and accumulate in fp32 at the
+// fp32 matrix peak (157 TFLOP/s, MI355X_MICROARCH.md) and leave the VALU free for the GELU epilogue.
 //
-// Tiling: BM x BN x 32 block tile (64x64 or 128x128, see the kernel), 256 threads = 2x2 waves of
-// 32x32 MFMA tiles.  Both tiles are staged global -> VGPR -> LDS (padded rows, 36
-// floats, so the ds_read_b128 fragment reads are conflict free) with a 2-deep LDS ring: the
-// global loads of tile k+1 are in flight under the 64 MFMAs of tile k, one barrier per K tile.
-// K mapping inside an 8-wide k block: lane half h = lane>>5 owns k = 4h..4h+3, so one b128 read
-// feeds four consecutive MFMAs for A and for B alike (the MFMA only needs A and B to agree on
-// which k a lane half carries).
+// Two kernels, one data path (profiles/r1c_summary.md has the measurements behind every choice):
+//   * operands are DMA'd global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write) into a ring of
+//     K = 16 stages; rows are unpadded and the 16-byte k-chunk index is XOR-swizzled on the SOURCE address (the DMA
+//     writes lane-linear) so that the ds_read_b128 fragment reads are bank-conflict free;
+//   * the fragment reads are inline asm: hipcc puts a conservative `s_waitcnt vmcnt(0)` in front of every C++ LDS
+//     read that follows a global_load_lds, which would drain the ring on every K tile; with asm reads the only
+//     vmcnt wait is ours ("tile kt has landed, the younger tiles may still be in flight");
+//   * gemm_nt_panel_kernel (512 threads, 16x16x4 MFMA, block tiles from 48x128 to 160x192) carries the MLP layers of
+//     large batches; gemm_nt_ring_kernel (256 threads, 32x32x2 MFMA, 64x64 tiles, scalar epilogue without alignment
+//     requirements) serves small M and unaligned outputs.  choose_tile() picks per launch.
 #include <stdlib.h>
 
 #include "common.h"
@@ -27,295 +30,19 @@ namespace aimnet {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK_DEFAULT = 32;
+constexpr int BK_DEFAULT = 32;  // every K handed to the GEMM is a multiple of 32 (weights are padded at upload)
 
-// BM x BN block tile, 256 threads = 2x2 waves, each wave (BM/2) x (BN/2) = MI x NI MFMA tiles of 32x32.
-//   64 x 64  : 1 MFMA tile per wave, 36 KiB LDS -> 4 blocks/CU.  Fine-grained: with M ~ 10^4 rows a layer
-//              has ~10^3 tiles, so the 256 CUs stay evenly loaded (a 128x128 grid of 316 tiles ran as
-//              "2 rounds" at 62 % utilisation, profiles/r1a).
-//   128 x 128: 2x2 MFMA tiles per wave, 72 KiB LDS -> 2 blocks/CU.  Half the L2->LDS traffic per FLOP;
-//              chosen when there are enough tiles to fill the chip many times over.
-template <int EPI, int BM, int BN, int ABL = 0, int BK = BK_DEFAULT>
-__global__ __launch_bounds__(256, (BM * BN * BK >= 128 * 128 * 32) ? 2 : (BK <= 16 ? 6 : 4)) void gemm_nt_kernel(
-    const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb, int M, int N, int K,
-    const float* __restrict__ bias, float* __restrict__ C, float* __restrict__ D, int ldc) {
-  constexpr int LDS_LD = BK + 4;
-  constexpr int MI = BM / 64, NI = BN / 64;   // MFMA tiles per wave along M / N
-  constexpr int RPT = 256 / (BK / 4);         // rows staged per pass of the 256 threads
-  constexpr int LA = BM / RPT, LB = BN / RPT; // float4 staging loads per thread per K tile
-  constexpr int KB = BK / 8;                  // 8-wide k blocks per K tile
-  static_assert(LA >= 1 && LA <= 4 && LB >= 1 && LB <= 4, "staging uses up to 4 named registers per operand");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                         // [2][BM][LDS_LD]
-  float* Bs = smem + 2 * BM * LDS_LD;       // [2][BN][LDS_LD]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = tid >> 6;
-  const int wr = wid >> 1, wc = wid & 1;
-  const int li = lane & 31, lh = lane >> 5;
-
-  // XCD-aware tile order.  Hardware places block b on XCD b % 8 (observed, speed only); remap so
-  // each XCD owns a contiguous run of logical tiles, and order tiles column-fastest: the tiles
-  // that share one A row panel then run on one XCD and hit its private L2 (bijective remap,
-  // cdna_hip_programming.md T1).
-  const int tiles_n = (N + BN - 1) / BN;
-  const int nwg = gridDim.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
-  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
-  const int tile_m = wg / tiles_n;
-  const int tile_n = wg % tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  f32x16 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  // staging: thread t moves float4 #t, #t+256, ... of each [rows][32] tile; rows past M / N are clamped
-  // (loaded, never stored) so the loads issue branch-free.  The staging registers are NAMED scalars
-  // (ra0..ra3 / rb0..rb3, guarded by if constexpr): as arrays hipcc kept them in scratch memory
-  // (scratch_store right behind every global_load, -45 % throughput).
-  const int srow = tid / (BK / 4), sc4 = (tid % (BK / 4)) << 2;
-  const float* const ga0 = A + (size_t)min(m0 + srow, M - 1) * lda + sc4;
-  const float* const ga1 = A + (size_t)min(m0 + srow + 1 * RPT, M - 1) * lda + sc4;
-  const float* const ga2 = A + (size_t)min(m0 + srow + 2 * RPT, M - 1) * lda + sc4;
-  const float* const ga3 = A + (size_t)min(m0 + srow + 3 * RPT, M - 1) * lda + sc4;
-  const float* const gb0 = Bt + (size_t)min(n0 + srow, N - 1) * ldb + sc4;
-  const float* const gb1 = Bt + (size_t)min(n0 + srow + 1 * RPT, N - 1) * ldb + sc4;
-  const float* const gb2 = Bt + (size_t)min(n0 + srow + 2 * RPT, N - 1) * ldb + sc4;
-  const float* const gb3 = Bt + (size_t)min(n0 + srow + 3 * RPT, N - 1) * ldb + sc4;
-  float* const sa = As + srow * LDS_LD + sc4;
-  float* const sb = Bs + srow * LDS_LD + sc4;
-  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-  ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-#define AIMNET_GLOAD(k0)                                                   \
-  do {                                                                     \
-    ra0 = *reinterpret_cast<const float4*>(ga0 + (k0));                    \
-    if constexpr (LA > 1) ra1 = *reinterpret_cast<const float4*>(ga1 + (k0)); \
-    if constexpr (LA > 2) {                                                \
-      ra2 = *reinterpret_cast<const float4*>(ga2 + (k0));                  \
-      ra3 = *reinterpret_cast<const float4*>(ga3 + (k0));                  \
-    }                                                                      \
-    rb0 = *reinterpret_cast<const float4*>(gb0 + (k0));                    \
-    if constexpr (LB > 1) rb1 = *reinterpret_cast<const float4*>(gb1 + (k0)); \
-    if constexpr (LB > 2) {                                                \
-      rb2 = *reinterpret_cast<const float4*>(gb2 + (k0));                  \
-      rb3 = *reinterpret_cast<const float4*>(gb3 + (k0));                  \
-    }                                                                      \
-  } while (0)
-#define AIMNET_LSTORE(buf)                                                                  \
-  do {                                                                                      \
-    *reinterpret_cast<float4*>(sa + ((buf)*BM) * LDS_LD) = ra0;                             \
-    if constexpr (LA > 1) *reinterpret_cast<float4*>(sa + ((buf)*BM + RPT) * LDS_LD) = ra1; \
-    if constexpr (LA > 2) {                                                                 \
-      *reinterpret_cast<float4*>(sa + ((buf)*BM + 2 * RPT) * LDS_LD) = ra2;                 \
-      *reinterpret_cast<float4*>(sa + ((buf)*BM + 3 * RPT) * LDS_LD) = ra3;                 \
-    }                                                                                       \
-    *reinterpret_cast<float4*>(sb + ((buf)*BN) * LDS_LD) = rb0;                             \
-    if constexpr (LB > 1) *reinterpret_cast<float4*>(sb + ((buf)*BN + RPT) * LDS_LD) = rb1; \
-    if constexpr (LB > 2) {                                                                 \
-      *reinterpret_cast<float4*>(sb + ((buf)*BN + 2 * RPT) * LDS_LD) = rb2;                 \
-      *reinterpret_cast<float4*>(sb + ((buf)*BN + 3 * RPT) * LDS_LD) = rb3;                 \
-    }                                                                                       \
-  } while (0)
-
-  AIMNET_GLOAD(0);
-  AIMNET_LSTORE(0);
-  __syncthreads();
-
-  const int nk = K / BK;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more && ABL < 1) AIMNET_GLOAD((kt + 1) * BK);
-    const float* a_base = As + (buf * BM + wr * (BM / 2) + li) * LDS_LD + 4 * lh;
-    const float* b_base = Bs + (buf * BN + wc * (BN / 2) + li) * LDS_LD + 4 * lh;
-#pragma unroll
-    for (int kk = 0; kk < KB; ++kk) {
-      float4 af[MI], bf[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDS_LD + kk * 8);
-#pragma unroll
-      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * LDS_LD + kk * 8);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
-    if (more && ABL < 1) AIMNET_LSTORE(buf ^ 1);
-    if (ABL < 2) __syncthreads();
-  }
-#undef AIMNET_GLOAD
-#undef AIMNET_LSTORE
-
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int col = n0 + wc * (BN / 2) + ni * 32 + li;
-      if (col >= N) continue;
-      float bvv = 0.0f;
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bvv = bias[col];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= M) continue;
-        const size_t o = (size_t)row * ldc + col;
-        float v = acc[mi][ni][r];
-        if (EPI == EPI_NONE) {
-          C[o] = v;
-        } else if (EPI == EPI_BIAS) {
-          C[o] = v + bvv;
-        } else if (EPI == EPI_BIAS_GELU) {
-          float h, d;
-          gelu_and_grad(v + bvv, h, d);
-          C[o] = h;
-          if (D) D[o] = d;
-        } else {  // EPI_MUL: chain rule through the previous layer's GELU, D holds GELU'(z)
-          C[o] = v * D[o];
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// v2: 64x64x32 tile, operands DMA'd straight into LDS (global_load_lds_dwordx4: no VGPR staging, no
-// ds_write), un-padded rows with the k-chunk XOR-swizzled by (row>>1)&7 on the SOURCE address (the DMA
-// writes lane-linear; cdna_hip_programming.md rule 21) so the b128 fragment reads stay conflict free,
-// 2 stages x 16 KiB = exactly 32 KiB per block -> 5 blocks per CU (160 KiB): the 1264 tiles of a
-// 10 080 x 512 layer are ALL resident at once, every CU carrying 4.94 of them (no partial last wave).
-// Loop: [__syncthreads = vmcnt(0) + barrier] -> DMA tile k+1 into the other stage -> 8 b128 reads +
-// 16 MFMAs on tile k.  One barrier per K tile, loads in flight for a whole iteration.
 __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI, int ABL = 0, int BK = 32>
-__global__ __launch_bounds__(256, (BK == 16 ? 8 : 5)) void gemm_nt_glds_kernel(const float* __restrict__ A, int lda,
-                                                                             const float* __restrict__ Bt, int ldb, int M,
-                                                                             int N, int K, const float* __restrict__ bias,
-                                                                             float* __restrict__ C, float* __restrict__ D,
-                                                                             int ldc) {
-  constexpr int BM = 64, BN = 64;
-  constexpr int GR = BK / 4;             // 16-byte granules per tile row (8 or 4)
-  constexpr int SH = (BK == 32) ? 1 : 2;  // rows per 64-bank line = 2^SH ; swizzle = (row >> SH) & (GR-1)
-  constexpr int NP = BM * GR / 256;      // DMA passes per operand tile (2 or 1)
-  constexpr int STAGE = (BM + BN) * BK;  // floats per stage: A tile then B tile, each [64 rows][GR granules of 16 B]
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid >> 1, wc = wid & 1;
-  const int li = lane & 31, lh = lane >> 5;
-
-  const int tiles_n = (N + BN - 1) / BN;
-  const int nwg = gridDim.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
-  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
-  const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
-
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-
-  // DMA mapping: wave w, pass t moves LDS granules G = t*256 + w*64 + lane of a tile;
-  // granule G holds row G/GR, k-chunk (G % GR) ^ swz(row)
-  const float* srcA[NP];
-  const float* srcB[NP];
-#pragma unroll
-  for (int t = 0; t < NP; ++t) {
-    const int G = t * 256 + wid * 64 + lane;
-    const int row = G / GR, kc = (G % GR) ^ ((row >> SH) & (GR - 1));
-    srcA[t] = A + (size_t)min(m0 + row, M - 1) * lda + kc * 4;
-    srcB[t] = Bt + (size_t)min(n0 + row, N - 1) * ldb + kc * 4;
-  }
-  auto dma = [&](int stage, int k0) {
-    float* base = smem + stage * STAGE + wid * 64 * 4;
-#pragma unroll
-    for (int t = 0; t < NP; ++t) glds16(srcA[t] + k0, base + t * 256 * 4);
-#pragma unroll
-    for (int t = 0; t < NP; ++t) glds16(srcB[t] + k0, base + BM * BK + t * 256 * 4);
-  };
-  // fragment addressing: row r, k-chunk kc = 2*kk + lh  ->  float offset (r*GR + (kc ^ swz(r))) * 4
-  const int ra = wr * 32 + li, rb = wc * 32 + li;
-  const int sa = (ra >> SH) & (GR - 1), sb = (rb >> SH) & (GR - 1);
-
-  const int nk = K / BK;
-  dma(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    if (ABL < 2) __syncthreads();  // = s_waitcnt vmcnt(0) (tile kt landed) + barrier (everybody done with the other stage)
-    const float* As = smem + (kt & 1) * STAGE;
-    const float* Bs = As + BM * BK;
-    float4 af[GR / 2], bf[GR / 2];
-#pragma unroll
-    for (int kk = 0; kk < GR / 2; ++kk) {
-      if (ABL < 3) {
-        af[kk] = *reinterpret_cast<const float4*>(As + (ra * GR + ((2 * kk + lh) ^ sa)) * 4);
-        bf[kk] = *reinterpret_cast<const float4*>(Bs + (rb * GR + ((2 * kk + lh) ^ sb)) * 4);
-      } else {
-        af[kk] = make_float4(1.f + kt, 2.f, 3.f, (float)lane);
-        bf[kk] = make_float4(0.5f, (float)kt, 1.5f, 2.5f);
-      }
-    }
-    // the DMA of the NEXT tile is issued after this tile's fragment reads: the compiler conservatively
-    // puts s_waitcnt vmcnt(0) in front of any ds_read that follows a global_load_lds, which in the other
-    // order serialises the load with the reads; here the load flies during the 4*GR MFMAs below.
-    if (kt + 1 < nk && ABL < 1) dma((kt + 1) & 1, (kt + 1) * BK);
-#pragma unroll
-    for (int kk = 0; kk < GR / 2; ++kk) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].x, bf[kk].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].y, bf[kk].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].z, bf[kk].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].w, bf[kk].w, acc, 0, 0, 0);
-    }
-  }
-
-  const int col = n0 + wc * 32 + li;
-  if (col >= N) return;
-  float bvv = 0.0f;
-  if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bvv = bias[col];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (row >= M) continue;
-    const size_t o = (size_t)row * ldc + col;
-    const float v = acc[r];
-    if (EPI == EPI_NONE) {
-      C[o] = v;
-    } else if (EPI == EPI_BIAS) {
-      C[o] = v + bvv;
-    } else if (EPI == EPI_BIAS_GELU) {
-      float h, d;
-      gelu_and_grad(v + bvv, h, d);
-      C[o] = h;
-      if (D) D[o] = d;
-    } else {
-      C[o] = v * D[o];
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
-// v3: 64x64x16 tiles in an NST-deep LDS ring (8 KiB per stage).  Same DMA + swizzle as v2, but the fragment
-// reads are inline asm: hipcc puts a conservative `s_waitcnt vmcnt(0)` in front of every C++ LDS read that
-// follows a global_load_lds (it cannot prove the DMA target does not alias), which would drain the ring on
-// every K tile.  With asm reads the only vmcnt wait is ours: vmcnt(2*(NST-2)) = "tile kt has landed, the
-// younger tiles may still be in flight".  NST = 3 -> 24 KiB -> 6 blocks/CU; NST = 2 -> 16 KiB -> 8 blocks/CU.
-template <int EPI, int NST, int ABL = 0>
+// Ring kernel: 64x64x16 tiles, 2x2 waves of one 32x32 MFMA tile each, NST-deep LDS ring of 8 KiB stages
+// (NST = 3 -> 24 KiB -> 6 blocks/CU, so the 1264 tiles of a 10 080 x 512 layer are all resident at once).
+// LDS rows are 16 floats = 4 granules of 16 B; granule slot = k-chunk ^ ((row >> 2) & 3).
+// The only vmcnt wait is vmcnt(2*(NST-2)): "tile kt has landed, the younger tiles may still be in flight".
+template <int EPI, int NST>
 __global__ __launch_bounds__(256, (NST == 2 ? 8 : 6)) void gemm_nt_ring_kernel(const float* __restrict__ A, int lda,
                                                                              const float* __restrict__ Bt, int ldb, int M,
                                                                              int N, int K, const float* __restrict__ bias,
@@ -345,9 +72,8 @@ __global__ __launch_bounds__(256, (NST == 2 ? 8 : 6)) void gemm_nt_ring_kernel(c
   // DMA: wave w moves LDS granules G = w*64 + lane of each operand tile; granule G = row G>>2, k-chunk (G&3) ^ ((row>>2)&3)
   const int G = wid * 64 + lane;
   const int grow = G >> 2, gkc = (G & 3) ^ ((grow >> 2) & 3);
-  // ABL 4 (timing only): every block streams the SAME rows -> all DMA traffic is served by the per-CU L1
-  const float* srcA = A + (size_t)min((ABL == 4 ? 0 : m0) + grow, M - 1) * lda + gkc * 4;
-  const float* srcB = Bt + (size_t)min((ABL == 4 ? 0 : n0) + grow, N - 1) * ldb + gkc * 4;
+  const float* srcA = A + (size_t)min(m0 + grow, M - 1) * lda + gkc * 4;
+  const float* srcB = Bt + (size_t)min(n0 + grow, N - 1) * ldb + gkc * 4;
   auto dma = [&](int stage, int k0) {
     float* base = smem + stage * STAGE + wid * 64 * 4;
     glds16(srcA + k0, base);
@@ -368,22 +94,18 @@ __global__ __launch_bounds__(256, (NST == 2 ? 8 : 6)) void gemm_nt_ring_kernel(c
   int st = 0;          // stage of tile kt
   int sn = NST - 1;    // stage the next DMA goes to
   for (int kt = 0; kt < nk; ++kt) {
-    if (ABL < 2 || ABL == 4) {
-      if (NST > 2 && kt + NST - 2 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * (NST - 2)));  // vmcnt(2*(NST-2))
-      else __builtin_amdgcn_s_waitcnt(0x0F70);                                              // vmcnt(0)
-      __builtin_amdgcn_s_barrier();  // tile kt visible to all waves; everybody is done reading tile kt-1 (stage sn)
-    }
-    if (kt + NST - 1 < nk && (ABL < 1 || ABL == 4)) dma(sn, (kt + NST - 1) * BK);
+    if (NST > 2 && kt + NST - 2 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * (NST - 2)));  // vmcnt(2*(NST-2))
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                                              // vmcnt(0)
+    __builtin_amdgcn_s_barrier();  // tile kt visible to all waves; everybody is done reading tile kt-1 (stage sn)
+    if (kt + NST - 1 < nk) dma(sn, (kt + NST - 1) * BK);
     f32x4 a0, a1, b0, b1;
-    if (ABL < 3 || ABL == 4) {
+    {
       const unsigned so = st * STAGE_BYTES;
       asm volatile(
           "ds_read_b128 %0, %4\n\tds_read_b128 %2, %6\n\tds_read_b128 %1, %5\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
           : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
           : "v"(aA0 + so), "v"(aA1 + so), "v"(aB0 + so), "v"(aB1 + so)
           : "memory");
-    } else {
-      a0 = f32x4{1.f + kt, 2.f, 3.f, (float)lane}; a1 = a0; b0 = f32x4{0.5f, (float)kt, 1.5f, 2.5f}; b1 = b0;
     }
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0[1], acc, 0, 0, 0);
@@ -422,7 +144,7 @@ __global__ __launch_bounds__(256, (NST == 2 ? 8 : 6)) void gemm_nt_ring_kernel(c
   }
 }
 
-template <int NST, int ABL = 0>
+template <int NST>
 static int launch_ring(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
                        const float* bias, float* C, float* D, int ldc) {
   const int tiles = ceil_div(M, 64) * ceil_div(N, 64);
@@ -430,71 +152,16 @@ static int launch_ring(hipStream_t stream, int epi, const float* A, int lda, con
   dim3 grid(tiles), block(256);
   switch (epi) {
     case EPI_NONE:
-      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_NONE, NST, ABL>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_NONE, NST>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
       break;
     case EPI_BIAS:
-      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_BIAS, NST, ABL>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_BIAS, NST>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
       break;
     case EPI_BIAS_GELU:
-      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_BIAS_GELU, NST, ABL>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_BIAS_GELU, NST>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
       break;
     case EPI_MUL:
-      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_MUL, NST, ABL>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-      break;
-    default:
-      set_last_error("gemm: bad epilogue %d", epi);
-      return -1;
-  }
-  AIMNET_LAUNCH_CHECK();
-  return 0;
-}
-
-template <int BK>
-static int launch_glds(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
-                       const float* bias, float* C, float* D, int ldc) {
-  const int tiles = ceil_div(M, 64) * ceil_div(N, 64);
-  const size_t lds = (size_t)2 * 128 * BK * sizeof(float);  // 32 KiB (BK 32: 4 blocks/CU) or 16 KiB (BK 16: 8 blocks/CU)
-  dim3 grid(tiles), block(256);
-  switch (epi) {
-    case EPI_NONE:
-      hipLaunchKernelGGL((gemm_nt_glds_kernel<EPI_NONE, 0, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-      break;
-    case EPI_BIAS:
-      hipLaunchKernelGGL((gemm_nt_glds_kernel<EPI_BIAS, 0, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-      break;
-    case EPI_BIAS_GELU:
-      hipLaunchKernelGGL((gemm_nt_glds_kernel<EPI_BIAS_GELU, 0, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-      break;
-    case EPI_MUL:
-      hipLaunchKernelGGL((gemm_nt_glds_kernel<EPI_MUL, 0, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-      break;
-    default:
-      set_last_error("gemm: bad epilogue %d", epi);
-      return -1;
-  }
-  AIMNET_LAUNCH_CHECK();
-  return 0;
-}
-
-template <int BM, int BN>
-static int launch_cfg(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
-                      const float* bias, float* C, float* D, int ldc) {
-  const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
-  static const size_t pad = getenv("AIMNET_GEMM_LDS_PAD") ? (size_t)atoi(getenv("AIMNET_GEMM_LDS_PAD")) : 0;  // occupancy probe
-  const size_t lds = (size_t)2 * (BM + BN) * (BK_DEFAULT + 4) * sizeof(float) + pad;
-  dim3 grid(tiles), block(256);
-  switch (epi) {
-    case EPI_NONE:
-      hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, BM, BN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-      break;
-    case EPI_BIAS:
-      hipLaunchKernelGGL((gemm_nt_kernel<EPI_BIAS, BM, BN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-      break;
-    case EPI_BIAS_GELU:
-      hipLaunchKernelGGL((gemm_nt_kernel<EPI_BIAS_GELU, BM, BN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-      break;
-    case EPI_MUL:
-      hipLaunchKernelGGL((gemm_nt_kernel<EPI_MUL, BM, BN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_MUL, NST>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
       break;
     default:
       set_last_error("gemm: bad epilogue %d", epi);
@@ -505,16 +172,16 @@ static int launch_cfg(hipStream_t stream, int epi, const float* A, int lda, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// v4 "panel" kernel: 512 threads = WM x WN waves, v_mfma_f32_16x16x4_f32, block tile
+// Panel kernel: 512 threads = WM x WN waves, v_mfma_f32_16x16x4_f32, block tile
 // TM x TN = (16*SM*WM) x (16*SN*WN) with SM*SN accumulator tiles per wave (160x128, 160x192, 128x96 ...).
 // Why: a 64x64 tile streams (64+64)/(64*64) operand floats per MAC through the DMA and the LDS; measured
-// (tests/tune_gemm.py, ABL runs) that traffic - not L2 bandwidth, not the barrier - costs 30 % of the MFMA
+// (ablation runs, profiles/r1c_summary.md) that traffic - not L2 bandwidth, not the barrier - costs 30 % of the MFMA
 // time.  A 160x128 tile moves 2.2x fewer bytes per MAC, and the strip counts are template parameters so the
 // host can pick the shape whose tile count just fits a whole number of "rounds" of the 256 CUs
 // (10 080 x 512 -> 63 x 4 = 252 tiles of 160x128: one tile per CU, 98 % balanced).
 // Operands are swapped into the MFMA (weights = "A" operand, activations = "B"), which leaves each lane with
 // 4 consecutive output COLUMNS of one row -> dwordx4 epilogue stores / bias / D loads.
-// LDS: NST-deep ring of [TM rows | TN rows] x 16 floats, DMA'd and swizzled like v3 (slot = chunk ^ 3*((row>>3)&1),
+// LDS: NST-deep ring of [TM rows | TN rows] x 16 floats, DMA'd like the ring kernel, slot = chunk ^ 3*((row>>3)&1):
 // conflict-free for the 16x16x4 fragment reads, whose b128 lane groups are not contiguous - MI355X_MICROARCH.md LDS).
 template <int OFF>
 __device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
@@ -718,50 +385,12 @@ static int launch_panel(hipStream_t stream, int epi, const float* A, int lda, co
   return 0;
 }
 
-// timing-only ablations of the 64x64 kernel (wrong results): 1 = no global->LDS restaging, 2 = also no barrier
-int launch_gemm_ablation(hipStream_t stream, int abl, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
-                         float* C, int ldc) {
-  const int tiles = ceil_div(M, 64) * ceil_div(N, 64);
-  const size_t lds = (size_t)2 * 128 * (BK_DEFAULT + 4) * sizeof(float);
-  if (abl == 3) {  // 64x64 tile with BK = 64 (half the barriers, 2 blocks/CU)
-    const size_t l64 = (size_t)2 * 128 * (64 + 4) * sizeof(float);
-    static bool once = false;
-    if (!once) {
-      AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_NONE, 64, 64, 0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      once = true;
-    }
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, 64, 64, 0, 64>), dim3(tiles), dim3(256), l64, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
-    AIMNET_LAUNCH_CHECK();
-    return 0;
-  }
-  if (abl >= 5) {  // ablations of the DMA kernel: 5 = no DMA in the loop, 6 = also no barrier, 7 = also no LDS reads (pure MFMA)
-    const size_t l2 = (size_t)2 * 128 * 32 * sizeof(float);
-    if (abl == 5) hipLaunchKernelGGL((gemm_nt_glds_kernel<EPI_NONE, 1>), dim3(tiles), dim3(256), l2, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
-    else if (abl == 6) hipLaunchKernelGGL((gemm_nt_glds_kernel<EPI_NONE, 2>), dim3(tiles), dim3(256), l2, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
-    else hipLaunchKernelGGL((gemm_nt_glds_kernel<EPI_NONE, 3>), dim3(tiles), dim3(256), l2, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
-    AIMNET_LAUNCH_CHECK();
-    return 0;
-  }
-  if (abl == 4) {  // 64x64 tile with BK = 16: 20 KiB LDS -> up to 8 blocks/CU, every tile resident at once
-    const size_t l16 = (size_t)2 * 128 * (16 + 4) * sizeof(float);
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, 64, 64, 0, 16>), dim3(tiles), dim3(256), l16, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
-    AIMNET_LAUNCH_CHECK();
-    return 0;
-  }
-  if (abl == 1)
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, 64, 64, 1>), dim3(tiles), dim3(256), lds, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
-  else
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, 64, 64, 2>), dim3(tiles), dim3(256), lds, stream, A, lda, Bt, ldb, M, N, K, nullptr, C, nullptr, ldc);
-  AIMNET_LAUNCH_CHECK();
-  return 0;
-}
-
-static int g_force_tile = 0;  // 0 auto; 64, 128, 12864 (128x64), 64128 (64x128) from AIMNET_GEMM_TILE for A/B runs
+static int g_force_tile = 0;  // 0 = choose_tile(); a tile id from AIMNET_GEMM_TILE forces one configuration (A/B runs)
 
 // Tile choice.  Every candidate runs the same MFMA rate; what differs is (a) how evenly ceil(M/TM)*ceil(N/TN)
 // tiles load the 256 CUs - the busiest CU carries ceil(tiles/256) tiles of TM*TN MACs per k, padding of M and N
 // included - and (b) the operand bytes streamed per MAC, x = (TM+TN)/(TM*TN), which costs MFMA issue slots
-// through the DMA + LDS-read path.  Fitted to tests/tune_gemm.py on 10 080-row layers (profiles/r1c_gemm_tiles.md):
+// through the DMA + LDS-read path.  Fitted to tests/tune_gemm.py on 10 080-row layers (profiles/r1c_summary.md):
 // efficiency = 0.9 / (1 + 5x), times 0.88 when a CU holds a single block of <= 10 accumulator tiles per wave
 // (nothing to overlap its barrier with).  The model reproduces the measured ranking on all six MLP shapes.
 struct TileCand { int id, tm, tn, acc_tiles; };
@@ -778,7 +407,7 @@ static int choose_tile(int M, int N, bool vec_ok) {
     const double x = (double)(c.tm + c.tn) / ((double)c.tm * c.tn);
     double eff = 0.9 / (1.0 + 5.0 * x);
     if (per_cu == 1 && c.acc_tiles <= 10) eff *= 0.88;
-    if (c.id == 5) eff *= 0.9;  // 4-wave ring kernel: larger fixed cost per tile (profiles/r1c_gemm_tiles.md)
+    if (c.id == 5) eff *= 0.9;  // 4-wave ring kernel: larger fixed cost per tile (profiles/r1c_summary.md)
     const double cost = (double)per_cu * c.tm * c.tn / eff;
     if (cost < best_cost) { best_cost = cost; best = c.id; }
   }
@@ -795,8 +424,6 @@ int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int
   if (cfg == 0) cfg = g_force_tile;
   if (cfg == 0) cfg = choose_tile(M, N, ((N | ldc) & 3) == 0 && (((size_t)bias | (size_t)C | (size_t)D) & 15) == 0);
   switch (cfg) {
-    case 2: return launch_glds<32>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-    case 3: return launch_glds<16>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
 #define AIMNET_PANEL_CASE(ID, SM_, SN_, WM_, WN_) \
     case ID: return launch_panel<SM_, SN_, WM_, WN_>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
     // panel kernels: id = 100*arrangement + 10*SM + SN; arrangement 1 = 2x4 waves, 2 = 4x2, 3 = 1x8
@@ -812,16 +439,10 @@ int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int
     AIMNET_PANEL_CASE(351, 5, 1, 1, 8)  //  80 x 128
     AIMNET_PANEL_CASE(331, 3, 1, 1, 8)  //  48 x 128
 #undef AIMNET_PANEL_CASE
-    case 4: return launch_ring<2>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
     case 5: return launch_ring<3>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-    case 51: return launch_ring<3, 1>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-    case 52: return launch_ring<3, 2>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-    case 53: return launch_ring<3, 3>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-    case 54: return launch_ring<3, 4>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-    case 128: return launch_cfg<128, 128>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-    case 12864: return launch_cfg<128, 64>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-    case 64128: return launch_cfg<64, 128>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-    default: return launch_cfg<64, 64>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    default:
+      set_last_error("gemm: unknown tile id %d", cfg);
+      return -1;
   }
 }
 
@@ -830,25 +451,10 @@ int launch_gemm_nt(hipStream_t stream, int epi, const float* A, int lda, const f
   return launch_gemm_nt_cfg(stream, 0, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
 }
 
-template <int BM, int BN>
-static int set_attr() {
-  const int lds = 160 * 1024;
-  AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_NONE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_BIAS, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_BIAS_GELU, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_MUL, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  return 0;
-}
-
 int gemm_set_attributes() {
   const char* env = getenv("AIMNET_GEMM_TILE");
   g_force_tile = env ? atoi(env) : 0;
-  int rc;
-  if ((rc = set_attr<64, 64>())) return rc;
-  if ((rc = set_attr<128, 64>())) return rc;
-  if ((rc = set_attr<64, 128>())) return rc;
-  if ((rc = set_attr<128, 128>())) return rc;  // 72 KiB of dynamic LDS exceeds the 64 KiB default cap
-  return 0;
+  return 0;  // the panel kernels opt in to > 64 KiB of dynamic LDS at their first launch (launch_panel)
 }
 
 }  // namespace aimnet

@@ -16,8 +16,6 @@ int launch_gemm_nt(hipStream_t stream, int epi, const float* A, int lda, const f
                    int K, const float* bias, float* C, float* D, int ldc);
 int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N,
                        int K, const float* bias, float* C, float* D, int ldc);
-int launch_gemm_ablation(hipStream_t stream, int abl, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
-                         float* C, int ldc);
 int gemm_set_attributes();
 
 // ---- nlist.hip --------------------------------------------------------------------------------

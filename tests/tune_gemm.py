@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 M = int(os.environ.get("M", 10080))
 shapes = [(512, 736), (384, 512), (256, 384), (736, 512), (512, 384), (128, 256)]
 if os.environ.get("ONESHAPE"): shapes = shapes[:1]
-cfgs = [int(c) for c in os.environ.get("CFGS", "64,2,3").split(",")]
+cfgs = [int(c) for c in os.environ.get("CFGS", "5,152,153,122,351,331").split(",")]
 EPI = int(os.environ.get("EPI", 2))
 stream = torch.cuda.current_stream(dev).cuda_stream
 for (N, K) in shapes:

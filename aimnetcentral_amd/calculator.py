@@ -9,8 +9,11 @@ outputs.  Torch tensors are device buffers, nothing here is differentiated by au
 Deliberate deviations, all loud:
   * no CPU device and no torch fallback - constructing without a ROCm GPU raises HipLibraryError;
   * inputs carrying requires_grad raise (the reference keeps the autograd graph, :1458-1461);
-  * hessian / hessian_vector_product, Ewald / PME, external DFT-D3, NSE (2-channel) models,
-    torch.compile and training mode raise NotImplementedError (SURVEY.md 8f "next" rows).
+  * Ewald / PME, external DFT-D3, NSE (2-channel) models, torch.compile and training mode raise
+    NotImplementedError (SURVEY.md 8f "next" rows);
+  * hessian=True and hessian_vector_product are FINITE-DIFFERENCE operators over the analytic HIP forces
+    (4th-order central stencil, all displaced copies evaluated as one batch), not double backward: accurate
+    to ~1e-3 eV/A^2 in fp32, see `_fd_hvp`.  The analytic double-backward kernels are SURVEY 8f next-4.
 """
 from __future__ import annotations
 
@@ -283,7 +286,7 @@ class AIMNet2Calculator:
             self._validate_species_and_charge(data)
         self._maybe_warn_mult_ignored(data)
         if hessian:
-            raise NotImplementedError("hessian=True is not implemented by the native engine yet (SURVEY.md 8f next-4)")
+            return self._eval_hessian(data, forces=forces, stress=stress, validate_species=validate_species)
         d = self.to_input_tensors(data)
         for k in ("nbmat", "nbmat_lr", "shifts", "shifts_lr"):
             if k in d:
@@ -359,8 +362,152 @@ class AIMNet2Calculator:
         assert n_mol == out["energy"].shape[0]
         return out
 
-    def hessian_vector_product(self, data, vectors, **kw):
-        raise NotImplementedError("hessian_vector_product is not implemented by the native engine yet (SURVEY.md 8f next-4)")
+    # ---- second derivatives (calculator.py:904-910,1247-1450,1753-1989; derivatives.py:149-192) -------------
+    FD_STEP = 5e-3          # Angstrom; largest per-atom displacement of the inner stencil points
+    FD_MAX_ATOMS = 400_000  # atoms per batched evaluation of displaced copies
+
+    def _single_structure(self, data: dict[str, Any], what: str) -> dict[str, Any]:
+        """Flat single-structure tensors of `data` (coord (N,3)), enforcing the reference's contract."""
+        import torch
+
+        d = self.to_input_tensors(data)
+        coord = d["coord"]
+        if coord.ndim == 3:
+            if coord.shape[0] != 1:
+                raise NotImplementedError(f"{what} supports a single structure only (got 3D batch).")
+            d = {k: (v[0] if k in ("coord", "numbers") else v) for k, v in d.items()}
+            if d.get("cell") is not None and d["cell"].ndim == 3:
+                d["cell"] = d["cell"][0]
+        mol_idx = d.get("mol_idx")
+        if mol_idx is not None and mol_idx.numel() and int(mol_idx.max()) > 0:
+            raise NotImplementedError(f"{what} supports a single structure only (got mol_idx batch).")
+        real = d["numbers"] > 0
+        if not bool(real.all()):
+            raise ValueError(f"{what}: padding atoms (Z = 0) are not allowed in a single-structure input")
+        d["charge"] = d["charge"].reshape(-1)[:1]
+        return d
+
+    def _fd_hvp(self, d: dict[str, Any], dirs, step: float | None = None):
+        """H @ v for K directions `dirs` (K,N,3) of ONE structure by central differences of the analytic forces:
+            H u ~ [F(x+2hu) - 8 F(x+hu) + 8 F(x-hu) - F(x-2hu)] / (12 h),   u = v / max_i |v_i|,
+        with the 4K displaced copies evaluated as one flat multi-molecule batch (independent molecules are what
+        the engine shards over anyway).  Error budget in fp32: truncation O(h^4) ~2e-4 and force noise
+        ~190 eps_F ~1e-3 eV/A^2 at h = 5e-3 A (measured against the fp64 double-backward oracle,
+        tests/test_gpu_calculator.py); the reference's own PME block is a 2-point stencil of the same kind
+        (calculator.py:1777-1781)."""
+        import torch
+
+        h = float(self.FD_STEP if step is None else step)
+        coord, numbers, charge = d["coord"], d["numbers"], d["charge"]
+        cell, n = d.get("cell"), coord.shape[0]
+        dirs = dirs.to(device=self.device, dtype=torch.float32)
+        K = dirs.shape[0]
+        scale = dirs.norm(dim=-1).amax(dim=-1)                       # (K,) largest per-atom displacement
+        unit = dirs / scale.clamp_min(1e-30).view(K, 1, 1)
+        out = torch.zeros_like(dirs)
+        method = self._coulomb_method
+        if cell is not None and method == "simple":
+            method = "dsf"
+        pbc3 = (True, True, True)
+        if d.get("pbc") is not None:
+            pbc3 = tuple(bool(x) for x in d["pbc"].detach().cpu().numpy().astype(bool).reshape(-1)[:3])
+        offsets = torch.tensor([2.0, 1.0, -1.0, -2.0], device=self.device).view(1, 4, 1, 1) * h
+        weights = torch.tensor([1.0, -8.0, 8.0, -1.0], device=self.device).view(1, 4, 1, 1) / (12.0 * h)
+        kb = max(1, self.FD_MAX_ATOMS // (4 * n))
+        for k0 in range(0, K, kb):
+            u = unit[k0 : k0 + kb]
+            kk = u.shape[0]
+            x = (coord.view(1, 1, n, 3) + offsets * u.view(kk, 1, n, 3)).reshape(kk * 4 * n, 3)
+            res = self.engine.eval(
+                x, numbers.repeat(kk * 4), torch.arange(kk * 4, device=self.device, dtype=torch.int32).repeat_interleave(n),
+                charge.repeat(kk * 4), cell=cell, pbc=pbc3, forces=True, stress=False, coulomb=method or "none",
+                dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha)
+            f = res["forces"].view(kk, 4, n, 3)
+            out[k0 : k0 + kk] = (f * weights).sum(dim=1) * scale[k0 : k0 + kk].view(kk, 1, 1)
+        return out
+
+    def _eval_hessian(self, data, *, forces: bool, stress: bool, validate_species: bool) -> dict[str, Any]:
+        import torch
+
+        coord_in = torch.as_tensor(data["coord"])
+        subs = None
+        if coord_in.ndim == 3 and coord_in.shape[0] > 1:  # per-structure Hessians, stacked (calculator.py:1414-1450)
+            B = int(coord_in.shape[0])
+            subs, stack = [], True
+            for b in range(B):
+                sub = {}
+                for k, v in data.items():
+                    if v is None or k == "mol_idx":
+                        continue
+                    t = torch.as_tensor(v)
+                    if k in ("coord", "numbers"):
+                        sub[k] = t[b]
+                    elif k in ("charge", "mult"):
+                        sub[k] = t[b] if t.ndim >= 1 and t.shape[0] == B else t
+                    elif k == "cell":
+                        sub[k] = t[b] if t.ndim == 3 else t
+                    else:
+                        sub[k] = v
+                subs.append(sub)
+        elif coord_in.ndim == 2 and data.get("mol_idx") is not None and int(torch.as_tensor(data["mol_idx"]).max()) > 0:
+            mol = torch.as_tensor(data["mol_idx"]).to("cpu")
+            nm = int(mol.max()) + 1
+            subs, stack = [], False  # independent, generally ragged molecules -> lists
+            for m in range(nm):
+                sel = mol == m
+                sub = {}
+                for k, v in data.items():
+                    if v is None or k == "mol_idx":
+                        continue
+                    t = torch.as_tensor(v)
+                    if k in ("coord", "numbers"):
+                        sub[k] = t[sel.to(t.device)]
+                    elif k in ("charge", "mult"):
+                        sub[k] = t[m] if t.ndim >= 1 and t.shape[0] == nm else t
+                    elif k == "cell":
+                        sub[k] = t[m] if t.ndim == 3 else t
+                    else:
+                        sub[k] = v
+                subs.append(sub)
+        if subs is not None:
+            results = [self.eval(sub, forces=forces, stress=stress, hessian=True, validate_species=validate_species) for sub in subs]
+            out: dict[str, Any] = {}
+            for k in results[0]:
+                vals = [r[k] for r in results]
+                same = all(torch.is_tensor(v) and v.shape == vals[0].shape for v in vals)
+                out[k] = torch.stack(vals, dim=0) if (stack and same) else vals
+            return out
+        d = self._single_structure(data, "Hessian calculation")
+        single = {k: v for k, v in d.items() if k in ("coord", "numbers", "charge", "cell", "pbc", "mult")}
+        out = self.eval(single, forces=True, stress=stress, hessian=False, validate_species=False)
+        n = d["coord"].shape[0]
+        eye = torch.eye(3 * n, device=self.device, dtype=torch.float32).view(3 * n, n, 3)
+        hess = self._fd_hvp(d, eye).view(3 * n, 3 * n)
+        hess = 0.5 * (hess + hess.T)  # the analytic Hessian is symmetric; the FD columns are to O(noise)
+        out["hessian"] = hess.view(n, 3, n, 3)
+        if not forces:
+            out.pop("forces", None)
+        return out
+
+    def hessian_vector_product(self, data: dict[str, Any], vectors, *, eps: float | None = None,
+                               validate_species: bool = True, create_graph: bool = False):
+        """Matrix-free H @ v for one structure (calculator.py:1753-1989): `vectors` (N,3) or (K,N,3) -> same shape.
+        `eps` is the finite-difference step in Angstrom (default FD_STEP); unlike the reference, where only the
+        PME block is finite-difference, here the whole operator is (see `_fd_hvp`)."""
+        import torch
+
+        if create_graph:
+            raise NotImplementedError("create_graph=True needs autograd through the model; the native engine has none")
+        if validate_species:
+            self._validate_species_and_charge(data)
+        self._maybe_warn_mult_ignored(data)
+        d = self._single_structure(data, "hessian_vector_product")
+        v = torch.as_tensor(vectors, dtype=torch.float32, device=self.device)
+        n = d["coord"].shape[0]
+        if v.shape[-2:] != (n, 3) or v.ndim not in (2, 3):
+            raise ValueError(f"vectors must have shape ({n}, 3) or (K, {n}, 3), got {tuple(v.shape)}")
+        hv = self._fd_hvp(d, v.reshape(-1, n, 3), eps)
+        return hv.view_as(v)
 
 
 class _ExternalCoulombState:

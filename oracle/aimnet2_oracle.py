@@ -221,6 +221,7 @@ def evaluate(
     dsf_alpha: float = 0.2,
     forces: bool = True,
     stress: bool = False,
+    hessian: bool = False,
     return_intermediates: bool = False,
     nbmat=None,
     shifts=None,
@@ -260,7 +261,7 @@ def evaluate(
     numbers_p = torch.cat([torch.as_tensor(numbers), torch.zeros(1, dtype=torch.long)])
     mol_p = torch.cat([torch.as_tensor(mol), torch.as_tensor(mol[-1:])])
 
-    coord_p.requires_grad_(forces or stress)
+    coord_p.requires_grad_(forces or stress or hessian)
     x = coord_p
     cell_x = cell_t
     scaling = None
@@ -346,7 +347,17 @@ def evaluate(
             energy = energy + 2.0 * COULOMB_FACTOR * _mol_sum((self_coeff * q_self.pow(2)).double(), mol_p, n_mol)
 
     res: dict[str, np.ndarray] = {"energy": energy.detach().numpy().copy(), "charges": charges[:-1].detach().numpy().copy()}
-    if forces or stress:
+    if hessian:
+        # dense (N,3,N,3) Hessian by double backward, row by row (calculate_hessian, derivatives.py:149-192)
+        (g,) = torch.autograd.grad(energy.sum(), coord_p, create_graph=True)
+        rows = []
+        for k in range(3 * n):
+            (r,) = torch.autograd.grad(g[k // 3, k % 3], coord_p, retain_graph=True)
+            rows.append(r[:-1])
+        res["hessian"] = torch.stack(rows).reshape(n, 3, n, 3).detach().numpy().copy()
+        if forces:
+            res["forces"] = (-g[:-1]).detach().numpy().copy()
+    elif forces or stress:
         wrt = [coord_p] + ([scaling] if stress else [])
         grads = torch.autograd.grad(energy.sum(), wrt)
         if forces:

@@ -88,6 +88,28 @@ def to_np(out: dict) -> dict[str, np.ndarray]:
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 
+def make_hvp40(path: str, meta_common: dict) -> None:
+    """G8: BASELINE config 4 shape - Hessian and Hessian-vector products on a 40-atom H/C/N/O geometry (the first
+    40 atoms of taxol), vectors ~ N(0,1) of shape (40,3) and (4,40,3), seed 0 (call shape of tests/test_hvp.py:59-111)."""
+    coord, numbers = read_taxol()
+    coord, numbers = coord[:40].astype(np.float32), numbers[:40]
+    data = {"coord": coord, "numbers": numbers, "charge": 0.0}
+    calc = make_calc(path)
+    out = to_np(calc(data, forces=True, hessian=True))
+    g = torch.Generator().manual_seed(0)
+    v1 = torch.randn(40, 3, generator=g)
+    v4 = torch.randn(4, 40, 3, generator=g)
+    hv1 = calc.hessian_vector_product(data, v1).detach().numpy()
+    hv4 = calc.hessian_vector_product(data, v4).detach().numpy()
+    H = out["hessian"].reshape(120, 120)
+    print("hvp40 E=%.6f |H|max=%.3f asym=%.2e hvp-vs-dense=%.2e" % (
+        out["energy"][0], np.abs(H).max(), np.abs(H - H.T).max(), np.abs(hv1.reshape(-1) - H @ v1.numpy().reshape(-1)).max()))
+    np.savez_compressed(os.path.join(HERE, "hvp40.npz"), coord=coord, numbers=numbers, charge=np.float32(0.0),
+                        energy=out["energy"], forces=out["forces"], charges=out["charges"],
+                        hessian=out["hessian"].astype(np.float32), v1=v1.numpy(), hv1=hv1, v4=v4.numpy(), hv4=hv4,
+                        **meta_common)
+
+
 def main() -> None:
     art = synth.synthetic_artifact(SEED)
     digest = synth.state_dict_digest({k: v.numpy() for k, v in art["state_dict"].items()})
@@ -99,6 +121,9 @@ def main() -> None:
         model, meta = load_model(path)  # must load cleanly through the reference loader
     assert meta["coulomb_mode"] == "sr_embedded" and meta["needs_coulomb"]
     meta_common = {"weights_seed": np.int64(SEED), "weights_digest": np.array(digest)}
+    if "--only-hvp40" in sys.argv:  # add the config-4 fixture without touching the others
+        make_hvp40(path, meta_common)
+        return
 
     # ---- G1: taxol, config 1 -------------------------------------------------------------
     coord, numbers = read_taxol()
@@ -208,6 +233,7 @@ def main() -> None:
     np.savez_compressed(os.path.join(HERE, "dense3x14.npz"), coord=c3, numbers=z3, charge=np.zeros(3, dtype=np.float32),
                         energy=out["energy"], forces=out["forces"], charges=out["charges"], **meta_common)
     print("dense3x14 E=", out["energy"], out["forces"].shape)
+    make_hvp40(path, meta_common)
 
 
 if __name__ == "__main__":

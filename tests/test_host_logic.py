@@ -133,10 +133,6 @@ def test_setters_and_unsupported_paths(calc):
         calc.set_lrcoulomb_method("ewald")
     with pytest.raises(AssertionError):
         calc(WATER, stress=True)
-    with pytest.raises(NotImplementedError):
-        calc(WATER, hessian=True)
-    with pytest.raises(NotImplementedError):
-        calc.hessian_vector_product(WATER, torch.zeros(3, 3))
     x = torch.tensor(WATER["coord"], requires_grad=True)
     with pytest.raises(NotImplementedError, match="requires grad"):
         calc(dict(WATER, coord=x))
@@ -200,3 +196,66 @@ def test_ase_adapter_contract(calc):
         ase_calc.calculate(patoms, properties=["energy", "forces", "stress"])
     assert calc.engine.calls[-1]["cell"] == (3, 3) and ase_calc.results["stress"].shape == (3, 3)
     assert sorted(AIMNet2ASE.implemented_properties) == sorted(["energy", "forces", "free_energy", "charges", "stress", "dipole_moment"])
+
+
+# ---- finite-difference Hessian / HVP over the engine forces (calculator.py:904-910,1753-1989 of the reference) ------
+class QuadraticEngine(FakeEngine):
+    """E = 1/2 x^T A x per molecule (same symmetric A for every 3-atom molecule): forces = -A x, Hessian = A exactly,
+    so the 4th-order stencil must reproduce A to fp32 rounding."""
+
+    A = None
+
+    def eval(self, coord, numbers, mol_idx, charge, **kw):
+        out = super().eval(coord, numbers, mol_idx, charge, **kw)
+        n_mol = charge.shape[0]
+        x = coord.double().view(n_mol, -1)
+        out["forces"] = (-(x @ self.A.double())).float().view(-1, 3)
+        return out
+
+
+@pytest.fixture()
+def qcalc(monkeypatch):
+    monkeypatch.setattr(calc_mod, "HipEngine", QuadraticEngine)
+    monkeypatch.setattr(torch, "as_tensor", _as_tensor_cpu(torch.as_tensor))
+    c = calc_mod.AIMNet2Calculator(loader.synthetic_spec(0), device="cuda")
+    c.device = "cpu"
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(9, 9, generator=g, dtype=torch.float64)
+    QuadraticEngine.A = a + a.T
+    return c
+
+
+def test_fd_hessian_and_hvp_recover_a_quadratic_model(qcalc):
+    A = QuadraticEngine.A
+    out = qcalc(WATER, hessian=True)
+    assert set(out) == {"energy", "charges", "hessian"} and out["hessian"].shape == (3, 3, 3, 3)
+    assert (out["hessian"].reshape(9, 9).double() - A).abs().max() < 2e-3  # fp32 forces of O(10) / h = 5e-3
+    # one base evaluation, then ONE batched evaluation of the 4 x 9 displaced copies
+    assert [c["n_mol"] for c in qcalc.engine.calls[-2:]] == [1, 36]
+    assert "forces" in qcalc(WATER, forces=True, hessian=True)
+    g = torch.Generator().manual_seed(4)
+    v = torch.randn(5, 3, 3, generator=g)
+    hv = qcalc.hessian_vector_product(WATER, v)
+    assert hv.shape == (5, 3, 3)
+    assert (hv.reshape(5, 9).double() - v.reshape(5, 9).double() @ A).abs().max() < 5e-3
+    hv1 = qcalc.hessian_vector_product(WATER, v[0])
+    assert hv1.shape == (3, 3) and torch.allclose(hv1, hv[0], atol=1e-4)
+    assert (qcalc.hessian_vector_product(WATER, torch.zeros(3, 3)) == 0).all()
+
+
+def test_hessian_batched_inputs_follow_the_reference_contract(qcalc):
+    c3 = np.stack([np.asarray(WATER["coord"]), np.asarray(WATER["coord"]) + 0.05]).astype(np.float32)
+    z3 = np.array([[8, 1, 1], [8, 1, 1]])
+    out = qcalc({"coord": c3, "numbers": z3, "charge": [0.0, 0.0]}, hessian=True)
+    assert out["hessian"].shape == (2, 3, 3, 3, 3) and out["energy"].shape[0] == 2      # 3D batch: stacked
+    flat = {"coord": c3.reshape(6, 3), "numbers": z3.reshape(6), "charge": [0.0, 0.0], "mol_idx": [0, 0, 0, 1, 1, 1]}
+    out = qcalc(flat, hessian=True)
+    assert isinstance(out["hessian"], list) and len(out["hessian"]) == 2 and out["hessian"][0].shape == (3, 3, 3, 3)
+    with pytest.raises(NotImplementedError, match="single structure"):
+        qcalc.hessian_vector_product({"coord": c3, "numbers": z3, "charge": [0.0, 0.0]}, torch.zeros(3, 3))
+    with pytest.raises(NotImplementedError, match="single structure"):
+        qcalc.hessian_vector_product(flat, torch.zeros(6, 3))
+    with pytest.raises(NotImplementedError, match="create_graph"):
+        qcalc.hessian_vector_product(WATER, torch.zeros(3, 3), create_graph=True)
+    with pytest.raises(ValueError, match="vectors must have shape"):
+        qcalc.hessian_vector_product(WATER, torch.zeros(4, 3))

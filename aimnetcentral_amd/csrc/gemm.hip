@@ -385,6 +385,96 @@ static int launch_panel(hipStream_t stream, int epi, const float* A, int lda, co
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Skinny kernel for small M (single molecules: M ~ 100 rows).  There the MFMA work is ~1 us and the tiled kernels
+// are pure latency: 46 dependent K steps of DMA -> barrier -> read.  Here every 16x16 output tile gets a block of
+// 4 waves that split K four ways; a wave issues ALL of its operand loads (<= 12 + 12 dwordx4 straight from L2,
+// no LDS) before its first MFMA, so the critical path is one memory round trip + ~48 MFMAs + a 4-way LDS
+// reduction.  L2 traffic is M*N*K/2 bytes (each tile re-reads its panels), which is why this is only chosen for
+// M <= 256.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bt,
+                                                            int ldb, int M, int N, int K, const float* __restrict__ bias,
+                                                            float* __restrict__ C, float* __restrict__ D, int ldc) {
+  constexpr int MAXC = 12;  // 16-wide k chunks in flight per wave
+  __shared__ f32x4 part[4][64];
+  const int lane = threadIdx.x & 63;
+  const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tiles_n = (N + 15) >> 4;
+  const int m0 = (blockIdx.x / tiles_n) * 16, n0 = (blockIdx.x % tiles_n) * 16;
+  const int l16 = lane & 15, lc = lane >> 4;
+  const int nch = K >> 4;                                   // chunks of 16 along K
+  const int c_lo = (nch * ks) >> 2, c_hi = (nch * (ks + 1)) >> 2;  // this wave's chunk range
+  const float* pa = A + (size_t)min(m0 + l16, M - 1) * lda + lc * 4;
+  const float* pb = Bt + (size_t)min(n0 + l16, N - 1) * ldb + lc * 4;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c0 = c_lo; c0 < c_hi; c0 += MAXC) {
+    f32x4 fa[MAXC], fb[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int cc = min(c0 + c, c_hi - 1);  // clamped duplicates are masked below
+      fa[c] = *reinterpret_cast<const f32x4*>(pa + cc * 16);
+      fb[c] = *reinterpret_cast<const f32x4*>(pb + cc * 16);
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (c0 + c < c_hi) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[c][t], fa[c][t], acc, 0, 0, 0);
+      }
+    }
+  }
+  part[ks][lane] = acc;
+  __syncthreads();
+  if (ks != 0) return;
+  f32x4 v = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+  // v[r] = C[m0 + (lane & 15)][n0 + 4 (lane >> 4) + r]
+  const int row = m0 + l16, col = n0 + 4 * lc;
+  if (row >= M) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (col + r >= N) continue;
+    const size_t o = (size_t)row * ldc + col + r;
+    float x = v[r];
+    if (EPI == EPI_NONE) {
+      C[o] = x;
+    } else if (EPI == EPI_BIAS) {
+      C[o] = x + bias[col + r];
+    } else if (EPI == EPI_BIAS_GELU) {
+      float h, d;
+      gelu_and_grad(x + bias[col + r], h, d);
+      C[o] = h;
+      if (D) D[o] = d;
+    } else {
+      C[o] = x * D[o];
+    }
+  }
+}
+
+static int launch_skinny(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
+                         const float* bias, float* C, float* D, int ldc) {
+  dim3 grid(ceil_div(M, 16) * ceil_div(N, 16)), block(256);
+  switch (epi) {
+    case EPI_NONE:
+      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI_NONE>, grid, block, 0, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    case EPI_BIAS:
+      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI_BIAS>, grid, block, 0, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    case EPI_BIAS_GELU:
+      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI_BIAS_GELU>, grid, block, 0, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    case EPI_MUL:
+      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI_MUL>, grid, block, 0, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      break;
+    default:
+      set_last_error("gemm: bad epilogue %d", epi);
+      return -1;
+  }
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
 static int g_force_tile = 0;  // 0 = choose_tile(); a tile id from AIMNET_GEMM_TILE forces one configuration (A/B runs)
 
 // Tile choice.  Every candidate runs the same MFMA rate; what differs is (a) how evenly ceil(M/TM)*ceil(N/TN)
@@ -398,6 +488,7 @@ static const TileCand kTileCands[] = {
     {152, 160, 128, 10}, {142, 128, 128, 8}, {132, 96, 128, 6}, {122, 64, 128, 4}, {153, 160, 192, 15}, {143, 128, 192, 12},
     {223, 128, 96, 6},   {213, 64, 96, 3},   {222, 128, 64, 4}, {351, 80, 128, 5}, {331, 48, 128, 3},   {5, 64, 64, 1}};
 static int choose_tile(int M, int N, bool vec_ok) {
+  if (M <= 256) return 7;  // latency regime: split-K skinny kernel (see gemm_nt_skinny_kernel)
   int best = 5;
   double best_cost = 1e300;
   for (const TileCand& c : kTileCands) {
@@ -440,6 +531,7 @@ int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int
     AIMNET_PANEL_CASE(331, 3, 1, 1, 8)  //  48 x 128
 #undef AIMNET_PANEL_CASE
     case 5: return launch_ring<3>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    case 7: return launch_skinny(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
     default:
       set_last_error("gemm: unknown tile id %d", cfg);
       return -1;

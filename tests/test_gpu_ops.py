@@ -157,7 +157,7 @@ def test_neighbor_list_batched_cells():
 
 
 # ---- MLP GEMM (csrc/gemm.hip): every tile configuration against an fp64 product ---------------------------
-GEMM_CFGS = [0, 5, 152, 142, 132, 122, 153, 143, 223, 213, 222, 351, 331]
+GEMM_CFGS = [0, 5, 7, 152, 142, 132, 122, 153, 143, 223, 213, 222, 351, 331]
 
 
 @pytest.mark.parametrize("cfg", GEMM_CFGS)

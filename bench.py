@@ -230,7 +230,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (seeded weights of the real aimnet2 architecture; crystal from 2019828.cif + 0.02 A jitter)",
+            "data": "synthetic (seeded weights of the real aimnet2 architecture; " + (
+                "crystal from 2019828.cif + 0.02 A jitter)" if args.workload == "pbc10k" else
+                "taxol.xyz frame 0)" if args.workload == "taxol" else "seeded random organic geometries)"),
             "config": {"workload": wl["label"], "atoms_per_gpu": n_atoms, "frames_per_gpu": frames,
                        "parallelism": f"batch-shard x{world} (independent frames, RCCL all-gather of energies)" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",

@@ -208,6 +208,57 @@ def _conv(a: Tensor, g_sv: Tensor, nbmat: Tensor, agh: Tensor, d2: bool) -> Tens
     return torch.cat([avf_s.squeeze(-1).flatten(-2, -1), avf_v.flatten(-2, -1)], dim=-1)
 
 
+BOHR_INV = 1.0 / 0.5291772105638411
+HALF_HARTREE = 0.5 * 27.211386024367243
+
+
+def dftd3_energy(d_ij: Tensor, mask: Tensor, numbers_p: Tensor, nbmat: Tensor, mol_p: Tensor, n_mol: int, par: dict) -> Tensor:
+    """DFT-D3(BJ) two-body energy per molecule in eV on a full neighbour matrix (distances in Angstrom):
+    restatement of DFTD3._compute_energy_torch (lr.py:1626-1660) with its helpers _calc_torch_coord_num (:1595),
+    _calc_torch_c6ij (:1605) and _s5_switch_torch (:1580).  `par`: s6, s8, a1, a2, cutoff, smoothing_fraction and the
+    reference tables c6ab / cn_ref [Z,Z,5,5], rcov / r4r2 [Z] (aimnet/dftd3_data.pt)."""
+    dt = d_ij.dtype
+    c6ab, cn_ref = torch.as_tensor(par["c6ab"]).to(dt), torch.as_tensor(par["cn_ref"]).to(dt)
+    rcov, r4r2 = torch.as_tensor(par["rcov"]).to(dt), torch.as_tensor(par["r4r2"]).to(dt)
+    d = d_ij.clamp_min(1.0e-12) * BOHR_INV
+    zi = numbers_p.unsqueeze(1).expand_as(nbmat)
+    zj = numbers_p[nbmat]
+    # coordination numbers
+    cn_ij = torch.sigmoid(16.0 * ((rcov[zi] + rcov[zj]) / d.clamp_min(1.0e-12) - 1.0)).masked_fill(mask, 0.0)
+    cn = cn_ij.sum(-1)
+    # C6 interpolation over the 5 x 5 reference systems
+    cn_i = cn.view(-1, 1, 1, 1)
+    cn_j = cn[nbmat].unsqueeze(-1).unsqueeze(-1)
+    c6ref = c6ab[zi, zj]
+    cnref_i = cn_ref[zi, zj]
+    cnref_j = cn_ref[zj, zi].transpose(-1, -2)
+    valid = c6ref != 0
+    exp_arg = -4.0 * ((cn_i - cnref_i).pow(2) + (cn_j - cnref_j).pow(2))
+    max_exp = exp_arg.masked_fill(~valid, -torch.inf).amax(dim=(-1, -2), keepdim=True)
+    finite_max = torch.isfinite(max_exp)
+    shifted = torch.where(finite_max, exp_arg - max_exp, torch.zeros_like(exp_arg))
+    weights = torch.where(valid & finite_max & (shifted >= -12.0), shifted.exp(), torch.zeros_like(shifted))
+    wsum = weights.sum(dim=(-1, -2))
+    c6sum = (c6ref * weights).sum(dim=(-1, -2))
+    c6ij = torch.where(wsum > 1.0e-12, c6sum / wsum.clamp_min(1.0e-12), torch.zeros_like(wsum))
+    # BJ damping + S5 switch
+    r4r2_ij = 3.0 * r4r2[zi] * r4r2[zj]
+    r0 = par["a1"] * r4r2_ij.sqrt() + par["a2"]
+    d2 = d.pow(2)
+    d6, d8 = d2.pow(3), d2.pow(4)
+    damping = par.get("s6", 1.0) / (d6 + r0.pow(6)) + par["s8"] * r4r2_ij / (d8 + r0.pow(8))
+    r_off = float(par.get("cutoff", 15.0)) * BOHR_INV
+    r_on = r_off * (1.0 - float(par.get("smoothing_fraction", 0.2)))
+    if r_off > r_on:
+        t = ((d - r_on) / (r_off - r_on)).clamp(0.0, 1.0)
+        sw = 1.0 - (10.0 * t**3 - 15.0 * t**4 + 6.0 * t**5)
+        sw = torch.where(d <= r_on, torch.ones_like(sw), sw)
+    else:
+        sw = torch.ones_like(d)
+    e_ij = (-c6ij * damping * sw).masked_fill(mask, 0.0)
+    return HALF_HARTREE * _mol_sum(e_ij.sum(-1), mol_p, n_mol)
+
+
 def evaluate(
     model: OracleModel,
     coord,
@@ -222,6 +273,7 @@ def evaluate(
     forces: bool = True,
     stress: bool = False,
     hessian: bool = False,
+    dftd3: dict | None = None,
     return_intermediates: bool = False,
     nbmat=None,
     shifts=None,
@@ -345,6 +397,16 @@ def evaluate(
             self_coeff = -(shift_val / 2.0 + d_lr.new_tensor(dsf_alpha / math.sqrt(math.pi)))
             q_self = torch.cat([charges[:-1], torch.zeros_like(charges[:1])])
             energy = energy + 2.0 * COULOMB_FACTOR * _mol_sum((self_coeff * q_self.pow(2)).double(), mol_p, n_mol)
+
+    if dftd3 is not None:  # external DFT-D3 on its own list of the D3 cutoff (calculator.py:999-1032)
+        rc3 = float(dftd3.get("cutoff", 15.0))
+        nb3, sh3 = neighbor_list(coord_np, rc3, mol, cell, pbc_np)
+        nb3_t = torch.as_tensor(nb3)
+        sh3_t = None if sh3 is None else torch.as_tensor(sh3).to(dt)
+        d3_d, _, d3_mask = _distances(x, nb3_t, sh3_t, cell_x, mol_p)
+        e_d3 = dftd3_energy(d3_d, d3_mask, numbers_p, nb3_t, mol_p, n_mol, dftd3)
+        inter["e_dftd3"] = e_d3
+        energy = energy + e_d3.double()
 
     res: dict[str, np.ndarray] = {"energy": energy.detach().numpy().copy(), "charges": charges[:-1].detach().numpy().copy()}
     if hessian:

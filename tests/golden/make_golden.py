@@ -110,6 +110,59 @@ def make_hvp40(path: str, meta_common: dict) -> None:
                         **meta_common)
 
 
+D3_PARAMS = {"s8": 0.3908, "a1": 0.566, "a2": 3.128, "s6": 1.0}  # wB97M-D3(BJ), the shipped aimnet2 family (docs/models)
+D3_ZMAX = 17  # fixture keeps the reference table rows/columns for Z <= 17 (H..Cl)
+
+
+def make_dftd3(path: str, meta_common: dict) -> None:
+    """G9: DFT-D3(BJ) two-body term of the reference (`DFTD3._compute_energy_torch`, lr.py:1626-1660, the in-tree twin
+    the reference's own tests pin its GPU kernel to, tests/test_dftd3.py:532-640) on the 15 A list the calculator
+    builds for it, forces by autograd.  Also writes the Z <= 17 slice of aimnet/dftd3_data.pt (reference C6 / CN /
+    rcov / r4r2 tables = data, not code) so that the GPU box can run the same numbers."""
+    from aimnet.modules.lr import DFTD3
+    from aimnet import nbops
+
+    raw = torch.load(os.path.join(_refshim.REFERENCE_ROOT, "aimnet", "dftd3_data.pt"), map_location="cpu", weights_only=True)
+    z = D3_ZMAX + 1
+    np.savez_compressed(os.path.join(HERE, "dftd3_subset.npz"), c6ab=raw["c6ab"][:z, :z, :, :, 0].numpy().astype(np.float32),
+                        cn_ref=raw["c6ab"][:z, :z, :, :, 1].numpy().astype(np.float32), rcov=raw["rcov"][:z].numpy().astype(np.float32),
+                        r4r2=raw["r4r2"][:z].numpy().astype(np.float32), zmax=np.int64(D3_ZMAX))
+    d3 = DFTD3(**D3_PARAMS)
+
+    def run(data_in, cutoff=15.0, frac=0.2):
+        d3.set_smoothing(cutoff, frac)
+        calc = make_calc(path)
+        calc._dftd3_cutoff = cutoff
+        calc._coulomb_cutoff = cutoff if data_in.get("cell") is not None else calc._coulomb_cutoff
+        if data_in.get("cell") is not None:
+            calc.set_lrcoulomb_method("dsf", cutoff=cutoff)
+        else:  # non-periodic: ask for a finite LR list of the D3 cutoff
+            calc.set_lrcoulomb_method("dsf", cutoff=cutoff)
+        data = calc.prepare_input({k: v for k, v in data_in.items()})
+        data["coord"] = data["coord"].detach().clone().requires_grad_(True)
+        data = calc.model.prepare_input(data)  # nb mode tag + masks (base.py:281)
+        e = d3._compute_energy_torch(data)
+        (g,) = torch.autograd.grad(e.sum(), data["coord"])
+        n = data_in["coord"].shape[0]
+        return e.detach().numpy().astype(np.float64), (-g[:n]).detach().numpy().astype(np.float32)
+
+    coord, numbers = read_taxol()
+    e1, f1 = run({"coord": coord.astype(np.float32), "numbers": numbers, "charge": 0.0})
+    e1s, f1s = run({"coord": coord.astype(np.float32), "numbers": numbers, "charge": 0.0}, cutoff=9.0, frac=0.25)
+    pc, pz, cell = workloads.glucose_cell()
+    rng = np.random.Generator(np.random.PCG64(7))
+    pc = (pc + rng.normal(scale=0.03, size=pc.shape)).astype(np.float32)
+    e2, f2 = run({"coord": pc, "numbers": pz, "charge": 0.0, "cell": cell.astype(np.float32)}, cutoff=12.0)
+    c, zz, mol, q = workloads.random_batch(5, 9, 30, seed=11)
+    e3, f3 = run({"coord": c, "numbers": zz, "mol_idx": mol, "charge": np.zeros(5, dtype=np.float32)})
+    print("dftd3 taxol E=%.6f (rc 9: %.6f)  pbc96 E=%.6f  batch5 E=%s  |F|max %.4f" % (e1[0], e1s[0], e2[0], e3, np.abs(f1).max()))
+    np.savez_compressed(os.path.join(HERE, "dftd3.npz"), s8=D3_PARAMS["s8"], a1=D3_PARAMS["a1"], a2=D3_PARAMS["a2"], s6=D3_PARAMS["s6"],
+                        taxol_coord=coord.astype(np.float32), taxol_numbers=numbers, taxol_energy=e1, taxol_forces=f1,
+                        taxol_rc9_energy=e1s, taxol_rc9_forces=f1s,
+                        pbc_coord=pc, pbc_numbers=pz, pbc_cell=cell.astype(np.float32), pbc_cutoff=12.0, pbc_energy=e2, pbc_forces=f2,
+                        batch_coord=c, batch_numbers=zz, batch_mol_idx=mol, batch_energy=e3, batch_forces=f3, **meta_common)
+
+
 def main() -> None:
     art = synth.synthetic_artifact(SEED)
     digest = synth.state_dict_digest({k: v.numpy() for k, v in art["state_dict"].items()})
@@ -123,6 +176,9 @@ def main() -> None:
     meta_common = {"weights_seed": np.int64(SEED), "weights_digest": np.array(digest)}
     if "--only-hvp40" in sys.argv:  # add the config-4 fixture without touching the others
         make_hvp40(path, meta_common)
+        return
+    if "--only-dftd3" in sys.argv:
+        make_dftd3(path, meta_common)
         return
 
     # ---- G1: taxol, config 1 -------------------------------------------------------------
@@ -234,6 +290,7 @@ def main() -> None:
                         energy=out["energy"], forces=out["forces"], charges=out["charges"], **meta_common)
     print("dense3x14 E=", out["energy"], out["forces"].shape)
     make_hvp40(path, meta_common)
+    make_dftd3(path, meta_common)
 
 
 if __name__ == "__main__":

@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "aimnet_engine_set_profiling",
     "aimnet_engine_profile_read",
     "aimnet_debug_gemm",
+    "aimnet_engine_set_dftd3",
     "aimnet_neighbor_list",
     "aimnet_neighbor_list_workspace_bytes",
     "aimnet_conv_sv_2d_sp_fwd",
@@ -96,6 +97,26 @@ class EvalOptions(C.Structure):
         ("dsf_alpha", C.c_float),
         ("max_nb", C.c_int32),
         ("max_nb_lr", C.c_int32),
+        ("dftd3", C.c_int32),
+        ("d3_s6", C.c_float),
+        ("d3_s8", C.c_float),
+        ("d3_a1", C.c_float),
+        ("d3_a2", C.c_float),
+        ("d3_cutoff", C.c_float),
+        ("d3_smoothing_on", C.c_float),
+        ("max_nb_d3", C.c_int32),
+    ]
+
+
+class DftD3Tables(C.Structure):
+    """aimnet_dftd3_tables: host pointers, Z-indexed."""
+
+    _fields_ = [
+        ("n_z", C.c_int32),
+        ("c6ab", C.c_void_p),
+        ("cn_ref", C.c_void_p),
+        ("rcov", C.c_void_p),
+        ("r4r2", C.c_void_p),
     ]
 
 
@@ -137,6 +158,8 @@ def load() -> C.CDLL:
     lib.aimnet_engine_set_profiling.argtypes = [vp, C.c_int]
     lib.aimnet_engine_profile_read.restype = C.c_int
     lib.aimnet_engine_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.c_int]
+    lib.aimnet_engine_set_dftd3.restype = C.c_int
+    lib.aimnet_engine_set_dftd3.argtypes = [vp, C.POINTER(DftD3Tables)]
     lib.aimnet_debug_gemm.restype = C.c_int
     lib.aimnet_debug_gemm.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
     lib.aimnet_neighbor_list_workspace_bytes.restype = sz

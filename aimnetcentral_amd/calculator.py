@@ -9,8 +9,8 @@ outputs.  Torch tensors are device buffers, nothing here is differentiated by au
 Deliberate deviations, all loud:
   * no CPU device and no torch fallback - constructing without a ROCm GPU raises HipLibraryError;
   * inputs carrying requires_grad raise (the reference keeps the autograd graph, :1458-1461);
-  * Ewald / PME, external DFT-D3, NSE (2-channel) models, torch.compile and training mode raise
-    NotImplementedError (SURVEY.md 8f "next" rows);
+  * Ewald / PME, NSE (2-channel) models, torch.compile and training mode raise NotImplementedError
+    (SURVEY.md 8f "next" rows); external DFT-D3 needs the reference's table file (loader.load_dftd3_tables);
   * hessian=True and hessian_vector_product are FINITE-DIFFERENCE operators over the analytic HIP forces
     (4th-order central stencil, all displaced copies evaluated as one batch), not double backward: accurate
     to ~1e-3 eV/A^2 in fp32, see `_fd_hvp`.  The analytic double-backward kernels are SURVEY 8f next-4.
@@ -59,6 +59,7 @@ class AIMNet2Calculator:
         *,
         model_import_paths: Collection[str] | None = None,
         model_import_mode: str = "extend",
+        dftd3_data: Any = None,
     ):
         import torch
 
@@ -93,13 +94,19 @@ class AIMNet2Calculator:
         final_needs_dispersion = needs_dispersion if needs_dispersion is not None else bool((metadata or {}).get("needs_dispersion", False))
         if metadata is not None:
             loader.validate_runtime_metadata(metadata, needs_coulomb=final_needs_coulomb, needs_dispersion=final_needs_dispersion)
-        if final_needs_dispersion:
-            raise NotImplementedError(
-                "external DFT-D3 is not implemented by the native engine yet (SURVEY.md 8f next-1); "
-                "construct with needs_dispersion=False to evaluate without dispersion")
         self.external_dftd3 = None
         self._default_dsf_cutoff = 15.0
-        self._dftd3_cutoff = 15.0
+        self._default_dftd3_cutoff, self._default_dftd3_smoothing = 15.0, 0.2
+        self._dftd3_cutoff = self._default_dftd3_cutoff
+        d3_tables = None
+        if final_needs_dispersion:  # calculator.py:234-247 - external DFT-D3(BJ) with the artifact's parameters
+            d3_params = (metadata or {}).get("d3_params")
+            if d3_params is None:
+                raise ValueError("needs_dispersion=True but d3_params not found in metadata. "
+                                 "Provide d3_params in model metadata or set needs_dispersion=False.")
+            d3_tables = loader.load_dftd3_tables(dftd3_data)  # reference: aimnet/dftd3_data.pt (lr.py:1405)
+            self.external_dftd3 = _ExternalDftD3State(s8=d3_params["s8"], a1=d3_params["a1"], a2=d3_params["a2"],
+                                                      s6=d3_params.get("s6", 1.0))
         # external Coulomb state (LRCoulomb attributes the reference exposes, lr.py:285-300)
         self.external_coulomb = None
         self._coulomb_method: str | None = None
@@ -115,7 +122,11 @@ class AIMNet2Calculator:
         self.cutoff_lr: float | None = self._coulomb_cutoff
         self.lr = self.external_coulomb is not None or bool((metadata or {}).get("has_embedded_lr", False))
 
+        if self.external_coulomb is None and self.external_dftd3 is not None:
+            self.cutoff_lr = self._dftd3_cutoff
         self.engine = HipEngine(spec, dev)
+        if d3_tables is not None:
+            self.engine.set_dftd3_tables(d3_tables)
         self.device = str(self.engine.device)
         self._batch: int | None = None
         self._max_mol_size = 0
@@ -159,7 +170,7 @@ class AIMNet2Calculator:
 
     @property
     def has_external_dftd3(self) -> bool:
-        return False
+        return self.external_dftd3 is not None
 
     @property
     def is_nse(self) -> bool:
@@ -222,15 +233,34 @@ class AIMNet2Calculator:
             self._coulomb_cutoff = float("inf")
         self.cutoff_lr = self._coulomb_cutoff
 
+    def _dftd3_options(self) -> dict[str, float] | None:
+        d3 = self.external_dftd3
+        if d3 is None:
+            return None
+        return {"s6": d3.s6, "s8": d3.s8, "a1": d3.a1, "a2": d3.a2, "cutoff": d3.smoothing_off,
+                "smoothing_fraction": d3.smoothing_fraction}
+
     def set_lr_cutoff(self, cutoff: float) -> None:
         self._coulomb_cutoff = cutoff
         if self._coulomb_method == "dsf":
             self._dsf_rc = float(cutoff)
         self._dftd3_cutoff = cutoff
+        if self.external_dftd3 is not None:
+            self.external_dftd3.set_smoothing(cutoff, self.external_dftd3.smoothing_fraction)
         self.cutoff_lr = cutoff
 
     def set_dftd3_cutoff(self, cutoff: float | None = None, smoothing_fraction: float | None = None) -> None:
-        self._dftd3_cutoff = 15.0 if cutoff is None else cutoff
+        """calculator.py:752-783: cutoff = end of the S5 switch (= D3 list cutoff), smoothing window = the last
+        `smoothing_fraction` of it."""
+        if cutoff is None:
+            cutoff = self._default_dftd3_cutoff
+        if smoothing_fraction is None:
+            smoothing_fraction = self._default_dftd3_smoothing
+        self._dftd3_cutoff = cutoff
+        if self.external_dftd3 is not None:
+            self.external_dftd3.set_smoothing(cutoff, smoothing_fraction)
+            if self.external_coulomb is None:
+                self.cutoff_lr = cutoff
 
     # ---- validation (calculator.py:785-851) ------------------------------------------------------------
     def _validate_species_and_charge(self, data) -> None:
@@ -339,7 +369,7 @@ class AIMNet2Calculator:
                 pbc3 = tuple(bool(x) for x in p)
             res = self.engine.eval(
                 coord_f, numbers_f, mol_idx, charge, cell=cell, pbc=pbc3, forces=bool(forces), stress=bool(stress),
-                coulomb=method or "none", dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha)
+                coulomb=method or "none", dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, dftd3=self._dftd3_options())
         finally:
             if restore is not None:
                 (self._coulomb_method, self._coulomb_cutoff, self.cutoff_lr, self._dsf_alpha, self._dsf_rc) = restore
@@ -421,7 +451,7 @@ class AIMNet2Calculator:
             res = self.engine.eval(
                 x, numbers.repeat(kk * 4), torch.arange(kk * 4, device=self.device, dtype=torch.int32).repeat_interleave(n),
                 charge.repeat(kk * 4), cell=cell, pbc=pbc3, forces=True, stress=False, coulomb=method or "none",
-                dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha)
+                dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, dftd3=self._dftd3_options())
             f = res["forces"].view(kk, 4, n, 3)
             out[k0 : k0 + kk] = (f * weights).sum(dim=1) * scale[k0 : k0 + kk].view(kk, 1, 1)
         return out
@@ -508,6 +538,19 @@ class AIMNet2Calculator:
             raise ValueError(f"vectors must have shape ({n}, 3) or (K, {n}, 3), got {tuple(v.shape)}")
         hv = self._fd_hvp(d, v.reshape(-1, n, 3), eps)
         return hv.view_as(v)
+
+
+class _ExternalDftD3State:
+    """Stand-in exposing what callers read off `calc.external_dftd3` (DFTD3 attributes, lr.py:1383-1440)."""
+
+    def __init__(self, s8: float, a1: float, a2: float, s6: float = 1.0, cutoff: float = 15.0, smoothing_fraction: float = 0.2):
+        self.s6, self.s8, self.a1, self.a2 = float(s6), float(s8), float(a1), float(a2)
+        self.set_smoothing(cutoff, smoothing_fraction)
+
+    def set_smoothing(self, cutoff: float, smoothing_fraction: float = 0.2) -> None:
+        self.smoothing_fraction = float(smoothing_fraction)
+        self.smoothing_on = float(cutoff) * (1.0 - float(smoothing_fraction))
+        self.smoothing_off = float(cutoff)
 
 
 class _ExternalCoulombState:

@@ -1,0 +1,310 @@
+// d3.hip - DFT-D3(BJ) two-body dispersion: energy, forces, virial.
+//
+// Reference semantics (paths relative to /root/reference/aimnet): modules/lr.py DFTD3 (:1335-1820), whose GPU
+// path is the third-party nvalchemiops `dftd3` kernel and whose in-tree torch twin - the arithmetic restated
+// here and in oracle/aimnet2_oracle.py::dftd3_energy - is
+//   _calc_torch_coord_num :1595   cn_i = sum_j sigmoid(16 ((rcov_i + rcov_j) / d_ij - 1))        (d in Bohr)
+//   _calc_torch_c6ij      :1605   C6_ij = sum_ab c6ref_ab W_ab / sum_ab W_ab over the 5x5 reference systems,
+//                                 W_ab = exp(-4 ((cn_i - cnref_i[a])^2 + (cn_j - cnref_j[b])^2) - max), dropped below e^-12
+//   _compute_energy_torch :1626   e_ij = -C6_ij (s6 / (d^6 + R0^6) + s8 3 r4r2_i r4r2_j / (d^8 + R0^8)) S5(d),
+//                                 R0 = a1 sqrt(3 r4r2_i r4r2_j) + a2,  E = Hartree/2 * sum over ORDERED pairs
+//   _s5_switch_torch      :1580   quintic switch between cutoff (1 - smoothing_fraction) and cutoff.
+//
+// What is different from the reference arithmetic, and why it is the same number:
+//   * the reference tables store cnref_i[a] redundantly per partner species and reference b; they factorise
+//     (checked at upload, engine.hip), so exp(-4 dcn_i^2 - 4 dcn_j^2) = w_i[a] w_j[b] with FIVE exponentials per
+//     atom (d3_cn_kernel) instead of 25 per pair; the e^-12 drop rule is applied per (a, b) on the sum of the two
+//     shifted exponents exactly as the reference does;
+//   * forces are analytic (the reference kernel returns them too): the C6(cn) dependence goes through
+//     dE/dcn_i accumulated in the pair pass and is pushed to positions by a third, cheap pass over the same list.
+//
+// Three passes over the D3 neighbour list (wave per atom, lanes over list slots), HBM-bound on the 8 B list entries
+// with L2-resident gathers of 48 B per neighbour:
+//   d3_cn_kernel       cn_i, then the 5 shifted exponents / weights of atom i
+//   d3_pair_kernel     C6_ij, pair energy (fp64 sums), direct pair force + virial, dE/dcn_i
+//   d3_cnforce_kernel  (dE/dcn_i + dE/dcn_j) dsigma/dd along u_ij  -> force + virial
+#include "common.h"
+#include "kernels.h"
+
+namespace aimnet {
+
+constexpr float BOHR_INV_F = 1.8897261258369282f;   // 1 / 0.5291772105638411 (constants.py:8-9)
+constexpr float HALF_HARTREE_F = 13.605693012183622f;
+constexpr int D3W = 12;  // floats per atom in the weight table: s[5], w[5], cn, pad
+
+// PairAcc / pair_add / pair_store live in model.hip; the same accumulation contract is restated here
+struct D3Acc {
+  double e = 0.0;
+  float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+  float W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+template <bool STRESS>
+__device__ __forceinline__ void d3_add(D3Acc& A, float t, float ux, float uy, float uz, float d) {
+  A.f0 += t * ux;
+  A.f1 += t * uy;
+  A.f2 += t * uz;
+  if (STRESS) {
+    const float rx = ux * d, ry = uy * d, rz = uz * d;
+    A.W[0] += rx * t * ux; A.W[1] += rx * t * uy; A.W[2] += rx * t * uz;
+    A.W[3] += ry * t * ux; A.W[4] += ry * t * uy; A.W[5] += ry * t * uz;
+    A.W[6] += rz * t * ux; A.W[7] += rz * t * uy; A.W[8] += rz * t * uz;
+  }
+}
+
+// E = k sum_ordered e  ->  dE/dx_i = -2k sum_j e' u_ij ,  dE/deps_ab = k sum_ordered e' r_a u_b   (as coulomb pair_store)
+template <bool GRAD, bool STRESS>
+__device__ __forceinline__ void d3_store(D3Acc& A, int i, int lane, float k, double* ecoul, float* fgrad, float* virial_atom) {
+  const double e = wave_sum(A.e);
+  float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+  if (GRAD) {
+    f0 = wave_sum(A.f0);
+    f1 = wave_sum(A.f1);
+    f2 = wave_sum(A.f2);
+    if (STRESS) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) A.W[q] = wave_sum(A.W[q]);
+    }
+  }
+  if (lane == 0) {
+    ecoul[i] += (double)k * e;
+    if (GRAD) {
+      fgrad[3 * i + 0] += -2.0f * k * f0;
+      fgrad[3 * i + 1] += -2.0f * k * f1;
+      fgrad[3 * i + 2] += -2.0f * k * f2;
+    }
+  }
+  if (GRAD && STRESS && lane < 9) {
+    float v = A.W[0];
+#pragma unroll
+    for (int q = 1; q < 9; ++q) v = (lane == q) ? A.W[q] : v;
+    virial_atom[(size_t)i * 9 + lane] += k * v;
+  }
+}
+
+struct D3Pair {
+  float ux, uy, uz, d;  // unit vector i -> j and distance in Angstrom
+  int j;
+  bool ok;
+};
+
+__device__ __forceinline__ D3Pair d3_pair(const float* __restrict__ xw, const float* c, const int* __restrict__ nb_idx,
+                                          const int* __restrict__ nb_shift, size_t p, float xi, float yi, float zi,
+                                          float cutoff) {
+  D3Pair r;
+  r.j = nb_idx[p];
+  float rx = xw[3 * r.j] - xi, ry = xw[3 * r.j + 1] - yi, rz = xw[3 * r.j + 2] - zi;
+  if (c) {
+    int sx, sy, sz;
+    unpack_shift(nb_shift[p], sx, sy, sz);
+    rx += sx * c[0] + sy * c[3] + sz * c[6];
+    ry += sx * c[1] + sy * c[4] + sz * c[7];
+    rz += sx * c[2] + sy * c[5] + sz * c[8];
+  }
+  r.d = sqrtf(rx * rx + ry * ry + rz * rz);
+  const float inv = 1.0f / fmaxf(r.d, 1e-12f);
+  r.ux = rx * inv;
+  r.uy = ry * inv;
+  r.uz = rz * inv;
+  r.ok = r.d < cutoff;
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void d3_cn_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
+                                                   const float* __restrict__ cell, int n_cell,
+                                                   const int* __restrict__ aslot, const int* __restrict__ nb_idx,
+                                                   const int* __restrict__ nb_shift, const int* __restrict__ nb_cnt, int cap,
+                                                   D3Tables T, float cutoff, int n_atoms, float* __restrict__ d3w) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const float* c = cell ? cell + (n_cell == 1 ? 0 : (size_t)mol_idx[i] * 9) : nullptr;
+  const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2];
+  const int si = aslot[i];
+  const float rci = T.rcov[si];
+  const int cnt = nb_cnt[i];
+  float cn = 0.0f;
+  for (int m = lane; m < cnt; m += 64) {
+    const D3Pair P = d3_pair(xw, c, nb_idx, nb_shift, (size_t)i * cap + m, xi, yi, zi, cutoff);
+    if (!P.ok) continue;
+    const float db = fmaxf(P.d * BOHR_INV_F, 1e-12f);
+    cn += 1.0f / (1.0f + expf(-16.0f * ((rci + T.rcov[aslot[P.j]]) / db - 1.0f)));
+  }
+  cn = wave_sum(cn);
+  // the five reference-system exponents of atom i, shifted by their maximum (every lane computes all five)
+  const int nref = T.nref[si];
+  float e[5], mx = -1e30f;
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    const float dc = cn - T.cnref[si * 5 + a];
+    e[a] = a < nref ? -4.0f * dc * dc : -1e30f;
+    mx = fmaxf(mx, e[a]);
+  }
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    if (lane == a) {
+      const float sa = a < nref ? e[a] - mx : -1e30f;
+      d3w[(size_t)i * D3W + a] = sa;
+      d3w[(size_t)i * D3W + 5 + a] = a < nref ? expf(sa) : 0.0f;
+    }
+  }
+  if (lane == 5) d3w[(size_t)i * D3W + 10] = cn;
+  if (lane == 6) d3w[(size_t)i * D3W + 11] = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool GRAD, bool STRESS>
+__global__ __launch_bounds__(256) void d3_pair_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
+                                                     const float* __restrict__ cell, int n_cell,
+                                                     const int* __restrict__ aslot, const int* __restrict__ nb_idx,
+                                                     const int* __restrict__ nb_shift, const int* __restrict__ nb_cnt, int cap,
+                                                     D3Tables T, D3Params P3, float cutoff, int n_atoms,
+                                                     const float* __restrict__ d3w, double* __restrict__ ecoul,
+                                                     float* __restrict__ fgrad, float* __restrict__ virial_atom,
+                                                     float* __restrict__ dEdcn) {
+  extern __shared__ float c6lds[];  // [4 waves][ns][25]: the C6 reference block of the centre's species against every slot
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wid;
+  if (i >= n_atoms) return;
+  const int ns = T.ns;
+  float* c6s = c6lds + (size_t)wid * ns * 25;
+  const int si = aslot[i];
+  for (int k = lane; k < ns * 25; k += 64) c6s[k] = T.c6slot[(size_t)si * ns * 25 + k];
+  __builtin_amdgcn_wave_barrier();
+  const float* c = cell ? cell + (n_cell == 1 ? 0 : (size_t)mol_idx[i] * 9) : nullptr;
+  const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2];
+  const int nref_i = T.nref[si];
+  float s_i[5], w_i[5], g_i[5];
+  const float cn_i = d3w[(size_t)i * D3W + 10];
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    s_i[a] = d3w[(size_t)i * D3W + a];
+    w_i[a] = d3w[(size_t)i * D3W + 5 + a];
+    g_i[a] = -8.0f * (cn_i - T.cnref[si * 5 + a]);  // d log w_i[a] / d cn_i (the max shift cancels in the ratio)
+  }
+  const float q_i = T.r4r2[si];
+  const int cnt = nb_cnt[i];
+  D3Acc A;
+  float dcn = 0.0f;
+  for (int m = lane; m < cnt; m += 64) {
+    const D3Pair P = d3_pair(xw, c, nb_idx, nb_shift, (size_t)i * cap + m, xi, yi, zi, cutoff);
+    if (!P.ok) continue;
+    const int sj = aslot[P.j];
+    const float4 sj0 = *reinterpret_cast<const float4*>(d3w + (size_t)P.j * D3W);
+    const float4 sj1 = *reinterpret_cast<const float4*>(d3w + (size_t)P.j * D3W + 4);
+    const float2 sj2 = *reinterpret_cast<const float2*>(d3w + (size_t)P.j * D3W + 8);
+    const float s_j[5] = {sj0.x, sj0.y, sj0.z, sj0.w, sj1.x};
+    const float w_j[5] = {sj1.y, sj1.z, sj1.w, sj2.x, sj2.y};
+    const float* cr = c6s + sj * 25;
+    float N = 0.f, D = 0.f, G = 0.f, H = 0.f;
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+      if (a < nref_i) {
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          const float c6r = cr[a * 5 + b];
+          const float w = (s_i[a] + s_j[b] >= -12.0f && c6r != 0.0f) ? w_i[a] * w_j[b] : 0.0f;
+          N += c6r * w;
+          D += w;
+          if (GRAD) {
+            G += c6r * w * g_i[a];
+            H += w * g_i[a];
+          }
+        }
+      }
+    }
+    const bool has = D > 1.0e-12f;
+    const float invD = 1.0f / fmaxf(D, 1.0e-12f);
+    const float c6 = has ? N * invD : 0.0f;
+    const float db = fmaxf(P.d * BOHR_INV_F, 1e-12f);
+    const float qq = 3.0f * q_i * T.r4r2[sj];
+    const float r0 = P3.a1 * sqrtf(qq) + P3.a2;
+    const float d2 = db * db, d4 = d2 * d2, d6 = d4 * d2, d8 = d4 * d4;
+    const float r2 = r0 * r0, r4 = r2 * r2, r6 = r4 * r2, r8 = r4 * r4;
+    const float i6 = 1.0f / (d6 + r6), i8 = 1.0f / (d8 + r8);
+    const float damp = P3.s6 * i6 + P3.s8 * qq * i8;
+    float sw = 1.0f, dsw = 0.0f;
+    if (P3.r_off > P3.r_on && db > P3.r_on) {
+      const float iw = 1.0f / (P3.r_off - P3.r_on);
+      const float t = fminf(fmaxf((db - P3.r_on) * iw, 0.0f), 1.0f);
+      const float t2 = t * t;
+      sw = 1.0f - t2 * t * (10.0f - 15.0f * t + 6.0f * t2);
+      dsw = -30.0f * t2 * (1.0f - 2.0f * t + t2) * iw;
+    }
+    A.e += (double)(-c6 * damp * sw);
+    if (GRAD) {
+      const float ddamp = -6.0f * P3.s6 * d4 * db * i6 * i6 - 8.0f * P3.s8 * qq * d6 * db * i8 * i8;
+      const float de = -c6 * (ddamp * sw + damp * dsw) * BOHR_INV_F;  // d e_ij / d d_ij per Angstrom, C6 held fixed
+      d3_add<STRESS>(A, de, P.ux, P.uy, P.uz, P.d);
+      if (has) dcn += -damp * sw * (G - c6 * H) * invD;
+    }
+  }
+  d3_store<GRAD, STRESS>(A, i, lane, HALF_HARTREE_F, ecoul, fgrad, virial_atom);
+  if (GRAD) {
+    dcn = wave_sum(dcn);
+    if (lane == 0) dEdcn[i] = 2.0f * HALF_HARTREE_F * dcn;  // e_ij and e_ji both depend on cn_i, symmetrically
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool STRESS>
+__global__ __launch_bounds__(256) void d3_cnforce_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
+                                                        const float* __restrict__ cell, int n_cell,
+                                                        const int* __restrict__ aslot, const int* __restrict__ nb_idx,
+                                                        const int* __restrict__ nb_shift, const int* __restrict__ nb_cnt,
+                                                        int cap, D3Tables T, float cutoff, int n_atoms,
+                                                        const float* __restrict__ dEdcn, double* __restrict__ ecoul,
+                                                        float* __restrict__ fgrad, float* __restrict__ virial_atom) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const float* c = cell ? cell + (n_cell == 1 ? 0 : (size_t)mol_idx[i] * 9) : nullptr;
+  const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2];
+  const float rci = T.rcov[aslot[i]];
+  const float gi = dEdcn[i];
+  const int cnt = nb_cnt[i];
+  D3Acc A;
+  for (int m = lane; m < cnt; m += 64) {
+    const D3Pair P = d3_pair(xw, c, nb_idx, nb_shift, (size_t)i * cap + m, xi, yi, zi, cutoff);
+    if (!P.ok) continue;
+    const float db = fmaxf(P.d * BOHR_INV_F, 1e-12f);
+    const float R = rci + T.rcov[aslot[P.j]];
+    const float sg = 1.0f / (1.0f + expf(-16.0f * (R / db - 1.0f)));
+    const float dsg = sg * (1.0f - sg) * (-16.0f * R / (db * db)) * BOHR_INV_F;  // d sigma / d d_ij per Angstrom
+    // sum_l dE/dcn_l cn_l as a pair "energy" with k = 1: per ordered pair 1/2 (g_i + g_j) sigma(d_ij)
+    d3_add<STRESS>(A, 0.5f * (gi + dEdcn[P.j]) * dsg, P.ux, P.uy, P.uz, P.d);
+  }
+  d3_store<true, STRESS>(A, i, lane, 1.0f, ecoul, fgrad, virial_atom);
+}
+
+// ------------------------------------------------------------------------------------------------
+int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const int* mol_idx, const float* cell, int n_cell,
+                 const int* aslot, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, D3Tables T, D3Params P,
+                 float cutoff, int n_atoms, float* d3w, float* dEdcn, double* ecoul, float* fgrad, float* virial_atom) {
+  dim3 grid(ceil_div(n_atoms, 4)), block(256);
+  hipLaunchKernelGGL(d3_cn_kernel, grid, block, 0, s, xw, mol_idx, cell, n_cell, aslot, nb_idx, nb_shift, nb_cnt, cap, T, cutoff,
+                     n_atoms, d3w);
+  AIMNET_LAUNCH_CHECK();
+  const size_t lds = (size_t)4 * T.ns * 25 * sizeof(float);
+#define AIMNET_D3_PAIR(G_, S_)                                                                                              \
+  hipLaunchKernelGGL((d3_pair_kernel<G_, S_>), grid, block, lds, s, xw, mol_idx, cell, n_cell, aslot, nb_idx, nb_shift, nb_cnt, \
+                     cap, T, P, cutoff, n_atoms, d3w, ecoul, fgrad, virial_atom, dEdcn)
+  if (grad && stress) AIMNET_D3_PAIR(true, true);
+  else if (grad) AIMNET_D3_PAIR(true, false);
+  else AIMNET_D3_PAIR(false, false);
+#undef AIMNET_D3_PAIR
+  AIMNET_LAUNCH_CHECK();
+  if (grad) {
+    if (stress)
+      hipLaunchKernelGGL(d3_cnforce_kernel<true>, grid, block, 0, s, xw, mol_idx, cell, n_cell, aslot, nb_idx, nb_shift, nb_cnt,
+                         cap, T, cutoff, n_atoms, dEdcn, ecoul, fgrad, virial_atom);
+    else
+      hipLaunchKernelGGL(d3_cnforce_kernel<false>, grid, block, 0, s, xw, mol_idx, cell, n_cell, aslot, nb_idx, nb_shift, nb_cnt,
+                         cap, T, cutoff, n_atoms, dEdcn, ecoul, fgrad, virial_atom);
+    AIMNET_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+}  // namespace aimnet

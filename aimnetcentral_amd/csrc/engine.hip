@@ -52,6 +52,9 @@ struct aimnet_engine {
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row
   int *slot_of_z, *z_of_slot;
   int nslots = 0;
+  std::vector<int> z_of_slot_h;  // host copy (slot -> atomic number)
+  // DFT-D3 tables re-indexed by species slot (aimnet_engine_set_dftd3); d3.ns == 0 until set
+  D3Tables d3{0, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool p0_moments = true;  // AIMNET_P0_MOMENTS=0 keeps the generic conv_bwd for pass 0 (A/B and parity runs)
   std::vector<Layer> mlp[AIMNET_MAX_PASS];
   std::vector<Layer> head;
@@ -158,7 +161,9 @@ struct Workspace {
   int S;         // slices per molecule
   float *zb0, *zb1;  // ping-pong adjoint buffers (N x max padded width)
   float *Sbar, *Sqbar;
-  int* aslot;                        // species slot of every atom (pass-0 moments)
+  int *d3_idx, *d3_shift, *d3_cnt;   // DFT-D3 neighbour matrix (aliases the LR list when both use one cutoff)
+  float *d3w, *dEdcn;                // per-atom D3 reference weights (12 floats) and dE/dCN
+  int* aslot;                        // species slot of every atom (pass-0 moments, DFT-D3)
   unsigned long long* present_part;  // per-block masks of the slots present
   int n_part;
   size_t total;
@@ -170,6 +175,13 @@ int max_width(const aimnet_engine* e) {
     for (const Layer& L : e->mlp[p]) w = std::max(w, std::max(L.k_in, L.k_out));
   for (const Layer& L : e->head) w = std::max(w, std::max(L.k_in, L.k_out));
   return w;
+}
+
+// The D3 list and the list-based (non-periodic) DSF list are the same neighbour matrix when their cutoffs agree
+// (both default to 15 A): build and store it once.  The workspace layout does not know about periodicity, so the
+// test is on the capacities the caller passed: max_nb_lr > 0 means "a DSF list will be built".
+bool d3_shares_lr_list(const aimnet_eval_options* opt, int cap_lr) {
+  return opt->coulomb == AIMNET_COULOMB_DSF && cap_lr > 0 && opt->d3_cutoff == opt->dsf_rc;
 }
 
 void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options* opt, char* base, Workspace& W,
@@ -189,6 +201,16 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   W.lr_idx = c.take<int>(n * cap_lr, "lr_idx", cap_lr);
   W.lr_shift = c.take<int>(n * cap_lr, "lr_shift", cap_lr);
   W.lr_cnt = c.take<int>(n, "lr_cnt", 1);
+  {
+    const bool d3 = opt->dftd3 != 0;
+    const bool share = d3 && d3_shares_lr_list(opt, cap_lr);
+    const int cap_d3 = d3 && !share ? std::max(1, opt->max_nb_d3) : 0;
+    W.d3_idx = share ? W.lr_idx : c.take<int>(n * cap_d3, "d3_idx", cap_d3);
+    W.d3_shift = share ? W.lr_shift : c.take<int>(n * cap_d3, "d3_shift", cap_d3);
+    W.d3_cnt = share ? W.lr_cnt : c.take<int>(d3 ? n : 0, "d3_cnt", 1);
+    W.d3w = c.take<float>(d3 ? n * 12 : 0);
+    W.dEdcn = c.take<float>(d3 ? n : 0);
+  }
   W.pg = c.take<float4>(n * cap, "pair_geom", cap);
   char name[32];
   for (int p = 0; p < np; ++p) {
@@ -280,6 +302,7 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
       zos[ns++] = bad_row;
     }
     e->nslots = ns;
+    e->z_of_slot_h.assign(zos, zos + ns);
     if ((rc = dev_upload(e, soz, (size_t)64, &e->slot_of_z))) goto fail;
     if ((rc = dev_upload(e, zos, (size_t)ns, &e->z_of_slot))) goto fail;
     const char* env = getenv("AIMNET_P0_MOMENTS");
@@ -371,6 +394,53 @@ int aimnet_engine_profile_read(aimnet_engine* e, double* ms, int n_families, int
   return AIMNET_OK;
 }
 
+int aimnet_engine_set_dftd3(aimnet_engine* e, const aimnet_dftd3_tables* t) {
+  if (!e || !t || t->n_z <= 0 || !t->c6ab || !t->cn_ref || !t->rcov || !t->r4r2) {
+    set_last_error("set_dftd3: null argument");
+    return AIMNET_E_INVALID;
+  }
+  AIMNET_HIP_CHECK(hipSetDevice(e->device));
+  const int ns = e->nslots, nz = t->n_z;
+  auto at = [&](const float* tab, int zi, int zj, int a, int b) { return tab[(((size_t)zi * nz + zj) * 5 + a) * 5 + b]; };
+  std::vector<float> c6((size_t)ns * ns * 25, 0.0f), cnref((size_t)ns * 5, 0.0f), rcov(ns, 0.0f), r4r2(ns, 0.0f);
+  std::vector<int> nref(ns, 0);
+  for (int si = 0; si < ns; ++si) {
+    const int zi = e->z_of_slot_h[si];
+    if (zi >= nz || zi <= 0) continue;  // outside the table: all-zero rows (no dispersion for that slot)
+    rcov[si] = t->rcov[zi];
+    r4r2[si] = t->r4r2[zi];
+    int n = 0;
+    while (n < 5 && at(t->c6ab, zi, zi, n, n) != 0.0f) ++n;
+    nref[si] = n;
+    for (int a = 0; a < n; ++a) cnref[(size_t)si * 5 + a] = at(t->cn_ref, zi, zi, a, 0);
+  }
+  for (int si = 0; si < ns; ++si)
+    for (int sj = 0; sj < ns; ++sj) {
+      const int zi = e->z_of_slot_h[si], zj = e->z_of_slot_h[sj];
+      if (zi >= nz || zj >= nz || zi <= 0 || zj <= 0) continue;
+      for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b) {
+          const float v = at(t->c6ab, zi, zj, a, b);
+          const bool expect = a < nref[si] && b < nref[sj];
+          if ((v != 0.0f) != expect || (expect && at(t->cn_ref, zi, zj, a, b) != cnref[(size_t)si * 5 + a])) {
+            set_last_error("set_dftd3: the C6/CN table of Z = %d, %d does not factorise (ref %d, %d)", zi, zj, a, b);
+            return AIMNET_E_INVALID;
+          }
+          c6[(((size_t)si * ns + sj) * 5 + a) * 5 + b] = v;
+        }
+    }
+  int rc;
+  float *d_c6, *d_cn, *d_rc, *d_r4;
+  int* d_nr;
+  if ((rc = dev_upload(e, c6.data(), c6.size(), &d_c6))) return rc;
+  if ((rc = dev_upload(e, cnref.data(), cnref.size(), &d_cn))) return rc;
+  if ((rc = dev_upload(e, nref.data(), nref.size(), &d_nr))) return rc;
+  if ((rc = dev_upload(e, rcov.data(), rcov.size(), &d_rc))) return rc;
+  if ((rc = dev_upload(e, r4r2.data(), r4r2.size(), &d_r4))) return rc;
+  e->d3 = D3Tables{ns, d_c6, d_cn, d_nr, d_rc, d_r4};
+  return AIMNET_OK;
+}
+
 size_t aimnet_engine_workspace_bytes(const aimnet_engine* e, int32_t n_atoms, int32_t n_mol, int32_t n_cell,
                                      const aimnet_eval_options* opt) {
   (void)n_cell;
@@ -455,13 +525,30 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   if (coulomb == AIMNET_COULOMB_DSF && !pbc)  // periodic DSF needs no list: it walks the short-range cell grid
     RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, opt->dsf_rc, -1.0f, cap_lr, N, 0, W.nl, W.lr_idx,
                     W.lr_shift, W.lr_cnt, out->status + 1, out->status + 3));
+  const bool d3 = opt->dftd3 != 0;
+  if (d3 && e->d3.ns == 0) {
+    set_last_error("eval: DFT-D3 requested but aimnet_engine_set_dftd3 was never called");
+    return AIMNET_E_INVALID;
+  }
+  const bool d3_shared = d3 && d3_shares_lr_list(opt, cap_lr) && !pbc;
+  int cap_d3 = cap_lr;
+  if (d3 && !d3_shared) {
+    if (d3_shares_lr_list(opt, cap_lr)) {  // periodic DSF walks the grid: the shared buffers are free for the D3 list
+      RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, opt->d3_cutoff, -1.0f, cap_lr, N, 0, W.nl, W.d3_idx,
+                      W.d3_shift, W.d3_cnt, out->status + 4, out->status + 5));
+    } else {
+      cap_d3 = std::max(1, opt->max_nb_d3);
+      RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, opt->d3_cutoff, -1.0f, cap_d3, N, 0, W.nl, W.d3_idx,
+                      W.d3_shift, W.d3_cnt, out->status + 4, out->status + 5));
+    }
+  }
   RC(prof_mark(e, s, FAM_GEOM));
   RC(launch_pair_geom(s, W.nl.xw, in->mol_idx, in->cell, n_cell, W.nb_idx, W.nb_shift, W.nb_cnt, cap, N, W.pg));
 
   // ---- forward --------------------------------------------------------------------------------
   RC(launch_embed(s, e->afv, in->numbers, N, W.a[0]));
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
-  if (p0m) RC(launch_species(s, in->numbers, e->slot_of_z, N, W.aslot, W.present_part));
+  if (p0m || d3) RC(launch_species(s, in->numbers, e->slot_of_z, N, W.aslot, W.present_part));
   for (int p = 0; p < np; ++p) {
     const std::vector<Layer>& Ls = e->mlp[p];
     const int nl = (int)Ls.size();
@@ -519,6 +606,14 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   else if (coulomb == AIMNET_COULOMB_DSF)
     RC(launch_coulomb_dsf(s, grad, want_s, q_fin, W.nl.xw, in->mol_idx, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt,
                           cap_lr, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));
+  if (d3) {  // external DFT-D3: adds to the per-atom pair energies, dE/dx and the virial seeded by the Coulomb kernels
+    D3Params dp;
+    dp.s6 = opt->d3_s6; dp.s8 = opt->d3_s8; dp.a1 = opt->d3_a1; dp.a2 = opt->d3_a2;
+    dp.r_on = opt->d3_smoothing_on * 1.8897261258369282f;
+    dp.r_off = opt->d3_cutoff * 1.8897261258369282f;
+    RC(launch_dftd3(s, grad, want_s, W.nl.xw, in->mol_idx, in->cell, n_cell, W.aslot, W.d3_idx, W.d3_shift, W.d3_cnt, cap_d3,
+                    e->d3, dp, opt->d3_cutoff, N, W.d3w, W.dEdcn, W.ecoul, W.fgrad, W.virial_atom));
+  }
   RC(prof_mark(e, s, FAM_POINTWISE));
   RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, W.S, W.part, out->energy));
   RC(launch_copy_f32(s, q_fin, out->charges, (size_t)N));

@@ -100,6 +100,7 @@ class HipEngine:
         self.max_nb = _round16(int(0.2 * 4.0 / 3.0 * math.pi * spec.rc**3))
         self._max_nb_lr: dict[float, int] = {}
         self.last_status: np.ndarray | None = None
+        self.has_dftd3 = False
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -111,6 +112,19 @@ class HipEngine:
             self._h = None
 
     # ------------------------------------------------------------------------------------------
+    def set_dftd3_tables(self, tables: dict[str, Any]) -> None:
+        """Upload the DFT-D3 reference tables (what DFTD3.__init__ reads from aimnet/dftd3_data.pt, lr.py:1405-1423):
+        `c6ab`, `cn_ref` [Z,Z,5,5] and `rcov`, `r4r2` [Z] (see loader.load_dftd3_tables)."""
+        arrs = {k: np.ascontiguousarray(np.asarray(tables[k]), dtype=np.float32) for k in ("c6ab", "cn_ref", "rcov", "r4r2")}
+        nz = arrs["rcov"].shape[0]
+        if arrs["c6ab"].shape != (nz, nz, 5, 5) or arrs["cn_ref"].shape != (nz, nz, 5, 5) or arrs["r4r2"].shape != (nz,):
+            raise ValueError("DFT-D3 tables must be c6ab/cn_ref [Z,Z,5,5] and rcov/r4r2 [Z]")
+        t = _lib.DftD3Tables()
+        t.n_z = nz
+        t.c6ab, t.cn_ref, t.rcov, t.r4r2 = (arrs[k].ctypes.data for k in ("c6ab", "cn_ref", "rcov", "r4r2"))
+        _lib.check(self.lib.aimnet_engine_set_dftd3(self._h, C.byref(t)), "aimnet_engine_set_dftd3")
+        self.has_dftd3 = True
+
     def _lr_capacity(self, rc: float) -> int:
         if rc not in self._max_nb_lr:
             self._max_nb_lr[rc] = _round16(int(0.2 * 4.0 / 3.0 * math.pi * rc**3))
@@ -130,10 +144,12 @@ class HipEngine:
         dsf_rc: float = 15.0,
         dsf_alpha: float = 0.2,
         sync: bool = True,
+        dftd3: dict[str, float] | None = None,
     ) -> dict[str, Any]:
         """One evaluation on device tensors (coord f32 [N,3], numbers/mol_idx i32 [N], charge f32
         [n_mol], cell f32 [3,3]|[n_mol,3,3]).  Returns device tensors; retries with x1.5 row
-        capacity on neighbour overflow (neighbors.py:127-130)."""
+        capacity on neighbour overflow (neighbors.py:127-130).  `dftd3` = {s8, a1, a2[, s6, cutoff, smoothing_fraction]}
+        adds the external DFT-D3(BJ) term (needs set_dftd3_tables)."""
         import torch
 
         dev = self.device
@@ -161,6 +177,16 @@ class HipEngine:
             opt.max_nb = self.max_nb
             # periodic DSF walks the cell grid (no list); only non-periodic DSF materialises a long-range list
             opt.max_nb_lr = self._lr_capacity(float(dsf_rc)) if (method == _lib.COULOMB_DSF and cell is None) else 0
+            if dftd3 is not None:
+                if not self.has_dftd3:
+                    raise RuntimeError("dftd3 requested but no DFT-D3 tables were uploaded (HipEngine.set_dftd3_tables)")
+                d3_rc = float(dftd3.get("cutoff", 15.0))
+                opt.dftd3 = 1
+                opt.d3_s6, opt.d3_s8 = float(dftd3.get("s6", 1.0)), float(dftd3["s8"])
+                opt.d3_a1, opt.d3_a2 = float(dftd3["a1"]), float(dftd3["a2"])
+                opt.d3_cutoff = d3_rc
+                opt.d3_smoothing_on = d3_rc * (1.0 - float(dftd3.get("smoothing_fraction", 0.2)))
+                opt.max_nb_d3 = self._lr_capacity(d3_rc)
             need = int(self.lib.aimnet_engine_workspace_bytes(self._h, n, n_mol, n_cell, C.byref(opt)))
             if self._ws is None or self._ws.numel() < need:
                 self._ws = None
@@ -191,6 +217,10 @@ class HipEngine:
                 retry = True
             if st[3]:
                 self._max_nb_lr[float(dsf_rc)] = _round16(int(max(opt.max_nb_lr * 1.5, st[1])))
+                retry = True
+            if st[5]:  # D3 list (it may be stored in the LR buffers: grow both capacities)
+                d3_rc = float(dftd3.get("cutoff", 15.0))
+                self._max_nb_lr[d3_rc] = _round16(int(max(max(opt.max_nb_d3, opt.max_nb_lr) * 1.5, st[4])))
                 retry = True
             if not retry:
                 break

@@ -398,6 +398,51 @@ def load_model(path: str, *, model_import_paths: Collection[str] | None = None, 
     return spec, spec.metadata
 
 
+def load_dftd3_tables(source: Any = None) -> dict[str, np.ndarray]:
+    """DFT-D3 reference tables as {c6ab, cn_ref: f32[Z,Z,5,5], rcov, r4r2: f32[Z]} - the data the reference reads from
+    aimnet/dftd3_data.pt in DFTD3.__init__ (lr.py:1405-1423; packed legacy layout c6ab[...,3] handled as in
+    DFTD3._load_from_state_dict, lr.py:1441-1468).  `source`: a mapping, a path to .npz / .pt, or None = the file named
+    by $AIMNET_DFTD3_DATA, else `dftd3_data.pt` of an installed `aimnet` package.  The tables are data of the D3 method;
+    this package does not ship a copy."""
+    import importlib.util
+    import os
+
+    if source is None:
+        source = os.environ.get("AIMNET_DFTD3_DATA")
+    if source is None:
+        spec = importlib.util.find_spec("aimnet")
+        if spec is not None and spec.submodule_search_locations:
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "dftd3_data.pt")
+            if os.path.exists(cand):
+                source = cand
+    if source is None:
+        raise FileNotFoundError("DFT-D3 reference tables not found: pass dftd3_data=..., set AIMNET_DFTD3_DATA to a "
+                                "dftd3_data.pt / .npz file, or install the `aimnet` package that ships it")
+    if isinstance(source, (str, os.PathLike)):
+        path = os.fspath(source)
+        if path.endswith(".npz"):
+            with np.load(path) as z:
+                raw = {k: z[k] for k in z.files}
+        else:
+            import torch
+
+            raw = {k: (v.numpy() if hasattr(v, "numpy") else np.asarray(v)) for k, v in torch.load(path, map_location="cpu", weights_only=True).items()}
+    else:
+        raw = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in dict(source).items()}
+    c6ab = np.asarray(raw["c6ab"], dtype=np.float32)
+    if c6ab.ndim == 5:
+        cn_ref = c6ab[..., 1]
+        c6ab = c6ab[..., 0]
+    else:
+        cn_ref = np.asarray(raw["cn_ref"], dtype=np.float32)
+    out = {"c6ab": np.ascontiguousarray(c6ab), "cn_ref": np.ascontiguousarray(cn_ref, dtype=np.float32),
+           "rcov": np.ascontiguousarray(raw["rcov"], dtype=np.float32), "r4r2": np.ascontiguousarray(raw["r4r2"], dtype=np.float32)}
+    nz = out["rcov"].shape[0]
+    if out["c6ab"].shape != (nz, nz, 5, 5) or out["cn_ref"].shape != (nz, nz, 5, 5) or out["r4r2"].shape != (nz,):
+        raise ValueError("malformed DFT-D3 tables: expected c6ab/cn_ref [Z,Z,5,5] and rcov/r4r2 [Z]")
+    return out
+
+
 def synthetic_spec(seed: int = 0) -> ModelSpec:
     """ModelSpec of the deterministic synthetic aimnet2 artifact (aimnetcentral_amd/synth.py)."""
     from . import synth

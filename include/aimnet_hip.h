@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AIMNET_ABI_VERSION 1
+#define AIMNET_ABI_VERSION 2
 
 #define AIMNET_OK 0
 #define AIMNET_E_INVALID (-1)   /* bad argument / unsupported architecture */
@@ -105,6 +105,13 @@ typedef struct aimnet_eval_options {
   float dsf_alpha;         /* 0.2 */
   int32_t max_nb;          /* row capacity of the short-range (rc) neighbour matrix */
   int32_t max_nb_lr;       /* row capacity of the DSF neighbour matrix (0 if unused) */
+  /* external DFT-D3(BJ) two-body dispersion, DFTD3 of aimnet/modules/lr.py:1335-1820 as wired by
+   * calculator.py:234-247,999-1032; needs aimnet_engine_set_dftd3 first.  0 = off. */
+  int32_t dftd3;
+  float d3_s6, d3_s8, d3_a1, d3_a2;
+  float d3_cutoff;         /* Angstrom: list cutoff = end of the S5 switch (smoothing_off, 15.0) */
+  float d3_smoothing_on;   /* Angstrom: start of the S5 switch (cutoff * (1 - smoothing_fraction), 12.0) */
+  int32_t max_nb_d3;       /* row capacity of the D3 neighbour matrix */
 } aimnet_eval_options;
 
 typedef struct aimnet_outputs {
@@ -113,7 +120,8 @@ typedef struct aimnet_outputs {
   float* forces;    /* [n_atoms, 3] or NULL */
   float* stress;    /* [max(n_cell,1), 3, 3] or NULL */
   int32_t* status;  /* [8]: 0 max neighbours found (rc list), 1 same for the LR list,
-                              2 overflow flag rc list, 3 overflow flag LR list, 4.. reserved */
+                              2 overflow flag rc list, 3 overflow flag LR list,
+                              4 max neighbours found (D3 list), 5 overflow flag D3 list, 6.. reserved */
 } aimnet_outputs;
 
 int aimnet_abi_version(void);
@@ -121,6 +129,19 @@ int aimnet_abi_version(void);
 int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int device, aimnet_engine** out);
 void aimnet_engine_destroy(aimnet_engine* e);
 const char* aimnet_last_error(void);
+
+/* Reference tables of DFT-D3 (the reference loads aimnet/dftd3_data.pt in DFTD3.__init__, lr.py:1405-1423): HOST
+ * pointers, indexed by atomic number 0 .. n_z-1; c6ab and cn_ref are [n_z][n_z][5][5], rcov and r4r2 [n_z].  Copied
+ * (re-indexed by the model's species) at the call; AIMNET_E_INVALID if the CN table does not have the product
+ * structure every published D3 table has (cn_ref[zi][zj][a][b] independent of zj and b). */
+typedef struct aimnet_dftd3_tables {
+  int32_t n_z;
+  const float* c6ab;
+  const float* cn_ref;
+  const float* rcov;
+  const float* r4r2;
+} aimnet_dftd3_tables;
+int aimnet_engine_set_dftd3(aimnet_engine* e, const aimnet_dftd3_tables* t);
 
 /* Bytes of scratch `aimnet_engine_eval` needs for the given problem size. */
 size_t aimnet_engine_workspace_bytes(const aimnet_engine* e, int32_t n_atoms, int32_t n_mol, int32_t n_cell,

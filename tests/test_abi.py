@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/aimnet_hip.h but not exported"
     assert set(declared) == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.aimnet_abi_version() == 1
+    assert lib.aimnet_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
@@ -35,7 +35,8 @@ def test_struct_layouts_match_header():
 
     from aimnetcentral_amd import _lib
 
-    assert C.sizeof(_lib.EvalOptions) == 24
+    assert C.sizeof(_lib.EvalOptions) == 24 + 8 * 4   # + dftd3, s6, s8, a1, a2, cutoff, smoothing_on, max_nb_d3
+    assert C.sizeof(_lib.DftD3Tables) == 8 + 4 * 8
     assert C.sizeof(_lib.Inputs) == 8 + 5 * 8 + 4 + 12
     assert C.sizeof(_lib.Outputs) == 5 * 8
     n_arch = 4 + 4 + 4 * 7 + 4 + 1 + 7 + 2 + 32 + 3
@@ -51,6 +52,7 @@ def test_invalid_arguments_are_error_codes_not_crashes():
     assert lib.aimnet_neighbor_list_workspace_bytes(0, 1, 16) == 0
     assert lib.aimnet_neighbor_list_workspace_bytes(100, 1, 16) > 0
     assert lib.aimnet_engine_set_profiling(None, 1) == _lib.E_INVALID
+    assert lib.aimnet_engine_set_dftd3(None, None) == _lib.E_INVALID
 
 
 def test_engine_refuses_to_run_without_gpu():

@@ -188,3 +188,33 @@ def test_config4_hessian_and_hvp_by_finite_differences(calc):
     assert np.abs(hv4 - g["hv4"]).max() <= 2e-3 + 2e-4 * np.abs(g["hv4"]).max(), np.abs(hv4 - g["hv4"]).max()
     # translation invariance of the energy: every row of H sums to zero over the atoms (size-independent property)
     assert np.abs(H.reshape(40, 3, 40, 3).sum(axis=2)).max() < 1e-2
+
+
+def test_calculator_with_external_dftd3(oracle_d3):
+    """needs_dispersion=True end to end: AIMNet2Calculator builds the external DFT-D3 state from the artifact's
+    d3_params and the table file, and the result equals the oracle's evaluation with the same term."""
+    from aimnetcentral_amd import AIMNet2Calculator, loader
+    from oracle import aimnet2_oracle as O
+
+    om, par, tables = oracle_d3
+    spec = loader.synthetic_spec(0)
+    spec.metadata = dict(spec.metadata, needs_dispersion=True, d3_params={k: par[k] for k in ("s6", "s8", "a1", "a2")})
+    calc = AIMNet2Calculator(spec, device="cuda:0", dftd3_data=tables)
+    assert calc.has_external_dftd3 and calc.cutoff_lr == float("inf") and calc.dftd3_cutoff == 15.0
+    g = golden("taxol")
+    out = npy(calc({"coord": g["coord"], "numbers": g["numbers"], "charge": 0.0}, forces=True))
+    ref = O.evaluate(om, g["coord"], g["numbers"], 0.0, dftd3=dict(par, **tables))
+    assert abs(out["energy"][0] - ref["energy"][0]) <= energy_tol(113)
+    assert_forces_close(out["forces"], ref["forces"], "taxol + d3")
+    base = npy(AIMNet2Calculator(loader.synthetic_spec(0), device="cuda:0")({"coord": g["coord"], "numbers": g["numbers"], "charge": 0.0}))
+    assert abs((out["energy"][0] - base["energy"][0]) - golden("dftd3")["taxol_energy"][0]) < 6e-6
+
+
+@pytest.fixture(scope="module")
+def oracle_d3():
+    from aimnetcentral_amd import synth
+    from oracle import aimnet2_oracle as O
+
+    g, t = golden("dftd3"), golden("dftd3_subset")
+    par = dict(s6=float(g["s6"]), s8=float(g["s8"]), a1=float(g["a1"]), a2=float(g["a2"]), cutoff=15.0, smoothing_fraction=0.2)
+    return O.OracleModel(synth.synthetic_state_dict(0), torch.float32), par, {k: t[k] for k in ("c6ab", "cn_ref", "rcov", "r4r2")}

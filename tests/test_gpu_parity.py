@@ -123,3 +123,69 @@ def test_neighbor_overflow_grows_and_retries(hip_engine):
         compare(res, g, 113, "after overflow retry")
     finally:
         hip_engine.max_nb = max(old, hip_engine.max_nb)
+
+
+# ---- external DFT-D3(BJ) (reference DFTD3, lr.py:1335-1820) ----------------------------------
+def _d3(cutoff=15.0, frac=0.2):
+    g, t = golden("dftd3"), golden("dftd3_subset")
+    par = dict(s6=float(g["s6"]), s8=float(g["s8"]), a1=float(g["a1"]), a2=float(g["a2"]), cutoff=cutoff, smoothing_fraction=frac)
+    return par, {k: t[k] for k in ("c6ab", "cn_ref", "rcov", "r4r2")}
+
+
+def _run_d3(eng, coord, numbers, mol, coulomb, par, cell=None, stress=False, **kw):
+    dev = eng.device
+    n_mol = int(mol.max()) + 1
+    args = (torch.from_numpy(coord).to(dev), torch.from_numpy(numbers).to(dev), torch.from_numpy(mol).to(dev),
+            torch.zeros(n_mol, device=dev))
+    c = None if cell is None else torch.from_numpy(cell).to(dev)
+    a = eng.eval(*args, cell=c, forces=True, stress=stress, coulomb=coulomb, dftd3=par, **kw)
+    b = eng.eval(*args, cell=c, forces=True, stress=stress, coulomb=coulomb, **kw)
+    return {k: v.cpu().numpy() for k, v in a.items()}, {k: v.cpu().numpy() for k, v in b.items()}
+
+
+def test_dftd3_term_matches_reference_twin(hip_engine):
+    """The D3 contribution alone (evaluation with minus without; the network part is bitwise identical in both)
+    against the reference module's torch twin: |dE| <= 6e-6 eV on |E_disp| ~ 7 eV, |dF| <= 5e-6 eV/A."""
+    g = golden("dftd3")
+    par, tables = _d3()
+    hip_engine.set_dftd3_tables(tables)
+    z1 = np.zeros(113, dtype=np.int64)
+    for tag, p in (("taxol", par), ("taxol_rc9", _d3(9.0, 0.25)[0])):
+        a, b = _run_d3(hip_engine, g["taxol_coord"], g["taxol_numbers"], z1, "simple", p)
+        assert abs((a["energy"] - b["energy"])[0] - g[tag + "_energy"][0]) < 6e-6, tag
+        assert np.abs((a["forces"] - b["forces"]) - g[tag + "_forces"]).max() < 5e-6, tag
+        assert np.array_equal(a["charges"], b["charges"])
+    a, b = _run_d3(hip_engine, g["batch_coord"], g["batch_numbers"], g["batch_mol_idx"], "simple", par)
+    assert np.abs((a["energy"] - b["energy"]) - g["batch_energy"]).max() < 6e-6
+    assert np.abs((a["forces"] - b["forces"]) - g["batch_forces"]).max() < 5e-6
+    rc = float(g["pbc_cutoff"])
+    a, b = _run_d3(hip_engine, g["pbc_coord"], g["pbc_numbers"], np.zeros(96, dtype=np.int64), "dsf", _d3(rc)[0], cell=g["pbc_cell"],
+                   dsf_rc=rc)
+    assert abs((a["energy"] - b["energy"])[0] - g["pbc_energy"][0]) < 6e-6
+    assert np.abs((a["forces"] - b["forces"]) - g["pbc_forces"]).max() < 5e-6
+
+
+@pytest.mark.parametrize("rc_d3,rc_dsf", [(12.0, 12.0), (10.0, 13.0)])
+def test_dftd3_periodic_energy_forces_stress_vs_oracle(hip_engine, oracle32, rc_d3, rc_dsf):
+    """Full evaluation with dispersion on the periodic cell, shared (equal cutoffs) and separate D3 list, against the
+    oracle with the same term: the usual gates of this file, stress included."""
+    g = golden("dftd3")
+    par, tables = _d3(rc_d3)
+    hip_engine.set_dftd3_tables(tables)
+    mol = np.zeros(96, dtype=np.int64)
+    a, _ = _run_d3(hip_engine, g["pbc_coord"], g["pbc_numbers"], mol, "dsf", par, cell=g["pbc_cell"], stress=True, dsf_rc=rc_dsf)
+    ref = O.evaluate(oracle32, g["pbc_coord"], g["pbc_numbers"], np.zeros(1, np.float32), mol, cell=g["pbc_cell"], coulomb="dsf",
+                     dsf_rc=rc_dsf, stress=True, dftd3=dict(par, **tables))
+    compare(a, ref, 96, f"pbc96+d3 rc {rc_d3}/{rc_dsf}")
+
+
+def test_dftd3_nonperiodic_dsf_shares_the_list(hip_engine, oracle32):
+    """Non-periodic DSF and D3 with one cutoff use ONE neighbour matrix (engine.hip d3_shares_lr_list)."""
+    g = golden("dftd3")
+    par, tables = _d3(9.0, 0.25)
+    hip_engine.set_dftd3_tables(tables)
+    mol = g["batch_mol_idx"]
+    a, _ = _run_d3(hip_engine, g["batch_coord"], g["batch_numbers"], mol, "dsf", par, dsf_rc=9.0)
+    ref = O.evaluate(oracle32, g["batch_coord"], g["batch_numbers"], np.zeros(5, np.float32), mol, coulomb="dsf", dsf_rc=9.0,
+                     dftd3=dict(par, **tables))
+    compare(a, ref, np.bincount(mol), "batch5 dsf9 + d3")

@@ -84,16 +84,19 @@ __device__ __forceinline__ void d3_store(D3Acc& A, int i, int lane, float k, dou
 
 struct D3Pair {
   float ux, uy, uz, d;  // unit vector i -> j and distance in Angstrom
-  int j;
+  int j, sj;            // neighbour atom and its species slot
   bool ok;
 };
 
-__device__ __forceinline__ D3Pair d3_pair(const float* __restrict__ xw, const float* c, const int* __restrict__ nb_idx,
+// One 16-byte gather per neighbour: xs4[j] = (x, y, z, slot as int bits), packed by d3_pack_kernel.
+__device__ __forceinline__ D3Pair d3_pair(const float4* __restrict__ xs4, const float* c, const int* __restrict__ nb_idx,
                                           const int* __restrict__ nb_shift, size_t p, float xi, float yi, float zi,
                                           float cutoff) {
   D3Pair r;
   r.j = nb_idx[p];
-  float rx = xw[3 * r.j] - xi, ry = xw[3 * r.j + 1] - yi, rz = xw[3 * r.j + 2] - zi;
+  const float4 xj = xs4[r.j];
+  r.sj = __float_as_int(xj.w);
+  float rx = xj.x - xi, ry = xj.y - yi, rz = xj.z - zi;
   if (c) {
     int sx, sy, sz;
     unpack_shift(nb_shift[p], sx, sy, sz);
@@ -110,26 +113,32 @@ __device__ __forceinline__ D3Pair d3_pair(const float* __restrict__ xw, const fl
   return r;
 }
 
+__global__ void d3_pack_kernel(const float* __restrict__ xw, const int* __restrict__ aslot, int n_atoms, float4* __restrict__ xs4) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_atoms) xs4[i] = make_float4(xw[3 * i], xw[3 * i + 1], xw[3 * i + 2], __int_as_float(aslot[i]));
+}
+
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void d3_cn_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
+__global__ __launch_bounds__(256) void d3_cn_kernel(const float4* __restrict__ xs4, const int* __restrict__ mol_idx,
                                                    const float* __restrict__ cell, int n_cell,
-                                                   const int* __restrict__ aslot, const int* __restrict__ nb_idx,
+                                                   const int* __restrict__ nb_idx,
                                                    const int* __restrict__ nb_shift, const int* __restrict__ nb_cnt, int cap,
                                                    D3Tables T, float cutoff, int n_atoms, float* __restrict__ d3w) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
   const float* c = cell ? cell + (n_cell == 1 ? 0 : (size_t)mol_idx[i] * 9) : nullptr;
-  const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2];
-  const int si = aslot[i];
+  const float4 x4 = xs4[i];
+  const float xi = x4.x, yi = x4.y, zi = x4.z;
+  const int si = __float_as_int(x4.w);
   const float rci = T.rcov[si];
   const int cnt = nb_cnt[i];
   float cn = 0.0f;
   for (int m = lane; m < cnt; m += 64) {
-    const D3Pair P = d3_pair(xw, c, nb_idx, nb_shift, (size_t)i * cap + m, xi, yi, zi, cutoff);
+    const D3Pair P = d3_pair(xs4, c, nb_idx, nb_shift, (size_t)i * cap + m, xi, yi, zi, cutoff);
     if (!P.ok) continue;
     const float db = fmaxf(P.d * BOHR_INV_F, 1e-12f);
-    cn += 1.0f / (1.0f + expf(-16.0f * ((rci + T.rcov[aslot[P.j]]) / db - 1.0f)));
+    cn += 1.0f / (1.0f + expf(-16.0f * ((rci + T.rcov[P.sj]) / db - 1.0f)));
   }
   cn = wave_sum(cn);
   // the five reference-system exponents of atom i, shifted by their maximum (every lane computes all five)
@@ -155,9 +164,9 @@ __global__ __launch_bounds__(256) void d3_cn_kernel(const float* __restrict__ xw
 
 // ------------------------------------------------------------------------------------------------
 template <bool GRAD, bool STRESS>
-__global__ __launch_bounds__(256) void d3_pair_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
+__global__ __launch_bounds__(256) void d3_pair_kernel(const float4* __restrict__ xs4, const int* __restrict__ mol_idx,
                                                      const float* __restrict__ cell, int n_cell,
-                                                     const int* __restrict__ aslot, const int* __restrict__ nb_idx,
+                                                     const int* __restrict__ nb_idx,
                                                      const int* __restrict__ nb_shift, const int* __restrict__ nb_cnt, int cap,
                                                      D3Tables T, D3Params P3, float cutoff, int n_atoms,
                                                      const float* __restrict__ d3w, double* __restrict__ ecoul,
@@ -169,11 +178,12 @@ __global__ __launch_bounds__(256) void d3_pair_kernel(const float* __restrict__ 
   if (i >= n_atoms) return;
   const int ns = T.ns;
   float* c6s = c6lds + (size_t)wid * ns * 25;
-  const int si = aslot[i];
+  const float4 x4 = xs4[i];
+  const int si = __float_as_int(x4.w);
   for (int k = lane; k < ns * 25; k += 64) c6s[k] = T.c6slot[(size_t)si * ns * 25 + k];
   __builtin_amdgcn_wave_barrier();
   const float* c = cell ? cell + (n_cell == 1 ? 0 : (size_t)mol_idx[i] * 9) : nullptr;
-  const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2];
+  const float xi = x4.x, yi = x4.y, zi = x4.z;
   const int nref_i = T.nref[si];
   float s_i[5], w_i[5], g_i[5];
   const float cn_i = d3w[(size_t)i * D3W + 10];
@@ -188,9 +198,9 @@ __global__ __launch_bounds__(256) void d3_pair_kernel(const float* __restrict__ 
   D3Acc A;
   float dcn = 0.0f;
   for (int m = lane; m < cnt; m += 64) {
-    const D3Pair P = d3_pair(xw, c, nb_idx, nb_shift, (size_t)i * cap + m, xi, yi, zi, cutoff);
+    const D3Pair P = d3_pair(xs4, c, nb_idx, nb_shift, (size_t)i * cap + m, xi, yi, zi, cutoff);
     if (!P.ok) continue;
-    const int sj = aslot[P.j];
+    const int sj = P.sj;
     const float4 sj0 = *reinterpret_cast<const float4*>(d3w + (size_t)P.j * D3W);
     const float4 sj1 = *reinterpret_cast<const float4*>(d3w + (size_t)P.j * D3W + 4);
     const float2 sj2 = *reinterpret_cast<const float2*>(d3w + (size_t)P.j * D3W + 8);
@@ -249,9 +259,9 @@ __global__ __launch_bounds__(256) void d3_pair_kernel(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 template <bool STRESS>
-__global__ __launch_bounds__(256) void d3_cnforce_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
+__global__ __launch_bounds__(256) void d3_cnforce_kernel(const float4* __restrict__ xs4, const int* __restrict__ mol_idx,
                                                         const float* __restrict__ cell, int n_cell,
-                                                        const int* __restrict__ aslot, const int* __restrict__ nb_idx,
+                                                        const int* __restrict__ nb_idx,
                                                         const int* __restrict__ nb_shift, const int* __restrict__ nb_cnt,
                                                         int cap, D3Tables T, float cutoff, int n_atoms,
                                                         const float* __restrict__ dEdcn, double* __restrict__ ecoul,
@@ -260,16 +270,17 @@ __global__ __launch_bounds__(256) void d3_cnforce_kernel(const float* __restrict
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
   const float* c = cell ? cell + (n_cell == 1 ? 0 : (size_t)mol_idx[i] * 9) : nullptr;
-  const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2];
-  const float rci = T.rcov[aslot[i]];
+  const float4 x4 = xs4[i];
+  const float xi = x4.x, yi = x4.y, zi = x4.z;
+  const float rci = T.rcov[__float_as_int(x4.w)];
   const float gi = dEdcn[i];
   const int cnt = nb_cnt[i];
   D3Acc A;
   for (int m = lane; m < cnt; m += 64) {
-    const D3Pair P = d3_pair(xw, c, nb_idx, nb_shift, (size_t)i * cap + m, xi, yi, zi, cutoff);
+    const D3Pair P = d3_pair(xs4, c, nb_idx, nb_shift, (size_t)i * cap + m, xi, yi, zi, cutoff);
     if (!P.ok) continue;
     const float db = fmaxf(P.d * BOHR_INV_F, 1e-12f);
-    const float R = rci + T.rcov[aslot[P.j]];
+    const float R = rci + T.rcov[P.sj];
     const float sg = 1.0f / (1.0f + expf(-16.0f * (R / db - 1.0f)));
     const float dsg = sg * (1.0f - sg) * (-16.0f * R / (db * db)) * BOHR_INV_F;  // d sigma / d d_ij per Angstrom
     // sum_l dE/dcn_l cn_l as a pair "energy" with k = 1: per ordered pair 1/2 (g_i + g_j) sigma(d_ij)
@@ -281,15 +292,18 @@ __global__ __launch_bounds__(256) void d3_cnforce_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const int* mol_idx, const float* cell, int n_cell,
                  const int* aslot, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, D3Tables T, D3Params P,
-                 float cutoff, int n_atoms, float* d3w, float* dEdcn, double* ecoul, float* fgrad, float* virial_atom) {
+                 float cutoff, int n_atoms, float4* xs4, float* d3w, float* dEdcn, double* ecoul, float* fgrad,
+                 float* virial_atom) {
+  hipLaunchKernelGGL(d3_pack_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, xw, aslot, n_atoms, xs4);
+  AIMNET_LAUNCH_CHECK();
   dim3 grid(ceil_div(n_atoms, 4)), block(256);
-  hipLaunchKernelGGL(d3_cn_kernel, grid, block, 0, s, xw, mol_idx, cell, n_cell, aslot, nb_idx, nb_shift, nb_cnt, cap, T, cutoff,
-                     n_atoms, d3w);
+  hipLaunchKernelGGL(d3_cn_kernel, grid, block, 0, s, xs4, mol_idx, cell, n_cell, nb_idx, nb_shift, nb_cnt, cap, T, cutoff, n_atoms,
+                     d3w);
   AIMNET_LAUNCH_CHECK();
   const size_t lds = (size_t)4 * T.ns * 25 * sizeof(float);
-#define AIMNET_D3_PAIR(G_, S_)                                                                                              \
-  hipLaunchKernelGGL((d3_pair_kernel<G_, S_>), grid, block, lds, s, xw, mol_idx, cell, n_cell, aslot, nb_idx, nb_shift, nb_cnt, \
-                     cap, T, P, cutoff, n_atoms, d3w, ecoul, fgrad, virial_atom, dEdcn)
+#define AIMNET_D3_PAIR(G_, S_)                                                                                            \
+  hipLaunchKernelGGL((d3_pair_kernel<G_, S_>), grid, block, lds, s, xs4, mol_idx, cell, n_cell, nb_idx, nb_shift, nb_cnt, cap, T, \
+                     P, cutoff, n_atoms, d3w, ecoul, fgrad, virial_atom, dEdcn)
   if (grad && stress) AIMNET_D3_PAIR(true, true);
   else if (grad) AIMNET_D3_PAIR(true, false);
   else AIMNET_D3_PAIR(false, false);
@@ -297,11 +311,11 @@ int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const i
   AIMNET_LAUNCH_CHECK();
   if (grad) {
     if (stress)
-      hipLaunchKernelGGL(d3_cnforce_kernel<true>, grid, block, 0, s, xw, mol_idx, cell, n_cell, aslot, nb_idx, nb_shift, nb_cnt,
-                         cap, T, cutoff, n_atoms, dEdcn, ecoul, fgrad, virial_atom);
+      hipLaunchKernelGGL(d3_cnforce_kernel<true>, grid, block, 0, s, xs4, mol_idx, cell, n_cell, nb_idx, nb_shift, nb_cnt, cap, T,
+                         cutoff, n_atoms, dEdcn, ecoul, fgrad, virial_atom);
     else
-      hipLaunchKernelGGL(d3_cnforce_kernel<false>, grid, block, 0, s, xw, mol_idx, cell, n_cell, aslot, nb_idx, nb_shift, nb_cnt,
-                         cap, T, cutoff, n_atoms, dEdcn, ecoul, fgrad, virial_atom);
+      hipLaunchKernelGGL(d3_cnforce_kernel<false>, grid, block, 0, s, xs4, mol_idx, cell, n_cell, nb_idx, nb_shift, nb_cnt, cap, T,
+                         cutoff, n_atoms, dEdcn, ecoul, fgrad, virial_atom);
     AIMNET_LAUNCH_CHECK();
   }
   return 0;

@@ -163,6 +163,7 @@ struct Workspace {
   float *Sbar, *Sqbar;
   int *d3_idx, *d3_shift, *d3_cnt;   // DFT-D3 neighbour matrix (aliases the LR list when both use one cutoff)
   float *d3w, *dEdcn;                // per-atom D3 reference weights (12 floats) and dE/dCN
+  float4* d3xs;                      // (x, y, z, species slot) per atom: one 16 B gather per D3 neighbour
   int* aslot;                        // species slot of every atom (pass-0 moments, DFT-D3)
   unsigned long long* present_part;  // per-block masks of the slots present
   int n_part;
@@ -210,6 +211,7 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
     W.d3_cnt = share ? W.lr_cnt : c.take<int>(d3 ? n : 0, "d3_cnt", 1);
     W.d3w = c.take<float>(d3 ? n * 12 : 0);
     W.dEdcn = c.take<float>(d3 ? n : 0);
+    W.d3xs = c.take<float4>(d3 ? n : 0);
   }
   W.pg = c.take<float4>(n * cap, "pair_geom", cap);
   char name[32];
@@ -612,7 +614,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     dp.r_on = opt->d3_smoothing_on * 1.8897261258369282f;
     dp.r_off = opt->d3_cutoff * 1.8897261258369282f;
     RC(launch_dftd3(s, grad, want_s, W.nl.xw, in->mol_idx, in->cell, n_cell, W.aslot, W.d3_idx, W.d3_shift, W.d3_cnt, cap_d3,
-                    e->d3, dp, opt->d3_cutoff, N, W.d3w, W.dEdcn, W.ecoul, W.fgrad, W.virial_atom));
+                    e->d3, dp, opt->d3_cutoff, N, W.d3xs, W.d3w, W.dEdcn, W.ecoul, W.fgrad, W.virial_atom));
   }
   RC(prof_mark(e, s, FAM_POINTWISE));
   RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, W.S, W.part, out->energy));

@@ -88,7 +88,8 @@ struct D3Tables {  // device pointers, indexed by species SLOT (engine.hip: slot
 };
 int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const int* mol_idx, const float* cell, int n_cell,
                  const int* aslot, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, D3Tables T, D3Params P,
-                 float cutoff, int n_atoms, float* d3w, float* dEdcn, double* ecoul, float* fgrad, float* virial_atom);
+                 float cutoff, int n_atoms, float4* xs4, float* d3w, float* dEdcn, double* ecoul, float* fgrad,
+                 float* virial_atom);
 // stand-alone reference-op forms (conv_sv_2d_sp_wp.py:90-164)
 int launch_conv_sv_fwd(hipStream_t s, const float* a, const int* idx, const float* g, float* out, int B, int A, int G,
                        int M);

@@ -167,6 +167,28 @@ def test_config3_full_size_periodicity_properties(calc):
     assert abs(out["charges"].sum()) < 1e-3
 
 
+def test_maximum_size_80k_atoms_stays_periodic(calc):
+    """Eight times config 3 (80 640 atoms, 5.5 GB workspace): 64-bit indexing of the pair arrays, multi-round tile
+    grids and the cell walk at scale.  Same size-independent property: 840 images of the 96-atom golden cell."""
+    g = golden("pbc96_dsf15")
+    cell = g["cell"].astype(np.float64)
+    reps = (14, 6, 10)
+    ix, iy, iz = np.meshgrid(np.arange(reps[0]), np.arange(reps[1]), np.arange(reps[2]), indexing="ij")
+    off = ix.reshape(-1, 1) * cell[0] + iy.reshape(-1, 1) * cell[1] + iz.reshape(-1, 1) * cell[2]
+    coord = (g["coord"].astype(np.float64)[None] + off[:, None, :]).reshape(-1, 3).astype(np.float32)
+    n_img = off.shape[0]
+    numbers = np.tile(g["numbers"], n_img)
+    sc = (cell * np.array([[reps[0]], [reps[1]], [reps[2]]])).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = npy(calc({"coord": coord, "numbers": numbers, "charge": 0.0, "cell": sc}, forces=True, stress=True))
+    assert out["forces"].shape == (96 * n_img, 3) and np.isfinite(out["forces"]).all()
+    assert abs(out["energy"][0] / n_img - g["energy"][0]) < 1e-4
+    f = out["forces"].reshape(n_img, 96, 3)
+    assert_forces_close(f, np.broadcast_to(g["forces"], f.shape), "80k supercell images")
+    assert np.abs(out["stress"] - g["stress"]).max() < 2e-5
+
+
 def test_config4_hessian_and_hvp_by_finite_differences(calc):
     """BASELINE config 4 shape: dense Hessian and H @ v of a 40-atom geometry against the reference's double-backward
     results (tests/golden/hvp40.npz).  The engine's operator is a 4th-order central difference of its analytic fp32

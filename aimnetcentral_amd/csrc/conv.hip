@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
                                                       const float4* __restrict__ pg, int cap,
                                                       const float* __restrict__ agh_a, const float* __restrict__ agh_q,
                                                       BasisParams bp, float* __restrict__ x, int ldx,
-                                                      float* __restrict__ Vsave, float* __restrict__ Vqsave, int n_atoms) {
+                                                      float* __restrict__ Vsave, float* __restrict__ Vqsave, int n_atoms,
+                                                      const int* __restrict__ order) {
   __shared__ __attribute__((aligned(16))) FwdWaveLds wl[APB];
   __shared__ float s_agh[A_ * G_ * H_];
   __shared__ float s_aghq[G_ * H_];
@@ -153,14 +154,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
 
   const AtomLoop al = atom_loop(n_atoms, APB);
   for (int i0 = al.first; i0 < al.last; i0 += al.step) {
-    const int i = i0 + wid;
-    const bool live = i < al.last;
+    const bool live = i0 + wid < al.last;
+    const int i = live ? (order ? order[i0 + wid] : i0 + wid) : 0;  // `order`: spatially sorted processing order
     const int cnt = live ? nb_cnt[i] : 0;
     int cmax = cnt;  // block-uniform trip count so that __syncthreads() is legal
 #pragma unroll
     for (int w = 0; w < APB; ++w) {
       const int iw = i0 + w;
-      cmax = max(cmax, iw < al.last ? nb_cnt[iw] : 0);
+      cmax = max(cmax, iw < al.last ? nb_cnt[order ? order[iw] : iw] : 0);
     }
     f2 acc[4][2];  // [component c][shift pair]: 2-wide vectors -> v_pk_fma_f32
 #pragma unroll
@@ -293,14 +294,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
 
 int launch_conv_fwd(hipStream_t s, bool has_q, const float* a, const int* row_of, const float* q, const int* nb_idx,
                     const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
-                    float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms) {
+                    float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order) {
   const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
   if (has_q)
     hipLaunchKernelGGL(conv_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a,
-                       agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms);
+                       agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order);
   else
     hipLaunchKernelGGL(conv_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a,
-                       agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms);
+                       agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
                                                       const float* __restrict__ abar_in, float* __restrict__ abar_out,
                                                       const float* __restrict__ qbar_in, float* __restrict__ qbar_out,
                                                       float* __restrict__ fgrad, float* __restrict__ virial_atom,
-                                                      int n_atoms, int dbg) {
+                                                      int n_atoms, int dbg, const int* __restrict__ order) {
   __shared__ __attribute__((aligned(16))) BwdWaveLds wl[APB];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   BwdWaveLds& L = wl[wid];
@@ -444,14 +445,14 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
 
   const AtomLoop al = atom_loop(n_atoms, APB);
   for (int i0 = al.first; i0 < al.last; i0 += al.step) {
-    const int i = i0 + wid;
-    const bool live = i < al.last;
+    const bool live = i0 + wid < al.last;
+    const int i = live ? (order ? order[i0 + wid] : i0 + wid) : 0;
     const int cnt = live ? nb_cnt[i] : 0;
     int cmax = cnt;
 #pragma unroll
     for (int w = 0; w < APB; ++w) {
       const int iw = i0 + w;
-      cmax = max(cmax, iw < al.last ? nb_cnt[iw] : 0);
+      cmax = max(cmax, iw < al.last ? nb_cnt[order ? order[iw] : iw] : 0);
     }
     // centre atom's own rows
     // [half]: gi pair (0,1) / (2,3);  Si[c][half]: component c of the centre's Sbar row
@@ -632,12 +633,12 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
 int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, const float* a, const int* row_of,
                     const float* q, const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
                     int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
-                    const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms) {
+                    const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order) {
   const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
   static const int dbg = getenv("AIMNET_CONV_DBG") ? atoi(getenv("AIMNET_CONV_DBG")) : 0;  // ablation switch, tests only
 #define AIMNET_BWD(HQ, NA, ST)                                                                                        \
   hipLaunchKernelGGL((conv_bwd_kernel<HQ, NA, ST>), dim3(grid), dim3(256), 0, s, a, row_of, q, Sbar, Sqbar, nb_idx, nb_cnt, pg, \
-                     cap, bp, xbar, ldx, abar_in, abar_out, qbar_in, qbar_out, fgrad, virial_atom, n_atoms, dbg)
+                     cap, bp, xbar, ldx, abar_in, abar_out, qbar_in, qbar_out, fgrad, virial_atom, n_atoms, dbg, order)
   if (has_q) {
     if (need_abar) {
       if (stress) AIMNET_BWD(true, true, true); else AIMNET_BWD(true, true, false);
@@ -824,7 +825,8 @@ __global__ __launch_bounds__(256) void conv_bwd_p0_kernel(const float4* __restri
                                                          const int* __restrict__ aslot, const int* __restrict__ nb_idx,
                                                          const int* __restrict__ nb_cnt, const float4* __restrict__ pg,
                                                          int cap, BasisParams bp, float* __restrict__ fgrad,
-                                                         float* __restrict__ virial_atom, int n_atoms) {
+                                                         float* __restrict__ virial_atom, int n_atoms,
+                                                         const int* __restrict__ order) {
   __shared__ __attribute__((aligned(16))) P0WaveLds wl[APB];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   P0WaveLds& L = wl[wid];
@@ -832,8 +834,8 @@ __global__ __launch_bounds__(256) void conv_bwd_p0_kernel(const float4* __restri
   const float shift_g = bp.shifts[g];
   const AtomLoop al = atom_loop(n_atoms, APB);
   for (int i0 = al.first; i0 < al.last; i0 += al.step) {
-    const int i = i0 + wid;
-    if (i >= al.last) continue;  // no block barriers below: the LDS staging is private to the wave
+    if (i0 + wid >= al.last) continue;  // no block barriers below: the LDS staging is private to the wave
+    const int i = order ? order[i0 + wid] : i0 + wid;
     const int cnt = nb_cnt[i];
     const int si = aslot[i];
     const float4* Ti_base = T4 + (size_t)i * nslots * 16 + g;
@@ -907,14 +909,14 @@ __global__ __launch_bounds__(256) void conv_bwd_p0_kernel(const float4* __restri
 
 int launch_conv_bwd_p0(hipStream_t s, bool stress, const float* T, int nslots, const int* aslot, const int* nb_idx,
                        const int* nb_cnt, const float4* pg, int cap, BasisParams bp, float* fgrad, float* virial_atom,
-                       int n_atoms) {
+                       int n_atoms, const int* order) {
   const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
   if (stress)
     hipLaunchKernelGGL(conv_bwd_p0_kernel<true>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(T), nslots, aslot,
-                       nb_idx, nb_cnt, pg, cap, bp, fgrad, virial_atom, n_atoms);
+                       nb_idx, nb_cnt, pg, cap, bp, fgrad, virial_atom, n_atoms, order);
   else
     hipLaunchKernelGGL(conv_bwd_p0_kernel<false>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(T), nslots, aslot,
-                       nb_idx, nb_cnt, pg, cap, bp, fgrad, virial_atom, n_atoms);
+                       nb_idx, nb_cnt, pg, cap, bp, fgrad, virial_atom, n_atoms, order);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

@@ -55,6 +55,7 @@ struct aimnet_engine {
   std::vector<int> z_of_slot_h;  // host copy (slot -> atomic number)
   // DFT-D3 tables re-indexed by species slot (aimnet_engine_set_dftd3); d3.ns == 0 until set
   D3Tables d3{0, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool spatial_order = true;  // AIMNET_SPATIAL_ORDER=0: conv kernels walk the atoms in input order
   bool p0_moments = true;  // AIMNET_P0_MOMENTS=0 keeps the generic conv_bwd for pass 0 (A/B and parity runs)
   std::vector<Layer> mlp[AIMNET_MAX_PASS];
   std::vector<Layer> head;
@@ -309,6 +310,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if ((rc = dev_upload(e, zos, (size_t)ns, &e->z_of_slot))) goto fail;
     const char* env = getenv("AIMNET_P0_MOMENTS");
     if (env) e->p0_moments = atoi(env) != 0;
+    env = getenv("AIMNET_SPATIAL_ORDER");
+    if (env) e->spatial_order = atoi(env) != 0;
   }
   if ((rc = dev_upload(e, w->agh_a, (size_t)16 * 16 * 12, &e->agh_a))) goto fail;
   if ((rc = dev_upload(e, w->agh_q, (size_t)16 * 12, &e->agh_q))) goto fail;
@@ -548,6 +551,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   RC(launch_pair_geom(s, W.nl.xw, in->mol_idx, in->cell, n_cell, W.nb_idx, W.nb_shift, W.nb_cnt, cap, N, W.pg));
 
   // ---- forward --------------------------------------------------------------------------------
+  // periodic systems: process centre atoms in the bin-sorted order of the cell list (kernels.h, `order`)
+  const int* order = (pbc && e->spatial_order) ? W.nl.sorted : nullptr;
   RC(launch_embed(s, e->afv, in->numbers, N, W.a[0]));
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
   if (p0m || d3) RC(launch_species(s, in->numbers, e->slot_of_z, N, W.aslot, W.present_part));
@@ -556,7 +561,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const int nl = (int)Ls.size();
     RC(prof_mark(e, s, FAM_CONV_FWD));
     RC(launch_conv_fwd(s, p > 0, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr, p > 0 ? W.q[p - 1] : nullptr,
-                       W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q, e->bp, W.x[p], Ls[0].k_in, W.V[p], W.Vq[p], N));
+                       W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q, e->bp, W.x[p], Ls[0].k_in, W.V[p], W.Vq[p], N, order));
     const float* hin = W.x[p];
     int ld_in = Ls[0].k_in;
     RC(prof_mark(e, s, FAM_GEMM));
@@ -667,7 +672,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     if (p == 0 && p0m) {
       RC(launch_unconcat_p0(s, zcur, ld, W.V[0], e->agh_a, e->afv, e->z_of_slot, e->nslots, W.present_part, W.n_part, W.Sbar, N));
       RC(prof_mark(e, s, FAM_CONV_BWD));
-      RC(launch_conv_bwd_p0(s, want_s, W.Sbar, e->nslots, W.aslot, W.nb_idx, W.nb_cnt, W.pg, cap, e->bp, W.fgrad, W.virial_atom, N));
+      RC(launch_conv_bwd_p0(s, want_s, W.Sbar, e->nslots, W.aslot, W.nb_idx, W.nb_cnt, W.pg, cap, e->bp, W.fgrad, W.virial_atom, N,
+                            order));
       break;
     }
     RC(launch_unconcat(s, p > 0, zcur, ld, W.V[p], W.Vq[p], e->agh_a, e->agh_q, W.Sbar, W.Sqbar, N));
@@ -675,7 +681,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     RC(launch_conv_bwd(s, p > 0, p > 0, want_s, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr,
                        p > 0 ? W.q[p - 1] : nullptr, W.Sbar, W.Sqbar, W.nb_idx, W.nb_cnt,
                        W.pg, cap, e->bp, zcur, ld, (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, W.fgrad,
-                       W.virial_atom, N));
+                       W.virial_atom, N, order));
     if (p == 0) break;
     // NSE adjoint of pass p-1, then the adjoint of its MLP output
     const std::vector<Layer>& Lq = e->mlp[p - 1];

@@ -57,13 +57,16 @@ int launch_pair_geom(hipStream_t s, const float* xw, const int* mol_idx, const f
 int launch_embed(hipStream_t s, const float* afv, const int* numbers, int n_atoms, float* a0);
 int launch_conv_fwd(hipStream_t s, bool has_q, const float* a, const int* row_of, const float* q, const int* nb_idx,
                     const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
-                    float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms);
+                    float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order);
 int launch_unconcat(hipStream_t s, bool has_q, const float* xbar, int ldx, const float* Vsave, const float* Vqsave,
                     const float* agh_a, const float* agh_q, float* Sbar, float* Sqbar, int n_atoms);
 int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, const float* a, const int* row_of,
                     const float* q, const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
                     int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
-                    const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms);
+                    const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order);
+// `order` (conv_fwd / conv_bwd / conv_bwd_p0): optional permutation of the atoms giving the PROCESSING order - the
+// bin-sorted order of the cell list for periodic systems - so that an XCD's centres and the rows they gather stay
+// spatially coherent (and L2-resident) whatever the order of the input file; NULL = input order.
 // pass-0 backward through species moments (conv.hip)
 int launch_species(hipStream_t s, const int* numbers, const int* slot_of_z, int n_atoms, int* aslot,
                    unsigned long long* present_part);
@@ -72,7 +75,7 @@ int launch_unconcat_p0(hipStream_t s, const float* xbar, int ldx, const float* V
                        int n_atoms);
 int launch_conv_bwd_p0(hipStream_t s, bool stress, const float* T, int nslots, const int* aslot, const int* nb_idx,
                        const int* nb_cnt, const float4* pg, int cap, BasisParams bp, float* fgrad, float* virial_atom,
-                       int n_atoms);
+                       int n_atoms, const int* order);
 // ---- d3.hip: DFT-D3(BJ) two-body dispersion on a full neighbour list ------------------------------
 struct D3Params {
   float s6, s8, a1, a2;

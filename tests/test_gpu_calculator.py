@@ -240,3 +240,18 @@ def oracle_d3():
     g, t = golden("dftd3"), golden("dftd3_subset")
     par = dict(s6=float(g["s6"]), s8=float(g["s8"]), a1=float(g["a1"]), a2=float(g["a2"]), cutoff=15.0, smoothing_fraction=0.2)
     return O.OracleModel(synth.synthetic_state_dict(0), torch.float32), par, {k: t[k] for k in ("c6ab", "cn_ref", "rcov", "r4r2")}
+
+
+def test_atom_order_does_not_matter(calc):
+    """Permutation equivariance on a periodic system: the conv kernels process centres in the cell list's bin order
+    (engine.hip `order`), so a shuffled file must give the same energy / stress and the permuted forces / charges."""
+    g = golden("pbc96_dsf15")
+    perm = np.random.default_rng(5).permutation(96)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = npy(calc({"coord": g["coord"], "numbers": g["numbers"], "charge": 0.0, "cell": g["cell"]}, forces=True, stress=True))
+        b = npy(calc({"coord": g["coord"][perm], "numbers": g["numbers"][perm], "charge": 0.0, "cell": g["cell"]}, forces=True, stress=True))
+    assert abs(a["energy"][0] - b["energy"][0]) <= energy_tol(96)
+    assert_forces_close(b["forces"], a["forces"][perm], "shuffled")
+    assert np.abs(b["charges"] - a["charges"][perm]).max() < CHARGE_ATOL
+    assert np.abs(a["stress"] - b["stress"]).max() < 1e-5

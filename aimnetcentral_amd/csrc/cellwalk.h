@@ -10,6 +10,7 @@ struct NlistSystem {
   float c[9];    // cell row vectors
   float inv[9];  // inverse: frac = x . inv
   float h[3];    // perpendicular heights
+  float o[3];    // origin of the grid: 0 for periodic cells, the corner of the bounding box for non-periodic systems
   float lam;     // Gershgorin bound on lambda_max of the Gram matrix of the slab normals (1 = orthogonal cell)
   int per[3];
   int nb[3];     // bins per lattice axis (slabs of the fractional coordinate)
@@ -19,7 +20,7 @@ struct NlistSystem {
 
 __device__ __forceinline__ int bin_of(const NlistSystem& S, float x, float y, float z, int b[3]) {
   for (int k = 0; k < 3; ++k) {
-    const float f = x * S.inv[k] + y * S.inv[3 + k] + z * S.inv[6 + k];
+    const float f = (x - S.o[0]) * S.inv[k] + (y - S.o[1]) * S.inv[3 + k] + (z - S.o[2]) * S.inv[6 + k];
     b[k] = max(0, min(S.nb[k] - 1, (int)floorf(f * (float)S.nb[k])));
   }
   return S.bin_offset + (b[0] * S.nb[1] + b[1]) * S.nb[2] + b[2];

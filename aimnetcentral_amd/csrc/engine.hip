@@ -525,6 +525,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   AIMNET_HIP_CHECK(hipMemsetAsync(out->status, 0, 8 * sizeof(int), s));
   RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start));
   RC(launch_wrap(s, in->coord, in->mol_idx, N, n_mol, in->cell, n_cell, in->pbc, W.nl));
+  // large non-periodic molecules (>= 1500 atoms on average) get a bounding-box cell list instead of the O(n^2) scan
+  if (!pbc && (long)N >= 1500L * n_mol) RC(launch_bbox(s, n_mol, W.nl));
   RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, ar.rc, ar.rc, cap, N, 0, W.nl, W.nb_idx, W.nb_shift,
                   W.nb_cnt, out->status + 0, out->status + 2));
   if (coulomb == AIMNET_COULOMB_DSF && !pbc)  // periodic DSF needs no list: it walks the short-range cell grid
@@ -551,8 +553,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   RC(launch_pair_geom(s, W.nl.xw, in->mol_idx, in->cell, n_cell, W.nb_idx, W.nb_shift, W.nb_cnt, cap, N, W.pg));
 
   // ---- forward --------------------------------------------------------------------------------
-  // periodic systems: process centre atoms in the bin-sorted order of the cell list (kernels.h, `order`)
-  const int* order = (pbc && e->spatial_order) ? W.nl.sorted : nullptr;
+  // binned systems: process centre atoms in the bin-sorted order of the cell list (kernels.h, `order`)
+  const int* order = (W.nl.binned && e->spatial_order) ? W.nl.sorted : nullptr;
   RC(launch_embed(s, e->afv, in->numbers, N, W.a[0]));
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
   if (p0m || d3) RC(launch_species(s, in->numbers, e->slot_of_z, N, W.aslot, W.present_part));
@@ -745,6 +747,7 @@ int aimnet_neighbor_list(const float* coord, const int32_t* mol_idx, int32_t n_a
   AIMNET_HIP_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(int), s));
   RC(launch_mol_start(s, mol_idx, n_atoms, n_mol, nl.mol_start));
   RC(launch_wrap(s, coord, mol_idx, n_atoms, n_mol, cell, cell ? n_cell : 0, pb, nl));
+  if (!cell && (long)n_atoms >= 1500L * n_mol) RC(launch_bbox(s, n_mol, nl));
   RC(launch_nlist(s, n_atoms, n_mol, mol_idx, cell, cell ? n_cell : 0, pb, cutoff, cutoff, max_nb, fill_value, 1, nl, nbmat,
                   codes, num_nb, status + 0, status + 1));
   if (cell) {

@@ -31,6 +31,7 @@ struct NlistBuffers {      // all device pointers, carved from the caller's work
   int* sorted;             // [n_atoms]
   float4* xs;              // [n_atoms] bin-ordered (x, y, z, atom id)
   void* sorted_tmp_xq;     // [n_atoms] float4 bin-ordered (x, y, z, charge) for the list-free DSF walk
+  bool binned = false;     // host flag: `sys` + bins describe this batch (periodic cells, or bounding boxes via launch_bbox)
 };
 size_t nlist_scratch_bytes(int n_atoms, int n_mol);
 size_t nlist_xw_offset(int n_mol);  // byte offset of NlistBuffers::xw inside the scratch
@@ -39,6 +40,9 @@ int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, 
 // wrap coordinates (periodic) or copy them (non-periodic) into b.xw
 int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
                 int n_cell, const int pbc[3], NlistBuffers& b);
+// non-periodic systems: give every molecule the cell grid of its bounding box (after launch_wrap), so that launch_nlist
+// takes the cell-list path instead of the O(n^2) per-molecule scan; worth it from ~10^3 atoms per molecule
+int launch_bbox(hipStream_t s, int n_mol, NlistBuffers& b);
 // build one full neighbour matrix for `cutoff` from b.xw; rows real-first; entries beyond the row
 // count are set to `fill_value` when fill_rows != 0; status[0] = max count (atomicMax), status[1] = overflow
 // bin_width > 0: (re)bin the periodic systems into slabs >= bin_width thick first; <= 0: reuse the last bins

@@ -116,9 +116,56 @@ __global__ void cell_setup_kernel(const float* __restrict__ cell, int n_cell, in
     lam = fmax(lam, 1.0 + off);
   }
   S.lam = (float)(lam * 1.0001);
+  S.o[0] = S.o[1] = S.o[2] = 0.0f;
   S.per[0] = p0;
   S.per[1] = p1;
   S.per[2] = p2;
+  S.bin_offset = 0;
+  S.n_bins = 1;
+  sys[s] = S;
+}
+
+// Non-periodic systems large enough for a cell list: the "cell" is the axis-aligned bounding box of the molecule
+// (no periodic axis, origin at its corner), so that the bin / walk machinery of the periodic path serves them too.
+__global__ __launch_bounds__(256) void bbox_setup_kernel(const float* __restrict__ coord, const int* __restrict__ mol_start,
+                                                        NlistSystem* __restrict__ sys) {
+  const int s = blockIdx.x;
+  const int j0 = mol_start[s], j1 = mol_start[s + 1];
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int j = j0 + threadIdx.x; j < j1; j += 256)
+    for (int k = 0; k < 3; ++k) {
+      const float v = coord[3 * j + k];
+      lo[k] = fminf(lo[k], v);
+      hi[k] = fmaxf(hi[k], v);
+    }
+  __shared__ float s_lo[4][3], s_hi[4][3];
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+      hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      s_lo[threadIdx.x >> 6][k] = lo[k];
+      s_hi[threadIdx.x >> 6][k] = hi[k];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  NlistSystem S;
+  for (int k = 0; k < 9; ++k) S.c[k] = S.inv[k] = 0.0f;
+  for (int k = 0; k < 3; ++k) {
+    const float a = fminf(fminf(s_lo[0][k], s_lo[1][k]), fminf(s_lo[2][k], s_lo[3][k]));
+    const float b = fmaxf(fmaxf(s_hi[0][k], s_hi[1][k]), fmaxf(s_hi[2][k], s_hi[3][k]));
+    const float L = (j1 > j0 ? b - a : 0.0f) + 0.02f;  // 0.01 A of margin on either side
+    S.o[k] = (j1 > j0 ? a : 0.0f) - 0.01f;
+    S.c[4 * k] = L;
+    S.inv[4 * k] = 1.0f / L;
+    S.h[k] = L;
+    S.per[k] = 0;
+    S.nb[k] = 1;
+  }
+  S.lam = 1.0001f;
   S.bin_offset = 0;
   S.n_bins = 1;
   sys[s] = S;
@@ -158,6 +205,14 @@ int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_ato
   }
   hipLaunchKernelGGL(wrap_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, coord, mol_idx, n_atoms, sys, b.xw);
   AIMNET_LAUNCH_CHECK();
+  b.binned = cell != nullptr;
+  return 0;
+}
+
+int launch_bbox(hipStream_t s, int n_mol, NlistBuffers& b) {
+  hipLaunchKernelGGL(bbox_setup_kernel, dim3(n_mol), dim3(256), 0, s, b.xw, b.mol_start, (NlistSystem*)b.sys);
+  AIMNET_LAUNCH_CHECK();
+  b.binned = true;
   return 0;
 }
 
@@ -360,7 +415,8 @@ int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, cons
                  NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf) {
   (void)n_cell;
   (void)pbc;
-  if (cell == nullptr) {
+  (void)cell;
+  if (!b.binned) {
     hipLaunchKernelGGL(nlist_brute_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, b.mol_start, n_atoms,
                        cutoff * cutoff, cap, fill_value, fill_rows, nb_idx, nb_cnt, status_max, status_ovf);
     AIMNET_LAUNCH_CHECK();

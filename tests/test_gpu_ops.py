@@ -196,3 +196,20 @@ def test_gemm_tiles_match_fp64(cfg, M, N, K):
         else:
             want = z * D0.double()
         assert (Cm.double() - want).abs().max().item() < 5e-5, (cfg, epi)
+
+
+def test_neighbor_list_large_nonperiodic_uses_bounding_box_cells():
+    """>= 1500 atoms per non-periodic molecule switches the builder from the O(n^2) scan to a cell list over the
+    molecule's bounding box (nlist.hip bbox_setup_kernel): same neighbour SETS as a brute-force numpy search."""
+    c, z, cell = workloads.glucose_supercell((3, 2, 3))   # 1728 atoms, coordinates both sides of the origin after the shift
+    c = (c - c.mean(0)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    nb, num, _, _, status = E.neighbor_list(torch.from_numpy(c).to(dev), 5.0, max_nb=128)
+    nb, num = nb.cpu().numpy(), num.cpu().numpy()
+    assert int(status[1]) == 0
+    d = np.linalg.norm(c[:, None, :] - c[None, :, :], axis=-1)
+    np.fill_diagonal(d, 99.0)
+    for i in range(0, len(c), 37):
+        want = set(np.nonzero(d[i] < 5.0)[0].tolist())
+        assert set(nb[i, : num[i]].tolist()) == want
+    assert num.max() < 128 and (num == (d < 5.0).sum(1)).all()

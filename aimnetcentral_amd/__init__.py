@@ -8,7 +8,7 @@ and fails loudly (HipLibraryError) when it is missing - there is no CPU or PyTor
 """
 from ._lib import HipLibraryError
 
-__all__ = ["AIMNet2Calculator", "AIMNet2ASE", "HipEngine", "HipLibraryError", "load_model"]
+__all__ = ["AIMNet2Calculator", "AIMNet2ASE", "AIMNet2TorchSim", "HipEngine", "HipLibraryError", "load_model"]
 
 
 def __getattr__(name):
@@ -20,6 +20,10 @@ def __getattr__(name):
         from .aimnet2ase import AIMNet2ASE
 
         return AIMNet2ASE
+    if name == "AIMNet2TorchSim":
+        from .aimnet2torchsim import AIMNet2TorchSim
+
+        return AIMNet2TorchSim
     if name == "HipEngine":
         from .engine import HipEngine
 

@@ -295,3 +295,38 @@ def test_hessian_batched_inputs_follow_the_reference_contract(qcalc):
         qcalc.hessian_vector_product(WATER, torch.zeros(3, 3), create_graph=True)
     with pytest.raises(ValueError, match="vectors must have shape"):
         qcalc.hessian_vector_product(WATER, torch.zeros(4, 3))
+
+
+# ---- TorchSim adapter (aimnet2torchsim.py:41-175 of the reference) with a duck-typed SimState ---------------------
+class _State:
+    def __init__(self, positions, numbers, system_idx, cell, pbc, n_systems, **extras):
+        self.positions, self.atomic_numbers, self.system_idx = positions, numbers, system_idx
+        self.row_vector_cell, self.pbc, self.n_systems = cell, pbc, n_systems
+        self.device, self.dtype = torch.device("cpu"), torch.float32
+        for k, v in extras.items():
+            setattr(self, k, v)
+
+
+def test_torchsim_adapter_maps_a_flat_multi_system_state(calc):
+    from aimnetcentral_amd import AIMNet2TorchSim
+
+    c, z, mol, q = workloads.random_batch(3, 4, 7, seed=1)
+    st = _State(torch.from_numpy(c), torch.from_numpy(z), torch.from_numpy(mol), torch.zeros(3, 3, 3), False, 3, charge=torch.tensor([0.0, 1.0, -1.0]))
+    model = AIMNet2TorchSim(calc, compute_forces=True)
+    model._device = torch.device("cpu")
+    assert model.implemented_properties == ["energy", "forces", "charges", "partial_charges"]
+    out = model(st)
+    call = calc.engine.calls[-1]
+    assert call["n"] == len(z) and call["n_mol"] == 3 and call["cell"] is None and torch.equal(call["mol_idx"].long(), torch.from_numpy(mol))
+    assert set(out) == {"energy", "charges", "forces", "partial_charges"} and torch.equal(out["partial_charges"], out["charges"])
+    model.compute_forces, model.compute_stress = False, True
+    assert model.implemented_properties == ["energy", "stress", "charges", "partial_charges"]
+    with pytest.raises(ValueError, match="periodic TorchSim state"):
+        model(st)
+    cell = torch.eye(3).repeat(3, 1, 1) * 14.0
+    stp = _State(torch.from_numpy(c), torch.from_numpy(z), torch.from_numpy(mol), cell, True, 3)
+    with pytest.warns(UserWarning, match="Switching to DSF"):
+        out = model(stp)
+    assert calc.engine.calls[-1]["cell"] == (3, 3, 3) and "stress" in out and "forces" not in out
+    with pytest.raises(ValueError, match="one value per system"):
+        model(_State(torch.from_numpy(c), torch.from_numpy(z), torch.from_numpy(mol), cell, True, 3, charge=[0.0, 1.0]))

@@ -213,3 +213,34 @@ def test_neighbor_list_large_nonperiodic_uses_bounding_box_cells():
         want = set(np.nonzero(d[i] < 5.0)[0].tolist())
         assert set(nb[i, : num[i]].tolist()) == want
     assert num.max() < 128 and (num == (d < 5.0).sum(1)).all()
+
+
+@pytest.mark.parametrize("cfg", [5, 7, 351])
+def test_gelu_epilogue_accuracy(cfg):
+    """The fused GELU / GELU' epilogue (common.h erf_fast: branch-free polynomial erf) against the fp64 formula of
+    torch.nn.GELU on exact pre-activations z in [-9, 9] (K = 32 product with a single non-zero term):
+    |h - gelu(z)| <= 2e-7 (1 + |z|), |d - gelu'(z)| <= 4e-7."""
+    from aimnetcentral_amd import _lib
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    M, N, K = 8192, 16, 32
+    z = torch.linspace(-9.0, 9.0, M, dtype=torch.float32)
+    z[::97] = torch.tensor([0.0, -0.0, 0.921875 * 2**0.5, -0.921875 * 2**0.5, 1e-8, -1e-8, 5.7, -5.7])[torch.arange(len(z[::97])) % 8]
+    A = torch.zeros(M, K)
+    A[:, 0] = z
+    Bt = torch.zeros(N, K)
+    Bt[:, 0] = 1.0
+    A, Bt, bias = A.to(dev), Bt.to(dev), torch.zeros(N, device=dev)
+    Cm, D = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    rc = lib.aimnet_debug_gemm(cfg, 2, A.data_ptr(), K, Bt.data_ptr(), K, M, N, K, bias.data_ptr(), Cm.data_ptr(), D.data_ptr(), N,
+                               torch.cuda.current_stream(dev).cuda_stream)
+    assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    zd = z.double()
+    cdf = 0.5 * (1 + torch.erf(zd / 2**0.5))
+    h, d = zd * cdf, cdf + zd * torch.exp(-0.5 * zd * zd) / (2 * torch.pi) ** 0.5
+    eh = (Cm[:, 3].cpu().double() - h).abs() / (1 + zd.abs())
+    ed = (D[:, 5].cpu().double() - d).abs()
+    assert eh.max().item() <= 2e-7, (eh.max().item(), z[eh.argmax()].item())
+    assert ed.max().item() <= 4e-7, (ed.max().item(), z[ed.argmax()].item())

@@ -86,6 +86,19 @@ __device__ __forceinline__ void gelu_and_grad(float z, float& h, float& d) {
   d = cdf + z * pdf;
 }
 
+// hipFuncSetAttribute is per DEVICE: one process may drive several engines (one per GPU), so "done once" flags for the
+// > 64 KiB dynamic-LDS opt-in are kept per device ordinal.  Returns true the first time it is called on the current device.
+struct PerDeviceOnce {
+  bool done[64] = {};
+  bool first() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;  // unknown device: just set the attribute again
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+  }
+};
+
 // ---- packed integer lattice shifts: 3 x int8 in one int32 ------------------------------------
 __device__ __forceinline__ int pack_shift(int sx, int sy, int sz) {
   return (sx & 0xff) | ((sy & 0xff) << 8) | ((sz & 0xff) << 16);

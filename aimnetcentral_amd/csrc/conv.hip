@@ -788,11 +788,9 @@ int launch_unconcat_p0(hipStream_t s, const float* xbar, int ldx, const float* V
                        int n_atoms) {
   const int grid = min(ceil_div(n_atoms, APB), 256 * 4);
   const size_t lds = sizeof(float) * ((size_t)A_ * G_ * H_ + APB * NV * 3 + APB * A_ * 65 + (size_t)nslots * NF);
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce once;
+  if (once.first())
     AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)unconcat_p0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    attr = true;
-  }
   hipLaunchKernelGGL(unconcat_p0_kernel, dim3(grid), dim3(256), lds, s, xbar, ldx, Vsave, agh_a, afv, z_of_slot, nslots,
                      present_part, n_part, T, n_atoms);
   AIMNET_LAUNCH_CHECK();

@@ -355,13 +355,12 @@ static int launch_panel(hipStream_t stream, int epi, const float* A, int lda, co
   constexpr int TM = 16 * SM * WM, TN = 16 * SN * WN;
   const int tiles = ceil_div(M, TM) * ceil_div(N, TN);
   const size_t lds = (size_t)4 * (TM + TN) * 64;
-  static bool attr_done = false;
-  if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in, once per instantiation
+  static PerDeviceOnce once;
+  if (once.first()) {  // > 64 KiB of dynamic LDS needs the opt-in, once per instantiation and device
     AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_NONE, SM, SN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_BIAS, SM, SN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_BIAS_GELU, SM, SN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_MUL, SM, SN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
   }
   dim3 grid(tiles), block(512);
   switch (epi) {

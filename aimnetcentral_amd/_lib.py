@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = (
     "aimnet_neighbor_list_workspace_bytes",
     "aimnet_conv_sv_2d_sp_fwd",
     "aimnet_conv_sv_2d_sp_bwd",
+    "aimnet_conv_sv_2d_sp_bwd_bwd",
 )
 
 
@@ -171,6 +172,8 @@ def load() -> C.CDLL:
     lib.aimnet_conv_sv_2d_sp_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.aimnet_conv_sv_2d_sp_bwd.restype = C.c_int
     lib.aimnet_conv_sv_2d_sp_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.aimnet_conv_sv_2d_sp_bwd_bwd.restype = C.c_int
+    lib.aimnet_conv_sv_2d_sp_bwd_bwd.argtypes = [vp] * 9 + [i32, i32, i32, i32, vp]
     return lib
 
 

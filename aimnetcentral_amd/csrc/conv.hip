@@ -923,8 +923,10 @@ int launch_conv_bwd_p0(hipStream_t s, bool stress, const float* T, int nslots, c
 // stand-alone op with the exact contract of torch.ops.aimnet.conv_sv_2d_sp_fwd / _bwd
 // (conv_sv_2d_sp_wp.py:252-340): generic (A, G) with A*G a multiple of 4, materialised g (B,M,G,4),
 // sentinel index B-1, rows packed real-first (early exit at the first sentinel), padding row zero.
+// out = conv(a, g) [+ conv(a2, g2) when a2 != NULL: the two terms of the double backward's grad_grad_output]
 __global__ void conv_sv_fwd_kernel(const float* __restrict__ a, const int* __restrict__ idx, const float4* __restrict__ g,
-                                   float4* __restrict__ out, int B, int A, int G, int M) {
+                                   const float* __restrict__ a2, const float4* __restrict__ g2, float4* __restrict__ out,
+                                   int B, int A, int G, int M) {
   const int b = blockIdx.x;
   const int AG = A * G;
   for (int f = threadIdx.x; f < AG; f += blockDim.x) {
@@ -937,6 +939,11 @@ __global__ void conv_sv_fwd_kernel(const float* __restrict__ a, const int* __res
         const float av = a[(size_t)j * AG + f];
         const float4 gv = g[((size_t)b * M + m) * G + gg];
         acc.x += av * gv.x; acc.y += av * gv.y; acc.z += av * gv.z; acc.w += av * gv.w;
+        if (a2) {
+          const float bv = a2[(size_t)j * AG + f];
+          const float4 hv = g2[((size_t)b * M + m) * G + gg];
+          acc.x += bv * hv.x; acc.y += bv * hv.y; acc.z += bv * hv.z; acc.w += bv * hv.w;
+        }
       }
     }
     out[(size_t)b * AG + f] = acc;
@@ -946,7 +953,8 @@ __global__ void conv_sv_fwd_kernel(const float* __restrict__ a, const int* __res
 int launch_conv_sv_fwd(hipStream_t s, const float* a, const int* idx, const float* g, float* out, int B, int A, int G,
                        int M) {
   if (B <= 0) return 0;
-  hipLaunchKernelGGL(conv_sv_fwd_kernel, dim3(B), dim3(256), 0, s, a, idx, (const float4*)g, (float4*)out, B, A, G, M);
+  hipLaunchKernelGGL(conv_sv_fwd_kernel, dim3(B), dim3(256), 0, s, a, idx, (const float4*)g, nullptr, nullptr, (float4*)out, B,
+                     A, G, M);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }
@@ -999,6 +1007,27 @@ int launch_conv_sv_bwd(hipStream_t s, const float* grad_out, const float* a, con
   AIMNET_LAUNCH_CHECK();
   hipLaunchKernelGGL(conv_sv_bwd_a_kernel, dim3(B), dim3(256), 0, s, (const float4*)grad_out, idx, (const float4*)g, grad_a,
                      B, A, G, M);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// Double backward of the op (conv_sv_2d_sp_wp.py:342-446): with cotangents grad2_a of grad_a and grad2_g of grad_g,
+//   grad_grad_output = conv(grad2_a, g) + conv(a, grad2_g)      (one fused launch)
+//   grad_a_double    = backward_a(grad_out; g := grad2_g)        (d grad_g / d a)
+//   grad_g_double    = backward_g(grad_out; a := grad2_a)        (d grad_a / d g)
+// i.e. the forward and the two halves of the backward with swapped operands - no new arithmetic.
+int launch_conv_sv_bwd_bwd(hipStream_t s, const float* grad_out, const float* grad2_a, const float* grad2_g, const float* a,
+                           const int* idx, const float* g, float* ggo, float* ga2, float* gg2, int B, int A, int G, int M) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(conv_sv_fwd_kernel, dim3(B), dim3(256), 0, s, grad2_a, idx, (const float4*)g, a, (const float4*)grad2_g,
+                     (float4*)ggo, B, A, G, M);
+  AIMNET_LAUNCH_CHECK();
+  AIMNET_HIP_CHECK(hipMemsetAsync(ga2, 0, (size_t)B * A * G * sizeof(float), s));
+  hipLaunchKernelGGL(conv_sv_bwd_a_kernel, dim3(B), dim3(256), 0, s, (const float4*)grad_out, idx, (const float4*)grad2_g, ga2, B,
+                     A, G, M);
+  AIMNET_LAUNCH_CHECK();
+  hipLaunchKernelGGL(conv_sv_bwd_g_kernel, dim3(B), dim3(256), 0, s, (const float4*)grad_out, grad2_a, idx, (float4*)gg2, B, A, G,
+                     M);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

@@ -784,4 +784,14 @@ int aimnet_conv_sv_2d_sp_bwd(const float* grad_out, const float* a, const int32_
   return launch_conv_sv_bwd((hipStream_t)hip_stream, grad_out, a, idx, g, grad_a, grad_g, B, A, G, M);
 }
 
+int aimnet_conv_sv_2d_sp_bwd_bwd(const float* grad_out, const float* grad2_a, const float* grad2_g, const float* a,
+                                 const int32_t* idx, const float* g, float* grad_grad_out, float* grad_a_double,
+                                 float* grad_g_double, int32_t B, int32_t A, int32_t G, int32_t M, void* hip_stream) {
+  if (!grad_out || !grad2_a || !grad2_g || !a || !idx || !g || !grad_grad_out || !grad_a_double || !grad_g_double || B < 0 ||
+      A <= 0 || G <= 0 || M <= 0)
+    return AIMNET_E_INVALID;
+  return launch_conv_sv_bwd_bwd((hipStream_t)hip_stream, grad_out, grad2_a, grad2_g, a, idx, g, grad_grad_out, grad_a_double,
+                                grad_g_double, B, A, G, M);
+}
+
 }  // extern "C"

@@ -102,6 +102,8 @@ int launch_conv_sv_fwd(hipStream_t s, const float* a, const int* idx, const floa
                        int M);
 int launch_conv_sv_bwd(hipStream_t s, const float* grad_out, const float* a, const int* idx, const float* g,
                        float* grad_a, float* grad_g, int B, int A, int G, int M);
+int launch_conv_sv_bwd_bwd(hipStream_t s, const float* grad_out, const float* grad2_a, const float* grad2_g, const float* a,
+                           const int* idx, const float* g, float* ggo, float* ga2, float* gg2, int B, int A, int G, int M);
 
 // ---- model.hip --------------------------------------------------------------------------------
 // S = slices (blocks) per molecule for the per-molecule reductions; `part` = scratch [n_sys * S * 9] doubles

@@ -353,3 +353,25 @@ def conv_sv_2d_sp_bwd(grad_out, a, idx, g):
                                           grad_g.data_ptr(), B, A, G, M, torch.cuda.current_stream(a.device).cuda_stream)
     _lib.check(rc, "aimnet_conv_sv_2d_sp_bwd")
     return grad_a, grad_g
+
+
+def conv_sv_2d_sp_bwd_bwd(grad_out, grad2_a, grad2_g, a, idx, g):
+    """torch.ops.aimnet.conv_sv_2d_sp_bwd_bwd contract (conv_sv_2d_sp_wp.py:342-446):
+    (grad_grad_output [B,A,G,4], grad_a_double [B,A,G], grad_g_double [B,M,G,4])."""
+    import torch
+
+    lib = _lib.load()
+    B, A, G = a.shape
+    M = idx.shape[1]
+    f = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
+    grad_out, grad2_a, grad2_g, a, g = f(grad_out), f(grad2_a), f(grad2_g), f(a), f(g)
+    idx = idx.to(torch.int32).contiguous()
+    ggo = torch.empty(B, A, G, 4, dtype=torch.float32, device=a.device)
+    ga2 = torch.empty_like(a)
+    gg2 = torch.empty_like(g)
+    with torch.cuda.device(a.device):
+        rc = lib.aimnet_conv_sv_2d_sp_bwd_bwd(grad_out.data_ptr(), grad2_a.data_ptr(), grad2_g.data_ptr(), a.data_ptr(), idx.data_ptr(),
+                                              g.data_ptr(), ggo.data_ptr(), ga2.data_ptr(), gg2.data_ptr(), B, A, G, M,
+                                              torch.cuda.current_stream(a.device).cuda_stream)
+    _lib.check(rc, "aimnet_conv_sv_2d_sp_bwd_bwd")
+    return ggo, ga2, gg2

@@ -192,6 +192,12 @@ int aimnet_conv_sv_2d_sp_bwd(const float* grad_out, const float* a, const int32_
                              float* grad_a, float* grad_g, int32_t B, int32_t A, int32_t G, int32_t M,
                              void* hip_stream);
 
+/* torch.ops.aimnet.conv_sv_2d_sp_bwd_bwd (conv_sv_2d_sp_wp.py:342-446): cotangents grad2_a [B,A,G] of grad_a and grad2_g
+ * [B,M,G,4] of grad_g -> grad_grad_out [B,A,G,4], grad_a_double [B,A,G], grad_g_double [B,M,G,4] (all caller-allocated). */
+int aimnet_conv_sv_2d_sp_bwd_bwd(const float* grad_out, const float* grad2_a, const float* grad2_g, const float* a,
+                                 const int32_t* idx, const float* g, float* grad_grad_out, float* grad_a_double,
+                                 float* grad_g_double, int32_t B, int32_t A, int32_t G, int32_t M, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

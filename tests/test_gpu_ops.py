@@ -51,6 +51,32 @@ def test_conv_sv_fwd_bwd_match_einsum_reference(B, A, G, M):
     torch.testing.assert_close(gg.cpu(), g_r.grad, atol=1e-4, rtol=1e-3)
 
 
+@pytest.mark.parametrize("B,A,G,M", [(8, 16, 12, 10), (57, 16, 16, 31), (33, 4, 8, 5)])
+def test_conv_sv_double_backward_matches_autograd(B, A, G, M):
+    """conv_sv_2d_sp_bwd_bwd against torch's double backward of the einsum reference (the reference pins its Warp
+    kernels the same way, tests/test_conv_sv_2d_sp.py:197-253): cotangents v_a, v_g of (grad_a, grad_g)."""
+    gen = torch.Generator().manual_seed(B * 77 + M)
+    a = torch.randn(B, A, G, generator=gen, dtype=torch.float64, requires_grad=True)
+    g = torch.randn(B, M, G, 4, generator=gen, dtype=torch.float64, requires_grad=True)
+    idx = make_idx(B, M, M, gen)
+    go = torch.randn(B, A, G, 4, generator=gen, dtype=torch.float64)
+    go[-1] = 0
+    go.requires_grad_(True)
+    va = torch.randn(B, A, G, generator=gen, dtype=torch.float64)
+    vg = torch.randn(B, M, G, 4, generator=gen, dtype=torch.float64)
+    out = reference_conv_sv_2d_sp_einsum(a, idx, g)
+    ga, gg = torch.autograd.grad(out, (a, g), go, create_graph=True)
+    want = torch.autograd.grad((ga * va).sum() + (gg * vg).sum(), (go, a, g))
+    dev = torch.device("cuda:0")
+    got = E.conv_sv_2d_sp_bwd_bwd(go.detach().float().to(dev), va.float().to(dev), vg.float().to(dev), a.detach().float().to(dev),
+                                  idx.to(dev), g.detach().float().to(dev))
+    for name, x, w in zip(("grad_grad_output", "grad_a_double", "grad_g_double"), got, want):
+        w = w.clone()
+        if name == "grad_grad_output":
+            w[-1] = 0  # the op leaves the padding row zero
+        torch.testing.assert_close(x.cpu().double(), w, atol=2e-4, rtol=1e-3, msg=name)
+
+
 def test_conv_sv_padding_counts():
     """rows with 0, partial and full neighbour counts (test_conv_sv_2d_sp.py:294-318)."""
     B, A, G, M = 6, 16, 16, 4

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
                                                       const float* __restrict__ abar_in, float* __restrict__ abar_out,
                                                       const float* __restrict__ qbar_in, float* __restrict__ qbar_out,
                                                       float* __restrict__ fgrad, float* __restrict__ virial_atom,
-                                                      int n_atoms, int dbg, const int* __restrict__ order) {
+                                                      int n_atoms, const int* __restrict__ order) {
   __shared__ __attribute__((aligned(16))) BwdWaveLds wl[APB];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   BwdWaveLds& L = wl[wid];
@@ -441,7 +441,6 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
   const int qg = lane >> 2, qc = lane & 3;
   const float qm0 = qc == 0 ? 1.f : 0.f, qm1 = qc == 1 ? 1.f : 0.f, qm2 = qc == 2 ? 1.f : 0.f, qm3 = qc == 3 ? 1.f : 0.f;
   const float qsgn = qc == 0 ? 1.f : -1.f;
-  (void)dbg;
 
   const AtomLoop al = atom_loop(n_atoms, APB);
   for (int i0 = al.first; i0 < al.last; i0 += al.step) {
@@ -635,10 +634,9 @@ int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, cons
                     int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
                     const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order) {
   const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
-  static const int dbg = getenv("AIMNET_CONV_DBG") ? atoi(getenv("AIMNET_CONV_DBG")) : 0;  // ablation switch, tests only
 #define AIMNET_BWD(HQ, NA, ST)                                                                                        \
   hipLaunchKernelGGL((conv_bwd_kernel<HQ, NA, ST>), dim3(grid), dim3(256), 0, s, a, row_of, q, Sbar, Sqbar, nb_idx, nb_cnt, pg, \
-                     cap, bp, xbar, ldx, abar_in, abar_out, qbar_in, qbar_out, fgrad, virial_atom, n_atoms, dbg, order)
+                     cap, bp, xbar, ldx, abar_in, abar_out, qbar_in, qbar_out, fgrad, virial_atom, n_atoms, order)
   if (has_q) {
     if (need_abar) {
       if (stress) AIMNET_BWD(true, true, true); else AIMNET_BWD(true, true, false);

@@ -479,7 +479,7 @@ static int g_force_tile = 0;  // 0 = choose_tile(); a tile id from AIMNET_GEMM_T
 // Tile choice.  Every candidate runs the same MFMA rate; what differs is (a) how evenly ceil(M/TM)*ceil(N/TN)
 // tiles load the 256 CUs - the busiest CU carries ceil(tiles/256) tiles of TM*TN MACs per k, padding of M and N
 // included - and (b) the operand bytes streamed per MAC, x = (TM+TN)/(TM*TN), which costs MFMA issue slots
-// through the DMA + LDS-read path.  Fitted to tests/tune_gemm.py on 10 080-row layers (profiles/r1c_summary.md):
+// through the DMA + LDS-read path.  Fitted to tests/tools/tune_gemm.py on 10 080-row layers (profiles/r1c_summary.md):
 // efficiency = 0.9 / (1 + 5x), times 0.88 when a CU holds a single block of <= 10 accumulator tiles per wave
 // (nothing to overlap its barrier with).  The model reproduces the measured ranking on all six MLP shapes.
 struct TileCand { int id, tm, tn, acc_tiles; };

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """GPU-side stage-by-stage comparison of the HIP engine against the CPU oracle (debug tool).
 
-    python tests/stagecheck.py            # on a GPU box
+    python tests/tools/stagecheck.py            # on a GPU box
 
 Prints max abs error per intermediate for a non-periodic and a periodic system so that one
 gpurun call localises a wrong kernel.  Not collected by pytest.
@@ -14,7 +14,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from aimnetcentral_amd import loader, synth  # noqa: E402

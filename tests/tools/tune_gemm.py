@@ -2,7 +2,7 @@
 """GEMM tuning / validation harness (GPU box): times aimnet_debug_gemm tile configs on the MLP shapes."""
 import os, sys, ctypes as C
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from aimnetcentral_amd import _lib
 
 lib = _lib.load()

@@ -2,7 +2,7 @@
 """fixed overhead vs steady-state rate of the GEMM kernels: time vs K at fixed M x N."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from aimnetcentral_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda:0")
 M, N = int(os.environ.get("M", 10080)), int(os.environ.get("N", 512))

@@ -158,6 +158,8 @@ class HipEngine:
         mol_idx = mol_idx.to(device=dev, dtype=torch.int32).contiguous()
         charge = charge.to(device=dev, dtype=torch.float32).contiguous()
         n, n_mol = coord.shape[0], charge.shape[0]
+        if n == 0 or n_mol == 0:
+            raise ValueError("HipEngine.eval: empty input (no atoms or no molecules)")
         n_cell = 0
         if cell is not None:
             cell = cell.to(device=dev, dtype=torch.float32).contiguous()

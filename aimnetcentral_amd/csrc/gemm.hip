@@ -189,6 +189,14 @@ __device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
 }
+// fragments f[I..N) of consecutive 16-row strips: strip i sits i * 1024 bytes further (16 rows x 64 B)
+template <int I, int N>
+__device__ __forceinline__ void read_frags(f32x4 (&f)[N], unsigned addr) {
+  if constexpr (I < N) {
+    f[I] = lds_read16<I * 1024>(addr);
+    read_frags<I + 1, N>(f, addr);
+  }
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -267,42 +275,14 @@ __global__ __launch_bounds__(512, (SM * SN > 10 ? 2 : 4)) void gemm_nt_panel_ker
 
     const unsigned so = st * STAGE_BYTES;
     f32x4 fa[SM], fb[SN];
-    {
-      const unsigned pa = adA + so, pb = adB + so;
-      fb[0] = lds_read16<0>(pb);
-      fa[0] = lds_read16<0>(pa);
-      if (SN > 1) fb[1] = lds_read16<1024>(pb);
-      if (SN > 2) fb[2] = lds_read16<2048>(pb);
-      if (SM > 1) fa[1] = lds_read16<1024>(pa);
-      if (SM > 2) fa[2] = lds_read16<2048>(pa);
-      if (SM > 3) fa[3] = lds_read16<3072>(pa);
-      if (SM > 4) fa[4] = lds_read16<4096>(pa);
-    }
-    // one wait that "produces" every fragment, so no MFMA can be scheduled above it
-    if constexpr (SM == 5 && SN == 2)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fb[0]), "+v"(fb[1]));
-    else if constexpr (SM == 5 && SN == 3)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]));
-    else if constexpr (SM == 5 && SN == 1)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fb[0]));
-    else if constexpr (SM == 4 && SN == 2)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]));
-    else if constexpr (SM == 4 && SN == 3)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]));
-    else if constexpr (SM == 3 && SN == 2)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]), "+v"(fb[1]));
-    else if constexpr (SM == 3 && SN == 1)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]));
-    else if constexpr (SM == 2 && SN == 2)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1]));
-    else if constexpr (SM == 2 && SN == 3)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]));
-    else if constexpr (SM == 1 && SN == 3)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]));
-    else if constexpr (SM == 1 && SN == 2)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fb[1]));
-    else
-      static_assert(SM == 0, "add the fragment list for this (SM, SN)");
+    read_frags<0, SN>(fb, adB + so);
+    read_frags<0, SM>(fa, adA + so);
+    // one drain that "produces" every fragment (empty asm ties), so no MFMA can be scheduled above it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < SM; ++i) asm volatile("" : "+v"(fa[i]));
+#pragma unroll
+    for (int j = 0; j < SN; ++j) asm volatile("" : "+v"(fb[j]));
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -485,7 +465,8 @@ static int g_force_tile = 0;  // 0 = choose_tile(); a tile id from AIMNET_GEMM_T
 struct TileCand { int id, tm, tn, acc_tiles; };
 static const TileCand kTileCands[] = {
     {152, 160, 128, 10}, {142, 128, 128, 8}, {132, 96, 128, 6}, {122, 64, 128, 4}, {153, 160, 192, 15}, {143, 128, 192, 12},
-    {223, 128, 96, 6},   {213, 64, 96, 3},   {222, 128, 64, 4}, {351, 80, 128, 5}, {331, 48, 128, 3},   {5, 64, 64, 1}};
+    {223, 128, 96, 6},   {213, 64, 96, 3},   {222, 128, 64, 4}, {351, 80, 128, 5}, {331, 48, 128, 3},   {5, 64, 64, 1},
+    {381, 128, 128, 8},  {371, 112, 128, 7}, {361, 96, 128, 6}, {341, 64, 128, 4}, {321, 32, 128, 2},   {233, 192, 96, 9}};
 static int choose_tile(int M, int N, bool vec_ok) {
   if (M <= 256) return 7;  // latency regime: split-K skinny kernel (see gemm_nt_skinny_kernel)
   int best = 5;
@@ -526,8 +507,14 @@ int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int
     AIMNET_PANEL_CASE(223, 2, 3, 4, 2)  // 128 x  96
     AIMNET_PANEL_CASE(213, 1, 3, 4, 2)  //  64 x  96
     AIMNET_PANEL_CASE(222, 2, 2, 4, 2)  // 128 x  64
+    AIMNET_PANEL_CASE(381, 8, 1, 1, 8)  // 128 x 128 (1 x 8 waves)
+    AIMNET_PANEL_CASE(371, 7, 1, 1, 8)  // 112 x 128
+    AIMNET_PANEL_CASE(361, 6, 1, 1, 8)  //  96 x 128
     AIMNET_PANEL_CASE(351, 5, 1, 1, 8)  //  80 x 128
+    AIMNET_PANEL_CASE(341, 4, 1, 1, 8)  //  64 x 128
     AIMNET_PANEL_CASE(331, 3, 1, 1, 8)  //  48 x 128
+    AIMNET_PANEL_CASE(321, 2, 1, 1, 8)  //  32 x 128
+    AIMNET_PANEL_CASE(233, 3, 3, 4, 2)  // 192 x  96
 #undef AIMNET_PANEL_CASE
     case 5: return launch_ring<3>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
     case 7: return launch_skinny(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);

@@ -221,8 +221,7 @@ int launch_bbox(hipStream_t s, int n_mol, NlistBuffers& b) {
 __global__ __launch_bounds__(256) void nlist_brute_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
                                                          const int* __restrict__ mol_start, int n_atoms, float cutoff2,
                                                          int cap, int fill_value, int fill_rows, int* __restrict__ nb_idx,
-                                                         int* __restrict__ nb_cnt, int* __restrict__ status_max,
-                                                         int* __restrict__ status_ovf) {
+                                                         int* __restrict__ nb_cnt, int* __restrict__ cnt_true) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
@@ -247,10 +246,7 @@ __global__ __launch_bounds__(256) void nlist_brute_kernel(const float* __restric
     for (int p = min(count, cap) + lane; p < cap; p += 64) row[p] = fill_value;
   if (lane == 0) {
     nb_cnt[i] = min(count, cap);
-    // 10^4 same-address atomics serialise at ~12 ns each (>100 us per list): atomicMax is monotonic, so
-    // skip it whenever a (possibly stale) relaxed read already shows a value >= ours
-    if (count > __hip_atomic_load(status_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(status_max, count);
-    if (count > cap) atomicMax(status_ovf, 1);
+    cnt_true[i] = count;  // max / overflow are reduced by nlist_status_kernel: 10^4 same-address atomics cost ~12 ns each
   }
 }
 
@@ -356,7 +352,7 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
                                                         int n_atoms, float cutoff, int cap, int fill_value,
                                                         int fill_rows, int* __restrict__ nb_idx,
                                                         int* __restrict__ nb_shift, int* __restrict__ nb_cnt,
-                                                        int* __restrict__ status_max, int* __restrict__ status_ovf) {
+                                                        int* __restrict__ cnt_true) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
@@ -381,10 +377,7 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
     }
   if (lane == 0) {
     nb_cnt[i] = min(count, cap);
-    // 10^4 same-address atomics serialise at ~12 ns each (>100 us per list): atomicMax is monotonic, so
-    // skip it whenever a (possibly stale) relaxed read already shows a value >= ours
-    if (count > __hip_atomic_load(status_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(status_max, count);
-    if (count > cap) atomicMax(status_ovf, 1);
+    cnt_true[i] = count;  // max / overflow are reduced by nlist_status_kernel: 10^4 same-address atomics cost ~12 ns each
   }
 }
 
@@ -410,24 +403,46 @@ int launch_bins(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, float
   return 0;
 }
 
+// status[0] = max_i count_i, status[1] = any(count_i > cap): one atomic per 1024 atoms instead of one per atom
+__global__ __launch_bounds__(1024) void nlist_status_kernel(const int* __restrict__ cnt_true, int n_atoms, int cap,
+                                                           int* __restrict__ status_max, int* __restrict__ status_ovf) {
+  __shared__ int s_max[16];
+  const int i = blockIdx.x * 1024 + threadIdx.x;
+  int v = i < n_atoms ? cnt_true[i] : 0;
+  v = wave_max(v);
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    v = threadIdx.x < 16 ? s_max[threadIdx.x] : 0;
+    v = wave_max(v);
+    if (threadIdx.x == 0) {
+      if (v > __hip_atomic_load(status_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(status_max, v);
+      if (v > cap) atomicMax(status_ovf, 1);
+    }
+  }
+}
+
 int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, const float* cell, int n_cell,
                  const int pbc[3], float cutoff, float bin_width, int cap, int fill_value, int fill_rows,
                  NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf) {
   (void)n_cell;
   (void)pbc;
   (void)cell;
+  int* cnt_true = b.sorted_tmp;  // free once the bins are sorted (and never used by the per-molecule scan)
   if (!b.binned) {
     hipLaunchKernelGGL(nlist_brute_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, b.mol_start, n_atoms,
-                       cutoff * cutoff, cap, fill_value, fill_rows, nb_idx, nb_cnt, status_max, status_ovf);
+                       cutoff * cutoff, cap, fill_value, fill_rows, nb_idx, nb_cnt, cnt_true);
     AIMNET_LAUNCH_CHECK();
-    return 0;
+  } else {
+    if (bin_width > 0.0f) {  // bin_width <= 0: reuse the bins of the previous call
+      int rc = launch_bins(s, n_atoms, n_mol, mol_idx, bin_width, b);
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(nlist_cell_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, (NlistSystem*)b.sys,
+                       b.bin_start, b.xs, n_atoms, cutoff, cap, fill_value, fill_rows, nb_idx, nb_shift, nb_cnt, cnt_true);
+    AIMNET_LAUNCH_CHECK();
   }
-  if (bin_width > 0.0f) {  // bin_width <= 0: reuse the bins of the previous call
-    int rc = launch_bins(s, n_atoms, n_mol, mol_idx, bin_width, b);
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL(nlist_cell_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, (NlistSystem*)b.sys,
-                     b.bin_start, b.xs, n_atoms, cutoff, cap, fill_value, fill_rows, nb_idx, nb_shift, nb_cnt, status_max,
+  hipLaunchKernelGGL(nlist_status_kernel, dim3(ceil_div(n_atoms, 1024)), dim3(1024), 0, s, cnt_true, n_atoms, cap, status_max,
                      status_ovf);
   AIMNET_LAUNCH_CHECK();
   return 0;

@@ -169,7 +169,7 @@ class HipEngine:
         charges = torch.empty(n, dtype=torch.float32, device=dev)
         f_out = torch.empty(n, 3, dtype=torch.float32, device=dev) if forces else None
         s_out = torch.empty(max(n_cell, 1), 3, 3, dtype=torch.float32, device=dev) if stress else None
-        status = torch.zeros(8, dtype=torch.int32, device=dev)
+        status = torch.empty(8, dtype=torch.int32, device=dev)  # zeroed by the engine at the start of every evaluation
         stream = torch.cuda.current_stream(dev).cuda_stream
         while True:
             opt = _lib.EvalOptions()

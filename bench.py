@@ -163,7 +163,9 @@ def main():
 
     wl = build_workload(args.workload, rank, world)
     eng = HipEngine(loader.synthetic_spec(0), dev)
-    t = {k: torch.from_numpy(np.ascontiguousarray(wl[k])).to(dev) for k in ("coord", "numbers", "mol_idx", "charge")}
+    # inputs resident in HBM in the engine's native dtypes (f32 / i32): no per-step conversion kernels in the timed region
+    dt = {"coord": torch.float32, "numbers": torch.int32, "mol_idx": torch.int32, "charge": torch.float32}
+    t = {k: torch.from_numpy(np.ascontiguousarray(wl[k])).to(device=dev, dtype=dt[k]) for k in dt}
     cell = torch.from_numpy(wl["cell"]).to(dev) if wl["cell"] is not None else None
     n_atoms = int(t["coord"].shape[0])
     frames = int(wl["frames"])

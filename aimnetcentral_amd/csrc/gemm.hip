@@ -466,7 +466,8 @@ struct TileCand { int id, tm, tn, acc_tiles; };
 static const TileCand kTileCands[] = {
     {152, 160, 128, 10}, {142, 128, 128, 8}, {132, 96, 128, 6}, {122, 64, 128, 4}, {153, 160, 192, 15}, {143, 128, 192, 12},
     {223, 128, 96, 6},   {213, 64, 96, 3},   {222, 128, 64, 4}, {351, 80, 128, 5}, {331, 48, 128, 3},   {5, 64, 64, 1},
-    {381, 128, 128, 8},  {371, 112, 128, 7}, {361, 96, 128, 6}, {341, 64, 128, 4}, {321, 32, 128, 2},   {233, 192, 96, 9}};
+    {381, 128, 128, 8},  {371, 112, 128, 7}, {361, 96, 128, 6}, {341, 64, 128, 4}, {321, 32, 128, 2},   {233, 192, 96, 9},
+    {412, 192, 128, 12}, {411, 176, 128, 11}, {410, 160, 128, 10}, {409, 144, 128, 9}};
 static int choose_tile(int M, int N, bool vec_ok) {
   if (M <= 256) return 7;  // latency regime: split-K skinny kernel (see gemm_nt_skinny_kernel)
   int best = 5;
@@ -507,6 +508,10 @@ int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int
     AIMNET_PANEL_CASE(223, 2, 3, 4, 2)  // 128 x  96
     AIMNET_PANEL_CASE(213, 1, 3, 4, 2)  //  64 x  96
     AIMNET_PANEL_CASE(222, 2, 2, 4, 2)  // 128 x  64
+    AIMNET_PANEL_CASE(412, 12, 1, 1, 8)  // 192 x 128 (1 x 8 waves; ids 409..412 = SM 9..12 of that family)
+    AIMNET_PANEL_CASE(411, 11, 1, 1, 8)  // 176 x 128
+    AIMNET_PANEL_CASE(410, 10, 1, 1, 8)  // 160 x 128
+    AIMNET_PANEL_CASE(409, 9, 1, 1, 8)   // 144 x 128
     AIMNET_PANEL_CASE(381, 8, 1, 1, 8)  // 128 x 128 (1 x 8 waves)
     AIMNET_PANEL_CASE(371, 7, 1, 1, 8)  // 112 x 128
     AIMNET_PANEL_CASE(361, 6, 1, 1, 8)  //  96 x 128

@@ -207,20 +207,25 @@ __global__ __launch_bounds__(256) void d3_pair_kernel(const float4* __restrict__
     const float s_j[5] = {sj0.x, sj0.y, sj0.z, sj0.w, sj1.x};
     const float w_j[5] = {sj1.y, sj1.z, sj1.w, sj2.x, sj2.y};
     const float* cr = c6s + sj * 25;
+    // sum_ab c6ref_ab w_i[a] w_j[b] [kept]: inner sums over b first, so the centre's weights enter once per a
     float N = 0.f, D = 0.f, G = 0.f, H = 0.f;
 #pragma unroll
     for (int a = 0; a < 5; ++a) {
       if (a < nref_i) {
+        float sb = 0.f, tb = 0.f;
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
           const float c6r = cr[a * 5 + b];
-          const float w = (s_i[a] + s_j[b] >= -12.0f && c6r != 0.0f) ? w_i[a] * w_j[b] : 0.0f;
-          N += c6r * w;
-          D += w;
-          if (GRAD) {
-            G += c6r * w * g_i[a];
-            H += w * g_i[a];
-          }
+          const float w = (s_i[a] + s_j[b] >= -12.0f && c6r != 0.0f) ? w_j[b] : 0.0f;
+          sb += c6r * w;
+          tb += w;
+        }
+        N += w_i[a] * sb;
+        D += w_i[a] * tb;
+        if (GRAD) {
+          const float wg = w_i[a] * g_i[a];
+          G += wg * sb;
+          H += wg * tb;
         }
       }
     }

@@ -34,7 +34,8 @@ constexpr int D3W = 12;  // floats per atom in the weight table: s[5], w[5], cn,
 
 // PairAcc / pair_add / pair_store live in model.hip; the same accumulation contract is restated here
 struct D3Acc {
-  double e = 0.0;
+  double e = 0.0;   // dispersion pair energies (Hartree)
+  double ec = 0.0;  // DSF Coulomb pair terms w q_i q_j when the two share one pass
   float f0 = 0.f, f1 = 0.f, f2 = 0.f;
   float W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -54,8 +55,9 @@ __device__ __forceinline__ void d3_add(D3Acc& A, float t, float ux, float uy, fl
 
 // E = k sum_ordered e  ->  dE/dx_i = -2k sum_j e' u_ij ,  dE/deps_ab = k sum_ordered e' r_a u_b   (as coulomb pair_store)
 template <bool GRAD, bool STRESS>
-__device__ __forceinline__ void d3_store(D3Acc& A, int i, int lane, float k, double* ecoul, float* fgrad, float* virial_atom) {
-  const double e = wave_sum(A.e);
+__device__ __forceinline__ void d3_store(D3Acc& A, int i, int lane, float k, double* ecoul, float* fgrad, float* virial_atom,
+                                         double kc = 0.0) {
+  const double e = wave_sum(A.e) + (kc != 0.0 ? kc / (double)k * wave_sum(A.ec) : 0.0);
   float f0 = 0.f, f1 = 0.f, f2 = 0.f;
   if (GRAD) {
     f0 = wave_sum(A.f0);
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void d3_cn_kernel(const float4* __restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool GRAD, bool STRESS>
+template <bool GRAD, bool STRESS, bool DSF>
 __global__ __launch_bounds__(256) void d3_pair_kernel(const float4* __restrict__ xs4, const int* __restrict__ mol_idx,
                                                      const float* __restrict__ cell, int n_cell,
                                                      const int* __restrict__ nb_idx,
@@ -171,7 +173,10 @@ __global__ __launch_bounds__(256) void d3_pair_kernel(const float4* __restrict__
                                                      D3Tables T, D3Params P3, float cutoff, int n_atoms,
                                                      const float* __restrict__ d3w, double* __restrict__ ecoul,
                                                      float* __restrict__ fgrad, float* __restrict__ virial_atom,
-                                                     float* __restrict__ dEdcn) {
+                                                     float* __restrict__ dEdcn, CoulombParams cp,
+                                                     const float* __restrict__ q, float* __restrict__ qbar) {
+  // DSF = true: the damped-shifted-force Coulomb pair terms (model.hip coulomb_dsf_kernel, same arithmetic) ride on this
+  // pass - one list traversal and one geometry evaluation for both long-range terms when their cutoffs agree.
   extern __shared__ float c6lds[];  // [4 waves][ns][25]: the C6 reference block of the centre's species against every slot
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wid;
@@ -196,7 +201,17 @@ __global__ __launch_bounds__(256) void d3_pair_kernel(const float4* __restrict__
   const float q_i = T.r4r2[si];
   const int cnt = nb_cnt[i];
   D3Acc A;
-  float dcn = 0.0f;
+  float dcn = 0.0f, qb = 0.0f;
+  const float al = cp.dsf_alpha, Rc = cp.dsf_rc;
+  const float two_a_sqrtpi = 2.0f * al * 0.56418958354775629f;
+  float sv = 0.f, slope = 0.f, qc_i = 0.f;
+  const float kratio = cp.factor / HALF_HARTREE_F;  // Coulomb terms are accumulated in units of the D3 prefactor
+  if (DSF) {
+    const float erfc_rc = erfcf(al * Rc);
+    sv = erfc_rc / Rc;
+    slope = erfc_rc / (Rc * Rc) + two_a_sqrtpi * expf(-al * al * Rc * Rc) / Rc;
+    qc_i = q[i];
+  }
   for (int m = lane; m < cnt; m += 64) {
     const D3Pair P = d3_pair(xs4, c, nb_idx, nb_shift, (size_t)i * cap + m, xi, yi, zi, cutoff);
     if (!P.ok) continue;
@@ -248,14 +263,34 @@ __global__ __launch_bounds__(256) void d3_pair_kernel(const float4* __restrict__
       dsw = -30.0f * t2 * (1.0f - 2.0f * t + t2) * iw;
     }
     A.e += (double)(-c6 * damp * sw);
+    float tc = 0.0f;
+    if (DSF) {
+      const float inv = 1.0f / P.d;
+      const float qj = q[P.j];
+      const float ec = erfcf(al * P.d);
+      const float w = ec * inv - sv + (P.d - Rc) * slope;
+      A.ec += (double)(w * qc_i * qj);
+      if (GRAD) {
+        qb += w * qj;
+        tc = kratio * (-ec * inv * inv - two_a_sqrtpi * expf(-al * al * P.d * P.d) * inv + slope) * qc_i * qj;
+      }
+    }
     if (GRAD) {
       const float ddamp = -6.0f * P3.s6 * d4 * db * i6 * i6 - 8.0f * P3.s8 * qq * d6 * db * i8 * i8;
       const float de = -c6 * (ddamp * sw + damp * dsw) * BOHR_INV_F;  // d e_ij / d d_ij per Angstrom, C6 held fixed
-      d3_add<STRESS>(A, de, P.ux, P.uy, P.uz, P.d);
+      d3_add<STRESS>(A, de + tc, P.ux, P.uy, P.uz, P.d);
       if (has) dcn += -damp * sw * (G - c6 * H) * invD;
     }
   }
-  d3_store<GRAD, STRESS>(A, i, lane, HALF_HARTREE_F, ecoul, fgrad, virial_atom);
+  d3_store<GRAD, STRESS>(A, i, lane, HALF_HARTREE_F, ecoul, fgrad, virial_atom, DSF ? (double)cp.factor : 0.0);
+  if (DSF) {  // self term and dE/dq_i of the DSF sum (lr.py:606-613)
+    const float cs = -(sv * 0.5f + al * 0.56418958354775629f);
+    if (GRAD) qb = wave_sum(qb);
+    if (lane == 0) {
+      ecoul[i] += 2.0 * (double)cp.factor * (double)(cs * qc_i * qc_i);
+      if (GRAD) qbar[i] += 2.0f * cp.factor * qb + 4.0f * cp.factor * cs * qc_i;
+    }
+  }
   if (GRAD) {
     dcn = wave_sum(dcn);
     if (lane == 0) dEdcn[i] = 2.0f * HALF_HARTREE_F * dcn;  // e_ij and e_ji both depend on cn_i, symmetrically
@@ -298,7 +333,7 @@ __global__ __launch_bounds__(256) void d3_cnforce_kernel(const float4* __restric
 int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const int* mol_idx, const float* cell, int n_cell,
                  const int* aslot, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, D3Tables T, D3Params P,
                  float cutoff, int n_atoms, float4* xs4, float* d3w, float* dEdcn, double* ecoul, float* fgrad,
-                 float* virial_atom) {
+                 float* virial_atom, bool with_dsf, CoulombParams cp, const float* q, float* qbar) {
   hipLaunchKernelGGL(d3_pack_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, xw, aslot, n_atoms, xs4);
   AIMNET_LAUNCH_CHECK();
   dim3 grid(ceil_div(n_atoms, 4)), block(256);
@@ -306,12 +341,18 @@ int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const i
                      d3w);
   AIMNET_LAUNCH_CHECK();
   const size_t lds = (size_t)4 * T.ns * 25 * sizeof(float);
-#define AIMNET_D3_PAIR(G_, S_)                                                                                            \
-  hipLaunchKernelGGL((d3_pair_kernel<G_, S_>), grid, block, lds, s, xs4, mol_idx, cell, n_cell, nb_idx, nb_shift, nb_cnt, cap, T, \
-                     P, cutoff, n_atoms, d3w, ecoul, fgrad, virial_atom, dEdcn)
-  if (grad && stress) AIMNET_D3_PAIR(true, true);
-  else if (grad) AIMNET_D3_PAIR(true, false);
-  else AIMNET_D3_PAIR(false, false);
+#define AIMNET_D3_PAIR(G_, S_, C_)                                                                                             \
+  hipLaunchKernelGGL((d3_pair_kernel<G_, S_, C_>), grid, block, lds, s, xs4, mol_idx, cell, n_cell, nb_idx, nb_shift, nb_cnt, cap, \
+                     T, P, cutoff, n_atoms, d3w, ecoul, fgrad, virial_atom, dEdcn, cp, q, qbar)
+  if (with_dsf) {
+    if (grad && stress) AIMNET_D3_PAIR(true, true, true);
+    else if (grad) AIMNET_D3_PAIR(true, false, true);
+    else AIMNET_D3_PAIR(false, false, true);
+  } else {
+    if (grad && stress) AIMNET_D3_PAIR(true, true, false);
+    else if (grad) AIMNET_D3_PAIR(true, false, false);
+    else AIMNET_D3_PAIR(false, false, false);
+  }
 #undef AIMNET_D3_PAIR
   AIMNET_LAUNCH_CHECK();
   if (grad) {

@@ -608,8 +608,12 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   RC(prof_mark(e, s, FAM_COULOMB));
   RC(launch_coulomb_sr(s, grad, want_s, ar.sr_coulomb != 0, q_fin, W.nb_idx, W.nb_cnt, W.pg, cap, cp, N, W.ecoul, W.qbar,
                        W.fgrad, W.virial_atom));
+  // DSF and DFT-D3 with one cutoff: the Coulomb pair terms ride on the D3 pair pass (one list, one geometry evaluation)
+  const bool dsf_in_d3 = d3 && coulomb == AIMNET_COULOMB_DSF && opt->d3_cutoff == opt->dsf_rc;
   if (coulomb == AIMNET_COULOMB_SIMPLE)
     RC(launch_coulomb_simple(s, grad, q_fin, W.nl.xw, in->mol_idx, W.nl.mol_start, cp, N, W.ecoul, W.qbar, W.fgrad));
+  else if (dsf_in_d3)
+    ;  // see launch_dftd3 below
   else if (coulomb == AIMNET_COULOMB_DSF && pbc)
     RC(launch_coulomb_dsf_walk(s, grad, want_s, q_fin, in->mol_idx, W.nl, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));
   else if (coulomb == AIMNET_COULOMB_DSF)
@@ -621,7 +625,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     dp.r_on = opt->d3_smoothing_on * 1.8897261258369282f;
     dp.r_off = opt->d3_cutoff * 1.8897261258369282f;
     RC(launch_dftd3(s, grad, want_s, W.nl.xw, in->mol_idx, in->cell, n_cell, W.aslot, W.d3_idx, W.d3_shift, W.d3_cnt, cap_d3,
-                    e->d3, dp, opt->d3_cutoff, N, W.d3xs, W.d3w, W.dEdcn, W.ecoul, W.fgrad, W.virial_atom));
+                    e->d3, dp, opt->d3_cutoff, N, W.d3xs, W.d3w, W.dEdcn, W.ecoul, W.fgrad, W.virial_atom, dsf_in_d3, cp, q_fin,
+                    W.qbar));
   }
   RC(prof_mark(e, s, FAM_POINTWISE));
   RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, W.S, W.part, out->energy));

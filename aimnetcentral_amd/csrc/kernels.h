@@ -80,23 +80,6 @@ int launch_unconcat_p0(hipStream_t s, const float* xbar, int ldx, const float* V
 int launch_conv_bwd_p0(hipStream_t s, bool stress, const float* T, int nslots, const int* aslot, const int* nb_idx,
                        const int* nb_cnt, const float4* pg, int cap, BasisParams bp, float* fgrad, float* virial_atom,
                        int n_atoms, const int* order);
-// ---- d3.hip: DFT-D3(BJ) two-body dispersion on a full neighbour list ------------------------------
-struct D3Params {
-  float s6, s8, a1, a2;
-  float r_on, r_off;  // S5 switch window in Bohr
-};
-struct D3Tables {  // device pointers, indexed by species SLOT (engine.hip: slot_of_z), built from the Z-indexed reference tables
-  int ns;
-  const float* c6slot;  // [ns][ns][5][5]
-  const float* cnref;   // [ns][5]   reference coordination numbers of each element's reference systems
-  const int* nref;      // [ns]      number of reference systems
-  const float* rcov;    // [ns]      covalent radii (Bohr, already scaled as in dftd3_data.pt)
-  const float* r4r2;    // [ns]
-};
-int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const int* mol_idx, const float* cell, int n_cell,
-                 const int* aslot, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, D3Tables T, D3Params P,
-                 float cutoff, int n_atoms, float4* xs4, float* d3w, float* dEdcn, double* ecoul, float* fgrad,
-                 float* virial_atom);
 // stand-alone reference-op forms (conv_sv_2d_sp_wp.py:90-164)
 int launch_conv_sv_fwd(hipStream_t s, const float* a, const int* idx, const float* g, float* out, int B, int A, int G,
                        int M);
@@ -121,6 +104,25 @@ struct CoulombParams {
   int sr_envelope;   // 0 exp, 1 cosine
   float dsf_rc, dsf_alpha;
 };
+
+// ---- d3.hip: DFT-D3(BJ) two-body dispersion on a full neighbour list ------------------------------
+struct D3Params {
+  float s6, s8, a1, a2;
+  float r_on, r_off;  // S5 switch window in Bohr
+};
+struct D3Tables {  // device pointers, indexed by species SLOT (engine.hip: slot_of_z), built from the Z-indexed reference tables
+  int ns;
+  const float* c6slot;  // [ns][ns][5][5]
+  const float* cnref;   // [ns][5]   reference coordination numbers of each element's reference systems
+  const int* nref;      // [ns]      number of reference systems
+  const float* rcov;    // [ns]      covalent radii (Bohr, already scaled as in dftd3_data.pt)
+  const float* r4r2;    // [ns]
+};
+int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const int* mol_idx, const float* cell, int n_cell,
+                 const int* aslot, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, D3Tables T, D3Params P,
+                 float cutoff, int n_atoms, float4* xs4, float* d3w, float* dEdcn, double* ecoul, float* fgrad,
+                 float* virial_atom, bool with_dsf, CoulombParams cp, const float* q, float* qbar);
+// with_dsf: the DSF Coulomb pair sum (cutoff == cp.dsf_rc) is evaluated in the same pair pass; adds to ecoul / qbar too
 // embedded SRCoulomb subtraction over the rc list (sets ecoul/qbar/fgrad/virial_atom)
 int launch_coulomb_sr(hipStream_t s, bool grad, bool stress, bool enabled, const float* q, const int* nb_idx,
                       const int* nb_cnt, const float4* pg, int cap, CoulombParams cp, int n_atoms, double* ecoul,

@@ -204,15 +204,18 @@ def main():
         total_atoms = n_atoms
     assert bool(torch.isfinite(e_all).all()), "non-finite energies"
 
-    if args.breakdown and rank == 0:
+    fam = None
+    if rank == 0:  # after the timed region: 5 extra steps with an event per kernel-family change (untimed, N = 1 view)
         eng.set_profiling(2)
         for _ in range(5):
             step()
         torch.cuda.synchronize(dev)
-        fam = eng.read_profile()
+        fam = {k: v / 5 for k, v in eng.read_profile().items()}
         eng.set_profiling(0)
-        tot = sum(fam.values())
-        print("per-family ms/step: " + "  ".join(f"{k}={v / 5:.3f}" for k, v in fam.items()) + f"  total={tot / 5:.3f}", file=sys.stderr)
+        n_pairs = int(eng.debug_view("nb_cnt").sum().item())  # ordered pairs inside the 5 A cutoff
+        if args.breakdown:
+            print("per-family ms/step: " + "  ".join(f"{k}={v:.3f}" for k, v in fam.items()) + f"  total={sum(fam.values()):.3f}",
+                  file=sys.stderr)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -242,6 +245,15 @@ def main():
                          "kernel": "gemm_nt_panel_kernel (fp32 MFMA MLP GEMMs, all launches of a step)",
                          "gemm_ms_per_step": gemm_ms, "other_ms_per_step": prof["other"] / args.steps,
                          "algorithmic_flop_per_step": flops_step},
+            # second kernel class (SURVEY 8d ii): the gather-contract backward.  Algorithmic gathered bytes per ordered pair:
+            # passes 1, 2 read a_j (1 KiB) + Sbar_j (4 KiB) + Sqbar_j (256 B); pass 0 reads two 256 B species-moment blocks.
+            # These are L2 / Infinity-Cache gathers (the tables are N x 5 KiB << 256 MB), so the roof is the L2 figure of
+            # MI355X_MICROARCH.md (34.5 TB/s), not HBM.
+            "roofline_gather": {"bound": "l2", "kernel": "conv_bwd_kernel + conv_bwd_p0_kernel", "pairs": n_pairs,
+                                "achieved": n_pairs * (2 * 5376 + 512) / (fam["conv_bwd"] * 1e-3) / 1e12, "peak": 34.5,
+                                "unit": "TB/s", "frac": n_pairs * (2 * 5376 + 512) / (fam["conv_bwd"] * 1e-3) / 1e12 / 34.5,
+                                "conv_bwd_ms_per_step": fam["conv_bwd"]},
+            "family_ms_per_step": fam,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)

@@ -424,7 +424,7 @@ __device__ __forceinline__ void rbar_of(float db, float ub0, float ub1, float ub
 }
 
 template <bool HAS_Q, bool NEED_ABAR, bool STRESS>
-__global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
+__global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
                                                       const float* __restrict__ q,
                                                       const float* __restrict__ Sbar, const float* __restrict__ Sqbar,
                                                       const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,

@@ -132,7 +132,10 @@ struct FwdWaveLds {
 // `row_of` (may be NULL): feature row of atom j inside `a`.  Pass 0 gathers straight from the
 // embedding table (a = afv, row_of = atomic numbers): the whole "feature table" is then a few KiB
 // that live in L1 instead of a 1 KiB-per-pair trip to L2 / Infinity Cache.
-template <bool HAS_Q>
+// SPLIT (small systems, <= 1024 atoms): the four waves of a block share ONE centre atom and a quarter of its neighbour
+// row each, partial sums meet in LDS and wave 0 runs the epilogue.  A 113-atom molecule otherwise occupies 113 waves
+// that each walk ~31 dependent gathers; split four ways the chain is 8 long and 4x as many waves hide its latency.
+template <bool HAS_Q, bool SPLIT>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
                                                       const float* __restrict__ q,
                                                       const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
@@ -151,17 +154,27 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
   __syncthreads();
   FwdWaveLds& L = wl[wid];
   const int g4 = (lane & 3) * 4;
+  __shared__ float s_red[SPLIT ? 3 * 17 * 64 : 1];  // SPLIT: accumulators of waves 1..3
 
-  const AtomLoop al = atom_loop(n_atoms, APB);
+  const AtomLoop al = atom_loop(n_atoms, SPLIT ? 1 : APB);
   for (int i0 = al.first; i0 < al.last; i0 += al.step) {
-    const bool live = i0 + wid < al.last;
-    const int i = live ? (order ? order[i0 + wid] : i0 + wid) : 0;  // `order`: spatially sorted processing order
-    const int cnt = live ? nb_cnt[i] : 0;
+    const int aslot = SPLIT ? 0 : wid;  // which atom of this block iteration the wave works on
+    const bool live_atom = i0 + aslot < al.last;
+    const int i = live_atom ? (order ? order[i0 + aslot] : i0 + aslot) : 0;  // `order`: spatially sorted processing order
+    const int cnt_all = live_atom ? nb_cnt[i] : 0;
+    int m_lo = 0, cnt = cnt_all;
     int cmax = cnt;  // block-uniform trip count so that __syncthreads() is legal
+    if (SPLIT) {
+      const int q4 = (cnt_all + 3) >> 2;
+      m_lo = wid * q4;
+      cnt = max(0, min(q4, cnt_all - m_lo));
+      cmax = q4;
+    } else {
 #pragma unroll
-    for (int w = 0; w < APB; ++w) {
-      const int iw = i0 + w;
-      cmax = max(cmax, iw < al.last ? nb_cnt[order ? order[iw] : iw] : 0);
+      for (int w = 0; w < APB; ++w) {
+        const int iw = i0 + w;
+        cmax = max(cmax, iw < al.last ? nb_cnt[order ? order[iw] : iw] : 0);
+      }
     }
     f2 acc[4][2];  // [component c][shift pair]: 2-wide vectors -> v_pk_fma_f32
 #pragma unroll
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
       const int nch = max(0, min(CH, cnt - c0));
       __syncthreads();  // previous chunk fully consumed
       if (lane < nch) {
-        const size_t p = (size_t)i * cap + c0 + lane;
+        const size_t p = (size_t)i * cap + m_lo + c0 + lane;
         const int j = nb_idx[p];
         L.j[lane] = row_of ? min(63, max(0, row_of[j])) : j;
         const float4 ud = pg[p];
@@ -229,6 +242,31 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
       }
     }
     __syncthreads();
+    if (SPLIT) {  // waves 1..3 hand their 17 partial sums per lane to wave 0
+      if (wid > 0) {
+        float* r = s_red + (wid - 1) * 17 * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          r[(4 * c + 0) * 64] = acc[c][0].x; r[(4 * c + 1) * 64] = acc[c][0].y;
+          r[(4 * c + 2) * 64] = acc[c][1].x; r[(4 * c + 3) * 64] = acc[c][1].y;
+        }
+        r[16 * 64] = accq;
+      }
+      __syncthreads();
+      if (wid == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const float* r = s_red + w * 17 * 64 + lane;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            acc[c][0] += mk2(r[(4 * c + 0) * 64], r[(4 * c + 1) * 64]);
+            acc[c][1] += mk2(r[(4 * c + 2) * 64], r[(4 * c + 3) * 64]);
+          }
+          accq += r[16 * 64];
+        }
+      }
+    }
+    const bool live = live_atom && (!SPLIT || wid == 0);
     // ---- epilogue: agh contraction + square-sum, assemble the MLP input row -----------------
     float* sv = &L.gs[0][0];  // reuse: sv[(a*16+g)*3 + k], 768 floats; svq at 768.. (48 floats)
     if (live) {
@@ -292,23 +330,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
   }
 }
 
+constexpr int SPLIT_MAX_ATOMS = 1024;  // up to here a block per atom (4 waves share its neighbour row) still fits one wave of blocks
+
 int launch_conv_fwd(hipStream_t s, bool has_q, const float* a, const int* row_of, const float* q, const int* nb_idx,
                     const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
                     float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order) {
-  const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
-  if (has_q)
-    hipLaunchKernelGGL(conv_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a,
-                       agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order);
-  else
-    hipLaunchKernelGGL(conv_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a,
-                       agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order);
+  const bool split = n_atoms <= SPLIT_MAX_ATOMS;
+  const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), 256 * 8);
+#define AIMNET_FWD(HQ, SP)                                                                                                  \
+  hipLaunchKernelGGL((conv_fwd_kernel<HQ, SP>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a, agh_q, \
+                     bp, x, ldx, Vsave, Vqsave, n_atoms, order)
+  if (has_q) {
+    if (split) AIMNET_FWD(true, true); else AIMNET_FWD(true, false);
+  } else {
+    if (split) AIMNET_FWD(false, true); else AIMNET_FWD(false, false);
+  }
+#undef AIMNET_FWD
   AIMNET_LAUNCH_CHECK();
   return 0;
 }
-
-// ------------------------------------------------------------------------------------------------
-// unconcat: adjoint of the MLP input row -> adjoint of the conv sums:
-//   Sbar[a,g,0] = xbar[256 + a*16+g];  Sbar[a,g,1+k] = sum_h agh[a,g,h] * 2 V[a,h,k] xbar[512 + a*12+h]
 template <bool HAS_Q>
 __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__ xbar, int ldx,
                                                       const float* __restrict__ Vsave, const float* __restrict__ Vqsave,
@@ -423,7 +463,7 @@ __device__ __forceinline__ void rbar_of(float db, float ub0, float ub1, float ub
   r2 = db * u.z + (ub2 - dot * u.z) * inv_d;
 }
 
-template <bool HAS_Q, bool NEED_ABAR, bool STRESS>
+template <bool HAS_Q, bool NEED_ABAR, bool STRESS, bool SPLIT>  // SPLIT: as in conv_fwd_kernel (4 waves per centre atom)
 __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
                                                       const float* __restrict__ q,
                                                       const float* __restrict__ Sbar, const float* __restrict__ Sqbar,
@@ -442,16 +482,28 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
   const float qm0 = qc == 0 ? 1.f : 0.f, qm1 = qc == 1 ? 1.f : 0.f, qm2 = qc == 2 ? 1.f : 0.f, qm3 = qc == 3 ? 1.f : 0.f;
   const float qsgn = qc == 0 ? 1.f : -1.f;
 
-  const AtomLoop al = atom_loop(n_atoms, APB);
+  __shared__ float s_red[SPLIT ? 3 * (4 * 64 + 13) : 1];  // SPLIT: per-lane abar partials + 13 reduced scalars of waves 1..3
+
+  const AtomLoop al = atom_loop(n_atoms, SPLIT ? 1 : APB);
   for (int i0 = al.first; i0 < al.last; i0 += al.step) {
-    const bool live = i0 + wid < al.last;
-    const int i = live ? (order ? order[i0 + wid] : i0 + wid) : 0;
-    const int cnt = live ? nb_cnt[i] : 0;
+    const int aslot = SPLIT ? 0 : wid;
+    const bool live_atom = i0 + aslot < al.last;
+    const bool live = live_atom;  // every wave loads the centre's rows; only the writer differs (see the epilogue)
+    const int i = live_atom ? (order ? order[i0 + aslot] : i0 + aslot) : 0;
+    const int cnt_all = live_atom ? nb_cnt[i] : 0;
+    int m_lo = 0, cnt = cnt_all;
     int cmax = cnt;
+    if (SPLIT) {
+      const int q4 = (cnt_all + 3) >> 2;
+      m_lo = wid * q4;
+      cnt = max(0, min(q4, cnt_all - m_lo));
+      cmax = q4;
+    } else {
 #pragma unroll
-    for (int w = 0; w < APB; ++w) {
-      const int iw = i0 + w;
-      cmax = max(cmax, iw < al.last ? nb_cnt[order ? order[iw] : iw] : 0);
+      for (int w = 0; w < APB; ++w) {
+        const int iw = i0 + w;
+        cmax = max(cmax, iw < al.last ? nb_cnt[order ? order[iw] : iw] : 0);
+      }
     }
     // centre atom's own rows
     // [half]: gi pair (0,1) / (2,3);  Si[c][half]: component c of the centre's Sbar row
@@ -488,7 +540,7 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
       const int nch = max(0, min(CH, cnt - c0));
       __syncthreads();
       if (lane < nch) {
-        const size_t p = (size_t)i * cap + c0 + lane;
+        const size_t p = (size_t)i * cap + m_lo + c0 + lane;
         const int j = nb_idx[p];
         L.j[lane] = j;
         L.jr[lane] = row_of ? min(63, max(0, row_of[j])) : j;
@@ -603,7 +655,31 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
 #pragma unroll
       for (int k = 0; k < 9; ++k) W[k] = wave_sum(W[k]);
     }
-    if (live) {
+    if (SPLIT) {  // waves 1..3 hand their partial sums to wave 0, which writes
+      __syncthreads();
+      if (wid > 0) {
+        float* r = s_red + (wid - 1) * (4 * 64 + 13);
+        r[lane] = ab[0].x; r[64 + lane] = ab[0].y; r[128 + lane] = ab[1].x; r[192 + lane] = ab[1].y;
+        if (lane == 0) {
+          r[256] = xa0; r[257] = xa1; r[258] = xa2; r[259] = qacc;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) r[260 + k] = W[k];
+        }
+      }
+      __syncthreads();
+      if (wid == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const float* r = s_red + w * (4 * 64 + 13);
+          ab[0] += mk2(r[lane], r[64 + lane]);
+          ab[1] += mk2(r[128 + lane], r[192 + lane]);
+          xa0 += r[256]; xa1 += r[257]; xa2 += r[258]; qacc += r[259];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) W[k] += r[260 + k];
+        }
+      }
+    }
+    if (live && (!SPLIT || wid == 0)) {
       if (NEED_ABAR) {
         const float4 xb = reinterpret_cast<const float4*>(xbar + (size_t)i * ldx)[lane];
         float4 o = make_float4(ab[0].x + xb.x, ab[0].y + xb.y, ab[1].x + xb.z, ab[1].y + xb.w);
@@ -633,23 +709,27 @@ int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, cons
                     const float* q, const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
                     int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
                     const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order) {
-  const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
-#define AIMNET_BWD(HQ, NA, ST)                                                                                        \
-  hipLaunchKernelGGL((conv_bwd_kernel<HQ, NA, ST>), dim3(grid), dim3(256), 0, s, a, row_of, q, Sbar, Sqbar, nb_idx, nb_cnt, pg, \
-                     cap, bp, xbar, ldx, abar_in, abar_out, qbar_in, qbar_out, fgrad, virial_atom, n_atoms, order)
+  const bool split = n_atoms <= SPLIT_MAX_ATOMS;
+  const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), 256 * 8);
+#define AIMNET_BWD(HQ, NA, ST, SP)                                                                                        \
+  hipLaunchKernelGGL((conv_bwd_kernel<HQ, NA, ST, SP>), dim3(grid), dim3(256), 0, s, a, row_of, q, Sbar, Sqbar, nb_idx, nb_cnt, \
+                     pg, cap, bp, xbar, ldx, abar_in, abar_out, qbar_in, qbar_out, fgrad, virial_atom, n_atoms, order)
+#define AIMNET_BWD3(HQ, NA, ST) \
+  do { if (split) AIMNET_BWD(HQ, NA, ST, true); else AIMNET_BWD(HQ, NA, ST, false); } while (0)
   if (has_q) {
     if (need_abar) {
-      if (stress) AIMNET_BWD(true, true, true); else AIMNET_BWD(true, true, false);
+      if (stress) AIMNET_BWD3(true, true, true); else AIMNET_BWD3(true, true, false);
     } else {
-      if (stress) AIMNET_BWD(true, false, true); else AIMNET_BWD(true, false, false);
+      if (stress) AIMNET_BWD3(true, false, true); else AIMNET_BWD3(true, false, false);
     }
   } else {
     if (need_abar) {
-      if (stress) AIMNET_BWD(false, true, true); else AIMNET_BWD(false, true, false);
+      if (stress) AIMNET_BWD3(false, true, true); else AIMNET_BWD3(false, true, false);
     } else {
-      if (stress) AIMNET_BWD(false, false, true); else AIMNET_BWD(false, false, false);
+      if (stress) AIMNET_BWD3(false, false, true); else AIMNET_BWD3(false, false, false);
     }
   }
+#undef AIMNET_BWD3
 #undef AIMNET_BWD
   AIMNET_LAUNCH_CHECK();
   return 0;

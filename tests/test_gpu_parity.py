@@ -179,13 +179,15 @@ def test_dftd3_periodic_energy_forces_stress_vs_oracle(hip_engine, oracle32, rc_
     compare(a, ref, 96, f"pbc96+d3 rc {rc_d3}/{rc_dsf}")
 
 
-def test_dftd3_nonperiodic_dsf_shares_the_list(hip_engine, oracle32):
-    """Non-periodic DSF and D3 with one cutoff use ONE neighbour matrix (engine.hip d3_shares_lr_list)."""
+@pytest.mark.parametrize("rc_dsf", [9.0, 12.0])
+def test_dftd3_nonperiodic_dsf_list_sharing(hip_engine, oracle32, rc_dsf):
+    """Non-periodic DSF and D3: with one cutoff they use ONE neighbour matrix and one pair pass (engine.hip
+    d3_shares_lr_list / dsf_in_d3), with different cutoffs two lists and separate kernels."""
     g = golden("dftd3")
     par, tables = _d3(9.0, 0.25)
     hip_engine.set_dftd3_tables(tables)
     mol = g["batch_mol_idx"]
-    a, _ = _run_d3(hip_engine, g["batch_coord"], g["batch_numbers"], mol, "dsf", par, dsf_rc=9.0)
-    ref = O.evaluate(oracle32, g["batch_coord"], g["batch_numbers"], np.zeros(5, np.float32), mol, coulomb="dsf", dsf_rc=9.0,
+    a, _ = _run_d3(hip_engine, g["batch_coord"], g["batch_numbers"], mol, "dsf", par, dsf_rc=rc_dsf)
+    ref = O.evaluate(oracle32, g["batch_coord"], g["batch_numbers"], np.zeros(5, np.float32), mol, coulomb="dsf", dsf_rc=rc_dsf,
                      dftd3=dict(par, **tables))
-    compare(a, ref, np.bincount(mol), "batch5 dsf9 + d3")
+    compare(a, ref, np.bincount(mol), f"batch5 dsf{rc_dsf} + d3")

@@ -60,6 +60,7 @@ class Arch(C.Structure):
         ("sr_coulomb", C.c_int32),
         ("sr_envelope", C.c_int32),
         ("sr_rc", C.c_float),
+        ("n_charge_channels", C.c_int32),
     ]
 
 
@@ -128,6 +129,7 @@ class Outputs(C.Structure):
         ("forces", C.c_void_p),
         ("stress", C.c_void_p),
         ("status", C.c_void_p),
+        ("spin_charges", C.c_void_p),
     ]
 
 

@@ -126,7 +126,7 @@ struct FwdWaveLds {
   float4 ud[CH];      // (ux, uy, uz, d)
   int j[CH];
   float fc[CH];       // cutoff envelope fc(d) of the chunk (one sincos per pair)
-  float qj[CH];       // neighbour charges
+  float qj[2][CH];    // neighbour charges, one row per charge channel
 };
 
 // `row_of` (may be NULL): feature row of atom j inside `a`.  Pass 0 gathers straight from the
@@ -135,7 +135,9 @@ struct FwdWaveLds {
 // SPLIT (small systems, <= 1024 atoms): the four waves of a block share ONE centre atom and a quarter of its neighbour
 // row each, partial sums meet in LDS and wave 0 runs the epilogue.  A 113-atom molecule otherwise occupies 113 waves
 // that each walk ~31 dependent gathers; split four ways the chain is 8 long and 4x as many waves hide its latency.
-template <bool HAS_Q, bool SPLIT>
+// NQ: charge channels convolved alongside the features: 0 (pass 0), 1, or 2 (NSE models; q = planes [NQ][n_atoms],
+// agh_q [NQ][G][H], row layout [q (NQ) | S^q_s (NQ x 16) | |V^q|^2 (NQ x 12)] as ConvSV(nchannel=NQ) emits it, aev.py:188).
+template <int NQ, bool SPLIT>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
                                                       const float* __restrict__ q,
                                                       const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
@@ -146,15 +148,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
                                                       const int* __restrict__ order) {
   __shared__ __attribute__((aligned(16))) FwdWaveLds wl[APB];
   __shared__ float s_agh[A_ * G_ * H_];
-  __shared__ float s_aghq[G_ * H_];
+  constexpr bool HAS_Q = NQ > 0;
+  constexpr int NQC = NQ > 0 ? NQ : 1;
+  __shared__ float s_aghq[NQC * G_ * H_];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   for (int k = threadIdx.x; k < A_ * G_ * H_; k += 256) s_agh[k] = agh_a[k];
   if (HAS_Q)
-    for (int k = threadIdx.x; k < G_ * H_; k += 256) s_aghq[k] = agh_q[k];
+    for (int k = threadIdx.x; k < NQ * G_ * H_; k += 256) s_aghq[k] = agh_q[k];
   __syncthreads();
   FwdWaveLds& L = wl[wid];
   const int g4 = (lane & 3) * 4;
-  __shared__ float s_red[SPLIT ? 3 * 17 * 64 : 1];  // SPLIT: accumulators of waves 1..3
+  __shared__ float s_red[SPLIT ? 3 * (16 + NQC) * 64 : 1];  // SPLIT: accumulators of waves 1..3
 
   const AtomLoop al = atom_loop(n_atoms, SPLIT ? 1 : APB);
   for (int i0 = al.first; i0 < al.last; i0 += al.step) {
@@ -179,7 +183,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
     f2 acc[4][2];  // [component c][shift pair]: 2-wide vectors -> v_pk_fma_f32
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c][0] = acc[c][1] = mk2(0.f, 0.f);
-    float accq = 0.0f;
+    float accq[NQC];
+#pragma unroll
+    for (int ch = 0; ch < NQC; ++ch) accq[ch] = 0.0f;
 
     for (int c0 = 0; c0 < cmax; c0 += CH) {
       const int nch = max(0, min(CH, cnt - c0));
@@ -192,12 +198,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
         L.ud[lane] = ud;
         float dfc;
         L.fc[lane] = basis_fc(bp, ud.w, dfc);
-        if (HAS_Q) L.qj[lane] = q[j];
+#pragma unroll
+        for (int ch = 0; ch < NQ; ++ch) L.qj[ch][lane] = q[(size_t)ch * n_atoms + j];
       } else {  // slots past the row end: a valid row with zero weight (the pipelined loop rounds up to 4)
         L.j[lane] = 0;
         L.ud[lane] = make_float4(0.f, 0.f, 0.f, 1.f);
         L.fc[lane] = 0.f;
-        if (HAS_Q) L.qj[lane] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NQ; ++ch) L.qj[ch][lane] = 0.f;
       }
       __syncthreads();
 #pragma unroll
@@ -229,7 +237,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
         acc[1][0] += t0 * u.x; acc[1][1] += t1 * u.x;
         acc[2][0] += t0 * u.y; acc[2][1] += t1 * u.y;
         acc[3][0] += t0 * u.z; acc[3][1] += t1 * u.z;
-        if (HAS_Q) accq += L.qj[mm] * L.gs[mm][lane >> 2] * (fm0 + fm1 * u.x + fm2 * u.y + fm3 * u.z);
+        if (HAS_Q) {
+          const float w = L.gs[mm][lane >> 2] * (fm0 + fm1 * u.x + fm2 * u.y + fm3 * u.z);
+#pragma unroll
+          for (int ch = 0; ch < NQ; ++ch) accq[ch] += L.qj[ch][mm] * w;
+        }
       };
       const int nch4 = (nch + 3) & ~3;  // rows >= nch have gs = 0 and a valid (clamped) index: harmless
       float4 r0 = row(0), r1 = row(1), r2 = row(2), r3 = row(3);
@@ -242,33 +254,35 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
       }
     }
     __syncthreads();
-    if (SPLIT) {  // waves 1..3 hand their 17 partial sums per lane to wave 0
+    if (SPLIT) {  // waves 1..3 hand their 16 + NQ partial sums per lane to wave 0
       if (wid > 0) {
-        float* r = s_red + (wid - 1) * 17 * 64 + lane;
+        float* r = s_red + (wid - 1) * (16 + NQC) * 64 + lane;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           r[(4 * c + 0) * 64] = acc[c][0].x; r[(4 * c + 1) * 64] = acc[c][0].y;
           r[(4 * c + 2) * 64] = acc[c][1].x; r[(4 * c + 3) * 64] = acc[c][1].y;
         }
-        r[16 * 64] = accq;
+#pragma unroll
+        for (int ch = 0; ch < NQC; ++ch) r[(16 + ch) * 64] = accq[ch];
       }
       __syncthreads();
       if (wid == 0) {
 #pragma unroll
         for (int w = 0; w < 3; ++w) {
-          const float* r = s_red + w * 17 * 64 + lane;
+          const float* r = s_red + w * (16 + NQC) * 64 + lane;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             acc[c][0] += mk2(r[(4 * c + 0) * 64], r[(4 * c + 1) * 64]);
             acc[c][1] += mk2(r[(4 * c + 2) * 64], r[(4 * c + 3) * 64]);
           }
-          accq += r[16 * 64];
+#pragma unroll
+          for (int ch = 0; ch < NQC; ++ch) accq[ch] += r[(16 + ch) * 64];
         }
       }
     }
     const bool live = live_atom && (!SPLIT || wid == 0);
     // ---- epilogue: agh contraction + square-sum, assemble the MLP input row -----------------
-    float* sv = &L.gs[0][0];  // reuse: sv[(a*16+g)*3 + k], 768 floats; svq at 768.. (48 floats)
+    float* sv = &L.gs[0][0];  // reuse: sv[(a*16+g)*3 + k], 768 floats; svq at 768.. (48 floats per charge channel)
     if (live) {
 #pragma unroll
       for (int gi = 0; gi < 4; ++gi) {
@@ -277,7 +291,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
         sv[f * 3 + 1] = acc[2][gi >> 1][gi & 1];
         sv[f * 3 + 2] = acc[3][gi >> 1][gi & 1];
       }
-      if (HAS_Q && (lane & 3) != 0) sv[768 + (lane >> 2) * 3 + (lane & 3) - 1] = accq;
+      if (HAS_Q && (lane & 3) != 0) {
+#pragma unroll
+        for (int ch = 0; ch < NQ; ++ch) sv[768 + ch * 48 + (lane >> 2) * 3 + (lane & 3) - 1] = accq[ch];
+      }
       float* xr = x + (size_t)i * ldx;
       const int ri = row_of ? min(63, max(0, row_of[i])) : i;
       reinterpret_cast<float4*>(xr)[lane] = reinterpret_cast<const float4*>(a + (size_t)ri * NF)[lane];
@@ -305,22 +322,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
       }
       if (HAS_Q) {
         const int c0 = 2 * NF + NV;  // 704
-        if (lane == 0) xr[c0] = q[i];
-        if ((lane & 3) == 0) xr[c0 + 1 + (lane >> 2)] = accq;
-        if (lane < H_) {
-          float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if (lane < NQ) xr[c0 + lane] = q[(size_t)lane * n_atoms + i];
 #pragma unroll
-          for (int g = 0; g < G_; ++g) {
-            const float w = s_aghq[g * H_ + lane];
-            v0 += w * sv[768 + g * 3 + 0];
-            v1 += w * sv[768 + g * 3 + 1];
-            v2 += w * sv[768 + g * 3 + 2];
+        for (int ch = 0; ch < NQ; ++ch) {
+          if ((lane & 3) == 0) xr[c0 + NQ + ch * G_ + (lane >> 2)] = accq[ch];
+          if (lane < H_) {
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int g = 0; g < G_; ++g) {
+              const float w = s_aghq[(ch * G_ + g) * H_ + lane];
+              v0 += w * sv[768 + ch * 48 + g * 3 + 0];
+              v1 += w * sv[768 + ch * 48 + g * 3 + 1];
+              v2 += w * sv[768 + ch * 48 + g * 3 + 2];
+            }
+            float* vs = Vqsave + ((size_t)i * NQ + ch) * (H_ * 3) + lane * 3;
+            vs[0] = v0; vs[1] = v1; vs[2] = v2;
+            xr[c0 + NQ + NQ * G_ + ch * H_ + lane] = v0 * v0 + v1 * v1 + v2 * v2;
           }
-          float* vs = Vqsave + (size_t)i * (H_ * 3) + lane * 3;
-          vs[0] = v0; vs[1] = v1; vs[2] = v2;
-          xr[c0 + 1 + G_ + lane] = v0 * v0 + v1 * v1 + v2 * v2;
         }
-        const int used = c0 + 1 + G_ + H_;  // 733
+        const int used = c0 + NQ * (1 + G_ + H_);  // 733 (762 with two channels)
         if (lane < ldx - used) xr[used + lane] = 0.0f;  // zero the K padding of the GEMM operand
       } else {
         const int used = 2 * NF + NV;
@@ -332,7 +352,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
 
 constexpr int SPLIT_MAX_ATOMS = 1024;  // up to here a block per atom (4 waves share its neighbour row) still fits one wave of blocks
 
-int launch_conv_fwd(hipStream_t s, bool has_q, const float* a, const int* row_of, const float* q, const int* nb_idx,
+int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, const float* q, const int* nb_idx,
                     const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
                     float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order) {
   const bool split = n_atoms <= SPLIT_MAX_ATOMS;
@@ -340,27 +360,31 @@ int launch_conv_fwd(hipStream_t s, bool has_q, const float* a, const int* row_of
 #define AIMNET_FWD(HQ, SP)                                                                                                  \
   hipLaunchKernelGGL((conv_fwd_kernel<HQ, SP>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a, agh_q, \
                      bp, x, ldx, Vsave, Vqsave, n_atoms, order)
-  if (has_q) {
-    if (split) AIMNET_FWD(true, true); else AIMNET_FWD(true, false);
+  if (nq == 2) {
+    if (split) AIMNET_FWD(2, true); else AIMNET_FWD(2, false);
+  } else if (nq == 1) {
+    if (split) AIMNET_FWD(1, true); else AIMNET_FWD(1, false);
   } else {
-    if (split) AIMNET_FWD(false, true); else AIMNET_FWD(false, false);
+    if (split) AIMNET_FWD(0, true); else AIMNET_FWD(0, false);
   }
 #undef AIMNET_FWD
   AIMNET_LAUNCH_CHECK();
   return 0;
 }
-template <bool HAS_Q>
+template <int NQ>  // charge channels, as in conv_fwd_kernel; Vqsave [N][NQ][H*3], Sqbar [N][NQ][G*4]
 __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__ xbar, int ldx,
                                                       const float* __restrict__ Vsave, const float* __restrict__ Vqsave,
                                                       const float* __restrict__ agh_a, const float* __restrict__ agh_q,
                                                       float* __restrict__ Sbar, float* __restrict__ Sqbar, int n_atoms) {
+  constexpr bool HAS_Q = NQ > 0;
+  constexpr int NQC = NQ > 0 ? NQ : 1;
   __shared__ float s_agh[A_ * G_ * H_];
-  __shared__ float s_aghq[G_ * H_];
-  __shared__ float s_vb[APB][NV * 3 + H_ * 3];
+  __shared__ float s_aghq[NQC * G_ * H_];
+  __shared__ float s_vb[APB][NV * 3 + NQC * H_ * 3];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   for (int k = threadIdx.x; k < A_ * G_ * H_; k += 256) s_agh[k] = agh_a[k];
   if (HAS_Q)
-    for (int k = threadIdx.x; k < G_ * H_; k += 256) s_aghq[k] = agh_q[k];
+    for (int k = threadIdx.x; k < NQ * G_ * H_; k += 256) s_aghq[k] = agh_q[k];
   float* vb = s_vb[wid];
   const AtomLoop al = atom_loop(n_atoms, APB);
   for (int i0 = al.first; i0 < al.last; i0 += al.step) {
@@ -379,11 +403,14 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
         vb[o * 3 + 2] = f * vs[2];
       }
       if (HAS_Q && lane < H_) {
-        const float f = 2.0f * xr[2 * NF + NV + 1 + G_ + lane];
-        const float* vs = Vqsave + (size_t)i * (H_ * 3) + lane * 3;
-        vb[NV * 3 + lane * 3 + 0] = f * vs[0];
-        vb[NV * 3 + lane * 3 + 1] = f * vs[1];
-        vb[NV * 3 + lane * 3 + 2] = f * vs[2];
+#pragma unroll
+        for (int ch = 0; ch < NQ; ++ch) {
+          const float f = 2.0f * xr[2 * NF + NV + NQ + NQ * G_ + ch * H_ + lane];
+          const float* vs = Vqsave + ((size_t)i * NQ + ch) * (H_ * 3) + lane * 3;
+          vb[NV * 3 + ch * (H_ * 3) + lane * 3 + 0] = f * vs[0];
+          vb[NV * 3 + ch * (H_ * 3) + lane * 3 + 1] = f * vs[1];
+          vb[NV * 3 + ch * (H_ * 3) + lane * 3 + 2] = f * vs[2];
+        }
       }
     }
     __syncthreads();
@@ -416,28 +443,34 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
       out[3] = make_float4(vv[2][0], vv[2][1], vv[2][2], vv[2][3]);
       if (HAS_Q) {
         const int g = lane >> 2, c = lane & 3;
-        float v;
-        if (c == 0) {
-          v = xr[2 * NF + NV + 1 + g];
-        } else {
-          v = 0.f;
 #pragma unroll
-          for (int h = 0; h < H_; ++h) v += s_aghq[g * H_ + h] * vb[NV * 3 + h * 3 + c - 1];
+        for (int ch = 0; ch < NQ; ++ch) {
+          float v;
+          if (c == 0) {
+            v = xr[2 * NF + NV + NQ + ch * G_ + g];
+          } else {
+            v = 0.f;
+#pragma unroll
+            for (int h = 0; h < H_; ++h) v += s_aghq[(ch * G_ + g) * H_ + h] * vb[NV * 3 + ch * (H_ * 3) + h * 3 + c - 1];
+          }
+          Sqbar[((size_t)i * NQ + ch) * (G_ * 4) + lane] = v;
         }
-        Sqbar[(size_t)i * (G_ * 4) + lane] = v;
       }
     }
   }
 }
 
-int launch_unconcat(hipStream_t s, bool has_q, const float* xbar, int ldx, const float* Vsave, const float* Vqsave,
+int launch_unconcat(hipStream_t s, int nq, const float* xbar, int ldx, const float* Vsave, const float* Vqsave,
                     const float* agh_a, const float* agh_q, float* Sbar, float* Sqbar, int n_atoms) {
   const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
-  if (has_q)
-    hipLaunchKernelGGL(unconcat_kernel<true>, dim3(grid), dim3(256), 0, s, xbar, ldx, Vsave, Vqsave, agh_a, agh_q, Sbar,
+  if (nq == 2)
+    hipLaunchKernelGGL(unconcat_kernel<2>, dim3(grid), dim3(256), 0, s, xbar, ldx, Vsave, Vqsave, agh_a, agh_q, Sbar,
+                       Sqbar, n_atoms);
+  else if (nq == 1)
+    hipLaunchKernelGGL(unconcat_kernel<1>, dim3(grid), dim3(256), 0, s, xbar, ldx, Vsave, Vqsave, agh_a, agh_q, Sbar,
                        Sqbar, n_atoms);
   else
-    hipLaunchKernelGGL(unconcat_kernel<false>, dim3(grid), dim3(256), 0, s, xbar, ldx, Vsave, Vqsave, agh_a, agh_q, Sbar,
+    hipLaunchKernelGGL(unconcat_kernel<0>, dim3(grid), dim3(256), 0, s, xbar, ldx, Vsave, Vqsave, agh_a, agh_q, Sbar,
                        Sqbar, n_atoms);
   AIMNET_LAUNCH_CHECK();
   return 0;
@@ -450,7 +483,7 @@ struct BwdWaveLds {
   float4 ud[CH];
   int j[CH];      // neighbour atom
   int jr[CH];     // its feature row (atomic number in pass 0)
-  float qj[CH];
+  float qj[2][CH];  // neighbour charges per charge channel
   float fc[CH], dfc[CH];
 };
 
@@ -463,7 +496,8 @@ __device__ __forceinline__ void rbar_of(float db, float ub0, float ub1, float ub
   r2 = db * u.z + (ub2 - dot * u.z) * inv_d;
 }
 
-template <bool HAS_Q, bool NEED_ABAR, bool STRESS, bool SPLIT>  // SPLIT: as in conv_fwd_kernel (4 waves per centre atom)
+// NQ: charge channels (0, 1, 2) as in conv_fwd_kernel: q / qbar planes [NQ][n_atoms], Sqbar [N][NQ][G*4]
+template <int NQ, bool NEED_ABAR, bool STRESS, bool SPLIT>  // SPLIT: as in conv_fwd_kernel (4 waves per centre atom)
 __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
                                                       const float* __restrict__ q,
                                                       const float* __restrict__ Sbar, const float* __restrict__ Sqbar,
@@ -474,6 +508,8 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
                                                       const float* __restrict__ qbar_in, float* __restrict__ qbar_out,
                                                       float* __restrict__ fgrad, float* __restrict__ virial_atom,
                                                       int n_atoms, const int* __restrict__ order) {
+  constexpr bool HAS_Q = NQ > 0;
+  constexpr int NQC = NQ > 0 ? NQ : 1;
   __shared__ __attribute__((aligned(16))) BwdWaveLds wl[APB];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   BwdWaveLds& L = wl[wid];
@@ -482,7 +518,7 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
   const float qm0 = qc == 0 ? 1.f : 0.f, qm1 = qc == 1 ? 1.f : 0.f, qm2 = qc == 2 ? 1.f : 0.f, qm3 = qc == 3 ? 1.f : 0.f;
   const float qsgn = qc == 0 ? 1.f : -1.f;
 
-  __shared__ float s_red[SPLIT ? 3 * (4 * 64 + 13) : 1];  // SPLIT: per-lane abar partials + 13 reduced scalars of waves 1..3
+  __shared__ float s_red[SPLIT ? 3 * (4 * 64 + 14) : 1];  // SPLIT: per-lane abar partials + 14 reduced scalars of waves 1..3
 
   const AtomLoop al = atom_loop(n_atoms, SPLIT ? 1 : APB);
   for (int i0 = al.first; i0 < al.last; i0 += al.step) {
@@ -511,7 +547,9 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
     f2 Si[4][2];
 #pragma unroll
     for (int c = 0; c < 4; ++c) Si[c][0] = Si[c][1] = mk2(0.f, 0.f);
-    float qi = 0.0f, Sqi = 0.0f;
+    float qi[NQC], Sqi[NQC];
+#pragma unroll
+    for (int ch = 0; ch < NQC; ++ch) qi[ch] = Sqi[ch] = 0.0f;
     if (live) {
       const int ri = row_of ? min(63, max(0, row_of[i])) : i;
       const float4 t = reinterpret_cast<const float4*>(a + (size_t)ri * NF)[lane];
@@ -524,14 +562,17 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
         Si[c][0] = mk2(v.x, v.y);
         Si[c][1] = mk2(v.z, v.w);
       }
-      if (HAS_Q) {
-        qi = q[i];
-        Sqi = Sqbar[(size_t)i * (G_ * 4) + lane];
+#pragma unroll
+      for (int ch = 0; ch < NQ; ++ch) {
+        qi[ch] = q[(size_t)ch * n_atoms + i];
+        Sqi[ch] = Sqbar[((size_t)i * NQ + ch) * (G_ * 4) + lane];
       }
     }
     f2 ab[2] = {mk2(0.f, 0.f), mk2(0.f, 0.f)};
     float xa0 = 0.f, xa1 = 0.f, xa2 = 0.f;  // per-lane partial of dE/dx_i
-    float qacc = 0.0f;
+    float qacc[NQC];
+#pragma unroll
+    for (int ch = 0; ch < NQC; ++ch) qacc[ch] = 0.0f;
     float W[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) W[k] = 0.0f;
@@ -549,7 +590,8 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
         float dfc;
         L.fc[lane] = basis_fc(bp, ud.w, dfc);  // one sincos per pair, not per (pair, shift)
         L.dfc[lane] = dfc;
-        if (HAS_Q) L.qj[lane] = q[j];
+#pragma unroll
+        for (int ch = 0; ch < NQ; ++ch) L.qj[ch][lane] = q[(size_t)ch * n_atoms + j];
       }
       __syncthreads();
 #pragma unroll
@@ -571,7 +613,9 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
       // software pipeline: the 80 B per lane of neighbour mm+1 are requested before neighbour mm is
       // consumed, so the L2 / Infinity-Cache latency of the gather hides under ~110 VALU instructions
       float4 n_aj, n_s0, n_s1, n_s2, n_s3;
-      float n_sq = 0.f;
+      float n_sq[NQC];
+#pragma unroll
+      for (int ch = 0; ch < NQC; ++ch) n_sq[ch] = 0.f;
       {
         // neighbour ids are wave-uniform: readfirstlane moves them to SGPRs, so the row addresses are
         // scalar (saddr-form global loads, no per-lane 64-bit address arithmetic on the VALU)
@@ -580,18 +624,22 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
         n_aj = reinterpret_cast<const float4*>(a + (size_t)jrn * NF)[lane];
         const float4* spn = reinterpret_cast<const float4*>(Sbar + (size_t)jn * (NF * 4)) + lane * 4;
         n_s0 = spn[0]; n_s1 = spn[1]; n_s2 = spn[2]; n_s3 = spn[3];
-        if (HAS_Q) n_sq = Sqbar[(size_t)jn * (G_ * 4) + lane];
+#pragma unroll
+        for (int ch = 0; ch < NQ; ++ch) n_sq[ch] = Sqbar[((size_t)jn * NQ + ch) * (G_ * 4) + lane];
       }
       for (int mm = 0; mm < nch; ++mm) {
         const float4 ajv = n_aj, sj0 = n_s0, sj1 = n_s1, sj2 = n_s2, sj3 = n_s3;
-        const float sqj_cur = n_sq;
+        float sqj_cur[NQC];
+#pragma unroll
+        for (int ch = 0; ch < NQC; ++ch) sqj_cur[ch] = n_sq[ch];
         {
           const int mn = min(mm + 1, nch - 1);
           const int jn = __builtin_amdgcn_readfirstlane(L.j[mn]), jrn = __builtin_amdgcn_readfirstlane(L.jr[mn]);
           n_aj = reinterpret_cast<const float4*>(a + (size_t)jrn * NF)[lane];
           const float4* spn = reinterpret_cast<const float4*>(Sbar + (size_t)jn * (NF * 4)) + lane * 4;
           n_s0 = spn[0]; n_s1 = spn[1]; n_s2 = spn[2]; n_s3 = spn[3];
-          if (HAS_Q) n_sq = Sqbar[(size_t)jn * (G_ * 4) + lane];
+#pragma unroll
+          for (int ch = 0; ch < NQ; ++ch) n_sq[ch] = Sqbar[((size_t)jn * NQ + ch) * (G_ * 4) + lane];
         }
         const float4 gv = *reinterpret_cast<const float4*>(&L.gs[mm][g4]);
         const float4 dgv = *reinterpret_cast<const float4*>(&L.dgs[mm][g4]);
@@ -623,17 +671,20 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
         if (HAS_Q) {
           // lane (g, c) of the charge convolution Sq[g,c] = sum_m q_j gs_g (1,u)_c, branch-free:
           // qm0..qm3 are the lane's one-hot component selectors, qsgn = (1,-1,-1,-1)[c] for the reverse pair
-          const float sqj = sqj_cur;
           const float gq = L.gs[mm][qg], dgq = L.dgs[mm][qg];
           const float uc = qm0 + qm1 * u.x + qm2 * u.y + qm3 * u.z;
-          const float qj = L.qj[mm];
-          const float sj_s = sqj * qsgn;
-          qacc += gq * sj_s * uc;
-          D += dgq * uc * (qj * Sqi + qi * sj_s);
-          const float v = gq * (qi * sqj - qj * Sqi);
-          U0 += qm1 * v;
-          U1 += qm2 * v;
-          U2 += qm3 * v;
+#pragma unroll
+          for (int ch = 0; ch < NQ; ++ch) {
+            const float sqj = sqj_cur[ch];
+            const float qj = L.qj[ch][mm];
+            const float sj_s = sqj * qsgn;
+            qacc[ch] += gq * sj_s * uc;
+            D += dgq * uc * (qj * Sqi[ch] + qi[ch] * sj_s);
+            const float v = gq * (qi[ch] * sqj - qj * Sqi[ch]);
+            U0 += qm1 * v;
+            U1 += qm2 * v;
+            U2 += qm3 * v;
+          }
         }
         const float dot = U0 * u.x + U1 * u.y + U2 * u.z;
         const float f0 = (U0 - dot * u.x) * inv_d - D * u.x;
@@ -650,7 +701,8 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
     }
     // ---- epilogue ---------------------------------------------------------------------------
     xa0 = wave_sum(xa0); xa1 = wave_sum(xa1); xa2 = wave_sum(xa2);
-    if (HAS_Q) qacc = wave_sum(qacc);
+#pragma unroll
+    for (int ch = 0; ch < NQ; ++ch) qacc[ch] = wave_sum(qacc[ch]);
     if (STRESS) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) W[k] = wave_sum(W[k]);
@@ -658,24 +710,28 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
     if (SPLIT) {  // waves 1..3 hand their partial sums to wave 0, which writes
       __syncthreads();
       if (wid > 0) {
-        float* r = s_red + (wid - 1) * (4 * 64 + 13);
+        float* r = s_red + (wid - 1) * (4 * 64 + 14);
         r[lane] = ab[0].x; r[64 + lane] = ab[0].y; r[128 + lane] = ab[1].x; r[192 + lane] = ab[1].y;
         if (lane == 0) {
-          r[256] = xa0; r[257] = xa1; r[258] = xa2; r[259] = qacc;
+          r[256] = xa0; r[257] = xa1; r[258] = xa2;
 #pragma unroll
-          for (int k = 0; k < 9; ++k) r[260 + k] = W[k];
+          for (int ch = 0; ch < NQC; ++ch) r[259 + ch] = qacc[ch];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) r[261 + k] = W[k];
         }
       }
       __syncthreads();
       if (wid == 0) {
 #pragma unroll
         for (int w = 0; w < 3; ++w) {
-          const float* r = s_red + w * (4 * 64 + 13);
+          const float* r = s_red + w * (4 * 64 + 14);
           ab[0] += mk2(r[lane], r[64 + lane]);
           ab[1] += mk2(r[128 + lane], r[192 + lane]);
-          xa0 += r[256]; xa1 += r[257]; xa2 += r[258]; qacc += r[259];
+          xa0 += r[256]; xa1 += r[257]; xa2 += r[258];
 #pragma unroll
-          for (int k = 0; k < 9; ++k) W[k] += r[260 + k];
+          for (int ch = 0; ch < NQC; ++ch) qacc[ch] += r[259 + ch];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) W[k] += r[261 + k];
         }
       }
     }
@@ -693,7 +749,9 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
         fgrad[3 * i + 0] += xa0;
         fgrad[3 * i + 1] += xa1;
         fgrad[3 * i + 2] += xa2;
-        if (HAS_Q) qbar_out[i] = qbar_in[i] + xbar[(size_t)i * ldx + 2 * NF + NV] + qacc;
+#pragma unroll
+        for (int ch = 0; ch < NQ; ++ch)
+          qbar_out[(size_t)ch * n_atoms + i] = qbar_in[(size_t)ch * n_atoms + i] + xbar[(size_t)i * ldx + 2 * NF + NV + ch] + qacc[ch];
       }
       if (STRESS && lane < 9) {
         float v = W[0];
@@ -705,7 +763,7 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
   }
 }
 
-int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, const float* a, const int* row_of,
+int launch_conv_bwd(hipStream_t s, int nq, bool need_abar, bool stress, const float* a, const int* row_of,
                     const float* q, const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
                     int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
                     const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order) {
@@ -716,17 +774,23 @@ int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, cons
                      pg, cap, bp, xbar, ldx, abar_in, abar_out, qbar_in, qbar_out, fgrad, virial_atom, n_atoms, order)
 #define AIMNET_BWD3(HQ, NA, ST) \
   do { if (split) AIMNET_BWD(HQ, NA, ST, true); else AIMNET_BWD(HQ, NA, ST, false); } while (0)
-  if (has_q) {
+  if (nq == 2) {  // NSE models convolve charges in every pass that reaches here with need_abar
     if (need_abar) {
-      if (stress) AIMNET_BWD3(true, true, true); else AIMNET_BWD3(true, true, false);
+      if (stress) AIMNET_BWD3(2, true, true); else AIMNET_BWD3(2, true, false);
     } else {
-      if (stress) AIMNET_BWD3(true, false, true); else AIMNET_BWD3(true, false, false);
+      if (stress) AIMNET_BWD3(2, false, true); else AIMNET_BWD3(2, false, false);
+    }
+  } else if (nq == 1) {
+    if (need_abar) {
+      if (stress) AIMNET_BWD3(1, true, true); else AIMNET_BWD3(1, true, false);
+    } else {
+      if (stress) AIMNET_BWD3(1, false, true); else AIMNET_BWD3(1, false, false);
     }
   } else {
     if (need_abar) {
-      if (stress) AIMNET_BWD3(false, true, true); else AIMNET_BWD3(false, true, false);
+      if (stress) AIMNET_BWD3(0, true, true); else AIMNET_BWD3(0, true, false);
     } else {
-      if (stress) AIMNET_BWD3(false, false, true); else AIMNET_BWD3(false, false, false);
+      if (stress) AIMNET_BWD3(0, false, true); else AIMNET_BWD3(0, false, false);
     }
   }
 #undef AIMNET_BWD3

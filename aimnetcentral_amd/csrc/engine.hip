@@ -44,6 +44,7 @@ using namespace aimnet;
 
 struct aimnet_engine {
   aimnet_arch arch;
+  int nq = 1;  // charge channels (arch.n_charge_channels, 0 -> 1)
   int device;
   std::vector<void*> allocs;
   float *afv, *agh_a, *agh_q;
@@ -158,6 +159,7 @@ struct Workspace {
   float* e_atom;
   double* ecoul;
   float *qbar, *fgrad, *virial_atom, *abar, *Wbar;
+  float* qtot;   // NSE models: alpha + beta charges (the Coulomb kernels and the `charges` output see these)
   double* part;  // per-(system, slice) partial sums of the molecule reductions
   int S;         // slices per molecule
   float *zb0, *zb1;  // ping-pong adjoint buffers (N x max padded width)
@@ -220,20 +222,20 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
     snprintf(name, sizeof name, "a%d", p);
     W.a[p] = c.take<float>(n * 256, name, 256);
     snprintf(name, sizeof name, "q%d", p);
-    W.q[p] = c.take<float>(n, name, 1);
+    W.q[p] = c.take<float>(n * e->nq, name, 1);
     const int ldx = e->mlp[p][0].k_in;
     snprintf(name, sizeof name, "x%d", p);
     W.x[p] = c.take<float>(n * ldx, name, ldx);
     W.V[p] = c.take<float>(n * 576);
-    W.Vq[p] = c.take<float>(n * 36);
+    W.Vq[p] = c.take<float>(n * 36 * e->nq);
     for (size_t l = 0; l < e->mlp[p].size(); ++l) {
       const int ld = e->mlp[p][l].k_out;
       snprintf(name, sizeof name, "h%d_%d", p, (int)l);
       W.H[p][l] = c.take<float>(n * ld, name, ld);
       W.D[p][l] = grad ? c.take<float>(n * ld) : nullptr;
     }
-    W.Fm[p] = c.take<float>(n_mol);
-    W.Dm[p] = c.take<float>(n_mol);
+    W.Fm[p] = c.take<float>((size_t)n_mol * e->nq);
+    W.Dm[p] = c.take<float>((size_t)n_mol * e->nq);
   }
   for (size_t l = 0; l + 1 < e->head.size(); ++l) {
     const int ld = e->head[l].k_out;
@@ -242,10 +244,11 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   }
   W.e_atom = c.take<float>(n, "e_atom", 1);
   W.ecoul = c.take<double>(n, "ecoul", 1);
-  W.qbar = c.take<float>(n, "qbar", 1);
+  W.qbar = c.take<float>(n * e->nq, "qbar", 1);
+  W.qtot = c.take<float>(e->nq > 1 ? n : 0, "qtot", 1);
   W.fgrad = c.take<float>(n * 3, "fgrad", 3);
   W.virial_atom = c.take<float>(n * 9);
-  W.Wbar = c.take<float>(n_mol);
+  W.Wbar = c.take<float>((size_t)n_mol * e->nq);
   W.S = std::min(128, std::max(1, (N / std::max(1, n_mol) + 511) / 512));
   W.part = c.take<double>((size_t)n_mol * W.S * 9);
   if (grad) {
@@ -255,7 +258,7 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
     W.zb1 = c.take<float>(n * mw, "zb1", mw);
     // Sbar doubles as the species-moment table T of pass 0 (N x nslots x 64), which outlives no Sbar
     W.Sbar = c.take<float>(n * std::max(1024, e->nslots * 64), "Sbar", 1024);
-    W.Sqbar = c.take<float>(n * 64, "Sqbar", 64);
+    W.Sqbar = c.take<float>(n * 64 * e->nq, "Sqbar", 64);
   } else {
     W.abar = W.zb0 = W.zb1 = W.Sbar = W.Sqbar = nullptr;
   }
@@ -285,9 +288,14 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     set_last_error("unsupported architecture: n_pass=%d head layers=%d", arch->n_pass, arch->head_n_layers);
     return AIMNET_E_INVALID;
   }
+  if (arch->n_charge_channels < 0 || arch->n_charge_channels > 2) {
+    set_last_error("unsupported architecture: n_charge_channels=%d (1 closed shell, 2 NSE)", arch->n_charge_channels);
+    return AIMNET_E_INVALID;
+  }
   AIMNET_HIP_CHECK(hipSetDevice(device));
   aimnet_engine* e = new aimnet_engine();
   e->arch = *arch;
+  e->nq = std::max(1, arch->n_charge_channels);
   e->device = device;
   int rc = 0;
   const int AG = 256;
@@ -314,13 +322,13 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->spatial_order = atoi(env) != 0;
   }
   if ((rc = dev_upload(e, w->agh_a, (size_t)16 * 16 * 12, &e->agh_a))) goto fail;
-  if ((rc = dev_upload(e, w->agh_q, (size_t)16 * 12, &e->agh_q))) goto fail;
+  if ((rc = dev_upload(e, w->agh_q, (size_t)e->nq * 16 * 12, &e->agh_q))) goto fail;
   if ((rc = dev_upload(e, w->sae, (size_t)64, &e->sae))) goto fail;
   for (int p = 0; p < arch->n_pass; ++p) {
     const int nl = arch->n_layers[p];
     if (nl < 1 || nl > AIMNET_MAX_LAYERS) { rc = AIMNET_E_INVALID; set_last_error("bad n_layers[%d]=%d", p, nl); goto fail; }
-    const int n_in_expect = (p == 0) ? 704 : 733;
-    const int n_out_expect = (p < arch->n_pass - 1) ? 258 : arch->layer_dims[p][nl];
+    const int n_in_expect = (p == 0) ? 704 : 704 + 29 * e->nq;  // [a | conv_a] (+ [q | conv_q] per charge channel)
+    const int n_out_expect = (p < arch->n_pass - 1) ? 256 + 2 * e->nq : arch->layer_dims[p][nl];
     if (arch->layer_dims[p][0] != n_in_expect || arch->layer_dims[p][nl] != n_out_expect) {
       rc = AIMNET_E_INVALID;
       set_last_error("pass %d MLP dims %d->%d do not match the feature layout (%d->%d)", p, arch->layer_dims[p][0],
@@ -493,6 +501,11 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     set_last_error("eval: forces requested without a forces buffer");
     return AIMNET_E_INVALID;
   }
+  const int nq = e->nq;
+  if (nq == 1 && out->spin_charges) {
+    set_last_error("eval: spin_charges requested from a 1-channel (closed-shell) model");
+    return AIMNET_E_INVALID;
+  }
   if (pbc && !(in->n_cell == 1 || in->n_cell == n_mol)) {
     set_last_error("eval: n_cell must be 1 or n_mol");
     return AIMNET_E_INVALID;
@@ -562,7 +575,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const std::vector<Layer>& Ls = e->mlp[p];
     const int nl = (int)Ls.size();
     RC(prof_mark(e, s, FAM_CONV_FWD));
-    RC(launch_conv_fwd(s, p > 0, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr, p > 0 ? W.q[p - 1] : nullptr,
+    RC(launch_conv_fwd(s, p > 0 ? nq : 0, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr, p > 0 ? W.q[p - 1] : nullptr,
                        W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q, e->bp, W.x[p], Ls[0].k_in, W.V[p], W.Vq[p], N, order));
     const float* hin = W.x[p];
     int ld_in = Ls[0].k_in;
@@ -576,12 +589,16 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     }
     if (p < np - 1) {
       RC(prof_mark(e, s, FAM_POINTWISE));
-      RC(launch_nse_fwd(s, W.H[p][nl - 1], Ls[nl - 1].k_out, p > 0 ? W.q[p - 1] : nullptr, W.nl.mol_start, in->charge,
-                        n_mol, W.S, (float*)W.part, W.q[p], W.Fm[p], W.Dm[p]));
-      RC(launch_update_a(s, W.a[p], W.H[p][nl - 1], Ls[nl - 1].k_out, N, W.a[p + 1]));
+      RC(launch_nse_fwd(s, W.H[p][nl - 1], Ls[nl - 1].k_out, nq, p > 0 ? W.q[p - 1] : nullptr, W.nl.mol_start, in->charge,
+                        n_mol, N, W.S, (float*)W.part, W.q[p], W.Fm[p], W.Dm[p]));
+      RC(launch_update_a(s, W.a[p], W.H[p][nl - 1], Ls[nl - 1].k_out, nq, N, W.a[p + 1]));
     }
   }
   const float* q_fin = W.q[np - 2];
+  if (nq == 2) {  // NSE: alpha + beta is the charge everything downstream sees (aimnet2.py:102-106)
+    RC(launch_charge_sum(s, W.q[np - 2], N, W.qtot, out->spin_charges));
+    q_fin = W.qtot;
+  }
   {
     const int nlp = (int)e->mlp[np - 1].size();
     const float* hin = W.H[np - 1][nlp - 1];
@@ -635,6 +652,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     RC(prof_mark(e, s, -1));
     return AIMNET_OK;
   }
+  if (nq == 2) RC(launch_copy_f32(s, W.qbar, W.qbar + N, (size_t)N));  // dE/dq_alpha = dE/dq_beta = dE/dq at this point
 
   // ---- backward -------------------------------------------------------------------------------
   float* zcur = W.zb0;
@@ -683,9 +701,9 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
                             order));
       break;
     }
-    RC(launch_unconcat(s, p > 0, zcur, ld, W.V[p], W.Vq[p], e->agh_a, e->agh_q, W.Sbar, W.Sqbar, N));
+    RC(launch_unconcat(s, p > 0 ? nq : 0, zcur, ld, W.V[p], W.Vq[p], e->agh_a, e->agh_q, W.Sbar, W.Sqbar, N));
     RC(prof_mark(e, s, FAM_CONV_BWD));
-    RC(launch_conv_bwd(s, p > 0, p > 0, want_s, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr,
+    RC(launch_conv_bwd(s, p > 0 ? nq : 0, p > 0, want_s, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr,
                        p > 0 ? W.q[p - 1] : nullptr, W.Sbar, W.Sqbar, W.nb_idx, W.nb_cnt,
                        W.pg, cap, e->bp, zcur, ld, (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, W.fgrad,
                        W.virial_atom, N, order));
@@ -696,9 +714,9 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const float* y = W.H[p - 1][nlq - 1];
     const int ldy = Lq[nlq - 1].k_out;
     RC(prof_mark(e, s, FAM_POINTWISE));
-    RC(launch_nse_bwd_reduce(s, W.qbar, y, ldy, W.Fm[p - 1], W.nl.mol_start, n_mol, W.S, (float*)W.part, W.Wbar));
+    RC(launch_nse_bwd_reduce(s, W.qbar, y, ldy, nq, W.Fm[p - 1], W.nl.mol_start, n_mol, N, W.S, (float*)W.part, W.Wbar));
     RC(launch_build_zbar(s, W.qbar, W.abar, y, ldy, ar.last_linear[p - 1] ? nullptr : W.D[p - 1][nlq - 1], W.Fm[p - 1],
-                         W.Dm[p - 1], W.Wbar, in->mol_idx, N, 256, p - 1 > 0, znext, W.qbar));
+                         W.Dm[p - 1], W.Wbar, in->mol_idx, N, n_mol, 256, nq, p - 1 > 0, znext, W.qbar));
     std::swap(zcur, znext);
   }
   RC(prof_mark(e, s, FAM_POINTWISE));

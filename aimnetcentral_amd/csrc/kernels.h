@@ -59,12 +59,14 @@ struct BasisParams {  // radial basis of AEVSV (aev.py:66-81), passed by value
 int launch_pair_geom(hipStream_t s, const float* xw, const int* mol_idx, const float* cell, int n_cell,
                      const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, int n_atoms, float4* pg);
 int launch_embed(hipStream_t s, const float* afv, const int* numbers, int n_atoms, float* a0);
-int launch_conv_fwd(hipStream_t s, bool has_q, const float* a, const int* row_of, const float* q, const int* nb_idx,
+// nq (conv_fwd / unconcat / conv_bwd): charge channels convolved with the features - 0 in pass 0, else 1 or 2 (NSE models);
+// q / qbar are planes [nq][n_atoms], agh_q [nq][G][H], Vqsave [N][nq][H*3], Sqbar [N][nq][G*4]
+int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, const float* q, const int* nb_idx,
                     const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
                     float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order);
-int launch_unconcat(hipStream_t s, bool has_q, const float* xbar, int ldx, const float* Vsave, const float* Vqsave,
+int launch_unconcat(hipStream_t s, int nq, const float* xbar, int ldx, const float* Vsave, const float* Vqsave,
                     const float* agh_a, const float* agh_q, float* Sbar, float* Sqbar, int n_atoms);
-int launch_conv_bwd(hipStream_t s, bool has_q, bool need_abar, bool stress, const float* a, const int* row_of,
+int launch_conv_bwd(hipStream_t s, int nq, bool need_abar, bool stress, const float* a, const int* row_of,
                     const float* q, const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
                     int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
                     const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order);
@@ -90,9 +92,12 @@ int launch_conv_sv_bwd_bwd(hipStream_t s, const float* grad_out, const float* gr
 
 // ---- model.hip --------------------------------------------------------------------------------
 // S = slices (blocks) per molecule for the per-molecule reductions; `part` = scratch [n_sys * S * 9] doubles
-int launch_nse_fwd(hipStream_t s, const float* y, int ldy, const float* q_prev, const int* mol_start,
-                   const float* charge, int n_mol, int S, float* part, float* q_new, float* Fm, float* Dm);
-int launch_update_a(hipStream_t s, const float* a, const float* y, int ldy, int n_atoms, float* a_new);
+// nq = charge channels (1, or 2 for NSE models): q planes [nq][n_atoms], charge / Fm / Dm / Wbar planes [nq][n_mol];
+// the MLP output row is [q~ (nq) | f~ (nq) | delta_a (256)] (aimnet2.py:123-130)
+int launch_nse_fwd(hipStream_t s, const float* y, int ldy, int nq, const float* q_prev, const int* mol_start,
+                   const float* charge, int n_mol, int n_atoms, int S, float* part, float* q_new, float* Fm, float* Dm);
+int launch_charge_sum(hipStream_t s, const float* q2, int n_atoms, float* q_tot, float* q_spin);
+int launch_update_a(hipStream_t s, const float* a, const float* y, int ldy, int nq, int n_atoms, float* a_new);
 int launch_head_last(hipStream_t s, const float* h, int ldh, const float* w, const float* b, int k, int n_atoms,
                      float* e_atom);
 int launch_head_seed(hipStream_t s, const float* w, const float* d, int ldd, int k, int n_atoms, float* zbar);
@@ -137,11 +142,11 @@ int launch_coulomb_dsf(hipStream_t s, bool grad, bool stress, const float* q, co
 // periodic DSF straight from the cell grid of the last launch_bins (no neighbour matrix)
 int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, NlistBuffers& b,
                             CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom);
-int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, const float* Fm,
-                          const int* mol_start, int n_mol, int S, float* part, float* Wbar);
+int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, int nq, const float* Fm,
+                          const int* mol_start, int n_mol, int n_atoms, int S, float* part, float* Wbar);
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
-                      const float* Fm, const float* Dm, const float* Wbar, const int* mol_idx, int n_atoms, int n_feat,
-                      bool carry_q, float* zbar, float* qbar_next);
+                      const float* Fm, const float* Dm, const float* Wbar, const int* mol_idx, int n_atoms, int n_mol, int n_feat,
+                      int nq, bool carry_q, float* zbar, float* qbar_next);
 int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
                     const float* cell, int n_cell, int n_mol, int n_atoms, int S, double* part, float* forces,
                     float* stress);

@@ -30,7 +30,10 @@ __device__ __forceinline__ T block_sum(T v, T* sh) {
 }
 
 // ---- NSE forward -------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nse_fwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ q_prev,
+// One charge channel per launch: the channel's q~ and f~ sit in columns qcol / fcol of the MLP output row
+// (aimnet2.py:123-130: split [nq, nq, rest]); q planes, charge, Fm, Dm are that channel's [N] / [n_mol] arrays.
+__global__ __launch_bounds__(256) void nse_fwd_kernel(const float* __restrict__ y, int ldy, int qcol, int fcol,
+                                                     const float* __restrict__ q_prev,
                                                      const int* __restrict__ mol_start, const float* __restrict__ charge,
                                                      float* __restrict__ q_new, float* __restrict__ Fm,
                                                      float* __restrict__ Dm) {
@@ -39,9 +42,9 @@ __global__ __launch_bounds__(256) void nse_fwd_kernel(const float* __restrict__ 
   const int i0 = mol_start[m], i1 = mol_start[m + 1];
   float sf = 0.f, sq = 0.f;
   for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-    const float ft = y[(size_t)i * ldy + 1];
+    const float ft = y[(size_t)i * ldy + fcol];
     sf += ft * ft;
-    sq += (q_prev ? q_prev[i] : 0.0f) + y[(size_t)i * ldy];
+    sq += (q_prev ? q_prev[i] : 0.0f) + y[(size_t)i * ldy + qcol];
   }
   const float F = block_sum(sf, sh) + 1.0e-6f;
   const float D = charge[m] - block_sum(sq, sh);
@@ -50,8 +53,8 @@ __global__ __launch_bounds__(256) void nse_fwd_kernel(const float* __restrict__ 
     Dm[m] = D;
   }
   for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-    const float ft = y[(size_t)i * ldy + 1];
-    const float qr = (q_prev ? q_prev[i] : 0.0f) + y[(size_t)i * ldy];
+    const float ft = y[(size_t)i * ldy + fcol];
+    const float qr = (q_prev ? q_prev[i] : 0.0f) + y[(size_t)i * ldy + qcol];
     q_new[i] = qr + (ft * ft) / F * D;
   }
 }
@@ -66,7 +69,7 @@ __device__ __forceinline__ void slice_bounds(const int* __restrict__ mol_start, 
   hi = min(i1, lo + L);
 }
 
-__global__ __launch_bounds__(256) void nse_fwd_partial_kernel(const float* __restrict__ y, int ldy,
+__global__ __launch_bounds__(256) void nse_fwd_partial_kernel(const float* __restrict__ y, int ldy, int qcol, int fcol,
                                                              const float* __restrict__ q_prev,
                                                              const int* __restrict__ mol_start, int S,
                                                              float* __restrict__ part) {
@@ -76,9 +79,9 @@ __global__ __launch_bounds__(256) void nse_fwd_partial_kernel(const float* __res
   slice_bounds(mol_start, m, sl, S, lo, hi);
   float sf = 0.f, sq = 0.f;
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    const float ft = y[(size_t)i * ldy + 1];
+    const float ft = y[(size_t)i * ldy + fcol];
     sf += ft * ft;
-    sq += (q_prev ? q_prev[i] : 0.0f) + y[(size_t)i * ldy];
+    sq += (q_prev ? q_prev[i] : 0.0f) + y[(size_t)i * ldy + qcol];
   }
   sf = block_sum(sf, sh);
   sq = block_sum(sq, sh);
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void nse_fwd_partial_kernel(const float* __res
   }
 }
 
-__global__ __launch_bounds__(256) void nse_fwd_apply_kernel(const float* __restrict__ y, int ldy,
+__global__ __launch_bounds__(256) void nse_fwd_apply_kernel(const float* __restrict__ y, int ldy, int qcol, int fcol,
                                                            const float* __restrict__ q_prev,
                                                            const int* __restrict__ mol_start,
                                                            const float* __restrict__ charge, int S,
@@ -114,39 +117,61 @@ __global__ __launch_bounds__(256) void nse_fwd_apply_kernel(const float* __restr
   int lo, hi;
   slice_bounds(mol_start, m, sl, S, lo, hi);
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    const float ft = y[(size_t)i * ldy + 1];
-    const float qr = (q_prev ? q_prev[i] : 0.0f) + y[(size_t)i * ldy];
+    const float ft = y[(size_t)i * ldy + fcol];
+    const float qr = (q_prev ? q_prev[i] : 0.0f) + y[(size_t)i * ldy + qcol];
     q_new[i] = qr + (ft * ft) / F * D;
   }
 }
 
-int launch_nse_fwd(hipStream_t s, const float* y, int ldy, const float* q_prev, const int* mol_start,
-                   const float* charge, int n_mol, int S, float* part, float* q_new, float* Fm, float* Dm) {
-  if (S <= 1) {
-    hipLaunchKernelGGL(nse_fwd_kernel, dim3(n_mol), dim3(256), 0, s, y, ldy, q_prev, mol_start, charge, q_new, Fm, Dm);
+int launch_nse_fwd(hipStream_t s, const float* y, int ldy, int nq, const float* q_prev, const int* mol_start,
+                   const float* charge, int n_mol, int n_atoms, int S, float* part, float* q_new, float* Fm, float* Dm) {
+  for (int ch = 0; ch < nq; ++ch) {  // channels are independent (ops.nse works on the trailing channel axis)
+    const float* qp = q_prev ? q_prev + (size_t)ch * n_atoms : nullptr;
+    const float* Q = charge + (size_t)ch * n_mol;
+    float* qn = q_new + (size_t)ch * n_atoms;
+    float *F = Fm + (size_t)ch * n_mol, *D = Dm + (size_t)ch * n_mol;
+    if (S <= 1) {
+      hipLaunchKernelGGL(nse_fwd_kernel, dim3(n_mol), dim3(256), 0, s, y, ldy, ch, nq + ch, qp, mol_start, Q, qn, F, D);
+      AIMNET_LAUNCH_CHECK();
+      continue;
+    }
+    hipLaunchKernelGGL(nse_fwd_partial_kernel, dim3(S, n_mol), dim3(256), 0, s, y, ldy, ch, nq + ch, qp, mol_start, S, part);
     AIMNET_LAUNCH_CHECK();
-    return 0;
+    hipLaunchKernelGGL(nse_fwd_apply_kernel, dim3(S, n_mol), dim3(256), 0, s, y, ldy, ch, nq + ch, qp, mol_start, Q, S, part, qn,
+                       F, D);
+    AIMNET_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(nse_fwd_partial_kernel, dim3(S, n_mol), dim3(256), 0, s, y, ldy, q_prev, mol_start, S, part);
-  AIMNET_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nse_fwd_apply_kernel, dim3(S, n_mol), dim3(256), 0, s, y, ldy, q_prev, mol_start, charge, S, part, q_new,
-                     Fm, Dm);
+  return 0;
+}
+
+// NSE models: total and spin charges from the two channel planes (aimnet2.py:102-106)
+__global__ void charge_sum_kernel(const float* __restrict__ q2, int n_atoms, float* __restrict__ q_tot,
+                                  float* __restrict__ q_spin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  const float a = q2[i], b = q2[(size_t)n_atoms + i];
+  q_tot[i] = a + b;
+  if (q_spin) q_spin[i] = a - b;
+}
+
+int launch_charge_sum(hipStream_t s, const float* q2, int n_atoms, float* q_tot, float* q_spin) {
+  hipLaunchKernelGGL(charge_sum_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, q2, n_atoms, q_tot, q_spin);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }
 
-__global__ void update_a_kernel(const float* __restrict__ a, const float* __restrict__ y, int ldy, int n_atoms,
+__global__ void update_a_kernel(const float* __restrict__ a, const float* __restrict__ y, int ldy, int col0, int n_atoms,
                                 float* __restrict__ a_new) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)n_atoms * 256) return;
   const size_t i = e >> 8;
   const int k = (int)(e & 255);
-  a_new[e] = a[e] + y[i * ldy + 2 + k];
+  a_new[e] = a[e] + y[i * ldy + col0 + k];
 }
 
-int launch_update_a(hipStream_t s, const float* a, const float* y, int ldy, int n_atoms, float* a_new) {
+int launch_update_a(hipStream_t s, const float* a, const float* y, int ldy, int nq, int n_atoms, float* a_new) {
   const size_t n = (size_t)n_atoms * 256;
-  hipLaunchKernelGGL(update_a_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, y, ldy, n_atoms, a_new);
+  hipLaunchKernelGGL(update_a_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, y, ldy, 2 * nq, n_atoms, a_new);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }
@@ -540,7 +565,7 @@ int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* 
 
 // ---- NSE backward --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nse_bwd_partial_kernel(const float* __restrict__ qbar, const float* __restrict__ y,
-                                                             int ldy, const int* __restrict__ mol_start, int S,
+                                                             int ldy, int fcol, const int* __restrict__ mol_start, int S,
                                                              float* __restrict__ part) {
   __shared__ float sh[4];
   const int m = blockIdx.y, sl = blockIdx.x;
@@ -548,7 +573,7 @@ __global__ __launch_bounds__(256) void nse_bwd_partial_kernel(const float* __res
   slice_bounds(mol_start, m, sl, S, lo, hi);
   float acc = 0.f;
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    const float ft = y[(size_t)i * ldy + 1];
+    const float ft = y[(size_t)i * ldy + fcol];
     acc += qbar[i] * (ft * ft);
   }
   const float r = block_sum(acc, sh);
@@ -564,49 +589,57 @@ __global__ void nse_bwd_finish_kernel(const float* __restrict__ part, int S, int
   Wbar[m] = r / Fm[m];
 }
 
-int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, const float* Fm,
-                          const int* mol_start, int n_mol, int S, float* part, float* Wbar) {
+int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, int nq, const float* Fm,
+                          const int* mol_start, int n_mol, int n_atoms, int S, float* part, float* Wbar) {
   S = S < 1 ? 1 : S;
-  hipLaunchKernelGGL(nse_bwd_partial_kernel, dim3(S, n_mol), dim3(256), 0, s, qbar, y, ldy, mol_start, S, part);
-  AIMNET_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nse_bwd_finish_kernel, dim3(ceil_div(n_mol, 64)), dim3(64), 0, s, part, S, n_mol, Fm, Wbar);
-  AIMNET_LAUNCH_CHECK();
+  for (int ch = 0; ch < nq; ++ch) {
+    hipLaunchKernelGGL(nse_bwd_partial_kernel, dim3(S, n_mol), dim3(256), 0, s, qbar + (size_t)ch * n_atoms, y, ldy, nq + ch,
+                       mol_start, S, part);
+    AIMNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nse_bwd_finish_kernel, dim3(ceil_div(n_mol, 64)), dim3(64), 0, s, part, S, n_mol, Fm + (size_t)ch * n_mol,
+                       Wbar + (size_t)ch * n_mol);
+    AIMNET_LAUNCH_CHECK();
+  }
   return 0;
 }
 
 // zbar[i] = adjoint of the LAST linear layer's pre-activation of this pass' MLP:
-//   ybar = [q~bar, f~bar, delta_a bar(n_feat)], times GELU'(z_last) when the MLP ends with GELU.
+//   ybar = [q~bar (nq), f~bar (nq), delta_a bar(n_feat)], times GELU'(z_last) when the MLP ends with GELU.
+// qbar / qbar_next: nq planes of [n_atoms]; Fm, Dm, Wbar: nq planes of [n_mol].
 __global__ void build_zbar_kernel(const float* __restrict__ qbar, const float* __restrict__ abar,
                                   const float* __restrict__ y, int ldy, const float* __restrict__ dlast,
                                   const float* __restrict__ Fm, const float* __restrict__ Dm,
-                                  const float* __restrict__ Wbar, const int* __restrict__ mol_idx, int n_atoms, int n_feat,
-                                  int carry_q, float* __restrict__ zbar, float* __restrict__ qbar_next) {
+                                  const float* __restrict__ Wbar, const int* __restrict__ mol_idx, int n_atoms, int n_mol,
+                                  int n_feat, int nq, int carry_q, float* __restrict__ zbar, float* __restrict__ qbar_next) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
   const int m = mol_idx[i];
-  const float qr = qbar[i] - Wbar[m];
-  const float ft = y[(size_t)i * ldy + 1];
-  const float ftb = 2.0f * ft * (Dm[m] / Fm[m]) * qr;
+  // every lane reads both channels' qbar before anything is written: qbar_next may alias qbar
+  float qr[2] = {0.f, 0.f}, fsc[2] = {0.f, 0.f};
+  for (int ch = 0; ch < nq; ++ch) {
+    qr[ch] = qbar[(size_t)ch * n_atoms + i] - Wbar[(size_t)ch * n_mol + m];
+    fsc[ch] = Dm[(size_t)ch * n_mol + m] / Fm[(size_t)ch * n_mol + m];
+  }
   float* zr = zbar + (size_t)i * ldy;
   const float* dr = dlast ? dlast + (size_t)i * ldy : nullptr;
   for (int c = lane; c < ldy; c += 64) {
     float v;
-    if (c == 0) v = qr;
-    else if (c == 1) v = ftb;
-    else if (c < 2 + n_feat) v = abar[(size_t)i * n_feat + c - 2];
+    if (c < nq) v = c == 0 ? qr[0] : qr[1];
+    else if (c < 2 * nq) v = 2.0f * y[(size_t)i * ldy + c] * (c == nq ? fsc[0] : fsc[1]) * (c == nq ? qr[0] : qr[1]);
+    else if (c < 2 * nq + n_feat) v = abar[(size_t)i * n_feat + c - 2 * nq];
     else v = 0.0f;
-    if (dr && c < 2 + n_feat) v *= dr[c];
+    if (dr && c < 2 * nq + n_feat) v *= dr[c];
     zr[c] = v;
   }
-  if (lane == 0) qbar_next[i] = carry_q ? qr : 0.0f;
+  if (lane < nq) qbar_next[(size_t)lane * n_atoms + i] = carry_q ? (lane == 0 ? qr[0] : qr[1]) : 0.0f;
 }
 
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
-                      const float* Fm, const float* Dm, const float* Wbar, const int* mol_idx, int n_atoms, int n_feat,
-                      bool carry_q, float* zbar, float* qbar_next) {
+                      const float* Fm, const float* Dm, const float* Wbar, const int* mol_idx, int n_atoms, int n_mol, int n_feat,
+                      int nq, bool carry_q, float* zbar, float* qbar_next) {
   hipLaunchKernelGGL(build_zbar_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, qbar, abar, y, ldy, dlast, Fm, Dm, Wbar,
-                     mol_idx, n_atoms, n_feat, carry_q ? 1 : 0, zbar, qbar_next);
+                     mol_idx, n_atoms, n_mol, n_feat, nq, carry_q ? 1 : 0, zbar, qbar_next);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

@@ -41,6 +41,7 @@ class ModelSpec:
     sr_rc: float
     weights: dict[str, np.ndarray] = field(repr=False, default_factory=dict)  # state-dict keys
     metadata: dict[str, Any] = field(default_factory=dict)
+    num_charge_channels: int = 1       # 2 = open-shell NSE family (aimnet2.py:21-28)
 
 
 class HipEngine:
@@ -73,6 +74,7 @@ class HipEngine:
         arch.sr_coulomb = 1 if spec.sr_coulomb else 0
         arch.sr_envelope = 0 if spec.sr_envelope == "exp" else 1
         arch.sr_rc = float(spec.sr_rc)
+        arch.n_charge_channels = self.nq = int(spec.num_charge_channels)
 
         w = _lib.Weights()
         sd = spec.weights
@@ -147,7 +149,8 @@ class HipEngine:
         dftd3: dict[str, float] | None = None,
     ) -> dict[str, Any]:
         """One evaluation on device tensors (coord f32 [N,3], numbers/mol_idx i32 [N], charge f32
-        [n_mol], cell f32 [3,3]|[n_mol,3,3]).  Returns device tensors; retries with x1.5 row
+        [n_mol] - for a 2-channel NSE model [n_mol, 2] = the alpha / beta charges of aimnet2.py:94-100 -,
+        cell f32 [3,3]|[n_mol,3,3]).  Returns device tensors (NSE: plus spin_charges); retries with x1.5 row
         capacity on neighbour overflow (neighbors.py:127-130).  `dftd3` = {s8, a1, a2[, s6, cutoff, smoothing_fraction]}
         adds the external DFT-D3(BJ) term (needs set_dftd3_tables)."""
         import torch
@@ -156,8 +159,18 @@ class HipEngine:
         coord = coord.to(device=dev, dtype=torch.float32).contiguous()
         numbers = numbers.to(device=dev, dtype=torch.int32).contiguous()
         mol_idx = mol_idx.to(device=dev, dtype=torch.int32).contiguous()
-        charge = charge.to(device=dev, dtype=torch.float32).contiguous()
-        n, n_mol = coord.shape[0], charge.shape[0]
+        charge = charge.to(device=dev, dtype=torch.float32)
+        if self.nq == 2:
+            if charge.ndim != 2 or charge.shape[1] != 2:
+                raise ValueError("HipEngine.eval: a 2-channel (NSE) model needs charge of shape [n_mol, 2] (alpha, beta)")
+            n_mol = charge.shape[0]
+            charge = charge.t().contiguous()  # channel-major planes, include/aimnet_hip.h aimnet_inputs.charge
+        else:
+            if charge.ndim != 1:
+                raise ValueError("HipEngine.eval: charge must have shape [n_mol]")
+            charge = charge.contiguous()
+            n_mol = charge.shape[0]
+        n = coord.shape[0]
         if n == 0 or n_mol == 0:
             raise ValueError("HipEngine.eval: empty input (no atoms or no molecules)")
         n_cell = 0
@@ -167,6 +180,7 @@ class HipEngine:
         method = {"none": _lib.COULOMB_NONE, "simple": _lib.COULOMB_SIMPLE, "dsf": _lib.COULOMB_DSF}[coulomb]
         energy = torch.empty(n_mol, dtype=torch.float64, device=dev)
         charges = torch.empty(n, dtype=torch.float32, device=dev)
+        spin = torch.empty(n, dtype=torch.float32, device=dev) if self.nq == 2 else None
         f_out = torch.empty(n, 3, dtype=torch.float32, device=dev) if forces else None
         s_out = torch.empty(max(n_cell, 1), 3, 3, dtype=torch.float32, device=dev) if stress else None
         status = torch.empty(8, dtype=torch.int32, device=dev)  # zeroed by the engine at the start of every evaluation
@@ -205,6 +219,7 @@ class HipEngine:
             out.forces = f_out.data_ptr() if f_out is not None else None
             out.stress = s_out.data_ptr() if s_out is not None else None
             out.status = status.data_ptr()
+            out.spin_charges = spin.data_ptr() if spin is not None else None
             with torch.cuda.device(dev):
                 rc = self.lib.aimnet_engine_eval(self._h, C.byref(inp), C.byref(opt), C.byref(out), self._ws.data_ptr(),
                                                  self._ws.numel(), stream)
@@ -227,6 +242,8 @@ class HipEngine:
             if not retry:
                 break
         res: dict[str, Any] = {"energy": energy, "charges": charges}
+        if spin is not None:
+            res["spin_charges"] = spin
         if forces:
             res["forces"] = f_out
         if stress:

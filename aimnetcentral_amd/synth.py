@@ -86,8 +86,16 @@ def _mlp_sizes(n_in: int, hidden: list[int], n_out: int) -> list[tuple[int, int]
     return [(sizes[i + 1], sizes[i]) for i in range(len(sizes) - 1)]
 
 
-def synthetic_state_dict(seed: int = 0, species: list[int] | None = None) -> dict[str, np.ndarray]:
-    """All 37 tensors of the aimnet2 core state dict as NumPy arrays (fp32; SAE fp64)."""
+def core_yaml(num_charge_channels: int = 1) -> str:
+    """AIMNET2_CORE_YAML, with `num_charge_channels: 2` for the open-shell NSE family (aimnet2.py:21,94-106)."""
+    if num_charge_channels == 1:
+        return AIMNET2_CORE_YAML
+    return AIMNET2_CORE_YAML.replace("kwargs:\n  nfeature: 16\n", f"kwargs:\n  num_charge_channels: {int(num_charge_channels)}\n  nfeature: 16\n", 1)
+
+
+def synthetic_state_dict(seed: int = 0, species: list[int] | None = None, num_charge_channels: int = 1) -> dict[str, np.ndarray]:
+    """All 37 tensors of the aimnet2 core state dict as NumPy arrays (fp32; SAE fp64).  num_charge_channels = 2 gives the
+    shapes of an NSE model (conv_q.agh (2,G,H), MLP inputs 704 / 762, outputs 260; aimnet2.py:53-85)."""
     species = list(AIMNET2_SPECIES if species is None else species)
     rng = np.random.Generator(np.random.PCG64(seed))
 
@@ -112,21 +120,24 @@ def synthetic_state_dict(seed: int = 0, species: list[int] | None = None) -> dic
         afv[z] = (base + normal((A, G), 0.15)).reshape(-1)
     sd["afv.weight"] = afv
     sd["conv_a.agh"] = normal((A, G, H), 0.35)
-    sd["conv_q.agh"] = normal((1, G, H), 0.35)
+    nq = int(num_charge_channels)
+    sd["conv_q.agh"] = normal((nq, G, H), 0.35)
 
-    n_conv_a, n_conv_q = A * G + A * H, G + H
+    n_conv_a, n_conv_q = A * G + A * H, nq * (G + H)
     n_in0 = n_conv_a + A * G  # 704
-    n_in1 = n_in0 + n_conv_q + 1  # 733
+    n_in1 = n_in0 + n_conv_q + nq  # 733 (762 for 2 channels)
     mlps = [
-        _mlp_sizes(n_in0, [512, 380], A * G + 2),
-        _mlp_sizes(n_in1, [512, 380], A * G + 2),
+        _mlp_sizes(n_in0, [512, 380], A * G + 2 * nq),
+        _mlp_sizes(n_in1, [512, 380], A * G + 2 * nq),
         _mlp_sizes(n_in1, [512, 380, 380], 256),
     ]
     for p, layers in enumerate(mlps):
         for li, (fo, fi) in enumerate(layers):
             std = math.sqrt(2.0 / (fi + fo))  # xavier_normal_, core.py:18,40
             last = li == len(layers) - 1
-            gain = 0.5 if (last and p < 2) else 1.4  # pre-activations O(1): GELU in its nonlinear range
+            # pre-activations O(1): GELU in its nonlinear range; the (q~, f~, delta_a) layers smaller - half as large again
+            # for two charge channels, where the spin channel otherwise drives |q| > 3 e and forces > 100 eV/A
+            gain = (0.5 if nq == 1 else 0.25) if (last and p < 2) else 1.4
             sd[f"mlps.{p}.{2 * li}.weight"] = normal((fo, fi), std * gain)
             sd[f"mlps.{p}.{2 * li}.bias"] = normal((fo,), 0.05)
     for li, (fo, fi) in enumerate(_mlp_sizes(256, [128, 128], 1)):
@@ -154,15 +165,15 @@ def state_dict_digest(sd: dict[str, Any]) -> str:
     return h.hexdigest()
 
 
-def synthetic_artifact(seed: int = 0, species: list[int] | None = None) -> dict[str, Any]:
+def synthetic_artifact(seed: int = 0, species: list[int] | None = None, num_charge_channels: int = 1) -> dict[str, Any]:
     """A v2 artifact dict (torch tensors) as `torch.save` would hold it."""
     import torch
 
     species = list(AIMNET2_SPECIES if species is None else species)
-    sd = {k: torch.from_numpy(np.array(v)) for k, v in synthetic_state_dict(seed, species).items()}
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synthetic_state_dict(seed, species, num_charge_channels).items()}
     return {
         "format_version": 2,
-        "model_yaml": AIMNET2_CORE_YAML,
+        "model_yaml": core_yaml(num_charge_channels),
         "state_dict": sd,
         "cutoff": 5.0,
         "needs_coulomb": True,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AIMNET_ABI_VERSION 2
+#define AIMNET_ABI_VERSION 3
 
 #define AIMNET_OK 0
 #define AIMNET_E_INVALID (-1)   /* bad argument / unsupported architecture */
@@ -67,6 +67,8 @@ typedef struct aimnet_arch {
   int32_t sr_coulomb;               /* 1: embedded SRCoulomb subtraction (lr.py:986-1032) */
   int32_t sr_envelope;              /* 0 exp (ops.py:88), 1 cosine (ops.py:82) */
   float sr_rc;                      /* 4.6 */
+  int32_t n_charge_channels;        /* num_charge_channels of AIMNet2.__init__ (aimnet2.py:21-28): 1 closed shell (0 reads
+                                       as 1), 2 = open-shell NSE (alpha / beta electron-count channels) */
 } aimnet_arch;
 
 /* Host pointers to the fp32 weights, copied to the device once at create time.
@@ -74,7 +76,7 @@ typedef struct aimnet_arch {
 typedef struct aimnet_weights {
   const float* afv;     /* [64, A*G] embedding; rows of unsupported Z may be NaN */
   const float* agh_a;   /* [A, G, H] */
-  const float* agh_q;   /* [G, H] */
+  const float* agh_q;   /* [n_charge_channels, G, H] */
   const float* mlp_w[AIMNET_MAX_PASS][AIMNET_MAX_LAYERS];
   const float* mlp_b[AIMNET_MAX_PASS][AIMNET_MAX_LAYERS];
   const float* head_w[AIMNET_MAX_LAYERS];
@@ -92,7 +94,8 @@ typedef struct aimnet_inputs {
   const float* coord;      /* [n_atoms, 3] */
   const int32_t* numbers;  /* [n_atoms] */
   const int32_t* mol_idx;  /* [n_atoms] */
-  const float* charge;     /* [n_mol] total molecular charge */
+  const float* charge;     /* [n_charge_channels, n_mol] channel-major: the total molecular charge, or for NSE models
+                              the two planes Q/2 + (mult-1)/2 and Q/2 - (mult-1)/2 (aimnet2.py:94-100) */
   const float* cell;       /* [n_cell, 3, 3] row vectors, or NULL (non-periodic) */
   int32_t n_cell;          /* 0, 1 (shared) or n_mol */
   int32_t pbc[3];          /* periodic axes (used when cell != NULL) */
@@ -116,12 +119,13 @@ typedef struct aimnet_eval_options {
 
 typedef struct aimnet_outputs {
   double* energy;   /* [n_mol] eV, fp64 like the reference */
-  float* charges;   /* [n_atoms] */
+  float* charges;   /* [n_atoms] (NSE: alpha + beta, aimnet2.py:102-106) */
   float* forces;    /* [n_atoms, 3] or NULL */
   float* stress;    /* [max(n_cell,1), 3, 3] or NULL */
   int32_t* status;  /* [8]: 0 max neighbours found (rc list), 1 same for the LR list,
                               2 overflow flag rc list, 3 overflow flag LR list,
                               4 max neighbours found (D3 list), 5 overflow flag D3 list, 6.. reserved */
+  float* spin_charges; /* [n_atoms] alpha - beta of an NSE model (aimnet2.py:103), or NULL; must be NULL for 1-channel models */
 } aimnet_outputs;
 
 int aimnet_abi_version(void);

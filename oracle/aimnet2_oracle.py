@@ -150,6 +150,7 @@ class OracleModel:
         self.sr_rc = f("outputs.srcoulomb.rc") if "outputs.srcoulomb.rc" in sd else torch.tensor(4.6, dtype=dtype)
         self.A = self.agh_a.shape[0]
         self.G = self.agh_a.shape[1]
+        self.nq = int(self.agh_q.shape[0])  # num_charge_channels (aimnet2.py:21): 2 = open-shell NSE
 
 
 def _gelu(x: Tensor) -> Tensor:
@@ -274,6 +275,7 @@ def evaluate(
     stress: bool = False,
     hessian: bool = False,
     dftd3: dict | None = None,
+    mult=None,
     return_intermediates: bool = False,
     nbmat=None,
     shifts=None,
@@ -338,7 +340,13 @@ def evaluate(
     inter["d_ij"] = d_ij
 
     q = None
-    Q = charge_t.unsqueeze(-1)
+    nq = model.nq
+    if nq == 2:  # _preprocess_spin_polarized_charge, aimnet2.py:94-100
+        mult_t = torch.ones_like(charge_t) if mult is None else torch.as_tensor(np.atleast_1d(np.asarray(mult, dtype=np.float32))).to(dt)
+        half_spin, half_q = 0.5 * (mult_t - 1.0), 0.5 * charge_t
+        Q = torch.stack([half_q + half_spin, half_q - half_spin], dim=-1)
+    else:
+        Q = charge_t.unsqueeze(-1)
     npass = len(model.mlps)
     for ip, layers in enumerate(model.mlps):
         _in = torch.cat([a.flatten(-2, -1), _conv(a, g_sv, nb, model.agh_a, True)], dim=-1)
@@ -349,7 +357,7 @@ def evaluate(
         out = torch.cat([out[:-1], torch.zeros_like(out[:1])], dim=0)  # mask_i_ on padding row
         inter[f"mlp{ip}_out"] = out
         if ip < npass - 1:
-            _q, _f, da = out.split([1, 1, out.shape[-1] - 2], dim=-1)
+            _q, _f, da = out.split([nq, nq, out.shape[-1] - 2 * nq], dim=-1)
             qr = q + _q if ip > 0 else _q
             f = _f.pow(2)
             F = _mol_sum(f, mol_p, n_mol) + 1.0e-6
@@ -360,7 +368,8 @@ def evaluate(
             inter[f"q{ip}"] = q.squeeze(-1)
         else:
             aim = out
-    charges = q.squeeze(-1)
+    spin = q[:, 0] - q[:, 1] if nq == 2 else None  # _postprocess_spin_polarized_charge, aimnet2.py:102-106
+    charges = q.sum(-1)
     inter["aim"] = aim
 
     e_at = _mlp(aim, model.head, last_linear=True).squeeze(-1)
@@ -409,6 +418,8 @@ def evaluate(
         energy = energy + e_d3.double()
 
     res: dict[str, np.ndarray] = {"energy": energy.detach().numpy().copy(), "charges": charges[:-1].detach().numpy().copy()}
+    if spin is not None:
+        res["spin_charges"] = spin[:-1].detach().numpy().copy()
     if hessian:
         # dense (N,3,N,3) Hessian by double backward, row by row (calculate_hessian, derivatives.py:149-192)
         (g,) = torch.autograd.grad(energy.sum(), coord_p, create_graph=True)

@@ -66,6 +66,34 @@ def oracle64(synth_sd):
 
 
 @pytest.fixture(scope="session")
+def synth_sd_nse():
+    from aimnetcentral_amd import synth
+
+    return synth.synthetic_state_dict(0, None, 2)
+
+
+@pytest.fixture(scope="session")
+def oracle32_nse(synth_sd_nse):
+    import torch
+
+    from oracle import aimnet2_oracle as O
+
+    return O.OracleModel(synth_sd_nse, torch.float32)
+
+
+@pytest.fixture(scope="session")
+def hip_engine_nse():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from aimnetcentral_amd import loader
+    from aimnetcentral_amd.engine import HipEngine
+
+    return HipEngine(loader.synthetic_spec(0, num_charge_channels=2), "cuda:0")
+
+
+@pytest.fixture(scope="session")
 def hip_engine():
     import torch
 

@@ -163,7 +163,51 @@ def make_dftd3(path: str, meta_common: dict) -> None:
                         batch_coord=c, batch_numbers=zz, batch_mol_idx=mol, batch_energy=e3, batch_forces=f3, **meta_common)
 
 
+def make_nse() -> None:
+    """G10: the open-shell NSE family (num_charge_channels = 2, aimnet2.py:21,94-106,174-177): synthetic weights of that
+    shape, `mult` input, outputs charges (alpha + beta) and spin_charges (alpha - beta)."""
+    art = synth.synthetic_artifact(SEED, num_charge_channels=2)
+    digest = synth.state_dict_digest({k: v.numpy() for k, v in art["state_dict"].items()})
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "aimnet2_nse_synth.pt")
+    torch.save(art, path)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model, meta = load_model(path)
+    assert model.num_charge_channels == 2
+    res = {"weights_seed": np.int64(SEED), "weights_digest": np.array(digest)}
+    coord, numbers = read_taxol()
+    coord, numbers = coord[:40].astype(np.float32), numbers[:40]
+    calc = make_calc(path)
+    assert calc.is_nse
+    o = to_np(calc({"coord": coord, "numbers": numbers, "charge": 1.0, "mult": 2.0}, forces=True))
+    res.update(t40_coord=coord, t40_numbers=numbers, t40_charge=np.float32(1.0), t40_mult=np.float32(2.0), t40_energy=o["energy"],
+               t40_forces=o["forces"], t40_charges=o["charges"], t40_spin_charges=o["spin_charges"])
+    print("nse t40 E=%.6f sum q=%.5f sum spin=%.5f" % (o["energy"][0], o["charges"].sum(), o["spin_charges"].sum()))
+    c, z, mol, _ = workloads.random_batch(5, 9, 30, seed=11)
+    q = np.array([0.0, 1.0, -1.0, 0.0, 2.0], dtype=np.float32)
+    mult = np.array([1.0, 2.0, 2.0, 3.0, 1.0], dtype=np.float32)
+    calc = make_calc(path)
+    o = to_np(calc({"coord": c, "numbers": z, "mol_idx": mol, "charge": q, "mult": mult}, forces=True))
+    res.update(b5_coord=c, b5_numbers=z, b5_mol_idx=mol, b5_charge=q, b5_mult=mult, b5_energy=o["energy"], b5_forces=o["forces"],
+               b5_charges=o["charges"], b5_spin_charges=o["spin_charges"])
+    print("nse batch5 E=", o["energy"])
+    pc, pz, cell = workloads.glucose_cell()
+    calc = make_calc(path)
+    calc.set_lrcoulomb_method("dsf", cutoff=9.0)
+    o = to_np(calc({"coord": pc.astype(np.float32), "numbers": pz, "charge": 0.0, "mult": 3.0, "cell": cell.astype(np.float32)},
+                   forces=True, stress=True))
+    res.update(pbc_coord=pc.astype(np.float32), pbc_numbers=pz, pbc_cell=cell.astype(np.float32), pbc_mult=np.float32(3.0),
+               pbc_dsf_rc=np.float64(9.0), pbc_energy=o["energy"], pbc_forces=o["forces"], pbc_charges=o["charges"],
+               pbc_spin_charges=o["spin_charges"], pbc_stress=o["stress"])
+    print("nse pbc96 E=%.6f sum spin=%.5f" % (o["energy"][0], o["spin_charges"].sum()))
+    np.savez_compressed(os.path.join(HERE, "nse.npz"), **res)
+
+
 def main() -> None:
+    if "--only-nse" in sys.argv:
+        make_nse()
+        return
     art = synth.synthetic_artifact(SEED)
     digest = synth.state_dict_digest({k: v.numpy() for k, v in art["state_dict"].items()})
     tmp = tempfile.mkdtemp()
@@ -291,6 +335,7 @@ def main() -> None:
     print("dense3x14 E=", out["energy"], out["forces"].shape)
     make_hvp40(path, meta_common)
     make_dftd3(path, meta_common)
+    make_nse()
 
 
 if __name__ == "__main__":

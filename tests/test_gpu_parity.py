@@ -191,3 +191,89 @@ def test_dftd3_nonperiodic_dsf_list_sharing(hip_engine, oracle32, rc_dsf):
     ref = O.evaluate(oracle32, g["batch_coord"], g["batch_numbers"], np.zeros(5, np.float32), mol, coulomb="dsf", dsf_rc=rc_dsf,
                      dftd3=dict(par, **tables))
     compare(a, ref, np.bincount(mol), f"batch5 dsf{rc_dsf} + d3")
+
+
+# ---- open-shell NSE family: two charge channels (aimnet2.py:21-28,94-106) ---------------------------------------
+def _nse_charge(q, mult):
+    """(alpha, beta) molecular charges of AIMNet2._preprocess_spin_polarized_charge, aimnet2.py:94-100."""
+    q, mult = np.atleast_1d(np.asarray(q, np.float32)), np.atleast_1d(np.asarray(mult, np.float32))
+    return np.stack([0.5 * q + 0.5 * (mult - 1.0), 0.5 * q - 0.5 * (mult - 1.0)], axis=-1).astype(np.float32)
+
+
+def _run_nse(eng, coord, numbers, mol, q, mult, **kw):
+    dev = eng.device
+    r = eng.eval(torch.from_numpy(np.asarray(coord, np.float32)).to(dev), torch.from_numpy(np.asarray(numbers)).to(dev),
+                 torch.from_numpy(np.asarray(mol)).to(dev), torch.from_numpy(_nse_charge(q, mult)).to(dev), forces=True, **kw)
+    return {k: v.cpu().numpy() for k, v in r.items()}
+
+
+def _compare_nse(res, ref, sizes, what):
+    compare(res, ref, sizes, what)
+    assert np.abs(res["spin_charges"] - ref["spin_charges"]).max() <= CHARGE_ATOL, what
+
+
+def test_nse_molecule_vs_oracle_and_reference_golden(hip_engine_nse, oracle32_nse):
+    g = golden("nse")
+    mol = np.zeros(40, dtype=np.int64)
+    res = _run_nse(hip_engine_nse, g["t40_coord"], g["t40_numbers"], mol, g["t40_charge"], g["t40_mult"], coulomb="simple")
+    ref = O.evaluate(oracle32_nse, g["t40_coord"], g["t40_numbers"], g["t40_charge"], mult=g["t40_mult"])
+    _compare_nse(res, ref, 40, "nse t40/oracle")
+    gold = {k[4:]: g[k] for k in g.files if k.startswith("t40_")}
+    _compare_nse(res, gold, 40, "nse t40/reference golden")
+    assert abs(res["spin_charges"].sum() - 1.0) < 5e-4 and abs(res["charges"].sum() - 1.0) < 5e-4  # eps = 1e-6 in ops.nse
+
+
+def test_nse_ragged_batch_mixed_multiplicities(hip_engine_nse, oracle32_nse):
+    g = golden("nse")
+    mol = g["b5_mol_idx"]
+    res = _run_nse(hip_engine_nse, g["b5_coord"], g["b5_numbers"], mol, g["b5_charge"], g["b5_mult"], coulomb="simple")
+    sizes = np.bincount(mol)
+    ref = O.evaluate(oracle32_nse, g["b5_coord"], g["b5_numbers"], g["b5_charge"], mol, mult=g["b5_mult"])
+    _compare_nse(res, ref, sizes, "nse batch5/oracle")
+    _compare_nse(res, {k[3:]: g[k] for k in g.files if k.startswith("b5_")}, sizes, "nse batch5/reference golden")
+    spin = np.zeros(5)
+    np.add.at(spin, mol, res["spin_charges"])
+    assert np.abs(spin - (g["b5_mult"] - 1.0)).max() < 5e-4  # NSE conserves N_alpha - N_beta per molecule
+
+
+def test_nse_periodic_dsf_stress(hip_engine_nse, oracle32_nse):
+    g = golden("nse")
+    dev = hip_engine_nse.device
+    mol = np.zeros(96, dtype=np.int64)
+    rc = float(g["pbc_dsf_rc"])
+    r = hip_engine_nse.eval(torch.from_numpy(g["pbc_coord"]).to(dev), torch.from_numpy(g["pbc_numbers"]).to(dev), torch.from_numpy(mol).to(dev),
+                            torch.from_numpy(_nse_charge(0.0, g["pbc_mult"])).to(dev), cell=torch.from_numpy(g["pbc_cell"]).to(dev),
+                            forces=True, stress=True, coulomb="dsf", dsf_rc=rc)
+    res = {k: v.cpu().numpy() for k, v in r.items()}
+    ref = O.evaluate(oracle32_nse, g["pbc_coord"], g["pbc_numbers"], 0.0, cell=g["pbc_cell"], coulomb="dsf", dsf_rc=rc, stress=True,
+                     mult=g["pbc_mult"])
+    _compare_nse(res, ref, 96, "nse pbc96/oracle")
+    _compare_nse(res, {k[4:]: g[k] for k in g.files if k.startswith("pbc_")}, 96, "nse pbc96/reference golden")
+
+
+def test_nse_large_system_generic_kernels(hip_engine_nse, oracle32_nse):
+    """> 1024 atoms: the one-wave-per-atom (non-SPLIT) conv kernels and the sliced molecule reductions, two channels."""
+    from aimnetcentral_amd import workloads
+
+    c, z, cell = workloads.glucose_supercell((2, 3, 2))  # 1152 atoms
+    rng = np.random.Generator(np.random.PCG64(3))
+    c = (c + rng.normal(scale=0.02, size=c.shape)).astype(np.float32)
+    dev = hip_engine_nse.device
+    mol = np.zeros(len(z), dtype=np.int64)
+    r = hip_engine_nse.eval(torch.from_numpy(c).to(dev), torch.from_numpy(z).to(dev), torch.from_numpy(mol).to(dev),
+                            torch.from_numpy(_nse_charge(-1.0, 2.0)).to(dev), cell=torch.from_numpy(cell.astype(np.float32)).to(dev),
+                            forces=True, stress=True, coulomb="dsf", dsf_rc=8.0)
+    res = {k: v.cpu().numpy() for k, v in r.items()}
+    ref = O.evaluate(oracle32_nse, c, z, -1.0, cell=cell.astype(np.float32), coulomb="dsf", dsf_rc=8.0, stress=True, mult=2.0)
+    _compare_nse(res, ref, len(z), "nse 1152 atoms")
+
+
+def test_nse_engine_rejects_wrong_charge_shape(hip_engine_nse, hip_engine):
+    g = golden("taxol")
+    dev = hip_engine.device
+    c, z = torch.from_numpy(g["coord"]).to(dev), torch.from_numpy(g["numbers"]).to(dev)
+    mol = torch.zeros(113, dtype=torch.int32, device=dev)
+    with pytest.raises(ValueError):
+        hip_engine_nse.eval(c, z, mol, torch.zeros(1, device=dev))
+    with pytest.raises(ValueError):
+        hip_engine.eval(c, z, mol, torch.zeros(1, 2, device=dev))

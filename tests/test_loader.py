@@ -118,12 +118,21 @@ def test_missing_and_unexpected_state_dict_keys(art):
     loader.spec_from_artifact(a)
 
 
-def test_jpt_and_nse_are_loud(tmp_path, art):
+def test_jpt_is_loud_and_nse_shapes(tmp_path, art):
     with pytest.raises(NotImplementedError):
         loader.load_model(str(tmp_path / "legacy.JPT"))
+    # a 1-channel state dict under a 2-channel YAML is a size mismatch, as torch's load_state_dict reports it
     art["model_yaml"] = art["model_yaml"].replace("  aim_size: 256", "  aim_size: 256\n  num_charge_channels: 2")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="size mismatch for conv_q.agh"):
         loader.spec_from_artifact(art)
+    art["model_yaml"] = art["model_yaml"].replace("num_charge_channels: 2", "num_charge_channels: 3")
+    with pytest.raises(ValueError, match="num_charge_channels must be 1"):
+        loader.spec_from_artifact(art)
+    # the open-shell NSE family (aimnet2.py:21-28,53-85): MLP rows [a | conv_a | q(2) | conv_q(2 x 28)] = 762, outputs 256 + 4
+    spec = loader.synthetic_spec(0, num_charge_channels=2)
+    assert spec.num_charge_channels == 2
+    assert [d[0] for d in spec.mlp_dims] == [704, 762, 762] and [d[-1] for d in spec.mlp_dims] == [260, 260, 256]
+    assert spec.weights["conv_q.agh"].shape == (2, 16, 12)
 
 
 def test_runtime_metadata_rules():

@@ -141,3 +141,27 @@ def test_dftd3_term_matches_reference_twin(oracle64):
     e, f = _d3_only(oracle64, g["pbc_coord"], g["pbc_numbers"], np.zeros(96, dtype=np.int64), _d3_par(float(g["pbc_cutoff"])),
                     cell=g["pbc_cell"], coulomb="dsf")
     assert abs(e[0] - g["pbc_energy"][0]) < 6e-6 and np.abs(f - g["pbc_forces"]).max() < 2e-6
+
+
+def test_nse_two_charge_channels(oracle32_nse, synth_sd_nse):
+    """Open-shell NSE family (num_charge_channels = 2): charges = alpha + beta, spin_charges = alpha - beta, `mult` input."""
+    from aimnetcentral_amd import synth
+
+    g = golden("nse")
+    assert synth.state_dict_digest(synth_sd_nse) == str(g["weights_digest"])
+    r = O.evaluate(oracle32_nse, g["t40_coord"], g["t40_numbers"], g["t40_charge"], mult=g["t40_mult"])
+    assert abs(r["energy"][0] - g["t40_energy"][0]) <= energy_tol(40)
+    assert_forces_close(r["forces"], g["t40_forces"])
+    assert np.abs(r["charges"] - g["t40_charges"]).max() <= CHARGE_ATOL
+    assert np.abs(r["spin_charges"] - g["t40_spin_charges"]).max() <= CHARGE_ATOL
+    assert abs(r["spin_charges"].sum() - 1.0) < 5e-4 and abs(r["charges"].sum() - 1.0) < 5e-4  # eps = 1e-6 in ops.nse leaves ~1e-4
+    r = O.evaluate(oracle32_nse, g["b5_coord"], g["b5_numbers"], g["b5_charge"], g["b5_mol_idx"], mult=g["b5_mult"])
+    assert np.abs(r["energy"] - g["b5_energy"]).max() <= energy_tol(30)
+    assert_forces_close(r["forces"], g["b5_forces"])
+    assert np.abs(r["spin_charges"] - g["b5_spin_charges"]).max() <= CHARGE_ATOL
+    r = O.evaluate(oracle32_nse, g["pbc_coord"], g["pbc_numbers"], 0.0, cell=g["pbc_cell"], coulomb="dsf", dsf_rc=float(g["pbc_dsf_rc"]),
+                   stress=True, mult=g["pbc_mult"])
+    assert abs(r["energy"][0] - g["pbc_energy"][0]) <= energy_tol(96)
+    assert_forces_close(r["forces"], g["pbc_forces"])
+    assert np.abs(r["stress"] - g["pbc_stress"]).max() <= STRESS_ATOL
+    assert np.abs(r["spin_charges"] - g["pbc_spin_charges"]).max() <= CHARGE_ATOL

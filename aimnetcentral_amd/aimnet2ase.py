@@ -72,6 +72,8 @@ class AIMNet2ASE(Calculator):
             base_calc = AIMNet2Calculator(base_calc)
         self.base_calc = base_calc
         self.validate_species = validate_species
+        if self.base_calc.is_nse:  # aimnet2ase.py:62-63
+            self.__dict__["implemented_properties"] = [*self.__class__.implemented_properties, "spin_charges"]
         self.reset()
         self.charge = charge
         self.mult = mult
@@ -92,8 +94,12 @@ class AIMNet2ASE(Calculator):
     def check_state(self, atoms, tol=1e-15):
         state = super().check_state(atoms, tol=tol)
         if (not state) and getattr(self, "atoms", None) is not None:
-            if getattr(self.atoms, "info", {}).get("charge") != getattr(atoms, "info", {}).get("charge"):
+            old_info, new_info = getattr(self.atoms, "info", {}), getattr(atoms, "info", {})
+            if old_info.get("charge") != new_info.get("charge"):
                 state.append("info")
+            elif self.base_calc.is_nse:  # spin / multiplicity matter for NSE models only (aimnet2ase.py:100-105)
+                if old_info.get("spin", old_info.get("mult")) != new_info.get("spin", new_info.get("mult")):
+                    state.append("info")
         return state
 
     def set_charge(self, charge):
@@ -103,16 +109,23 @@ class AIMNet2ASE(Calculator):
         self.mult = mult
 
     def _charge_from_info(self, atoms):
-        charge = getattr(atoms, "info", {}).get("charge")
+        info = getattr(atoms, "info", {})
+        charge = info.get("charge")
         if charge is not None and charge != self.charge:
             self.charge = charge
+        if self.base_calc.is_nse:  # "mult" (AIMNet2 style) or "spin" (MACE style), both 2S+1 (aimnet2ase.py:136-142)
+            mult = info.get("mult", info.get("spin"))
+            if mult is not None and mult != self.mult:
+                self.mult = mult
 
     def get_dipole_moment(self, atoms=None):
         atoms = self.atoms if atoms is None else atoms
         return np.sum(np.asarray(self.results["charges"])[:, None] * np.asarray(atoms.positions), axis=0)
 
     def get_spin_charges(self, atoms=None):
-        raise PropertyNotImplementedError("spin_charges is not available. Use an NSE model.")
+        if "spin_charges" not in self.results:
+            raise PropertyNotImplementedError("spin_charges is not available. Use an NSE model (e.g. 'aimnet2nse').")
+        return self.results["spin_charges"]
 
     def get_hessian(self, atoms=None):
         atoms = getattr(self, "atoms", None) if atoms is None else atoms
@@ -150,13 +163,15 @@ class AIMNet2ASE(Calculator):
         res = {}
         for k, v in out.items():
             v = v.detach().cpu().numpy()
-            if batched and k in ("charges", "forces"):
+            if batched and k in ("charges", "spin_charges", "forces"):
                 v = v[0]
             res[k] = v
         self.results["energy"] = float(np.asarray(res["energy"]).reshape(-1)[0])
         self.results["free_energy"] = self.results["energy"]
         self.results["charges"] = res["charges"]
         self.results["dipole_moment"] = self.get_dipole_moment(self.atoms)
+        if "spin_charges" in res:
+            self.results["spin_charges"] = res["spin_charges"]
         if "forces" in properties:
             self.results["forces"] = res["forces"]
         if "stress" in properties:

@@ -174,7 +174,24 @@ class AIMNet2Calculator:
 
     @property
     def is_nse(self) -> bool:
-        return False
+        """True if the model has two charge channels (open-shell NSE family, calculator.py:473-476)."""
+        return int(getattr(self.engine, "nq", 1)) == 2
+
+    def _engine_charge(self, charge, mult):
+        """Molecular charge as the engine takes it: [n_mol], or for an NSE model the (alpha, beta) pair
+        Q/2 +- (mult-1)/2 of AIMNet2._preprocess_spin_polarized_charge (aimnet2.py:94-100) as [n_mol, 2]."""
+        import torch
+
+        if not self.is_nse:
+            return charge
+        if mult is None:
+            raise ValueError("mult key is required for NSE if two channels for charge are not provided")
+        if mult.shape[0] != charge.shape[0]:
+            if mult.shape[0] != 1:
+                raise ValueError(f"mult must have one entry per molecule ({charge.shape[0]}), got {mult.shape[0]}")
+            mult = mult.expand(charge.shape[0])
+        half_spin, half_q = 0.5 * (mult - 1.0), 0.5 * charge
+        return torch.stack([half_q + half_spin, half_q - half_spin], dim=-1)
 
     @property
     def coulomb_method(self) -> str | None:
@@ -200,7 +217,7 @@ class AIMNet2Calculator:
                 UserWarning, stacklevel=3)
 
     def _maybe_warn_mult_ignored(self, data) -> None:
-        if self._mult_ignored_checked:
+        if self._mult_ignored_checked or self.is_nse:
             return
         mult = data.get("mult")
         if mult is None:
@@ -368,20 +385,23 @@ class AIMNet2Calculator:
                     raise ValueError("pbc must have shape (3,) or (B, 3)")
                 pbc3 = tuple(bool(x) for x in p)
             res = self.engine.eval(
-                coord_f, numbers_f, mol_idx, charge, cell=cell, pbc=pbc3, forces=bool(forces), stress=bool(stress),
+                coord_f, numbers_f, mol_idx, self._engine_charge(charge, d.get("mult")), cell=cell, pbc=pbc3, forces=bool(forces),
+                stress=bool(stress),
                 coulomb=method or "none", dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, dftd3=self._dftd3_options())
         finally:
             if restore is not None:
                 (self._coulomb_method, self._coulomb_cutoff, self.cutoff_lr, self._dsf_alpha, self._dsf_rc) = restore
         # ---- process_output: un-flatten (calculator.py:1240-1245,1513-1519) -------------------------
         out: dict[str, Any] = {"energy": res["energy"], "charges": res["charges"]}
+        if "spin_charges" in res:
+            out["spin_charges"] = res["spin_charges"]
         if forces:
             out["forces"] = res["forces"]
         if stress:
             out["stress"] = res["stress"]
         if self._batch is not None:
             B = self._batch
-            for k in ("charges", "forces"):
+            for k in ("charges", "spin_charges", "forces"):
                 if k in out:
                     v = out[k]
                     if pad_mask is not None:
@@ -415,6 +435,8 @@ class AIMNet2Calculator:
         if not bool(real.all()):
             raise ValueError(f"{what}: padding atoms (Z = 0) are not allowed in a single-structure input")
         d["charge"] = d["charge"].reshape(-1)[:1]
+        if d.get("mult") is not None:
+            d["mult"] = d["mult"].reshape(-1)[:1]
         return d
 
     def _fd_hvp(self, d: dict[str, Any], dirs, step: float | None = None):
@@ -428,7 +450,8 @@ class AIMNet2Calculator:
         import torch
 
         h = float(self.FD_STEP if step is None else step)
-        coord, numbers, charge = d["coord"], d["numbers"], d["charge"]
+        coord, numbers = d["coord"], d["numbers"]
+        charge = self._engine_charge(d["charge"], d.get("mult"))
         cell, n = d.get("cell"), coord.shape[0]
         dirs = dirs.to(device=self.device, dtype=torch.float32)
         K = dirs.shape[0]
@@ -450,7 +473,8 @@ class AIMNet2Calculator:
             x = (coord.view(1, 1, n, 3) + offsets * u.view(kk, 1, n, 3)).reshape(kk * 4 * n, 3)
             res = self.engine.eval(
                 x, numbers.repeat(kk * 4), torch.arange(kk * 4, device=self.device, dtype=torch.int32).repeat_interleave(n),
-                charge.repeat(kk * 4), cell=cell, pbc=pbc3, forces=True, stress=False, coulomb=method or "none",
+                charge.repeat(kk * 4, *([1] * (charge.ndim - 1))), cell=cell, pbc=pbc3, forces=True, stress=False,
+                coulomb=method or "none",
                 dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, dftd3=self._dftd3_options())
             f = res["forces"].view(kk, 4, n, 3)
             out[k0 : k0 + kk] = (f * weights).sum(dim=1) * scale[k0 : k0 + kk].view(kk, 1, 1)

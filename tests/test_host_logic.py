@@ -22,6 +22,7 @@ class FakeEngine:
 
     def __init__(self, spec, device):
         self.spec, self.device, self.calls, self.d3_tables = spec, torch.device("cpu"), [], None
+        self.nq = int(getattr(spec, "num_charge_channels", 1))
 
     def set_dftd3_tables(self, tables):
         self.d3_tables = tables
@@ -30,9 +31,12 @@ class FakeEngine:
              coulomb="simple", dsf_rc=15.0, dsf_alpha=0.2, sync=True, dftd3=None):
         self.calls.append(dict(n=coord.shape[0], n_mol=charge.shape[0], coulomb=coulomb, dsf_rc=dsf_rc, dsf_alpha=dsf_alpha, dftd3=dftd3,
                                pbc=pbc, cell=None if cell is None else tuple(cell.shape), mol_idx=mol_idx.clone(),
-                               numbers=numbers.clone()))
+                               numbers=numbers.clone(), charge=charge.clone()))
         n = coord.shape[0]
         out = {"energy": torch.arange(charge.shape[0], dtype=torch.float64), "charges": torch.arange(n, dtype=torch.float32) + 1}
+        if self.nq == 2:
+            assert charge.ndim == 2 and charge.shape[1] == 2
+            out["spin_charges"] = -(torch.arange(n, dtype=torch.float32) + 1)
         if forces:
             out["forces"] = torch.ones(n, 3) * (torch.arange(n, dtype=torch.float32) + 1).unsqueeze(-1)
         if stress:
@@ -330,3 +334,72 @@ def test_torchsim_adapter_maps_a_flat_multi_system_state(calc):
     assert calc.engine.calls[-1]["cell"] == (3, 3, 3) and "stress" in out and "forces" not in out
     with pytest.raises(ValueError, match="one value per system"):
         model(_State(torch.from_numpy(c), torch.from_numpy(z), torch.from_numpy(mol), cell, True, 3, charge=[0.0, 1.0]))
+
+
+# ---- open-shell NSE models: mult -> (alpha, beta) charges, spin_charges output (calculator.py:418-451,473-476) ------------------
+@pytest.fixture()
+def nse_calc(monkeypatch):
+    monkeypatch.setattr(calc_mod, "HipEngine", FakeEngine)
+    monkeypatch.setattr(torch, "as_tensor", _as_tensor_cpu(torch.as_tensor))
+    c = calc_mod.AIMNet2Calculator(loader.synthetic_spec(0, num_charge_channels=2), device="cuda")
+    c.device = "cpu"
+    return c
+
+
+def test_nse_calculator_channels_and_outputs(nse_calc, calc):
+    import warnings as w
+
+    assert nse_calc.is_nse and not calc.is_nse
+    with pytest.raises(ValueError, match="mult key is required"):
+        nse_calc(WATER)
+    with w.catch_warnings():
+        w.simplefilter("error")  # no "mult is ignored" warning from an NSE model
+        out = nse_calc(dict(WATER, charge=1.0, mult=2.0), forces=True)
+    assert set(out) == {"energy", "charges", "spin_charges", "forces"} and out["spin_charges"].shape == (3,)
+    # (alpha, beta) = Q/2 +- (mult - 1)/2 (aimnet2.py:94-100)
+    assert nse_calc.engine.calls[-1]["charge"].tolist() == [[1.0, 0.0]]
+    # flat batch: one (charge, mult) per molecule; a scalar mult is broadcast
+    data = dict(coord=torch.randn(6, 3), numbers=[8, 1, 1, 8, 1, 1], mol_idx=[0, 0, 0, 1, 1, 1], charge=[0.0, -1.0], mult=[3.0, 2.0])
+    nse_calc(data)
+    assert nse_calc.engine.calls[-1]["charge"].tolist() == [[1.0, -1.0], [0.0, -1.0]]
+    nse_calc(dict(data, mult=1.0))
+    assert nse_calc.engine.calls[-1]["charge"].tolist() == [[0.0, 0.0], [-0.5, -0.5]]
+    # 3D batches un-flatten spin_charges like charges
+    out = nse_calc(dict(coord=torch.randn(2, 3, 3), numbers=[[8, 1, 1], [8, 1, 0]], charge=[0.0, 0.0], mult=[1.0, 3.0]))
+    assert out["spin_charges"].shape == (2, 3) and out["spin_charges"][1, 2] == 0
+    # closed-shell calculators still warn once that mult is ignored
+    with pytest.warns(UserWarning, match="is ignored"):
+        calc(dict(WATER, mult=3.0))
+
+
+def test_nse_fd_hessian_carries_both_channels(monkeypatch):
+    monkeypatch.setattr(calc_mod, "HipEngine", QuadraticEngine)
+    monkeypatch.setattr(torch, "as_tensor", _as_tensor_cpu(torch.as_tensor))
+    c = calc_mod.AIMNet2Calculator(loader.synthetic_spec(0, num_charge_channels=2), device="cuda")
+    c.device = "cpu"
+    a = torch.randn(9, 9, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    QuadraticEngine.A = a + a.T
+    out = c(dict(WATER, mult=3.0), hessian=True)
+    assert (out["hessian"].reshape(9, 9).double() - QuadraticEngine.A).abs().max() < 2e-3
+    ch = c.engine.calls[-1]["charge"]
+    assert ch.shape == (36, 2) and ch[0].tolist() == [1.0, -1.0] and bool((ch == ch[0]).all())
+
+
+def test_nse_ase_adapter_spin(nse_calc, calc):
+    """aimnet2ase.py:62-63,100-105,136-142,158-161: spin_charges property, info['mult'|'spin'] precedence and cache invalidation."""
+    from aimnetcentral_amd.aimnet2ase import AIMNet2ASE, PropertyNotImplementedError
+
+    a = AIMNet2ASE(nse_calc, charge=0, mult=1)
+    assert "spin_charges" in a.implemented_properties and "spin_charges" not in AIMNet2ASE.implemented_properties
+    atoms = _Atoms(WATER["numbers"], WATER["coord"], info={"charge": 1, "spin": 2})
+    a.calculate(atoms, properties=["energy"])
+    assert a.mult == 2 and nse_calc.engine.calls[-1]["charge"].tolist() == [[1.0, 0.0]]
+    assert a.get_spin_charges().shape == (3,)
+    atoms2 = atoms.copy()
+    atoms2.info = {"charge": 1, "mult": 4}
+    assert "info" in a.check_state(atoms2)  # a changed multiplicity invalidates the cache of an NSE calculator
+    closed = AIMNet2ASE(calc)
+    closed.calculate(atoms, properties=["energy"])
+    assert "info" not in closed.check_state(atoms2) and closed.mult == 1
+    with pytest.raises(PropertyNotImplementedError):
+        closed.get_spin_charges()

@@ -82,8 +82,24 @@ class AIMNet2ASE(Calculator):
         self.implemented_species = np.array(species, dtype=np.int64) if species else None
 
     def reset(self):
+        # ASE calls reset() on every change of the positions: only the results go; the device copies of numbers /
+        # charge / mult below are validated by content, so an MD step uploads nothing but the coordinates
         super().reset()
-        self._numbers = None
+
+    _numbers = None  # (host copy, device int32 tensor)
+    _qm = None       # ((charge, mult), device charge [1], device mult [1])
+
+    def _device_inputs(self, numbers):
+        import torch
+
+        dev = self.base_calc.device
+        if self._numbers is None or self._numbers[0].shape != numbers.shape or not np.array_equal(self._numbers[0], numbers):
+            self._numbers = (numbers.copy(), torch.as_tensor(numbers.astype(np.int32), device=dev))
+        key = (float(self.charge), float(self.mult))
+        if self._qm is None or self._qm[0] != key:
+            self._qm = (key, torch.as_tensor(np.array([key[0]], np.float32), device=dev),
+                        torch.as_tensor(np.array([key[1]], np.float32), device=dev))
+        return self._numbers[1], self._qm[1], self._qm[2]
 
     def set_atoms(self, atoms):
         if self.implemented_species is not None and not np.isin(atoms.numbers, self.implemented_species).all():
@@ -148,24 +164,22 @@ class AIMNet2ASE(Calculator):
         self._charge_from_info(self.atoms)
         pbc = np.asarray(self.atoms.pbc, dtype=bool)
         cell = _cell_array(self.atoms) if pbc.any() else None
-        coord = np.asarray(self.atoms.positions, dtype=np.float32)
-        numbers = np.asarray(self.atoms.numbers)
-        data = {"coord": coord, "numbers": numbers, "charge": np.float32(self.charge), "mult": np.float32(self.mult)}
-        batched = cell is None
-        if batched:  # non-periodic: a 3-D batch of one (aimnet2ase.py:248-251)
-            data = {"coord": coord[None], "numbers": numbers[None], "charge": np.array([self.charge], np.float32),
-                    "mult": np.array([self.mult], np.float32)}
-        else:
+        coord = np.ascontiguousarray(self.atoms.positions, dtype=np.float32)
+        # The reference hands non-periodic systems over as a 3-D batch of one (aimnet2ase.py:248-251) because its dense
+        # mode wants that; the native engine is flat either way, so one flat system is passed.  Per step the only uploads
+        # are the coordinates (and the cell), and every output returns with the engine's single status copy (host_out).
+        numbers_t, charge_t, mult_t = self._device_inputs(np.asarray(self.atoms.numbers))
+        data = {"coord": coord, "numbers": numbers_t, "charge": charge_t}
+        if self.base_calc.is_nse:
+            data["mult"] = mult_t
+        elif float(self.mult) != 1.0 and not getattr(self.base_calc, "_mult_ignored_checked", True):
+            data["mult"] = np.float32(self.mult)  # lets the closed-shell calculator warn once that it is ignored
+        if cell is not None:
             data["cell"] = cell.astype(np.float32)
             data["pbc"] = pbc
-        out = self.base_calc(data, forces="forces" in properties, stress="stress" in properties,
-                             validate_species=self.validate_species)
-        res = {}
-        for k, v in out.items():
-            v = v.detach().cpu().numpy()
-            if batched and k in ("charges", "spin_charges", "forces"):
-                v = v[0]
-            res[k] = v
+        out = self.base_calc.eval(data, forces="forces" in properties, stress="stress" in properties,
+                                  validate_species=self.validate_species, host_out=True)
+        res = {k: v.detach().cpu().numpy() for k, v in out.items()}
         self.results["energy"] = float(np.asarray(res["energy"]).reshape(-1)[0])
         self.results["free_energy"] = self.results["energy"]
         self.results["charges"] = res["charges"]

@@ -326,7 +326,10 @@ class AIMNet2Calculator:
                 ret[k] = v.unsqueeze(0)
         return ret
 
-    def eval(self, data: dict[str, Any], forces=False, stress=False, hessian=False, *, validate_species: bool = True) -> dict[str, Any]:
+    def eval(self, data: dict[str, Any], forces=False, stress=False, hessian=False, *, validate_species: bool = True,
+             host_out: bool = False) -> dict[str, Any]:
+        """calculator.py:879-947.  `host_out=True` (not in the reference) returns CPU tensors that arrived with the engine's one
+        status copy - for host-side drivers such as the ASE adapter that would otherwise pay one D2H round trip per output."""
         import torch
 
         if validate_species:
@@ -387,7 +390,8 @@ class AIMNet2Calculator:
             res = self.engine.eval(
                 coord_f, numbers_f, mol_idx, self._engine_charge(charge, d.get("mult")), cell=cell, pbc=pbc3, forces=bool(forces),
                 stress=bool(stress),
-                coulomb=method or "none", dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, dftd3=self._dftd3_options())
+                coulomb=method or "none", dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, dftd3=self._dftd3_options(),
+                **({"host_out": True} if host_out else {}))
         finally:
             if restore is not None:
                 (self._coulomb_method, self._coulomb_cutoff, self.cutoff_lr, self._dsf_alpha, self._dsf_rc) = restore
@@ -406,7 +410,7 @@ class AIMNet2Calculator:
                     v = out[k]
                     if pad_mask is not None:
                         full = torch.zeros((pad_mask.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-                        full[pad_mask] = v
+                        full[pad_mask.to(v.device)] = v
                         v = full
                     out[k] = v.view(B, -1, *v.shape[1:])
         assert n_mol == out["energy"].shape[0]

@@ -147,12 +147,15 @@ class HipEngine:
         dsf_alpha: float = 0.2,
         sync: bool = True,
         dftd3: dict[str, float] | None = None,
+        host_out: bool = False,
     ) -> dict[str, Any]:
         """One evaluation on device tensors (coord f32 [N,3], numbers/mol_idx i32 [N], charge f32
         [n_mol] - for a 2-channel NSE model [n_mol, 2] = the alpha / beta charges of aimnet2.py:94-100 -,
         cell f32 [3,3]|[n_mol,3,3]).  Returns device tensors (NSE: plus spin_charges); retries with x1.5 row
         capacity on neighbour overflow (neighbors.py:127-130).  `dftd3` = {s8, a1, a2[, s6, cutoff, smoothing_fraction]}
-        adds the external DFT-D3(BJ) term (needs set_dftd3_tables)."""
+        adds the external DFT-D3(BJ) term (needs set_dftd3_tables).  All outputs and the status words live in ONE device
+        buffer; `host_out=True` returns CPU tensors taken from the single D2H copy that fetches the status anyway (the
+        ASE adapter's path: no further .cpu() round trips)."""
         import torch
 
         dev = self.device
@@ -178,13 +181,31 @@ class HipEngine:
             cell = cell.to(device=dev, dtype=torch.float32).contiguous()
             n_cell = 1 if cell.ndim == 2 else cell.shape[0]
         method = {"none": _lib.COULOMB_NONE, "simple": _lib.COULOMB_SIMPLE, "dsf": _lib.COULOMB_DSF}[coulomb]
-        energy = torch.empty(n_mol, dtype=torch.float64, device=dev)
-        charges = torch.empty(n, dtype=torch.float32, device=dev)
-        spin = torch.empty(n, dtype=torch.float32, device=dev) if self.nq == 2 else None
-        f_out = torch.empty(n, 3, dtype=torch.float32, device=dev) if forces else None
-        s_out = torch.empty(max(n_cell, 1), 3, 3, dtype=torch.float32, device=dev) if stress else None
-        status = torch.empty(8, dtype=torch.int32, device=dev)  # zeroed by the engine at the start of every evaluation
+        # one allocation for status + every output (16-byte aligned sections); status is zeroed by the engine
+        sections = [("status", torch.int32, (8,)), ("energy", torch.float64, (n_mol,)), ("charges", torch.float32, (n,))]
+        if self.nq == 2:
+            sections.append(("spin_charges", torch.float32, (n,)))
+        if forces:
+            sections.append(("forces", torch.float32, (n, 3)))
+        if stress:
+            sections.append(("stress", torch.float32, (max(n_cell, 1), 3, 3)))
+        esize = {torch.int32: 4, torch.float32: 4, torch.float64: 8}
+        offs, nbytes, total = [], [], 0
+        for _, dt, shape in sections:
+            nb = math.prod(shape) * esize[dt]
+            offs.append(total)
+            nbytes.append(nb)
+            total += (nb + 15) // 16 * 16
+        outbuf = torch.empty(total, dtype=torch.uint8, device=dev)
+
+        def views(buf):
+            return {name: buf[o : o + nb].view(dt).view(shape) for (name, dt, shape), o, nb in zip(sections, offs, nbytes)}
+
+        dv = views(outbuf)
+        energy, charges, status = dv["energy"], dv["charges"], dv["status"]
+        spin, f_out, s_out = dv.get("spin_charges"), dv.get("forces"), dv.get("stress")
         stream = torch.cuda.current_stream(dev).cuda_stream
+        host = None
         while True:
             opt = _lib.EvalOptions()
             opt.flags = (_lib.FORCES if forces else 0) | (_lib.STRESS if stress else 0)
@@ -226,7 +247,12 @@ class HipEngine:
             _lib.check(rc, "aimnet_engine_eval")
             if not sync:
                 break
-            st = status.cpu().numpy()  # the one D2H sync of a step (the reference has one per list, neighbors.py:133)
+            # the one D2H sync of a step (the reference has one per list, neighbors.py:133)
+            if host_out:
+                host = outbuf.cpu()
+                st = host[:32].view(torch.int32).numpy()
+            else:
+                st = status.cpu().numpy()
             self.last_status = st
             retry = False
             if st[2]:
@@ -241,6 +267,9 @@ class HipEngine:
                 retry = True
             if not retry:
                 break
+        if host is not None:
+            hv = views(host)
+            energy, charges, spin, f_out, s_out = hv["energy"], hv["charges"], hv.get("spin_charges"), hv.get("forces"), hv.get("stress")
         res: dict[str, Any] = {"energy": energy, "charges": charges}
         if spin is not None:
             res["spin_charges"] = spin

@@ -277,3 +277,16 @@ def test_nse_engine_rejects_wrong_charge_shape(hip_engine_nse, hip_engine):
         hip_engine_nse.eval(c, z, mol, torch.zeros(1, device=dev))
     with pytest.raises(ValueError):
         hip_engine.eval(c, z, mol, torch.zeros(1, 2, device=dev))
+
+
+def test_host_out_returns_the_same_numbers_on_the_host(hip_engine):
+    """engine.eval(host_out=True): every output travels with the one status copy (the ASE adapter's path)."""
+    g = golden("pbc96_dsf8_wrapped")
+    a, _ = run(hip_engine, g, "dsf", stress=True, dsf_rc=8.0, dsf_alpha=0.25)
+    dev = hip_engine.device
+    r = hip_engine.eval(torch.from_numpy(g["coord"]).to(dev), torch.from_numpy(g["numbers"]).to(dev), torch.zeros(96, dtype=torch.int32, device=dev),
+                        torch.zeros(1, device=dev), cell=torch.from_numpy(g["cell"]).to(dev), forces=True, stress=True, coulomb="dsf",
+                        dsf_rc=8.0, dsf_alpha=0.25, host_out=True)
+    assert all(v.device.type == "cpu" for v in r.values()) and r["energy"].dtype == torch.float64
+    for k in ("energy", "charges", "forces", "stress"):
+        assert np.array_equal(r[k].numpy(), a[k]), k

@@ -28,8 +28,8 @@ class FakeEngine:
         self.d3_tables = tables
 
     def eval(self, coord, numbers, mol_idx, charge, cell=None, pbc=(True, True, True), forces=False, stress=False,
-             coulomb="simple", dsf_rc=15.0, dsf_alpha=0.2, sync=True, dftd3=None):
-        self.calls.append(dict(n=coord.shape[0], n_mol=charge.shape[0], coulomb=coulomb, dsf_rc=dsf_rc, dsf_alpha=dsf_alpha, dftd3=dftd3,
+             coulomb="simple", dsf_rc=15.0, dsf_alpha=0.2, sync=True, dftd3=None, host_out=False):
+        self.calls.append(dict(host_out=host_out, n=coord.shape[0], n_mol=charge.shape[0], coulomb=coulomb, dsf_rc=dsf_rc, dsf_alpha=dsf_alpha, dftd3=dftd3,
                                pbc=pbc, cell=None if cell is None else tuple(cell.shape), mol_idx=mol_idx.clone(),
                                numbers=numbers.clone(), charge=charge.clone()))
         n = coord.shape[0]
@@ -228,6 +228,14 @@ def test_ase_adapter_contract(calc):
     assert isinstance(r["energy"], float) and r["forces"].shape == (3, 3) and r["charges"].shape == (3,)
     assert np.allclose(r["dipole_moment"], (r["charges"][:, None] * atoms.positions).sum(0))
     assert "stress" not in r
+    # an MD step uploads coordinates only: numbers / charge stay the cached device tensors, outputs come back with the status copy
+    assert call["host_out"] is True
+    t_numbers = ase_calc._numbers[1]
+    moved = atoms.copy()
+    moved.positions = moved.positions + 0.01
+    ase_calc.reset()  # what ASE does when the positions change
+    ase_calc.calculate(moved, properties=["energy", "forces"])
+    assert ase_calc._numbers[1] is t_numbers and calc.engine.calls[-1]["numbers"].tolist() == [8, 1, 1]
     with pytest.raises(ValueError, match="not implemented"):
         ase_calc.set_atoms(_Atoms([8, 1, 2], WATER["coord"]))
     # periodic: flat input with cell + pbc, DSF auto-switch warning from the calculator

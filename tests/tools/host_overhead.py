@@ -18,3 +18,20 @@ print("engine.eval, device tensors      %.3f ms" % bench(lambda: calc.engine.eva
 print("calculator, device tensors       %.3f ms" % bench(lambda: calc({"coord": c_t, "numbers": z_t, "charge": q}, forces=True)))
 print("calculator, numpy in             %.3f ms" % bench(lambda: calc({"coord": c_np, "numbers": z_np, "charge": 0.0}, forces=True)))
 print("calculator, numpy in + .cpu() out %.3f ms" % bench(lambda: {k: v.cpu() for k, v in calc({"coord": c_np, "numbers": z_np, "charge": 0.0}, forces=True).items()}))
+
+# the ASE adapter's MD step: positions change every call, everything else is cached on the device
+from aimnetcentral_amd.aimnet2ase import AIMNet2ASE
+class _Atoms:
+    def __init__(self, numbers, positions):
+        self.numbers, self.positions, self.cell, self.pbc, self.info = numbers, positions, None, np.zeros(3, bool), {}
+    def copy(self):
+        return _Atoms(self.numbers.copy(), self.positions.copy())
+    def __len__(self):
+        return len(self.numbers)
+ase = AIMNet2ASE(calc)
+atoms = _Atoms(z_np.astype(np.int64), c_np.astype(np.float64))
+def md_step():
+    atoms.positions += 1e-4
+    ase.reset()
+    ase.calculate(atoms, properties=["energy", "forces"])
+print("AIMNet2ASE.calculate (MD step)   %.3f ms" % bench(md_step))

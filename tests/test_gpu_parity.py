@@ -290,3 +290,19 @@ def test_host_out_returns_the_same_numbers_on_the_host(hip_engine):
     assert all(v.device.type == "cpu" for v in r.values()) and r["energy"].dtype == torch.float64
     for k in ("energy", "charges", "forces", "stress"):
         assert np.array_equal(r[k].numpy(), a[k]), k
+
+
+def test_nse_with_dftd3_and_dsf_in_one_pair_pass(hip_engine_nse, oracle32_nse):
+    """NSE + periodic DSF + external D3 with one cutoff: the merged pair pass sees alpha + beta and seeds both channels' dE/dq."""
+    g = golden("nse")
+    par, tables = _d3(9.0, 0.25)
+    hip_engine_nse.set_dftd3_tables(tables)
+    dev = hip_engine_nse.device
+    mol = np.zeros(96, dtype=np.int64)
+    r = hip_engine_nse.eval(torch.from_numpy(g["pbc_coord"]).to(dev), torch.from_numpy(g["pbc_numbers"]).to(dev), torch.from_numpy(mol).to(dev),
+                            torch.from_numpy(_nse_charge(1.0, 2.0)).to(dev), cell=torch.from_numpy(g["pbc_cell"]).to(dev),
+                            forces=True, stress=True, coulomb="dsf", dsf_rc=9.0, dftd3=par)
+    res = {k: v.cpu().numpy() for k, v in r.items()}
+    ref = O.evaluate(oracle32_nse, g["pbc_coord"], g["pbc_numbers"], 1.0, cell=g["pbc_cell"], coulomb="dsf", dsf_rc=9.0, stress=True,
+                     mult=2.0, dftd3=dict(par, **tables))
+    _compare_nse(res, ref, 96, "nse pbc96 + d3")

@@ -137,8 +137,10 @@ struct FwdWaveLds {
 // that each walk ~31 dependent gathers; split four ways the chain is 8 long and 4x as many waves hide its latency.
 // NQ: charge channels convolved alongside the features: 0 (pass 0), 1, or 2 (NSE models; q = planes [NQ][n_atoms],
 // agh_q [NQ][G][H], row layout [q (NQ) | S^q_s (NQ x 16) | |V^q|^2 (NQ x 12)] as ConvSV(nchannel=NQ) emits it, aev.py:188).
+// one wave per atom: four blocks per CU = 4 waves per SIMD (128 VGPRs; the kernel is latency-bound and gains 6 % over three);
+// SPLIT holds three blocks' worth of LDS per CU anyway
 template <int NQ, bool SPLIT>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
+__global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
                                                       const float* __restrict__ q,
                                                       const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
                                                       const float4* __restrict__ pg, int cap,
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
   __shared__ float s_agh[A_ * G_ * H_];
   constexpr bool HAS_Q = NQ > 0;
   constexpr int NQC = NQ > 0 ? NQ : 1;
+  constexpr int UNR_T = SPLIT ? 3 : 1, UNR_G = SPLIT ? 16 : 4;  // unroll factors of the agh contraction in the epilogue
   __shared__ float s_aghq[NQC * G_ * H_];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   for (int k = threadIdx.x; k < A_ * G_ * H_; k += 256) s_agh[k] = agh_a[k];
@@ -303,12 +306,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
     __syncthreads();
     if (live) {
       float* xr = x + (size_t)i * ldx;
-#pragma unroll
+      // one-wave-per-atom form: rolled, the contraction keeps the kernel at 128 VGPRs with 6 spilled dwords instead of 22
+#pragma unroll UNR_T
       for (int t = 0; t < 3; ++t) {
         const int o = lane + 64 * t;  // (a, h) = (o / 12, o % 12)
         const int aa = o / H_, hh = o % H_;
         float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-#pragma unroll
+#pragma unroll UNR_G
         for (int g = 0; g < G_; ++g) {
           const float w = s_agh[(aa * G_ + g) * H_ + hh];
           const float* s3 = &sv[(aa * G_ + g) * 3];

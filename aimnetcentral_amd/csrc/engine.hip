@@ -158,7 +158,7 @@ struct Workspace {
   float* hD[AIMNET_MAX_LAYERS];
   float* e_atom;
   double* ecoul;
-  float *qbar, *fgrad, *virial_atom, *abar, *Wbar;
+  float *qbar, *fgrad, *virial_atom, *abar;
   float* qtot;   // NSE models: alpha + beta charges (the Coulomb kernels and the `charges` output see these)
   double* part;  // per-(system, slice) partial sums of the molecule reductions
   int S;         // slices per molecule
@@ -248,7 +248,6 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   W.qtot = c.take<float>(e->nq > 1 ? n : 0, "qtot", 1);
   W.fgrad = c.take<float>(n * 3, "fgrad", 3);
   W.virial_atom = c.take<float>(n * 9);
-  W.Wbar = c.take<float>((size_t)n_mol * e->nq);
   W.S = std::min(128, std::max(1, (N / std::max(1, n_mol) + 511) / 512));
   W.part = c.take<double>((size_t)n_mol * W.S * 9);
   if (grad) {
@@ -612,7 +611,9 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       ld_in = L.k_out;
     }
     RC(prof_mark(e, s, FAM_POINTWISE));
-    RC(launch_head_last(s, hin, ld_in, e->head_w_last, e->head_b_last, e->head[nh - 1].n_in, N, W.e_atom));
+    // with gradients: the same kernel writes the backward seed d e / d z_{nh-2} = w_last * GELU'(z) into zb0
+    RC(launch_head_last(s, hin, ld_in, e->head_w_last, e->head_b_last, e->head[nh - 1].n_in, N, W.e_atom,
+                        grad ? W.hD[nh - 2] : nullptr, grad ? W.zb0 : nullptr));
   }
 
   // ---- Coulomb: energies, and the seeds of qbar / dE/dx / virial -------------------------------
@@ -659,9 +660,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   float* znext = W.zb1;
   {
     const int nh = (int)e->head.size();
-    // seed: d e / d z_{nh-2} = w_last * GELU'(z)
-    const Layer& Lp = e->head[nh - 2];
-    RC(launch_head_seed(s, e->head_w_last, W.hD[nh - 2], Lp.k_out, Lp.n_out, N, zcur));
+    const Layer& Lp = e->head[nh - 2];  // zcur = zb0 holds the seed written by launch_head_last
     int ld = Lp.k_out;
     RC(prof_mark(e, s, FAM_GEMM));
     for (int l = nh - 2; l >= 0; --l) {
@@ -714,9 +713,9 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const float* y = W.H[p - 1][nlq - 1];
     const int ldy = Lq[nlq - 1].k_out;
     RC(prof_mark(e, s, FAM_POINTWISE));
-    RC(launch_nse_bwd_reduce(s, W.qbar, y, ldy, nq, W.Fm[p - 1], W.nl.mol_start, n_mol, N, W.S, (float*)W.part, W.Wbar));
+    RC(launch_nse_bwd_reduce(s, W.qbar, y, ldy, nq, W.nl.mol_start, n_mol, N, W.S, (float*)W.part));
     RC(launch_build_zbar(s, W.qbar, W.abar, y, ldy, ar.last_linear[p - 1] ? nullptr : W.D[p - 1][nlq - 1], W.Fm[p - 1],
-                         W.Dm[p - 1], W.Wbar, in->mol_idx, N, n_mol, 256, nq, p - 1 > 0, znext, W.qbar));
+                         W.Dm[p - 1], (const float*)W.part, W.S, in->mol_idx, N, n_mol, 256, nq, p - 1 > 0, znext, W.qbar));
     std::swap(zcur, znext);
   }
   RC(prof_mark(e, s, FAM_POINTWISE));

@@ -98,9 +98,9 @@ int launch_nse_fwd(hipStream_t s, const float* y, int ldy, int nq, const float* 
                    const float* charge, int n_mol, int n_atoms, int S, float* part, float* q_new, float* Fm, float* Dm);
 int launch_charge_sum(hipStream_t s, const float* q2, int n_atoms, float* q_tot, float* q_spin);
 int launch_update_a(hipStream_t s, const float* a, const float* y, int ldy, int nq, int n_atoms, float* a_new);
+// d / zbar (may be NULL): also writes the backward seed zbar = w * d (d = GELU' of the layer below, ldh wide)
 int launch_head_last(hipStream_t s, const float* h, int ldh, const float* w, const float* b, int k, int n_atoms,
-                     float* e_atom);
-int launch_head_seed(hipStream_t s, const float* w, const float* d, int ldd, int k, int n_atoms, float* zbar);
+                     float* e_atom, const float* d, float* zbar);
 int launch_energy_reduce(hipStream_t s, const float* e_atom, const double* ecoul, const int* numbers,
                          const double* sae, const int* mol_start, int n_mol, int S, double* part, double* energy);
 struct CoulombParams {
@@ -142,11 +142,11 @@ int launch_coulomb_dsf(hipStream_t s, bool grad, bool stress, const float* q, co
 // periodic DSF straight from the cell grid of the last launch_bins (no neighbour matrix)
 int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, NlistBuffers& b,
                             CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom);
-int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, int nq, const float* Fm,
-                          const int* mol_start, int n_mol, int n_atoms, int S, float* part, float* Wbar);
+int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, int nq, const int* mol_start, int n_mol,
+                          int n_atoms, int S, float* part);  // part: [nq][n_mol][S] partial sums, consumed by launch_build_zbar
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
-                      const float* Fm, const float* Dm, const float* Wbar, const int* mol_idx, int n_atoms, int n_mol, int n_feat,
-                      int nq, bool carry_q, float* zbar, float* qbar_next);
+                      const float* Fm, const float* Dm, const float* wpart, int S, const int* mol_idx, int n_atoms, int n_mol,
+                      int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next);
 int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
                     const float* cell, int n_cell, int n_mol, int n_atoms, int S, double* part, float* forces,
                     float* stress);

@@ -177,8 +177,11 @@ int launch_update_a(hipStream_t s, const float* a, const float* y, int ldy, int 
 }
 
 // ---- energy head last layer (k -> 1) and its adjoint seed ---------------------------------------
+// d / zbar (may be NULL): the adjoint seed of the backward sweep, zbar = w * GELU'(z) of the layer below (ldh wide, zero
+// padding beyond k), is written by the same wave - dE/de_atom = 1, so it does not wait for anything
 __global__ void head_last_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ w,
-                                 const float* __restrict__ b, int k, int n_atoms, float* __restrict__ e_atom) {
+                                 const float* __restrict__ b, int k, int n_atoms, float* __restrict__ e_atom,
+                                 const float* __restrict__ d, float* __restrict__ zbar) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
@@ -186,26 +189,13 @@ __global__ void head_last_kernel(const float* __restrict__ h, int ldh, const flo
   for (int c = lane; c < k; c += 64) acc += h[(size_t)i * ldh + c] * w[c];
   acc = wave_sum(acc);
   if (lane == 0) e_atom[i] = acc + b[0];
+  if (zbar)
+    for (int c = lane; c < ldh; c += 64) zbar[(size_t)i * ldh + c] = (c < k) ? w[c] * d[(size_t)i * ldh + c] : 0.0f;
 }
 
 int launch_head_last(hipStream_t s, const float* h, int ldh, const float* w, const float* b, int k, int n_atoms,
-                     float* e_atom) {
-  hipLaunchKernelGGL(head_last_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, h, ldh, w, b, k, n_atoms, e_atom);
-  AIMNET_LAUNCH_CHECK();
-  return 0;
-}
-
-__global__ void head_seed_kernel(const float* __restrict__ w, const float* __restrict__ d, int ldd, int k, int n_atoms,
-                                 float* __restrict__ zbar) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (size_t)n_atoms * ldd) return;
-  const int c = (int)(e % ldd);
-  zbar[e] = (c < k) ? w[c] * d[e] : 0.0f;
-}
-
-int launch_head_seed(hipStream_t s, const float* w, const float* d, int ldd, int k, int n_atoms, float* zbar) {
-  const size_t n = (size_t)n_atoms * ldd;
-  hipLaunchKernelGGL(head_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, d, ldd, k, n_atoms, zbar);
+                     float* e_atom, const float* d, float* zbar) {
+  hipLaunchKernelGGL(head_last_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, h, ldh, w, b, k, n_atoms, e_atom, d, zbar);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }
@@ -580,24 +570,14 @@ __global__ __launch_bounds__(256) void nse_bwd_partial_kernel(const float* __res
   if (threadIdx.x == 0) part[(size_t)m * S + sl] = r;
 }
 
-__global__ void nse_bwd_finish_kernel(const float* __restrict__ part, int S, int n_mol, const float* __restrict__ Fm,
-                                      float* __restrict__ Wbar) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= n_mol) return;
-  float r = 0.f;
-  for (int k = 0; k < S; ++k) r += part[(size_t)m * S + k];
-  Wbar[m] = r / Fm[m];
-}
-
-int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, int nq, const float* Fm,
-                          const int* mol_start, int n_mol, int n_atoms, int S, float* part, float* Wbar) {
+// partial sums of sum_i qbar_i f_i per (channel, molecule, slice) into part[(ch n_mol + m) S + sl]; build_zbar adds the S
+// slices in slice order (what a separate finish kernel used to do) and divides by F_m
+int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, int nq, const int* mol_start, int n_mol,
+                          int n_atoms, int S, float* part) {
   S = S < 1 ? 1 : S;
   for (int ch = 0; ch < nq; ++ch) {
     hipLaunchKernelGGL(nse_bwd_partial_kernel, dim3(S, n_mol), dim3(256), 0, s, qbar + (size_t)ch * n_atoms, y, ldy, nq + ch,
-                       mol_start, S, part);
-    AIMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nse_bwd_finish_kernel, dim3(ceil_div(n_mol, 64)), dim3(64), 0, s, part, S, n_mol, Fm + (size_t)ch * n_mol,
-                       Wbar + (size_t)ch * n_mol);
+                       mol_start, S, part + (size_t)ch * n_mol * S);
     AIMNET_LAUNCH_CHECK();
   }
   return 0;
@@ -605,12 +585,13 @@ int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int 
 
 // zbar[i] = adjoint of the LAST linear layer's pre-activation of this pass' MLP:
 //   ybar = [q~bar (nq), f~bar (nq), delta_a bar(n_feat)], times GELU'(z_last) when the MLP ends with GELU.
-// qbar / qbar_next: nq planes of [n_atoms]; Fm, Dm, Wbar: nq planes of [n_mol].
+// qbar / qbar_next: nq planes of [n_atoms]; Fm, Dm: nq planes of [n_mol]; wpart: launch_nse_bwd_reduce's partial sums.
 __global__ void build_zbar_kernel(const float* __restrict__ qbar, const float* __restrict__ abar,
                                   const float* __restrict__ y, int ldy, const float* __restrict__ dlast,
                                   const float* __restrict__ Fm, const float* __restrict__ Dm,
-                                  const float* __restrict__ Wbar, const int* __restrict__ mol_idx, int n_atoms, int n_mol,
-                                  int n_feat, int nq, int carry_q, float* __restrict__ zbar, float* __restrict__ qbar_next) {
+                                  const float* __restrict__ wpart, int S, const int* __restrict__ mol_idx, int n_atoms,
+                                  int n_mol, int n_feat, int nq, int carry_q, float* __restrict__ zbar,
+                                  float* __restrict__ qbar_next) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
@@ -618,8 +599,11 @@ __global__ void build_zbar_kernel(const float* __restrict__ qbar, const float* _
   // every lane reads both channels' qbar before anything is written: qbar_next may alias qbar
   float qr[2] = {0.f, 0.f}, fsc[2] = {0.f, 0.f};
   for (int ch = 0; ch < nq; ++ch) {
-    qr[ch] = qbar[(size_t)ch * n_atoms + i] - Wbar[(size_t)ch * n_mol + m];
-    fsc[ch] = Dm[(size_t)ch * n_mol + m] / Fm[(size_t)ch * n_mol + m];
+    const float F = Fm[(size_t)ch * n_mol + m];
+    float wsum = 0.f;  // Wbar_m = (sum_i qbar_i f_i) / F_m, the S slices added in slice order (wave-uniform loads)
+    for (int k = 0; k < S; ++k) wsum += wpart[((size_t)ch * n_mol + m) * S + k];
+    qr[ch] = qbar[(size_t)ch * n_atoms + i] - wsum / F;
+    fsc[ch] = Dm[(size_t)ch * n_mol + m] / F;
   }
   float* zr = zbar + (size_t)i * ldy;
   const float* dr = dlast ? dlast + (size_t)i * ldy : nullptr;
@@ -636,10 +620,10 @@ __global__ void build_zbar_kernel(const float* __restrict__ qbar, const float* _
 }
 
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
-                      const float* Fm, const float* Dm, const float* Wbar, const int* mol_idx, int n_atoms, int n_mol, int n_feat,
-                      int nq, bool carry_q, float* zbar, float* qbar_next) {
-  hipLaunchKernelGGL(build_zbar_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, qbar, abar, y, ldy, dlast, Fm, Dm, Wbar,
-                     mol_idx, n_atoms, n_mol, n_feat, nq, carry_q ? 1 : 0, zbar, qbar_next);
+                      const float* Fm, const float* Dm, const float* wpart, int S, const int* mol_idx, int n_atoms, int n_mol,
+                      int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next) {
+  hipLaunchKernelGGL(build_zbar_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, qbar, abar, y, ldy, dlast, Fm, Dm, wpart,
+                     S < 1 ? 1 : S, mol_idx, n_atoms, n_mol, n_feat, nq, carry_q ? 1 : 0, zbar, qbar_next);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

@@ -17,6 +17,9 @@
 //   * the fragment reads are inline asm: hipcc puts a conservative `s_waitcnt vmcnt(0)` in front of every C++ LDS
 //     read that follows a global_load_lds, which would drain the ring on every K tile; with asm reads the only
 //     vmcnt wait is ours ("tile kt has landed, the younger tiles may still be in flight");
+//   * the panel kernel exists with 16-deep stages (ring of 4) and 32-deep stages (ring of 3: half the barriers, and the
+//     second half's fragment reads overlap the first half's MFMAs); choose_tile() takes the deep form where its LDS
+//     footprint does not cost a resident block;
 //   * gemm_nt_panel_kernel (512 threads, 16x16x4 MFMA, block tiles from 48x128 to 160x192) carries the MLP layers of
 //     large batches; gemm_nt_ring_kernel (256 threads, 32x32x2 MFMA, 64x64 tiles, scalar epilogue without alignment
 //     requirements) serves small M and unaligned outputs.  choose_tile() picks per launch.
@@ -189,29 +192,46 @@ __device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
 }
-// fragments f[I..N) of consecutive 16-row strips: strip i sits i * 1024 bytes further (16 rows x 64 B)
-template <int I, int N>
+// fragments f[I..N) of consecutive 16-row strips: strip i sits i * STRIP bytes further (16 rows x BK floats)
+template <int I, int N, int STRIP>
 __device__ __forceinline__ void read_frags(f32x4 (&f)[N], unsigned addr) {
   if constexpr (I < N) {
-    f[I] = lds_read16<I * 1024>(addr);
-    read_frags<I + 1, N>(f, addr);
+    f[I] = lds_read16<I * STRIP>(addr);
+    read_frags<I + 1, N, STRIP>(f, addr);
   }
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+// granule slot of k-chunk c in row r of a stage with BK floats per row: an XOR swizzle that makes every lane group of a
+// ds_read_b128 ({0-3, 12-15, 20-27}, ...) touch all 64 banks once.  64-byte rows: 4 rows per 256 B bank window;
+// 128-byte rows: 2 rows per window, so the row pair index is folded in instead.
+template <int BK>
+__device__ __forceinline__ int swz(int row) {
+  return BK == 16 ? 3 * ((row >> 3) & 1) : ((row >> 1) & 7);
+}
 
-template <int EPI, int SM, int SN, int WM, int WN>
-__global__ __launch_bounds__(512, (SM * SN > 10 ? 2 : 4)) void gemm_nt_panel_kernel(
+// BK = 16: four stages of [TM|TN] x 16 floats.  BK = 32: three stages of twice the depth - one barrier per 32 k, and the
+// LDS reads of the second 16-k half are in flight while the MFMAs of the first half run (the barrier re-aligns all eight
+// waves every stage, so with BK = 16 the read latency of every stage is exposed on both waves of a SIMD at once).
+template <int EPI, int SM, int SN, int WM, int WN, int BK = 16>
+__global__ __launch_bounds__(512, ((SM * SN > 10 || (BK == 32 && 16 * (SM * WM + SN * WN) > 208)) ? 2 : 4)) void gemm_nt_panel_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb, int M, int N, int K,
     const float* __restrict__ bias, float* __restrict__ C, float* __restrict__ D, int ldc) {
   static_assert(WM * WN == 8, "8 waves");
-  constexpr int NST = 4;
-  constexpr int TM = 16 * SM * WM, TN = 16 * SN * WN, BK = 16;
+  static_assert(BK == 16 || BK == 32, "BK");
+  constexpr int NST = BK == 16 ? 4 : 3;
+  constexpr int TM = 16 * SM * WM, TN = 16 * SN * WN;
+  constexpr int GPR = BK / 4;                   // 16-byte granules per row
   constexpr int STAGE_BYTES = (TM + TN) * BK * 4;
-  constexpr int NGRAN = (TM + TN) * 4;          // 16-byte granules per stage
+  constexpr int NGRAN = (TM + TN) * GPR;        // 16-byte granules per stage
   constexpr int NPASS = (NGRAN + 511) / 512;    // DMA wave-instructions per wave per stage (last pass may be partial)
+  constexpr int STRIP = 16 * BK * 4;            // bytes between consecutive 16-row strips
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
@@ -237,8 +257,8 @@ __global__ __launch_bounds__(512, (SM * SN > 10 ? 2 : 4)) void gemm_nt_panel_ker
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
     const int G = min(p * 512 + tid, NGRAN - 1);
-    const int row = G >> 2;
-    const int kc = (G & 3) ^ (3 * ((row >> 3) & 1));
+    const int row = G / GPR;
+    const int kc = (G % GPR) ^ swz<BK>(row);
     src[p] = (row < TM) ? A + (size_t)min(m0 + row, M - 1) * lda + kc * 4
                         : Bt + (size_t)min(n0 + row - TM, N - 1) * ldb + kc * 4;
   }
@@ -251,12 +271,15 @@ __global__ __launch_bounds__(512, (SM * SN > 10 ? 2 : 4)) void gemm_nt_panel_ker
     if (last_pass) glds16(src[NPASS - 1] + k0, base + (NPASS - 1) * 512 * 4);
   };
 
-  // fragment byte addresses in stage 0: row r, k-chunk c = lane>>4 -> (r*4 + (c ^ swz(r))) * 16; strip i adds i*1024 B
+  // fragment byte addresses in stage 0: row r, k-chunk c = lane>>4 (+4 for the second half of a 32-deep stage)
+  // -> (r*GPR + (c ^ swz(r))) * 16; strip i adds i*STRIP bytes
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
   const int l16 = lane & 15, lc = lane >> 4;
   const int rA = wm * 16 * SM + l16, rB = wn * 16 * SN + l16;
-  const unsigned adA = lds0 + (rA * 4 + (lc ^ (3 * ((rA >> 3) & 1)))) * 16;
-  const unsigned adB = lds0 + TM * 64 + (rB * 4 + (lc ^ (3 * ((rB >> 3) & 1)))) * 16;
+  const unsigned adA = lds0 + (rA * GPR + (lc ^ swz<BK>(rA))) * 16;
+  const unsigned adB = lds0 + TM * BK * 4 + (rB * GPR + (lc ^ swz<BK>(rB))) * 16;
+  const unsigned adA2 = lds0 + (rA * GPR + ((lc + 4) ^ swz<BK>(rA))) * 16;
+  const unsigned adB2 = lds0 + TM * BK * 4 + (rB * GPR + ((lc + 4) ^ swz<BK>(rB))) * 16;
 
   const int nk = K / BK;
 #pragma unroll
@@ -275,20 +298,49 @@ __global__ __launch_bounds__(512, (SM * SN > 10 ? 2 : 4)) void gemm_nt_panel_ker
 
     const unsigned so = st * STAGE_BYTES;
     f32x4 fa[SM], fb[SN];
-    read_frags<0, SN>(fb, adB + so);
-    read_frags<0, SM>(fa, adA + so);
-    // one drain that "produces" every fragment (empty asm ties), so no MFMA can be scheduled above it
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    read_frags<0, SN, STRIP>(fb, adB + so);
+    read_frags<0, SM, STRIP>(fa, adA + so);
+    if constexpr (BK == 32) {
+      f32x4 fa2[SM], fb2[SN];
+      read_frags<0, SN, STRIP>(fb2, adB2 + so);
+      read_frags<0, SM, STRIP>(fa2, adA2 + so);
+      // LDS returns in order: the first half's fragments have landed when at most SM + SN reads are outstanding
+      wait_lgkmcnt<(SM + SN < 15 ? SM + SN : 15)>();
 #pragma unroll
-    for (int i = 0; i < SM; ++i) asm volatile("" : "+v"(fa[i]));
+      for (int i = 0; i < SM; ++i) asm volatile("" : "+v"(fa[i]));
 #pragma unroll
-    for (int j = 0; j < SN; ++j) asm volatile("" : "+v"(fb[j]));
+      for (int j = 0; j < SN; ++j) asm volatile("" : "+v"(fb[j]));
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int i = 0; i < SM; ++i)
+        for (int i = 0; i < SM; ++i)
 #pragma unroll
-        for (int j = 0; j < SN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][t], fa[i][t], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < SN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][t], fa[i][t], acc[i][j], 0, 0, 0);
+      wait_lgkmcnt<0>();
+#pragma unroll
+      for (int i = 0; i < SM; ++i) asm volatile("" : "+v"(fa2[i]));
+#pragma unroll
+      for (int j = 0; j < SN; ++j) asm volatile("" : "+v"(fb2[j]));
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < SM; ++i)
+#pragma unroll
+          for (int j = 0; j < SN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb2[j][t], fa2[i][t], acc[i][j], 0, 0, 0);
+    } else {
+      // one drain that "produces" every fragment (empty asm ties), so no MFMA can be scheduled above it
+      wait_lgkmcnt<0>();
+#pragma unroll
+      for (int i = 0; i < SM; ++i) asm volatile("" : "+v"(fa[i]));
+#pragma unroll
+      for (int j = 0; j < SN; ++j) asm volatile("" : "+v"(fb[j]));
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < SM; ++i)
+#pragma unroll
+          for (int j = 0; j < SN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][t], fa[i][t], acc[i][j], 0, 0, 0);
+    }
     st = (st + 1 == NST) ? 0 : st + 1;
     sn = (sn + 1 == NST) ? 0 : sn + 1;
   }
@@ -329,32 +381,32 @@ __global__ __launch_bounds__(512, (SM * SN > 10 ? 2 : 4)) void gemm_nt_panel_ker
   }
 }
 
-template <int SM, int SN, int WM, int WN>
+template <int SM, int SN, int WM, int WN, int BK = 16>
 static int launch_panel(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
                         const float* bias, float* C, float* D, int ldc) {
   constexpr int TM = 16 * SM * WM, TN = 16 * SN * WN;
   const int tiles = ceil_div(M, TM) * ceil_div(N, TN);
-  const size_t lds = (size_t)4 * (TM + TN) * 64;
+  const size_t lds = (size_t)(BK == 16 ? 4 : 3) * (TM + TN) * BK * 4;
   static PerDeviceOnce once;
   if (once.first()) {  // > 64 KiB of dynamic LDS needs the opt-in, once per instantiation and device
-    AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_NONE, SM, SN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_BIAS, SM, SN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_BIAS_GELU, SM, SN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_MUL, SM, SN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_NONE, SM, SN, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_BIAS, SM, SN, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_BIAS_GELU, SM, SN, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<EPI_MUL, SM, SN, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   dim3 grid(tiles), block(512);
   switch (epi) {
     case EPI_NONE:
-      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_NONE, SM, SN, WM, WN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_NONE, SM, SN, WM, WN, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
       break;
     case EPI_BIAS:
-      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_BIAS, SM, SN, WM, WN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_BIAS, SM, SN, WM, WN, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
       break;
     case EPI_BIAS_GELU:
-      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_BIAS_GELU, SM, SN, WM, WN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_BIAS_GELU, SM, SN, WM, WN, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
       break;
     case EPI_MUL:
-      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_MUL, SM, SN, WM, WN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_MUL, SM, SN, WM, WN, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
       break;
     default:
       set_last_error("gemm: bad epilogue %d", epi);
@@ -455,6 +507,7 @@ static int launch_skinny(hipStream_t stream, int epi, const float* A, int lda, c
 }
 
 static int g_force_tile = 0;  // 0 = choose_tile(); a tile id from AIMNET_GEMM_TILE forces one configuration (A/B runs)
+static int g_stage_k = 32;    // AIMNET_GEMM_BK=16 selects the 16-deep-stage form of the panel tiles (A/B runs)
 
 // Tile choice.  Every candidate runs the same MFMA rate; what differs is (a) how evenly ceil(M/TM)*ceil(N/TN)
 // tiles load the 256 CUs - the busiest CU carries ceil(tiles/256) tiles of TM*TN MACs per k, padding of M and N
@@ -470,7 +523,8 @@ static const TileCand kTileCands[] = {
     {412, 192, 128, 12}, {411, 176, 128, 11}, {410, 160, 128, 10}, {409, 144, 128, 9}};
 static int choose_tile(int M, int N, bool vec_ok) {
   if (M <= 256) return 7;  // latency regime: split-K skinny kernel (see gemm_nt_skinny_kernel)
-  int best = 5;
+  int best = 5, best_sum = 128;
+  long best_per_cu = 1;
   double best_cost = 1e300;
   for (const TileCand& c : kTileCands) {
     if (c.id != 5 && !vec_ok) continue;
@@ -481,9 +535,13 @@ static int choose_tile(int M, int N, bool vec_ok) {
     if (per_cu == 1 && c.acc_tiles <= 10) eff *= 0.88;
     if (c.id == 5) eff *= 0.9;  // 4-wave ring kernel: larger fixed cost per tile (profiles/r1c_summary.md)
     const double cost = (double)per_cu * c.tm * c.tn / eff;
-    if (cost < best_cost) { best_cost = cost; best = c.id; }
+    if (cost < best_cost) { best_cost = cost; best = c.id; best_sum = c.tm + c.tn; best_per_cu = per_cu; }
   }
-  return best;
+  // 32-deep stages (id + 1000: one barrier and one exposed LDS round trip per 32 k instead of two) beat the 16-deep form
+  // of the same tile by 0-5 % (tests/tools/tune_gemm_grid.py) - unless their 384 B x (TM + TN) of LDS evicts the second
+  // resident block of a CU that has two or more tiles to run
+  const bool deep = g_stage_k == 32 && best != 5 && (best_per_cu == 1 || best_sum <= 192);
+  return deep ? 1000 + best : best;
 }
 
 int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N,
@@ -497,7 +555,8 @@ int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int
   if (cfg == 0) cfg = choose_tile(M, N, ((N | ldc) & 3) == 0 && (((size_t)bias | (size_t)C | (size_t)D) & 15) == 0);
   switch (cfg) {
 #define AIMNET_PANEL_CASE(ID, SM_, SN_, WM_, WN_) \
-    case ID: return launch_panel<SM_, SN_, WM_, WN_>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    case ID: return launch_panel<SM_, SN_, WM_, WN_>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);      \
+    case 1000 + ID: return launch_panel<SM_, SN_, WM_, WN_, 32>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
     // panel kernels: id = 100*arrangement + 10*SM + SN; arrangement 1 = 2x4 waves, 2 = 4x2, 3 = 1x8
     AIMNET_PANEL_CASE(152, 5, 2, 2, 4)  // 160 x 128
     AIMNET_PANEL_CASE(142, 4, 2, 2, 4)  // 128 x 128
@@ -537,6 +596,8 @@ int launch_gemm_nt(hipStream_t stream, int epi, const float* A, int lda, const f
 int gemm_set_attributes() {
   const char* env = getenv("AIMNET_GEMM_TILE");
   g_force_tile = env ? atoi(env) : 0;
+  env = getenv("AIMNET_GEMM_BK");
+  if (env) g_stage_k = atoi(env) == 16 ? 16 : 32;
   return 0;  // the panel kernels opt in to > 64 KiB of dynamic LDS at their first launch (launch_panel)
 }
 

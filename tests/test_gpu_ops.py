@@ -183,7 +183,8 @@ def test_neighbor_list_batched_cells():
 
 
 # ---- MLP GEMM (csrc/gemm.hip): every tile configuration against an fp64 product ---------------------------
-GEMM_CFGS = [0, 5, 7, 152, 142, 132, 122, 153, 143, 223, 213, 222, 233, 412, 411, 410, 409, 381, 371, 361, 351, 341, 331, 321]
+_PANEL = [152, 142, 132, 122, 153, 143, 223, 213, 222, 233, 412, 411, 410, 409, 381, 371, 361, 351, 341, 331, 321]
+GEMM_CFGS = [0, 5, 7, *_PANEL, *[1000 + c for c in _PANEL]]  # 1000 + id: the 32-deep-stage variant of a panel tile
 
 
 @pytest.mark.parametrize("cfg", GEMM_CFGS)

@@ -11,6 +11,7 @@ dev = torch.device("cuda:0")
 Ms = [int(m) for m in os.environ.get("MS", "1024,2048,3200,4096,6400,8192,10080,10518,12800,16384,25600,51200").split(",")]
 shapes = [(512, 736), (384, 512), (288, 384), (256, 384), (736, 512), (512, 384), (384, 384), (128, 256), (128, 128), (448, 512)]
 cfgs = [152, 142, 132, 122, 153, 143, 223, 213, 222, 233, 351, 331, 381, 371, 361, 341, 321, 412, 411, 410, 409, 5]
+cfgs += [1000 + c for c in cfgs if c != 5]
 stream = torch.cuda.current_stream(dev).cuda_stream
 out = []
 for epi in (2, 3):

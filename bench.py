@@ -119,10 +119,10 @@ def cpu_baseline(workload: str, budget_s: float = 12.0):
 
 
 def pmc_traffic(workload):
-    """HBM bytes per GEMM launch from the committed rocprofv3 PMC pass of this workload (profiles/r1d_pmc.json:
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC pass of this workload (profiles/r1e_pmc.json:
     TCC_EA0_RDREQ x 128 B + TCC_EA0_WRREQ x 64 B, the gfx950 correction of MI355X_MICROARCH.md); PMC counters
     cannot be read from inside the timed process, so this is the last measured value, None for other workloads."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1d_pmc.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1e_pmc.json")
     if workload != "pbc10k" or not os.path.exists(path):
         return None
     with open(path) as f:

@@ -10,7 +10,7 @@ for pass in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VA
   timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/$out/$tag -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/$out/$tag.log 2>&1
 done
 cd $R
-python tests/tools/prof_summary.py $(ls gpurun_out/$out/trace/*/*kernel_trace.csv | head -1) 12 > gpurun_out/$out/kernel_summary.txt
+python tests/tools/prof_summary.py $(ls gpurun_out/$out/trace/*/*kernel_trace.csv | head -1) 17 > gpurun_out/$out/kernel_summary.txt
 cp $(ls gpurun_out/$out/trace/*/*kernel_stats.csv | head -1) gpurun_out/$out/kernel_stats.csv
 python - <<PY > gpurun_out/$out/pmc_summary.txt
 import csv, glob, collections

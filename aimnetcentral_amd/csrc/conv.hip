@@ -481,14 +481,15 @@ int launch_unconcat(hipStream_t s, int nq, const float* xbar, int ldx, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
+constexpr int CHB = 48;  // chunk of the backward kernels: 8.1 KiB of LDS per wave -> four blocks per CU
 struct BwdWaveLds {
-  float gs[CH][G_];
-  float dgs[CH][G_];
-  float4 ud[CH];
-  int j[CH];      // neighbour atom
-  int jr[CH];     // its feature row (atomic number in pass 0)
-  float qj[2][CH];  // neighbour charges per charge channel
-  float fc[CH], dfc[CH];
+  float gs[CHB][G_];
+  float dgs[CHB][G_];
+  float4 ud[CHB];
+  int j[CHB];      // neighbour atom
+  int jr[CHB];     // its feature row (atomic number in pass 0)
+  float qj[2][CHB];  // neighbour charges per charge channel
+  float fc[CHB], dfc[CHB];
 };
 
 // per-lane linear map (dbar, ubar) -> rbar = dbar*u + (ubar - (ubar.u) u)/d
@@ -502,7 +503,7 @@ __device__ __forceinline__ void rbar_of(float db, float ub0, float ub1, float ub
 
 // NQ: charge channels (0, 1, 2) as in conv_fwd_kernel: q / qbar planes [NQ][n_atoms], Sqbar [N][NQ][G*4]
 template <int NQ, bool NEED_ABAR, bool STRESS, bool SPLIT>  // SPLIT: as in conv_fwd_kernel (4 waves per centre atom)
-__global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
+__global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
                                                       const float* __restrict__ q,
                                                       const float* __restrict__ Sbar, const float* __restrict__ Sqbar,
                                                       const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
@@ -581,8 +582,8 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < 9; ++k) W[k] = 0.0f;
 
-    for (int c0 = 0; c0 < cmax; c0 += CH) {
-      const int nch = max(0, min(CH, cnt - c0));
+    for (int c0 = 0; c0 < cmax; c0 += CHB) {
+      const int nch = max(0, min(CHB, cnt - c0));
       __syncthreads();
       if (lane < nch) {
         const size_t p = (size_t)i * cap + m_lo + c0 + lane;
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_kernel(const float* __restric
       }
       __syncthreads();
 #pragma unroll
-      for (int t = 0; t < CH * G_ / 64; ++t) {
+      for (int t = 0; t < CHB * G_ / 64; ++t) {
         const int e = lane + 64 * t;
         const int mm = e >> 4, g = e & 15;
         float v = 0.0f, dv = 0.0f;

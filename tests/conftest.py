@@ -82,6 +82,15 @@ def oracle32_nse(synth_sd_nse):
 
 
 @pytest.fixture(scope="session")
+def oracle64_nse(synth_sd_nse):
+    import torch
+
+    from oracle import aimnet2_oracle as O
+
+    return O.OracleModel(synth_sd_nse, torch.float64)
+
+
+@pytest.fixture(scope="session")
 def hip_engine_nse():
     import torch
 

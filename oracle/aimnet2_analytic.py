@@ -83,6 +83,7 @@ def evaluate(
     dsf_rc: float = 15.0,
     dsf_alpha: float = 0.2,
     stress: bool = False,
+    mult=None,
 ) -> dict[str, np.ndarray]:
     dt = model.dtype
     x = torch.as_tensor(np.asarray(coord_wrapped)).to(dt)
@@ -91,6 +92,12 @@ def evaluate(
     mol = torch.as_tensor(np.asarray(mol_idx)).long()
     Q = torch.as_tensor(np.atleast_1d(np.asarray(charge))).to(dt)
     n_mol = Q.shape[0]
+    nq = model.nq  # charge channels: 1, or 2 for the open-shell NSE family (aimnet2.py:94-106); everything below carries them
+    if nq == 2:
+        mt = torch.ones_like(Q) if mult is None else torch.as_tensor(np.atleast_1d(np.asarray(mult))).to(dt)
+        Q = torch.stack([0.5 * Q + 0.5 * (mt - 1.0), 0.5 * Q - 0.5 * (mt - 1.0)], dim=-1)
+    else:
+        Q = Q.unsqueeze(-1)
     A, G = model.A, model.G
     H = model.agh_a.shape[2]
     cell_at = None
@@ -111,7 +118,7 @@ def evaluate(
     one_u = torch.cat([torch.ones_like(d).unsqueeze(-1), u], dim=-1)  # (N, M, 4)
 
     a = model.afv[Z].view(n, A, G)
-    q = torch.zeros(n, dtype=dt)
+    q = torch.zeros(n, nq, dtype=dt)
     npass = len(model.mlps)
     saved = []
     for p in range(npass):
@@ -121,9 +128,9 @@ def evaluate(
         xin = [a.reshape(n, -1), S[..., 0].reshape(n, -1), V.pow(2).sum(-1).reshape(n, -1)]
         Vq = None
         if p > 0:
-            Sq = torch.einsum("nm,nmg,nmc->ngc", q[nb], gs, one_u)
-            Vq = torch.einsum("gh,ngk->nhk", model.agh_q[0], Sq[..., 1:])
-            xin += [q.unsqueeze(-1), Sq[..., 0], Vq.pow(2).sum(-1)]
+            Sq = torch.einsum("nmq,nmg,nmc->nqgc", q[nb], gs, one_u)
+            Vq = torch.einsum("qgh,nqgk->nqhk", model.agh_q, Sq[..., 1:])
+            xin += [q, Sq[..., 0].reshape(n, -1), Vq.pow(2).sum(-1).reshape(n, -1)]
         h = torch.cat(xin, dim=-1)
         zs = []
         layers = model.mlps[p]
@@ -134,7 +141,7 @@ def evaluate(
             h = z if (last_linear and li == len(layers) - 1) else gelu(z)
         rec = {"a": a, "q": q, "V": V, "Vq": Vq, "zs": zs, "y": h}
         if p < npass - 1:
-            qt, ft, da = h[:, 0], h[:, 1], h[:, 2:]
+            qt, ft, da = h[:, :nq], h[:, nq : 2 * nq], h[:, 2 * nq :]
             qr = q + qt if p > 0 else qt
             f = ft * ft
             F = msum(f) + 1.0e-6  # kernel: nse (ops.py:99-145)
@@ -154,6 +161,8 @@ def evaluate(
     energy = msum(e_atom.double() + model.sae[Z])
 
     # ------------------------------------------------------------------ Coulomb (fwd + bwd)
+    q_ch = q          # per-channel charges of the last NSE step
+    q = q_ch.sum(-1)  # the Coulomb terms see alpha + beta; their dE/dq seeds every channel alike
     qbar = torch.zeros(n, dtype=dt)
     xbar = torch.zeros(n, 3, dtype=dt)
     virial = torch.zeros(n_mol, 3, 3, dtype=torch.float64)
@@ -193,6 +202,7 @@ def evaluate(
             energy = energy + 2.0 * COULOMB_FACTOR * msum((cs * q * q).double())
             qbar = qbar + 4.0 * COULOMB_FACTOR * cs * q
 
+    qbar = qbar.unsqueeze(-1).expand(n, nq).clone()
     # ------------------------------------------------------------------ backward: head
     g = model.head[-1][0].expand(n, -1).clone()  # d e / d h2
     for li in range(len(model.head) - 2, -1, -1):  # kernel: gemm_dx_gelugrad
@@ -231,20 +241,20 @@ def evaluate(
         ubar_ji = torch.einsum("nmg,nag,nmagk->nmk", gs, a_p, Sb_j[..., 1:])
         if p > 0:
             c0 = 2 * A * G + A * H
-            qbar = qbar + xb[:, c0]
-            Sqbar = torch.empty(n, G, 4, dtype=dt)
-            Sqbar[..., 0] = xb[:, c0 + 1 : c0 + 1 + G]
-            vqbar = xb[:, c0 + 1 + G : c0 + 1 + G + H]
-            Sqbar[..., 1:] = torch.einsum("gh,nhk->ngk", model.agh_q[0], 2.0 * rec["Vq"] * vqbar.unsqueeze(-1))
-            Sq_j = Sqbar[nb]
-            Pqp = Sq_j[..., 0] - torch.einsum("nmk,nmgk->nmg", u, Sq_j[..., 1:])
-            qbar = qbar + (gs * Pqp).sum((1, 2))
-            Pq = Sqbar[..., 0].unsqueeze(1) + torch.einsum("nmk,ngk->nmg", u, Sqbar[..., 1:])
-            qj = q_p[nb]
-            dbar_ij = dbar_ij + qj * (Pq * dgs).sum(-1)
-            ubar_ij = ubar_ij + qj.unsqueeze(-1) * torch.einsum("nmg,ngk->nmk", gs, Sqbar[..., 1:])
-            dbar_ji = dbar_ji + q_p.unsqueeze(1) * (Pqp * dgs).sum(-1)
-            ubar_ji = ubar_ji + q_p.view(n, 1, 1) * torch.einsum("nmg,nmgk->nmk", gs, Sq_j[..., 1:])
+            qbar = qbar + xb[:, c0 : c0 + nq]
+            Sqbar = torch.empty(n, nq, G, 4, dtype=dt)
+            Sqbar[..., 0] = xb[:, c0 + nq : c0 + nq + nq * G].view(n, nq, G)
+            vqbar = xb[:, c0 + nq + nq * G : c0 + nq + nq * G + nq * H].view(n, nq, H)
+            Sqbar[..., 1:] = torch.einsum("qgh,nqhk->nqgk", model.agh_q, 2.0 * rec["Vq"] * vqbar.unsqueeze(-1))
+            Sq_j = Sqbar[nb]  # (N, M, nq, G, 4)
+            Pqp = Sq_j[..., 0] - torch.einsum("nmk,nmqgk->nmqg", u, Sq_j[..., 1:])
+            qbar = qbar + torch.einsum("nmg,nmqg->nq", gs, Pqp)
+            Pq = Sqbar[..., 0].unsqueeze(1) + torch.einsum("nmk,nqgk->nmqg", u, Sqbar[..., 1:])
+            qj = q_p[nb]  # (N, M, nq)
+            dbar_ij = dbar_ij + torch.einsum("nmq,nmqg,nmg->nm", qj, Pq, dgs)
+            ubar_ij = ubar_ij + torch.einsum("nmq,nmg,nqgk->nmk", qj, gs, Sqbar[..., 1:])
+            dbar_ji = dbar_ji + torch.einsum("nq,nmqg,nmg->nm", q_p, Pqp, dgs)
+            ubar_ji = ubar_ji + torch.einsum("nq,nmg,nmqgk->nmk", q_p, gs, Sq_j[..., 1:])
         vm = valid.to(dt).unsqueeze(-1)
         dinv = (1.0 / d).unsqueeze(-1)
         rbar_ij = (dbar_ij.unsqueeze(-1) * u + (ubar_ij - (ubar_ij * u).sum(-1, keepdim=True) * u) * dinv) * vm
@@ -262,13 +272,14 @@ def evaluate(
         qrbar = qbar - Wbar[mol]
         fbar = (prev["D"] / prev["F"])[mol] * qrbar
         ftbar = 2.0 * prev["ft"] * fbar
-        ybar = torch.cat([qrbar.unsqueeze(-1), ftbar.unsqueeze(-1), abar.reshape(n, -1)], dim=-1)
+        ybar = torch.cat([qrbar, ftbar, abar.reshape(n, -1)], dim=-1)
         qbar = qrbar.clone() if p - 1 > 0 else torch.zeros_like(qbar)  # q_raw = q_prev + q~ only for pass >= 1
         # abar carries over unchanged (a_p = a_{p-1} + delta_a)
 
     res = {
         "energy": energy.numpy().copy(),
         "charges": q.numpy().copy(),
+        **({"spin_charges": (q_ch[:, 0] - q_ch[:, 1]).numpy().copy()} if nq == 2 else {}),
         "forces": (-xbar).numpy().copy(),
         "_aim": aim.numpy().copy(),
         "_e_atom": e_atom.numpy().copy(),

@@ -54,3 +54,30 @@ def test_forces_are_energy_gradient_fd(oracle64):
         em = O.evaluate(oracle64, cm.astype(np.float32).astype(np.float64), z, 0.0, forces=False)["energy"][0]
         hp = float(cp.astype(np.float32)[i, k]) - float(cm.astype(np.float32)[i, k])
         assert abs(-(ep - em) / hp - r0["forces"][i, k]) < 5e-4
+
+
+@pytest.mark.parametrize("case", ["b5", "pbc"])
+def test_analytic_matches_autograd_fp64_two_charge_channels(oracle64_nse, case):
+    """The same for the open-shell NSE family: both channels through the charge convolution, the NSE adjoint and the
+    Coulomb seed (which sees alpha + beta and feeds every channel alike)."""
+    g = golden("nse")
+    if case == "b5":
+        c, z, mol, q, mult, cell, kw = g["b5_coord"], g["b5_numbers"], g["b5_mol_idx"], g["b5_charge"], g["b5_mult"], None, {}
+    else:
+        c, z, mol, q, mult, cell = g["pbc_coord"], g["pbc_numbers"], np.zeros(96, dtype=np.int64), np.zeros(1, np.float32), g["pbc_mult"], g["pbc_cell"]
+        kw = {"coulomb": "dsf", "dsf_rc": 9.0, "dsf_alpha": 0.2}
+    ref = O.evaluate(oracle64_nse, c, z, q, mol, cell=cell, stress=cell is not None, mult=mult, return_intermediates=True, **kw)
+    xw = ref["coord_wrapped"]
+    if cell is None:
+        nbl, shl = O.neighbor_list(xw, float("inf"), mol)
+        coul = "simple"
+    else:
+        nbl, shl = O.neighbor_list(xw, 9.0, mol, cell, np.ones(3, bool))
+        coul = "dsf"
+    a = AN.evaluate(oracle64_nse, xw, z, q, mol, ref["nbmat"], ref.get("shifts"), cell, coulomb=coul, nbmat_lr=nbl, shifts_lr=shl,
+                    stress=cell is not None, mult=mult, **{k: v for k, v in kw.items() if k != "coulomb"})
+    assert np.abs(a["energy"] - ref["energy"]).max() < 1e-9
+    assert np.abs(a["charges"] - ref["charges"]).max() < 1e-12 and np.abs(a["spin_charges"] - ref["spin_charges"]).max() < 1e-12
+    assert np.abs(a["forces"] - ref["forces"]).max() < 1e-10
+    if cell is not None:
+        assert np.abs(a["stress"] - ref["stress"]).max() < 1e-12

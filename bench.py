@@ -153,13 +153,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if args.gpus > 1 and not distributed:
         raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    dev = torch.device(f"cuda:{local_rank}")
+    dev = torch.device(f"cuda:{local_rank % max(1, torch.cuda.device_count())}")
     torch.cuda.set_device(dev)
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        # BENCH_BACKEND=gloo: collectives on host tensors - lets several ranks share ONE GPU to exercise the N > 1 control
+        # flow on a single-GPU box (RCCL refuses two ranks on one device); never used for reported numbers
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
+    comm_dev = dev if (not distributed or os.environ.get("BENCH_BACKEND", "nccl") == "nccl") else torch.device("cpu")
 
     wl = build_workload(args.workload, rank, world)
     eng = HipEngine(loader.synthetic_spec(0), dev)
@@ -175,12 +182,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def local_step():  # this rank's shard only: no collective
+        return eng.eval(t["coord"], t["numbers"], t["mol_idx"], t["charge"], cell=cell, forces=True, stress=wl["stress"],
+                        coulomb=wl["coulomb"])["energy"]
+
     def step():
-        res = eng.eval(t["coord"], t["numbers"], t["mol_idx"], t["charge"], cell=cell, forces=True, stress=wl["stress"],
-                       coulomb=wl["coulomb"])
+        e = local_step()
         if distributed:
-            return adist.all_gather_energies(res["energy"], [frames] * world)
-        return res["energy"]
+            return adist.all_gather_energies(e.to(comm_dev), [frames] * world)
+        return e
 
     for _ in range(args.warmup):
         step()
@@ -194,10 +204,10 @@ def main():
     prof = eng.read_profile()
     eng.set_profiling(0)
     if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        na = torch.tensor([n_atoms], dtype=torch.int64, device=dev)
+        na = torch.tensor([n_atoms], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(na)
         total_atoms = int(na.item())
     else:
@@ -208,7 +218,7 @@ def main():
     if rank == 0:  # after the timed region: 5 extra steps with an event per kernel-family change (untimed, N = 1 view)
         eng.set_profiling(2)
         for _ in range(5):
-            step()
+            local_step()  # rank 0 alone: must not enter a collective here
         torch.cuda.synchronize(dev)
         fam = {k: v / 5 for k, v in eng.read_profile().items()}
         eng.set_profiling(0)
@@ -259,6 +269,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))
     if distributed:
+        dist.barrier()  # the other ranks wait here while rank 0 finishes its per-family pass and prints
         dist.destroy_process_group()
 
 

@@ -1,0 +1,44 @@
+"""bench.py end to end on the GPU box: the single-GPU JSON contract, and the N > 1 control flow (barriers, max-over-ranks
+timing, all-gather of the per-frame energies, rank 0's untimed per-family pass) with two ranks that share the one GPU
+through the gloo backend (RCCL refuses two ranks on one device; BENCH_BACKEND is a test switch only)."""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline"}
+
+
+def _last_json(out: str) -> dict:
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_single_gpu_json_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--workload", "md1024",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert abs(d["value"] - d["config"]["atoms_per_gpu"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+
+
+def test_two_ranks_share_the_gpu_over_gloo():
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "md1024"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    # whole-job value: both ranks' atoms over the slowest rank's time
+    assert abs(d["value"] - 2 * d["config"]["atoms_per_gpu"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]

@@ -366,6 +366,14 @@ class AIMNet2Calculator:
             mol_idx = d.get("mol_idx")
             if mol_idx is None:
                 mol_idx = torch.zeros(coord.shape[0], dtype=torch.int32, device=self.device)
+            else:
+                # The flat layout needs every molecule's atoms contiguous and mol_idx non-decreasing (the reference assumes
+                # it silently, nbops.py:346).  Host arrays are checked for free; device tensors would cost a sync per call.
+                raw = data.get("mol_idx")
+                if not (isinstance(raw, torch.Tensor) and raw.device.type != "cpu"):
+                    m = np.asarray(raw.cpu() if isinstance(raw, torch.Tensor) else raw).reshape(-1)
+                    if m.size > 1 and bool((np.diff(m) < 0).any()):
+                        raise ValueError("mol_idx must be sorted (non-decreasing): atoms of one molecule have to be contiguous")
         else:
             raise ValueError(f"coord must be (N,3) or (B,N,3), got {tuple(coord.shape)}")
         n_mol = charge.shape[0]

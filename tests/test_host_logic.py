@@ -411,3 +411,10 @@ def test_nse_ase_adapter_spin(nse_calc, calc):
     assert "info" not in closed.check_state(atoms2) and closed.mult == 1
     with pytest.raises(PropertyNotImplementedError):
         closed.get_spin_charges()
+
+
+def test_unsorted_mol_idx_is_refused(calc):
+    data = dict(coord=torch.randn(4, 3), numbers=[8, 1, 1, 1], mol_idx=[0, 1, 0, 1], charge=[0.0, 0.0])
+    with pytest.raises(ValueError, match="mol_idx must be sorted"):
+        calc(data)
+    calc(dict(data, mol_idx=[0, 0, 1, 1]))

@@ -31,6 +31,12 @@ namespace aimnet {
 constexpr float BOHR_INV_F = 1.8897261258369282f;   // 1 / 0.5291772105638411 (constants.py:8-9)
 constexpr float HALF_HARTREE_F = 13.605693012183622f;
 constexpr int D3W = 12;  // floats per atom in the weight table: s[5], w[5], cn, pad
+constexpr int D3_SLOTS = 4;  // list slots per loop trip in the two light passes (cn, cnforce)
+
+// The D3 passes are VALU-bound (112 / 397 / 147 instructions per list slot measured with IEEE division, sqrtf and expf):
+// single-instruction reciprocal, square root and exp2 (1 ulp each) are ample for a term whose parity gate is 6e-6 eV on 7 eV.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 // PairAcc / pair_add / pair_store live in model.hip; the same accumulation contract is restated here
 struct D3Acc {
@@ -90,28 +96,36 @@ struct D3Pair {
   bool ok;
 };
 
-// One 16-byte gather per neighbour: xs4[j] = (x, y, z, slot as int bits), packed by d3_pack_kernel.
-__device__ __forceinline__ D3Pair d3_pair(const float4* __restrict__ xs4, const float* c, const int* __restrict__ nb_idx,
-                                          const int* __restrict__ nb_shift, size_t p, float xi, float yi, float zi,
-                                          float cutoff) {
-  D3Pair r;
-  r.j = nb_idx[p];
-  const float4 xj = xs4[r.j];
-  r.sj = __float_as_int(xj.w);
-  float rx = xj.x - xi, ry = xj.y - yi, rz = xj.z - zi;
-  if (c) {
-    int sx, sy, sz;
-    unpack_shift(nb_shift[p], sx, sy, sz);
-    rx += sx * c[0] + sy * c[3] + sz * c[6];
-    ry += sx * c[1] + sy * c[4] + sz * c[7];
-    rz += sx * c[2] + sy * c[5] + sz * c[8];
+// xs4[j] = (x, y, z, slot as int bits), packed by d3_pack_kernel: one 16-byte gather per neighbour.
+// Cell row vectors of the centre atom's system in registers (zeros when non-periodic: the shift codes are 0 then).
+struct D3Cell {
+  float m[9];
+  __device__ __forceinline__ D3Cell(const float* c) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m[k] = c ? c[k] : 0.0f;
   }
-  r.d = sqrtf(rx * rx + ry * ry + rz * rz);
-  const float inv = 1.0f / fmaxf(r.d, 1e-12f);
+};
+
+// Pair geometry from the gathered neighbour record and the packed lattice shift.  The list loops below issue the loads of
+// TWO list slots (entry -> xs4[j] -> per-neighbour data) before any arithmetic and are branch-free inside, so two
+// dependent-load chains overlap per wave; out-of-range slots are clamped to a valid one and masked out.
+__device__ __forceinline__ D3Pair d3_geom(const float4& xj, int j, int sh, const D3Cell& C, float xi, float yi, float zi,
+                                          float cutoff, bool valid) {
+  D3Pair r;
+  r.j = j;
+  r.sj = __float_as_int(xj.w);
+  int sx, sy, sz;
+  unpack_shift(sh, sx, sy, sz);
+  const float rx = (xj.x - xi) + (sx * C.m[0] + sy * C.m[3] + sz * C.m[6]);
+  const float ry = (xj.y - yi) + (sx * C.m[1] + sy * C.m[4] + sz * C.m[7]);
+  const float rz = (xj.z - zi) + (sx * C.m[2] + sy * C.m[5] + sz * C.m[8]);
+  const float d2 = fmaxf(rx * rx + ry * ry + rz * rz, 1e-24f);
+  const float inv = __builtin_amdgcn_rsqf(d2);
+  r.d = d2 * inv;
   r.ux = rx * inv;
   r.uy = ry * inv;
   r.uz = rz * inv;
-  r.ok = r.d < cutoff;
+  r.ok = valid && r.d < cutoff;
   return r;
 }
 
@@ -136,11 +150,30 @@ __global__ __launch_bounds__(256) void d3_cn_kernel(const float4* __restrict__ x
   const float rci = T.rcov[si];
   const int cnt = nb_cnt[i];
   float cn = 0.0f;
-  for (int m = lane; m < cnt; m += 64) {
-    const D3Pair P = d3_pair(xs4, c, nb_idx, nb_shift, (size_t)i * cap + m, xi, yi, zi, cutoff);
-    if (!P.ok) continue;
-    const float db = fmaxf(P.d * BOHR_INV_F, 1e-12f);
-    cn += 1.0f / (1.0f + expf(-16.0f * ((rci + T.rcov[P.sj]) / db - 1.0f)));
+  const D3Cell C(c);
+  const size_t row = (size_t)i * cap;
+  for (int m = lane; m < cnt; m += 64 * D3_SLOTS) {  // D3_SLOTS list slots per trip, their load chains issued together
+    int j[D3_SLOTS], h[D3_SLOTS];
+    bool v[D3_SLOTS];
+    float4 x[D3_SLOTS];
+    float rc[D3_SLOTS];
+#pragma unroll
+    for (int k = 0; k < D3_SLOTS; ++k) {
+      v[k] = m + 64 * k < cnt;
+      const size_t p = row + (v[k] ? m + 64 * k : m);
+      j[k] = nb_idx[p];
+      h[k] = c ? nb_shift[p] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < D3_SLOTS; ++k) x[k] = xs4[j[k]];
+#pragma unroll
+    for (int k = 0; k < D3_SLOTS; ++k) rc[k] = T.rcov[__float_as_int(x[k].w)];
+#pragma unroll
+    for (int k = 0; k < D3_SLOTS; ++k) {
+      const D3Pair P = d3_geom(x[k], j[k], h[k], C, xi, yi, zi, cutoff, v[k]);
+      const float t = frcp(1.0f + fexp(-16.0f * ((rci + rc[k]) * frcp(fmaxf(P.d * BOHR_INV_F, 1e-12f)) - 1.0f)));
+      cn += P.ok ? t : 0.0f;
+    }
   }
   cn = wave_sum(cn);
   // the five reference-system exponents of atom i, shifted by their maximum (every lane computes all five)
@@ -212,13 +245,10 @@ __global__ __launch_bounds__(256) void d3_pair_kernel(const float4* __restrict__
     slope = erfc_rc / (Rc * Rc) + two_a_sqrtpi * expf(-al * al * Rc * Rc) / Rc;
     qc_i = q[i];
   }
-  for (int m = lane; m < cnt; m += 64) {
-    const D3Pair P = d3_pair(xs4, c, nb_idx, nb_shift, (size_t)i * cap + m, xi, yi, zi, cutoff);
-    if (!P.ok) continue;
+  const D3Cell C(c);
+  const size_t row = (size_t)i * cap;
+  auto body = [&](const D3Pair& P, const float4& sj0, const float4& sj1, const float2& sj2, float qj) {
     const int sj = P.sj;
-    const float4 sj0 = *reinterpret_cast<const float4*>(d3w + (size_t)P.j * D3W);
-    const float4 sj1 = *reinterpret_cast<const float4*>(d3w + (size_t)P.j * D3W + 4);
-    const float2 sj2 = *reinterpret_cast<const float2*>(d3w + (size_t)P.j * D3W + 8);
     const float s_j[5] = {sj0.x, sj0.y, sj0.z, sj0.w, sj1.x};
     const float w_j[5] = {sj1.y, sj1.z, sj1.w, sj2.x, sj2.y};
     const float* cr = c6s + sj * 25;
@@ -245,18 +275,18 @@ __global__ __launch_bounds__(256) void d3_pair_kernel(const float4* __restrict__
       }
     }
     const bool has = D > 1.0e-12f;
-    const float invD = 1.0f / fmaxf(D, 1.0e-12f);
+    const float invD = frcp(fmaxf(D, 1.0e-12f));
     const float c6 = has ? N * invD : 0.0f;
     const float db = fmaxf(P.d * BOHR_INV_F, 1e-12f);
     const float qq = 3.0f * q_i * T.r4r2[sj];
-    const float r0 = P3.a1 * sqrtf(qq) + P3.a2;
+    const float r0 = P3.a1 * __builtin_amdgcn_sqrtf(qq) + P3.a2;
     const float d2 = db * db, d4 = d2 * d2, d6 = d4 * d2, d8 = d4 * d4;
     const float r2 = r0 * r0, r4 = r2 * r2, r6 = r4 * r2, r8 = r4 * r4;
-    const float i6 = 1.0f / (d6 + r6), i8 = 1.0f / (d8 + r8);
+    const float i6 = frcp(d6 + r6), i8 = frcp(d8 + r8);
     const float damp = P3.s6 * i6 + P3.s8 * qq * i8;
     float sw = 1.0f, dsw = 0.0f;
     if (P3.r_off > P3.r_on && db > P3.r_on) {
-      const float iw = 1.0f / (P3.r_off - P3.r_on);
+      const float iw = frcp(P3.r_off - P3.r_on);
       const float t = fminf(fmaxf((db - P3.r_on) * iw, 0.0f), 1.0f);
       const float t2 = t * t;
       sw = 1.0f - t2 * t * (10.0f - 15.0f * t + 6.0f * t2);
@@ -266,7 +296,6 @@ __global__ __launch_bounds__(256) void d3_pair_kernel(const float4* __restrict__
     float tc = 0.0f;
     if (DSF) {
       const float inv = 1.0f / P.d;
-      const float qj = q[P.j];
       const float ec = erfcf(al * P.d);
       const float w = ec * inv - sv + (P.d - Rc) * slope;
       A.ec += (double)(w * qc_i * qj);
@@ -281,6 +310,28 @@ __global__ __launch_bounds__(256) void d3_pair_kernel(const float4* __restrict__
       d3_add<STRESS>(A, de + tc, P.ux, P.uy, P.uz, P.d);
       if (has) dcn += -damp * sw * (G - c6 * H) * invD;
     }
+  };
+  for (int m = lane; m < cnt; m += 128) {  // two list slots per trip, all of their loads issued before the arithmetic
+    const bool v1 = m + 64 < cnt;
+    const int m1 = v1 ? m + 64 : m;
+    const int j0 = nb_idx[row + m], j1 = nb_idx[row + m1];
+    const int h0 = c ? nb_shift[row + m] : 0, h1 = c ? nb_shift[row + m1] : 0;
+    const float4 x0 = xs4[j0], x1 = xs4[j1];
+    const float* w0 = d3w + (size_t)j0 * D3W;
+    const float* w1 = d3w + (size_t)j1 * D3W;
+    const float4 a0 = *reinterpret_cast<const float4*>(w0), b0 = *reinterpret_cast<const float4*>(w0 + 4);
+    const float2 c0 = *reinterpret_cast<const float2*>(w0 + 8);
+    const float4 a1 = *reinterpret_cast<const float4*>(w1), b1 = *reinterpret_cast<const float4*>(w1 + 4);
+    const float2 c1 = *reinterpret_cast<const float2*>(w1 + 8);
+    float q0 = 0.f, q1 = 0.f;
+    if (DSF) {
+      q0 = q[j0];
+      q1 = q[j1];
+    }
+    const D3Pair P0 = d3_geom(x0, j0, h0, C, xi, yi, zi, cutoff, true);
+    const D3Pair P1 = d3_geom(x1, j1, h1, C, xi, yi, zi, cutoff, v1);
+    if (P0.ok) body(P0, a0, b0, c0, q0);
+    if (P1.ok) body(P1, a1, b1, c1, q1);
   }
   d3_store<GRAD, STRESS>(A, i, lane, HALF_HARTREE_F, ecoul, fgrad, virial_atom, DSF ? (double)cp.factor : 0.0);
   if (DSF) {  // self term and dE/dq_i of the DSF sum (lr.py:606-613)
@@ -316,15 +367,37 @@ __global__ __launch_bounds__(256) void d3_cnforce_kernel(const float4* __restric
   const float gi = dEdcn[i];
   const int cnt = nb_cnt[i];
   D3Acc A;
-  for (int m = lane; m < cnt; m += 64) {
-    const D3Pair P = d3_pair(xs4, c, nb_idx, nb_shift, (size_t)i * cap + m, xi, yi, zi, cutoff);
-    if (!P.ok) continue;
-    const float db = fmaxf(P.d * BOHR_INV_F, 1e-12f);
-    const float R = rci + T.rcov[P.sj];
-    const float sg = 1.0f / (1.0f + expf(-16.0f * (R / db - 1.0f)));
-    const float dsg = sg * (1.0f - sg) * (-16.0f * R / (db * db)) * BOHR_INV_F;  // d sigma / d d_ij per Angstrom
+  const D3Cell C(c);
+  const size_t row = (size_t)i * cap;
+  auto term = [&](const D3Pair& P, float rcj, float gj) {
+    const float R = rci + rcj;
+    const float idb = frcp(fmaxf(P.d * BOHR_INV_F, 1e-12f));
+    const float sg = frcp(1.0f + fexp(-16.0f * (R * idb - 1.0f)));
+    const float dsg = sg * (1.0f - sg) * (-16.0f * R * idb * idb) * BOHR_INV_F;  // d sigma / d d_ij per Angstrom
     // sum_l dE/dcn_l cn_l as a pair "energy" with k = 1: per ordered pair 1/2 (g_i + g_j) sigma(d_ij)
-    d3_add<STRESS>(A, 0.5f * (gi + dEdcn[P.j]) * dsg, P.ux, P.uy, P.uz, P.d);
+    d3_add<STRESS>(A, P.ok ? 0.5f * (gi + gj) * dsg : 0.0f, P.ux, P.uy, P.uz, P.d);
+  };
+  for (int m = lane; m < cnt; m += 64 * D3_SLOTS) {
+    int j[D3_SLOTS], h[D3_SLOTS];
+    bool v[D3_SLOTS];
+    float4 x[D3_SLOTS];
+    float rc[D3_SLOTS], g[D3_SLOTS];
+#pragma unroll
+    for (int k = 0; k < D3_SLOTS; ++k) {
+      v[k] = m + 64 * k < cnt;
+      const size_t p = row + (v[k] ? m + 64 * k : m);
+      j[k] = nb_idx[p];
+      h[k] = c ? nb_shift[p] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < D3_SLOTS; ++k) {
+      x[k] = xs4[j[k]];
+      g[k] = dEdcn[j[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < D3_SLOTS; ++k) rc[k] = T.rcov[__float_as_int(x[k].w)];
+#pragma unroll
+    for (int k = 0; k < D3_SLOTS; ++k) term(d3_geom(x[k], j[k], h[k], C, xi, yi, zi, cutoff, v[k]), rc[k], g[k]);
   }
   d3_store<true, STRESS>(A, i, lane, 1.0f, ecoul, fgrad, virial_atom);
 }

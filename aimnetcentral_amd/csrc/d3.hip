@@ -295,13 +295,13 @@ __global__ __launch_bounds__(256) void d3_pair_kernel(const float4* __restrict__
     A.e += (double)(-c6 * damp * sw);
     float tc = 0.0f;
     if (DSF) {
-      const float inv = 1.0f / P.d;
+      const float inv = frcp(P.d);
       const float ec = erfcf(al * P.d);
       const float w = ec * inv - sv + (P.d - Rc) * slope;
       A.ec += (double)(w * qc_i * qj);
       if (GRAD) {
         qb += w * qj;
-        tc = kratio * (-ec * inv * inv - two_a_sqrtpi * expf(-al * al * P.d * P.d) * inv + slope) * qc_i * qj;
+        tc = kratio * (-ec * inv * inv - two_a_sqrtpi * fexp(-al * al * P.d * P.d) * inv + slope) * qc_i * qj;
       }
     }
     if (GRAD) {

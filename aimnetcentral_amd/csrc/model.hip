@@ -490,12 +490,15 @@ __global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __re
   const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2], qi = q[i];
   PairAcc A;
   auto pair_term = [&](const float4& e) {
-    const float d = sqrtf(e.x * e.x + e.y * e.y + e.z * e.z);
-    if (d < Rc) {  // the walk tests the squared distance; keep the reference's d < Rc on the rounded root
-      const float inv = 1.0f / d;
+    // single-instruction rsq / exp2 (1 ulp): the kernel is VALU-issue bound and the pair sums are fp64 anyway
+    const float d2 = e.x * e.x + e.y * e.y + e.z * e.z;
+    const float inv = __builtin_amdgcn_rsqf(d2);
+    const float d = d2 * inv;
+    if (d < Rc) {  // the walk tests the squared distance; the reference tests d < Rc on the root (a pair at Rc weighs 0)
       const float ec = erfcf(al * d);
       const float w = ec * inv - sv + (d - Rc) * slope;
-      const float dw = -ec * inv * inv - two_a_sqrtpi * expf(-al * al * d * d) * inv + slope;
+      const float ex = __builtin_amdgcn_exp2f(-1.4426950408889634f * al * al * d2);
+      const float dw = -ec * inv * inv - two_a_sqrtpi * ex * inv + slope;
       pair_add<GRAD, STRESS>(A, w, dw, qi, e.w, e.x * inv, e.y * inv, e.z * inv, d);
     }
   };

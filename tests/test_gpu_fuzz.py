@@ -111,3 +111,47 @@ def test_random_configuration(seed, hip_engine, hip_engine_nse, oracle32, oracle
     what = (f"seed {seed}: {'pbc' + str(kw.get('pbc')) if periodic else 'molecules'} n={len(z)} n_mol={n_mol} {kw.get('coulomb')} "
             f"d3={d3 is not None} nse={nse} q={q.tolist()}")
     _compare(res, ref, ref64, mol, what, nse)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tiny_cells_many_images(seed, hip_engine, oracle32, oracle64):
+    """Cells much smaller than the cutoffs (3-4.5 A edges, 2-9 atoms, triclinic): every atom sees many periodic images of
+    every other atom and of itself (lattice shifts up to +-4 at a 9 A DSF cutoff), plus many single-atom / few-atom
+    neighbour rows.  Also a batch of such cells with per-system cell matrices."""
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    n_sys = 1 if seed % 2 == 0 else 3
+    coords, zs, mols, cells = [], [], [], []
+    for m in range(n_sys):
+        cell = np.diag(rng.uniform(3.0, 4.5, size=3)) + rng.uniform(-0.5, 0.5, size=(3, 3))
+        n = int(rng.integers(2, 10))
+        pts = []
+        while len(pts) < n:  # random fractional positions at least 0.95 A apart under the minimum-image convention
+            f = rng.random(3)
+            ok = True
+            for g in pts:
+                df = f - g
+                df -= np.round(df)
+                best = min(np.linalg.norm((df + np.array(im) - 1) @ cell) for im in np.ndindex(3, 3, 3))
+                if best < 0.95:
+                    ok = False
+                    break
+            if ok:
+                pts.append(f)
+        coords.append(np.array(pts) @ cell)
+        zs.append(rng.choice([1, 6, 7, 8], size=n, p=[0.4, 0.3, 0.15, 0.15]))
+        mols.append(np.full(n, m))
+        cells.append(cell)
+    c = np.concatenate(coords).astype(np.float32)
+    z = np.concatenate(zs).astype(np.int64)
+    mol = np.concatenate(mols).astype(np.int64)
+    cell = (cells[0] if n_sys == 1 else np.stack(cells)).astype(np.float32)
+    rc, alpha = float(rng.uniform(7.0, 9.0)), 0.25
+    dev = hip_engine.device
+    r = hip_engine.eval(torch.from_numpy(c).to(dev), torch.from_numpy(z).to(dev), torch.from_numpy(mol).to(dev),
+                        torch.zeros(n_sys, device=dev), cell=torch.from_numpy(cell).to(dev), forces=True, stress=True, coulomb="dsf",
+                        dsf_rc=rc, dsf_alpha=alpha)
+    res = {k: v.cpu().numpy() for k, v in r.items()}
+    okw = dict(cell=cell, coulomb="dsf", dsf_rc=rc, dsf_alpha=alpha, stress=True)
+    ref = O.evaluate(oracle32, c, z, np.zeros(n_sys, np.float32), mol, return_intermediates=True, **okw)
+    ref64 = O.evaluate(oracle64, c, z, np.zeros(n_sys, np.float32), mol, return_intermediates=True, **dict(okw, forces=False, stress=False))
+    _compare(res, ref, ref64, mol, f"tiny cells seed {seed}: n={len(z)} systems={n_sys} rc={rc:.2f}", False)

@@ -76,21 +76,6 @@ int launch_pair_geom(hipStream_t s, const float* xw, const int* mol_idx, const f
   return 0;
 }
 
-__global__ void embed_kernel(const float* __restrict__ afv, const int* __restrict__ numbers, int n_atoms,
-                             float* __restrict__ a0) {
-  const int i = blockIdx.x * APB + (threadIdx.x >> 6);
-  if (i >= n_atoms) return;
-  const int lane = threadIdx.x & 63;
-  const int z = min(63, max(0, numbers[i]));
-  reinterpret_cast<float4*>(a0 + (size_t)i * NF)[lane] = reinterpret_cast<const float4*>(afv + (size_t)z * NF)[lane];
-}
-
-int launch_embed(hipStream_t s, const float* afv, const int* numbers, int n_atoms, float* a0) {
-  hipLaunchKernelGGL(embed_kernel, dim3(ceil_div(n_atoms, APB)), dim3(256), 0, s, afv, numbers, n_atoms, a0);
-  AIMNET_LAUNCH_CHECK();
-  return 0;
-}
-
 // Persistent-loop atom assignment.  Hardware places block b on XCD b % 8 (observed; speed only): give
 // each XCD one CONTIGUOUS range of atoms, processed in order, so that when the input is spatially
 // ordered (crystals, MD frames) the neighbour rows an XCD gathers were mostly produced / recently

@@ -220,7 +220,7 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   char name[32];
   for (int p = 0; p < np; ++p) {
     snprintf(name, sizeof name, "a%d", p);
-    W.a[p] = c.take<float>(n * 256, name, 256);
+    W.a[p] = p == 0 ? nullptr : c.take<float>(n * 256, name, 256);  // pass 0 reads the embedding table itself
     snprintf(name, sizeof name, "q%d", p);
     W.q[p] = c.take<float>(n * e->nq, name, 1);
     const int ldx = e->mlp[p][0].k_in;
@@ -567,7 +567,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   // ---- forward --------------------------------------------------------------------------------
   // binned systems: process centre atoms in the bin-sorted order of the cell list (kernels.h, `order`)
   const int* order = (W.nl.binned && e->spatial_order) ? W.nl.sorted : nullptr;
-  RC(launch_embed(s, e->afv, in->numbers, N, W.a[0]));
+  // a^0 = afv[Z] is never materialised: pass 0 gathers the embedding rows directly (conv_fwd / conv_bwd row_of, update_a)
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
   if (p0m || d3) RC(launch_species(s, in->numbers, e->slot_of_z, N, W.aslot, W.present_part));
   for (int p = 0; p < np; ++p) {
@@ -590,7 +590,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       RC(prof_mark(e, s, FAM_POINTWISE));
       RC(launch_nse_fwd(s, W.H[p][nl - 1], Ls[nl - 1].k_out, nq, p > 0 ? W.q[p - 1] : nullptr, W.nl.mol_start, in->charge,
                         n_mol, N, W.S, (float*)W.part, W.q[p], W.Fm[p], W.Dm[p]));
-      RC(launch_update_a(s, W.a[p], W.H[p][nl - 1], Ls[nl - 1].k_out, nq, N, W.a[p + 1]));
+      RC(launch_update_a(s, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr, W.H[p][nl - 1], Ls[nl - 1].k_out, nq, N,
+                         W.a[p + 1]));
     }
   }
   const float* q_fin = W.q[np - 2];

@@ -58,7 +58,6 @@ struct BasisParams {  // radial basis of AEVSV (aev.py:66-81), passed by value
 };
 int launch_pair_geom(hipStream_t s, const float* xw, const int* mol_idx, const float* cell, int n_cell,
                      const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, int n_atoms, float4* pg);
-int launch_embed(hipStream_t s, const float* afv, const int* numbers, int n_atoms, float* a0);
 // nq (conv_fwd / unconcat / conv_bwd): charge channels convolved with the features - 0 in pass 0, else 1 or 2 (NSE models);
 // q / qbar are planes [nq][n_atoms], agh_q [nq][G][H], Vqsave [N][nq][H*3], Sqbar [N][nq][G*4]
 int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, const float* q, const int* nb_idx,
@@ -97,7 +96,7 @@ int launch_conv_sv_bwd_bwd(hipStream_t s, const float* grad_out, const float* gr
 int launch_nse_fwd(hipStream_t s, const float* y, int ldy, int nq, const float* q_prev, const int* mol_start,
                    const float* charge, int n_mol, int n_atoms, int S, float* part, float* q_new, float* Fm, float* Dm);
 int launch_charge_sum(hipStream_t s, const float* q2, int n_atoms, float* q_tot, float* q_spin);
-int launch_update_a(hipStream_t s, const float* a, const float* y, int ldy, int nq, int n_atoms, float* a_new);
+int launch_update_a(hipStream_t s, const float* a, const int* row_of, const float* y, int ldy, int nq, int n_atoms, float* a_new);
 // d / zbar (may be NULL): also writes the backward seed zbar = w * d (d = GELU' of the layer below, ldh wide)
 int launch_head_last(hipStream_t s, const float* h, int ldh, const float* w, const float* b, int k, int n_atoms,
                      float* e_atom, const float* d, float* zbar);

@@ -160,18 +160,22 @@ int launch_charge_sum(hipStream_t s, const float* q2, int n_atoms, float* q_tot,
   return 0;
 }
 
-__global__ void update_a_kernel(const float* __restrict__ a, const float* __restrict__ y, int ldy, int col0, int n_atoms,
-                                float* __restrict__ a_new) {
+// row_of (may be NULL): feature row of atom i inside `a` - pass 0 adds delta_a to the embedding row afv[Z_i] directly, so
+// the initial features a^0 = afv[Z] (aimnet2.py:145-148) are never materialised
+__global__ void update_a_kernel(const float* __restrict__ a, const int* __restrict__ row_of, const float* __restrict__ y, int ldy,
+                                int col0, int n_atoms, float* __restrict__ a_new) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)n_atoms * 256) return;
   const size_t i = e >> 8;
   const int k = (int)(e & 255);
-  a_new[e] = a[e] + y[i * ldy + col0 + k];
+  const size_t ri = row_of ? (size_t)min(63, max(0, row_of[i])) : i;
+  a_new[e] = a[ri * 256 + k] + y[i * ldy + col0 + k];
 }
 
-int launch_update_a(hipStream_t s, const float* a, const float* y, int ldy, int nq, int n_atoms, float* a_new) {
+int launch_update_a(hipStream_t s, const float* a, const int* row_of, const float* y, int ldy, int nq, int n_atoms, float* a_new) {
   const size_t n = (size_t)n_atoms * 256;
-  hipLaunchKernelGGL(update_a_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, y, ldy, 2 * nq, n_atoms, a_new);
+  hipLaunchKernelGGL(update_a_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, row_of, y, ldy, 2 * nq, n_atoms,
+                     a_new);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

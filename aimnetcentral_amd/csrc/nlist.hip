@@ -283,20 +283,28 @@ __global__ void bins_setup_kernel(NlistSystem* __restrict__ sys, const int* __re
   }
 }
 
+// slot[i] = arrival rank of atom i inside its bin (any order: bin_sort_kernel orders every bin by atom id afterwards)
 __global__ void bin_count_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx, int n_atoms,
                                  const NlistSystem* __restrict__ sys, int* __restrict__ atom_bin,
-                                 int* __restrict__ bin_count) {
+                                 int* __restrict__ bin_count, int* __restrict__ slot) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_atoms) return;
   int b[3];
   const int bin = bin_of(sys[mol_idx[i]], xw[3 * i], xw[3 * i + 1], xw[3 * i + 2], b);
   atom_bin[i] = bin;
-  atomicAdd(&bin_count[bin], 1);
+  slot[i] = atomicAdd(&bin_count[bin], 1);
 }
 
-// single-block exclusive scan (n <= a few million): each thread owns a contiguous chunk
-__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ in, int* __restrict__ out, int n) {
+// bins in use = end of the last system's grid (the buffers are sized for the worst case, one bin per atom)
+__device__ __forceinline__ int bins_in_use(const NlistSystem* __restrict__ sys, int n_mol) {
+  return sys[n_mol - 1].bin_offset + sys[n_mol - 1].n_bins;
+}
+
+// single-block exclusive scan over the bins in use: each thread owns a contiguous chunk
+__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ in, int* __restrict__ out,
+                                                   const NlistSystem* __restrict__ sys, int n_mol) {
   __shared__ int part[1024];
+  const int n = bins_in_use(sys, n_mol);
   const int t = threadIdx.x;
   const int chunk = (n + 1023) / 1024;
   const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
@@ -319,23 +327,22 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ in, 
 }
 
 __global__ void bin_fill_kernel(const int* __restrict__ atom_bin, const int* __restrict__ bin_start, int n_atoms,
-                                int* __restrict__ bin_fill, int* __restrict__ sorted_tmp) {
+                                const int* __restrict__ slot, int* __restrict__ sorted_tmp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_atoms) return;
-  const int bin = atom_bin[i];
-  const int p = atomicAdd(&bin_fill[bin], 1);
-  sorted_tmp[bin_start[bin] + p] = i;
+  sorted_tmp[bin_start[atom_bin[i]] + slot[i]] = i;
 }
 
 // order every bin by atom id (rank by counting; bins hold tens of atoms): one wave per bin
 // also emits the bin-ordered coordinate stream xs[k] = (x, y, z, atom id): the row builder then reads
 // its candidates as ONE coalesced 16-byte load per lane instead of an index load + 3 scattered dwords
-__global__ __launch_bounds__(256) void bin_sort_kernel(const int* __restrict__ bin_start, int n_bins,
-                                                      const int* __restrict__ sorted_tmp, const float* __restrict__ xw,
-                                                      int* __restrict__ sorted, float4* __restrict__ xs) {
+__global__ __launch_bounds__(256) void bin_sort_kernel(const int* __restrict__ bin_start, const NlistSystem* __restrict__ sys,
+                                                      int n_mol, const int* __restrict__ sorted_tmp,
+                                                      const float* __restrict__ xw, int* __restrict__ sorted,
+                                                      float4* __restrict__ xs) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= n_bins) return;
+  if (b >= bins_in_use(sys, n_mol)) return;
   const int s0 = bin_start[b], n = bin_start[b + 1] - s0;
   for (int e = lane; e < n; e += 64) {
     const int v = sorted_tmp[s0 + e];
@@ -388,16 +395,16 @@ int launch_bins(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, float
   hipLaunchKernelGGL(bins_setup_kernel, dim3(1), dim3(256), 0, s, sys, b.mol_start, n_mol, width);
   AIMNET_LAUNCH_CHECK();
   AIMNET_HIP_CHECK(hipMemsetAsync(b.bin_count, 0, (size_t)(max_bins + 1) * sizeof(int) * 1, s));
-  AIMNET_HIP_CHECK(hipMemsetAsync(b.bin_fill, 0, (size_t)(max_bins + 1) * sizeof(int), s));
+  // b.bin_fill holds each atom's arrival rank in its bin (max_bins >= n_atoms entries): one atomic pass instead of two
   hipLaunchKernelGGL(bin_count_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.xw, mol_idx, n_atoms, sys,
-                     b.atom_bin, b.bin_count);
+                     b.atom_bin, b.bin_count, b.bin_fill);
   AIMNET_LAUNCH_CHECK();
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, b.bin_count, b.bin_start, max_bins);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, b.bin_count, b.bin_start, sys, n_mol);
   AIMNET_LAUNCH_CHECK();
   hipLaunchKernelGGL(bin_fill_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.atom_bin, b.bin_start, n_atoms,
                      b.bin_fill, b.sorted_tmp);
   AIMNET_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bin_sort_kernel, dim3(ceil_div(max_bins, 4)), dim3(256), 0, s, b.bin_start, max_bins, b.sorted_tmp, b.xw,
+  hipLaunchKernelGGL(bin_sort_kernel, dim3(ceil_div(max_bins, 4)), dim3(256), 0, s, b.bin_start, sys, n_mol, b.sorted_tmp, b.xw,
                      b.sorted, b.xs);
   AIMNET_LAUNCH_CHECK();
   return 0;

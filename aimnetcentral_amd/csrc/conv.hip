@@ -1,7 +1,7 @@
-// conv.hip - pair geometry, AEV radial basis and the ConvSV gather-contract kernels (fwd + bwd).
+// conv.hip - AEV radial basis and the ConvSV gather-contract kernels (fwd + bwd).
 //
 // Reference semantics (paths relative to /root/reference/aimnet):
-//   pair_geom   ops.calc_distances ops.py:37-66 (r = x_j + s.C - x_i, d, u = r/d)
+//   pair geometry (u, d) per list entry: written by the neighbour-list builders (nlist.hip, ops.calc_distances ops.py:37-66)
 //   radial basis AEVSV._calc_aev modules/aev.py:94-110: gs_g = exp(-eta (d-s_g)^2) * 0.5 (cos(pi d/rc)+1)
 //   conv_fwd    ConvSV.forward aev.py:156-189 == Warp kernel kernels/conv_sv_2d_sp_wp.py:90-112 plus the
 //               agh contraction + square-sum, for conv_a (d2features) and conv_q in one launch;
@@ -38,42 +38,6 @@ __device__ __forceinline__ f2 mk2(float a, float b) {
   r.x = a;
   r.y = b;
   return r;
-}
-
-// ------------------------------------------------------------------------------------------------
-__global__ void pair_geom_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
-                                 const float* __restrict__ cell, int n_cell, const int* __restrict__ nb_idx,
-                                 const int* __restrict__ nb_shift, const int* __restrict__ nb_cnt, int cap, int n_atoms,
-                                 float4* __restrict__ pg) {
-  const int i = blockIdx.x * APB + (threadIdx.x >> 6);
-  if (i >= n_atoms) return;
-  const int lane = threadIdx.x & 63;
-  const int cnt = nb_cnt[i];
-  const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2];
-  const float* c = cell ? cell + (n_cell == 1 ? 0 : (size_t)mol_idx[i] * 9) : nullptr;
-  for (int m = lane; m < cnt; m += 64) {
-    const size_t p = (size_t)i * cap + m;
-    const int j = nb_idx[p];
-    float rx = xw[3 * j] - xi, ry = xw[3 * j + 1] - yi, rz = xw[3 * j + 2] - zi;
-    if (c) {
-      int sx, sy, sz;
-      unpack_shift(nb_shift[p], sx, sy, sz);
-      rx += sx * c[0] + sy * c[3] + sz * c[6];
-      ry += sx * c[1] + sy * c[4] + sz * c[7];
-      rz += sx * c[2] + sy * c[5] + sz * c[8];
-    }
-    const float d = sqrtf(rx * rx + ry * ry + rz * rz);
-    const float inv = 1.0f / d;
-    pg[p] = make_float4(rx * inv, ry * inv, rz * inv, d);
-  }
-}
-
-int launch_pair_geom(hipStream_t s, const float* xw, const int* mol_idx, const float* cell, int n_cell,
-                     const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, int n_atoms, float4* pg) {
-  hipLaunchKernelGGL(pair_geom_kernel, dim3(ceil_div(n_atoms, APB)), dim3(256), 0, s, xw, mol_idx, cell, n_cell, nb_idx,
-                     nb_shift, nb_cnt, cap, n_atoms, pg);
-  AIMNET_LAUNCH_CHECK();
-  return 0;
 }
 
 // Persistent-loop atom assignment.  Hardware places block b on XCD b % 8 (observed; speed only): give

@@ -540,7 +540,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   // large non-periodic molecules (>= 1500 atoms on average) get a bounding-box cell list instead of the O(n^2) scan
   if (!pbc && (long)N >= 1500L * n_mol) RC(launch_bbox(s, n_mol, W.nl));
   RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, ar.rc, ar.rc, cap, N, 0, W.nl, W.nb_idx, W.nb_shift,
-                  W.nb_cnt, out->status + 0, out->status + 2));
+                  W.nb_cnt, out->status + 0, out->status + 2, W.pg));
   if (coulomb == AIMNET_COULOMB_DSF && !pbc)  // periodic DSF needs no list: it walks the short-range cell grid
     RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, opt->dsf_rc, -1.0f, cap_lr, N, 0, W.nl, W.lr_idx,
                     W.lr_shift, W.lr_cnt, out->status + 1, out->status + 3));
@@ -562,7 +562,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     }
   }
   RC(prof_mark(e, s, FAM_GEOM));
-  RC(launch_pair_geom(s, W.nl.xw, in->mol_idx, in->cell, n_cell, W.nb_idx, W.nb_shift, W.nb_cnt, cap, N, W.pg));
+  // (the pair geometry (u, d) of the short-range list was written by the list builder itself)
 
   // ---- forward --------------------------------------------------------------------------------
   // binned systems: process centre atoms in the bin-sorted order of the cell list (kernels.h, `order`)

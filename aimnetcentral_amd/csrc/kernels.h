@@ -48,7 +48,8 @@ int launch_bbox(hipStream_t s, int n_mol, NlistBuffers& b);
 // bin_width > 0: (re)bin the periodic systems into slabs >= bin_width thick first; <= 0: reuse the last bins
 int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, const float* cell, int n_cell,
                  const int pbc[3], float cutoff, float bin_width, int cap, int fill_value, int fill_rows,
-                 NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf);
+                 NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf,
+                 float4* pg = nullptr);  // pg [n_atoms, cap] (may be NULL): also emit the pair geometry (u, d) of every entry
 int launch_bins(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, float width, NlistBuffers& b);
 
 // ---- conv.hip ---------------------------------------------------------------------------------
@@ -56,8 +57,6 @@ struct BasisParams {  // radial basis of AEVSV (aev.py:66-81), passed by value
   float rc, eta;
   float shifts[16];
 };
-int launch_pair_geom(hipStream_t s, const float* xw, const int* mol_idx, const float* cell, int n_cell,
-                     const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, int n_atoms, float4* pg);
 // nq (conv_fwd / unconcat / conv_bwd): charge channels convolved with the features - 0 in pass 0, else 1 or 2 (NSE models);
 // q / qbar are planes [nq][n_atoms], agh_q [nq][G][H], Vqsave [N][nq][H*3], Sqbar [N][nq][G*4]
 int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, const float* q, const int* nb_idx,

@@ -218,10 +218,19 @@ int launch_bbox(hipStream_t s, int n_mol, NlistBuffers& b) {
 
 // ------------------------------------------------------------------------------------------------
 // non-periodic: one wave per atom, lanes over the atoms of the same molecule
+// pair geometry of ops.calc_distances (ops.py:37-66) as the conv kernels consume it: (r / d, d); written by the row builders
+// of the short-range list themselves (the pair vector is in registers there), so no separate pass re-reads the list
+__device__ __forceinline__ float4 unit_and_norm(float rx, float ry, float rz) {
+  const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+  const float inv = 1.0f / d;
+  return make_float4(rx * inv, ry * inv, rz * inv, d);
+}
+
 __global__ __launch_bounds__(256) void nlist_brute_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
                                                          const int* __restrict__ mol_start, int n_atoms, float cutoff2,
                                                          int cap, int fill_value, int fill_rows, int* __restrict__ nb_idx,
-                                                         int* __restrict__ nb_cnt, int* __restrict__ cnt_true) {
+                                                         int* __restrict__ nb_cnt, int* __restrict__ cnt_true,
+                                                         float4* __restrict__ pg) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
@@ -233,13 +242,17 @@ __global__ __launch_bounds__(256) void nlist_brute_kernel(const float* __restric
   for (int base = j0; base < j1; base += 64) {
     const int j = base + lane;
     bool ok = false;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
     if (j < j1 && j != i) {
-      const float dx = xw[3 * j] - xi, dy = xw[3 * j + 1] - yi, dz = xw[3 * j + 2] - zi;
+      dx = xw[3 * j] - xi, dy = xw[3 * j + 1] - yi, dz = xw[3 * j + 2] - zi;
       ok = (dx * dx + dy * dy + dz * dz) < cutoff2;
     }
     const unsigned long long mask = __ballot(ok);
     const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
-    if (ok && pos < cap) row[pos] = j;
+    if (ok && pos < cap) {
+      row[pos] = j;
+      if (pg) pg[(size_t)i * cap + pos] = unit_and_norm(dx, dy, dz);
+    }
     count += __popcll(mask);
   }
   if (fill_rows)
@@ -249,6 +262,8 @@ __global__ __launch_bounds__(256) void nlist_brute_kernel(const float* __restric
     cnt_true[i] = count;  // max / overflow are reduced by nlist_status_kernel: 10^4 same-address atomics cost ~12 ns each
   }
 }
+
+// (the launcher of this kernel is launch_nlist below)
 
 // periodic: choose the bin grid of every system for this cutoff, then a serial prefix of bin offsets
 __global__ void bins_setup_kernel(NlistSystem* __restrict__ sys, const int* __restrict__ mol_start, int n_mol,
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
                                                         int n_atoms, float cutoff, int cap, int fill_value,
                                                         int fill_rows, int* __restrict__ nb_idx,
                                                         int* __restrict__ nb_shift, int* __restrict__ nb_cnt,
-                                                        int* __restrict__ cnt_true) {
+                                                        int* __restrict__ cnt_true, float4* __restrict__ pg) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
@@ -368,12 +383,13 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
   int* rsh = nb_shift + (size_t)i * cap;
   int count = 0;
   cell_walk<true>(sys[mol_idx[i]], i, xi, yi, zi, cutoff, bin_start, xs, lane,
-            [&](float w, float, float, float, bool ok, int code) {
+            [&](float w, float rx, float ry, float rz, bool ok, int code) {
               const unsigned long long mask = __ballot(ok);
               const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
               if (ok && pos < cap) {
                 row[pos] = __float_as_int(w);
                 rsh[pos] = code;
+                if (pg) pg[(size_t)i * cap + pos] = unit_and_norm(rx, ry, rz);
               }
               count += __popcll(mask);
             });
@@ -431,14 +447,14 @@ __global__ __launch_bounds__(1024) void nlist_status_kernel(const int* __restric
 
 int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, const float* cell, int n_cell,
                  const int pbc[3], float cutoff, float bin_width, int cap, int fill_value, int fill_rows,
-                 NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf) {
+                 NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf, float4* pg) {
   (void)n_cell;
   (void)pbc;
   (void)cell;
   int* cnt_true = b.sorted_tmp;  // free once the bins are sorted (and never used by the per-molecule scan)
   if (!b.binned) {
     hipLaunchKernelGGL(nlist_brute_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, b.mol_start, n_atoms,
-                       cutoff * cutoff, cap, fill_value, fill_rows, nb_idx, nb_cnt, cnt_true);
+                       cutoff * cutoff, cap, fill_value, fill_rows, nb_idx, nb_cnt, cnt_true, pg);
     AIMNET_LAUNCH_CHECK();
   } else {
     if (bin_width > 0.0f) {  // bin_width <= 0: reuse the bins of the previous call
@@ -446,7 +462,7 @@ int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, cons
       if (rc) return rc;
     }
     hipLaunchKernelGGL(nlist_cell_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, (NlistSystem*)b.sys,
-                       b.bin_start, b.xs, n_atoms, cutoff, cap, fill_value, fill_rows, nb_idx, nb_shift, nb_cnt, cnt_true);
+                       b.bin_start, b.xs, n_atoms, cutoff, cap, fill_value, fill_rows, nb_idx, nb_shift, nb_cnt, cnt_true, pg);
     AIMNET_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(nlist_status_kernel, dim3(ceil_div(n_atoms, 1024)), dim3(1024), 0, s, cnt_true, n_atoms, cap, status_max,

@@ -257,7 +257,7 @@ def test_atom_order_does_not_matter(calc):
     assert np.abs(a["stress"] - b["stress"]).max() < 1e-5
 
 
-def test_nse_calculator_open_shell(oracle32_nse):
+def test_nse_calculator_open_shell(oracle32_nse, oracle64_nse):
     """Open-shell NSE family through the calculator API: `mult` input, spin_charges output, the reference golden
     (tests/golden/nse.npz), 3D batches, and the FD Hessian-vector product against a central difference of the oracle forces."""
     from aimnetcentral_amd import AIMNet2Calculator, loader
@@ -278,7 +278,9 @@ def test_nse_calculator_open_shell(oracle32_nse):
     # flat ragged batch with per-molecule multiplicities == the reference golden
     b = npy(calc({"coord": g["b5_coord"], "numbers": g["b5_numbers"], "mol_idx": g["b5_mol_idx"], "charge": g["b5_charge"],
                   "mult": g["b5_mult"]}, forces=True))
-    assert np.abs(b["energy"] - g["b5_energy"]).max() <= energy_tol(30)
+    # gate widened by the golden's own distance from the fp64 energy (1.2e-5 eV on the 30-atom cation), see test_gpu_parity.compare
+    e64 = O.evaluate(oracle64_nse, g["b5_coord"], g["b5_numbers"], g["b5_charge"], g["b5_mol_idx"], mult=g["b5_mult"], forces=False)["energy"]
+    assert (np.abs(b["energy"] - g["b5_energy"]) <= energy_tol(30) + np.abs(g["b5_energy"] - e64)).all()
     assert np.abs(b["spin_charges"] - g["b5_spin_charges"]).max() <= CHARGE_ATOL
     # H v by the calculator's finite differences vs a central difference of the fp64-free oracle forces along v
     n = 12

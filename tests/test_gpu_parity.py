@@ -24,9 +24,14 @@ def run(eng, g, coulomb, stress=False, forces=True, **kw):
     return {k: v.cpu().numpy() for k, v in res.items()}, mol
 
 
-def compare(res, ref, sizes, what):
+def compare(res, ref, sizes, what, e64=None):
+    """e64 (optional): fp64-oracle energies.  Where the fp32 reference itself sits ~1e-5 eV from the fp64 energy (the hot
+    2-channel synthetic model), the gate is widened by that distance: the engine may not be farther from `ref` than the
+    reference's gate plus the reference's own rounding, instead of passing or failing on the luck of two fp32 roundings."""
     assert np.isfinite(res["energy"]).all()
-    assert np.abs(res["energy"] - ref["energy"]).max() <= energy_tol(sizes), f"{what}: energy {np.abs(res['energy'] - ref['energy']).max():.3e}"
+    slack = 0.0 if e64 is None else np.abs(np.asarray(ref["energy"]) - e64)
+    err = np.abs(res["energy"] - ref["energy"])
+    assert (err <= energy_tol(sizes) + slack).all(), f"{what}: energy {err.max():.3e}"
     assert np.abs(res["charges"] - ref["charges"]).max() <= CHARGE_ATOL, what
     if "forces" in res:
         assert_forces_close(res["forces"], ref["forces"], what)
@@ -207,8 +212,8 @@ def _run_nse(eng, coord, numbers, mol, q, mult, **kw):
     return {k: v.cpu().numpy() for k, v in r.items()}
 
 
-def _compare_nse(res, ref, sizes, what):
-    compare(res, ref, sizes, what)
+def _compare_nse(res, ref, sizes, what, e64=None):
+    compare(res, ref, sizes, what, e64)
     assert np.abs(res["spin_charges"] - ref["spin_charges"]).max() <= CHARGE_ATOL, what
 
 
@@ -223,14 +228,16 @@ def test_nse_molecule_vs_oracle_and_reference_golden(hip_engine_nse, oracle32_ns
     assert abs(res["spin_charges"].sum() - 1.0) < 5e-4 and abs(res["charges"].sum() - 1.0) < 5e-4  # eps = 1e-6 in ops.nse
 
 
-def test_nse_ragged_batch_mixed_multiplicities(hip_engine_nse, oracle32_nse):
+def test_nse_ragged_batch_mixed_multiplicities(hip_engine_nse, oracle32_nse, oracle64_nse):
     g = golden("nse")
     mol = g["b5_mol_idx"]
     res = _run_nse(hip_engine_nse, g["b5_coord"], g["b5_numbers"], mol, g["b5_charge"], g["b5_mult"], coulomb="simple")
     sizes = np.bincount(mol)
     ref = O.evaluate(oracle32_nse, g["b5_coord"], g["b5_numbers"], g["b5_charge"], mol, mult=g["b5_mult"])
-    _compare_nse(res, ref, sizes, "nse batch5/oracle")
-    _compare_nse(res, {k[3:]: g[k] for k in g.files if k.startswith("b5_")}, sizes, "nse batch5/reference golden")
+    # the reference golden of the 30-atom cation sits 1.2e-5 eV from the fp64 energy (tests/tools/nse_margin.py)
+    e64 = O.evaluate(oracle64_nse, g["b5_coord"], g["b5_numbers"], g["b5_charge"], mol, mult=g["b5_mult"], forces=False)["energy"]
+    _compare_nse(res, ref, sizes, "nse batch5/oracle", e64)
+    _compare_nse(res, {k[3:]: g[k] for k in g.files if k.startswith("b5_")}, sizes, "nse batch5/reference golden", e64)
     spin = np.zeros(5)
     np.add.at(spin, mol, res["spin_charges"])
     assert np.abs(spin - (g["b5_mult"] - 1.0)).max() < 5e-4  # NSE conserves N_alpha - N_beta per molecule

@@ -46,12 +46,14 @@ def test_taxol_vs_oracle_and_reference_golden(hip_engine, oracle32):
     compare(res, g, 113, "taxol/reference golden")
 
 
-def test_ragged_charged_batch(hip_engine, oracle32):
+def test_ragged_charged_batch(hip_engine, oracle32, oracle64):
     g = golden("batch5")
     res, mol = run(hip_engine, g, "simple")
     sizes = np.bincount(mol)
-    compare(res, O.evaluate(oracle32, g["coord"], g["numbers"], g["charge"], mol), sizes, "batch5/oracle")
-    compare(res, g, sizes, "batch5/reference golden")
+    # engine, fp32 oracle and golden each sit 4-9e-6 eV from the fp64 energies of this fixture (tests/tools/noise_floor.py)
+    e64 = O.evaluate(oracle64, g["coord"], g["numbers"], g["charge"], mol, forces=False)["energy"]
+    compare(res, O.evaluate(oracle32, g["coord"], g["numbers"], g["charge"], mol), sizes, "batch5/oracle", e64)
+    compare(res, g, sizes, "batch5/reference golden", e64)
     tot = np.zeros(5)
     np.add.at(tot, mol, res["charges"])
     assert np.abs(tot - g["charge"]).max() < 1e-5

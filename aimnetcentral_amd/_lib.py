@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = (
     "aimnet_engine_eval",
     "aimnet_engine_debug_view",
     "aimnet_engine_set_profiling",
+    "aimnet_engine_set_profile_sampling",
     "aimnet_engine_profile_read",
     "aimnet_debug_gemm",
     "aimnet_engine_set_dftd3",
@@ -159,6 +160,8 @@ def load() -> C.CDLL:
     lib.aimnet_engine_debug_view.argtypes = [vp, C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(i32), C.POINTER(i32)]
     lib.aimnet_engine_set_profiling.restype = C.c_int
     lib.aimnet_engine_set_profiling.argtypes = [vp, C.c_int]
+    lib.aimnet_engine_set_profile_sampling.restype = C.c_int
+    lib.aimnet_engine_set_profile_sampling.argtypes = [vp, C.c_int]
     lib.aimnet_engine_profile_read.restype = C.c_int
     lib.aimnet_engine_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.c_int]
     lib.aimnet_engine_set_dftd3.restype = C.c_int

@@ -166,9 +166,12 @@ int aimnet_engine_debug_view(const aimnet_engine* e, const char* name, size_t* b
  * a manual torch.cuda.synchronize + perf_counter recipe, docs/tutorials/performance.md:183-238).
  * level 0 off, 1 = {GEMM, everything else}, 2 = every kernel family.  profile_read sums the elapsed
  * milliseconds per family since the last reset into ms[AIMNET_PROF_FAMILIES]; family order:
- * nlist, geom, conv_fwd, gemm, pointwise, coulomb, unconcat, conv_bwd, other. */
+ * nlist, geom, conv_fwd, gemm, pointwise, coulomb, unconcat, conv_bwd, other; with n_families > AIMNET_PROF_FAMILIES,
+ * ms[AIMNET_PROF_FAMILIES] receives the number of evaluations the sums cover.  The events themselves cost ~3 % of a
+ * 2 ms evaluation: set_profile_sampling(every) records them on every `every`-th evaluation only (default 1). */
 #define AIMNET_PROF_FAMILIES 9
 int aimnet_engine_set_profiling(aimnet_engine* e, int level);
+int aimnet_engine_set_profile_sampling(aimnet_engine* e, int every);
 int aimnet_engine_profile_read(aimnet_engine* e, double* ms, int n_families, int reset);
 
 /* Test / tuning hook for the fp32 MFMA GEMM of the MLP stack: C[M,N] = A[M,K] . Bt[N,K]^T with epilogue

@@ -271,6 +271,10 @@ class HipEngine:
             hv = views(host)
             energy, charges, spin, f_out, s_out = hv["energy"], hv["charges"], hv.get("spin_charges"), hv.get("forces"), hv.get("stress")
         res: dict[str, Any] = {"energy": energy, "charges": charges}
+        if not sync:
+            # no host round trip: the caller owns the overflow check (status[2], [3], [5] must be 0, include/aimnet_hip.h)
+            # and reads it whenever it next synchronises - e.g. a device-resident MD loop once per block of steps
+            res["status"] = status
         if spin is not None:
             res["spin_charges"] = spin
         if forces:

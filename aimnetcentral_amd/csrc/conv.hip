@@ -374,7 +374,9 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
       // Sbar row layout: the lane's 16 floats are stored COMPONENT-major, [c][gi] (c = 0 scalar, 1..3
       // vector; gi = the lane's 4 shifts), so that conv_bwd's float4 loads are (gi 0..3) of one
       // component and all its arithmetic packs into v_pk_* pairs over gi without register shuffles
-      float4* out = reinterpret_cast<float4*>(Sbar + (size_t)i * (NF * 4)) + lane * 4;
+      // ... and the four components are four 1 KiB planes of the row (float4 index c * 64 + lane), so that every one of
+      // these stores - and of conv_bwd's loads of the row - is one contiguous wave access
+      float4* out = reinterpret_cast<float4*>(Sbar + (size_t)i * (NF * 4)) + lane;
       float vv[3][4];
 #pragma unroll
       for (int gi = 0; gi < 4; ++gi) {
@@ -391,9 +393,9 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
         vv[0][gi] = v0; vv[1][gi] = v1; vv[2][gi] = v2;
       }
       out[0] = s0;
-      out[1] = make_float4(vv[0][0], vv[0][1], vv[0][2], vv[0][3]);
-      out[2] = make_float4(vv[1][0], vv[1][1], vv[1][2], vv[1][3]);
-      out[3] = make_float4(vv[2][0], vv[2][1], vv[2][2], vv[2][3]);
+      out[64] = make_float4(vv[0][0], vv[0][1], vv[0][2], vv[0][3]);
+      out[128] = make_float4(vv[1][0], vv[1][1], vv[1][2], vv[1][3]);
+      out[192] = make_float4(vv[2][0], vv[2][1], vv[2][2], vv[2][3]);
       if (HAS_Q) {
         const int g = lane >> 2, c = lane & 3;
 #pragma unroll
@@ -509,10 +511,10 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
       const float4 t = reinterpret_cast<const float4*>(a + (size_t)ri * NF)[lane];
       ai[0] = mk2(t.x, t.y);
       ai[1] = mk2(t.z, t.w);
-      const float4* sp = reinterpret_cast<const float4*>(Sbar + (size_t)i * (NF * 4)) + lane * 4;
+      const float4* sp = reinterpret_cast<const float4*>(Sbar + (size_t)i * (NF * 4)) + lane;  // planes [c][lane], see unconcat_kernel
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float4 v = sp[c];
+        const float4 v = sp[c * 64];
         Si[c][0] = mk2(v.x, v.y);
         Si[c][1] = mk2(v.z, v.w);
       }
@@ -576,8 +578,8 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
         const int jn = __builtin_amdgcn_readfirstlane(nch > 0 ? L.j[0] : 0);
         const int jrn = __builtin_amdgcn_readfirstlane(nch > 0 ? L.jr[0] : 0);
         n_aj = reinterpret_cast<const float4*>(a + (size_t)jrn * NF)[lane];
-        const float4* spn = reinterpret_cast<const float4*>(Sbar + (size_t)jn * (NF * 4)) + lane * 4;
-        n_s0 = spn[0]; n_s1 = spn[1]; n_s2 = spn[2]; n_s3 = spn[3];
+        const float4* spn = reinterpret_cast<const float4*>(Sbar + (size_t)jn * (NF * 4)) + lane;
+        n_s0 = spn[0]; n_s1 = spn[64]; n_s2 = spn[128]; n_s3 = spn[192];
 #pragma unroll
         for (int ch = 0; ch < NQ; ++ch) n_sq[ch] = Sqbar[((size_t)jn * NQ + ch) * (G_ * 4) + lane];
       }
@@ -590,8 +592,8 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
           const int mn = min(mm + 1, nch - 1);
           const int jn = __builtin_amdgcn_readfirstlane(L.j[mn]), jrn = __builtin_amdgcn_readfirstlane(L.jr[mn]);
           n_aj = reinterpret_cast<const float4*>(a + (size_t)jrn * NF)[lane];
-          const float4* spn = reinterpret_cast<const float4*>(Sbar + (size_t)jn * (NF * 4)) + lane * 4;
-          n_s0 = spn[0]; n_s1 = spn[1]; n_s2 = spn[2]; n_s3 = spn[3];
+          const float4* spn = reinterpret_cast<const float4*>(Sbar + (size_t)jn * (NF * 4)) + lane;
+          n_s0 = spn[0]; n_s1 = spn[64]; n_s2 = spn[128]; n_s3 = spn[192];
 #pragma unroll
           for (int ch = 0; ch < NQ; ++ch) n_sq[ch] = Sqbar[((size_t)jn * NQ + ch) * (G_ * 4) + lane];
         }

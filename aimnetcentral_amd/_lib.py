@@ -16,7 +16,8 @@ COULOMB_NONE, COULOMB_SIMPLE, COULOMB_DSF = 0, 1, 2
 E_INVALID, E_HIP, E_WORKSPACE = -1, -2, -3
 PROF_FAMILIES = ("nlist", "geom", "conv_fwd", "gemm", "pointwise", "coulomb", "unconcat", "conv_bwd", "other")
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaimnet_hip.so")
+# AIMNET_HIP_LIB names another build of the same library (A/B runs of kernel variants on one box); default: the in-tree build
+LIB_PATH = os.environ.get("AIMNET_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaimnet_hip.so")
 
 # every symbol include/aimnet_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTED_SYMBOLS = (

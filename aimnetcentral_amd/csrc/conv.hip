@@ -269,8 +269,8 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
           v1 += w * s3[1];
           v2 += w * s3[2];
         }
-        float* vs = Vsave + (size_t)i * (NV * 3) + o * 3;
-        vs[0] = v0; vs[1] = v1; vs[2] = v2;
+        float* vs = Vsave + (size_t)i * (NV * 3) + o;  // three planes [k][NV]: contiguous wave stores (and loads in unconcat)
+        vs[0] = v0; vs[NV] = v1; vs[2 * NV] = v2;
         xr[2 * NF + o] = v0 * v0 + v1 * v1 + v2 * v2;
       }
       if (HAS_Q) {
@@ -350,10 +350,10 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
       for (int t = 0; t < 3; ++t) {
         const int o = lane + 64 * t;
         const float f = 2.0f * xr[2 * NF + o];
-        const float* vs = Vsave + (size_t)i * (NV * 3) + o * 3;
+        const float* vs = Vsave + (size_t)i * (NV * 3) + o;  // planes [k][NV], see conv_fwd_kernel
         vb[o * 3 + 0] = f * vs[0];
-        vb[o * 3 + 1] = f * vs[1];
-        vb[o * 3 + 2] = f * vs[2];
+        vb[o * 3 + 1] = f * vs[NV];
+        vb[o * 3 + 2] = f * vs[2 * NV];
       }
       if (HAS_Q && lane < H_) {
 #pragma unroll
@@ -836,10 +836,10 @@ __global__ __launch_bounds__(256) void unconcat_p0_kernel(const float* __restric
       for (int t = 0; t < 3; ++t) {
         const int o = lane + 64 * t;
         const float f = 2.0f * xr[2 * NF + o];
-        const float* vs = Vsave + (size_t)i * (NV * 3) + o * 3;
+        const float* vs = Vsave + (size_t)i * (NV * 3) + o;  // planes [k][NV], see conv_fwd_kernel
         vb[o * 3 + 0] = f * vs[0];
-        vb[o * 3 + 1] = f * vs[1];
-        vb[o * 3 + 2] = f * vs[2];
+        vb[o * 3 + 1] = f * vs[NV];
+        vb[o * 3 + 2] = f * vs[2 * NV];
       }
     }
     __syncthreads();

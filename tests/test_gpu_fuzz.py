@@ -61,7 +61,9 @@ def _compare(res, ref, ref64, mol, what, nse, energy=None):
 
 import os  # noqa: E402
 
-# AIMNET_FUZZ_SEEDS="lo:hi" widens the sweep for a soak run (default: the 32 seeds that are part of the suite)
+# AIMNET_FUZZ_SEEDS="lo:hi" widens the sweep for a soak run (default: the 32 seeds that are part of the suite).  The energy
+# gate is statistical (reference gate + fp32 oracle's own distance + a 3-sigma random walk of its per-atom errors): in a
+# 1 000-seed soak one configuration (seed 535) exceeded it, by 2.5 %; nothing else failed.
 _LO, _HI = (int(v) for v in os.environ.get("AIMNET_FUZZ_SEEDS", "0:32").split(":"))
 
 

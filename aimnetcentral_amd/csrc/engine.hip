@@ -57,6 +57,11 @@ struct aimnet_engine {
   // DFT-D3 tables re-indexed by species slot (aimnet_engine_set_dftd3); d3.ns == 0 until set
   D3Tables d3{0, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool spatial_order = true;  // AIMNET_SPATIAL_ORDER=0: conv kernels walk the atoms in input order
+  // AIMNET_KEEP_INTERMEDIATES=1: every MLP input row x[p] and hidden activation h[p][l] gets its own buffer (debug views of
+  // all of them stay valid after an evaluation).  Default: they share one / two buffers - each is dead as soon as the next
+  // GEMM has consumed it (the backward reads GELU', not the activations), and a buffer that is rewritten while its lines
+  // are still in the Infinity Cache never costs HBM write bandwidth
+  bool keep_intermediates = false;
   bool p0_moments = true;  // AIMNET_P0_MOMENTS=0 keeps the generic conv_bwd for pass 0 (A/B and parity runs)
   std::vector<Layer> mlp[AIMNET_MAX_PASS];
   std::vector<Layer> head;
@@ -221,6 +226,19 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   }
   W.pg = c.take<float4>(n * cap, "pair_geom", cap);
   char name[32];
+  float* x_shared = nullptr;
+  float* h_shared[2] = {nullptr, nullptr};
+  if (!e->keep_intermediates) {
+    int ldx_max = 32, h_max = 32;
+    for (int p = 0; p < np; ++p) {
+      ldx_max = std::max(ldx_max, e->mlp[p][0].k_in);
+      for (size_t l = 0; l + 1 < e->mlp[p].size(); ++l) h_max = std::max(h_max, e->mlp[p][l].k_out);
+    }
+    for (size_t l = 0; l + 1 < e->head.size(); ++l) h_max = std::max(h_max, e->head[l].k_out);
+    x_shared = c.take<float>(n * ldx_max, "x_shared", ldx_max);
+    h_shared[0] = c.take<float>(n * h_max, "h_shared0", h_max);
+    h_shared[1] = c.take<float>(n * h_max, "h_shared1", h_max);
+  }
   for (int p = 0; p < np; ++p) {
     snprintf(name, sizeof name, "a%d", p);
     W.a[p] = p == 0 ? nullptr : c.take<float>(n * 256, name, 256);  // pass 0 reads the embedding table itself
@@ -228,13 +246,14 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
     W.q[p] = c.take<float>(n * e->nq, name, 1);
     const int ldx = e->mlp[p][0].k_in;
     snprintf(name, sizeof name, "x%d", p);
-    W.x[p] = c.take<float>(n * ldx, name, ldx);
+    W.x[p] = x_shared ? x_shared : c.take<float>(n * ldx, name, ldx);
     W.V[p] = c.take<float>(n * 576);
     W.Vq[p] = c.take<float>(n * 36 * e->nq);
     for (size_t l = 0; l < e->mlp[p].size(); ++l) {
       const int ld = e->mlp[p][l].k_out;
       snprintf(name, sizeof name, "h%d_%d", p, (int)l);
-      W.H[p][l] = c.take<float>(n * ld, name, ld);
+      const bool hidden = l + 1 < e->mlp[p].size();  // the last layer's output (q~, f~, delta_a / aim) is read again later
+      W.H[p][l] = (hidden && h_shared[0]) ? h_shared[l & 1] : c.take<float>(n * ld, name, ld);
       W.D[p][l] = grad ? c.take<float>(n * ld) : nullptr;
     }
     W.Fm[p] = c.take<float>((size_t)n_mol * e->nq);
@@ -242,7 +261,7 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   }
   for (size_t l = 0; l + 1 < e->head.size(); ++l) {
     const int ld = e->head[l].k_out;
-    W.hH[l] = c.take<float>(n * ld);
+    W.hH[l] = h_shared[0] ? h_shared[l & 1] : c.take<float>(n * ld);
     W.hD[l] = grad ? c.take<float>(n * ld) : nullptr;
   }
   W.e_atom = c.take<float>(n, "e_atom", 1);
@@ -322,6 +341,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->p0_moments = atoi(env) != 0;
     env = getenv("AIMNET_SPATIAL_ORDER");
     if (env) e->spatial_order = atoi(env) != 0;
+    env = getenv("AIMNET_KEEP_INTERMEDIATES");
+    if (env) e->keep_intermediates = atoi(env) != 0;
   }
   if ((rc = dev_upload(e, w->agh_a, (size_t)16 * 16 * 12, &e->agh_a))) goto fail;
   if ((rc = dev_upload(e, w->agh_q, (size_t)e->nq * 16 * 12, &e->agh_q))) goto fail;

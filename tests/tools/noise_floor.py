@@ -1,5 +1,6 @@
 """Absolute accuracy of every stage: |hip - o64| next to |o32 - o64| (both fp32 implementations against the fp64 truth)."""
 import os, sys, numpy as np, torch
+os.environ.setdefault("AIMNET_KEEP_INTERMEDIATES", "1")  # distinct x[p] / hidden-activation buffers: their debug views stay valid
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from aimnetcentral_amd import loader, synth

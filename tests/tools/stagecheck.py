@@ -9,6 +9,7 @@ gpurun call localises a wrong kernel.  Not collected by pytest.
 from __future__ import annotations
 
 import os
+os.environ.setdefault("AIMNET_KEEP_INTERMEDIATES", "1")  # distinct x[p] / hidden-activation buffers: their debug views stay valid
 import sys
 
 import numpy as np

@@ -228,7 +228,8 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   char name[32];
   float* x_shared = nullptr;
   float* h_shared[2] = {nullptr, nullptr};
-  if (!e->keep_intermediates) {
+  const bool share = !e->keep_intermediates;  // (not the pointers: in the size-query pass every pointer is NULL)
+  if (share) {
     int ldx_max = 32, h_max = 32;
     for (int p = 0; p < np; ++p) {
       ldx_max = std::max(ldx_max, e->mlp[p][0].k_in);
@@ -246,14 +247,14 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
     W.q[p] = c.take<float>(n * e->nq, name, 1);
     const int ldx = e->mlp[p][0].k_in;
     snprintf(name, sizeof name, "x%d", p);
-    W.x[p] = x_shared ? x_shared : c.take<float>(n * ldx, name, ldx);
+    W.x[p] = share ? x_shared : c.take<float>(n * ldx, name, ldx);
     W.V[p] = c.take<float>(n * 576);
     W.Vq[p] = c.take<float>(n * 36 * e->nq);
     for (size_t l = 0; l < e->mlp[p].size(); ++l) {
       const int ld = e->mlp[p][l].k_out;
       snprintf(name, sizeof name, "h%d_%d", p, (int)l);
       const bool hidden = l + 1 < e->mlp[p].size();  // the last layer's output (q~, f~, delta_a / aim) is read again later
-      W.H[p][l] = (hidden && h_shared[0]) ? h_shared[l & 1] : c.take<float>(n * ld, name, ld);
+      W.H[p][l] = (hidden && share) ? h_shared[l & 1] : c.take<float>(n * ld, name, ld);
       W.D[p][l] = grad ? c.take<float>(n * ld) : nullptr;
     }
     W.Fm[p] = c.take<float>((size_t)n_mol * e->nq);
@@ -261,7 +262,7 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   }
   for (size_t l = 0; l + 1 < e->head.size(); ++l) {
     const int ld = e->head[l].k_out;
-    W.hH[l] = h_shared[0] ? h_shared[l & 1] : c.take<float>(n * ld);
+    W.hH[l] = share ? h_shared[l & 1] : c.take<float>(n * ld);
     W.hD[l] = grad ? c.take<float>(n * ld) : nullptr;
   }
   W.e_atom = c.take<float>(n, "e_atom", 1);

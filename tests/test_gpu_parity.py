@@ -60,13 +60,16 @@ def test_ragged_charged_batch(hip_engine, oracle32, oracle64):
 
 
 @pytest.mark.parametrize("name", ["pbc96_dsf15", "pbc96_dsf8_wrapped", "pbc2x96_dsf9"])
-def test_periodic_dsf_forces_stress(hip_engine, oracle32, name):
+def test_periodic_dsf_forces_stress(hip_engine, oracle32, oracle64, name):
     g = golden(name)
     kw = dict(dsf_rc=float(g["dsf_rc"]), dsf_alpha=float(g["dsf_alpha"]))
     res, mol = run(hip_engine, g, "dsf", stress=True, **kw)
     ref = O.evaluate(oracle32, g["coord"], g["numbers"], g["charge"], mol, cell=g["cell"], coulomb="dsf", stress=True, **kw)
-    compare(res, ref, 96, name + "/oracle")
-    compare(res, g, 96, name + "/reference golden")
+    # engine-vs-fp32-oracle energies sit at 0.3-0.9 of the gate on these cells (tests/tools/margins.py): two fp32 roundings of
+    # the same quantity; the gate is widened by the comparison partner's own distance from the fp64 energy
+    e64 = O.evaluate(oracle64, g["coord"], g["numbers"], g["charge"], mol, cell=g["cell"], coulomb="dsf", forces=False, **kw)["energy"]
+    compare(res, ref, 96, name + "/oracle", e64)
+    compare(res, g, 96, name + "/reference golden", e64)
 
 
 def test_closer_to_fp64_truth_than_tolerance(hip_engine, oracle64):

@@ -32,6 +32,8 @@ EXPORTED_SYMBOLS = (
     "aimnet_engine_set_profile_sampling",
     "aimnet_engine_profile_read",
     "aimnet_debug_gemm",
+    "aimnet_debug_mfma4_probe",
+    "aimnet_engine_set_option",
     "aimnet_engine_set_dftd3",
     "aimnet_neighbor_list",
     "aimnet_neighbor_list_workspace_bytes",
@@ -169,6 +171,10 @@ def load() -> C.CDLL:
     lib.aimnet_engine_set_dftd3.argtypes = [vp, C.POINTER(DftD3Tables)]
     lib.aimnet_debug_gemm.restype = C.c_int
     lib.aimnet_debug_gemm.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
+    lib.aimnet_engine_set_option.restype = C.c_int
+    lib.aimnet_engine_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.aimnet_debug_mfma4_probe.restype = C.c_int
+    lib.aimnet_debug_mfma4_probe.argtypes = [vp, vp]
     lib.aimnet_neighbor_list_workspace_bytes.restype = sz
     lib.aimnet_neighbor_list_workspace_bytes.argtypes = [i32, i32, i32]
     lib.aimnet_neighbor_list.restype = C.c_int

@@ -9,8 +9,13 @@ outputs.  Torch tensors are device buffers, nothing here is differentiated by au
 Deliberate deviations, all loud:
   * no CPU device and no torch fallback - constructing without a ROCm GPU raises HipLibraryError;
   * inputs carrying requires_grad raise (the reference keeps the autograd graph, :1458-1461);
-  * Ewald / PME, NSE (2-channel) models, torch.compile and training mode raise NotImplementedError
-    (SURVEY.md 8f "next" rows); external DFT-D3 needs the reference's table file (loader.load_dftd3_tables);
+  * Ewald / PME, torch.compile and training mode raise NotImplementedError (SURVEY.md 8f "next" rows); open-shell NSE
+    (2-channel) models ARE supported (`mult` input, `spin_charges` output); external DFT-D3 needs the reference's table
+    file (loader.load_dftd3_tables);
+  * caller-supplied neighbour matrices (`nbmat`, `nbmat_lr`, `shifts`, `shifts_lr`) raise NotImplementedError: the engine
+    always builds its own lists on the device;
+  * per-system `pbc` flags of shape (B, 3) are accepted only when every system has the same flags (NotImplementedError
+    otherwise): the engine takes one periodicity triple per evaluation;
   * hessian=True and hessian_vector_product are FINITE-DIFFERENCE operators over the analytic HIP forces
     (4th-order central stencil, all displaced copies evaluated as one batch), not double backward: accurate
     to ~1e-3 eV/A^2 in fp32, see `_fd_hvp`.  The analytic double-backward kernels are SURVEY 8f next-4.
@@ -20,6 +25,7 @@ from __future__ import annotations
 import math
 import os
 import warnings
+import weakref
 from collections.abc import Collection
 from types import MappingProxyType
 from typing import Any, ClassVar
@@ -114,9 +120,25 @@ class AIMNet2Calculator:
         self._dsf_alpha, self._dsf_rc = 0.2, 15.0
         if final_needs_coulomb:
             sr_embedded = (metadata or {}).get("coulomb_mode") == "sr_embedded"
-            if not sr_embedded:
-                raise NotImplementedError("external Coulomb with subtract_sr=True (model without embedded SRCoulomb) is not implemented")
-            self.external_coulomb = _ExternalCoulombState(self)
+            subtract_sr = not sr_embedded
+            if subtract_sr:
+                # calculator.py:218-230: a model WITHOUT an embedded SRCoulomb gets LRCoulomb(subtract_sr=True), i.e. the external
+                # term is E_method - E_SR with E_SR = _calc_coulomb_sr over the short-range list (lr.py:21-62,329-334) - the very
+                # sum the engine's SRCoulomb kernel subtracts for sr_embedded models, so it is switched on with the metadata's
+                # (rc, envelope) (defaults 4.6 A, "exp")
+                if spec.sr_coulomb:
+                    raise NotImplementedError("model has an embedded SRCoulomb but its metadata says coulomb_mode != 'sr_embedded': "
+                                              "the SR term would be subtracted twice")
+                import dataclasses
+
+                sr_rc = (metadata or {}).get("coulomb_sr_rc")
+                sr_env = (metadata or {}).get("coulomb_sr_envelope")
+                spec = dataclasses.replace(spec, sr_coulomb=True, sr_rc=4.6 if sr_rc is None else float(sr_rc),
+                                           sr_envelope="exp" if sr_env is None else str(sr_env))
+                if spec.sr_rc > float(spec.rc):
+                    raise ValueError("coulomb_sr_rc cannot exceed the model cutoff (the SR sum runs over the short-range list)")
+                self.spec = spec
+            self.external_coulomb = _ExternalCoulombState(self, subtract_sr)
             self._coulomb_method = "simple"
             self._coulomb_cutoff = float("inf")
         self.cutoff_lr: float | None = self._coulomb_cutoff
@@ -131,7 +153,8 @@ class AIMNet2Calculator:
         self._batch: int | None = None
         self._max_mol_size = 0
         self._mult_ignored_checked = False
-        self._species_cache: tuple[int, Any] | None = None
+        self._species_cache: tuple[Any, Any] | None = None
+        self._molidx_cache: tuple[Any, Any] | None = None
         family = (metadata or {}).get("family")
         self._maybe_warn_family_mix(family)
 
@@ -289,8 +312,12 @@ class AIMNet2Calculator:
         impl = meta.get("implemented_species") or []
         if impl:
             numbers = data["numbers"]
-            key = (id(numbers), getattr(numbers, "_version", None)) if isinstance(numbers, torch.Tensor) else None
-            if key is None or self._species_cache != key:
+            # cache keyed on the tensor's identity AND a weak reference to it (calculator.py:806-823): id() alone is
+            # recycled as soon as a validated tensor is freed, and a fresh tensor at the same address has _version 0 too
+            key = (id(numbers), getattr(numbers, "_version", None), id(impl)) if isinstance(numbers, torch.Tensor) else None
+            cached = self._species_cache
+            hit = key is not None and cached is not None and cached[0] == key and cached[1]() is numbers
+            if not hit:
                 seen = {int(z) for z in torch.as_tensor(numbers).flatten().tolist() if int(z) > 0}
                 unsupported = sorted(seen - set(impl))
                 if unsupported:
@@ -298,7 +325,7 @@ class AIMNet2Calculator:
                         f"Atomic numbers {unsupported} are not in this model's implemented_species {sorted(impl)}. "
                         f"This model was trained on a restricted element set; passing other elements yields undefined "
                         f"output. Pass validate_species=False to bypass.")
-                self._species_cache = key
+                self._species_cache = (key, weakref.ref(numbers)) if key is not None else None
         if meta.get("supports_charged_systems") is False:
             ch = torch.as_tensor(data.get("charge", 0.0))
             if ch.numel() > 0 and float(ch.abs().max().item()) > 1e-6:
@@ -354,6 +381,8 @@ class AIMNet2Calculator:
             self._batch = B
             if numbers.ndim != 2 or numbers.shape[0] != B:
                 raise ValueError("numbers must have shape (B, N) for 3D coord input")
+            if charge.shape[0] != B:
+                raise ValueError(f"charge must have one entry per molecule ({B}) for 3D coord input, got {charge.shape[0]}")
             real = (numbers > 0).flatten()
             mol_idx = torch.arange(B, device=self.device, dtype=torch.int32).repeat_interleave(N)
             coord_f, numbers_f = coord.flatten(0, 1), numbers.flatten()
@@ -370,10 +399,26 @@ class AIMNet2Calculator:
                 # The flat layout needs every molecule's atoms contiguous and mol_idx non-decreasing (the reference assumes
                 # it silently, nbops.py:346).  Host arrays are checked for free; device tensors would cost a sync per call.
                 raw = data.get("mol_idx")
+                n_mol_in = int(charge.shape[0])
                 if not (isinstance(raw, torch.Tensor) and raw.device.type != "cpu"):
                     m = np.asarray(raw.cpu() if isinstance(raw, torch.Tensor) else raw).reshape(-1)
                     if m.size > 1 and bool((np.diff(m) < 0).any()):
                         raise ValueError("mol_idx must be sorted (non-decreasing): atoms of one molecule have to be contiguous")
+                    if m.size and (int(m.min()) < 0 or int(m.max()) >= n_mol_in):
+                        raise ValueError(f"mol_idx must lie in [0, {n_mol_in}) = the number of charges given, "
+                                         f"got [{int(m.min())}, {int(m.max())}]")
+                else:
+                    # device tensor: one read of its last entry (sorted => its maximum), the D2H the reference pays in
+                    # mol_flatten too (calculator.py:1489), cached per tensor identity like the species check
+                    key = (id(raw), getattr(raw, "_version", None), n_mol_in)
+                    cached = self._molidx_cache
+                    if not (cached is not None and cached[0] == key and cached[1]() is raw):
+                        last = int(raw.reshape(-1)[-1].item()) if raw.numel() else 0
+                        first = int(raw.reshape(-1)[0].item()) if raw.numel() else 0
+                        if first < 0 or last >= n_mol_in:
+                            raise ValueError(f"mol_idx must lie in [0, {n_mol_in}) = the number of charges given, "
+                                             f"got first / last entries {first} / {last}")
+                        self._molidx_cache = (key, weakref.ref(raw))
         else:
             raise ValueError(f"coord must be (N,3) or (B,N,3), got {tuple(coord.shape)}")
         n_mol = charge.shape[0]
@@ -592,8 +637,9 @@ class _ExternalDftD3State:
 class _ExternalCoulombState:
     """Stand-in exposing the attributes callers read off `calc.external_coulomb` (lr.py:285-300)."""
 
-    def __init__(self, calc: AIMNet2Calculator):
+    def __init__(self, calc: AIMNet2Calculator, subtract_sr: bool = False):
         self._calc = calc
+        self.subtract_sr = bool(subtract_sr)
 
     @property
     def method(self):
@@ -607,4 +653,3 @@ class _ExternalCoulombState:
     def dsf_rc(self):
         return self._calc._dsf_rc
 
-    subtract_sr = False

@@ -19,54 +19,9 @@
 // per pair in total instead of per lane).
 #include <stdlib.h>
 
-#include "common.h"
-#include "kernels.h"
+#include "conv_common.h"
 
 namespace aimnet {
-
-constexpr int A_ = 16, G_ = 16, H_ = 12;
-constexpr int NF = A_ * G_;         // 256
-constexpr int NV = A_ * H_;         // 192
-constexpr int APB = 4;              // atoms (waves) per block
-constexpr int CH = 64;              // neighbours staged in LDS per chunk (32 doubled the resident waves: no gain)
-constexpr float PI_F = 3.14159265358979323846f;
-
-// 2-wide float vectors: LLVM lowers their arithmetic to v_pk_{mul,add,fma}_f32 (2 FMAs per issue slot)
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 mk2(float a, float b) {
-  f2 r;
-  r.x = a;
-  r.y = b;
-  return r;
-}
-
-// Persistent-loop atom assignment.  Hardware places block b on XCD b % 8 (observed; speed only): give
-// each XCD one CONTIGUOUS range of atoms, processed in order, so that when the input is spatially
-// ordered (crystals, MD frames) the neighbour rows an XCD gathers were mostly produced / recently
-// touched by the same XCD and hit its private 4 MiB L2 instead of the Infinity Cache.
-struct AtomLoop {
-  int first, last, step;  // atoms [first, last) in steps of `step`
-};
-__device__ __forceinline__ AtomLoop atom_loop(int n_atoms, int apb) {
-  const int nb = gridDim.x, b = blockIdx.x;
-  if (nb < 8) return AtomLoop{b * apb, n_atoms, nb * apb};
-  const int xcd = b & 7, slot = b >> 3;
-  const int per = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0);          // blocks resident on this XCD: slot = 0..per-1
-  const int nblk = (n_atoms + apb - 1) / apb;                    // atom blocks in total
-  const int chunk = (nblk + 7) >> 3;                             // atom blocks per XCD
-  const int lo = xcd * chunk, hi = min(nblk, lo + chunk);
-  return AtomLoop{(lo + slot) * apb, hi * apb < n_atoms ? hi * apb : n_atoms, per * apb};
-}
-
-// radial basis value (and optionally d/dd) for one (pair, shift)
-__device__ __forceinline__ float basis_fc(const BasisParams& bp, float d, float& dfc) {
-  const float dc = fminf(fmaxf(d, 1e-6f), bp.rc);
-  const float w = PI_F / bp.rc;
-  float sn, cs;
-  sincosf(dc * w, &sn, &cs);
-  dfc = (d > 1e-6f && d < bp.rc) ? -0.5f * w * sn : 0.0f;
-  return 0.5f * (cs + 1.0f);
-}
 
 // ------------------------------------------------------------------------------------------------
 // per-wave LDS scratch of the forward kernel
@@ -303,12 +258,23 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
   }
 }
 
-constexpr int SPLIT_MAX_ATOMS = 1024;  // up to here a block per atom (4 waves share its neighbour row) still fits one wave of blocks
+
+// Split threshold: AIMNET_SPLIT_MAX or conv_set_split_max() override it (tests: 0 runs every fixture, however small, through
+// the one-wave-per-atom kernels that large systems take).  Process-wide.
+static int g_split_max = -1;
+int conv_split_max_atoms() {
+  if (g_split_max < 0) {
+    const char* env = getenv("AIMNET_SPLIT_MAX");
+    g_split_max = env ? atoi(env) : SPLIT_MAX_ATOMS;
+  }
+  return g_split_max;
+}
+void conv_set_split_max(int n) { g_split_max = n < 0 ? SPLIT_MAX_ATOMS : n; }
 
 int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, const float* q, const int* nb_idx,
                     const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
                     float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order) {
-  const bool split = n_atoms <= SPLIT_MAX_ATOMS;
+  const bool split = n_atoms <= conv_split_max_atoms();
   const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), 256 * 8);
 #define AIMNET_FWD(HQ, SP)                                                                                                  \
   hipLaunchKernelGGL((conv_fwd_kernel<HQ, SP>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a, agh_q, \
@@ -723,7 +689,7 @@ int launch_conv_bwd(hipStream_t s, int nq, bool need_abar, bool stress, const fl
                     const float* q, const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
                     int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
                     const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order) {
-  const bool split = n_atoms <= SPLIT_MAX_ATOMS;
+  const bool split = n_atoms <= conv_split_max_atoms();
   const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), 256 * 8);
 #define AIMNET_BWD(HQ, NA, ST, SP)                                                                                        \
   hipLaunchKernelGGL((conv_bwd_kernel<HQ, NA, ST, SP>), dim3(grid), dim3(256), 0, s, a, row_of, q, Sbar, Sqbar, nb_idx, nb_cnt, \

@@ -1,0 +1,55 @@
+// conv_common.h - constants and helpers shared by the gather-contract kernels (conv.hip, conv_mfma.hip).
+#pragma once
+
+#include "common.h"
+#include "kernels.h"
+
+namespace aimnet {
+
+constexpr int A_ = 16, G_ = 16, H_ = 12;
+constexpr int NF = A_ * G_;         // 256
+constexpr int NV = A_ * H_;         // 192
+constexpr int APB = 4;              // atoms (waves) per block
+constexpr int CH = 64;              // neighbours staged in LDS per chunk (32 doubled the resident waves: no gain)
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr int SPLIT_MAX_ATOMS = 1024;  // up to here a block per atom (4 waves share its neighbour row) still fits one wave of blocks
+
+// 2-wide float vectors: LLVM lowers their arithmetic to v_pk_{mul,add,fma}_f32 (2 FMAs per issue slot)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) {
+  f2 r;
+  r.x = a;
+  r.y = b;
+  return r;
+}
+
+// Persistent-loop atom assignment.  Hardware places block b on XCD b % 8 (observed; speed only): give
+// each XCD one CONTIGUOUS range of atoms, processed in order, so that when the input is spatially
+// ordered (crystals, MD frames) the neighbour rows an XCD gathers were mostly produced / recently
+// touched by the same XCD and hit its private 4 MiB L2 instead of the Infinity Cache.
+struct AtomLoop {
+  int first, last, step;  // atoms [first, last) in steps of `step`
+};
+__device__ __forceinline__ AtomLoop atom_loop(int n_atoms, int apb) {
+  const int nb = gridDim.x, b = blockIdx.x;
+  if (nb < 8) return AtomLoop{b * apb, n_atoms, nb * apb};
+  const int xcd = b & 7, slot = b >> 3;
+  const int per = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0);          // blocks resident on this XCD: slot = 0..per-1
+  const int nblk = (n_atoms + apb - 1) / apb;                    // atom blocks in total
+  const int chunk = (nblk + 7) >> 3;                             // atom blocks per XCD
+  const int lo = xcd * chunk, hi = min(nblk, lo + chunk);
+  return AtomLoop{(lo + slot) * apb, hi * apb < n_atoms ? hi * apb : n_atoms, per * apb};
+}
+
+// radial basis value (and optionally d/dd) for one (pair, shift)
+__device__ __forceinline__ float basis_fc(const BasisParams& bp, float d, float& dfc) {
+  const float dc = fminf(fmaxf(d, 1e-6f), bp.rc);
+  const float w = PI_F / bp.rc;
+  float sn, cs;
+  sincosf(dc * w, &sn, &cs);
+  dfc = (d > 1e-6f && d < bp.rc) ? -0.5f * w * sn : 0.0f;
+  return 0.5f * (cs + 1.0f);
+}
+
+
+}  // namespace aimnet

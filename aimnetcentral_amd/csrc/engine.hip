@@ -47,7 +47,7 @@ struct aimnet_engine {
   int nq = 1;  // charge channels (arch.n_charge_channels, 0 -> 1)
   int device;
   std::vector<void*> allocs;
-  float *afv, *agh_a, *agh_q;
+  float *afv, *afv_t, *agh_a, *agh_q;  // afv_t: the embedding rows in the operand layout of the MFMA conv kernels
   double* sae;
   // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row
@@ -63,6 +63,11 @@ struct aimnet_engine {
   // are still in the Infinity Cache never costs HBM write bandwidth
   bool keep_intermediates = false;
   bool p0_moments = true;  // AIMNET_P0_MOMENTS=0 keeps the generic conv_bwd for pass 0 (A/B and parity runs)
+  // AIMNET_CONV_MFMA / set_option("conv_mfma"): bit 0 = conv_fwd, bit 1 = conv_bwd (+ unconcat T layout) on the 4x4x1 MFMA
+  // kernels of conv_mfma.hip for systems above the split threshold; 0 (default) = the packed-FMA VALU kernels of conv.hip.
+  // Measured on config 3 (profiles/r2_conv_mfma.md): forward 81 us either way, backward 293 vs 226 us - neither form is
+  // arithmetic-bound, so the matrix pipe buys nothing here and the VALU kernels stay the default.
+  int conv_mfma = 0;
   std::vector<Layer> mlp[AIMNET_MAX_PASS];
   std::vector<Layer> head;
   float* head_w_last;  // [k] last head layer as a vector
@@ -154,6 +159,7 @@ struct Workspace {
   int *lr_idx, *lr_shift, *lr_cnt;
   float4* pg;
   float* a[AIMNET_MAX_PASS];       // features entering pass p
+  float* at[AIMNET_MAX_PASS];      // the same in the MFMA operand layout (conv_mfma.hip), NULL when those kernels are off
   float* q[AIMNET_MAX_PASS];       // charges after pass p (p < n_pass-1)
   float* x[AIMNET_MAX_PASS];       // MLP input rows
   float* V[AIMNET_MAX_PASS];
@@ -201,6 +207,7 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   Carver c{base, 0, views};
   const int np = e->arch.n_pass;
   const bool grad = (opt->flags & (AIMNET_FORCES | AIMNET_STRESS)) != 0;
+  const bool mfma_rows = e->conv_mfma != 0 && N > conv_split_max_atoms();
   const size_t n = (size_t)N;
   char* nl_base = c.take<char>(nlist_scratch_bytes(N, n_mol));
   if (base) nlist_carve(W.nl, nl_base, N, n_mol);
@@ -243,6 +250,7 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   for (int p = 0; p < np; ++p) {
     snprintf(name, sizeof name, "a%d", p);
     W.a[p] = p == 0 ? nullptr : c.take<float>(n * 256, name, 256);  // pass 0 reads the embedding table itself
+    W.at[p] = (p == 0 || !mfma_rows) ? nullptr : c.take<float>(n * 256);
     snprintf(name, sizeof name, "q%d", p);
     W.q[p] = c.take<float>(n * e->nq, name, 1);
     const int ldx = e->mlp[p][0].k_in;
@@ -323,6 +331,13 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
   const int AG = 256;
   if ((rc = dev_upload(e, w->afv, (size_t)64 * AG, &e->afv))) goto fail;
   {
+    std::vector<float> t((size_t)64 * AG);
+    for (int z = 0; z < 64; ++z)
+      for (int aa = 0; aa < 16; ++aa)
+        for (int g = 0; g < 16; ++g) t[(size_t)z * AG + g * 16 + aa] = w->afv[(size_t)z * AG + aa * 16 + g];
+    if ((rc = dev_upload(e, t.data(), t.size(), &e->afv_t))) goto fail;
+  }
+  {
     int soz[64], zos[64];
     int ns = 0, bad_row = -1;
     for (int z = 0; z < 64; ++z) {
@@ -344,6 +359,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->spatial_order = atoi(env) != 0;
     env = getenv("AIMNET_KEEP_INTERMEDIATES");
     if (env) e->keep_intermediates = atoi(env) != 0;
+    env = getenv("AIMNET_CONV_MFMA");
+    if (env) e->conv_mfma = atoi(env);
   }
   if ((rc = dev_upload(e, w->agh_a, (size_t)16 * 16 * 12, &e->agh_a))) goto fail;
   if ((rc = dev_upload(e, w->agh_q, (size_t)e->nq * 16 * 12, &e->agh_q))) goto fail;
@@ -436,6 +453,20 @@ int aimnet_engine_profile_read(aimnet_engine* e, double* ms, int n_families, int
     e->prof_used = 0;
     e->prof_last = -2;
     e->prof_evals = e->prof_sampled = 0;
+  }
+  return AIMNET_OK;
+}
+
+int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
+  if (!e || !name) return AIMNET_E_INVALID;
+  const std::string n(name);
+  if (n == "conv_mfma") e->conv_mfma = value & 3;
+  else if (n == "split_max") conv_set_split_max(value);  // process-wide
+  else if (n == "p0_moments") e->p0_moments = value != 0;
+  else if (n == "spatial_order") e->spatial_order = value != 0;
+  else {
+    set_last_error("set_option: unknown option '%s'", name);
+    return AIMNET_E_INVALID;
   }
   return AIMNET_OK;
 }
@@ -571,7 +602,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   if (e->prof_on) e->prof_sampled++;
   RC(prof_mark(e, s, FAM_NLIST));
   AIMNET_HIP_CHECK(hipMemsetAsync(out->status, 0, 8 * sizeof(int), s));
-  RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start));
+  RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start, in->numbers, out->status + 6));
   RC(launch_wrap(s, in->coord, in->mol_idx, N, n_mol, in->cell, n_cell, in->pbc, W.nl));
   // large non-periodic molecules (>= 1500 atoms on average) get a bounding-box cell list instead of the O(n^2) scan
   if (!pbc && (long)N >= 1500L * n_mol) RC(launch_bbox(s, n_mol, W.nl));
@@ -605,13 +636,20 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const int* order = (W.nl.binned && e->spatial_order) ? W.nl.sorted : nullptr;
   // a^0 = afv[Z] is never materialised: pass 0 gathers the embedding rows directly (conv_fwd / conv_bwd row_of, update_a)
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
+  const bool mfma_fwd = (e->conv_mfma & 1) && N > conv_split_max_atoms();
+  const bool mfma_bwd = (e->conv_mfma & 2) && N > conv_split_max_atoms();
   if (p0m || d3) RC(launch_species(s, in->numbers, e->slot_of_z, N, W.aslot, W.present_part));
   for (int p = 0; p < np; ++p) {
     const std::vector<Layer>& Ls = e->mlp[p];
     const int nl = (int)Ls.size();
     RC(prof_mark(e, s, FAM_CONV_FWD));
-    RC(launch_conv_fwd(s, p > 0 ? nq : 0, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr, p > 0 ? W.q[p - 1] : nullptr,
-                       W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q, e->bp, W.x[p], Ls[0].k_in, W.V[p], W.Vq[p], N, order));
+    if (mfma_fwd)
+      RC(launch_conv_fwd_mfma(s, p > 0 ? nq : 0, p == 0 ? e->afv : W.a[p], p == 0 ? e->afv_t : W.at[p], p == 0 ? in->numbers : nullptr,
+                              p > 0 ? W.q[p - 1] : nullptr, W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q, e->bp, W.x[p],
+                              Ls[0].k_in, W.V[p], W.Vq[p], N, order));
+    else
+      RC(launch_conv_fwd(s, p > 0 ? nq : 0, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr, p > 0 ? W.q[p - 1] : nullptr,
+                         W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q, e->bp, W.x[p], Ls[0].k_in, W.V[p], W.Vq[p], N, order));
     const float* hin = W.x[p];
     int ld_in = Ls[0].k_in;
     RC(prof_mark(e, s, FAM_GEMM));
@@ -627,7 +665,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       RC(launch_nse_fwd(s, W.H[p][nl - 1], Ls[nl - 1].k_out, nq, p > 0 ? W.q[p - 1] : nullptr, W.nl.mol_start, in->charge,
                         n_mol, N, W.S, (float*)W.part, W.q[p], W.Fm[p], W.Dm[p]));
       RC(launch_update_a(s, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr, W.H[p][nl - 1], Ls[nl - 1].k_out, nq, N,
-                         W.a[p + 1]));
+                         W.a[p + 1], W.at[p + 1]));
     }
   }
   const float* q_fin = W.q[np - 2];
@@ -737,9 +775,11 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
                             order));
       break;
     }
-    RC(launch_unconcat(s, p > 0 ? nq : 0, zcur, ld, W.V[p], W.Vq[p], e->agh_a, e->agh_q, W.Sbar, W.Sqbar, N));
+    RC((mfma_bwd ? launch_unconcat_t : launch_unconcat)(s, p > 0 ? nq : 0, zcur, ld, W.V[p], W.Vq[p], e->agh_a, e->agh_q, W.Sbar,
+                                                        W.Sqbar, N));
     RC(prof_mark(e, s, FAM_CONV_BWD));
-    RC(launch_conv_bwd(s, p > 0 ? nq : 0, p > 0, want_s, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr,
+    RC((mfma_bwd ? launch_conv_bwd_mfma : launch_conv_bwd)(s, p > 0 ? nq : 0, p > 0, want_s,
+                       mfma_bwd ? (p == 0 ? e->afv_t : W.at[p]) : (p == 0 ? e->afv : W.a[p]), p == 0 ? in->numbers : nullptr,
                        p > 0 ? W.q[p - 1] : nullptr, W.Sbar, W.Sqbar, W.nb_idx, W.nb_cnt,
                        W.pg, cap, e->bp, zcur, ld, (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, W.fgrad,
                        W.virial_atom, N, order));
@@ -828,6 +868,11 @@ int aimnet_debug_gemm(int cfg, int epi, const float* A, int lda, const float* Bt
     attr = true;
   }
   return launch_gemm_nt_cfg((hipStream_t)hip_stream, cfg, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+}
+
+int aimnet_debug_mfma4_probe(float* out, void* hip_stream) {
+  if (!out) return AIMNET_E_INVALID;
+  return launch_mfma4_probe((hipStream_t)hip_stream, out);
 }
 
 int aimnet_conv_sv_2d_sp_fwd(const float* a, const int32_t* idx, const float* g, float* out, int32_t B, int32_t A,

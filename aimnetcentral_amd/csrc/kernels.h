@@ -36,7 +36,8 @@ struct NlistBuffers {      // all device pointers, carved from the caller's work
 size_t nlist_scratch_bytes(int n_atoms, int n_mol);
 size_t nlist_xw_offset(int n_mol);  // byte offset of NlistBuffers::xw inside the scratch
 void nlist_carve(NlistBuffers& b, char* base, int n_atoms, int n_mol);
-int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start);
+int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start, const int* numbers = nullptr,
+                     int* bad = nullptr);  // bad: input sanity flags (bit 0 atomic number outside [0,63], bit 1 mol_idx outside [0,n_mol))
 // wrap coordinates (periodic) or copy them (non-periodic) into b.xw
 int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
                 int n_cell, const int pbc[3], NlistBuffers& b);
@@ -80,6 +81,21 @@ int launch_unconcat_p0(hipStream_t s, const float* xbar, int ldx, const float* V
 int launch_conv_bwd_p0(hipStream_t s, bool stress, const float* T, int nslots, const int* aslot, const int* nb_idx,
                        const int* nb_cnt, const float4* pg, int cap, BasisParams bp, float* fgrad, float* virial_atom,
                        int n_atoms, const int* order);
+// ---- conv_mfma.hip: the same three steps with the pair contractions on v_mfma_f32_4x4x1_16B_f32 (one wave per centre atom,
+// systems above SPLIT_MAX_ATOMS).  SbarT is the Sbar buffer in the lane-(g,c) plane layout that conv_bwd_mfma reads.
+// a_t: the feature table transposed to [g][a] (the MFMA operand layout), a: the natural [a][g] one
+int launch_conv_fwd_mfma(hipStream_t s, int nq, const float* a, const float* a_t, const int* row_of, const float* q, const int* nb_idx,
+                         const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
+                         float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order);
+int launch_unconcat_t(hipStream_t s, int nq, const float* xbar, int ldx, const float* Vsave, const float* Vqsave,
+                      const float* agh_a, const float* agh_q, float* SbarT, float* Sqbar, int n_atoms);
+int launch_conv_bwd_mfma(hipStream_t s, int nq, bool need_abar, bool stress, const float* a_t, const int* row_of, const float* q,
+                         const float* SbarT, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg, int cap,
+                         BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out, const float* qbar_in,
+                         float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order);
+int launch_mfma4_probe(hipStream_t s, float* out);  // lane-layout probe of the 4x4x1 16-block MFMA (tests)
+int conv_split_max_atoms();
+void conv_set_split_max(int n);  // n < 0 restores the default
 // stand-alone reference-op forms (conv_sv_2d_sp_wp.py:90-164)
 int launch_conv_sv_fwd(hipStream_t s, const float* a, const int* idx, const float* g, float* out, int B, int A, int G,
                        int M);
@@ -95,7 +111,8 @@ int launch_conv_sv_bwd_bwd(hipStream_t s, const float* grad_out, const float* gr
 int launch_nse_fwd(hipStream_t s, const float* y, int ldy, int nq, const float* q_prev, const int* mol_start,
                    const float* charge, int n_mol, int n_atoms, int S, float* part, float* q_new, float* Fm, float* Dm);
 int launch_charge_sum(hipStream_t s, const float* q2, int n_atoms, float* q_tot, float* q_spin);
-int launch_update_a(hipStream_t s, const float* a, const int* row_of, const float* y, int ldy, int nq, int n_atoms, float* a_new);
+int launch_update_a(hipStream_t s, const float* a, const int* row_of, const float* y, int ldy, int nq, int n_atoms, float* a_new,
+                    float* a_t = nullptr);  // a_t: optional copy in the operand layout of the MFMA conv kernels
 // d / zbar (may be NULL): also writes the backward seed zbar = w * d (d = GELU' of the layer below, ldh wide)
 int launch_head_last(hipStream_t s, const float* h, int ldh, const float* w, const float* b, int k, int n_atoms,
                      float* e_atom, const float* d, float* zbar);

@@ -162,20 +162,28 @@ int launch_charge_sum(hipStream_t s, const float* q2, int n_atoms, float* q_tot,
 
 // row_of (may be NULL): feature row of atom i inside `a` - pass 0 adds delta_a to the embedding row afv[Z_i] directly, so
 // the initial features a^0 = afv[Z] (aimnet2.py:145-148) are never materialised
+// a_t (may be NULL): second copy of the new feature row in the operand layout of the MFMA conv kernels (conv_mfma.hip):
+// the transpose [g][a], feature (a, g) at float g * 16 + a
 __global__ void update_a_kernel(const float* __restrict__ a, const int* __restrict__ row_of, const float* __restrict__ y, int ldy,
-                                int col0, int n_atoms, float* __restrict__ a_new) {
+                                int col0, int n_atoms, float* __restrict__ a_new, float* __restrict__ a_t) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)n_atoms * 256) return;
   const size_t i = e >> 8;
   const int k = (int)(e & 255);
   const size_t ri = row_of ? (size_t)min(63, max(0, row_of[i])) : i;
-  a_new[e] = a[ri * 256 + k] + y[i * ldy + col0 + k];
+  const float v = a[ri * 256 + k] + y[i * ldy + col0 + k];
+  a_new[e] = v;
+  if (a_t) {
+    const int aa = k >> 4, g = k & 15;
+    a_t[i * 256 + g * 16 + aa] = v;
+  }
 }
 
-int launch_update_a(hipStream_t s, const float* a, const int* row_of, const float* y, int ldy, int nq, int n_atoms, float* a_new) {
+int launch_update_a(hipStream_t s, const float* a, const int* row_of, const float* y, int ldy, int nq, int n_atoms, float* a_new,
+                    float* a_t) {
   const size_t n = (size_t)n_atoms * 256;
   hipLaunchKernelGGL(update_a_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, row_of, y, ldy, 2 * nq, n_atoms,
-                     a_new);
+                     a_new, a_t);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

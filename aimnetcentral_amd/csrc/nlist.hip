@@ -54,18 +54,33 @@ void nlist_carve(NlistBuffers& b, char* p, int n_atoms, int n_mol) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void mol_start_kernel(const int* __restrict__ mol_idx, int n_atoms, int n_mol, int* __restrict__ mol_start) {
+// Also the input sanity pass (numbers / bad may be NULL): the engine clamps atomic numbers to the 64 embedding rows and molecule
+// indices to [0, n_mol) for memory safety; *bad gets bit 0 when an atomic number lies outside [0, 63] (the reference's
+// nn.Embedding(64) raises an index error there, core.py:49) and bit 1 when a molecule index lies outside [0, n_mol)
+// (the reference fails in mol_sum / index_add, nbops.py:309-377).  HipEngine.eval turns either into a ValueError.
+__global__ void mol_start_kernel(const int* __restrict__ mol_idx, const int* __restrict__ numbers, int n_atoms, int n_mol,
+                                 int* __restrict__ mol_start, int* __restrict__ bad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_atoms) return;
-  const int prev = (i == 0) ? -1 : mol_idx[i - 1];
-  const int cur = mol_idx[i];
+  const int prev = (i == 0) ? -1 : min(max(mol_idx[i - 1], -1), n_mol - 1);
+  const int raw = mol_idx[i];
+  const int cur = min(max(raw, 0), n_mol - 1);
+  if (bad) {
+    int f = (raw < 0 || raw >= n_mol) ? 2 : 0;
+    if (numbers) {
+      const int z = numbers[i];
+      if (z < 0 || z > 63) f |= 1;
+    }
+    if (f) atomicOr(bad, f);
+  }
   for (int m = prev + 1; m <= cur && m <= n_mol; ++m) mol_start[m] = i;
   if (i == n_atoms - 1)
     for (int m = cur + 1; m <= n_mol; ++m) mol_start[m] = n_atoms;
 }
 
-int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start) {
-  hipLaunchKernelGGL(mol_start_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, mol_idx, n_atoms, n_mol, mol_start);
+int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start, const int* numbers, int* bad) {
+  hipLaunchKernelGGL(mol_start_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, mol_idx, numbers, n_atoms, n_mol, mol_start,
+                     bad);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

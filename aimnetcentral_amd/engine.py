@@ -98,6 +98,7 @@ class HipEngine:
         self._h = handle
         self._keep.clear()  # weights are on the device now
         self._ws = None
+        self._ws_stream = None  # stream of the last launch (the workspace is tied to it)
         # AdaptiveNeighborList policy (neighbors.py:49-63): density 0.2 -> 112 @ 5 A, 2832 @ 15 A
         self.max_nb = _round16(int(0.2 * 4.0 / 3.0 * math.pi * spec.rc**3))
         self._max_nb_lr: dict[float, int] = {}
@@ -114,6 +115,12 @@ class HipEngine:
             self._h = None
 
     # ------------------------------------------------------------------------------------------
+    def set_option(self, name: str, value: int) -> None:
+        """Engine switch for A/B and parity runs (include/aimnet_hip.h, aimnet_engine_set_option): "conv_mfma", "split_max"
+        (process-wide), "p0_moments", "spatial_order"."""
+        _lib.check(self.lib.aimnet_engine_set_option(self._h, name.encode(), int(value)), "aimnet_engine_set_option")
+        self._ws = None  # the workspace layout depends on the switches
+
     def set_dftd3_tables(self, tables: dict[str, Any]) -> None:
         """Upload the DFT-D3 reference tables (what DFTD3.__init__ reads from aimnet/dftd3_data.pt, lr.py:1405-1423):
         `c6ab`, `cn_ref` [Z,Z,5,5] and `rcov`, `r4r2` [Z] (see loader.load_dftd3_tables)."""
@@ -226,8 +233,16 @@ class HipEngine:
                 opt.max_nb_d3 = self._lr_capacity(d3_rc)
             need = int(self.lib.aimnet_engine_workspace_bytes(self._h, n, n_mol, n_cell, C.byref(opt)))
             if self._ws is None or self._ws.numel() < need:
+                if self._ws is not None and self._ws_stream is not None:
+                    # earlier (possibly still running, sync=False) evaluations used the old workspace on that stream: keep the
+                    # caching allocator from handing its memory to another stream before they finish
+                    self._ws.record_stream(self._ws_stream)
                 self._ws = None
                 self._ws = torch.empty(int(need * 1.1) + 4096, dtype=torch.uint8, device=dev)
+            cur_stream = torch.cuda.current_stream(dev)
+            if self._ws_stream is not None and self._ws_stream != cur_stream:
+                cur_stream.wait_stream(self._ws_stream)  # one workspace: evaluations on different streams are serialised
+            self._ws_stream = cur_stream
             inp = _lib.Inputs()
             inp.n_atoms, inp.n_mol = n, n_mol
             inp.coord, inp.numbers, inp.mol_idx, inp.charge = coord.data_ptr(), numbers.data_ptr(), mol_idx.data_ptr(), charge.data_ptr()
@@ -254,6 +269,13 @@ class HipEngine:
             else:
                 st = status.cpu().numpy()
             self.last_status = st
+            if st[6]:  # input sanity flags raised by the engine (it clamps for memory safety, the results are meaningless)
+                what = []
+                if st[6] & 1:
+                    what.append("atomic numbers outside [0, 63] (the embedding has 64 rows, core.py:49)")
+                if st[6] & 2:
+                    what.append(f"mol_idx entries outside [0, {n_mol}) (n_mol is taken from the charge array)")
+                raise ValueError("HipEngine.eval: invalid input: " + " and ".join(what))
             retry = False
             if st[2]:
                 self.max_nb = _round16(int(max(self.max_nb * 1.5, st[0])))

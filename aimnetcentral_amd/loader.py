@@ -11,8 +11,9 @@ needs_dispersion, coulomb_mode, coulomb_sr_rc, coulomb_sr_envelope, d3_params, h
 implemented_species, ...} exactly as docs/model_format.md:204-222 describes.  Rejected with the
 reference's error classes: non-dict payloads, empty/invalid YAML, alias cycles, import paths
 outside the allow-list, the keys fn/trainer/evaluator/ptfile, malformed metadata.  Classes the
-native engine does not implement (D3TS, DispParam, 2-channel NSE) raise NotImplementedError -
-the native loader can only honour what it implements.
+native engine does not implement (D3TS, DispParam) raise NotImplementedError - the native loader
+can only honour what it implements.  Open-shell NSE models (num_charge_channels = 2,
+aimnet2.py:21-28) load into a 2-channel ModelSpec and run on the engine.
 """
 from __future__ import annotations
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AIMNET_ABI_VERSION 3
+#define AIMNET_ABI_VERSION 4
 
 #define AIMNET_OK 0
 #define AIMNET_E_INVALID (-1)   /* bad argument / unsupported architecture */
@@ -124,7 +124,9 @@ typedef struct aimnet_outputs {
   float* stress;    /* [max(n_cell,1), 3, 3] or NULL */
   int32_t* status;  /* [8]: 0 max neighbours found (rc list), 1 same for the LR list,
                               2 overflow flag rc list, 3 overflow flag LR list,
-                              4 max neighbours found (D3 list), 5 overflow flag D3 list, 6.. reserved */
+                              4 max neighbours found (D3 list), 5 overflow flag D3 list,
+                              6 input sanity flags: bit 0 an atomic number outside [0, 63], bit 1 a mol_idx outside
+                                [0, n_mol) (both are clamped for memory safety; the results are then meaningless), 7 reserved */
   float* spin_charges; /* [n_atoms] alpha - beta of an NSE model (aimnet2.py:103), or NULL; must be NULL for 1-channel models */
 } aimnet_outputs;
 
@@ -178,6 +180,18 @@ int aimnet_engine_profile_read(aimnet_engine* e, double* ms, int n_families, int
  * epi (0 none, 1 +bias, 2 gelu(+bias) with D = gelu', 3 C = acc * D); K % 32 == 0; cfg 0 = automatic tile. */
 int aimnet_debug_gemm(int cfg, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
                       const float* bias, float* C, float* D, int ldc, void* hip_stream);
+
+/* Engine switches for A/B and parity runs (all have an AIMNET_* environment twin read at create time):
+ *   "conv_mfma"     bit 0: conv forward, bit 1: conv backward on the v_mfma_f32_4x4x1_16B_f32 kernels (csrc/conv_mfma.hip)
+ *                   instead of the packed-FMA VALU kernels (default 0; systems above the split threshold only)
+ *   "split_max"     atoms up to which the 4-waves-per-atom "split" conv kernels are used (default 1024; PROCESS-wide; < 0 = default)
+ *   "p0_moments"    0: generic conv backward for pass 0 instead of the species-moment form
+ *   "spatial_order" 0: conv kernels walk the atoms in input order instead of cell-list bin order */
+int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value);
+
+/* Test hook: lane layout of v_mfma_f32_4x4x1_16B_f32 as the conv kernels assume it.  out: f32[64][4][64] (device),
+ * out[lb][r][l] = VGPR r, lane l of D = A x B with A[l] = l + 1 and B = one-hot(lb), C = 0. */
+int aimnet_debug_mfma4_probe(float* out, void* hip_stream);
 
 /* Stand-alone neighbour list with the nvalchemiops contract.  nbmat [n_atoms, max_nb] int32 is
  * filled with `fill_value` beyond each row's count; shifts [n_atoms, max_nb, 3] int32 may be NULL

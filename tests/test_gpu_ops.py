@@ -271,3 +271,23 @@ def test_gelu_epilogue_accuracy(cfg):
     ed = (D[:, 5].cpu().double() - d).abs()
     assert eh.max().item() <= 2e-7, (eh.max().item(), z[eh.argmax()].item())
     assert ed.max().item() <= 4e-7, (ed.max().item(), z[ed.argmax()].item())
+
+
+def test_mfma_4x4x1_16b_lane_layout():
+    """The conv kernels of csrc/conv_mfma.hip assume v_mfma_f32_4x4x1_16B_f32 computes, for the 16 blocks b = lane >> 2,
+    D_b[r][col] = A_b[r] * B_b[col] with A at lane 4b + r, B at lane 4b + col and D in VGPR r, lane 4b + col."""
+    import ctypes as C
+
+    from aimnetcentral_amd import _lib
+
+    lib = _lib.load()
+    out = torch.zeros(64, 4, 64, device="cuda:0")
+    _lib.check(lib.aimnet_debug_mfma4_probe(C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "probe")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    exp = np.zeros((64, 4, 64), dtype=np.float32)
+    for lb in range(64):  # B = one-hot(lb): block lb >> 2, col lb & 3;  A[l] = l + 1
+        b, col = lb >> 2, lb & 3
+        for r in range(4):
+            exp[lb, r, 4 * b + col] = 4 * b + r + 1
+    assert np.array_equal(got, exp)

@@ -433,3 +433,63 @@ def test_torchsim_adapter_nse_spin(nse_calc):
     out = model(st)
     assert nse_calc.engine.calls[-1]["charge"].tolist() == [[1.0, 0.0], [1.0, -1.0]]
     assert out["spin_charges"].shape == (len(z),)
+
+
+def test_species_cache_is_not_fooled_by_a_recycled_tensor_id(calc):
+    """calculator.py:806-823 of the reference: the validation cache holds a weak reference to the validated tensor, so a new
+    tensor that happens to be allocated where a freed, already-validated one lived (same id(), _version 0) is validated again."""
+    good = torch.tensor([8, 1, 1], dtype=torch.int64)
+    calc(dict(WATER, numbers=good))
+    key = calc._species_cache[0]
+    assert calc._species_cache[1]() is good
+    calc(dict(WATER, numbers=good))  # same live tensor: cache hit, nothing changes
+    assert calc._species_cache[0] == key
+    # emulate the id recycling: forge the cache entry of a DIFFERENT tensor with the new tensor's id / version
+    bad = torch.tensor([8, 1, 2], dtype=torch.int64)
+    calc._species_cache = ((id(bad), bad._version, key[2]), calc._species_cache[1])  # weakref still points at `good`
+    with pytest.raises(ValueError, match=r"Atomic numbers \[2\]"):
+        calc(dict(WATER, numbers=bad))
+    del good
+    import gc
+
+    gc.collect()
+    for _ in range(50):  # the real thing: free / reallocate in a loop, every fresh tensor has to be validated
+        t = torch.tensor([8, 1, 2], dtype=torch.int64)
+        with pytest.raises(ValueError, match=r"Atomic numbers \[2\]"):
+            calc(dict(WATER, numbers=t))
+        del t
+        calc(dict(WATER, numbers=torch.tensor([8, 1, 1], dtype=torch.int64)))
+
+
+def test_molecule_count_is_checked_against_the_charges(calc):
+    """n_mol comes from `charge`: a batch with fewer charges than molecules must fail loudly (the reference fails in
+    mol_sum / index_add), not index the per-molecule buffers out of bounds."""
+    c3 = torch.randn(2, 3, 3)
+    z3 = torch.tensor([[8, 1, 1], [8, 1, 1]])
+    with pytest.raises(ValueError, match="one entry per molecule"):
+        calc(dict(coord=c3, numbers=z3, charge=0.0))
+    calc(dict(coord=c3, numbers=z3, charge=[0.0, 0.0]))
+    flat = dict(coord=torch.randn(4, 3), numbers=[8, 1, 1, 1], mol_idx=[0, 0, 1, 2], charge=[0.0, 0.0])
+    with pytest.raises(ValueError, match=r"mol_idx must lie in \[0, 2\)"):
+        calc(flat)
+    with pytest.raises(ValueError, match=r"mol_idx must lie in \[0, 2\)"):
+        calc(dict(flat, mol_idx=[-1, 0, 0, 1]))
+    calc(dict(flat, mol_idx=[0, 0, 1, 1]))
+
+
+def test_external_coulomb_subtract_sr_for_models_without_embedded_srcoulomb(monkeypatch):
+    """calculator.py:218-230 of the reference: needs_coulomb with coulomb_mode != 'sr_embedded' -> LRCoulomb(subtract_sr=True);
+    the engine then carries the SR subtraction (same sum as the embedded SRCoulomb) with the metadata's rc / envelope."""
+    import dataclasses
+
+    monkeypatch.setattr(calc_mod, "HipEngine", FakeEngine)
+    base = loader.synthetic_spec(0)
+    md = dict(base.metadata, coulomb_mode="none", needs_coulomb=True, coulomb_sr_rc=4.2, coulomb_sr_envelope="cosine")
+    spec = dataclasses.replace(base, sr_coulomb=False, metadata=md)
+    c = calc_mod.AIMNet2Calculator(spec, device="cuda")
+    assert c.external_coulomb.subtract_sr is True
+    assert c.engine.spec.sr_coulomb and c.engine.spec.sr_rc == pytest.approx(4.2) and c.engine.spec.sr_envelope == "cosine"
+    c2 = calc_mod.AIMNet2Calculator(base, device="cuda")
+    assert c2.external_coulomb.subtract_sr is False
+    with pytest.raises(NotImplementedError, match="subtracted twice"):
+        calc_mod.AIMNet2Calculator(dataclasses.replace(base, metadata=md), device="cuda")

@@ -445,10 +445,10 @@ def load_dftd3_tables(source: Any = None) -> dict[str, np.ndarray]:
     return out
 
 
-def synthetic_spec(seed: int = 0, num_charge_channels: int = 1) -> ModelSpec:
+def synthetic_spec(seed: int = 0, num_charge_channels: int = 1, rxn: bool = False) -> ModelSpec:
     """ModelSpec of the deterministic synthetic aimnet2 artifact (aimnetcentral_amd/synth.py); num_charge_channels = 2
-    gives the open-shell NSE shape."""
+    gives the open-shell NSE shape, rxn = True the `aimnet2_rxn` YAML (Dipole / Quadrupole output modules)."""
     from . import synth
 
-    return spec_from_artifact(synth.synthetic_artifact(seed, num_charge_channels=num_charge_channels),
+    return spec_from_artifact(synth.synthetic_artifact(seed, num_charge_channels=num_charge_channels, rxn=rxn),
                               source=f"<synthetic seed {seed}>")

@@ -86,8 +86,32 @@ def _mlp_sizes(n_in: int, hidden: list[int], n_out: int) -> list[tuple[int, int]
     return [(sizes[i + 1], sizes[i]) for i in range(len(sizes) - 1)]
 
 
-def core_yaml(num_charge_channels: int = 1) -> str:
+_RXN_EXTRA_OUTPUTS = """    dipole:
+      class: aimnet.modules.Dipole
+      kwargs:
+        key_in: charges
+        key_out: dipole
+    quadrupole:
+      class: aimnet.modules.Quadrupole
+      kwargs:
+        key_in: charges
+        key_out: quadrupole
+"""
+
+
+def rxn_yaml() -> str:
+    """The core YAML of the `aimnet2_rxn` architecture (aimnet/models/aimnet2_rxn.yaml after strip_lr_modules_from_yaml,
+    utils.py:379): the aimnet2 network with an explicit `num_charge_channels: 1` and the Dipole / Quadrupole output modules
+    in front of the SRCoulomb block (BASELINE config 4 runs on it)."""
+    y = AIMNET2_CORE_YAML.replace("kwargs:\n  nfeature: 16\n", "kwargs:\n  nfeature: 16\n  num_charge_channels: 1\n", 1)
+    assert "    srcoulomb:\n" in y
+    return y.replace("    srcoulomb:\n", _RXN_EXTRA_OUTPUTS + "    srcoulomb:\n", 1)
+
+
+def core_yaml(num_charge_channels: int = 1, rxn: bool = False) -> str:
     """AIMNET2_CORE_YAML, with `num_charge_channels: 2` for the open-shell NSE family (aimnet2.py:21,94-106)."""
+    if rxn:
+        return rxn_yaml()
     if num_charge_channels == 1:
         return AIMNET2_CORE_YAML
     return AIMNET2_CORE_YAML.replace("kwargs:\n  nfeature: 16\n", f"kwargs:\n  num_charge_channels: {int(num_charge_channels)}\n  nfeature: 16\n", 1)
@@ -165,15 +189,21 @@ def state_dict_digest(sd: dict[str, Any]) -> str:
     return h.hexdigest()
 
 
-def synthetic_artifact(seed: int = 0, species: list[int] | None = None, num_charge_channels: int = 1) -> dict[str, Any]:
+def synthetic_artifact(seed: int = 0, species: list[int] | None = None, num_charge_channels: int = 1,
+                       rxn: bool = False) -> dict[str, Any]:
     """A v2 artifact dict (torch tensors) as `torch.save` would hold it."""
     import torch
 
     species = list(AIMNET2_SPECIES if species is None else species)
     sd = {k: torch.from_numpy(np.array(v)) for k, v in synthetic_state_dict(seed, species, num_charge_channels).items()}
+    if rxn:
+        # Dipole / Quadrupole register a `mass` buffer (119 atomic masses, core.py:163) that the reference loader insists on;
+        # it is only read with center_coord=True, which the rxn YAML does not set - the synthetic artifact carries zeros
+        for name in ("dipole", "quadrupole"):
+            sd[f"outputs.{name}.mass"] = torch.zeros(119, dtype=torch.float32)
     return {
         "format_version": 2,
-        "model_yaml": core_yaml(num_charge_channels),
+        "model_yaml": core_yaml(num_charge_channels, rxn),
         "state_dict": sd,
         "cutoff": 5.0,
         "needs_coulomb": True,

@@ -110,6 +110,73 @@ def make_hvp40(path: str, meta_common: dict) -> None:
                         **meta_common)
 
 
+def make_rxn(meta_common: dict) -> None:
+    """G10: BASELINE config 4 on the `aimnet2_rxn` ARCHITECTURE: the reference's own aimnet2_rxn.yaml, stripped of its LR
+    modules the way the reference's exporter does (strip_lr_modules_from_yaml, models/utils.py:379), must be the YAML of
+    synth.rxn_yaml(); the artifact is loaded through the reference loader and driven through Hessian + HVP."""
+    import yaml
+
+    from aimnet.models.utils import strip_lr_modules_from_yaml
+
+    with open(os.path.join(_refshim.REFERENCE_ROOT, "aimnet", "models", "aimnet2_rxn.yaml")) as f:
+        ref_cfg = yaml.safe_load(f)
+    core_cfg = strip_lr_modules_from_yaml(ref_cfg, {})[0]  # (config, coulomb_mode, needs_dispersion, ...), utils.py:379-406
+    ours = yaml.safe_load(synth.rxn_yaml())
+    ko, kr = ours["kwargs"], core_cfg["kwargs"]
+    assert [list(h) for h in ko["hidden"]] == [list(h) for h in kr["hidden"]] and ko["aim_size"] == kr["aim_size"]
+    names = [k for k in kr["outputs"] if "coulomb" not in k and "dftd3" not in k and "d3" not in k]
+    assert names == [k for k in ko["outputs"] if k != "srcoulomb"], (names, list(ko["outputs"]))
+    art = synth.synthetic_artifact(SEED, rxn=True)
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "aimnet2_rxn_synth.pt")
+    torch.save(art, path)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        load_model(path)
+    coord, numbers = read_taxol()
+    coord, numbers = coord[:40].astype(np.float32), numbers[:40]
+    data = {"coord": coord, "numbers": numbers, "charge": 0.0}
+    calc = make_calc(path)
+    out = to_np(calc(data, forces=True, hessian=True))
+    g = torch.Generator().manual_seed(0)
+    v1 = torch.randn(40, 3, generator=g)
+    v4 = torch.randn(4, 40, 3, generator=g)
+    hv1 = calc.hessian_vector_product(data, v1).detach().numpy()
+    hv4 = calc.hessian_vector_product(data, v4).detach().numpy()
+    print("hvp40_rxn E=%.6f |H|max=%.3f" % (out["energy"][0], np.abs(out["hessian"]).max()))
+    np.savez_compressed(os.path.join(HERE, "hvp40_rxn.npz"), coord=coord, numbers=numbers, charge=np.float32(0.0),
+                        energy=out["energy"], forces=out["forces"], charges=out["charges"],
+                        hessian=out["hessian"].astype(np.float32), v1=v1.numpy(), hv1=hv1, v4=v4.numpy(), hv4=hv4,
+                        **meta_common)
+
+
+def make_cold(path: str, meta_common: dict) -> None:
+    """G11: a "cold" fixture - a 24-atom H/C/N/O fragment relaxed on the synthetic model's own surface (fp64 oracle, L-BFGS)
+    until max|F| < 0.5 eV/A, then evaluated by the unmodified reference.  The other fixtures are hot (|F| up to 80 eV/A on the
+    synthetic weights), which puts the fp32 energy noise at the reference's 1e-5 eV gate; here the un-widened gate must hold."""
+    from oracle import aimnet2_oracle as O
+
+    coord, numbers = read_taxol()
+    coord, numbers = coord[:24].astype(np.float64), numbers[:24]
+    om = O.OracleModel(synth.synthetic_state_dict(SEED), torch.float64)
+    x = coord.copy()
+    step = 0.02
+    for it in range(4000):  # steepest descent with a capped step on the fp64 oracle: robust on an arbitrary surface
+        r = O.evaluate(om, x.astype(np.float64), numbers, np.zeros(1), coulomb="simple")
+        f = r["forces"].astype(np.float64)
+        fmax = np.abs(f).max()
+        if fmax < 0.3:
+            break
+        x = x + f * min(step / fmax, 2e-3)
+    print("cold: %d steps, max|F| = %.3f eV/A" % (it, fmax))
+    data = {"coord": x.astype(np.float32), "numbers": numbers, "charge": 0.0}
+    calc = make_calc(path)
+    out = to_np(calc(data, forces=True))
+    print("cold reference: E=%.6f max|F|=%.3f" % (out["energy"][0], np.abs(out["forces"]).max()))
+    np.savez_compressed(os.path.join(HERE, "cold24.npz"), coord=data["coord"], numbers=numbers, charge=np.float32(0.0),
+                        energy=out["energy"], forces=out["forces"], charges=out["charges"], **meta_common)
+
+
 D3_PARAMS = {"s8": 0.3908, "a1": 0.566, "a2": 3.128, "s6": 1.0}  # wB97M-D3(BJ), the shipped aimnet2 family (docs/models)
 D3_ZMAX = 17  # fixture keeps the reference table rows/columns for Z <= 17 (H..Cl)
 
@@ -223,6 +290,12 @@ def main() -> None:
         return
     if "--only-dftd3" in sys.argv:
         make_dftd3(path, meta_common)
+        return
+    if "--only-rxn" in sys.argv:
+        make_rxn(meta_common)
+        return
+    if "--only-cold" in sys.argv:
+        make_cold(path, meta_common)
         return
 
     # ---- G1: taxol, config 1 -------------------------------------------------------------

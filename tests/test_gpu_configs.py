@@ -1,0 +1,201 @@
+"""BASELINE.json configurations at FULL size against the oracle / reference goldens:
+config 2 (256 molecules of 20-60 atoms, flat and padded-dense), config 4 on the aimnet2_rxn architecture, config 5 (one
+rank's shard: 128 frames x 50 atoms), the ASE / TorchSim adapters through the real engine, and a "cold" fixture on which
+the reference's un-widened 1e-5 eV energy gate holds."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import CHARGE_ATOL, STRESS_ATOL, assert_forces_close, energy_tol, golden
+from aimnetcentral_amd import workloads
+from oracle import aimnet2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def calc():
+    from aimnetcentral_amd import AIMNet2Calculator, loader
+
+    return AIMNet2Calculator(loader.synthetic_spec(0), device="cuda:0")
+
+
+def npy(out):
+    return {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
+
+
+def check_batch(out_e, out_f, out_q, ref, ref64, mol, what):
+    """Forces and charges at the reference's gates against the fp32 oracle.  Energies: these random geometries are hot
+    (contacts of 0.9 A, max|F| ~ 800 eV/A, per-atom energies up to 85 eV on the synthetic weights); the fp32 ORACLE itself
+    sits up to 1.2e-3 eV from the fp64 energy of a 50-atom molecule, and its per-atom errors are one-signed within a molecule,
+    not a random walk (tests/tools/cfg5_diag.py: engine and fp32 oracle both -3e-4 .. -1.2e-3 eV on the worst frames).
+    So the engine is held against the fp64 oracle (i) in the rms over the batch - its fp32 noise may exceed the reference
+    path's own by at most a factor 1.5 (measured 1.07) - and (ii) per molecule at the reference's gate + the fp32 oracle's
+    own distance from fp64 + twice the coherent sum of the fp32 oracle's per-atom errors."""
+    mol = np.asarray(mol)
+    sizes = np.bincount(mol)
+    assert np.isfinite(out_e).all(), what
+    err = np.abs(out_e - ref64["energy"])
+    err_ref = np.abs(ref["energy"] - ref64["energy"])
+    rms, rms_ref = np.sqrt(np.mean(err**2)), np.sqrt(np.mean(err_ref**2))
+    assert rms <= 1.5 * rms_ref + 1e-5, f"{what}: rms energy error {rms:.3e} vs the fp32 oracle's {rms_ref:.3e}"
+    d = np.abs(ref["_e_atom"][: len(mol)].astype(np.float64) - ref64["_e_atom"][: len(mol)])
+    l1 = np.zeros(len(sizes))
+    np.add.at(l1, mol, d)
+    gate = energy_tol(sizes) + err_ref + 2.0 * l1
+    assert (err <= gate).all(), f"{what}: energy |hip - fp64| / gate = {np.max(err / gate):.2f} (molecule {int(np.argmax(err / gate))})"
+    assert_forces_close(out_f, ref["forces"], what)
+    assert np.abs(out_q - ref["charges"]).max() <= CHARGE_ATOL, what
+
+
+def test_config2_full_size_flat_and_padded_dense(calc, oracle32, oracle64):
+    """256 random neutral organics of 20-60 atoms (10.5 k atoms): flat mol_idx input and the (256, 60, 3) zero-padded dense
+    input of the GPU configuration, both against the oracle on the flat layout (the engine compacts the padding away)."""
+    c, z, mol, q = workloads.random_batch(256, 20, 60, seed=2)
+    ref = O.evaluate(oracle32, c, z, q, mol, coulomb="simple", return_intermediates=True)
+    e64 = O.evaluate(oracle64, c, z, q, mol, coulomb="simple", forces=False, return_intermediates=True)
+    flat = npy(calc({"coord": c, "numbers": z, "mol_idx": mol, "charge": q}, forces=True))
+    check_batch(flat["energy"], flat["forces"], flat["charges"], ref, e64, mol, "config 2 flat")
+    cp, zp = workloads.pad_batch(c, z, mol, 256)
+    assert cp.shape == (256, 60, 3)
+    dense = npy(calc({"coord": cp, "numbers": zp, "charge": q}, forces=True))
+    assert dense["forces"].shape == (256, 60, 3) and dense["energy"].shape == (256,)
+    real = zp > 0
+    check_batch(dense["energy"], dense["forces"][real], dense["charges"][real], ref, e64, mol, "config 2 padded dense")
+    assert (dense["forces"][~real] == 0).all() and (dense["charges"][~real] == 0).all()
+
+
+def test_config5_one_rank_shard(calc, oracle32, oracle64):
+    """1024 frames x 50 atoms over 8 ranks: rank 0's 128 frames, through the same sharding helpers bench.py uses."""
+    from aimnetcentral_amd import dist as adist
+
+    c, z, mol, q = workloads.random_batch(1024, 50, 50, seed=5)
+    sizes = np.bincount(mol, minlength=1024)
+    a, b = adist.shard_frames(sizes, 8)[0]
+    assert b - a == 128
+    c, z, mol, q = adist.local_batch(c, z, mol, q, a, b)
+    ref = O.evaluate(oracle32, c, z, q, mol, coulomb="simple", return_intermediates=True)
+    e64 = O.evaluate(oracle64, c, z, q, mol, coulomb="simple", forces=False, return_intermediates=True)
+    out = npy(calc({"coord": c, "numbers": z, "mol_idx": mol, "charge": q}, forces=True))
+    check_batch(out["energy"], out["forces"], out["charges"], ref, e64, np.asarray(mol), "config 5 shard")
+
+
+def test_config4_on_the_rxn_architecture():
+    """aimnet2_rxn.yaml (Dipole / Quadrupole output modules next to the energy head) through the loader, then Hessian and
+    Hessian-vector products against the reference's double backward on the same artifact (tests/golden/hvp40_rxn.npz)."""
+    from aimnetcentral_amd import AIMNet2Calculator, loader
+
+    from aimnetcentral_amd import synth
+
+    assert "aimnet.modules.Dipole" in synth.rxn_yaml() and "aimnet.modules.Quadrupole" in synth.rxn_yaml()
+    spec = loader.synthetic_spec(0, rxn=True)
+    calc = AIMNet2Calculator(spec, device="cuda:0")
+    g = golden("hvp40_rxn")
+    data = {"coord": g["coord"], "numbers": g["numbers"], "charge": 0.0}
+    out = npy(calc(data, forces=True, hessian=True))
+    assert abs(out["energy"][0] - g["energy"][0]) <= energy_tol(40)
+    assert_forces_close(out["forces"], g["forces"], "rxn forces")
+    H = out["hessian"].reshape(120, 120)
+    assert np.abs(H - g["hessian"].reshape(120, 120)).max() < 2e-3  # finite-difference operator, DESIGN 1
+    hv1 = calc.hessian_vector_product(data, g["v1"]).cpu().numpy()
+    hv4 = calc.hessian_vector_product(data, g["v4"]).cpu().numpy()
+    assert hv1.shape == (40, 3) and hv4.shape == (4, 40, 3)
+    assert np.abs(hv1 - g["hv1"]).max() < 5e-3 and np.abs(hv4 - g["hv4"]).max() < 5e-3
+
+
+def test_cold_fixture_holds_the_unwidened_energy_gate(calc):
+    """A geometry relaxed on the synthetic surface (max|F| = 0.3 eV/A): engine vs the reference golden at the reference's own
+    |dE| < 1e-5 eV (tests/test_calculator_gpu.py:445) with NO fp64-anchored slack, forces to 1e-5 + 1e-4 max|F|."""
+    g = golden("cold24")
+    assert np.abs(g["forces"]).max() < 0.5
+    out = npy(calc({"coord": g["coord"], "numbers": g["numbers"], "charge": 0.0}, forces=True))
+    assert abs(out["energy"][0] - g["energy"][0]) < 1e-5
+    assert np.abs(out["forces"] - g["forces"]).max() <= 1e-5 + 1e-4 * np.abs(g["forces"]).max()
+    assert np.abs(out["charges"] - g["charges"]).max() <= CHARGE_ATOL
+
+
+# ---- adapters through the real engine (duck-typed ase.Atoms / torch_sim SimState: neither package is installed) ----------
+class _Atoms:
+    def __init__(self, numbers, positions, cell=None, pbc=(False, False, False), info=None):
+        self.numbers, self.positions = np.asarray(numbers), np.asarray(positions, dtype=float)
+        self.cell, self.pbc, self.info = cell, np.asarray(pbc), dict(info or {})
+
+    def copy(self):
+        return _Atoms(self.numbers.copy(), self.positions.copy(), None if self.cell is None else np.array(self.cell), self.pbc.copy(), self.info)
+
+    def __len__(self):
+        return len(self.numbers)
+
+
+class _State:
+    def __init__(self, positions, numbers, system_idx, cell, pbc, n_systems, **extras):
+        self.positions, self.atomic_numbers, self.system_idx = positions, numbers, system_idx
+        self.row_vector_cell, self.pbc, self.n_systems = cell, pbc, n_systems
+        self.device, self.dtype = positions.device, torch.float32
+        for k, v in extras.items():
+            setattr(self, k, v)
+
+
+def test_ase_adapter_on_the_gpu_matches_the_reference_goldens(calc):
+    """AIMNet2ASE.calculate (aimnet2ase.py:238-263 of the reference) on taxol and on the periodic DSF cell."""
+    from aimnetcentral_amd.aimnet2ase import AIMNet2ASE
+
+    g = golden("taxol")
+    ase_calc = AIMNet2ASE(calc, charge=0)
+    atoms = _Atoms(g["numbers"], g["coord"])
+    ase_calc.calculate(atoms, properties=["energy", "forces"])
+    r = ase_calc.results
+    assert abs(r["energy"] - g["energy"][0]) <= energy_tol(113)
+    assert_forces_close(r["forces"], g["forces"], "ase taxol")
+    assert np.abs(r["charges"] - g["charges"]).max() <= CHARGE_ATOL
+    # an MD-like second step: moved positions, cached device inputs, results change
+    moved = atoms.copy()
+    moved.positions = moved.positions + 0.01 * np.sin(np.arange(339).reshape(113, 3))
+    ase_calc.reset()
+    ase_calc.calculate(moved, properties=["energy", "forces"])
+    assert abs(ase_calc.results["energy"] - r["energy"]) > 1e-6
+    p = golden("pbc96_dsf15")
+    calc.set_lrcoulomb_method("dsf", cutoff=15.0, dsf_alpha=0.2)
+    try:
+        patoms = _Atoms(p["numbers"], p["coord"], cell=p["cell"], pbc=(True, True, True))
+        pc = AIMNet2ASE(calc, charge=0)
+        pc.calculate(patoms, properties=["energy", "forces", "stress"])
+        rr = pc.results
+        assert abs(rr["energy"] - p["energy"][0]) <= 1e-4
+        assert_forces_close(rr["forces"], p["forces"], "ase pbc96")
+        s = np.asarray(rr["stress"])
+        ref_s = p["stress"].reshape(3, 3)
+        if s.shape == (6,):  # Voigt
+            ref_s = np.array([ref_s[0, 0], ref_s[1, 1], ref_s[2, 2], ref_s[1, 2], ref_s[0, 2], ref_s[0, 1]])
+        assert np.abs(s - ref_s).max() <= STRESS_ATOL
+    finally:
+        calc.set_lrcoulomb_method("simple")
+
+
+def test_torchsim_adapter_on_the_gpu(calc, oracle32, oracle64):
+    """AIMNet2TorchSim.forward (aimnet2torchsim.py:106-144): a flat multi-system state of ragged molecules, and a periodic one."""
+    from aimnetcentral_amd import AIMNet2TorchSim
+
+    dev = torch.device("cuda:0")
+    c, z, mol, q = workloads.random_batch(5, 9, 23, seed=4)
+    st = _State(torch.from_numpy(c).to(dev), torch.from_numpy(z).to(dev), torch.from_numpy(mol).to(dev), torch.zeros(5, 3, 3, device=dev),
+                False, 5, charge=torch.from_numpy(q).to(dev))
+    model = AIMNet2TorchSim(calc, compute_forces=True)
+    out = model(st)
+    ref = O.evaluate(oracle32, c, z, q, mol, coulomb="simple", return_intermediates=True)
+    e64 = O.evaluate(oracle64, c, z, q, mol, coulomb="simple", forces=False, return_intermediates=True)
+    check_batch(out["energy"].cpu().numpy(), out["forces"].cpu().numpy(), out["charges"].cpu().numpy(), ref, e64, mol, "torchsim batch")
+    p = golden("pbc96_dsf15")
+    calc.set_lrcoulomb_method("dsf", cutoff=15.0, dsf_alpha=0.2)
+    try:
+        stp = _State(torch.from_numpy(p["coord"]).to(dev), torch.from_numpy(p["numbers"]).to(dev), torch.zeros(96, dtype=torch.int64, device=dev),
+                     torch.from_numpy(p["cell"]).to(dev).view(1, 3, 3), True, 1)
+        pm = AIMNet2TorchSim(calc, compute_forces=True, compute_stress=True)
+        o = pm(stp)
+        assert abs(float(o["energy"].cpu()[0]) - p["energy"][0]) <= 1e-4
+        assert_forces_close(o["forces"].cpu().numpy(), p["forces"], "torchsim pbc96")
+        assert np.abs(o["stress"].cpu().numpy().reshape(3, 3) - p["stress"].reshape(3, 3)).max() <= STRESS_ATOL
+    finally:
+        calc.set_lrcoulomb_method("simple")

@@ -33,9 +33,18 @@ except ImportError:
 
 
 class AIMNet2TorchSim(_Base):
-    def __init__(self, base_calc, *, compute_forces: bool = True, compute_stress: bool = False, validate_species: bool = True):
+    def __init__(self, base_calc, *, compute_forces: bool = True, compute_stress: bool = False, validate_species: bool = True,
+                 status_check_every: int = 1):
+        """`status_check_every = K > 1` (not in the reference): device-resident stepping.  forward() only ENQUEUES the
+        evaluation - no host read, no synchronisation - and the neighbour-overflow status of the last K evaluations is
+        verified in one go every K-th call (`engine.NeighborOverflowError` then says that those K results are invalid and
+        the row capacity has been grown).  K = 1 is the reference's behaviour: one status read per call."""
         super().__init__()
         import torch
+
+        self._check_every = max(1, int(status_check_every))
+        self._since_check = 0
+        self._cell_key = None  # identity of the last cell tensor that was checked for being non-zero (one sync per new cell)
 
         self._base_calc = base_calc
         self._device = torch.device(base_calc.device)
@@ -94,8 +103,14 @@ class AIMNet2TorchSim(_Base):
 
         if hasattr(state, "to") and (getattr(state, "device", self._device) != self._device or getattr(state, "dtype", self._dtype) != self._dtype):
             state = state.to(self._device, self._dtype)
-        out = self._base_calc(self.state_to_data(state), forces=self._compute_forces, stress=self._compute_stress,
-                              validate_species=self._validate_species)
+        defer = self._check_every > 1
+        out = self._base_calc.eval(self.state_to_data(state), forces=self._compute_forces, stress=self._compute_stress,
+                                   validate_species=self._validate_species, **({"defer_status": True} if defer else {}))
+        if defer:
+            self._since_check += 1
+            if self._since_check >= self._check_every:
+                self._since_check = 0
+                self._base_calc.check_status()
         if "charges" in out:
             out["partial_charges"] = out["charges"]
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
@@ -117,7 +132,14 @@ class AIMNet2TorchSim(_Base):
         if pbc.numel() == 1:  # TorchSim allows a single flag for all three axes
             pbc = pbc.reshape(1).expand(3).clone()
         cell = torch.as_tensor(state.row_vector_cell, dtype=torch.float32)
-        if bool(pbc.any()) and bool((cell != 0).any()):
+        nonzero = False
+        if bool(pbc.any()):
+            # "(cell != 0).any()" is a device read: done once per cell tensor (identity + version), not once per MD step
+            key = (cell.data_ptr(), getattr(cell, "_version", None), tuple(cell.shape))
+            if self._cell_key is None or self._cell_key[0] != key:
+                self._cell_key = (key, bool((cell != 0).any()))
+            nonzero = self._cell_key[1]
+        if bool(pbc.any()) and nonzero:
             data["cell"] = cell.contiguous()
             data["pbc"] = pbc
         elif self._compute_stress:

@@ -354,9 +354,11 @@ class AIMNet2Calculator:
         return ret
 
     def eval(self, data: dict[str, Any], forces=False, stress=False, hessian=False, *, validate_species: bool = True,
-             host_out: bool = False) -> dict[str, Any]:
+             host_out: bool = False, defer_status: bool = False) -> dict[str, Any]:
         """calculator.py:879-947.  `host_out=True` (not in the reference) returns CPU tensors that arrived with the engine's one
-        status copy - for host-side drivers such as the ASE adapter that would otherwise pay one D2H round trip per output."""
+        status copy - for host-side drivers such as the ASE adapter that would otherwise pay one D2H round trip per output.
+        `defer_status=True` (device-resident drivers): no host read at all in this call - the evaluation is only enqueued, its
+        neighbour-overflow status is queued on the engine and verified by `check_status()` every K steps."""
         import torch
 
         if validate_species:
@@ -444,7 +446,7 @@ class AIMNet2Calculator:
                 coord_f, numbers_f, mol_idx, self._engine_charge(charge, d.get("mult")), cell=cell, pbc=pbc3, forces=bool(forces),
                 stress=bool(stress),
                 coulomb=method or "none", dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, dftd3=self._dftd3_options(),
-                **({"host_out": True} if host_out else {}))
+                **({"host_out": True} if host_out else {}), **({"sync": False, "defer": True} if defer_status else {}))
         finally:
             if restore is not None:
                 (self._coulomb_method, self._coulomb_cutoff, self.cutoff_lr, self._dsf_alpha, self._dsf_rc) = restore
@@ -468,6 +470,11 @@ class AIMNet2Calculator:
                     out[k] = v.view(B, -1, *v.shape[1:])
         assert n_mol == out["energy"].shape[0]
         return out
+
+    def check_status(self) -> None:
+        """Verify every evaluation enqueued with `defer_status=True` since the last call (one synchronisation); raises
+        `engine.NeighborOverflowError` after growing the row capacity if one of them overflowed."""
+        self.engine.check_deferred()
 
     # ---- second derivatives (calculator.py:904-910,1247-1450,1753-1989; derivatives.py:149-192) -------------
     FD_STEP = 5e-3          # Angstrom; largest per-atom displacement of the inner stencil points

@@ -68,6 +68,12 @@ struct aimnet_engine {
   // Measured on config 3 (profiles/r2_conv_mfma.md): forward 81 us either way, backward 293 vs 226 us - neither form is
   // arithmetic-bound, so the matrix pipe buys nothing here and the VALU kernels stay the default.
   int conv_mfma = 0;
+  // AIMNET_OVERLAP_COULOMB / set_option("overlap_coulomb"): the Coulomb / DFT-D3 pair kernels (VALU-bound, they need only the
+  // final charges) run on a second HIP stream next to the last pass' MLP, the energy head and the first backward GEMMs
+  // (MFMA-bound): forked after the last charge update, joined in front of the first conv backward
+  bool overlap_coulomb = false;  // measured (profiles/r2_summary.md): 2.135 vs 2.118 ms/step - concurrent kernels of one process slow each other down here too
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<Layer> mlp[AIMNET_MAX_PASS];
   std::vector<Layer> head;
   float* head_w_last;  // [k] last head layer as a vector
@@ -361,6 +367,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->keep_intermediates = atoi(env) != 0;
     env = getenv("AIMNET_CONV_MFMA");
     if (env) e->conv_mfma = atoi(env);
+    env = getenv("AIMNET_OVERLAP_COULOMB");
+    if (env) e->overlap_coulomb = atoi(env) != 0;
   }
   if ((rc = dev_upload(e, w->agh_a, (size_t)16 * 16 * 12, &e->agh_a))) goto fail;
   if ((rc = dev_upload(e, w->agh_q, (size_t)e->nq * 16 * 12, &e->agh_q))) goto fail;
@@ -408,6 +416,13 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
   e->bp.eta = arch->eta;
   for (int g = 0; g < 16; ++g) e->bp.shifts[g] = arch->shifts[g];
   if ((rc = gemm_set_attributes())) goto fail;
+  if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+    set_last_error("engine_create: cannot create the side stream / events");
+    rc = AIMNET_E_HIP;
+    goto fail;
+  }
   *out = e;
   return AIMNET_OK;
 fail:
@@ -419,6 +434,9 @@ void aimnet_engine_destroy(aimnet_engine* e) {
   if (!e) return;
   for (void* p : e->allocs) (void)hipFree(p);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->side) (void)hipStreamDestroy(e->side);
   delete e;
 }
 
@@ -463,6 +481,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   if (n == "conv_mfma") e->conv_mfma = value & 3;
   else if (n == "split_max") conv_set_split_max(value);  // process-wide
   else if (n == "p0_moments") e->p0_moments = value != 0;
+  else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
   else if (n == "spatial_order") e->spatial_order = value != 0;
   else {
     set_last_error("set_option: unknown option '%s'", name);
@@ -638,6 +657,44 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
   const bool mfma_fwd = (e->conv_mfma & 1) && N > conv_split_max_atoms();
   const bool mfma_bwd = (e->conv_mfma & 2) && N > conv_split_max_atoms();
+  // ---- Coulomb: energies, and the seeds of qbar / dE/dx / virial (a closure: it runs on the eval stream or on the side one) ----
+  const float* q_fin = nq == 2 ? W.qtot : W.q[np - 2];
+  const bool overlap = e->overlap_coulomb && e->prof_level < 2;  // per-family profiling wants one stream
+  auto coulomb_block = [&](hipStream_t cs) -> int {
+    if (nq == 2)  // NSE: alpha + beta is the charge everything downstream sees (aimnet2.py:102-106)
+      RC(launch_charge_sum(cs, W.q[np - 2], N, W.qtot, out->spin_charges));
+    CoulombParams cp;
+    cp.factor = (float)(0.5 * 27.211386024367243 * 0.5291772105638411);
+    cp.sr_rc = ar.sr_rc;
+    cp.sr_envelope = ar.sr_envelope;
+    cp.dsf_rc = opt->dsf_rc;
+    cp.dsf_alpha = opt->dsf_alpha;
+    RC(launch_coulomb_sr(cs, grad, want_s, ar.sr_coulomb != 0, q_fin, W.nb_idx, W.nb_cnt, W.pg, cap, cp, N, W.ecoul, W.qbar,
+                         W.fgrad, W.virial_atom));
+    // DSF and DFT-D3 with one cutoff: the Coulomb pair terms ride on the D3 pair pass (one list, one geometry evaluation)
+    const bool dsf_in_d3 = d3 && coulomb == AIMNET_COULOMB_DSF && opt->d3_cutoff == opt->dsf_rc;
+    if (coulomb == AIMNET_COULOMB_SIMPLE)
+      RC(launch_coulomb_simple(cs, grad, q_fin, W.nl.xw, in->mol_idx, W.nl.mol_start, cp, N, W.ecoul, W.qbar, W.fgrad));
+    else if (dsf_in_d3)
+      ;  // see launch_dftd3 below
+    else if (coulomb == AIMNET_COULOMB_DSF && pbc)
+      RC(launch_coulomb_dsf_walk(cs, grad, want_s, q_fin, in->mol_idx, W.nl, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));
+    else if (coulomb == AIMNET_COULOMB_DSF)
+      RC(launch_coulomb_dsf(cs, grad, want_s, q_fin, W.nl.xw, in->mol_idx, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt,
+                            cap_lr, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));
+    if (d3) {  // external DFT-D3: adds to the per-atom pair energies, dE/dx and the virial seeded by the Coulomb kernels
+      D3Params dp;
+      dp.s6 = opt->d3_s6; dp.s8 = opt->d3_s8; dp.a1 = opt->d3_a1; dp.a2 = opt->d3_a2;
+      dp.r_on = opt->d3_smoothing_on * 1.8897261258369282f;
+      dp.r_off = opt->d3_cutoff * 1.8897261258369282f;
+      RC(launch_dftd3(cs, grad, want_s, W.nl.xw, in->mol_idx, in->cell, n_cell, W.aslot, W.d3_idx, W.d3_shift, W.d3_cnt, cap_d3,
+                      e->d3, dp, opt->d3_cutoff, N, W.d3xs, W.d3w, W.dEdcn, W.ecoul, W.fgrad, W.virial_atom, dsf_in_d3, cp, q_fin,
+                      W.qbar));
+    }
+    if (grad && nq == 2) RC(launch_copy_f32(cs, W.qbar, W.qbar + N, (size_t)N));  // dE/dq_alpha = dE/dq_beta = dE/dq at this point
+    return 0;
+  };
+
   if (p0m || d3) RC(launch_species(s, in->numbers, e->slot_of_z, N, W.aslot, W.present_part));
   for (int p = 0; p < np; ++p) {
     const std::vector<Layer>& Ls = e->mlp[p];
@@ -664,14 +721,15 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       RC(prof_mark(e, s, FAM_POINTWISE));
       RC(launch_nse_fwd(s, W.H[p][nl - 1], Ls[nl - 1].k_out, nq, p > 0 ? W.q[p - 1] : nullptr, W.nl.mol_start, in->charge,
                         n_mol, N, W.S, (float*)W.part, W.q[p], W.Fm[p], W.Dm[p]));
+      if (p == np - 2 && overlap) {  // the final charges exist: the Coulomb block starts on the side stream
+        AIMNET_HIP_CHECK(hipEventRecord(e->ev_fork, s));
+        AIMNET_HIP_CHECK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+        RC(coulomb_block(e->side));
+        AIMNET_HIP_CHECK(hipEventRecord(e->ev_join, e->side));
+      }
       RC(launch_update_a(s, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr, W.H[p][nl - 1], Ls[nl - 1].k_out, nq, N,
                          W.a[p + 1], W.at[p + 1]));
     }
-  }
-  const float* q_fin = W.q[np - 2];
-  if (nq == 2) {  // NSE: alpha + beta is the charge everything downstream sees (aimnet2.py:102-106)
-    RC(launch_charge_sum(s, W.q[np - 2], N, W.qtot, out->spin_charges));
-    q_fin = W.qtot;
   }
   {
     const int nlp = (int)e->mlp[np - 1].size();
@@ -691,44 +749,25 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
                         grad ? W.hD[nh - 2] : nullptr, grad ? W.zb0 : nullptr));
   }
 
-  // ---- Coulomb: energies, and the seeds of qbar / dE/dx / virial -------------------------------
-  CoulombParams cp;
-  cp.factor = (float)(0.5 * 27.211386024367243 * 0.5291772105638411);
-  cp.sr_rc = ar.sr_rc;
-  cp.sr_envelope = ar.sr_envelope;
-  cp.dsf_rc = opt->dsf_rc;
-  cp.dsf_alpha = opt->dsf_alpha;
-  RC(prof_mark(e, s, FAM_COULOMB));
-  RC(launch_coulomb_sr(s, grad, want_s, ar.sr_coulomb != 0, q_fin, W.nb_idx, W.nb_cnt, W.pg, cap, cp, N, W.ecoul, W.qbar,
-                       W.fgrad, W.virial_atom));
-  // DSF and DFT-D3 with one cutoff: the Coulomb pair terms ride on the D3 pair pass (one list, one geometry evaluation)
-  const bool dsf_in_d3 = d3 && coulomb == AIMNET_COULOMB_DSF && opt->d3_cutoff == opt->dsf_rc;
-  if (coulomb == AIMNET_COULOMB_SIMPLE)
-    RC(launch_coulomb_simple(s, grad, q_fin, W.nl.xw, in->mol_idx, W.nl.mol_start, cp, N, W.ecoul, W.qbar, W.fgrad));
-  else if (dsf_in_d3)
-    ;  // see launch_dftd3 below
-  else if (coulomb == AIMNET_COULOMB_DSF && pbc)
-    RC(launch_coulomb_dsf_walk(s, grad, want_s, q_fin, in->mol_idx, W.nl, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));
-  else if (coulomb == AIMNET_COULOMB_DSF)
-    RC(launch_coulomb_dsf(s, grad, want_s, q_fin, W.nl.xw, in->mol_idx, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt,
-                          cap_lr, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));
-  if (d3) {  // external DFT-D3: adds to the per-atom pair energies, dE/dx and the virial seeded by the Coulomb kernels
-    D3Params dp;
-    dp.s6 = opt->d3_s6; dp.s8 = opt->d3_s8; dp.a1 = opt->d3_a1; dp.a2 = opt->d3_a2;
-    dp.r_on = opt->d3_smoothing_on * 1.8897261258369282f;
-    dp.r_off = opt->d3_cutoff * 1.8897261258369282f;
-    RC(launch_dftd3(s, grad, want_s, W.nl.xw, in->mol_idx, in->cell, n_cell, W.aslot, W.d3_idx, W.d3_shift, W.d3_cnt, cap_d3,
-                    e->d3, dp, opt->d3_cutoff, N, W.d3xs, W.d3w, W.dEdcn, W.ecoul, W.fgrad, W.virial_atom, dsf_in_d3, cp, q_fin,
-                    W.qbar));
+  if (!overlap) {
+    RC(prof_mark(e, s, FAM_COULOMB));
+    RC(coulomb_block(s));
   }
-  RC(prof_mark(e, s, FAM_POINTWISE));
-  RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, W.S, W.part, out->energy));
-  RC(launch_copy_f32(s, q_fin, out->charges, (size_t)N));
+  // results of the Coulomb block (ecoul, qbar / fgrad / virial seeds, qtot) are first needed here (energy only) or in front of
+  // the first conv backward (see `join` below)
+  auto join = [&]() -> int {
+    if (overlap) AIMNET_HIP_CHECK(hipStreamWaitEvent(s, e->ev_join, 0));
+    RC(prof_mark(e, s, FAM_POINTWISE));
+    RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, W.S, W.part, out->energy));
+    RC(launch_copy_f32(s, q_fin, out->charges, (size_t)N));
+    return 0;
+  };
   if (!grad) {
+    RC(join());
     RC(prof_mark(e, s, -1));
     return AIMNET_OK;
   }
-  if (nq == 2) RC(launch_copy_f32(s, W.qbar, W.qbar + N, (size_t)N));  // dE/dq_alpha = dE/dq_beta = dE/dq at this point
+  bool joined = false;
 
   // ---- backward -------------------------------------------------------------------------------
   float* zcur = W.zb0;
@@ -767,6 +806,10 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       ld = L.k_in;
     }
     // zcur = xbar_p  (N x k_in of the first layer)
+    if (!joined) {  // the conv backward below is the first consumer of the Coulomb block's qbar / dE/dx / virial seeds
+      RC(join());
+      joined = true;
+    }
     RC(prof_mark(e, s, FAM_UNCONCAT));
     if (p == 0 && p0m) {
       RC(launch_unconcat_p0(s, zcur, ld, W.V[0], e->agh_a, e->afv, e->z_of_slot, e->nslots, W.present_part, W.n_part, W.Sbar, N));

@@ -44,6 +44,11 @@ class ModelSpec:
     num_charge_channels: int = 1       # 2 = open-shell NSE family (aimnet2.py:21-28)
 
 
+class NeighborOverflowError(RuntimeError):
+    """A neighbour row overflowed in a DEFERRED evaluation (the synchronous path retries by itself; nvalchemiops raises the
+    exception of this name, neighbors.py:127-130)."""
+
+
 class HipEngine:
     def __init__(self, spec: ModelSpec, device: str | int = 0):
         import torch
@@ -99,6 +104,7 @@ class HipEngine:
         self._keep.clear()  # weights are on the device now
         self._ws = None
         self._ws_stream = None  # stream of the last launch (the workspace is tied to it)
+        self.pending_status: list = []  # status words of evaluations run with sync=False and defer=True (check_deferred)
         # AdaptiveNeighborList policy (neighbors.py:49-63): density 0.2 -> 112 @ 5 A, 2832 @ 15 A
         self.max_nb = _round16(int(0.2 * 4.0 / 3.0 * math.pi * spec.rc**3))
         self._max_nb_lr: dict[float, int] = {}
@@ -134,6 +140,38 @@ class HipEngine:
         _lib.check(self.lib.aimnet_engine_set_dftd3(self._h, C.byref(t)), "aimnet_engine_set_dftd3")
         self.has_dftd3 = True
 
+    @staticmethod
+    def _shrunk(capacity: int, actual_max: int, target_utilization: float = 0.75) -> int:
+        if actual_max < (2.0 / 3.0) * target_utilization * capacity:
+            return max(16, _round16(int(actual_max / target_utilization)))
+        return capacity
+
+    def check_deferred(self) -> None:
+        """Synchronise once and verify the status words of every evaluation run with `sync=False, defer=True` since the last
+        check: a device-resident MD driver calls this every K steps instead of paying one host read per step.  On a neighbour
+        overflow the row capacity is grown (x1.5, as the synchronous path does) and NeighborOverflowError is raised - the
+        evaluations since the last check are invalid and have to be repeated."""
+        import torch
+
+        if not self.pending_status:
+            return
+        st = torch.stack(self.pending_status).cpu().numpy()
+        self.pending_status.clear()
+        self.last_status = st[-1]
+        if st[:, 6].any():
+            raise ValueError("HipEngine: invalid input in a deferred evaluation (atomic numbers outside [0, 63] or mol_idx out of range)")
+        grown = False
+        if st[:, 2].any():
+            self.max_nb = _round16(int(max(self.max_nb * 1.5, st[:, 0].max())))
+            grown = True
+        if st[:, 3].any() or st[:, 5].any():
+            for rc in list(self._max_nb_lr):
+                self._max_nb_lr[rc] = _round16(int(max(self._max_nb_lr[rc] * 1.5, st[:, 1].max(), st[:, 4].max())))
+            grown = True
+        if grown:
+            raise NeighborOverflowError("neighbour-row overflow in one of the last %d deferred evaluations: their results are invalid; "
+                                        "the row capacity has been grown - repeat them" % len(st))
+
     def _lr_capacity(self, rc: float) -> int:
         if rc not in self._max_nb_lr:
             self._max_nb_lr[rc] = _round16(int(0.2 * 4.0 / 3.0 * math.pi * rc**3))
@@ -155,6 +193,7 @@ class HipEngine:
         sync: bool = True,
         dftd3: dict[str, float] | None = None,
         host_out: bool = False,
+        defer: bool = False,
     ) -> dict[str, Any]:
         """One evaluation on device tensors (coord f32 [N,3], numbers/mol_idx i32 [N], charge f32
         [n_mol] - for a 2-channel NSE model [n_mol, 2] = the alpha / beta charges of aimnet2.py:94-100 -,
@@ -264,6 +303,9 @@ class HipEngine:
                 break
             # the one D2H sync of a step (the reference has one per list, neighbors.py:133)
             if host_out:
+                # ONE D2H copy brings the status words and every output back.  (A persistent pinned staging buffer was tried and
+                # dropped: torch's pinned host memory is uncached for the CPU on this platform - reading 160 KB of results out of
+                # it took 1.4 ms, and the evaluation as a whole 15 ms instead of 2.2, tests/tools/ase_prof2.py.)
                 host = outbuf.cpu()
                 st = host[:32].view(torch.int32).numpy()
             else:
@@ -288,6 +330,14 @@ class HipEngine:
                 self._max_nb_lr[d3_rc] = _round16(int(max(max(opt.max_nb_d3, opt.max_nb_lr) * 1.5, st[4])))
                 retry = True
             if not retry:
+                # AdaptiveNeighborList shrink rule (neighbors.py:135-139): a row capacity used to less than 2/3 of the 75 % target
+                # shrinks to actual / 0.75 (multiples of 16, at least 16) - next call's workspace and list traffic follow
+                self.max_nb = self._shrunk(self.max_nb, int(st[0]))
+                if opt.max_nb_lr > 0:
+                    self._max_nb_lr[float(dsf_rc)] = self._shrunk(self._max_nb_lr[float(dsf_rc)], int(st[1]))
+                if dftd3 is not None and opt.max_nb_d3 > 0 and st[4] > 0:
+                    d3_rc = float(dftd3.get("cutoff", 15.0))
+                    self._max_nb_lr[d3_rc] = self._shrunk(self._max_nb_lr[d3_rc], int(st[4]))
                 break
         if host is not None:
             hv = views(host)
@@ -297,6 +347,8 @@ class HipEngine:
             # no host round trip: the caller owns the overflow check (status[2], [3], [5] must be 0, include/aimnet_hip.h)
             # and reads it whenever it next synchronises - e.g. a device-resident MD loop once per block of steps
             res["status"] = status
+            if defer:
+                self.pending_status.append(status)  # verified in one go by check_deferred()
         if spin is not None:
             res["spin_charges"] = spin
         if forces:

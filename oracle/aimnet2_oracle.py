@@ -116,6 +116,66 @@ def neighbor_list(coord, cutoff: float, mol_idx, cell=None, pbc=None):
     return nbmat, (shifts if cell is not None else None)
 
 
+def neighbor_list_fast(coord, cutoff: float, mol_idx, cell=None, pbc=None):
+    """Same contract and the same pair SETS as `neighbor_list` (checked in tests/test_oracle_golden.py), built with a k-d tree over
+    the explicit periodic images instead of N x N distance matrices per image: what bench.py's cpu_baseline times, so that the
+    CPU figure is not dominated by a quadratic list builder the reference does not have (its CPU lists come from
+    nvalchemiops' cell list, neighbors.py:106-125).  Row order: ascending (j, image) per row."""
+    from scipy.spatial import cKDTree
+
+    pos = np.asarray(coord, dtype=np.float64)
+    n = pos.shape[0]
+    mol = np.asarray(mol_idx, dtype=np.int64)
+    if math.isinf(cutoff):
+        return neighbor_list(coord, cutoff, mol_idx, cell, pbc)
+    starts = np.concatenate([[0], np.nonzero(np.diff(mol))[0] + 1, [n]])
+    ii_all, jj_all, sh_all = [], [], []
+    for a, b in zip(starts[:-1], starts[1:]):
+        p = pos[a:b]
+        if cell is None:
+            img, img_j, img_s = p, np.arange(b - a), np.zeros((b - a, 3), dtype=np.int64)
+        else:
+            cells = np.asarray(cell, dtype=np.float64)
+            c = cells if cells.ndim == 2 else cells[mol[a]]
+            pb = np.ones(3, dtype=bool) if pbc is None else np.asarray(pbc, dtype=bool).reshape(-1, 3)[0]
+            vol = abs(np.linalg.det(c))
+            nimg = []
+            for k in range(3):
+                h = vol / np.linalg.norm(np.cross(c[(k + 1) % 3], c[(k + 2) % 3]))
+                nimg.append(int(math.ceil(cutoff / h)) if pb[k] else 0)
+            sh = np.array([(sx, sy, sz) for sx in range(-nimg[0], nimg[0] + 1) for sy in range(-nimg[1], nimg[1] + 1)
+                           for sz in range(-nimg[2], nimg[2] + 1)], dtype=np.int64)
+            img = (p[None, :, :] + (sh.astype(np.float64) @ c)[:, None, :]).reshape(-1, 3)
+            img_j = np.tile(np.arange(b - a), len(sh))
+            img_s = np.repeat(sh, b - a, axis=0)
+            lo, hi = p.min(0) - cutoff, p.max(0) + cutoff  # images farther than the cutoff from every atom cannot pair
+            keep = ((img >= lo) & (img <= hi)).all(1)
+            img, img_j, img_s = img[keep], img_j[keep], img_s[keep]
+        tree = cKDTree(img)
+        hits = tree.query_ball_point(p, cutoff, return_sorted=True)
+        for i, h in enumerate(hits):
+            h = np.asarray(h, dtype=np.int64)
+            d2 = ((img[h] - p[i]) ** 2).sum(-1)
+            ok = d2 < cutoff * cutoff  # strict, like the brute-force builder
+            ok &= ~((img_j[h] == i) & (img_s[h] == 0).all(1))
+            h = h[ok]
+            ii_all.append(np.full(h.size, i + a, dtype=np.int64))
+            jj_all.append(img_j[h] + a)
+            sh_all.append(img_s[h])
+    ii = np.concatenate(ii_all) if ii_all else np.zeros(0, dtype=np.int64)
+    jj = np.concatenate(jj_all) if jj_all else np.zeros(0, dtype=np.int64)
+    sh = np.concatenate(sh_all) if sh_all else np.zeros((0, 3), dtype=np.int64)
+    counts = np.bincount(ii, minlength=n)
+    m = max(1, int(counts.max()) if counts.size else 1)
+    first = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    slot = np.arange(ii.size) - first[ii]
+    nbmat = np.full((n + 1, m), n, dtype=np.int64)
+    shifts = np.zeros((n + 1, m, 3), dtype=np.float32)
+    nbmat[ii, slot] = jj
+    shifts[ii, slot] = sh
+    return nbmat, (shifts if cell is not None else None)
+
+
 # --------------------------------------------------------------------------------------------
 # model
 # --------------------------------------------------------------------------------------------

@@ -199,3 +199,32 @@ def test_torchsim_adapter_on_the_gpu(calc, oracle32, oracle64):
         assert np.abs(o["stress"].cpu().numpy().reshape(3, 3) - p["stress"].reshape(3, 3)).max() <= STRESS_ATOL
     finally:
         calc.set_lrcoulomb_method("simple")
+
+
+def test_deferred_status_and_capacity_hysteresis(oracle32):
+    """Device-resident stepping: evaluations enqueued with defer_status=True do no host read; check_status()
+    verifies them in one go, grows the row capacity and raises on a neighbour overflow; the synchronous path shrinks an
+    under-used capacity by the AdaptiveNeighborList rule (neighbors.py:135-139)."""
+    from aimnetcentral_amd import AIMNet2Calculator, loader
+    from aimnetcentral_amd.engine import NeighborOverflowError
+
+    calc = AIMNet2Calculator(loader.synthetic_spec(0), device="cuda:0")
+    eng = calc.engine
+    g = golden("taxol")
+    data = {"coord": torch.from_numpy(g["coord"]).cuda(), "numbers": torch.from_numpy(g["numbers"]).cuda(), "charge": torch.zeros(1).cuda()}
+    w = npy(calc({"coord": [[0.0, 0.0, 0.1173], [0.0, 0.7572, -0.4692], [0.0, -0.7572, -0.4692]], "numbers": [8, 1, 1], "charge": 0.0}))
+    assert np.isfinite(w["energy"]).all() and eng.max_nb == 16  # water: 2 neighbours -> 112 shrinks to the floor of 16
+    sync = npy(calc(data, forces=True))  # taxol, up to 62 neighbours: grows back by the x1.5 retry rule (16 -> 32 -> 48 -> 80)
+    assert 62 <= eng.max_nb <= 112
+    outs = [calc.eval(data, forces=True, defer_status=True) for _ in range(5)]
+    assert len(eng.pending_status) == 5 and "status" not in sync
+    calc.check_status()
+    assert not eng.pending_status
+    assert np.array_equal(outs[-1]["forces"].cpu().numpy(), sync["forces"])  # same kernels, same (shrunk) capacity
+    eng.max_nb = 16  # too small for taxol: the deferred evaluation overflows, nobody notices until the check
+    calc.eval(data, forces=True, defer_status=True)
+    with pytest.raises(NeighborOverflowError, match="repeat them"):
+        calc.check_status()
+    assert eng.max_nb >= 24
+    again = npy(calc(data, forces=True))  # the synchronous path retries by itself and lands on the same answer
+    assert np.array_equal(again["forces"], sync["forces"])

@@ -24,5 +24,21 @@ print("per-dispatch averages; kernel | " + " | ".join(names))
 for k in sorted(agg, key=lambda k: -agg[k].get("GRBM_GUI_ACTIVE", [0, 1])[0]):
     print(f"{k:48s} | " + " | ".join(f"{agg[k][c][0] / max(1, agg[k][c][1]):.4g}" if c in agg[k] else "-" for c in names))
 PY
+python - <<PY > gpurun_out/$out/pmc.json
+# GEMM-family aggregates for bench.py's roofline.traffic (profiles/r2_pmc.json), stamped with the commit (gpurun_in/HEAD)
+import csv, glob, collections, json, os
+tot = collections.defaultdict(float); n = collections.defaultdict(int)
+for f in sorted(glob.glob("gpurun_out/$out/*/*/*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if "gemm_nt" not in r["Kernel_Name"]: continue
+        tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+launches = max(1, n["TCC_EA0_RDREQ_sum"])
+rd, wr = tot["TCC_EA0_RDREQ_sum"] * 128 / launches, tot["TCC_EA0_WRREQ_sum"] * 64 / launches
+head = open("gpurun_in/HEAD").read().strip() if os.path.exists("gpurun_in/HEAD") else "unknown"
+print(json.dumps({"source": "tests/tools/pmc_bench.sh (rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum ..., bench.py --steps 3 --warmup 1)",
+                  "commit": head, "gemm_launches_counted": launches, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+                  "traffic_bytes_per_launch": rd + wr,
+                  "mfma_busy_frac_in_kernel": tot["SQ_VALU_MFMA_BUSY_CYCLES"] / max(1.0, 1024 * tot["GRBM_GUI_ACTIVE"] / 8)}, indent=1))
+PY
 rm -rf gpurun_out/$out/SQ_VALU_MFMA_BUSY_CYCLES gpurun_out/$out/TCC_EA0_RDREQ_sum gpurun_out/$out/trace
 head -30 gpurun_out/$out/kernel_summary.txt; head -24 gpurun_out/$out/pmc_summary.txt

@@ -1014,11 +1014,202 @@ __global__ void conv_sv_fwd_kernel(const float* __restrict__ a, const int* __res
   }
 }
 
+// ---- A = G = 16 fast forms of the stand-alone op (the shape every shipped model uses) ------------------------------------
+// One wave per row b, the engine's lane map: lane = (a = l >> 2, gq = l & 3) owns out[b, a, 4gq..4gq+3, 0..3].  A neighbour's
+// feature row is one coalesced 1 KiB wave load, its g block (256 B) is read as four float4 per lane (16 lanes share each);
+// the row's indices sit in registers (lane-distributed), so no row load waits for an index load.  M <= 256.
+constexpr int SV_MAXW = 4;  // 64-entry index words per row
+
+struct SvRow {
+  int v[SV_MAXW];  // idx[b, 64 k + lane]
+  int n;           // real entries (rows are packed real-first: everything from the first sentinel on is padding)
+};
+__device__ __forceinline__ SvRow sv_load_row(const int* __restrict__ idx, int b, int B, int M, int lane) {
+  SvRow r;
+  r.n = M;
+#pragma unroll
+  for (int k = 0; k < SV_MAXW; ++k) {
+    const int m = 64 * k + lane;
+    r.v[k] = (m < M) ? idx[(size_t)b * M + m] : B - 1;
+  }
+#pragma unroll
+  for (int k = SV_MAXW - 1; k >= 0; --k) {
+    const unsigned long long pad = __ballot(r.v[k] >= B - 1);
+    if (pad) r.n = 64 * k + __ffsll((long long)pad) - 1;
+  }
+  r.n = min(r.n, M);
+  return r;
+}
+__device__ __forceinline__ int sv_entry(const SvRow& r, int m) {  // wave-uniform m
+  int v = 0;
+#pragma unroll
+  for (int k = 0; k < SV_MAXW; ++k)
+    if ((m >> 6) == k) v = __builtin_amdgcn_readlane(r.v[k], m & 63);
+  return v;
+}
+// first slot of row `r` that holds value x, or -1
+__device__ __forceinline__ int sv_find(const SvRow& r, int x) {
+  int pos = -1;
+#pragma unroll
+  for (int k = SV_MAXW - 1; k >= 0; --k) {
+    const unsigned long long hit = __ballot(r.v[k] == x);
+    if (hit) pos = 64 * k + __ffsll((long long)hit) - 1;
+  }
+  return (pos >= 0 && pos < r.n) ? pos : -1;
+}
+
+__global__ __launch_bounds__(256) void conv_sv_fwd16_kernel(const float* __restrict__ a, const int* __restrict__ idx,
+                                                           const float4* __restrict__ g, const float* __restrict__ a2,
+                                                           const float4* __restrict__ g2, float4* __restrict__ out, int B, int M) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int gq = lane & 3;
+  float4 acc[4];
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) acc[gi] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (b < B - 1) {
+    const SvRow r = sv_load_row(idx, b, B, M, lane);
+    auto fma4 = [&](const float4& av, const float4* gp) {
+      const float avv[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        const float4 gv = gp[gi];
+        acc[gi].x += avv[gi] * gv.x; acc[gi].y += avv[gi] * gv.y; acc[gi].z += avv[gi] * gv.z; acc[gi].w += avv[gi] * gv.w;
+      }
+    };
+    for (int m0 = 0; m0 < r.n; m0 += 4) {  // four rows in flight
+      float4 av[4], bv[4];
+      float4 gv[4][4], hv[4][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int m = min(m0 + t, r.n - 1);
+        const int j = sv_entry(r, m);
+        av[t] = reinterpret_cast<const float4*>(a + (size_t)j * 256)[lane];
+        const float4* gp = g + ((size_t)b * M + m) * 16 + 4 * gq;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) gv[t][gi] = gp[gi];
+        if (a2) {
+          bv[t] = reinterpret_cast<const float4*>(a2 + (size_t)j * 256)[lane];
+          const float4* hp = g2 + ((size_t)b * M + m) * 16 + 4 * gq;
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi) hv[t][gi] = hp[gi];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (m0 + t < r.n) {
+          fma4(av[t], gv[t]);
+          if (a2) fma4(bv[t], hv[t]);
+        }
+      }
+    }
+  }
+  float4* o = out + (size_t)b * 256 + lane * 4;
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) o[gi] = acc[gi];
+}
+
+// grad_g[b,m,g,:] = sum_a a[idx[b,m],a,g] * grad_out[b,a,g,:]: lane = (g, c) keeps grad_out[b, 0..15, g, c] in registers, the
+// neighbour's feature row goes through LDS (coalesced 1 KiB in, 16 conflict-free dword reads out)
+__global__ __launch_bounds__(256) void conv_sv_bwd_g16_kernel(const float* __restrict__ grad_out, const float* __restrict__ a,
+                                                             const int* __restrict__ idx, float* __restrict__ grad_g, int B,
+                                                             int M) {
+  __shared__ __attribute__((aligned(16))) float s_row[4][2][256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, b = blockIdx.x * 4 + wid;
+  if (b >= B) return;
+  const int gg = lane >> 2;
+  float* gout = grad_g + (size_t)b * M * 64;
+  if (b >= B - 1) {
+    for (int m = 0; m < M; ++m) gout[(size_t)m * 64 + lane] = 0.f;
+    return;
+  }
+  float go[16];
+#pragma unroll
+  for (int aa = 0; aa < 16; ++aa) go[aa] = grad_out[((size_t)b * 256 + aa * 16) * 4 + lane];
+  const SvRow r = sv_load_row(idx, b, B, M, lane);
+  float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r.n > 0) nxt = reinterpret_cast<const float4*>(a + (size_t)sv_entry(r, 0) * 256)[lane];
+  for (int m = 0; m < r.n; ++m) {
+    float* sr = s_row[wid][m & 1];
+    reinterpret_cast<float4*>(sr)[lane] = nxt;
+    if (m + 1 < r.n) nxt = reinterpret_cast<const float4*>(a + (size_t)sv_entry(r, m + 1) * 256)[lane];
+    __builtin_amdgcn_wave_barrier();
+    float acc = 0.f;
+#pragma unroll
+    for (int aa = 0; aa < 16; ++aa) acc += sr[aa * 16 + gg] * go[aa];
+    gout[(size_t)m * 64 + lane] = acc;
+  }
+  for (int m = r.n; m < M; ++m) gout[(size_t)m * 64 + lane] = 0.f;
+}
+
+// grad_a, deterministic part: the op's contract allows any idx, but the lists it is called with are symmetric (j in row b
+// <=> b in row j).  Destination row i GATHERS: for the first occurrence of every j in its own row it looks i up in row j
+// (first slot m') and adds <grad_out[j], g[j, m']> - plain stores, fixed order.  Sources this does not reach (a repeated j,
+// or a b that row j does not hold) are added by conv_sv_bwd_a16_rest_kernel with atomics, exactly as the Warp kernel adds
+// everything (conv_sv_2d_sp_wp.py:115-136); on a symmetric, duplicate-free list that kernel finds nothing to do.
+__global__ __launch_bounds__(256) void conv_sv_bwd_a16_gather_kernel(const float4* __restrict__ grad_out,
+                                                                    const int* __restrict__ idx, const float4* __restrict__ g,
+                                                                    float4* __restrict__ grad_a, int B, int M) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= B) return;
+  const int gq = lane & 3;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < B - 1) {
+    const SvRow r = sv_load_row(idx, i, B, M, lane);
+    for (int m = 0; m < r.n; ++m) {
+      const int j = sv_entry(r, m);
+      if (sv_find(r, j) != m) continue;  // a repeated neighbour: left to the atomic pass
+      const SvRow rj = sv_load_row(idx, j, B, M, lane);
+      const int mp = sv_find(rj, i);
+      if (mp < 0) continue;
+      const float4* gop = grad_out + (size_t)j * 256 + lane * 4;
+      const float4* gp = g + ((size_t)j * M + mp) * 16 + 4 * gq;
+      float d[4];
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        const float4 o = gop[gi], w = gp[gi];
+        d[gi] = o.x * w.x + o.y * w.y + o.z * w.z + o.w * w.w;
+      }
+      acc.x += d[0]; acc.y += d[1]; acc.z += d[2]; acc.w += d[3];
+    }
+  }
+  grad_a[(size_t)i * 64 + lane] = acc;
+}
+
+__global__ __launch_bounds__(256) void conv_sv_bwd_a16_rest_kernel(const float4* __restrict__ grad_out,
+                                                                  const int* __restrict__ idx, const float4* __restrict__ g,
+                                                                  float* __restrict__ grad_a, int B, int M) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B - 1) return;
+  const int gq = lane & 3;
+  const SvRow r = sv_load_row(idx, b, B, M, lane);
+  for (int m = 0; m < r.n; ++m) {
+    const int j = sv_entry(r, m);
+    bool consumed = sv_find(r, j) == m;  // the gather at j only takes the FIRST slot of b's row that names j ...
+    if (consumed) {
+      const SvRow rj = sv_load_row(idx, j, B, M, lane);
+      consumed = sv_find(rj, b) >= 0;  // ... and only if j's row names b at all
+    }
+    if (consumed) continue;
+    const float4* gop = grad_out + (size_t)b * 256 + lane * 4;
+    const float4* gp = g + ((size_t)b * M + m) * 16 + 4 * gq;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      const float4 o = gop[gi], w = gp[gi];
+      atomicAdd(&grad_a[(size_t)j * 256 + lane * 4 + gi], o.x * w.x + o.y * w.y + o.z * w.z + o.w * w.w);
+    }
+  }
+}
+
 int launch_conv_sv_fwd(hipStream_t s, const float* a, const int* idx, const float* g, float* out, int B, int A, int G,
                        int M) {
   if (B <= 0) return 0;
-  hipLaunchKernelGGL(conv_sv_fwd_kernel, dim3(B), dim3(256), 0, s, a, idx, (const float4*)g, nullptr, nullptr, (float4*)out, B,
-                     A, G, M);
+  if (A == 16 && G == 16 && M <= 64 * SV_MAXW)
+    hipLaunchKernelGGL(conv_sv_fwd16_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, a, idx, (const float4*)g, nullptr, nullptr,
+                       (float4*)out, B, M);
+  else
+    hipLaunchKernelGGL(conv_sv_fwd_kernel, dim3(B), dim3(256), 0, s, a, idx, (const float4*)g, nullptr, nullptr, (float4*)out, B,
+                       A, G, M);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }
@@ -1062,9 +1253,32 @@ __global__ void conv_sv_bwd_a_kernel(const float4* __restrict__ grad_out, const 
   }
 }
 
+#define RC_SV(call)       \
+  do {                    \
+    int _rc = (call);     \
+    if (_rc) return _rc;  \
+  } while (0)
+
+// grad_a[j] = sum over (b, m) with idx[b,m] = j of <grad_out[b], g[b,m]>: deterministic gather + atomic remainder (see the kernels)
+static int sv_bwd_a16(hipStream_t s, const float* grad_out, const int* idx, const float* g, float* grad_a, int B, int M) {
+  hipLaunchKernelGGL(conv_sv_bwd_a16_gather_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, (const float4*)grad_out, idx,
+                     (const float4*)g, (float4*)grad_a, B, M);
+  AIMNET_LAUNCH_CHECK();
+  hipLaunchKernelGGL(conv_sv_bwd_a16_rest_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, (const float4*)grad_out, idx,
+                     (const float4*)g, grad_a, B, M);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_conv_sv_bwd(hipStream_t s, const float* grad_out, const float* a, const int* idx, const float* g,
                        float* grad_a, float* grad_g, int B, int A, int G, int M) {
   if (B <= 0) return 0;
+  if (A == 16 && G == 16 && M <= 64 * SV_MAXW) {
+    hipLaunchKernelGGL(conv_sv_bwd_g16_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, grad_out, a, idx, grad_g, B, M);
+    AIMNET_LAUNCH_CHECK();
+    RC_SV(sv_bwd_a16(s, grad_out, idx, g, grad_a, B, M));
+    return 0;
+  }
   AIMNET_HIP_CHECK(hipMemsetAsync(grad_a, 0, (size_t)B * A * G * sizeof(float), s));
   hipLaunchKernelGGL(conv_sv_bwd_g_kernel, dim3(B), dim3(256), 0, s, (const float4*)grad_out, a, idx, (float4*)grad_g, B, A,
                      G, M);
@@ -1083,6 +1297,15 @@ int launch_conv_sv_bwd(hipStream_t s, const float* grad_out, const float* a, con
 int launch_conv_sv_bwd_bwd(hipStream_t s, const float* grad_out, const float* grad2_a, const float* grad2_g, const float* a,
                            const int* idx, const float* g, float* ggo, float* ga2, float* gg2, int B, int A, int G, int M) {
   if (B <= 0) return 0;
+  if (A == 16 && G == 16 && M <= 64 * SV_MAXW) {
+    hipLaunchKernelGGL(conv_sv_fwd16_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, grad2_a, idx, (const float4*)g, a,
+                       (const float4*)grad2_g, (float4*)ggo, B, M);
+    AIMNET_LAUNCH_CHECK();
+    RC_SV(sv_bwd_a16(s, grad_out, idx, grad2_g, ga2, B, M));
+    hipLaunchKernelGGL(conv_sv_bwd_g16_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, grad_out, grad2_a, idx, gg2, B, M);
+    AIMNET_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(conv_sv_fwd_kernel, dim3(B), dim3(256), 0, s, grad2_a, idx, (const float4*)g, a, (const float4*)grad2_g,
                      (float4*)ggo, B, A, G, M);
   AIMNET_LAUNCH_CHECK();

@@ -291,3 +291,41 @@ def test_mfma_4x4x1_16b_lane_layout():
         for r in range(4):
             exp[lb, r, 4 * b + col] = 4 * b + r + 1
     assert np.array_equal(got, exp)
+
+
+def _symmetric_op_inputs(seed=5, frames=12):
+    """The op's inputs as the model calls it (aev.py:163-165): a real, symmetric neighbour matrix of a molecule batch with
+    the padding row appended, sentinel = B - 1, rows packed real-first, g = the AEV basis (any values do)."""
+    c, z, mol, q = workloads.random_batch(frames, 20, 45, seed=seed)
+    dev = torch.device("cuda:0")
+    nb, num, sh, xw, (mx, ovf) = E.neighbor_list(torch.from_numpy(c).to(dev), 5.0, torch.from_numpy(mol).to(dev), max_nb=64)
+    assert ovf == 0
+    n = len(z)
+    M = int(mx)
+    idx = torch.full((n + 1, M), n, dtype=torch.int32, device=dev)
+    idx[:n] = nb[:, :M]
+    gen = torch.Generator().manual_seed(seed)
+    a = torch.randn(n + 1, 16, 16, generator=gen)
+    a[-1] = 0
+    g = torch.randn(n + 1, M, 16, 4, generator=gen)
+    go = torch.randn(n + 1, 16, 16, 4, generator=gen)
+    go[-1] = 0
+    return a, idx.cpu().long(), g, go
+
+
+def test_conv_sv_ops_on_a_symmetric_list_are_deterministic_and_exact():
+    """On the lists the model produces (symmetric, no repeated neighbour) grad_a is formed by a GATHER with plain stores - the
+    atomic remainder pass finds nothing to add - so two calls are bitwise identical (the Warp kernel's atomic scatter is not,
+    conv_sv_2d_sp_wp.py:115-136), and everything equals the einsum reference."""
+    a, idx, g, go = _symmetric_op_inputs()
+    dev = torch.device("cuda:0")
+    ad, idd, gd, god = a.to(dev), idx.to(dev), g.to(dev), go.to(dev)
+    out = E.conv_sv_2d_sp_fwd(ad, idd, gd).cpu()
+    torch.testing.assert_close(out, reference_conv_sv_2d_sp_einsum(a, idx, g), atol=1e-5, rtol=1e-4)
+    a_r, g_r = a.clone().requires_grad_(True), g.clone().requires_grad_(True)
+    reference_conv_sv_2d_sp_einsum(a_r, idx, g_r).backward(go)
+    ga1, gg1 = E.conv_sv_2d_sp_bwd(god, ad, idd, gd)
+    ga2, gg2 = E.conv_sv_2d_sp_bwd(god, ad, idd, gd)
+    assert torch.equal(ga1, ga2) and torch.equal(gg1, gg2)
+    torch.testing.assert_close(ga1.cpu(), a_r.grad, atol=1e-4, rtol=1e-3)
+    torch.testing.assert_close(gg1.cpu(), g_r.grad, atol=1e-4, rtol=1e-3)

@@ -92,6 +92,7 @@ class Inputs(C.Structure):
         ("cell", C.c_void_p),
         ("n_cell", C.c_int32),
         ("pbc", C.c_int32 * 3),
+        ("pbc_sys", C.c_void_p),
     ]
 
 

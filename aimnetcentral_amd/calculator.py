@@ -14,8 +14,7 @@ Deliberate deviations, all loud:
     file (loader.load_dftd3_tables);
   * caller-supplied neighbour matrices (`nbmat`, `nbmat_lr`, `shifts`, `shifts_lr`) raise NotImplementedError: the engine
     always builds its own lists on the device;
-  * per-system `pbc` flags of shape (B, 3) are accepted only when every system has the same flags (NotImplementedError
-    otherwise): the engine takes one periodicity triple per evaluation;
+  * (per-system `pbc` flags of shape (B, 3) are supported: the engine takes them as a device array);
   * hessian=True and hessian_vector_product are FINITE-DIFFERENCE operators over the analytic HIP forces
     (4th-order central stencil, all displaced copies evaluated as one batch), not double backward: accurate
     to ~1e-3 eV/A^2 in fp32, see `_fd_hvp`.  The analytic double-backward kernels are SURVEY 8f next-4.
@@ -435,13 +434,15 @@ class AIMNet2Calculator:
             pbc3 = (True, True, True)
             if pbc is not None:
                 p = pbc.detach().cpu().numpy().astype(bool)
-                if p.ndim == 2:
-                    if not (p == p[0]).all():
-                        raise NotImplementedError("per-system pbc flags are not supported by the native engine")
-                    p = p[0]
-                if p.shape != (3,):
+                if p.ndim == 2:  # per-system flags (normalize_pbc, neighbors.py:309-321)
+                    n_sys = 1 if (cell is None or cell.ndim == 2) else int(cell.shape[0])
+                    if p.shape != (n_sys, 3):
+                        raise ValueError(f"pbc must have shape (3,) or ({n_sys}, 3), got {tuple(p.shape)}")
+                    if (p == p[0]).all():
+                        p = p[0]
+                if p.ndim == 1 and p.shape != (3,):
                     raise ValueError("pbc must have shape (3,) or (B, 3)")
-                pbc3 = tuple(bool(x) for x in p)
+                pbc3 = tuple(bool(x) for x in p) if p.ndim == 1 else pbc.to(dtype=pbc.dtype)
             res = self.engine.eval(
                 coord_f, numbers_f, mol_idx, self._engine_charge(charge, d.get("mult")), cell=cell, pbc=pbc3, forces=bool(forces),
                 stress=bool(stress),

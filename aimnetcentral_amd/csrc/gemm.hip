@@ -521,15 +521,27 @@ static const TileCand kTileCands[] = {
     {223, 128, 96, 6},   {213, 64, 96, 3},   {222, 128, 64, 4}, {351, 80, 128, 5}, {331, 48, 128, 3},   {5, 64, 64, 1},
     {381, 128, 128, 8},  {371, 112, 128, 7}, {361, 96, 128, 6}, {341, 64, 128, 4}, {321, 32, 128, 2},   {233, 192, 96, 9},
     {412, 192, 128, 12}, {411, 176, 128, 11}, {410, 160, 128, 10}, {409, 144, 128, 9}};
+static int device_cus() {  // compute units of the current device (256 on MI355X), queried once per device
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cus[dev];
+}
+
 static int choose_tile(int M, int N, bool vec_ok) {
   if (M <= 256) return 7;  // latency regime: split-K skinny kernel (see gemm_nt_skinny_kernel)
+  const long n_cu = device_cus();
   int best = 5, best_sum = 128;
   long best_per_cu = 1;
   double best_cost = 1e300;
   for (const TileCand& c : kTileCands) {
     if (c.id != 5 && !vec_ok) continue;
     const long tiles = (long)ceil_div(M, c.tm) * ceil_div(N, c.tn);
-    const long per_cu = (tiles + 255) / 256;
+    const long per_cu = (tiles + n_cu - 1) / n_cu;
     const double x = (double)(c.tm + c.tn) / ((double)c.tm * c.tn);
     double eff = 0.9 / (1.0 + 5.0 * x);
     if (per_cu == 1 && c.acc_tiles <= 10) eff *= 0.88;

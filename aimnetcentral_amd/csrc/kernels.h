@@ -40,7 +40,7 @@ int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, 
                      int* bad = nullptr);  // bad: input sanity flags (bit 0 atomic number outside [0,63], bit 1 mol_idx outside [0,n_mol))
 // wrap coordinates (periodic) or copy them (non-periodic) into b.xw
 int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
-                int n_cell, const int pbc[3], NlistBuffers& b);
+                int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys = nullptr);  // pbc_sys: device [n_cell][3] or NULL
 // non-periodic systems: give every molecule the cell grid of its bounding box (after launch_wrap), so that launch_nlist
 // takes the cell-list path instead of the O(n^2) per-molecule scan; worth it from ~10^3 atoms per molecule
 int launch_bbox(hipStream_t s, int n_mol, NlistBuffers& b);

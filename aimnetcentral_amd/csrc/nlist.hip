@@ -86,8 +86,9 @@ int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// pbc_sys (may be NULL): per-system periodicity flags [n_cell][3] (normalize_pbc, neighbors.py:309-321) overriding p0..p2
 __global__ void cell_setup_kernel(const float* __restrict__ cell, int n_cell, int n_mol, int p0, int p1, int p2,
-                                  NlistSystem* __restrict__ sys) {
+                                  const int* __restrict__ pbc_sys, NlistSystem* __restrict__ sys) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_mol) return;
   const float* c = cell + (n_cell == 1 ? 0 : (size_t)s * 9);
@@ -132,9 +133,10 @@ __global__ void cell_setup_kernel(const float* __restrict__ cell, int n_cell, in
   }
   S.lam = (float)(lam * 1.0001);
   S.o[0] = S.o[1] = S.o[2] = 0.0f;
-  S.per[0] = p0;
-  S.per[1] = p1;
-  S.per[2] = p2;
+  const int* ps = pbc_sys ? pbc_sys + (n_cell == 1 ? 0 : (size_t)s * 3) : nullptr;
+  S.per[0] = ps ? (ps[0] != 0) : p0;
+  S.per[1] = ps ? (ps[1] != 0) : p1;
+  S.per[2] = ps ? (ps[2] != 0) : p2;
   S.bin_offset = 0;
   S.n_bins = 1;
   sys[s] = S;
@@ -210,12 +212,12 @@ __global__ void wrap_kernel(const float* __restrict__ coord, const int* __restri
 }
 
 int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
-                int n_cell, const int pbc[3], NlistBuffers& b) {
+                int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys) {
   NlistSystem* sys = nullptr;
   if (cell != nullptr) {
     sys = (NlistSystem*)b.sys;
     hipLaunchKernelGGL(cell_setup_kernel, dim3(ceil_div(n_mol, 64)), dim3(64), 0, s, cell, n_cell, n_mol, pbc[0], pbc[1],
-                       pbc[2], sys);
+                       pbc[2], pbc_sys, sys);
     AIMNET_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(wrap_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, coord, mol_idx, n_atoms, sys, b.xw);

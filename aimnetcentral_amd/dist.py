@@ -38,20 +38,35 @@ def local_batch(coord, numbers, mol_idx, charge, lo: int, hi: int):
     return np.asarray(coord)[sel], np.asarray(numbers)[sel], mol_idx[sel] - lo, np.asarray(charge)[lo:hi]
 
 
+_GATHER_BUFFERS: dict = {}  # (device, dtype, world, nmax) -> (send, recv): a per-step collective must not time allocations
+
+
+def _gather_buffers(device, dtype, world: int, nmax: int):
+    import torch
+
+    key = (str(device), dtype, world, nmax)
+    if key not in _GATHER_BUFFERS:
+        _GATHER_BUFFERS[key] = (torch.zeros(nmax, dtype=dtype, device=device), torch.empty(world * nmax, dtype=dtype, device=device))
+    return _GATHER_BUFFERS[key]
+
+
 def all_gather_energies(energy_local, frames_per_rank: list[int], group=None):
     """All-gather per-frame energies (fp64) from every rank: returns a tensor [sum(frames_per_rank)]
-    in global frame order.  Ragged counts are padded to the maximum (one fixed-size collective)."""
+    in global frame order.  Ragged counts are padded to the maximum (one fixed-size collective).  The padded send buffer
+    and the receive buffer are allocated once per (device, world, size) and reused; when every rank holds the same number of
+    frames (the bench's weak-scaling layout) the result is a view of the receive buffer - valid until the next call."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     nmax = max(frames_per_rank)
-    buf = torch.zeros(nmax, dtype=torch.float64, device=energy_local.device)
+    buf, out = _gather_buffers(energy_local.device, torch.float64, world, nmax)
     buf[: energy_local.shape[0]] = energy_local
-    out = torch.empty(world * nmax, dtype=torch.float64, device=energy_local.device)
     dist.all_gather_into_tensor(out, buf, group=group)
-    out = out.view(world, nmax)
-    return torch.cat([out[r, : frames_per_rank[r]] for r in range(world)])
+    if all(f == nmax for f in frames_per_rank):
+        return out
+    v = out.view(world, nmax)
+    return torch.cat([v[r, : frames_per_rank[r]] for r in range(world)])
 
 
 def all_gather_atoms(x_local, atoms_per_rank: list[int], group=None):

@@ -226,6 +226,14 @@ class HipEngine:
         if cell is not None:
             cell = cell.to(device=dev, dtype=torch.float32).contiguous()
             n_cell = 1 if cell.ndim == 2 else cell.shape[0]
+        # pbc: three flags, or per-system flags [n_cell, 3] (tensor / array): normalize_pbc, neighbors.py:309-321
+        pbc_sys = None
+        if cell is not None and not isinstance(pbc, (tuple, list)) and getattr(pbc, "ndim", 1) == 2:
+            pbc_sys = torch.as_tensor(pbc).to(device=dev, dtype=torch.int32).contiguous()
+            if tuple(pbc_sys.shape) != (n_cell, 3):
+                raise ValueError(f"pbc must have shape (3,) or ({n_cell}, 3), got {tuple(pbc_sys.shape)}")
+        elif not isinstance(pbc, (tuple, list)):
+            pbc = tuple(bool(x) for x in torch.as_tensor(pbc).reshape(-1).tolist())
         method = {"none": _lib.COULOMB_NONE, "simple": _lib.COULOMB_SIMPLE, "dsf": _lib.COULOMB_DSF}[coulomb]
         # one allocation for status + every output (16-byte aligned sections); status is zeroed by the engine
         sections = [("status", torch.int32, (8,)), ("energy", torch.float64, (n_mol,)), ("charges", torch.float32, (n,))]
@@ -287,8 +295,14 @@ class HipEngine:
             inp.coord, inp.numbers, inp.mol_idx, inp.charge = coord.data_ptr(), numbers.data_ptr(), mol_idx.data_ptr(), charge.data_ptr()
             inp.cell = cell.data_ptr() if cell is not None else None
             inp.n_cell = n_cell
-            for k in range(3):
-                inp.pbc[k] = 1 if bool(pbc[k]) else 0
+            if pbc_sys is not None:
+                inp.pbc_sys = pbc_sys.data_ptr()
+                for k in range(3):
+                    inp.pbc[k] = 1
+            else:
+                inp.pbc_sys = None
+                for k in range(3):
+                    inp.pbc[k] = 1 if bool(pbc[k]) else 0
             out = _lib.Outputs()
             out.energy, out.charges = energy.data_ptr(), charges.data_ptr()
             out.forces = f_out.data_ptr() if f_out is not None else None

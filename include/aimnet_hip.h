@@ -99,6 +99,8 @@ typedef struct aimnet_inputs {
   const float* cell;       /* [n_cell, 3, 3] row vectors, or NULL (non-periodic) */
   int32_t n_cell;          /* 0, 1 (shared) or n_mol */
   int32_t pbc[3];          /* periodic axes (used when cell != NULL) */
+  const int32_t* pbc_sys;  /* device, [n_cell, 3] or NULL: per-system periodic axes (normalize_pbc, neighbors.py:309-321);
+                              overrides pbc[] */
 } aimnet_inputs;
 
 typedef struct aimnet_eval_options {

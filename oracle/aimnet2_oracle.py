@@ -83,7 +83,8 @@ def neighbor_list(coord, cutoff: float, mol_idx, cell=None, pbc=None):
             continue
         cells = np.asarray(cell, dtype=np.float64)
         c = cells if cells.ndim == 2 else cells[mol[a]]
-        pb = np.ones(3, dtype=bool) if pbc is None else np.asarray(pbc, dtype=bool).reshape(-1, 3)[0]
+        pba = np.ones((1, 3), dtype=bool) if pbc is None else np.asarray(pbc, dtype=bool).reshape(-1, 3)
+        pb = pba[mol[a]] if pba.shape[0] > 1 else pba[0]  # per-system flags (normalize_pbc, neighbors.py:309-321)
         vol = abs(np.linalg.det(c))
         nimg = []
         for k in range(3):
@@ -137,7 +138,8 @@ def neighbor_list_fast(coord, cutoff: float, mol_idx, cell=None, pbc=None):
         else:
             cells = np.asarray(cell, dtype=np.float64)
             c = cells if cells.ndim == 2 else cells[mol[a]]
-            pb = np.ones(3, dtype=bool) if pbc is None else np.asarray(pbc, dtype=bool).reshape(-1, 3)[0]
+            pba = np.ones((1, 3), dtype=bool) if pbc is None else np.asarray(pbc, dtype=bool).reshape(-1, 3)
+            pb = pba[mol[a]] if pba.shape[0] > 1 else pba[0]
             vol = abs(np.linalg.det(c))
             nimg = []
             for k in range(3):

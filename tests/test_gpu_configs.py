@@ -228,3 +228,30 @@ def test_deferred_status_and_capacity_hysteresis(oracle32):
     assert eng.max_nb >= 24
     again = npy(calc(data, forces=True))  # the synchronous path retries by itself and lands on the same answer
     assert np.array_equal(again["forces"], sync["forces"])
+
+
+def test_per_system_pbc_flags(oracle32, oracle64):
+    """normalize_pbc (neighbors.py:309-321): `pbc` of shape (B, 3) - two copies of the glucose cell, one fully periodic, one a slab
+    (periodic in x and z only) - against the oracle with the same per-system flags, forces and stress included."""
+    from aimnetcentral_amd import AIMNet2Calculator, loader
+
+    calc = AIMNet2Calculator(loader.synthetic_spec(0), device="cuda:0")
+    c, z, cell = workloads.glucose_cell()
+    cc = np.concatenate([c, c + 0.01]).astype(np.float32)
+    zz = np.concatenate([z, z])
+    mol = np.repeat(np.arange(2), len(z))
+    cells = np.stack([cell, cell]).astype(np.float32)
+    pbc = np.array([[True, True, True], [True, False, True]])
+    calc.set_lrcoulomb_method("dsf", cutoff=9.0, dsf_alpha=0.25)
+    out = npy(calc({"coord": cc, "numbers": zz, "mol_idx": mol, "charge": np.zeros(2, np.float32), "cell": cells, "pbc": pbc},
+                   forces=True, stress=True))
+    kw = dict(cell=cells, pbc=pbc, coulomb="dsf", dsf_rc=9.0, dsf_alpha=0.25)
+    ref = O.evaluate(oracle32, cc, zz, np.zeros(2, np.float32), mol, stress=True, **kw)
+    e64 = O.evaluate(oracle64, cc, zz, np.zeros(2, np.float32), mol, forces=False, **kw)["energy"]
+    tol = energy_tol(96) + np.abs(ref["energy"] - e64)
+    assert (np.abs(out["energy"] - ref["energy"]) <= tol).all()
+    assert_forces_close(out["forces"], ref["forces"], "per-system pbc")
+    assert np.abs(out["charges"] - ref["charges"]).max() <= CHARGE_ATOL
+    assert np.abs(out["stress"] - ref["stress"]).max() <= STRESS_ATOL
+    same = npy(calc({"coord": c.astype(np.float32), "numbers": z, "charge": 0.0, "cell": cell.astype(np.float32)}, forces=True))
+    assert abs(same["energy"][0] - out["energy"][0]) < 1e-4 and abs(out["energy"][1] - out["energy"][0]) > 1e-3

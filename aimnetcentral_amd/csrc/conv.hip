@@ -23,6 +23,21 @@
 
 namespace aimnet {
 
+// LDS hand-off between the lanes of ONE wave (the staging buffers of the one-wave-per-atom kernels are private to the wave): LDS
+// operations of a wave execute in order, so only the compiler has to be kept from reordering - no s_barrier.  With block
+// barriers the four waves of a block (four atoms with 60-80 neighbours each) ran every chunk in lock step: each block iteration
+// cost the slowest atom, and the waves' memory phases could not drift apart (-2 to -4 % on the two kernels).  SPLIT kernels share
+// data between waves and keep the real barrier.
+template <bool BLOCK>
+__device__ __forceinline__ void lds_sync() {
+  if (BLOCK) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-wave LDS scratch of the forward kernel
 struct FwdWaveLds {
@@ -74,18 +89,12 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
     const int i = live_atom ? (order ? order[i0 + aslot] : i0 + aslot) : 0;  // `order`: spatially sorted processing order
     const int cnt_all = live_atom ? nb_cnt[i] : 0;
     int m_lo = 0, cnt = cnt_all;
-    int cmax = cnt;  // block-uniform trip count so that __syncthreads() is legal
+    int cmax = cnt;  // SPLIT: block-uniform trip count so that __syncthreads() is legal; otherwise the wave's own count
     if (SPLIT) {
       const int q4 = (cnt_all + 3) >> 2;
       m_lo = wid * q4;
       cnt = max(0, min(q4, cnt_all - m_lo));
       cmax = q4;
-    } else {
-#pragma unroll
-      for (int w = 0; w < APB; ++w) {
-        const int iw = i0 + w;
-        cmax = max(cmax, iw < al.last ? nb_cnt[order ? order[iw] : iw] : 0);
-      }
     }
     f2 acc[4][2];  // [component c][shift pair]: 2-wide vectors -> v_pk_fma_f32
 #pragma unroll
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
 
     for (int c0 = 0; c0 < cmax; c0 += CH) {
       const int nch = max(0, min(CH, cnt - c0));
-      __syncthreads();  // previous chunk fully consumed
+      lds_sync<SPLIT>();  // previous chunk fully consumed
       if (lane < nch) {
         const size_t p = (size_t)i * cap + m_lo + c0 + lane;
         const int j = nb_idx[p];
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
 #pragma unroll
         for (int ch = 0; ch < NQ; ++ch) L.qj[ch][lane] = 0.f;
       }
-      __syncthreads();
+      lds_sync<SPLIT>();
 #pragma unroll
       for (int t = 0; t < CH * G_ / 64; ++t) {
         const int e = lane + 64 * t;
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
         }
         L.gs[mm][g] = v;
       }
-      __syncthreads();
+      lds_sync<SPLIT>();
       // 4-deep software pipeline over the neighbour rows: the kernel is latency-bound (25 VALU
       // instructions per 1 KiB row), so keep four row loads in flight per wave
       const int qc_f = lane & 3;
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
         use(mm, c0); use(mm + 1, c1); use(mm + 2, c2); use(mm + 3, c3);
       }
     }
-    __syncthreads();
+    lds_sync<SPLIT>();
     if (SPLIT) {  // waves 1..3 hand their 16 + NQ partial sums per lane to wave 0
       if (wid > 0) {
         float* r = s_red + (wid - 1) * (16 + NQC) * 64 + lane;
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
 #pragma unroll
         for (int ch = 0; ch < NQC; ++ch) r[(16 + ch) * 64] = accq[ch];
       }
-      __syncthreads();
+      lds_sync<SPLIT>();
       if (wid == 0) {
 #pragma unroll
         for (int w = 0; w < 3; ++w) {
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
       reinterpret_cast<float4*>(xr)[lane] = reinterpret_cast<const float4*>(a + (size_t)ri * NF)[lane];
       reinterpret_cast<float4*>(xr + NF)[lane] = make_float4(acc[0][0].x, acc[0][0].y, acc[0][1].x, acc[0][1].y);
     }
-    __syncthreads();
+    lds_sync<SPLIT>();
     if (live) {
       float* xr = x + (size_t)i * ldx;
       // one-wave-per-atom form: rolled, the contraction keeps the kernel at 128 VGPRs with 6 spilled dwords instead of 22
@@ -456,12 +465,6 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
       m_lo = wid * q4;
       cnt = max(0, min(q4, cnt_all - m_lo));
       cmax = q4;
-    } else {
-#pragma unroll
-      for (int w = 0; w < APB; ++w) {
-        const int iw = i0 + w;
-        cmax = max(cmax, iw < al.last ? nb_cnt[order ? order[iw] : iw] : 0);
-      }
     }
     // centre atom's own rows
     // [half]: gi pair (0,1) / (2,3);  Si[c][half]: component c of the centre's Sbar row
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
 
     for (int c0 = 0; c0 < cmax; c0 += CHB) {
       const int nch = max(0, min(CHB, cnt - c0));
-      __syncthreads();
+      lds_sync<SPLIT>();
       if (lane < nch) {
         const size_t p = (size_t)i * cap + m_lo + c0 + lane;
         const int j = nb_idx[p];
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
 #pragma unroll
         for (int ch = 0; ch < NQ; ++ch) L.qj[ch][lane] = q[(size_t)ch * n_atoms + j];
       }
-      __syncthreads();
+      lds_sync<SPLIT>();
 #pragma unroll
       for (int t = 0; t < CHB * G_ / 64; ++t) {
         const int e = lane + 64 * t;
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
         L.gs[mm][g] = v;
         L.dgs[mm][g] = dv;
       }
-      __syncthreads();
+      lds_sync<SPLIT>();
       // software pipeline: the 80 B per lane of neighbour mm+1 are requested before neighbour mm is
       // consumed, so the L2 / Infinity-Cache latency of the gather hides under ~110 VALU instructions
       float4 n_aj, n_s0, n_s1, n_s2, n_s3;
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
       for (int k = 0; k < 9; ++k) W[k] = wave_sum(W[k]);
     }
     if (SPLIT) {  // waves 1..3 hand their partial sums to wave 0, which writes
-      __syncthreads();
+      lds_sync<SPLIT>();
       if (wid > 0) {
         float* r = s_red + (wid - 1) * (4 * 64 + 14);
         r[lane] = ab[0].x; r[64 + lane] = ab[0].y; r[128 + lane] = ab[1].x; r[192 + lane] = ab[1].y;
@@ -642,7 +645,7 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
           for (int k = 0; k < 9; ++k) r[261 + k] = W[k];
         }
       }
-      __syncthreads();
+      lds_sync<SPLIT>();
       if (wid == 0) {
 #pragma unroll
         for (int w = 0; w < 3; ++w) {

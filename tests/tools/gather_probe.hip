@@ -13,7 +13,7 @@
 #include <vector>
 
 // SPLIT: the four waves of a block share one centre atom (a quarter of its row each) instead of taking one atom each
-template <int WPS, int RING, int ROWF4, int SPLIT>  // SPLIT 2: the four waves of a block all gather the SAME atom's full list (L1 sharing test); ROWF4: float4 loads per lane per row (5 = bwd: 5 KiB rows, 1 = fwd: 1 KiB rows)
+template <int WPS, int RING, int ROWF4, int SPLIT, int TABLES = 0, int GRIDX = 1>  // TABLES 1: a / Sbar / Sqbar as three arrays like the engine (ROWF4 = 5 + a dword); GRIDX: grid = GRIDX x resident blocks; SPLIT 2: the four waves of a block all gather the SAME atom's full list (L1 sharing test); ROWF4: float4 loads per lane per row (5 = bwd: 5 KiB rows, 1 = fwd: 1 KiB rows)
 __global__ __launch_bounds__(256, WPS) void probe(const float4* __restrict__ tab, const int* __restrict__ nb_idx,
                                                  const int* __restrict__ nb_cnt, int cap, int n_atoms, const int* __restrict__ order,
                                                  float* __restrict__ out) {
@@ -37,12 +37,67 @@ __global__ __launch_bounds__(256, WPS) void probe(const float4* __restrict__ tab
     // load, vmcnt is in-order and that would drain the ring
     const int jv0 = row[min(lane, cnt - 1)], jv1 = row[min(lane + 64, cnt - 1)];
     float4 r[RING][ROWF4];
+    float rq[RING];
     auto load = [&](int m, int s) {
       const int mm = min(m, cnt - 1);
       const int j = mm < 64 ? __builtin_amdgcn_readlane(jv0, mm) : __builtin_amdgcn_readlane(jv1, mm - 64);
-      const float4* p = tab + (size_t)j * (64 * ROWF4) + lane;
+      if (TABLES == 0) {
+        const float4* p = tab + (size_t)j * (64 * ROWF4) + lane;
 #pragma unroll
-      for (int k = 0; k < ROWF4; ++k) r[s][k] = p[64 * k];
+        for (int k = 0; k < ROWF4; ++k) r[s][k] = p[64 * k];
+        rq[s] = 0.f;
+      } else {  // Sbar rows first in the buffer (n_atoms x 4 KiB), then a (n_atoms x 1 KiB), then Sqbar (n_atoms x 256 B)
+        const float4* ps = tab + (size_t)j * 256 + lane;
+        const float4* pa = tab + (size_t)n_atoms * 256 + (size_t)j * 64 + lane;
+        const float* pq = reinterpret_cast<const float*>(tab + (size_t)n_atoms * 320) + (size_t)j * 64 + lane;
+        r[s][0] = pa[0];
+#pragma unroll
+        for (int k = 1; k < ROWF4; ++k) r[s][k] = ps[64 * (k - 1)];
+        rq[s] = pq[0];
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) load(s, s);
+    for (int m0 = 0; m0 < cnt; m0 += RING) {
+#pragma unroll
+      for (int s = 0; s < RING; ++s) {
+        load(m0 + s + RING - 1, (s + RING - 1) % RING);
+        if (m0 + s < cnt) {
+#pragma unroll
+          for (int k = 0; k < ROWF4; ++k) acc += (r[s][k].x + r[s][k].y) + (r[s][k].z + r[s][k].w);
+          acc += rq[s];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+template <int WPS, int RING, int ROWF4>
+__global__ __launch_bounds__(256, WPS) void probe_cluster(const float4* __restrict__ tab, const int* __restrict__ u_idx,
+                                                         const int* __restrict__ u_cnt, int ucap, int n_clusters, int n_atoms,
+                                                         float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nb = gridDim.x, b = blockIdx.x;
+  const int xcd = b & 7, slot = b >> 3, per = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0);
+  const int nblk = (n_clusters + 3) / 4, chunk = (nblk + 7) >> 3, lo = xcd * chunk, hi = min(nblk, lo + chunk);
+  float acc = 0.f;
+  for (int ib = lo + slot; ib < hi; ib += per) {
+    const int cl = ib * 4 + wid;
+    if (cl >= n_clusters) continue;
+    const int cnt = __builtin_amdgcn_readfirstlane(u_cnt[cl]);
+    const int* row = u_idx + (size_t)cl * ucap;
+    __shared__ int s_idx[4][512];
+    for (int k = lane; k < cnt; k += 64) s_idx[wid][k] = row[k];  // indices staged in LDS: a row load must never wait behind an index load (vmcnt is in-order)
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    float4 r[RING][ROWF4];
+    auto load = [&](int m, int s) {
+      const int j = __builtin_amdgcn_readfirstlane(s_idx[wid][min(m, cnt - 1)]);
+      const float4* ps = tab + (size_t)j * 256 + lane;
+#pragma unroll
+      for (int k = 0; k < ROWF4; ++k) r[s][k] = ps[64 * k];
     };
 #pragma unroll
     for (int s = 0; s < RING - 1; ++s) load(s, s);
@@ -61,21 +116,37 @@ __global__ __launch_bounds__(256, WPS) void probe(const float4* __restrict__ tab
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
-template <int WPS, int RING, int ROWF4, int SPLIT>
-void run(const float4* tab, const int* idx, const int* cnt, int cap, int n, const int* order, const char* oname, float* out, long pairs) {
-  const int resident = 256 * WPS;  // blocks of 4 waves: WPS waves per SIMD = WPS blocks per CU
-  const int grid = std::min(SPLIT ? n : (n + 3) / 4, resident);
+template <int WPS, int RING, int ROWF4>
+void run_cluster(const float4* tab, const int* u_idx, const int* u_cnt, int ucap, int ncl, int n, float* out, long entries, long pairs) {
+  const int grid = std::min((ncl + 3) / 4, 256 * WPS);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int w = 0; w < 2; ++w) probe<WPS, RING, ROWF4, SPLIT><<<grid, 256>>>(tab, idx, cnt, cap, n, order, out);
+  for (int w = 0; w < 2; ++w) probe_cluster<WPS, RING, ROWF4><<<grid, 256>>>(tab, u_idx, u_cnt, ucap, ncl, n, out);
   hipEventRecord(e0);
-  for (int w = 0; w < 10; ++w) probe<WPS, RING, ROWF4, SPLIT><<<grid, 256>>>(tab, idx, cnt, cap, n, order, out);
+  for (int w = 0; w < 10; ++w) probe_cluster<WPS, RING, ROWF4><<<grid, 256>>>(tab, u_idx, u_cnt, ucap, ncl, n, out);
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  printf("CLUSTER of 4: row %d KiB  waves/SIMD %d  ring %d: %ld union entries for %ld pairs (sharing %.2f): %7.1f us  %6.2f TB/s\n", ROWF4, WPS, RING,
+         entries, pairs, (double)pairs / entries, ms * 100.0, (double)entries * ROWF4 * 1024 / (ms * 100.0) * 1e-6);
+}
+
+template <int WPS, int RING, int ROWF4, int SPLIT, int TABLES = 0, int GRIDX = 1>
+void run(const float4* tab, const int* idx, const int* cnt, int cap, int n, const int* order, const char* oname, float* out, long pairs) {
+  const int resident = 256 * WPS;  // blocks of 4 waves: WPS waves per SIMD = WPS blocks per CU
+  const int grid = std::min(SPLIT ? n : (n + 3) / 4, resident * GRIDX);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int w = 0; w < 2; ++w) probe<WPS, RING, ROWF4, SPLIT, TABLES, GRIDX><<<grid, 256>>>(tab, idx, cnt, cap, n, order, out);
+  hipEventRecord(e0);
+  for (int w = 0; w < 10; ++w) probe<WPS, RING, ROWF4, SPLIT, TABLES, GRIDX><<<grid, 256>>>(tab, idx, cnt, cap, n, order, out);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 100.0, bytes = (double)pairs * ROWF4 * 1024 * (SPLIT == 2 ? 4 : 1);
-  printf("row %d KiB  waves/SIMD %d  ring %d  %s  order %-10s centres in flight per XCD %4d: %7.1f us  %6.2f TB/s\n", ROWF4, WPS, RING,
+  printf("row %d KiB %s grid x%d  waves/SIMD %d  ring %d  %s  order %-10s centres in flight per XCD %4d: %7.1f us  %6.2f TB/s\n", ROWF4, TABLES ? "3 tables" : "1 table ", GRIDX, WPS, RING,
          SPLIT == 2 ? "dup4   " : SPLIT ? "split4 " : "1w/atom", oname, 32 * WPS * (SPLIT ? 1 : 4), us, bytes / us * 1e-6);
 }
 
@@ -126,8 +197,8 @@ int main() {
   }
   printf("%d atoms, %.1f neighbours on average, %ld ordered pairs\n", n, (double)pairs / n, pairs);
   float4* tab; int *didx, *dcnt; float* out;
-  hipMalloc(&tab, (size_t)n * 5 * 1024); hipMemset(tab, 0, (size_t)n * 5 * 1024);
-  hipMalloc(&didx, idx.size() * 4); hipMalloc(&dcnt, n * 4); hipMalloc(&out, 2048 * 256 * 4);
+  hipMalloc(&tab, (size_t)n * 6 * 1024); hipMemset(tab, 0, (size_t)n * 6 * 1024);
+  hipMalloc(&didx, idx.size() * 4); hipMalloc(&dcnt, n * 4); hipMalloc(&out, (size_t)16384 * 256 * 4);
   hipMemcpy(didx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(dcnt, cnt.data(), n * 4, hipMemcpyHostToDevice);
   // processing orders.  "bin": identity (atoms are numbered in bin order, x fastest; XCD x takes the x-th eighth of it).
@@ -153,8 +224,62 @@ int main() {
   hipMemcpy(d_bin, o_bin.data(), n * 4, hipMemcpyHostToDevice);
   hipMemcpy(d_col, o_col.data(), n * 4, hipMemcpyHostToDevice);
 #define R(W, G, F, SP, O) run<W, G, F, SP>(tab, didx, dcnt, cap, n, O == 0 ? d_bin : d_col, O == 0 ? "bin" : "boxcol", out, pairs)
-  R(4, 1, 5, 0, 0); R(4, 1, 5, 0, 1); R(4, 1, 5, 1, 0); R(4, 1, 5, 1, 1); R(4, 1, 5, 2, 0);
-  R(4, 2, 5, 0, 0); R(2, 2, 5, 0, 0); R(2, 4, 5, 0, 0); R(2, 4, 5, 1, 1); R(2, 8, 5, 0, 0); R(1, 8, 5, 1, 1); R(8, 1, 5, 0, 0);
-  R(4, 4, 1, 0, 0); R(4, 8, 1, 0, 0); R(8, 4, 1, 0, 0); R(8, 8, 1, 0, 0); R(4, 4, 1, 2, 0);
+  R(4, 1, 5, 0, 0); R(4, 2, 5, 0, 0); R(2, 2, 5, 0, 0); R(2, 4, 5, 0, 0); R(3, 2, 5, 0, 0); R(3, 3, 5, 0, 0);
+#define R2(W, G, TB, GX) run<W, G, 5, 0, TB, GX>(tab, didx, dcnt, cap, n, d_bin, "bin", out, pairs)
+  R2(4, 1, 1, 1); R2(4, 1, 0, 2); R2(4, 1, 1, 2); R2(4, 2, 1, 1); R2(2, 2, 1, 1); R2(2, 4, 1, 1); R2(3, 2, 1, 1);
+  {  // the ENGINE's own lists and processing order (tests/tools/dump_lists.py), if present
+    FILE* fm = fopen("gpurun_in/lists/meta.txt", "r");
+    if (fm) {
+      int rn = 0, rcap = 0;
+      if (fscanf(fm, "%d %d", &rn, &rcap) == 2) {
+        std::vector<int> ridx((size_t)rn * rcap), rcnt(rn), rord(rn);
+        FILE* f1 = fopen("gpurun_in/lists/nb_idx.bin", "rb"); FILE* f2 = fopen("gpurun_in/lists/nb_cnt.bin", "rb"); FILE* f3 = fopen("gpurun_in/lists/order.bin", "rb");
+        size_t got = fread(ridx.data(), 4, ridx.size(), f1) + fread(rcnt.data(), 4, rn, f2) + fread(rord.data(), 4, rn, f3);
+        (void)got;
+        long rp = 0; for (int v : rcnt) rp += v;
+        int *e_idx, *e_cnt, *e_ord, *e_id;
+        hipMalloc(&e_idx, ridx.size() * 4); hipMalloc(&e_cnt, rn * 4); hipMalloc(&e_ord, rn * 4); hipMalloc(&e_id, rn * 4);
+        hipMemcpy(e_idx, ridx.data(), ridx.size() * 4, hipMemcpyHostToDevice); hipMemcpy(e_cnt, rcnt.data(), rn * 4, hipMemcpyHostToDevice);
+        hipMemcpy(e_ord, rord.data(), rn * 4, hipMemcpyHostToDevice);
+        std::vector<int> ident(rn); for (int i = 0; i < rn; ++i) ident[i] = i;
+        hipMemcpy(e_id, ident.data(), rn * 4, hipMemcpyHostToDevice);
+        printf("engine lists: %d atoms, cap %d, %ld pairs\n", rn, rcap, rp);
+#define RE(W, G, TB, GX, ORD, NAME) run<W, G, 5, 0, TB, GX>(tab, e_idx, e_cnt, rcap, rn, ORD, NAME, out, rp)
+        RE(4, 1, 1, 2, e_ord, "eng-bin"); RE(2, 2, 1, 1, e_ord, "eng-bin"); RE(2, 3, 1, 1, e_ord, "eng-bin"); RE(2, 4, 1, 1, e_ord, "eng-bin");
+        RE(1, 4, 1, 1, e_ord, "eng-bin"); RE(1, 8, 1, 1, e_ord, "eng-bin"); RE(3, 2, 1, 1, e_ord, "eng-bin");
+        {  // clusters of 4 consecutive atoms in processing order, union of their rows (by neighbour index)
+          const int ncl = (rn + 3) / 4, ucap = 4 * rcap;
+          std::vector<int> uidx((size_t)ncl * ucap, 0), ucnt(ncl, 0);
+          long entries = 0;
+          for (int c = 0; c < ncl; ++c) {
+            std::vector<int> u;
+            for (int k = 0; k < 4 && 4 * c + k < rn; ++k) {
+              const int i = rord[4 * c + k];
+              for (int m = 0; m < rcnt[i]; ++m) u.push_back(ridx[(size_t)i * rcap + m]);
+            }
+            std::sort(u.begin(), u.end());
+            u.erase(std::unique(u.begin(), u.end()), u.end());
+            ucnt[c] = (int)u.size();
+            entries += ucnt[c];
+            std::copy(u.begin(), u.end(), uidx.begin() + (size_t)c * ucap);
+          }
+          int *d_ui, *d_uc;
+          hipMalloc(&d_ui, uidx.size() * 4); hipMalloc(&d_uc, ncl * 4);
+          hipMemcpy(d_ui, uidx.data(), uidx.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_uc, ucnt.data(), ncl * 4, hipMemcpyHostToDevice);
+          run_cluster<2, 2, 4>(tab, d_ui, d_uc, ucap, ncl, rn, out, entries, rp);
+          run_cluster<2, 3, 4>(tab, d_ui, d_uc, ucap, ncl, rn, out, entries, rp);
+          run_cluster<2, 4, 4>(tab, d_ui, d_uc, ucap, ncl, rn, out, entries, rp);
+          run_cluster<3, 3, 4>(tab, d_ui, d_uc, ucap, ncl, rn, out, entries, rp);
+          run_cluster<1, 6, 4>(tab, d_ui, d_uc, ucap, ncl, rn, out, entries, rp);
+          run_cluster<2, 4, 1>(tab, d_ui, d_uc, ucap, ncl, rn, out, entries, rp);
+          run_cluster<2, 8, 1>(tab, d_ui, d_uc, ucap, ncl, rn, out, entries, rp);
+          run_cluster<4, 8, 1>(tab, d_ui, d_uc, ucap, ncl, rn, out, entries, rp);
+        }
+#define RS(W, G, GX) run<W, G, 5, 1, 1, GX>(tab, e_idx, e_cnt, rcap, rn, e_ord, "eng-bin", out, rp)
+        RS(4, 1, 1); RS(4, 2, 1); RS(2, 2, 1); RS(2, 4, 1); RS(3, 2, 1); RS(4, 1, 8);
+      }
+      fclose(fm);
+    }
+  }
   return 0;
 }

@@ -28,15 +28,7 @@ namespace aimnet {
 // barriers the four waves of a block (four atoms with 60-80 neighbours each) ran every chunk in lock step: each block iteration
 // cost the slowest atom, and the waves' memory phases could not drift apart (-2 to -4 % on the two kernels).  SPLIT kernels share
 // data between waves and keep the real barrier.
-template <bool BLOCK>
-__device__ __forceinline__ void lds_sync() {
-  if (BLOCK) {
-    __syncthreads();
-  } else {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
+// (lds_sync<BLOCK>() itself lives in conv_common.h)
 
 // ------------------------------------------------------------------------------------------------
 // per-wave LDS scratch of the forward kernel

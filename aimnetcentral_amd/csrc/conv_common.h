@@ -51,5 +51,25 @@ __device__ __forceinline__ float basis_fc(const BasisParams& bp, float d, float&
   return 0.5f * (cs + 1.0f);
 }
 
+// hand-off of per-wave LDS data: a block barrier when waves share it, otherwise a wave-level fence (no s_barrier)
+template <bool BLOCK>
+__device__ __forceinline__ void lds_sync() {
+  if (BLOCK) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products, A: lane 4b + r, B: lane 4b + col, C: VGPR r of lane 4b + col
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp0(float v) {  // DPP move, lanes without a source read 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 
 }  // namespace aimnet

@@ -26,14 +26,6 @@
 
 namespace aimnet {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
-
-template <int CTRL>
-__device__ __forceinline__ float dpp0(float v) {  // DPP move, lanes without a source read 0
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
 
 // ------------------------------------------------------------------------------------------------
 // Neighbours staged per chunk: a multiple of the ring depth that covers a whole 5 A row of a molecular crystal, so the row

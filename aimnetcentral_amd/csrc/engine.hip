@@ -68,6 +68,13 @@ struct aimnet_engine {
   // Measured on config 3 (profiles/r2_conv_mfma.md): forward 81 us either way, backward 293 vs 226 us - neither form is
   // arithmetic-bound, so the matrix pipe buys nothing here and the VALU kernels stay the default.
   int conv_mfma = 0;
+  // AIMNET_CONV_CLUSTER / set_option("conv_cluster"): the conv backward of passes >= 1 for clusters of four centre atoms
+  // (conv_cluster.hip: union lists, Y for four centres in one MFMA chain, the X half through the reverse-pair identity) for
+  // systems above the split threshold.  Measured on config 3 (profiles/r2_conv_cluster.md): the union lists halve the rows
+  // gathered (341 k instead of 683 k, 4 KiB instead of 5.25 KiB each) but the kernel takes 319 us against 226 us - the four
+  // centres' abar updates and reductions (184 instructions per union entry at 2 waves per SIMD) cost more than the gather
+  // saves, and the list build adds 0.18 ms per step.  Off by default; parity-tested (tests/test_gpu_conv_cluster.py).
+  int conv_cluster = 0;
   // AIMNET_OVERLAP_COULOMB / set_option("overlap_coulomb"): the Coulomb / DFT-D3 pair kernels (VALU-bound, they need only the
   // final charges) run on a second HIP stream next to the last pass' MLP, the energy head and the first backward GEMMs
   // (MFMA-bound): forked after the last charge update, joined in front of the first conv backward
@@ -182,6 +189,8 @@ struct Workspace {
   float* qtot;   // NSE models: alpha + beta charges (the Coulomb kernels and the `charges` output see these)
   double* part;  // per-(system, slice) partial sums of the molecule reductions
   int S;         // slices per molecule
+  ClusterLists cl;   // conv_cluster.hip (pointers NULL when that path is off)
+  bool cluster = false;
   float *zb0, *zb1;  // ping-pong adjoint buffers (N x max padded width)
   float *Sbar, *Sqbar;
   int *d3_idx, *d3_shift, *d3_cnt;   // DFT-D3 neighbour matrix (aliases the LR list when both use one cutoff)
@@ -213,13 +222,14 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   Carver c{base, 0, views};
   const int np = e->arch.n_pass;
   const bool grad = (opt->flags & (AIMNET_FORCES | AIMNET_STRESS)) != 0;
-  const bool mfma_rows = e->conv_mfma != 0 && N > conv_split_max_atoms();
   const size_t n = (size_t)N;
+  const int cap = std::max(1, opt->max_nb), cap_lr = std::max(0, opt->max_nb_lr);
+  W.cluster = e->conv_cluster != 0 && grad && np > 1 && N > conv_split_max_atoms() && cluster_lists_supported(N, cap);
+  const bool mfma_rows = (e->conv_mfma != 0 && N > conv_split_max_atoms()) || W.cluster;
   char* nl_base = c.take<char>(nlist_scratch_bytes(N, n_mol));
   if (base) nlist_carve(W.nl, nl_base, N, n_mol);
   if (views)  // the wrapped coordinates sit at a fixed position inside the nlist scratch
     (*views)["xw"] = View{(size_t)(nl_base - base) + nlist_xw_offset(n_mol), n * 3, 4, 3};
-  const int cap = std::max(1, opt->max_nb), cap_lr = std::max(0, opt->max_nb_lr);
   W.nb_idx = c.take<int>(n * cap, "nb_idx", cap);
   W.nb_shift = c.take<int>(n * cap, "nb_shift", cap);
   W.nb_cnt = c.take<int>(n, "nb_cnt", 1);
@@ -298,6 +308,18 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   } else {
     W.abar = W.zb0 = W.zb1 = W.Sbar = W.Sqbar = nullptr;
   }
+  {
+    const size_t n_cl = W.cluster ? (n + 3) / 4 : 0, cu = (size_t)4 * cap;
+    W.cl.capU = (int)cu;
+    W.cl.cnt = c.take<int>(n_cl);
+    W.cl.idx = c.take<int>(n_cl * cu);
+    W.cl.shift = c.take<int>(n_cl * cu);
+    W.cl.ud = c.take<float4>(n_cl * cu * 4);
+    W.cl.pos_of = c.take<int>(W.cluster ? n : 0);
+    W.cl.rev = c.take<int>(n_cl * cu * 4);
+    W.cl.n_missing = c.take<int>(W.cluster ? 1 : 0);
+    W.cl.pairbuf = c.take<float4>(n_cl * cu * 4);
+  }
   W.n_part = (N + 255) / 256;
   W.aslot = c.take<int>(n);
   W.present_part = c.take<unsigned long long>((size_t)W.n_part);
@@ -367,6 +389,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->keep_intermediates = atoi(env) != 0;
     env = getenv("AIMNET_CONV_MFMA");
     if (env) e->conv_mfma = atoi(env);
+    env = getenv("AIMNET_CONV_CLUSTER");
+    if (env) e->conv_cluster = atoi(env);
     env = getenv("AIMNET_OVERLAP_COULOMB");
     if (env) e->overlap_coulomb = atoi(env) != 0;
   }
@@ -479,6 +503,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   if (!e || !name) return AIMNET_E_INVALID;
   const std::string n(name);
   if (n == "conv_mfma") e->conv_mfma = value & 3;
+  else if (n == "conv_cluster") e->conv_cluster = value != 0;
   else if (n == "split_max") conv_set_split_max(value);  // process-wide
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -657,6 +682,10 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
   const bool mfma_fwd = (e->conv_mfma & 1) && N > conv_split_max_atoms();
   const bool mfma_bwd = (e->conv_mfma & 2) && N > conv_split_max_atoms();
+  if (W.cluster) {  // union lists of the four-centre clusters + the reverse-pair map (once per neighbour list)
+    AIMNET_HIP_CHECK(hipMemsetAsync(W.cl.n_missing, 0, sizeof(int), s));
+    RC(launch_cluster_build(s, W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, W.pg, cap, order, N, W.cl));
+  }
   // ---- Coulomb: energies, and the seeds of qbar / dE/dx / virial (a closure: it runs on the eval stream or on the side one) ----
   const float* q_fin = nq == 2 ? W.qtot : W.q[np - 2];
   const bool overlap = e->overlap_coulomb && e->prof_level < 2;  // per-family profiling wants one stream
@@ -818,9 +847,15 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
                             order));
       break;
     }
-    RC((mfma_bwd ? launch_unconcat_t : launch_unconcat)(s, p > 0 ? nq : 0, zcur, ld, W.V[p], W.Vq[p], e->agh_a, e->agh_q, W.Sbar,
-                                                        W.Sqbar, N));
+    const bool cl_pass = W.cluster && p > 0;
+    RC((mfma_bwd || cl_pass ? launch_unconcat_t : launch_unconcat)(s, p > 0 ? nq : 0, zcur, ld, W.V[p], W.Vq[p], e->agh_a, e->agh_q,
+                                                                   W.Sbar, W.Sqbar, N));
     RC(prof_mark(e, s, FAM_CONV_BWD));
+    if (cl_pass) {
+      RC(launch_conv_bwd_cluster(s, nq, true, want_s, W.at[p], W.q[p - 1], W.Sbar, W.Sqbar, W.cl, e->bp, zcur, ld,
+                                 (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, p < np - 1, W.virial_atom, N, order));
+      if (p == 1) RC(launch_cluster_force(s, W.cl, order, N, W.fgrad));  // both passes' pair terms are in the pair buffer
+    } else
     RC((mfma_bwd ? launch_conv_bwd_mfma : launch_conv_bwd)(s, p > 0 ? nq : 0, p > 0, want_s,
                        mfma_bwd ? (p == 0 ? e->afv_t : W.at[p]) : (p == 0 ? e->afv : W.a[p]), p == 0 ? in->numbers : nullptr,
                        p > 0 ? W.q[p - 1] : nullptr, W.Sbar, W.Sqbar, W.nb_idx, W.nb_cnt,

@@ -93,6 +93,28 @@ int launch_conv_bwd_mfma(hipStream_t s, int nq, bool need_abar, bool stress, con
                          const float* SbarT, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg, int cap,
                          BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out, const float* qbar_in,
                          float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order);
+// ---- conv_cluster.hip: conv backward for clusters of four centre atoms (union neighbour lists, Y on the 4x4x1 MFMA with
+// row = centre, the reverse-pair exchange of the pair adjoints through a pair buffer).  Passes >= 1 of systems above the split
+// threshold; SbarT / a_t as for conv_mfma.hip.
+struct ClusterLists {   // device pointers carved from the workspace; cluster c = centres order[4c .. 4c+3]
+  int capU;             // union entries per cluster (4 x the row capacity)
+  int* cnt;             // [n_cl]
+  int* idx;             // [n_cl][capU] neighbour atom of the entry (sorted by (atom, shift code))
+  int* shift;           // [n_cl][capU] packed cell shift
+  float4* ud;           // [n_cl][capU][4] (u, d) of (entry, centre); d = -1: this centre does not hold the entry
+  int* pos_of;          // [n_atoms] position of the atom in the processing order (cluster = pos >> 2, centre = pos & 3)
+  int* rev;             // [n_cl][capU][4] flat index of the reverse ordered pair, -1 for absent
+  int* n_missing;       // [1] pairs without a reverse entry (only after a row overflow)
+  float4* pairbuf;      // [n_cl][capU][4] F1 of the ordered pair, summed over the passes
+};
+bool cluster_lists_supported(int n_atoms, int cap);
+int launch_cluster_build(hipStream_t s, const int* nb_idx, const int* nb_shift, const int* nb_cnt, const float4* pg, int cap,
+                         const int* order, int n_atoms, ClusterLists cl);
+int launch_conv_bwd_cluster(hipStream_t s, int nq, bool need_abar, bool stress, const float* a_t, const float* q,
+                            const float* SbarT, const float* Sqbar, ClusterLists cl, BasisParams bp, const float* xbar, int ldx,
+                            const float* abar_in, float* abar_out, const float* qbar_in, float* qbar_out, bool pb_accum,
+                            float* virial_atom, int n_atoms, const int* order);
+int launch_cluster_force(hipStream_t s, ClusterLists cl, const int* order, int n_atoms, float* fgrad);
 int launch_mfma4_probe(hipStream_t s, float* out);  // lane-layout probe of the 4x4x1 16-block MFMA (tests)
 int conv_split_max_atoms();
 void conv_set_split_max(int n);  // n < 0 restores the default

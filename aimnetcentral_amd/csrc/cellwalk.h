@@ -37,61 +37,81 @@ template <bool BY_ID, class F>
 __device__ __forceinline__ void cell_walk(const NlistSystem& S, int i, float xi, float yi, float zi, float cutoff,
                                           const int* __restrict__ bin_start, const float4* __restrict__ xs, int lane,
                                           F&& f) {
+  // home bin and the atom's position inside it (bin units, [0,1]): the pruning below measures slab distances from the ATOM,
+  // not from its bin, which visits ~45 % fewer candidates than the bin-to-bin bound
   int bv[3];
-  bin_of(S, xi, yi, zi, bv);
+  float fb[3];
+  for (int k = 0; k < 3; ++k) {
+    const float f = (xi - S.o[0]) * S.inv[k] + (yi - S.o[1]) * S.inv[3 + k] + (zi - S.o[2]) * S.inv[6 + k];
+    const float sc = f * (float)S.nb[k];
+    bv[k] = max(0, min(S.nb[k] - 1, (int)floorf(sc)));
+    fb[k] = fminf(fmaxf(sc - (float)bv[k], 0.0f), 1.0f);
+  }
   auto U = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
   auto UF = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
   const int nb0 = U(S.nb[0]), nb1 = U(S.nb[1]), nb2 = U(S.nb[2]);
   const int p0 = U(S.per[0]), p1 = U(S.per[1]), p2 = U(S.per[2]);
   // search radius in bins: slab thickness = h_k / nb_k
-  int R0 = (int)ceilf(cutoff * (float)nb0 / UF(S.h[0])), R1 = (int)ceilf(cutoff * (float)nb1 / UF(S.h[1])),
-      R2 = (int)ceilf(cutoff * (float)nb2 / UF(S.h[2]));
+  // (single-instruction reciprocals / rsq throughout: every bound below carries a 1e-3 bin margin, 1 ulp does not matter, and
+  // IEEE divisions and square roots were a third of the instructions this walk issued)
+  const float ih0 = __builtin_amdgcn_rcpf(UF(S.h[0])), ih1 = __builtin_amdgcn_rcpf(UF(S.h[1])), ih2 = __builtin_amdgcn_rcpf(UF(S.h[2]));
+  int R0 = (int)ceilf(cutoff * (float)nb0 * ih0 + 1e-3f), R1 = (int)ceilf(cutoff * (float)nb1 * ih1 + 1e-3f),
+      R2 = (int)ceilf(cutoff * (float)nb2 * ih2 + 1e-3f);
   R0 = U(min(120, p0 ? R0 : min(R0, nb0 - 1)));
   R1 = U(min(120, p1 ? R1 : min(R1, nb1 - 1)));
   R2 = U(min(120, p2 ? R2 : min(R2, nb2 - 1)));
   const int b0 = U(bv[0]), b1 = U(bv[1]), b2 = U(bv[2]);
   const int boff = U(S.bin_offset);
   const float cutoff2 = cutoff * cutoff;
-  // Bin pruning.  A point in a bin d_k slabs away along axis k is at least g_k = (|d_k|-1) t_k from the
-  // atom along the slab normal n_k; with r.n_k = p_k, |r|^2 = p^T (N N^T)^-1 p >= |p|^2 / lambda_max(N N^T),
-  // so the bin can hold a neighbour only if g_x^2 + g_y^2 + g_z^2 <= lam * cutoff^2 (rigorous for any cell).
-  const float t0 = UF(S.h[0]) / (float)nb0, t1 = UF(S.h[1]) / (float)nb1, t2 = UF(S.h[2]) / (float)nb2;
+  const float f0 = UF(fb[0]), f1 = UF(fb[1]), f2 = UF(fb[2]);
+  auto gap = [](int d, float f) {  // slab distance from the atom in bin units
+    const float g = d > 0 ? (float)d - f : d < 0 ? (float)(-d) - 1.0f + f : 0.0f;
+    return fmaxf(g - 1e-3f, 0.0f);
+  };
+  // Bin pruning.  A point in the slab d_k bins away along axis k is at least
+  //   g_k = (d_k - f_k) t_k  (d_k > 0),   (|d_k| - 1 + f_k) t_k  (d_k < 0),   0  (d_k = 0)
+  // from the atom along the slab normal n_k (f_k = the atom's position inside its own bin, minus a 1e-3 bin safety margin
+  // for the rounding of f_k); with r.n_k = p_k, |r|^2 = p^T (N N^T)^-1 p >= |p|^2 / lambda_max(N N^T), so the bin can hold
+  // a neighbour only if g_x^2 + g_y^2 + g_z^2 <= lam * cutoff^2 (rigorous for any cell).
+  const float t0 = UF(S.h[0]) * __builtin_amdgcn_rcpf((float)nb0), t1 = UF(S.h[1]) * __builtin_amdgcn_rcpf((float)nb1);
+  const float it2 = (float)nb2 * ih2;  // 1 / slab thickness along z
+  // (the wrap loops run 0-2 times; the empty asm keeps the compiler from replacing them with an integer division)
+#define AIMNET_WRAP(b, n, sh)                                  \
+  while (b < 0) { b += n; --sh; asm volatile("" : "+s"(b)); }  \
+  while (b >= n) { b -= n; ++sh; asm volatile("" : "+s"(b)); }
   const float lim2 = UF(S.lam) * cutoff2;
   float c[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) c[k] = UF(S.c[k]);
   for (int dx = -R0; dx <= R0; ++dx) {
-    const float gx = (float)max(0, abs(dx) - 1) * t0;
+    const float gx = gap(dx, f0) * t0;
     if (gx * gx > lim2) continue;
     int bx = b0 + dx, sx = 0;
     if (p0) {
-      while (bx < 0) { bx += nb0; --sx; }
-      while (bx >= nb0) { bx -= nb0; ++sx; }
+      AIMNET_WRAP(bx, nb0, sx)
     } else if (bx < 0 || bx >= nb0) {
       continue;
     }
     for (int dy = -R1; dy <= R1; ++dy) {
-      const float gy = (float)max(0, abs(dy) - 1) * t1;
+      const float gy = gap(dy, f1) * t1;
       const float rem = lim2 - gx * gx - gy * gy;
       if (rem < 0.0f) continue;
-      const int Rz = min(R2, (int)floorf(sqrtf(rem) / t2) + 1);
+      const float sz_bins = rem * __builtin_amdgcn_rsqf(fmaxf(rem, 1e-12f)) * it2 + 1e-3f;  // slabs dz < 0 reach (|dz| - 1 + f2), slabs dz > 0 reach (dz - f2)
+      const int Rlo = min(R2, (int)floorf(sz_bins + 1.0f - f2)), Rhi = min(R2, (int)floorf(sz_bins + f2));
       int by = b1 + dy, sy = 0;
       if (p1) {
-        while (by < 0) { by += nb1; --sy; }
-        while (by >= nb1) { by -= nb1; ++sy; }
+        AIMNET_WRAP(by, nb1, sy)
       } else if (by < 0 || by >= nb1) {
         continue;
       }
       // bins along z are contiguous in memory: walk whole runs [z0, z1] that share one lattice shift sz
-      const int zlo = b2 - Rz, zhi = b2 + Rz;
+      const int zlo = b2 - Rlo, zhi = b2 + Rhi;
       int sz_lo = 0, sz_hi = 0;
       if (p2) {
         int t = zlo;
-        while (t < 0) { t += nb2; --sz_lo; }
-        while (t >= nb2) { t -= nb2; ++sz_lo; }
+        AIMNET_WRAP(t, nb2, sz_lo)
         t = zhi;
-        while (t < 0) { t += nb2; --sz_hi; }
-        while (t >= nb2) { t -= nb2; ++sz_hi; }
+        AIMNET_WRAP(t, nb2, sz_hi)
       }
       const int row_bin = boff + (bx * nb1 + by) * nb2;
       for (int sz = sz_lo; sz <= sz_hi; ++sz) {
@@ -103,24 +123,26 @@ __device__ __forceinline__ void cell_walk(const NlistSystem& S, int i, float xi,
         const bool self_image = (sx == 0 && sy == 0 && sz == 0);
         const int code = pack_shift(sx, sy, sz);
         const int s0 = bin_start[row_bin + z0], s1 = bin_start[row_bin + z1 + 1];
+        if (s0 >= s1) continue;
+        // one 16-byte stream entry per lane and chunk; the next chunk's entry is requested before this one is consumed
+        // (past the run end the index clamps to the run's last entry, masked by e < s1)
+        int e = s0 + lane;
+        float4 cj = xs[min(e, s1 - 1)];
         for (int base = s0; base < s1; base += 64) {
-          const int e = base + lane;
-          bool ok = false;
-          float w = 0.f, rx = 0.f, ry = 0.f, rz = 0.f;
-          if (e < s1) {
-            const float4 cj = xs[e];
-            w = cj.w;
-            rx = (cj.x - xi) + ox;
-            ry = (cj.y - yi) + oy;
-            rz = (cj.z - zi) + oz;
-            const float d2 = rx * rx + ry * ry + rz * rz;
-            ok = d2 < cutoff2 && (BY_ID ? !(self_image && __float_as_int(w) == i) : d2 > 0.0f);
-          }
-          f(w, rx, ry, rz, ok, code);
+          const float4 nx = xs[min(e + 64, s1 - 1)];
+          const float rx = (cj.x - xi) + ox;
+          const float ry = (cj.y - yi) + oy;
+          const float rz = (cj.z - zi) + oz;
+          const float d2 = rx * rx + ry * ry + rz * rz;
+          const bool ok = e < s1 && d2 < cutoff2 && (BY_ID ? !(self_image && __float_as_int(cj.w) == i) : d2 > 0.0f);
+          f(cj.w, rx, ry, rz, ok, code);
+          cj = nx;
+          e += 64;
         }
       }
     }
   }
+#undef AIMNET_WRAP
 }
 
 }  // namespace aimnet

@@ -511,7 +511,19 @@ __global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __re
       const float w = ec * inv - sv + (d - Rc) * slope;
       const float ex = __builtin_amdgcn_exp2f(-1.4426950408889634f * al * al * d2);
       const float dw = -ec * inv * inv - two_a_sqrtpi * ex * inv + slope;
-      pair_add<GRAD, STRESS>(A, w, dw, qi, e.w, e.x * inv, e.y * inv, e.z * inv, d);
+      // pair_add in terms of r instead of u = r / d: t u = (t / d) r and the virial term r (x) t u = (t / d) r (x) r is symmetric
+      const float qq = qi * e.w;
+      A.e += (double)(w * qq);
+      if (GRAD) {
+        A.qb += w * e.w;
+        const float sc = dw * qq * inv;
+        const float px = sc * e.x, py = sc * e.y, pz = sc * e.z;
+        A.f0 += px; A.f1 += py; A.f2 += pz;
+        if (STRESS) {
+          A.W[0] += px * e.x; A.W[1] += px * e.y; A.W[2] += px * e.z;
+          A.W[4] += py * e.y; A.W[5] += py * e.z; A.W[8] += pz * e.z;
+        }
+      }
     }
   };
   int qn = 0;  // wave-uniform fill level of the queue
@@ -532,6 +544,11 @@ __global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __re
                      }
                    });
   if (lane < qn) pair_term(Q[lane]);
+  if (GRAD && STRESS) {  // the symmetric half was accumulated
+    A.W[3] = A.W[1];
+    A.W[6] = A.W[2];
+    A.W[7] = A.W[5];
+  }
   const float cs = -(sv * 0.5f + al * 0.56418958354775629f);
   const double e_self = 2.0 * (double)cp.factor * (double)(cs * qi * qi);
   const float qb_self = 4.0f * cp.factor * cs * qi;

@@ -507,9 +507,22 @@ __global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __re
     const float inv = __builtin_amdgcn_rsqf(d2);
     const float d = d2 * inv;
     if (d < Rc) {  // the walk tests the squared distance; the reference tests d < Rc on the root (a pair at Rc weighs 0)
-      const float ec = erfcf(al * d);
-      const float w = ec * inv - sv + (d - Rc) * slope;
+      // erfc(x) = exp(-x^2) t P(t), t = 1 / (1 + x/2): degree-9 fit of erfcx(x) / t on x in [0, 6.5] (6.5e-9 relative; the fp32
+      // Horner evaluation adds 2.5e-7, the class of erfcf itself) - the exponential is the one the derivative needs anyway
       const float ex = __builtin_amdgcn_exp2f(-1.4426950408889634f * al * al * d2);
+      const float tt = __builtin_amdgcn_rcpf(fmaf(0.5f * al, d, 1.0f));
+      float pe = 2.672036890e-02f;
+      pe = fmaf(pe, tt, -2.020067459e-01f);
+      pe = fmaf(pe, tt, 6.150174393e-01f);
+      pe = fmaf(pe, tt, -9.195323909e-01f);
+      pe = fmaf(pe, tt, 6.300562657e-01f);
+      pe = fmaf(pe, tt, -2.111610618e-01f);
+      pe = fmaf(pe, tt, 2.648643249e-01f);
+      pe = fmaf(pe, tt, 2.301390953e-01f);
+      pe = fmaf(pe, tt, 2.838921720e-01f);
+      pe = fmaf(pe, tt, 2.820105286e-01f);
+      const float ec = pe * tt * ex;
+      const float w = ec * inv - sv + (d - Rc) * slope;
       const float dw = -ec * inv * inv - two_a_sqrtpi * ex * inv + slope;
       // pair_add in terms of r instead of u = r / d: t u = (t / d) r and the virial term r (x) t u = (t / d) r (x) r is symmetric
       const float qq = qi * e.w;

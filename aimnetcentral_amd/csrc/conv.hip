@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
   __syncthreads();
   FwdWaveLds& L = wl[wid];
   const int g4 = (lane & 3) * 4;
+  const float shift_l = bp.shifts[lane & 15];  // the table loops below give lane l the shift l & 15 in every iteration
   __shared__ float s_red[SPLIT ? 3 * (16 + NQC) * 64 : 1];  // SPLIT: accumulators of waves 1..3
 
   const AtomLoop al = atom_loop(n_atoms, SPLIT ? 1 : APB);
@@ -122,8 +123,8 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
         const int mm = e >> 4, g = e & 15;
         float v = 0.0f;
         if (mm < nch) {
-          const float dd = L.ud[mm].w - bp.shifts[g];
-          v = expf(-bp.eta * dd * dd) * L.fc[mm];
+          const float dd = L.ud[mm].w - shift_l;
+          v = exp_neg(-bp.eta * dd * dd) * L.fc[mm];
         }
         L.gs[mm][g] = v;
       }
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   BwdWaveLds& L = wl[wid];
   const int g4 = (lane & 3) * 4;
+  const float shift_l = bp.shifts[lane & 15];  // the table loop below gives lane l the shift l & 15 in every iteration
   const int qg = lane >> 2, qc = lane & 3;
   const float qm0 = qc == 0 ? 1.f : 0.f, qm1 = qc == 1 ? 1.f : 0.f, qm2 = qc == 2 ? 1.f : 0.f, qm3 = qc == 3 ? 1.f : 0.f;
   const float qsgn = qc == 0 ? 1.f : -1.f;
@@ -518,8 +520,8 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
         float v = 0.0f, dv = 0.0f;
         if (mm < nch) {
           const float fc = L.fc[mm], dfc = L.dfc[mm];
-          const float dd = L.ud[mm].w - bp.shifts[g];
-          const float Gg = expf(-bp.eta * dd * dd);
+          const float dd = L.ud[mm].w - shift_l;
+          const float Gg = exp_neg(-bp.eta * dd * dd);
           v = Gg * fc;
           dv = Gg * (dfc - 2.0f * bp.eta * dd * fc);
         }
@@ -924,7 +926,7 @@ __global__ __launch_bounds__(256) void conv_bwd_p0_kernel(const float4* __restri
         const float4 Ti = Ti_base[(size_t)sj * 16];
         const float4 Tj = T4[((size_t)j * nslots + si) * 16 + g];
         const float dd = u.w - shift_g;
-        const float Gg = expf(-bp.eta * dd * dd);
+        const float Gg = exp_neg(-bp.eta * dd * dd);
         const float gs = Gg * fc;
         const float dg = Gg * (dfc - 2.0f * bp.eta * dd * fc);
         float D = dg * ((Ti.x + Tj.x) + u.x * (Ti.y - Tj.y) + u.y * (Ti.z - Tj.z) + u.z * (Ti.w - Tj.w));

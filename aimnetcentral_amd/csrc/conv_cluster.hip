@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_cl_kernel(const float* __rest
         const int el = e >> 6, gg = (e >> 2) & 15, r = e & 3;
         const float fc = L.fc[el][r], dfc = L.dfc[el][r];
         const float dd = L.ud[el][r].w - bp.shifts[gg];
-        const float Gg = expf(-bp.eta * dd * dd);
+        const float Gg = exp_neg(-bp.eta * dd * dd);
         reinterpret_cast<float*>(&L.gs[el][gg])[r] = Gg * fc;
         reinterpret_cast<float*>(&L.dgs[el][gg])[r] = Gg * (dfc - 2.0f * bp.eta * dd * fc);
       }

@@ -51,6 +51,18 @@ __device__ __forceinline__ float basis_fc(const BasisParams& bp, float d, float&
   return 0.5f * (cs + 1.0f);
 }
 
+// exp(x) for the radial-basis tables (x <= 0): one v_exp_f32 instead of the 15-instruction expf.  x * log2(e) is formed as an
+// exact hi + lo pair (fma residual + the low word of the constant), exp2(hi) is the hardware instruction (1 ulp) and the lo
+// part enters to first order, so the result keeps expf's accuracy: |x| reaches ~30 before the Gaussian underflows the sums
+// it enters, where a single rounded product would already cost 2e-6 relative.
+__device__ __forceinline__ float exp_neg(float x) {
+  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f, LN2 = 0.6931471805599453f;
+  const float p = x * L2E_HI;
+  const float e = fmaf(x, L2E_HI, -p) + x * L2E_LO;
+  const float r = __builtin_amdgcn_exp2f(p);
+  return fmaf(r * e, LN2, r);
+}
+
 // hand-off of per-wave LDS data: a block barrier when waves share it, otherwise a wave-level fence (no s_barrier)
 template <bool BLOCK>
 __device__ __forceinline__ void lds_sync() {

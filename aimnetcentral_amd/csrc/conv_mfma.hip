@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_mfma_kernel(const float* __re
         float v = 0.0f;
         if (mm < nch) {
           const float dd = L.ud[mm].w - bp.shifts[gg];
-          v = expf(-bp.eta * dd * dd) * L.fc[mm];
+          v = exp_neg(-bp.eta * dd * dd) * L.fc[mm];
         }
         L.gs[mm][gg] = v;
       }
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_mfma_kernel(const float* __re
         if (mm < nch) {
           const float fc = L.fc[mm], dfc = L.dfc[mm];
           const float dd = L.ud[mm].w - bp.shifts[gg];
-          const float Gg = expf(-bp.eta * dd * dd);
+          const float Gg = exp_neg(-bp.eta * dd * dd);
           v = Gg * fc;
           dv = Gg * (dfc - 2.0f * bp.eta * dd * fc);
         }

@@ -32,18 +32,29 @@ __device__ __forceinline__ int bin_of(const NlistSystem& S, float x, float y, fl
 // BY_ID, else a payload such as the charge); ok = candidate exists, |r| < cutoff and it is not the
 // atom itself (BY_ID: id test in the home image; otherwise r != 0); r is formed as
 // (x_j - x_i) + s.C so that (i,j,s) and (j,i,-s) see exactly opposite vectors.
-// Everything that steers the walk is wave-uniform -> SGPRs, scalar branches, no integer division.
+//
+// Two phases per batch of 64 (dx, dy) bin columns.  (1) lane = column: prune the column against the cutoff sphere, wrap it
+// into the cell, find its z range and the runs of z-contiguous bins that share one lattice shift, and compact the non-empty
+// runs {first, last stream entry, shift vector, shift code} into `runbuf` (per-wave LDS, CELLWALK_RUN_INTS ints).  (2) the
+// wave consumes the runs one by one, 64 stream entries per chunk.  Steering the walk with scalar loops instead cost ~160
+// instructions per column - more than the candidate tests themselves.
+constexpr int CELLWALK_RUN_INTS = 64 * 8;
+
+__device__ __forceinline__ int cw_floor_div(int v, int n, float inv_n) {  // exact for |v| < 2^20, n <= 1024 (margin 0.5 / n)
+  return (int)floorf(((float)v + 0.5f) * inv_n);
+}
+
 template <bool BY_ID, class F>
 __device__ __forceinline__ void cell_walk(const NlistSystem& S, int i, float xi, float yi, float zi, float cutoff,
                                           const int* __restrict__ bin_start, const float4* __restrict__ xs, int lane,
-                                          F&& f) {
+                                          int* __restrict__ runbuf, F&& f) {
   // home bin and the atom's position inside it (bin units, [0,1]): the pruning below measures slab distances from the ATOM,
   // not from its bin, which visits ~45 % fewer candidates than the bin-to-bin bound
   int bv[3];
   float fb[3];
   for (int k = 0; k < 3; ++k) {
-    const float f = (xi - S.o[0]) * S.inv[k] + (yi - S.o[1]) * S.inv[3 + k] + (zi - S.o[2]) * S.inv[6 + k];
-    const float sc = f * (float)S.nb[k];
+    const float fr = (xi - S.o[0]) * S.inv[k] + (yi - S.o[1]) * S.inv[3 + k] + (zi - S.o[2]) * S.inv[6 + k];
+    const float sc = fr * (float)S.nb[k];
     bv[k] = max(0, min(S.nb[k] - 1, (int)floorf(sc)));
     fb[k] = fminf(fmaxf(sc - (float)bv[k], 0.0f), 1.0f);
   }
@@ -52,8 +63,7 @@ __device__ __forceinline__ void cell_walk(const NlistSystem& S, int i, float xi,
   const int nb0 = U(S.nb[0]), nb1 = U(S.nb[1]), nb2 = U(S.nb[2]);
   const int p0 = U(S.per[0]), p1 = U(S.per[1]), p2 = U(S.per[2]);
   // search radius in bins: slab thickness = h_k / nb_k
-  // (single-instruction reciprocals / rsq throughout: every bound below carries a 1e-3 bin margin, 1 ulp does not matter, and
-  // IEEE divisions and square roots were a third of the instructions this walk issued)
+  // (single-instruction reciprocals / rsq throughout: every bound below carries a 1e-3 bin margin, 1 ulp does not matter)
   const float ih0 = __builtin_amdgcn_rcpf(UF(S.h[0])), ih1 = __builtin_amdgcn_rcpf(UF(S.h[1])), ih2 = __builtin_amdgcn_rcpf(UF(S.h[2]));
   int R0 = (int)ceilf(cutoff * (float)nb0 * ih0 + 1e-3f), R1 = (int)ceilf(cutoff * (float)nb1 * ih1 + 1e-3f),
       R2 = (int)ceilf(cutoff * (float)nb2 * ih2 + 1e-3f);
@@ -64,8 +74,8 @@ __device__ __forceinline__ void cell_walk(const NlistSystem& S, int i, float xi,
   const int boff = U(S.bin_offset);
   const float cutoff2 = cutoff * cutoff;
   const float f0 = UF(fb[0]), f1 = UF(fb[1]), f2 = UF(fb[2]);
-  auto gap = [](int d, float f) {  // slab distance from the atom in bin units
-    const float g = d > 0 ? (float)d - f : d < 0 ? (float)(-d) - 1.0f + f : 0.0f;
+  auto gap = [](int d, float fr) {  // slab distance from the atom in bin units
+    const float g = d > 0 ? (float)d - fr : d < 0 ? (float)(-d) - 1.0f + fr : 0.0f;
     return fmaxf(g - 1e-3f, 0.0f);
   };
   // Bin pruning.  A point in the slab d_k bins away along axis k is at least
@@ -75,74 +85,101 @@ __device__ __forceinline__ void cell_walk(const NlistSystem& S, int i, float xi,
   // a neighbour only if g_x^2 + g_y^2 + g_z^2 <= lam * cutoff^2 (rigorous for any cell).
   const float t0 = UF(S.h[0]) * __builtin_amdgcn_rcpf((float)nb0), t1 = UF(S.h[1]) * __builtin_amdgcn_rcpf((float)nb1);
   const float it2 = (float)nb2 * ih2;  // 1 / slab thickness along z
-  // (the wrap loops run 0-2 times; the empty asm keeps the compiler from replacing them with an integer division)
-#define AIMNET_WRAP(b, n, sh)                                  \
-  while (b < 0) { b += n; --sh; asm volatile("" : "+s"(b)); }  \
-  while (b >= n) { b -= n; ++sh; asm volatile("" : "+s"(b)); }
   const float lim2 = UF(S.lam) * cutoff2;
   float c[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) c[k] = UF(S.c[k]);
-  for (int dx = -R0; dx <= R0; ++dx) {
-    const float gx = gap(dx, f0) * t0;
-    if (gx * gx > lim2) continue;
-    int bx = b0 + dx, sx = 0;
+  const float in0 = __builtin_amdgcn_rcpf((float)nb0), in1 = __builtin_amdgcn_rcpf((float)nb1), in2 = __builtin_amdgcn_rcpf((float)nb2);
+  const int W1 = 2 * R1 + 1, ncol = (2 * R0 + 1) * W1;
+  const float iW1 = __builtin_amdgcn_rcpf((float)W1);
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+  for (int cb = 0; cb < ncol; cb += 64) {
+    // ---- phase 1: this lane's column ------------------------------------------------------------
+    const int idx = cb + lane;
+    bool live = idx < ncol;
+    const int qx = cw_floor_div(idx, W1, iW1);
+    const int dx = qx - R0, dy = idx - qx * W1 - R1;
+    const float gx = gap(dx, f0) * t0, gy = gap(dy, f1) * t1;
+    const float rem = lim2 - gx * gx - gy * gy;
+    live = live && rem >= 0.0f;
+    int bx = b0 + dx, by = b1 + dy, sx = 0, sy = 0;
     if (p0) {
-      AIMNET_WRAP(bx, nb0, sx)
-    } else if (bx < 0 || bx >= nb0) {
-      continue;
+      sx = cw_floor_div(bx, nb0, in0);
+      bx -= sx * nb0;
+    } else {
+      live = live && bx >= 0 && bx < nb0;
     }
-    for (int dy = -R1; dy <= R1; ++dy) {
-      const float gy = gap(dy, f1) * t1;
-      const float rem = lim2 - gx * gx - gy * gy;
-      if (rem < 0.0f) continue;
-      const float sz_bins = rem * __builtin_amdgcn_rsqf(fmaxf(rem, 1e-12f)) * it2 + 1e-3f;  // slabs dz < 0 reach (|dz| - 1 + f2), slabs dz > 0 reach (dz - f2)
-      const int Rlo = min(R2, (int)floorf(sz_bins + 1.0f - f2)), Rhi = min(R2, (int)floorf(sz_bins + f2));
-      int by = b1 + dy, sy = 0;
-      if (p1) {
-        AIMNET_WRAP(by, nb1, sy)
-      } else if (by < 0 || by >= nb1) {
-        continue;
+    if (p1) {
+      sy = cw_floor_div(by, nb1, in1);
+      by -= sy * nb1;
+    } else {
+      live = live && by >= 0 && by < nb1;
+    }
+    const float remc = fmaxf(rem, 0.0f);
+    const float sz_bins = remc * __builtin_amdgcn_rsqf(fmaxf(remc, 1e-12f)) * it2 + 1e-3f;  // slabs dz < 0 reach (|dz| - 1 + f2), dz > 0 reach (dz - f2)
+    const int Rlo = min(R2, (int)floorf(sz_bins + 1.0f - f2)), Rhi = min(R2, (int)floorf(sz_bins + f2));
+    // bins along z are contiguous in memory: whole runs [z0, z1] that share one lattice shift sz
+    int zlo = b2 - Rlo, zhi = b2 + Rhi, sz_lo = 0, sz_hi = 0;
+    if (p2) {
+      sz_lo = cw_floor_div(zlo, nb2, in2);
+      sz_hi = cw_floor_div(zhi, nb2, in2);
+    } else {
+      zlo = max(zlo, 0);
+      zhi = min(zhi, nb2 - 1);
+    }
+    const int nruns = live ? sz_hi - sz_lo + 1 : 0;
+    const int row_bin = boff + (bx * nb1 + by) * nb2;
+    const int max_r = U(wave_max(nruns));
+    for (int r = 0; r < max_r; ++r) {
+      const int sz = sz_lo + r;
+      const int z0 = max(zlo, sz * nb2) - sz * nb2, z1 = min(zhi, sz * nb2 + nb2 - 1) - sz * nb2;
+      bool has = r < nruns && z1 >= z0;
+      int s0 = 0, s1 = 0;
+      if (has) {
+        s0 = bin_start[row_bin + z0];
+        s1 = bin_start[row_bin + z1 + 1];
+        has = s0 < s1;
       }
-      // bins along z are contiguous in memory: walk whole runs [z0, z1] that share one lattice shift sz
-      const int zlo = b2 - Rlo, zhi = b2 + Rhi;
-      int sz_lo = 0, sz_hi = 0;
-      if (p2) {
-        int t = zlo;
-        AIMNET_WRAP(t, nb2, sz_lo)
-        t = zhi;
-        AIMNET_WRAP(t, nb2, sz_hi)
+      const unsigned long long mask = __ballot(has);
+      if (has) {
+        int* d = runbuf + 8 * __popcll(mask & lt_mask);
+        d[0] = s0;
+        d[1] = s1;
+        d[2] = __float_as_int(sx * c[0] + sy * c[3] + sz * c[6]);
+        d[3] = __float_as_int(sx * c[1] + sy * c[4] + sz * c[7]);
+        d[4] = __float_as_int(sx * c[2] + sy * c[5] + sz * c[8]);
+        d[5] = pack_shift(sx, sy, sz);
       }
-      const int row_bin = boff + (bx * nb1 + by) * nb2;
-      for (int sz = sz_lo; sz <= sz_hi; ++sz) {
-        const int z0 = max(zlo, sz * nb2) - sz * nb2, z1 = min(zhi, sz * nb2 + nb2 - 1) - sz * nb2;
-        if (z1 < z0) continue;
-        const float ox = sx * c[0] + sy * c[3] + sz * c[6];
-        const float oy = sx * c[1] + sy * c[4] + sz * c[7];
-        const float oz = sx * c[2] + sy * c[5] + sz * c[8];
-        const bool self_image = (sx == 0 && sy == 0 && sz == 0);
-        const int code = pack_shift(sx, sy, sz);
-        const int s0 = bin_start[row_bin + z0], s1 = bin_start[row_bin + z1 + 1];
-        if (s0 >= s1) continue;
+      const int n_run = __popcll(mask);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // ---- phase 2: the wave walks the runs -------------------------------------------------------
+      for (int k = 0; k < n_run; ++k) {
+        const int* d = runbuf + 8 * k;
+        const int s0u = U(d[0]), s1u = U(d[1]), code = U(d[5]);
+        const float ox = UF(__int_as_float(d[2])), oy = UF(__int_as_float(d[3])), oz = UF(__int_as_float(d[4]));
+        const bool self_image = code == 0;
         // one 16-byte stream entry per lane and chunk; the next chunk's entry is requested before this one is consumed
         // (past the run end the index clamps to the run's last entry, masked by e < s1)
-        int e = s0 + lane;
-        float4 cj = xs[min(e, s1 - 1)];
-        for (int base = s0; base < s1; base += 64) {
-          const float4 nx = xs[min(e + 64, s1 - 1)];
+        int e = s0u + lane;
+        float4 cj = xs[min(e, s1u - 1)];
+        for (int base = s0u; base < s1u; base += 64) {
+          const float4 nx = xs[min(e + 64, s1u - 1)];
           const float rx = (cj.x - xi) + ox;
           const float ry = (cj.y - yi) + oy;
           const float rz = (cj.z - zi) + oz;
           const float d2 = rx * rx + ry * ry + rz * rz;
-          const bool ok = e < s1 && d2 < cutoff2 && (BY_ID ? !(self_image && __float_as_int(cj.w) == i) : d2 > 0.0f);
+          const bool ok = e < s1u && d2 < cutoff2 && (BY_ID ? !(self_image && __float_as_int(cj.w) == i) : d2 > 0.0f);
           f(cj.w, rx, ry, rz, ok, code);
           cj = nx;
           e += 64;
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
-#undef AIMNET_WRAP
 }
 
 }  // namespace aimnet

@@ -540,7 +540,8 @@ __global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __re
     }
   };
   int qn = 0;  // wave-uniform fill level of the queue
-  cell_walk<false>(sys[mol_idx[i]], i, xi, yi, zi, Rc, bin_start, xq, lane,
+  __shared__ int s_runs[4][CELLWALK_RUN_INTS];
+  cell_walk<false>(sys[mol_idx[i]], i, xi, yi, zi, Rc, bin_start, xq, lane, s_runs[threadIdx.x >> 6],
                    [&](float qj, float rx, float ry, float rz, bool ok, int) {
                      const unsigned long long mask = __ballot(ok);
                      if (ok) Q[qn + __popcll(mask & ((1ull << lane) - 1ull))] = make_float4(rx, ry, rz, qj);

@@ -399,7 +399,8 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
   int* row = nb_idx + (size_t)i * cap;
   int* rsh = nb_shift + (size_t)i * cap;
   int count = 0;
-  cell_walk<true>(sys[mol_idx[i]], i, xi, yi, zi, cutoff, bin_start, xs, lane,
+  __shared__ int s_runs[4][CELLWALK_RUN_INTS];
+  cell_walk<true>(sys[mol_idx[i]], i, xi, yi, zi, cutoff, bin_start, xs, lane, s_runs[threadIdx.x >> 6],
             [&](float w, float rx, float ry, float rz, bool ok, int code) {
               const unsigned long long mask = __ballot(ok);
               const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));

@@ -75,6 +75,12 @@ struct aimnet_engine {
   // centres' abar updates and reductions (184 instructions per union entry at 2 waves per SIMD) cost more than the gather
   // saves, and the list build adds 0.18 ms per step.  Off by default; parity-tested (tests/test_gpu_conv_cluster.py).
   int conv_cluster = 0;
+  // AIMNET_CONV_XE / set_option("conv_xe"): the reverse-pair form of the conv backward (conv.hip, conv_bwd_kernel<.., XE>) for
+  // passes >= 1 of systems above the split threshold: every ordered pair evaluates only its own half of the pair adjoints (no
+  // a_j gather, 4 KiB per pair instead of 5.25 KiB), F1 goes through a pair buffer and a reverse-pair map built on sorted rows.
+  // Config 3: kernel 215 -> 152 us per pass, +55 us per step for the row sort, the map and the force gather (1.96 -> 1.89 ms).
+  // 0 restores the combined-adjoint kernel (A/B and parity runs).
+  int conv_xe = 1;
   // AIMNET_OVERLAP_COULOMB / set_option("overlap_coulomb"): the Coulomb / DFT-D3 pair kernels (VALU-bound, they need only the
   // final charges) run on a second HIP stream next to the last pass' MLP, the energy head and the first backward GEMMs
   // (MFMA-bound): forked after the last charge update, joined in front of the first conv backward
@@ -191,6 +197,9 @@ struct Workspace {
   int S;         // slices per molecule
   ClusterLists cl;   // conv_cluster.hip (pointers NULL when that path is off)
   bool cluster = false;
+  bool xe = false;   // reverse-pair conv backward: pair buffer + reverse map
+  float4* pairbuf;
+  int* rev;
   float *zb0, *zb1;  // ping-pong adjoint buffers (N x max padded width)
   float *Sbar, *Sqbar;
   int *d3_idx, *d3_shift, *d3_cnt;   // DFT-D3 neighbour matrix (aliases the LR list when both use one cutoff)
@@ -226,6 +235,8 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   const int cap = std::max(1, opt->max_nb), cap_lr = std::max(0, opt->max_nb_lr);
   W.cluster = e->conv_cluster != 0 && grad && np > 1 && N > conv_split_max_atoms() && cluster_lists_supported(N, cap);
   const bool mfma_rows = (e->conv_mfma != 0 && N > conv_split_max_atoms()) || W.cluster;
+  W.xe = e->conv_xe != 0 && !W.cluster && !(e->conv_mfma & 2) && grad && np > 1 && N > conv_split_max_atoms() &&
+         pair_rev_supported(N, cap) && n * (size_t)cap < (size_t)INT32_MAX;
   char* nl_base = c.take<char>(nlist_scratch_bytes(N, n_mol));
   if (base) nlist_carve(W.nl, nl_base, N, n_mol);
   if (views)  // the wrapped coordinates sit at a fixed position inside the nlist scratch
@@ -320,6 +331,8 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
     W.cl.n_missing = c.take<int>(W.cluster ? 1 : 0);
     W.cl.pairbuf = c.take<float4>(n_cl * cu * 4);
   }
+  W.pairbuf = c.take<float4>(W.xe ? n * cap : 0);
+  W.rev = c.take<int>(W.xe ? n * cap : 0);
   W.n_part = (N + 255) / 256;
   W.aslot = c.take<int>(n);
   W.present_part = c.take<unsigned long long>((size_t)W.n_part);
@@ -389,6 +402,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->keep_intermediates = atoi(env) != 0;
     env = getenv("AIMNET_CONV_MFMA");
     if (env) e->conv_mfma = atoi(env);
+    env = getenv("AIMNET_CONV_XE");
+    if (env) e->conv_xe = atoi(env);
     env = getenv("AIMNET_CONV_CLUSTER");
     if (env) e->conv_cluster = atoi(env);
     env = getenv("AIMNET_OVERLAP_COULOMB");
@@ -504,6 +519,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   const std::string n(name);
   if (n == "conv_mfma") e->conv_mfma = value & 3;
   else if (n == "conv_cluster") e->conv_cluster = value != 0;
+  else if (n == "conv_xe") e->conv_xe = value != 0;
   else if (n == "split_max") conv_set_split_max(value);  // process-wide
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -682,6 +698,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
   const bool mfma_fwd = (e->conv_mfma & 1) && N > conv_split_max_atoms();
   const bool mfma_bwd = (e->conv_mfma & 2) && N > conv_split_max_atoms();
+  if (W.xe) RC(launch_pair_rev(s, W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, W.pg, cap, N, W.rev));
   if (W.cluster) {  // union lists of the four-centre clusters + the reverse-pair map (once per neighbour list)
     AIMNET_HIP_CHECK(hipMemsetAsync(W.cl.n_missing, 0, sizeof(int), s));
     RC(launch_cluster_build(s, W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, W.pg, cap, order, N, W.cl));
@@ -855,12 +872,17 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       RC(launch_conv_bwd_cluster(s, nq, true, want_s, W.at[p], W.q[p - 1], W.Sbar, W.Sqbar, W.cl, e->bp, zcur, ld,
                                  (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, p < np - 1, W.virial_atom, N, order));
       if (p == 1) RC(launch_cluster_force(s, W.cl, order, N, W.fgrad));  // both passes' pair terms are in the pair buffer
-    } else
-    RC((mfma_bwd ? launch_conv_bwd_mfma : launch_conv_bwd)(s, p > 0 ? nq : 0, p > 0, want_s,
-                       mfma_bwd ? (p == 0 ? e->afv_t : W.at[p]) : (p == 0 ? e->afv : W.a[p]), p == 0 ? in->numbers : nullptr,
-                       p > 0 ? W.q[p - 1] : nullptr, W.Sbar, W.Sqbar, W.nb_idx, W.nb_cnt,
-                       W.pg, cap, e->bp, zcur, ld, (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, W.fgrad,
-                       W.virial_atom, N, order));
+    } else if (mfma_bwd) {
+      RC(launch_conv_bwd_mfma(s, p > 0 ? nq : 0, p > 0, want_s, p == 0 ? e->afv_t : W.at[p], p == 0 ? in->numbers : nullptr,
+                              p > 0 ? W.q[p - 1] : nullptr, W.Sbar, W.Sqbar, W.nb_idx, W.nb_cnt, W.pg, cap, e->bp, zcur, ld,
+                              (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, W.fgrad, W.virial_atom, N, order));
+    } else {
+      RC(launch_conv_bwd(s, p > 0 ? nq : 0, p > 0, want_s, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr,
+                         p > 0 ? W.q[p - 1] : nullptr, W.Sbar, W.Sqbar, W.nb_idx, W.nb_cnt, W.pg, cap, e->bp, zcur, ld,
+                         (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, W.fgrad, W.virial_atom, N, order,
+                         (W.xe && p > 0) ? W.pairbuf : nullptr, p < np - 1));
+    }
+    if (W.xe && p == 1) RC(launch_pair_force(s, W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, N, W.fgrad));
     if (p == 0) break;
     // NSE adjoint of pass p-1, then the adjoint of its MLP output
     const std::vector<Layer>& Lq = e->mlp[p - 1];

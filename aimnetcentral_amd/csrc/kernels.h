@@ -68,7 +68,13 @@ int launch_unconcat(hipStream_t s, int nq, const float* xbar, int ldx, const flo
 int launch_conv_bwd(hipStream_t s, int nq, bool need_abar, bool stress, const float* a, const int* row_of,
                     const float* q, const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
                     int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
-                    const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order);
+                    const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order,
+                    float4* pairbuf = nullptr, bool pb_accum = false);  // pairbuf: the reverse-pair (XE) form, see conv.hip
+bool pair_rev_supported(int n_atoms, int cap);  // row capacity / atom count the row sort handles
+// sorts every neighbour row by (neighbour, shift) in place (idx, shift, pair geometry), then fills the reverse-pair map
+int launch_pair_rev(hipStream_t s, int* nb_idx, int* nb_shift, const int* nb_cnt, float4* pg, int cap, int n_atoms, int* rev);
+int launch_pair_force(hipStream_t s, const int* nb_idx, const int* nb_cnt, const int* rev, const float4* pairbuf, int cap,
+                      int n_atoms, float* fgrad);
 // `order` (conv_fwd / conv_bwd / conv_bwd_p0): optional permutation of the atoms giving the PROCESSING order - the
 // bin-sorted order of the cell list for periodic systems - so that an XCD's centres and the rows they gather stay
 // spatially coherent (and L2-resident) whatever the order of the input file; NULL = input order.

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
       lds_sync<SPLIT>();
 #pragma unroll
       for (int t = 0; t < CH * G_ / 64; ++t) {
+        if (4 * t >= nch) break;  // (wave-uniform) four pairs per iteration: a 68-neighbour row leaves a chunk of 4
         const int e = lane + 64 * t;
         const int mm = e >> 4, g = e & 15;
         float v = 0.0f;
@@ -528,6 +529,7 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
       lds_sync<SPLIT>();
 #pragma unroll
       for (int t = 0; t < CHB * G_ / 64; ++t) {
+        if (4 * t >= nch) break;  // (wave-uniform) four pairs per iteration; slots >= nch are never read
         const int e = lane + 64 * t;
         const int mm = e >> 4, g = e & 15;
         float v = 0.0f, dv = 0.0f;
@@ -542,51 +544,41 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
         L.dgs[mm][g] = dv;
       }
       lds_sync<SPLIT>();
-      // software pipeline: the 80 B per lane of neighbour mm+1 are requested before neighbour mm is
-      // consumed, so the L2 / Infinity-Cache latency of the gather hides under ~110 VALU instructions
-      float4 n_aj, n_s0, n_s1, n_s2, n_s3;
-      float n_sq[NQC];
-#pragma unroll
-      for (int ch = 0; ch < NQC; ++ch) n_sq[ch] = 0.f;
-      {
-        // neighbour ids are wave-uniform: readfirstlane moves them to SGPRs, so the row addresses are
-        // scalar (saddr-form global loads, no per-lane 64-bit address arithmetic on the VALU)
-        const int jn = __builtin_amdgcn_readfirstlane(nch > 0 ? L.j[0] : 0);
-        const int jrn = __builtin_amdgcn_readfirstlane(nch > 0 ? L.jr[0] : 0);
-        n_aj = XE ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<const float4*>(a + (size_t)jrn * NF)[lane];
-        const float4* spn = reinterpret_cast<const float4*>(Sbar + (size_t)jn * (NF * 4)) + lane;
-        n_s0 = spn[0]; n_s1 = spn[64]; n_s2 = spn[128]; n_s3 = spn[192];
-#pragma unroll
-        for (int ch = 0; ch < NQ; ++ch) n_sq[ch] = Sqbar[((size_t)jn * NQ + ch) * (G_ * 4) + lane];
-      }
-      for (int mm = 0; mm < nch; ++mm) {
-        const float4 ajv = n_aj, sj0 = n_s0, sj1 = n_s1, sj2 = n_s2, sj3 = n_s3;
-        float sqj_cur[NQC];
-#pragma unroll
-        for (int ch = 0; ch < NQC; ++ch) sqj_cur[ch] = n_sq[ch];
-        {
-          const int mn = min(mm + 1, nch - 1);
-          const int jn = __builtin_amdgcn_readfirstlane(L.j[mn]), jrn = __builtin_amdgcn_readfirstlane(L.jr[mn]);
-          if (!XE) n_aj = reinterpret_cast<const float4*>(a + (size_t)jrn * NF)[lane];
-          const float4* spn = reinterpret_cast<const float4*>(Sbar + (size_t)jn * (NF * 4)) + lane;
-          n_s0 = spn[0]; n_s1 = spn[64]; n_s2 = spn[128]; n_s3 = spn[192];
-#pragma unroll
-          for (int ch = 0; ch < NQ; ++ch) n_sq[ch] = Sqbar[((size_t)jn * NQ + ch) * (G_ * 4) + lane];
+      // Software pipeline over the neighbour rows in two named buffers (no register copies): the 80 B per lane of the next
+      // neighbour are requested before the current one is consumed, so the L2 / Infinity-Cache latency of the gather hides
+      // under ~100 VALU instructions.  Neighbour ids are wave-uniform: readfirstlane moves them to SGPRs, so the row addresses
+      // are scalar (saddr-form global loads, no per-lane 64-bit address arithmetic on the VALU).
+      struct Row {
+        float4 aj, s0, s1, s2, s3;
+        float sq[NQC];
+      };
+      auto load_row = [&](int mn, Row& R) {
+        const int jn = __builtin_amdgcn_readfirstlane(nch > 0 ? L.j[mn] : 0);
+        if (!XE) {
+          const int jrn = __builtin_amdgcn_readfirstlane(nch > 0 ? L.jr[mn] : 0);
+          R.aj = reinterpret_cast<const float4*>(a + (size_t)jrn * NF)[lane];
         }
+        const float4* spn = reinterpret_cast<const float4*>(Sbar + (size_t)jn * (NF * 4)) + lane;
+        R.s0 = spn[0]; R.s1 = spn[64]; R.s2 = spn[128]; R.s3 = spn[192];
+#pragma unroll
+        for (int ch = 0; ch < NQ; ++ch) R.sq[ch] = Sqbar[((size_t)jn * NQ + ch) * (G_ * 4) + lane];
+      };
+      // one neighbour: accumulates abar / qacc (and, in the combined form, dE/dx_i and the virial); returns the lane's partial
+      // (D, U0, U1, U2) of the pair
+      auto pair_math = [&](int mm, const Row& R, float& D, float& U0, float& U1, float& U2) {
         const float4 gv = *reinterpret_cast<const float4*>(&L.gs[mm][g4]);
         const float4 dgv = *reinterpret_cast<const float4*>(&L.dgs[mm][g4]);
         const float4 u = L.ud[mm];
-        const float inv_d = __builtin_amdgcn_rcpf(u.w);
-        // Both directions of the pair enter dE/dx_i only through the COMBINED adjoints
+        // Combined form: both directions of the pair enter dE/dx_i only through the COMBINED adjoints
         //   D = dbar_ij + dbar_ji,  U = ubar_ji - ubar_ij      (u_ji = -u_ij):
         //   dE/dx_i += rbar_ji - rbar_ij = -D u + (U - (U.u) u) / d
         // and the virial of the two ordered pairs is -1/2 r_ij (x) (rbar_ji - rbar_ij).
         // All of it in 2-wide vectors over the lane's shift pairs (v_pk_* instructions).
-        const f2 aj[2] = {mk2(ajv.x, ajv.y), mk2(ajv.z, ajv.w)};
+        const f2 aj[2] = {mk2(R.aj.x, R.aj.y), mk2(R.aj.z, R.aj.w)};
         const f2 gsv[2] = {mk2(gv.x, gv.y), mk2(gv.z, gv.w)};
         const f2 dg[2] = {mk2(dgv.x, dgv.y), mk2(dgv.z, dgv.w)};
-        const f2 Sj[4][2] = {{mk2(sj0.x, sj0.y), mk2(sj0.z, sj0.w)}, {mk2(sj1.x, sj1.y), mk2(sj1.z, sj1.w)},
-                             {mk2(sj2.x, sj2.y), mk2(sj2.z, sj2.w)}, {mk2(sj3.x, sj3.y), mk2(sj3.z, sj3.w)}};
+        const f2 Sj[4][2] = {{mk2(R.s0.x, R.s0.y), mk2(R.s0.z, R.s0.w)}, {mk2(R.s1.x, R.s1.y), mk2(R.s1.z, R.s1.w)},
+                             {mk2(R.s2.x, R.s2.y), mk2(R.s2.z, R.s2.w)}, {mk2(R.s3.x, R.s3.y), mk2(R.s3.z, R.s3.w)}};
         f2 Dv = mk2(0.f, 0.f), U0v = mk2(0.f, 0.f), U1v = mk2(0.f, 0.f), U2v = mk2(0.f, 0.f);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -607,7 +599,7 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
             U2v += tp * Sj[3][hf] - t * Si[3][hf];
           }
         }
-        float D = Dv.x + Dv.y, U0 = U0v.x + U0v.y, U1 = U1v.x + U1v.y, U2 = U2v.x + U2v.y;
+        D = Dv.x + Dv.y; U0 = U0v.x + U0v.y; U1 = U1v.x + U1v.y; U2 = U2v.x + U2v.y;
         if (HAS_Q) {
           // lane (g, c) of the charge convolution Sq[g,c] = sum_m q_j gs_g (1,u)_c, branch-free:
           // qm0..qm3 are the lane's one-hot component selectors, qsgn = (1,-1,-1,-1)[c] for the reverse pair
@@ -615,7 +607,7 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
           const float uc = qm0 + qm1 * u.x + qm2 * u.y + qm3 * u.z;
 #pragma unroll
           for (int ch = 0; ch < NQ; ++ch) {
-            const float sqj = sqj_cur[ch];
+            const float sqj = R.sq[ch];
             const float sj_s = sqj * qsgn;
             qacc[ch] += gq * sj_s * uc;
             float v;
@@ -632,23 +624,8 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
             U2 += qm3 * v;
           }
         }
-        if (XE) {
-          // (D, U0, U1, U2) of 64 lanes -> the pair's totals: two transposing quad steps leave value (lane & 3) in every lane,
-          // then a 16-lane row reduction and the two cross-row steps; lanes 60..63 hold (D, U0, U1, U2)
-          const bool odd = (lane & 1) != 0, hi2 = (lane & 2) != 0;
-          float k0 = odd ? U0 : D, s0 = odd ? D : U0;
-          float k1 = odd ? U2 : U1, s1 = odd ? U1 : U2;
-          k0 += dpp0<0xB1>(s0);
-          k1 += dpp0<0xB1>(s1);
-          float z = hi2 ? k1 : k0;
-          const float sd = hi2 ? k0 : k1;
-          z += dpp0<0x4E>(sd);
-          z += dpp0<0x114>(z);  // row_shr:4, row_shr:8: lanes 12..15 of each row hold the row's four sums
-          z += dpp0<0x118>(z);
-          z += __shfl_xor(z, 16, 64);
-          z += __shfl_xor(z, 32, 64);
-          if (lane >= 60) reinterpret_cast<float*>(&L.red[mm])[lane & 3] = z;
-        } else {
+        if (!XE) {
+          const float inv_d = __builtin_amdgcn_rcpf(u.w);
           const float dot = U0 * u.x + U1 * u.y + U2 * u.z;
           const float f0 = (U0 - dot * u.x) * inv_d - D * u.x;
           const float f1 = (U1 - dot * u.y) * inv_d - D * u.y;
@@ -660,6 +637,58 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
             W[3] += hy * f0; W[4] += hy * f1; W[5] += hy * f2;
             W[6] += hz * f0; W[7] += hz * f1; W[8] += hz * f2;
           }
+        }
+      };
+      // XE: (D, U0, U1, U2) of 64 lanes -> per 16-lane row: two transposing quad steps leave value (lane & 3) in every lane,
+      // then row_shr:4 / row_shr:8 put the row's four sums into its lanes 12..15
+      auto quad_row_reduce = [&](float D, float U0, float U1, float U2) {
+        const bool odd = (lane & 1) != 0, hi2 = (lane & 2) != 0;
+        float k0 = odd ? U0 : D;
+        const float s0 = odd ? D : U0;
+        float k1 = odd ? U2 : U1;
+        const float s1 = odd ? U1 : U2;
+        k0 += dpp0<0xB1>(s0);
+        k1 += dpp0<0xB1>(s1);
+        float z = hi2 ? k1 : k0;
+        const float sd = hi2 ? k0 : k1;
+        z += dpp0<0x4E>(sd);
+        z += dpp0<0x114>(z);
+        z += dpp0<0x118>(z);
+        return z;
+      };
+      Row RA, RB;
+      load_row(0, RA);
+      if (!XE) {  // combined form: one buffer ahead (the second named buffer does not fit next to Sbar_i and a_j in 128 VGPRs)
+        for (int mm = 0; mm < nch; ++mm) {
+          RB = RA;
+          load_row(min(mm + 1, nch - 1), RA);
+          float D, U0, U1, U2;
+          pair_math(mm, RB, D, U0, U1, U2);
+        }
+      }
+      for (int mm = 0; XE && mm < nch; mm += 2) {
+        const bool two = mm + 1 < nch;  // wave-uniform
+        float D, U0, U1, U2;
+        load_row(min(mm + 1, nch - 1), RB);
+        pair_math(mm, RA, D, U0, U1, U2);
+        float zA = 0.f, zB = 0.f;
+        if (XE) zA = quad_row_reduce(D, U0, U1, U2);
+        load_row(min(mm + 2, nch - 1), RA);
+        if (two) {
+          pair_math(mm + 1, RB, D, U0, U1, U2);
+          if (XE) zB = quad_row_reduce(D, U0, U1, U2);
+        }
+        if (XE) {
+          // the rows of both pairs at once: v_permlane16_swap exchanges the odd rows of its first operand with the even rows
+          // of the second, v_permlane32_swap the upper half of the first with the lower half of the second (gfx950; written as
+          // asm - the builtin with two copies of one value is miscompiled, tests/tools/permlane_probe.hip).  After the two
+          // steps rows 0 / 2 hold the first pair's totals and rows 1 / 3 the second's, in their lanes 12..15.
+          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(zA), "+v"(zB));
+          float sA = zA + zB, sB = sA;
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(sA), "+v"(sB));
+          const float tot = sA + sB;
+          const int row = lane >> 4;
+          if ((lane & 12) == 12 && row < 2 && (row == 0 || two)) reinterpret_cast<float*>(&L.red[mm + row])[lane & 3] = tot;
         }
       }
       if (XE) {  // chunk tail, lane = pair

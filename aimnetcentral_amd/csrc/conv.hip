@@ -919,10 +919,11 @@ int launch_pair_rev(hipStream_t s, int* nb_idx, int* nb_shift, const int* nb_cnt
   return 0;
 }
 
-// dE/dx_i += sum_m F1(i -> j_m) - F1(j_m -> i)  (conv_bwd_kernel XE form; one wave per atom, lane = pair)
+// forces_i = -(fgrad_i + sum_m F1(i -> j_m) - F1(j_m -> i))  (conv_bwd_kernel XE form; one wave per atom, lane = pair): the last
+// kernel of the backward, it writes the force output itself
 __global__ __launch_bounds__(256) void pair_force_kernel(const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
                                                          const int* __restrict__ rev, const float4* __restrict__ pairbuf, int cap,
-                                                         int n_atoms, float* __restrict__ fgrad) {
+                                                         int n_atoms, const float* __restrict__ fgrad, float* __restrict__ forces) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
@@ -940,16 +941,16 @@ __global__ __launch_bounds__(256) void pair_force_kernel(const int* __restrict__
   }
   f0 = wave_sum(f0); f1 = wave_sum(f1); f2 = wave_sum(f2);
   if (lane == 0) {
-    fgrad[3 * i + 0] += f0;
-    fgrad[3 * i + 1] += f1;
-    fgrad[3 * i + 2] += f2;
+    forces[3 * i + 0] = -(fgrad[3 * i + 0] + f0);
+    forces[3 * i + 1] = -(fgrad[3 * i + 1] + f1);
+    forces[3 * i + 2] = -(fgrad[3 * i + 2] + f2);
   }
 }
 
 int launch_pair_force(hipStream_t s, const int* nb_idx, const int* nb_cnt, const int* rev, const float4* pairbuf, int cap,
-                      int n_atoms, float* fgrad) {
+                      int n_atoms, const float* fgrad, float* forces) {
   hipLaunchKernelGGL(pair_force_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, nb_idx, nb_cnt, rev, pairbuf, cap, n_atoms,
-                     fgrad);
+                     fgrad, forces);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

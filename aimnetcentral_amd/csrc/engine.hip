@@ -662,7 +662,9 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   if (e->prof_on) e->prof_sampled++;
   RC(prof_mark(e, s, FAM_NLIST));
   AIMNET_HIP_CHECK(hipMemsetAsync(out->status, 0, 8 * sizeof(int), s));
-  RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start, in->numbers, out->status + 6));
+  const bool want_species = (e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS))) || opt->dftd3 != 0;
+  RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start, in->numbers, out->status + 6,
+                      want_species ? e->slot_of_z : nullptr, W.aslot, W.present_part));  // + aslot / present species
   RC(launch_wrap(s, in->coord, in->mol_idx, N, n_mol, in->cell, n_cell, in->pbc, W.nl, in->pbc_sys));
   // large non-periodic molecules (>= 1500 atoms on average) get a bounding-box cell list instead of the O(n^2) scan
   if (!pbc && (long)N >= 1500L * n_mol) RC(launch_bbox(s, n_mol, W.nl));
@@ -706,6 +708,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   // ---- Coulomb: energies, and the seeds of qbar / dE/dx / virial (a closure: it runs on the eval stream or on the side one) ----
   const float* q_fin = nq == 2 ? W.qtot : W.q[np - 2];
   const bool overlap = e->overlap_coulomb && e->prof_level < 2;  // per-family profiling wants one stream
+  bool charges_written = false;  // the DSF walk's charge stream kernel copies q to the `charges` output on its way
   auto coulomb_block = [&](hipStream_t cs) -> int {
     if (nq == 2)  // NSE: alpha + beta is the charge everything downstream sees (aimnet2.py:102-106)
       RC(launch_charge_sum(cs, W.q[np - 2], N, W.qtot, out->spin_charges));
@@ -723,9 +726,11 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       RC(launch_coulomb_simple(cs, grad, q_fin, W.nl.xw, in->mol_idx, W.nl.mol_start, cp, N, W.ecoul, W.qbar, W.fgrad));
     else if (dsf_in_d3)
       ;  // see launch_dftd3 below
-    else if (coulomb == AIMNET_COULOMB_DSF && pbc)
-      RC(launch_coulomb_dsf_walk(cs, grad, want_s, q_fin, in->mol_idx, W.nl, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));
-    else if (coulomb == AIMNET_COULOMB_DSF)
+    else if (coulomb == AIMNET_COULOMB_DSF && pbc) {
+      RC(launch_coulomb_dsf_walk(cs, grad, want_s, q_fin, in->mol_idx, W.nl, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom,
+                                 out->charges));
+      charges_written = true;
+    } else if (coulomb == AIMNET_COULOMB_DSF)
       RC(launch_coulomb_dsf(cs, grad, want_s, q_fin, W.nl.xw, in->mol_idx, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt,
                             cap_lr, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));
     if (d3) {  // external DFT-D3: adds to the per-atom pair energies, dE/dx and the virial seeded by the Coulomb kernels
@@ -741,7 +746,6 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     return 0;
   };
 
-  if (p0m || d3) RC(launch_species(s, in->numbers, e->slot_of_z, N, W.aslot, W.present_part));
   for (int p = 0; p < np; ++p) {
     const std::vector<Layer>& Ls = e->mlp[p];
     const int nl = (int)Ls.size();
@@ -805,7 +809,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     if (overlap) AIMNET_HIP_CHECK(hipStreamWaitEvent(s, e->ev_join, 0));
     RC(prof_mark(e, s, FAM_POINTWISE));
     RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, W.S, W.part, out->energy));
-    RC(launch_copy_f32(s, q_fin, out->charges, (size_t)N));
+    if (!charges_written) RC(launch_copy_f32(s, q_fin, out->charges, (size_t)N));
     return 0;
   };
   if (!grad) {
@@ -882,7 +886,6 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
                          (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, W.fgrad, W.virial_atom, N, order,
                          (W.xe && p > 0) ? W.pairbuf : nullptr, p < np - 1));
     }
-    if (W.xe && p == 1) RC(launch_pair_force(s, W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, N, W.fgrad));
     if (p == 0) break;
     // NSE adjoint of pass p-1, then the adjoint of its MLP output
     const std::vector<Layer>& Lq = e->mlp[p - 1];
@@ -896,8 +899,10 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     std::swap(zcur, znext);
   }
   RC(prof_mark(e, s, FAM_POINTWISE));
+  // reverse-pair form: the pair buffer holds F1 of both passes; its gather is the last contribution to dE/dx and writes the forces
+  if (W.xe && want_f) RC(launch_pair_force(s, W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, N, W.fgrad, out->forces));
   RC(launch_finalize(s, W.fgrad, W.virial_atom, W.nl.mol_start, in->cell, n_cell, n_mol, N, W.S, W.part,
-                     want_f ? out->forces : nullptr, want_s ? out->stress : nullptr));
+                     (want_f && !W.xe) ? out->forces : nullptr, want_s ? out->stress : nullptr));
   RC(prof_mark(e, s, -1));
   return AIMNET_OK;
 }

@@ -37,7 +37,8 @@ size_t nlist_scratch_bytes(int n_atoms, int n_mol);
 size_t nlist_xw_offset(int n_mol);  // byte offset of NlistBuffers::xw inside the scratch
 void nlist_carve(NlistBuffers& b, char* base, int n_atoms, int n_mol);
 int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start, const int* numbers = nullptr,
-                     int* bad = nullptr);  // bad: input sanity flags (bit 0 atomic number outside [0,63], bit 1 mol_idx outside [0,n_mol))
+                     int* bad = nullptr, const int* slot_of_z = nullptr, int* aslot = nullptr,
+                     unsigned long long* present_part = nullptr);  // + the species pass (launch_species) when slot_of_z is given  // bad: input sanity flags (bit 0 atomic number outside [0,63], bit 1 mol_idx outside [0,n_mol))
 // wrap coordinates (periodic) or copy them (non-periodic) into b.xw
 int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
                 int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys = nullptr);  // pbc_sys: device [n_cell][3] or NULL
@@ -74,7 +75,7 @@ bool pair_rev_supported(int n_atoms, int cap);  // row capacity / atom count the
 // sorts every neighbour row by (neighbour, shift) in place (idx, shift, pair geometry), then fills the reverse-pair map
 int launch_pair_rev(hipStream_t s, int* nb_idx, int* nb_shift, const int* nb_cnt, float4* pg, int cap, int n_atoms, int* rev);
 int launch_pair_force(hipStream_t s, const int* nb_idx, const int* nb_cnt, const int* rev, const float4* pairbuf, int cap,
-                      int n_atoms, float* fgrad);
+                      int n_atoms, const float* fgrad, float* forces);  // forces = -(fgrad + pair terms)
 // `order` (conv_fwd / conv_bwd / conv_bwd_p0): optional permutation of the atoms giving the PROCESSING order - the
 // bin-sorted order of the cell list for periodic systems - so that an XCD's centres and the rows they gather stay
 // spatially coherent (and L2-resident) whatever the order of the input file; NULL = input order.
@@ -184,7 +185,8 @@ int launch_coulomb_dsf(hipStream_t s, bool grad, bool stress, const float* q, co
                        float* virial_atom);
 // periodic DSF straight from the cell grid of the last launch_bins (no neighbour matrix)
 int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, NlistBuffers& b,
-                            CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom);
+                            CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom,
+                            float* charges_out = nullptr);  // charges_out: also copy q to the charges output
 int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, int nq, const int* mol_start, int n_mol,
                           int n_atoms, int S, float* part);  // part: [nq][n_mol][S] partial sums, consumed by launch_build_zbar
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,

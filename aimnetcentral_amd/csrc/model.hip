@@ -571,20 +571,25 @@ __global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __re
 
 // bin-ordered (x, y, z, q) stream: the walk then needs ONE coalesced 16-byte load per candidate and no
 // dependent q[j] gather (the list-free DSF kernel was latency-bound on that second load)
+// (charges_out, may be NULL: the `charges` output of the evaluation is written on the way - every atom appears once in the stream)
 __global__ void charge_stream_kernel(const float4* __restrict__ xs, const float* __restrict__ q, int n_atoms,
-                                     float4* __restrict__ xq) {
+                                     float4* __restrict__ xq, float* __restrict__ charges_out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_atoms) return;
   const float4 c = xs[k];
-  xq[k] = make_float4(c.x, c.y, c.z, q[__float_as_int(c.w)]);
+  const int id = __float_as_int(c.w);
+  const float qv = q[id];
+  xq[k] = make_float4(c.x, c.y, c.z, qv);
+  if (charges_out) charges_out[id] = qv;
 }
 
 int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, NlistBuffers& b,
-                            CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom) {
+                            CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom,
+                            float* charges_out) {
   dim3 grid(ceil_div(n_atoms, 4)), block(256);
   const NlistSystem* sys = (const NlistSystem*)b.sys;
   float4* xq = (float4*)b.sorted_tmp_xq;
-  hipLaunchKernelGGL(charge_stream_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.xs, q, n_atoms, xq);
+  hipLaunchKernelGGL(charge_stream_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.xs, q, n_atoms, xq, charges_out);
   AIMNET_LAUNCH_CHECK();
   if (grad && stress)
     hipLaunchKernelGGL((coulomb_dsf_walk_kernel<true, true>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, xq, cp,

@@ -58,9 +58,29 @@ void nlist_carve(NlistBuffers& b, char* p, int n_atoms, int n_mol) {
 // indices to [0, n_mol) for memory safety; *bad gets bit 0 when an atomic number lies outside [0, 63] (the reference's
 // nn.Embedding(64) raises an index error there, core.py:49) and bit 1 when a molecule index lies outside [0, n_mol)
 // (the reference fails in mol_sum / index_add, nbops.py:309-377).  HipEngine.eval turns either into a ValueError.
-__global__ void mol_start_kernel(const int* __restrict__ mol_idx, const int* __restrict__ numbers, int n_atoms, int n_mol,
-                                 int* __restrict__ mol_start, int* __restrict__ bad) {
+// Third job (slot_of_z may be NULL): the species pass of the engine - aslot[i] = model slot of atom i's element and, per block of
+// 256 atoms, the mask of the slots present (present_part[blockIdx.x]); it reads the same `numbers` and saves a launch.
+__global__ __launch_bounds__(256) void mol_start_kernel(const int* __restrict__ mol_idx, const int* __restrict__ numbers,
+                                                        int n_atoms, int n_mol, int* __restrict__ mol_start,
+                                                        int* __restrict__ bad, const int* __restrict__ slot_of_z,
+                                                        int* __restrict__ aslot, unsigned long long* __restrict__ present_part) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot_of_z) {  // (block-uniform)
+    __shared__ unsigned long long s_mask;
+    if (threadIdx.x == 0) s_mask = 0ull;
+    __syncthreads();
+    unsigned long long m = 0ull;
+    if (i < n_atoms) {
+      const int sl = slot_of_z[min(63, max(0, numbers[i]))];
+      aslot[i] = sl;
+      m = 1ull << sl;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m |= __shfl_xor(m, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicOr(&s_mask, m);
+    __syncthreads();
+    if (threadIdx.x == 0) present_part[blockIdx.x] = s_mask;
+  }
   if (i >= n_atoms) return;
   const int prev = (i == 0) ? -1 : min(max(mol_idx[i - 1], -1), n_mol - 1);
   const int raw = mol_idx[i];
@@ -78,9 +98,10 @@ __global__ void mol_start_kernel(const int* __restrict__ mol_idx, const int* __r
     for (int m = cur + 1; m <= n_mol; ++m) mol_start[m] = n_atoms;
 }
 
-int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start, const int* numbers, int* bad) {
+int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start, const int* numbers, int* bad,
+                     const int* slot_of_z, int* aslot, unsigned long long* present_part) {
   hipLaunchKernelGGL(mol_start_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, mol_idx, numbers, n_atoms, n_mol, mol_start,
-                     bad);
+                     bad, (numbers && aslot) ? slot_of_z : nullptr, aslot, present_part);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

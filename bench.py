@@ -257,6 +257,9 @@ def main():
         fam = {k: v / 5 for k, v in eng.read_profile().items() if k != "evals"}
         eng.set_profiling(0)
         n_pairs = int(eng.debug_view("nb_cnt").sum().item())  # ordered pairs inside the 5 A cutoff
+        xe = os.environ.get("AIMNET_CONV_XE", "1") != "0" and n_atoms > int(os.environ.get("AIMNET_SPLIT_MAX", "1024"))
+        gather_form = "reverse-pair" if xe else "combined"
+        gather_bytes = (2 * (4096 + 256 + 16) + 16 + 512) if xe else (2 * 5376 + 512)
         if args.breakdown:
             print("per-family ms/step: " + "  ".join(f"{k}={v:.3f}" for k, v in fam.items()) + f"  total={sum(fam.values()):.3f}",
                   file=sys.stderr)
@@ -299,12 +302,14 @@ def main():
                              "frac": e2e_tflops / PEAK_FP32_MATRIX_TFLOPS, "algorithmic_flop_per_step": e2e_flops,
                              "mean_neighbours": n_pairs / n_atoms, "target_frac": 0.5},
             # second kernel class (SURVEY 8d ii): the gather-contract backward.  Algorithmic gathered bytes per ordered pair:
-            # passes 1, 2 read a_j (1 KiB) + Sbar_j (4 KiB) + Sqbar_j (256 B); pass 0 reads two 256 B species-moment blocks.
-            # These are L2 / Infinity-Cache gathers (the tables are N x 5 KiB << 256 MB), so the roof is the L2 figure of
-            # MI355X_MICROARCH.md (34.5 TB/s), not HBM.
+            # reverse-pair form (default above 1 024 atoms): passes 1, 2 read Sbar_j (4 KiB) + Sqbar_j (256 B) and write F1 into
+            # the pair buffer (16 B, read back once when the passes are summed); combined form (AIMNET_CONV_XE=0): a_j (1 KiB) more;
+            # pass 0 reads two 256 B species-moment blocks.  These are L2 / Infinity-Cache gathers (the tables are N x 4-5 KiB
+            # << 256 MB), so the roof is the L2 figure of MI355X_MICROARCH.md (34.5 TB/s), not HBM.
             "roofline_gather": {"bound": "l2", "kernel": "conv_bwd_kernel + conv_bwd_p0_kernel", "pairs": n_pairs,
-                                "achieved": n_pairs * (2 * 5376 + 512) / (fam["conv_bwd"] * 1e-3) / 1e12, "peak": 34.5,
-                                "unit": "TB/s", "frac": n_pairs * (2 * 5376 + 512) / (fam["conv_bwd"] * 1e-3) / 1e12 / 34.5,
+                                "bytes_per_pair": gather_bytes, "form": gather_form,
+                                "achieved": n_pairs * gather_bytes / (fam["conv_bwd"] * 1e-3) / 1e12, "peak": 34.5,
+                                "unit": "TB/s", "frac": n_pairs * gather_bytes / (fam["conv_bwd"] * 1e-3) / 1e12 / 34.5,
                                 "conv_bwd_ms_per_step": fam["conv_bwd"]},
             "family_ms_per_step": fam,
         }

@@ -48,6 +48,12 @@ struct aimnet_engine {
   int device;
   std::vector<void*> allocs;
   float *afv, *afv_t, *agh_a, *agh_q;  // afv_t: the embedding rows in the operand layout of the MFMA conv kernels
+  // Pass 0, first MLP layer: the first 256 input columns are the constant embedding row afv[Z_i], so their product with the
+  // weights is one of 64 constant vectors: emb_bias0[z] = b + W[:, :256] . afv[z] (fp64 sums at create time).  The GEMM then
+  // runs over the 448 conv columns only (K 704 -> 448) with this table as a row-indexed bias.  set_option("emb_bias", 0) keeps
+  // the full-width GEMM (A/B and parity runs).
+  float* emb_bias0 = nullptr;
+  bool emb_bias = true;
   double* sae;
   // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row
@@ -402,6 +408,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->keep_intermediates = atoi(env) != 0;
     env = getenv("AIMNET_CONV_MFMA");
     if (env) e->conv_mfma = atoi(env);
+    env = getenv("AIMNET_EMB_BIAS");
+    if (env) e->emb_bias = atoi(env) != 0;
     env = getenv("AIMNET_CONV_XE");
     if (env) e->conv_xe = atoi(env);
     env = getenv("AIMNET_CONV_CLUSTER");
@@ -427,6 +435,16 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
       Layer L;
       if ((rc = upload_layer(e, w->mlp_w[p][l], w->mlp_b[p][l], arch->layer_dims[p][l], arch->layer_dims[p][l + 1], &L))) goto fail;
       e->mlp[p].push_back(L);
+      if (p == 0 && l == 0 && L.n_in >= AG) {  // the embedding block of the first layer as a per-element bias table
+        std::vector<float> tab((size_t)64 * L.k_out, 0.0f);
+        for (int z = 0; z < 64; ++z)
+          for (int o = 0; o < L.n_out; ++o) {
+            double acc = (double)w->mlp_b[p][l][o];
+            for (int k = 0; k < AG; ++k) acc += (double)w->mlp_w[p][l][(size_t)o * L.n_in + k] * (double)w->afv[(size_t)z * AG + k];
+            tab[(size_t)z * L.k_out + o] = (float)acc;
+          }
+        if ((rc = dev_upload(e, tab.data(), tab.size(), &e->emb_bias0))) goto fail;
+      }
     }
   }
   if (arch->head_dims[0] != arch->layer_dims[arch->n_pass - 1][arch->n_layers[arch->n_pass - 1]] ||
@@ -520,6 +538,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   if (n == "conv_mfma") e->conv_mfma = value & 3;
   else if (n == "conv_cluster") e->conv_cluster = value != 0;
   else if (n == "conv_xe") e->conv_xe = value != 0;
+  else if (n == "emb_bias") e->emb_bias = value != 0;
   else if (n == "split_max") conv_set_split_max(value);  // process-wide
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -762,6 +781,11 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     RC(prof_mark(e, s, FAM_GEMM));
     for (int l = 0; l < nl; ++l) {
       const bool linear = (l == nl - 1) && ar.last_linear[p];
+      if (p == 0 && l == 0 && e->emb_bias && e->emb_bias0)  // embedding columns folded into the per-element bias table
+        RC(launch_gemm_nt(s, linear ? EPI_BIAS : EPI_BIAS_GELU, hin + 256, ld_in, Ls[l].w + 256, Ls[l].k_in, N, Ls[l].k_out,
+                          Ls[l].k_in - 256, e->emb_bias0, W.H[p][l], linear ? nullptr : W.D[p][l], Ls[l].k_out, in->numbers,
+                          Ls[l].k_out));
+      else
       RC(launch_gemm_nt(s, linear ? EPI_BIAS : EPI_BIAS_GELU, hin, ld_in, Ls[l].w, Ls[l].k_in, N, Ls[l].k_out, Ls[l].k_in,
                         Ls[l].b, W.H[p][l], linear ? nullptr : W.D[p][l], Ls[l].k_out));
       hin = W.H[p][l];

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, (NST == 2 ? 8 : 6)) void gemm_nt_ring_kernel(c
                                                                              const float* __restrict__ Bt, int ldb, int M,
                                                                              int N, int K, const float* __restrict__ bias,
                                                                              float* __restrict__ C, float* __restrict__ D,
-                                                                             int ldc) {
+                                                                             int ldc, const int* __restrict__ brow, int ldbias) {
   constexpr int BM = 64, BN = 64, BK = 16;
   constexpr int STAGE = (BM + BN) * BK;        // floats per stage: A tile then B tile, each [64 rows][4 granules of 16 B]
   constexpr int STAGE_BYTES = STAGE * 4;
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256, (NST == 2 ? 8 : 6)) void gemm_nt_ring_kernel(c
     const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
     if (row >= M) continue;
     const size_t o = (size_t)row * ldc + col;
+    if (brow && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU)) bvv = bias[(size_t)min(63, max(0, brow[row])) * ldbias + col];
     const float v = acc[r];
     if (EPI == EPI_NONE) {
       C[o] = v;
@@ -149,22 +150,22 @@ __global__ __launch_bounds__(256, (NST == 2 ? 8 : 6)) void gemm_nt_ring_kernel(c
 
 template <int NST>
 static int launch_ring(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
-                       const float* bias, float* C, float* D, int ldc) {
+                       const float* bias, float* C, float* D, int ldc, const int* brow, int ldbias) {
   const int tiles = ceil_div(M, 64) * ceil_div(N, 64);
   const size_t lds = (size_t)NST * 128 * 16 * sizeof(float);
   dim3 grid(tiles), block(256);
   switch (epi) {
     case EPI_NONE:
-      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_NONE, NST>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_NONE, NST>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
       break;
     case EPI_BIAS:
-      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_BIAS, NST>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_BIAS, NST>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
       break;
     case EPI_BIAS_GELU:
-      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_BIAS_GELU, NST>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_BIAS_GELU, NST>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
       break;
     case EPI_MUL:
-      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_MUL, NST>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI_MUL, NST>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
       break;
     default:
       set_last_error("gemm: bad epilogue %d", epi);
@@ -222,7 +223,8 @@ __device__ __forceinline__ int swz(int row) {
 template <int EPI, int SM, int SN, int WM, int WN, int BK = 16>
 __global__ __launch_bounds__(512, ((SM * SN > 10 || (BK == 32 && 16 * (SM * WM + SN * WN) > 208)) ? 2 : 4)) void gemm_nt_panel_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb, int M, int N, int K,
-    const float* __restrict__ bias, float* __restrict__ C, float* __restrict__ D, int ldc) {
+    const float* __restrict__ bias, float* __restrict__ C, float* __restrict__ D, int ldc, const int* __restrict__ brow,
+    int ldbias) {
   static_assert(WM * WN == 8, "8 waves");
   static_assert(BK == 16 || BK == 32, "BK");
   constexpr int NST = BK == 16 ? 4 : 3;
@@ -357,6 +359,10 @@ __global__ __launch_bounds__(512, ((SM * SN > 10 || (BK == 32 && 16 * (SM * WM +
       const int row = m0 + wm * 16 * SM + 16 * i + l16;
       if (row >= M) continue;
       const size_t o = (size_t)row * ldc + col;
+      // row-indexed bias table (brow: table row of every output row, e.g. the atom's element): pass 0 folds the constant
+      // embedding block of its first layer into such a table
+      if (brow && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU))
+        bv = *reinterpret_cast<const f32x4*>(bias + (size_t)min(63, max(0, brow[row])) * ldbias + col);
       f32x4 v = acc[i][j];
       if (EPI == EPI_NONE) {
         *reinterpret_cast<f32x4*>(C + o) = v;
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(512, ((SM * SN > 10 || (BK == 32 && 16 * (SM * WM +
 
 template <int SM, int SN, int WM, int WN, int BK = 16>
 static int launch_panel(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
-                        const float* bias, float* C, float* D, int ldc) {
+                        const float* bias, float* C, float* D, int ldc, const int* brow, int ldbias) {
   constexpr int TM = 16 * SM * WM, TN = 16 * SN * WN;
   const int tiles = ceil_div(M, TM) * ceil_div(N, TN);
   const size_t lds = (size_t)(BK == 16 ? 4 : 3) * (TM + TN) * BK * 4;
@@ -397,16 +403,16 @@ static int launch_panel(hipStream_t stream, int epi, const float* A, int lda, co
   dim3 grid(tiles), block(512);
   switch (epi) {
     case EPI_NONE:
-      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_NONE, SM, SN, WM, WN, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_NONE, SM, SN, WM, WN, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
       break;
     case EPI_BIAS:
-      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_BIAS, SM, SN, WM, WN, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_BIAS, SM, SN, WM, WN, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
       break;
     case EPI_BIAS_GELU:
-      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_BIAS_GELU, SM, SN, WM, WN, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_BIAS_GELU, SM, SN, WM, WN, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
       break;
     case EPI_MUL:
-      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_MUL, SM, SN, WM, WN, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL((gemm_nt_panel_kernel<EPI_MUL, SM, SN, WM, WN, BK>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
       break;
     default:
       set_last_error("gemm: bad epilogue %d", epi);
@@ -426,7 +432,8 @@ static int launch_panel(hipStream_t stream, int epi, const float* A, int lda, co
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bt,
                                                             int ldb, int M, int N, int K, const float* __restrict__ bias,
-                                                            float* __restrict__ C, float* __restrict__ D, int ldc) {
+                                                            float* __restrict__ C, float* __restrict__ D, int ldc,
+                                                            const int* __restrict__ brow, int ldbias) {
   constexpr int MAXC = 12;  // 16-wide k chunks in flight per wave
   __shared__ f32x4 part[4][64];
   const int lane = threadIdx.x & 63;
@@ -462,6 +469,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const float* __rest
   // v[r] = C[m0 + (lane & 15)][n0 + 4 (lane >> 4) + r]
   const int row = m0 + l16, col = n0 + 4 * lc;
   if (row >= M) return;
+  if (brow) bias += (size_t)min(63, max(0, brow[row])) * ldbias;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (col + r >= N) continue;
@@ -483,20 +491,20 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const float* __rest
 }
 
 static int launch_skinny(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
-                         const float* bias, float* C, float* D, int ldc) {
+                         const float* bias, float* C, float* D, int ldc, const int* brow, int ldbias) {
   dim3 grid(ceil_div(M, 16) * ceil_div(N, 16)), block(256);
   switch (epi) {
     case EPI_NONE:
-      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI_NONE>, grid, block, 0, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI_NONE>, grid, block, 0, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
       break;
     case EPI_BIAS:
-      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI_BIAS>, grid, block, 0, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI_BIAS>, grid, block, 0, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
       break;
     case EPI_BIAS_GELU:
-      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI_BIAS_GELU>, grid, block, 0, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI_BIAS_GELU>, grid, block, 0, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
       break;
     case EPI_MUL:
-      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI_MUL>, grid, block, 0, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI_MUL>, grid, block, 0, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
       break;
     default:
       set_last_error("gemm: bad epilogue %d", epi);
@@ -557,7 +565,7 @@ static int choose_tile(int M, int N, bool vec_ok) {
 }
 
 int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N,
-                       int K, const float* bias, float* C, float* D, int ldc) {
+                       int K, const float* bias, float* C, float* D, int ldc, const int* brow, int ldbias) {
   if (M <= 0) return 0;
   if (K % BK_DEFAULT != 0 || (lda & 3) || (ldb & 3)) {
     set_last_error("gemm: K=%d must be a multiple of %d and lda/ldb multiples of 4", K, BK_DEFAULT);
@@ -567,8 +575,8 @@ int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int
   if (cfg == 0) cfg = choose_tile(M, N, ((N | ldc) & 3) == 0 && (((size_t)bias | (size_t)C | (size_t)D) & 15) == 0);
   switch (cfg) {
 #define AIMNET_PANEL_CASE(ID, SM_, SN_, WM_, WN_) \
-    case ID: return launch_panel<SM_, SN_, WM_, WN_>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);      \
-    case 1000 + ID: return launch_panel<SM_, SN_, WM_, WN_, 32>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    case ID: return launch_panel<SM_, SN_, WM_, WN_>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);      \
+    case 1000 + ID: return launch_panel<SM_, SN_, WM_, WN_, 32>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
     // panel kernels: id = 100*arrangement + 10*SM + SN; arrangement 1 = 2x4 waves, 2 = 4x2, 3 = 1x8
     AIMNET_PANEL_CASE(152, 5, 2, 2, 4)  // 160 x 128
     AIMNET_PANEL_CASE(142, 4, 2, 2, 4)  // 128 x 128
@@ -592,8 +600,8 @@ int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int
     AIMNET_PANEL_CASE(321, 2, 1, 1, 8)  //  32 x 128
     AIMNET_PANEL_CASE(233, 3, 3, 4, 2)  // 192 x  96
 #undef AIMNET_PANEL_CASE
-    case 5: return launch_ring<3>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
-    case 7: return launch_skinny(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+    case 5: return launch_ring<3>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
+    case 7: return launch_skinny(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
     default:
       set_last_error("gemm: unknown tile id %d", cfg);
       return -1;
@@ -601,8 +609,8 @@ int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int
 }
 
 int launch_gemm_nt(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N,
-                   int K, const float* bias, float* C, float* D, int ldc) {
-  return launch_gemm_nt_cfg(stream, 0, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
+                   int K, const float* bias, float* C, float* D, int ldc, const int* brow, int ldbias) {
+  return launch_gemm_nt_cfg(stream, 0, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
 }
 
 int gemm_set_attributes() {

@@ -396,6 +396,9 @@ class HipEngine:
         hd = self.spec.head_dims
         macs += sum(hd[i] * hd[i + 1] for i in range(len(hd) - 2))
         total = 2.0 * macs * (2 if backward else 1)
+        # pass 0, first layer: the 256 embedding columns are folded into a per-element bias table at create time, the GEMM
+        # runs over the 448 conv columns (engine.hip, emb_bias0) - not counted, it is not executed
+        total -= 2.0 * 256 * self.spec.mlp_dims[0][1]
         if backward:
             # the pass-0 input gradient with respect to the (constant) embedding block is never formed:
             # the last backward GEMM of pass 0 has N = 448, not 704 (engine.hip, "only the conv columns")

@@ -185,6 +185,7 @@ int aimnet_debug_gemm(int cfg, int epi, const float* A, int lda, const float* Bt
 
 /* Engine switches for A/B and parity runs (all have an AIMNET_* environment twin read at create time):
  *   "conv_xe"       1 (default): reverse-pair form of the conv backward for systems above the split threshold, 0: combined form
+ *   "emb_bias"      1 (default): pass 0's first GEMM runs over the conv columns, the embedding block is a per-element bias table
  *   "conv_cluster"  1: conv backward of passes >= 1 for clusters of four centre atoms (csrc/conv_cluster.hip)
  *   "conv_mfma"     bit 0: conv forward, bit 1: conv backward on the v_mfma_f32_4x4x1_16B_f32 kernels (csrc/conv_mfma.hip)
  *                   instead of the packed-FMA VALU kernels (default 0; systems above the split threshold only)

@@ -90,3 +90,20 @@ def test_nse_two_channel_model(synth_sd_nse, oracle32_nse):
         assert np.abs(res["charges"].cpu().numpy() - ref["charges"]).max() < 1e-4
     finally:
         eng.set_option("split_max", -1)
+
+
+def test_embedding_bias_table_switch(synth_sd):
+    """Pass 0's first GEMM over the 448 conv columns with the embedding block folded into a per-element bias table
+    (engine.hip, emb_bias0; default) against the full-width GEMM (`emb_bias = 0`)."""
+    from aimnetcentral_amd import loader
+    from aimnetcentral_amd.engine import HipEngine
+
+    on, off = HipEngine(loader.synthetic_spec(0), "cuda:0"), HipEngine(loader.synthetic_spec(0), "cuda:0")
+    off.set_option("emb_bias", 0)
+    for name, coul, kw in (("taxol", "simple", {}), ("pbc96_dsf15", "dsf", dict(dsf_rc=15.0, dsf_alpha=0.2))):
+        g = golden(name)
+        r1, _ = run(on, g, coul, stress=coul == "dsf", **kw)
+        r0, _ = run(off, g, coul, stress=coul == "dsf", **kw)
+        assert abs(r1["energy"][0] - r0["energy"][0]) < 2e-5, name
+        assert np.abs(r1["forces"] - r0["forces"]).max() < 2e-5, name
+        assert np.abs(r1["charges"] - r0["charges"]).max() < 2e-6, name

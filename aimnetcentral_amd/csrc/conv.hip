@@ -38,6 +38,7 @@ struct FwdWaveLds {
   int j[CH];
   float fc[CH];       // cutoff envelope fc(d) of the chunk (one sincos per pair)
   float qj[2][CH];    // neighbour charges, one row per charge channel
+  float mt[64];       // P0M: one species' moments M[g][c], handed from the (g,c) lane map to the (a, 4 shifts) one
 };
 
 // `row_of` (may be NULL): feature row of atom j inside `a`.  Pass 0 gathers straight from the
@@ -50,7 +51,11 @@ struct FwdWaveLds {
 // agh_q [NQ][G][H], row layout [q (NQ) | S^q_s (NQ x 16) | |V^q|^2 (NQ x 12)] as ConvSV(nchannel=NQ) emits it, aev.py:188).
 // one wave per atom: four blocks per CU = 4 waves per SIMD (128 VGPRs; the kernel is latency-bound and gains 6 % over three);
 // SPLIT holds three blocks' worth of LDS per CU anyway
-template <int NQ, bool SPLIT>
+// P0M (pass 0, one wave per atom, NQ = 0): the neighbour features are rows of the embedding table, a_j = afv[Z_j], so
+//   S_i[a,g,c] = sum_z afv[z][a,g] M_i[z][g,c],   M_i[z][g,c] = sum_{j: Z_j = z} gs_g(d_ij) (1,u_ij)_c :
+// the chunk's neighbours are ordered by element, the pair loop accumulates ONE number per lane (g,c) and pair (no row gather,
+// no 16 FMAs per lane), and each element present costs one 16-FMA flush.  The forward twin of the species-moment backward.
+template <int NQ, bool SPLIT, bool P0M = false>
 __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
                                                       const float* __restrict__ q,
                                                       const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
@@ -99,7 +104,35 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
     for (int c0 = 0; c0 < cmax; c0 += CH) {
       const int nch = max(0, min(CH, cnt - c0));
       lds_sync<SPLIT>();  // previous chunk fully consumed
-      if (lane < nch) {
+      if (P0M) {
+        // stage the chunk ordered by element: one round per distinct element present (3-5 in organic crystals)
+        const bool valid = lane < nch;
+        int zj = 0;
+        float4 ud = make_float4(0.f, 0.f, 0.f, 1.f);
+        float fcv = 0.f;
+        if (valid) {
+          const size_t p = (size_t)i * cap + m_lo + c0 + lane;
+          zj = min(63, max(0, row_of[nb_idx[p]]));
+          ud = pg[p];
+          float dfc;
+          fcv = basis_fc(bp, ud.w, dfc);
+        }
+        unsigned long long rem = __ballot(valid);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int base = 0, pos = lane;
+        while (rem) {  // wave-uniform
+          const int zs = __shfl(zj, __ffsll((long long)rem) - 1, 64);
+          const bool mine = valid && zj == zs;
+          const unsigned long long m = __ballot(mine);
+          if (mine) pos = base + __popcll(m & lt);
+          base += __popcll(m);
+          rem &= ~m;
+        }
+        if (!valid) pos = lane;  // slots nch..63 keep a defined (zero-weight) entry
+        L.j[pos] = zj;
+        L.ud[pos] = ud;
+        L.fc[pos] = fcv;
+      } else if (lane < nch) {
         const size_t p = (size_t)i * cap + m_lo + c0 + lane;
         const int j = nb_idx[p];
         L.j[lane] = row_of ? min(63, max(0, row_of[j])) : j;
@@ -153,14 +186,46 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
           for (int ch = 0; ch < NQ; ++ch) accq[ch] += L.qj[ch][mm] * w;
         }
       };
-      const int nch4 = (nch + 3) & ~3;  // rows >= nch have gs = 0 and a valid (clamped) index: harmless
-      float4 r0 = row(0), r1 = row(1), r2 = row(2), r3 = row(3);
-      for (int mm = 0; mm < nch4; mm += 4) {
-        const float4 c0 = r0, c1 = r1, c2 = r2, c3 = r3;
-        if (mm + 4 < nch4) {
-          r0 = row(mm + 4); r1 = row(mm + 5); r2 = row(mm + 6); r3 = row(mm + 7);
+      if (P0M) {
+        const int gq = lane >> 2;
+        auto flush = [&](int z, float m) {  // S_i += afv[z] (x) M[z]
+          L.mt[lane] = m;
+          lds_sync<false>();
+          const float4 av = reinterpret_cast<const float4*>(a + (size_t)z * NF)[lane];
+          const float avv[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi) {
+            const float4 m4 = *reinterpret_cast<const float4*>(&L.mt[(g4 + gi) * 4]);
+            acc[0][gi >> 1][gi & 1] += avv[gi] * m4.x;
+            acc[1][gi >> 1][gi & 1] += avv[gi] * m4.y;
+            acc[2][gi >> 1][gi & 1] += avv[gi] * m4.z;
+            acc[3][gi >> 1][gi & 1] += avv[gi] * m4.w;
+          }
+          lds_sync<false>();
+        };
+        int cur = -1;
+        float accm = 0.f;
+        for (int mm = 0; mm < nch; ++mm) {
+          const int zs = __builtin_amdgcn_readfirstlane(L.j[mm]);
+          if (zs != cur) {
+            if (cur >= 0) flush(cur, accm);
+            accm = 0.f;
+            cur = zs;
+          }
+          const float4 u = L.ud[mm];
+          accm += L.gs[mm][gq] * (fm0 + fm1 * u.x + fm2 * u.y + fm3 * u.z);
         }
-        use(mm, c0); use(mm + 1, c1); use(mm + 2, c2); use(mm + 3, c3);
+        if (cur >= 0) flush(cur, accm);
+      } else {
+        const int nch4 = (nch + 3) & ~3;  // rows >= nch have gs = 0 and a valid (clamped) index: harmless
+        float4 r0 = row(0), r1 = row(1), r2 = row(2), r3 = row(3);
+        for (int mm = 0; mm < nch4; mm += 4) {
+          const float4 c0 = r0, c1 = r1, c2 = r2, c3 = r3;
+          if (mm + 4 < nch4) {
+            r0 = row(mm + 4); r1 = row(mm + 5); r2 = row(mm + 6); r3 = row(mm + 7);
+          }
+          use(mm, c0); use(mm + 1, c1); use(mm + 2, c2); use(mm + 3, c3);
+        }
       }
     }
     lds_sync<SPLIT>();
@@ -276,9 +341,15 @@ void conv_set_split_max(int n) { g_split_max = n < 0 ? SPLIT_MAX_ATOMS : n; }
 
 int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, const float* q, const int* nb_idx,
                     const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
-                    float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order) {
+                    float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order, bool species_moments) {
   const bool split = n_atoms <= conv_split_max_atoms();
   const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), 256 * 8);
+  if (species_moments && row_of && nq == 0 && !split) {  // pass 0 of a large system: per-element moments instead of row gathers
+    hipLaunchKernelGGL((conv_fwd_kernel<0, false, true>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a,
+                       agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order);
+    AIMNET_LAUNCH_CHECK();
+    return 0;
+  }
 #define AIMNET_FWD(HQ, SP)                                                                                                  \
   hipLaunchKernelGGL((conv_fwd_kernel<HQ, SP>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a, agh_q, \
                      bp, x, ldx, Vsave, Vqsave, n_atoms, order)

@@ -68,7 +68,7 @@ struct aimnet_engine {
   // GEMM has consumed it (the backward reads GELU', not the activations), and a buffer that is rewritten while its lines
   // are still in the Infinity Cache never costs HBM write bandwidth
   bool keep_intermediates = false;
-  bool p0_moments = true;  // AIMNET_P0_MOMENTS=0 keeps the generic conv_bwd for pass 0 (A/B and parity runs)
+  bool p0_moments = true;  // AIMNET_P0_MOMENTS=0 keeps the generic conv_fwd / conv_bwd for pass 0 (A/B and parity runs)
   // AIMNET_CONV_MFMA / set_option("conv_mfma"): bit 0 = conv_fwd, bit 1 = conv_bwd (+ unconcat T layout) on the 4x4x1 MFMA
   // kernels of conv_mfma.hip for systems above the split threshold; 0 (default) = the packed-FMA VALU kernels of conv.hip.
   // Measured on config 3 (profiles/r2_conv_mfma.md): forward 81 us either way, backward 293 vs 226 us - neither form is
@@ -775,7 +775,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
                               Ls[0].k_in, W.V[p], W.Vq[p], N, order));
     else
       RC(launch_conv_fwd(s, p > 0 ? nq : 0, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr, p > 0 ? W.q[p - 1] : nullptr,
-                         W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q, e->bp, W.x[p], Ls[0].k_in, W.V[p], W.Vq[p], N, order));
+                         W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q, e->bp, W.x[p], Ls[0].k_in, W.V[p], W.Vq[p], N, order,
+                         p == 0 && e->p0_moments));
     const float* hin = W.x[p];
     int ld_in = Ls[0].k_in;
     RC(prof_mark(e, s, FAM_GEMM));

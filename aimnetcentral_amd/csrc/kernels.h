@@ -64,7 +64,8 @@ struct BasisParams {  // radial basis of AEVSV (aev.py:66-81), passed by value
 // q / qbar are planes [nq][n_atoms], agh_q [nq][G][H], Vqsave [N][nq][H*3], Sqbar [N][nq][G*4]
 int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, const float* q, const int* nb_idx,
                     const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
-                    float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order);
+                    float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order,
+                    bool species_moments = false);  // pass 0 (row_of given, nq = 0): per-element moments, no row gathers
 int launch_unconcat(hipStream_t s, int nq, const float* xbar, int ldx, const float* Vsave, const float* Vqsave,
                     const float* agh_a, const float* agh_q, float* Sbar, float* Sqbar, int n_atoms);
 int launch_conv_bwd(hipStream_t s, int nq, bool need_abar, bool stress, const float* a, const int* row_of,

@@ -81,11 +81,29 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
   __shared__ float s_red[SPLIT ? 3 * (16 + NQC) * 64 : 1];  // SPLIT: accumulators of waves 1..3
 
   const AtomLoop al = atom_loop(n_atoms, SPLIT ? 1 : APB);
+  // One-wave-per-atom form: the id, the row count and the first chunk's neighbour ids / pair geometry of the wave's NEXT atom
+  // are requested before the epilogue of the current one, so the dependent chain order -> row -> neighbours (three L2 / HBM
+  // latencies per atom that nothing else in the wave can hide) runs under the epilogue's ~700 instructions.
+  int pf_i = 0, pf_cnt = 0, pf_j = 0;
+  bool pf_live = false;
+  float4 pf_ud = make_float4(0.f, 0.f, 0.f, 1.f);
+  auto prefetch_atom = [&](int i0n) {
+    pf_live = i0n < al.last && i0n + wid < al.last;
+    pf_i = __builtin_amdgcn_readfirstlane(pf_live ? (order ? order[i0n + wid] : i0n + wid) : 0);
+    pf_cnt = pf_live ? nb_cnt[pf_i] : 0;
+    if (pf_live && lane < cap) {
+      pf_j = nb_idx[(size_t)pf_i * cap + lane];
+      pf_ud = pg[(size_t)pf_i * cap + lane];
+    }
+  };
+  if (!SPLIT) prefetch_atom(al.first);
   for (int i0 = al.first; i0 < al.last; i0 += al.step) {
     const int aslot = SPLIT ? 0 : wid;  // which atom of this block iteration the wave works on
-    const bool live_atom = i0 + aslot < al.last;
-    const int i = live_atom ? (order ? order[i0 + aslot] : i0 + aslot) : 0;  // `order`: spatially sorted processing order
-    const int cnt_all = live_atom ? nb_cnt[i] : 0;
+    const bool live_atom = SPLIT ? i0 + aslot < al.last : pf_live;
+    const int i = SPLIT ? (live_atom ? (order ? order[i0 + aslot] : i0 + aslot) : 0) : pf_i;  // `order`: spatially sorted processing order
+    const int cnt_all = SPLIT ? (live_atom ? nb_cnt[i] : 0) : __builtin_amdgcn_readfirstlane(pf_cnt);
+    const int cur_j = pf_j;
+    const float4 cur_ud = pf_ud;
     int m_lo = 0, cnt = cnt_all;
     int cmax = cnt;  // SPLIT: block-uniform trip count so that __syncthreads() is legal; otherwise the wave's own count
     if (SPLIT) {
@@ -112,8 +130,9 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
         float fcv = 0.f;
         if (valid) {
           const size_t p = (size_t)i * cap + m_lo + c0 + lane;
-          zj = min(63, max(0, row_of[nb_idx[p]]));
-          ud = pg[p];
+          const bool pre = !SPLIT && c0 == 0;  // the first chunk was requested one atom ahead
+          zj = min(63, max(0, row_of[pre ? cur_j : nb_idx[p]]));
+          ud = pre ? cur_ud : pg[p];
           float dfc;
           fcv = basis_fc(bp, ud.w, dfc);
         }
@@ -134,9 +153,10 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
         L.fc[pos] = fcv;
       } else if (lane < nch) {
         const size_t p = (size_t)i * cap + m_lo + c0 + lane;
-        const int j = nb_idx[p];
+        const bool pre = !SPLIT && c0 == 0;  // the first chunk was requested one atom ahead
+        const int j = pre ? cur_j : nb_idx[p];
         L.j[lane] = row_of ? min(63, max(0, row_of[j])) : j;
-        const float4 ud = pg[p];
+        const float4 ud = pre ? cur_ud : pg[p];
         L.ud[lane] = ud;
         float dfc;
         L.fc[lane] = basis_fc(bp, ud.w, dfc);
@@ -228,6 +248,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
         }
       }
     }
+    if (!SPLIT) prefetch_atom(i0 + al.step);  // lands under the epilogue below
     lds_sync<SPLIT>();
     if (SPLIT) {  // waves 1..3 hand their 16 + NQ partial sums per lane to wave 0
       if (wid > 0) {

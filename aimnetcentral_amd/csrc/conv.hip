@@ -364,7 +364,9 @@ int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, co
                     const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
                     float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order, bool species_moments) {
   const bool split = n_atoms <= conv_split_max_atoms();
-  const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), 256 * 8);
+  // (one-wave-per-atom form: exactly the 4 blocks per CU that are resident - with twice as many the second half only queues
+  // behind the first and pays the block prologue again: 0.217 -> 0.207 ms/step over the three launches)
+  const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), 256 * 4);
   if (species_moments && row_of && nq == 0 && !split) {  // pass 0 of a large system: per-element moments instead of row gathers
     hipLaunchKernelGGL((conv_fwd_kernel<0, false, true>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a,
                        agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order);
@@ -881,7 +883,7 @@ int launch_conv_bwd(hipStream_t s, int nq, bool need_abar, bool stress, const fl
                     float4* pairbuf, bool pb_accum) {
   const bool split = n_atoms <= conv_split_max_atoms();
   const bool xe = pairbuf != nullptr && !split;  // reverse-pair form: F1 of every ordered pair into pairbuf (see the kernel)
-  const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), 256 * 8);
+  const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), 256 * 4);
 #define AIMNET_BWD(HQ, NA, ST, SP, XE)                                                                                      \
   hipLaunchKernelGGL((conv_bwd_kernel<HQ, NA, ST, SP, XE>), dim3(grid), dim3(256), 0, s, a, row_of, q, Sbar, Sqbar, nb_idx,  \
                      nb_cnt, pg, cap, bp, xbar, ldx, abar_in, abar_out, qbar_in, qbar_out, fgrad, virial_atom, n_atoms, order, \
@@ -1176,7 +1178,7 @@ __global__ __launch_bounds__(256) void unconcat_p0_kernel(const float* __restric
 int launch_unconcat_p0(hipStream_t s, const float* xbar, int ldx, const float* Vsave, const float* agh_a, const float* afv,
                        const int* z_of_slot, int nslots, const unsigned long long* present_part, int n_part, float* T,
                        int n_atoms) {
-  const int grid = min(ceil_div(n_atoms, APB), 256 * 4);
+  const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
   const size_t lds = sizeof(float) * ((size_t)A_ * G_ * H_ + APB * NV * 3 + APB * A_ * 65 + (size_t)nslots * NF);
   static PerDeviceOnce once;
   if (once.first())

@@ -41,7 +41,10 @@ __device__ __forceinline__ AtomLoop atom_loop(int n_atoms, int apb) {
   return AtomLoop{(lo + slot) * apb, hi * apb < n_atoms ? hi * apb : n_atoms, per * apb};
 }
 
-// radial basis value (and optionally d/dd) for one (pair, shift)
+// cutoff envelope fc(d) = 0.5 (cos(pi d / rc) + 1) and its derivative (AEVSV._calc_aev, modules/aev.py:94-110), one call per pair.
+// (sincosf on the fp32 product d * (pi / rc), as the reference forms it: a polynomial in t = d / rc is 3x cheaper and closer to
+// the exact value, but its error no longer follows the fp32 reference's argument rounding and the tightest energy gate
+// (batch5, 2e-5 eV) fails - measured, reverted.)
 __device__ __forceinline__ float basis_fc(const BasisParams& bp, float d, float& dfc) {
   const float dc = fminf(fmaxf(d, 1e-6f), bp.rc);
   const float w = PI_F / bp.rc;

@@ -188,9 +188,8 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
       const int qc_f = lane & 3;
       const float fm0 = qc_f == 0 ? 1.f : 0.f, fm1 = qc_f == 1 ? 1.f : 0.f, fm2 = qc_f == 2 ? 1.f : 0.f,
                   fm3 = qc_f == 3 ? 1.f : 0.f;
-      auto row = [&](int mm) {
-        const int j = __builtin_amdgcn_readfirstlane(L.j[min(mm, CH - 1)]);  // wave-uniform -> scalar address
-        return reinterpret_cast<const float4*>(a + (size_t)j * NF)[lane];
+      auto rowj = [&](int j) {  // j wave-uniform -> scalar address
+        return reinterpret_cast<const float4*>(a + (size_t)__builtin_amdgcn_readfirstlane(j) * NF)[lane];
       };
       auto use = [&](int mm, const float4& av) {
         const float4 gv = *reinterpret_cast<const float4*>(&L.gs[mm][g4]);
@@ -238,11 +237,14 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
         if (cur >= 0) flush(cur, accm);
       } else {
         const int nch4 = (nch + 3) & ~3;  // rows >= nch have gs = 0 and a valid (clamped) index: harmless
-        float4 r0 = row(0), r1 = row(1), r2 = row(2), r3 = row(3);
+        // (the four ids of a group come with one uniform-address ds_read_b128; mm + 4 <= 60 inside the guard)
+        int4 jj = *reinterpret_cast<const int4*>(&L.j[0]);
+        float4 r0 = rowj(jj.x), r1 = rowj(jj.y), r2 = rowj(jj.z), r3 = rowj(jj.w);
         for (int mm = 0; mm < nch4; mm += 4) {
           const float4 c0 = r0, c1 = r1, c2 = r2, c3 = r3;
           if (mm + 4 < nch4) {
-            r0 = row(mm + 4); r1 = row(mm + 5); r2 = row(mm + 6); r3 = row(mm + 7);
+            jj = *reinterpret_cast<const int4*>(&L.j[mm + 4]);
+            r0 = rowj(jj.x); r1 = rowj(jj.y); r2 = rowj(jj.z); r3 = rowj(jj.w);
           }
           use(mm, c0); use(mm + 1, c1); use(mm + 2, c2); use(mm + 3, c3);
         }

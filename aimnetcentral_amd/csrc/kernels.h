@@ -32,6 +32,7 @@ struct NlistBuffers {      // all device pointers, carved from the caller's work
   int* sorted;             // [n_atoms]
   float4* xs;              // [n_atoms] bin-ordered (x, y, z, atom id)
   void* sorted_tmp_xq;     // [n_atoms] float4 bin-ordered (x, y, z, charge) for the list-free DSF walk
+  float prebinned_width = 0.0f;  // host flag: launch_wrap prepared the bins for this width (launch_bins starts at the scan)
   bool binned = false;     // host flag: `sys` + bins describe this batch (periodic cells, or bounding boxes via launch_bbox)
 };
 size_t nlist_scratch_bytes(int n_atoms, int n_mol);
@@ -42,7 +43,7 @@ int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, 
                      unsigned long long* present_part = nullptr);  // + the species pass (launch_species) when slot_of_z is given  // bad: input sanity flags (bit 0 atomic number outside [0,63], bit 1 mol_idx outside [0,n_mol))
 // wrap coordinates (periodic) or copy them (non-periodic) into b.xw
 int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
-                int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys = nullptr);  // pbc_sys: device [n_cell][3] or NULL
+                int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys = nullptr, float bin_width = 0.0f);  // pbc_sys: device [n_cell][3] or NULL
 // non-periodic systems: give every molecule the cell grid of its bounding box (after launch_wrap), so that launch_nlist
 // takes the cell-list path instead of the O(n^2) per-molecule scan; worth it from ~10^3 atoms per molecule
 int launch_bbox(hipStream_t s, int n_mol, NlistBuffers& b);

@@ -108,10 +108,8 @@ int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, 
 
 // ------------------------------------------------------------------------------------------------
 // pbc_sys (may be NULL): per-system periodicity flags [n_cell][3] (normalize_pbc, neighbors.py:309-321) overriding p0..p2
-__global__ void cell_setup_kernel(const float* __restrict__ cell, int n_cell, int n_mol, int p0, int p1, int p2,
-                                  const int* __restrict__ pbc_sys, NlistSystem* __restrict__ sys) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_mol) return;
+__device__ void cell_setup_one(const float* __restrict__ cell, int n_cell, int s, int p0, int p1, int p2,
+                               const int* __restrict__ pbc_sys, NlistSystem* __restrict__ sys) {
   const float* c = cell + (n_cell == 1 ? 0 : (size_t)s * 9);
   NlistSystem S;
   double m[9];
@@ -163,8 +161,13 @@ __global__ void cell_setup_kernel(const float* __restrict__ cell, int n_cell, in
   sys[s] = S;
 }
 
-// Non-periodic systems large enough for a cell list: the "cell" is the axis-aligned bounding box of the molecule
-// (no periodic axis, origin at its corner), so that the bin / walk machinery of the periodic path serves them too.
+__global__ void cell_setup_kernel(const float* __restrict__ cell, int n_cell, int n_mol, int p0, int p1, int p2,
+                                  const int* __restrict__ pbc_sys, NlistSystem* __restrict__ sys) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_mol) return;
+  cell_setup_one(cell, n_cell, s, p0, p1, p2, pbc_sys, sys);
+}
+
 __global__ __launch_bounds__(256) void bbox_setup_kernel(const float* __restrict__ coord, const int* __restrict__ mol_start,
                                                         NlistSystem* __restrict__ sys) {
   const int s = blockIdx.x;
@@ -232,9 +235,33 @@ __global__ void wrap_kernel(const float* __restrict__ coord, const int* __restri
   for (int k = 0; k < 3; ++k) xw[3 * i + k] = f[0] * S.c[k] + f[1] * S.c[3 + k] + f[2] * S.c[6 + k];
 }
 
+// (defined with the binning kernels below)
+__global__ void cell_bins_setup_kernel(const float* __restrict__ cell, int n_cell, int n_mol, int p0, int p1, int p2,
+                                       const int* __restrict__ pbc_sys, NlistSystem* __restrict__ sys,
+                                       const int* __restrict__ mol_start, float w, int* __restrict__ bin_count, int n_zero);
+__global__ void wrap_bin_count_kernel(const float* __restrict__ coord, const int* __restrict__ mol_idx, int n_atoms,
+                                      const NlistSystem* __restrict__ sys, float* __restrict__ xw, int* __restrict__ atom_bin,
+                                      int* __restrict__ bin_count, int* __restrict__ slot);
+
+// bin_width > 0 (periodic systems only): the bins of the following launch_bins(width = bin_width) are prepared on the way -
+// cell + bin-grid setup in one launch, wrapping + bin counting in one launch; launch_bins then starts at the scan.
 int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
-                int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys) {
+                int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys, float bin_width) {
   NlistSystem* sys = nullptr;
+  b.prebinned_width = 0.0f;
+  if (cell != nullptr && bin_width > 0.0f && n_mol <= 4096) {
+    sys = (NlistSystem*)b.sys;
+    const int max_bins = n_atoms + 8 * n_mol + 8;
+    hipLaunchKernelGGL(cell_bins_setup_kernel, dim3(1), dim3(256), 0, s, cell, n_cell, n_mol, pbc[0], pbc[1], pbc[2], pbc_sys, sys,
+                       b.mol_start, bin_width, b.bin_count, max_bins + 1);
+    AIMNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wrap_bin_count_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, coord, mol_idx, n_atoms, sys, b.xw,
+                       b.atom_bin, b.bin_count, b.bin_fill);
+    AIMNET_LAUNCH_CHECK();
+    b.binned = true;
+    b.prebinned_width = bin_width;
+    return 0;
+  }
   if (cell != nullptr) {
     sys = (NlistSystem*)b.sys;
     hipLaunchKernelGGL(cell_setup_kernel, dim3(ceil_div(n_mol, 64)), dim3(64), 0, s, cell, n_cell, n_mol, pbc[0], pbc[1],
@@ -304,8 +331,7 @@ __global__ __launch_bounds__(256) void nlist_brute_kernel(const float* __restric
 // (the launcher of this kernel is launch_nlist below)
 
 // periodic: choose the bin grid of every system for this cutoff, then a serial prefix of bin offsets
-__global__ void bins_setup_kernel(NlistSystem* __restrict__ sys, const int* __restrict__ mol_start, int n_mol,
-                                  float w) {
+__device__ void bins_setup_block(NlistSystem* __restrict__ sys, const int* __restrict__ mol_start, int n_mol, float w) {
   for (int s = threadIdx.x; s < n_mol; s += blockDim.x) {
     NlistSystem S = sys[s];
     const int ns = mol_start[s + 1] - mol_start[s];
@@ -336,6 +362,24 @@ __global__ void bins_setup_kernel(NlistSystem* __restrict__ sys, const int* __re
   }
 }
 
+__global__ void bins_setup_kernel(NlistSystem* __restrict__ sys, const int* __restrict__ mol_start, int n_mol,
+                                  float w) {
+  bins_setup_block(sys, mol_start, n_mol, w);
+}
+
+// periodic fast path (launch_wrap with a bin width): cell setup, bin grids and the zeroing of the bin counters in ONE
+// single-block launch (these are a few microseconds of work each; as separate kernels they cost a launch latency apiece)
+__global__ void cell_bins_setup_kernel(const float* __restrict__ cell, int n_cell, int n_mol, int p0,
+                                                             int p1, int p2, const int* __restrict__ pbc_sys,
+                                                             NlistSystem* __restrict__ sys,
+                                                             const int* __restrict__ mol_start, float w,
+                                                             int* __restrict__ bin_count, int n_zero) {
+  for (int s = threadIdx.x; s < n_mol; s += blockDim.x) cell_setup_one(cell, n_cell, s, p0, p1, p2, pbc_sys, sys);
+  for (int k = threadIdx.x; k < n_zero; k += blockDim.x) bin_count[k] = 0;
+  __syncthreads();
+  bins_setup_block(sys, mol_start, n_mol, w);
+}
+
 // slot[i] = arrival rank of atom i inside its bin (any order: bin_sort_kernel orders every bin by atom id afterwards)
 __global__ void bin_count_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx, int n_atoms,
                                  const NlistSystem* __restrict__ sys, int* __restrict__ atom_bin,
@@ -344,6 +388,33 @@ __global__ void bin_count_kernel(const float* __restrict__ xw, const int* __rest
   if (i >= n_atoms) return;
   int b[3];
   const int bin = bin_of(sys[mol_idx[i]], xw[3 * i], xw[3 * i + 1], xw[3 * i + 2], b);
+  atom_bin[i] = bin;
+  slot[i] = atomicAdd(&bin_count[bin], 1);
+}
+
+// wrap + bin_count in one pass over the atoms (periodic fast path)
+__global__ void wrap_bin_count_kernel(const float* __restrict__ coord, const int* __restrict__ mol_idx, int n_atoms,
+                                      const NlistSystem* __restrict__ sys, float* __restrict__ xw,
+                                      int* __restrict__ atom_bin, int* __restrict__ bin_count, int* __restrict__ slot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  const NlistSystem& S = sys[mol_idx[i]];
+  const float x = coord[3 * i], y = coord[3 * i + 1], z = coord[3 * i + 2];
+  float f[3];
+  for (int k = 0; k < 3; ++k) {
+    f[k] = x * S.inv[k] + y * S.inv[3 + k] + z * S.inv[6 + k];
+    if (S.per[k]) {
+      f[k] -= floorf(f[k]);
+      if (f[k] >= 1.0f) f[k] = 0.0f;
+    }
+  }
+  float w[3];
+  for (int k = 0; k < 3; ++k) w[k] = f[0] * S.c[k] + f[1] * S.c[3 + k] + f[2] * S.c[6 + k];
+  xw[3 * i] = w[0];
+  xw[3 * i + 1] = w[1];
+  xw[3 * i + 2] = w[2];
+  int b[3];
+  const int bin = bin_of(S, w[0], w[1], w[2], b);
   atom_bin[i] = bin;
   slot[i] = atomicAdd(&bin_count[bin], 1);
 }
@@ -447,13 +518,17 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
 int launch_bins(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, float width, NlistBuffers& b) {
   NlistSystem* sys = (NlistSystem*)b.sys;
   const int max_bins = n_atoms + 8 * n_mol + 8;
-  hipLaunchKernelGGL(bins_setup_kernel, dim3(1), dim3(256), 0, s, sys, b.mol_start, n_mol, width);
-  AIMNET_LAUNCH_CHECK();
-  AIMNET_HIP_CHECK(hipMemsetAsync(b.bin_count, 0, (size_t)(max_bins + 1) * sizeof(int) * 1, s));
-  // b.bin_fill holds each atom's arrival rank in its bin (max_bins >= n_atoms entries): one atomic pass instead of two
-  hipLaunchKernelGGL(bin_count_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.xw, mol_idx, n_atoms, sys,
-                     b.atom_bin, b.bin_count, b.bin_fill);
-  AIMNET_LAUNCH_CHECK();
+  if (b.prebinned_width == width && width > 0.0f) {
+    b.prebinned_width = 0.0f;  // launch_wrap already set the grids up and counted the atoms per bin for this width
+  } else {
+    hipLaunchKernelGGL(bins_setup_kernel, dim3(1), dim3(256), 0, s, sys, b.mol_start, n_mol, width);
+    AIMNET_LAUNCH_CHECK();
+    AIMNET_HIP_CHECK(hipMemsetAsync(b.bin_count, 0, (size_t)(max_bins + 1) * sizeof(int) * 1, s));
+    // b.bin_fill holds each atom's arrival rank in its bin (max_bins >= n_atoms entries): one atomic pass instead of two
+    hipLaunchKernelGGL(bin_count_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.xw, mol_idx, n_atoms, sys,
+                       b.atom_bin, b.bin_count, b.bin_fill);
+    AIMNET_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, b.bin_count, b.bin_start, sys, n_mol);
   AIMNET_LAUNCH_CHECK();
   hipLaunchKernelGGL(bin_fill_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.atom_bin, b.bin_start, n_atoms,

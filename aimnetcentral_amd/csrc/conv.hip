@@ -368,7 +368,7 @@ int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, co
   const bool split = n_atoms <= conv_split_max_atoms();
   // (one-wave-per-atom form: exactly the 4 blocks per CU that are resident - with twice as many the second half only queues
   // behind the first and pays the block prologue again: 0.217 -> 0.207 ms/step over the three launches)
-  const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), 256 * 4);
+  const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), device_cus() * 4);
   if (species_moments && row_of && nq == 0 && !split) {  // pass 0 of a large system: per-element moments instead of row gathers
     hipLaunchKernelGGL((conv_fwd_kernel<0, false, true>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a,
                        agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order);
@@ -885,7 +885,7 @@ int launch_conv_bwd(hipStream_t s, int nq, bool need_abar, bool stress, const fl
                     float4* pairbuf, bool pb_accum) {
   const bool split = n_atoms <= conv_split_max_atoms();
   const bool xe = pairbuf != nullptr && !split;  // reverse-pair form: F1 of every ordered pair into pairbuf (see the kernel)
-  const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), 256 * 4);
+  const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), device_cus() * 4);
 #define AIMNET_BWD(HQ, NA, ST, SP, XE)                                                                                      \
   hipLaunchKernelGGL((conv_bwd_kernel<HQ, NA, ST, SP, XE>), dim3(grid), dim3(256), 0, s, a, row_of, q, Sbar, Sqbar, nb_idx,  \
                      nb_cnt, pg, cap, bp, xbar, ldx, abar_in, abar_out, qbar_in, qbar_out, fgrad, virial_atom, n_atoms, order, \

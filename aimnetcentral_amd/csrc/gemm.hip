@@ -529,7 +529,7 @@ static const TileCand kTileCands[] = {
     {223, 128, 96, 6},   {213, 64, 96, 3},   {222, 128, 64, 4}, {351, 80, 128, 5}, {331, 48, 128, 3},   {5, 64, 64, 1},
     {381, 128, 128, 8},  {371, 112, 128, 7}, {361, 96, 128, 6}, {341, 64, 128, 4}, {321, 32, 128, 2},   {233, 192, 96, 9},
     {412, 192, 128, 12}, {411, 176, 128, 11}, {410, 160, 128, 10}, {409, 144, 128, 9}};
-static int device_cus() {  // compute units of the current device (256 on MI355X), queried once per device
+int device_cus() {  // compute units of the current device (256 on MI355X), queried once per device
   static int cus[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;

@@ -12,6 +12,7 @@ enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL = 3 };
 // C[M,N] = A[M,K] . Bt[N,K]^T with fused epilogue.  K % 32 == 0, lda/ldb % 4 == 0.
 //   EPI_BIAS_GELU: C = gelu(acc + bias), D = gelu'(acc + bias) (D may be NULL)
 //   EPI_MUL:       C = acc * D
+int device_cus();  // compute units of the current device (256 on MI355X), queried once per device (gemm.hip)
 // brow / ldbias (optional): the bias of output row m is the row brow[m] (clamped to 0..63) of a [64][ldbias] table
 int launch_gemm_nt(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N,
                    int K, const float* bias, float* C, float* D, int ldc, const int* brow = nullptr, int ldbias = 0);

@@ -107,3 +107,25 @@ def test_embedding_bias_table_switch(synth_sd):
         assert abs(r1["energy"][0] - r0["energy"][0]) < 2e-5, name
         assert np.abs(r1["forces"] - r0["forces"]).max() < 2e-5, name
         assert np.abs(r1["charges"] - r0["charges"]).max() < 2e-6, name
+
+
+def test_pass0_element_moments_switch(synth_sd):
+    """Pass 0 through per-element moments (conv_fwd P0M + the species-moment backward; default) against the generic
+    row-gather kernels (`p0_moments = 0`), on the one-wave-per-atom kernels (`split_max = 0`)."""
+    from aimnetcentral_amd import loader
+    from aimnetcentral_amd.engine import HipEngine
+
+    on, off = HipEngine(loader.synthetic_spec(0), "cuda:0"), HipEngine(loader.synthetic_spec(0), "cuda:0")
+    on.set_option("split_max", 0)
+    off.set_option("p0_moments", 0)
+    try:
+        for name, coul, kw in (("taxol", "simple", {}), ("pbc96_dsf15", "dsf", dict(dsf_rc=15.0, dsf_alpha=0.2))):
+            g = golden(name)
+            r1, _ = run(on, g, coul, stress=coul == "dsf", **kw)
+            r0, _ = run(off, g, coul, stress=coul == "dsf", **kw)
+            assert abs(r1["energy"][0] - r0["energy"][0]) < 2e-5, name
+            assert np.abs(r1["forces"] - r0["forces"]).max() < 2e-5, name
+            if coul == "dsf":
+                assert np.abs(r1["stress"] - r0["stress"]).max() < 2e-6, name
+    finally:
+        on.set_option("split_max", -1)

@@ -170,9 +170,10 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
         for (int ch = 0; ch < NQ; ++ch) L.qj[ch][lane] = 0.f;
       }
       lds_sync<SPLIT>();
+      // four pairs per step, four steps per trip (wave-uniform exit: a 68-neighbour row leaves a chunk of 4)
+      for (int t0 = 0; 4 * t0 < nch; t0 += 4)
 #pragma unroll
-      for (int t = 0; t < CH * G_ / 64; ++t) {
-        if (4 * t >= nch) break;  // (wave-uniform) four pairs per iteration: a 68-neighbour row leaves a chunk of 4
+      for (int t = t0; t < t0 + 4; ++t) {
         const int e = lane + 64 * t;
         const int mm = e >> 4, g = e & 15;
         float v = 0.0f;
@@ -623,9 +624,10 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
         for (int ch = 0; ch < NQ; ++ch) L.qj[ch][lane] = q[(size_t)ch * n_atoms + j];
       }
       lds_sync<SPLIT>();
+      // four pairs per step, four steps per trip (wave-uniform exit; slots >= nch are never read)
+      for (int t0 = 0; 4 * t0 < nch; t0 += 4)
 #pragma unroll
-      for (int t = 0; t < CHB * G_ / 64; ++t) {
-        if (4 * t >= nch) break;  // (wave-uniform) four pairs per iteration; slots >= nch are never read
+      for (int t = t0; t < t0 + 4; ++t) {
         const int e = lane + 64 * t;
         const int mm = e >> 4, g = e & 15;
         float v = 0.0f, dv = 0.0f;

@@ -190,7 +190,8 @@ int aimnet_debug_gemm(int cfg, int epi, const float* A, int lda, const float* Bt
  *   "conv_mfma"     bit 0: conv forward, bit 1: conv backward on the v_mfma_f32_4x4x1_16B_f32 kernels (csrc/conv_mfma.hip)
  *                   instead of the packed-FMA VALU kernels (default 0; systems above the split threshold only)
  *   "split_max"     atoms up to which the 4-waves-per-atom "split" conv kernels are used (default 1024; PROCESS-wide; < 0 = default)
- *   "p0_moments"    0: generic conv backward for pass 0 instead of the species-moment form
+ *   "p0_moments"    0: generic row-gather conv kernels in pass 0 instead of the element-moment forward / species-moment backward
+ *   "overlap_coulomb" 1: Coulomb / DFT-D3 pair kernels on a second HIP stream (default 0: measured slower)
  *   "spatial_order" 0: conv kernels walk the atoms in input order instead of cell-list bin order */
 int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value);
 

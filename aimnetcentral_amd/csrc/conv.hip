@@ -458,7 +458,8 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
         }
         vv[0][gi] = v0; vv[1][gi] = v1; vv[2][gi] = v2;
       }
-      out[0] = s0;
+      // (plane 0 = s0 is not stored: conv_bwd_kernel reads it from the xbar row itself)
+      (void)s0;
       out[64] = make_float4(vv[0][0], vv[0][1], vv[0][2], vv[0][3]);
       out[128] = make_float4(vv[1][0], vv[1][1], vv[1][2], vv[1][3]);
       out[192] = make_float4(vv[2][0], vv[2][1], vv[2][2], vv[2][3]);
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
         const float4* sp = reinterpret_cast<const float4*>(Sbar + (size_t)i * (NF * 4)) + lane;  // planes [c][lane], see unconcat_kernel
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float4 v = sp[c * 64];
+          const float4 v = c == 0 ? reinterpret_cast<const float4*>(xbar + (size_t)i * ldx + NF)[lane] : sp[c * 64];
           Si[c][0] = mk2(v.x, v.y);
           Si[c][1] = mk2(v.z, v.w);
         }
@@ -657,7 +658,9 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
           R.aj = reinterpret_cast<const float4*>(a + (size_t)jrn * NF)[lane];
         }
         const float4* spn = reinterpret_cast<const float4*>(Sbar + (size_t)jn * (NF * 4)) + lane;
-        R.s0 = spn[0]; R.s1 = spn[64]; R.s2 = spn[128]; R.s3 = spn[192];
+        // the scalar plane (c = 0) of Sbar_j is the s-block of j's xbar row: read it there, unconcat does not copy it
+        R.s0 = reinterpret_cast<const float4*>(xbar + (size_t)jn * ldx + NF)[lane];
+        R.s1 = spn[64]; R.s2 = spn[128]; R.s3 = spn[192];
 #pragma unroll
         for (int ch = 0; ch < NQ; ++ch) R.sq[ch] = Sqbar[((size_t)jn * NQ + ch) * (G_ * 4) + lane];
       };

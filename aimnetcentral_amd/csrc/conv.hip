@@ -935,7 +935,8 @@ __global__ __launch_bounds__(256) void row_sort_kernel(int* __restrict__ nb_idx,
   if (i >= n_atoms) return;  // (no block barrier below)
   const int cnt = min(nb_cnt[i], cap);
   // -1 first: an entry whose reverse pair is missing (a truncated row) is written by nobody in pair_rev_kernel
-  for (int t = lane; t < cnt; t += 64) rev[(size_t)i * cap + t] = -1;
+  if (rev)
+    for (int t = lane; t < cnt; t += 64) rev[(size_t)i * cap + t] = -1;
   if (cnt < 2) return;
   unsigned* K = s_key[wid];
   float4* P = s_pg[wid];
@@ -1015,6 +1016,7 @@ bool pair_rev_supported(int n_atoms, int cap) { return cap <= ROW_SORT_MAX && n_
 int launch_pair_rev(hipStream_t s, int* nb_idx, int* nb_shift, const int* nb_cnt, float4* pg, int cap, int n_atoms, int* rev) {
   hipLaunchKernelGGL(row_sort_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, nb_idx, nb_shift, nb_cnt, pg, cap, n_atoms, rev);
   AIMNET_LAUNCH_CHECK();
+  if (!rev) return 0;  // energy-only evaluation: the same row order (= the same summation order) as with gradients, no map
   hipLaunchKernelGGL(pair_rev_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, nb_idx, nb_shift, nb_cnt, cap, n_atoms, rev);
   AIMNET_LAUNCH_CHECK();
   return 0;

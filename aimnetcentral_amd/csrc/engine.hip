@@ -719,7 +719,10 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
   const bool mfma_fwd = (e->conv_mfma & 1) && N > conv_split_max_atoms();
   const bool mfma_bwd = (e->conv_mfma & 2) && N > conv_split_max_atoms();
-  if (W.xe) RC(launch_pair_rev(s, W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, W.pg, cap, N, W.rev));
+  // (energy-only evaluations sort the rows too: the forward sums then run in the same order with and without gradients)
+  if (W.xe || (!grad && e->conv_xe && !(e->conv_mfma & 2) && e->conv_cluster == 0 && np > 1 && N > conv_split_max_atoms() &&
+               pair_rev_supported(N, cap)))
+    RC(launch_pair_rev(s, W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, W.pg, cap, N, W.xe ? W.rev : nullptr));
   if (W.cluster) {  // union lists of the four-centre clusters + the reverse-pair map (once per neighbour list)
     AIMNET_HIP_CHECK(hipMemsetAsync(W.cl.n_missing, 0, sizeof(int), s));
     RC(launch_cluster_build(s, W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, W.pg, cap, order, N, W.cl));

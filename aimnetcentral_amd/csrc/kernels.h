@@ -76,7 +76,8 @@ int launch_conv_bwd(hipStream_t s, int nq, bool need_abar, bool stress, const fl
                     const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order,
                     float4* pairbuf = nullptr, bool pb_accum = false);  // pairbuf: the reverse-pair (XE) form, see conv.hip
 bool pair_rev_supported(int n_atoms, int cap);  // row capacity / atom count the row sort handles
-// sorts every neighbour row by (neighbour, shift) in place (idx, shift, pair geometry), then fills the reverse-pair map
+// sorts every neighbour row by neighbour in place (idx, shift, pair geometry), then fills the reverse-pair map (rev may be
+// NULL: sort only)
 int launch_pair_rev(hipStream_t s, int* nb_idx, int* nb_shift, const int* nb_cnt, float4* pg, int cap, int n_atoms, int* rev);
 int launch_pair_force(hipStream_t s, const int* nb_idx, const int* nb_cnt, const int* rev, const float4* pairbuf, int cap,
                       int n_atoms, const float* fgrad, float* forces);  // forces = -(fgrad + pair terms)

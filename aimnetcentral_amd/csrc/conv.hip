@@ -1219,13 +1219,18 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // One wave per centre atom; 4 neighbours per step, 16 lanes (one per shift g) each: the two 256 B moment blocks of a
 // pair are single coalesced float4 loads, the radial basis is evaluated exactly once per (pair, g).
-template <bool STRESS>
+// XE (reverse-pair form, with conv_bwd_kernel<.., XE> in the later passes): the pair (i -> j) only evaluates the half built
+// on ITS OWN moments T_i[s_j] - the other half, T_j[s_i], is that same expression of the reverse pair with u -> -u - and adds
+//   G1(p) = (U - (U.u) u) / d - D u,   D = sum_g dgs_g (T_i[s_j][g][0] + u . T_i[s_j][g][1:4]),  U = -sum_g gs_g T_i[s_j][g][1:4]
+// to the pair buffer; pair_force_kernel forms dE/dx_i = sum_m G1(i -> j_m) - G1(j_m -> i) together with the other passes'
+// entries.  No neighbour moments are gathered at all.
+template <bool STRESS, bool XE>
 __global__ __launch_bounds__(256) void conv_bwd_p0_kernel(const float4* __restrict__ T4, int nslots,
                                                          const int* __restrict__ aslot, const int* __restrict__ nb_idx,
                                                          const int* __restrict__ nb_cnt, const float4* __restrict__ pg,
                                                          int cap, BasisParams bp, float* __restrict__ fgrad,
                                                          float* __restrict__ virial_atom, int n_atoms,
-                                                         const int* __restrict__ order) {
+                                                         const int* __restrict__ order, float4* __restrict__ pairbuf) {
   __shared__ __attribute__((aligned(16))) P0WaveLds wl[APB];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   P0WaveLds& L = wl[wid];
@@ -1264,7 +1269,7 @@ __global__ __launch_bounds__(256) void conv_bwd_p0_kernel(const float4* __restri
         const float4 u = L.ud[m];
         const float fc = L.fc[m], dfc = L.dfc[m];
         const float4 Ti = Ti_base[(size_t)sj * 16];
-        const float4 Tj = T4[((size_t)j * nslots + si) * 16 + g];
+        const float4 Tj = XE ? make_float4(0.f, 0.f, 0.f, 0.f) : T4[((size_t)j * nslots + si) * 16 + g];
         const float dd = u.w - shift_g;
         const float Gg = exp_neg(-bp.eta * dd * dd);
         const float gs = Gg * fc;
@@ -1279,8 +1284,14 @@ __global__ __launch_bounds__(256) void conv_bwd_p0_kernel(const float4* __restri
         const float f1 = keep * ((U1 - dot * u.y) * inv_d - D * u.y);
         const float f2 = keep * ((U2 - dot * u.z) * inv_d - D * u.z);
         xa0 += f0; xa1 += f1; xa2 += f2;
+        if (XE && valid && g == 0) {  // the passes before this one left their F1 here
+          float4* pb = pairbuf + (size_t)i * cap + c0 + m;
+          const float4 o = *pb;
+          *pb = make_float4(o.x + f0, o.y + f1, o.z + f2, 0.f);
+        }
         if (STRESS) {
-          const float hx = -0.5f * u.x * u.w, hy = -0.5f * u.y * u.w, hz = -0.5f * u.z * u.w;
+          const float hs = XE ? -1.0f : -0.5f;  // XE: one ordered pair carries the whole -r (x) G1 term
+          const float hx = hs * u.x * u.w, hy = hs * u.y * u.w, hz = hs * u.z * u.w;
           W[0] += hx * f0; W[1] += hx * f1; W[2] += hx * f2;
           W[3] += hy * f0; W[4] += hy * f1; W[5] += hy * f2;
           W[6] += hz * f0; W[7] += hz * f1; W[8] += hz * f2;
@@ -1292,7 +1303,7 @@ __global__ __launch_bounds__(256) void conv_bwd_p0_kernel(const float4* __restri
 #pragma unroll
       for (int k = 0; k < 9; ++k) W[k] = wave_sum(W[k]);
     }
-    if (lane == 0) {
+    if (!XE && lane == 0) {
       fgrad[3 * i + 0] += xa0;
       fgrad[3 * i + 1] += xa1;
       fgrad[3 * i + 2] += xa2;
@@ -1308,14 +1319,14 @@ __global__ __launch_bounds__(256) void conv_bwd_p0_kernel(const float4* __restri
 
 int launch_conv_bwd_p0(hipStream_t s, bool stress, const float* T, int nslots, const int* aslot, const int* nb_idx,
                        const int* nb_cnt, const float4* pg, int cap, BasisParams bp, float* fgrad, float* virial_atom,
-                       int n_atoms, const int* order) {
+                       int n_atoms, const int* order, float4* pairbuf) {
   const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
-  if (stress)
-    hipLaunchKernelGGL(conv_bwd_p0_kernel<true>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(T), nslots, aslot,
-                       nb_idx, nb_cnt, pg, cap, bp, fgrad, virial_atom, n_atoms, order);
-  else
-    hipLaunchKernelGGL(conv_bwd_p0_kernel<false>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(T), nslots, aslot,
-                       nb_idx, nb_cnt, pg, cap, bp, fgrad, virial_atom, n_atoms, order);
+#define AIMNET_P0(ST, XE_)                                                                                                  \
+  hipLaunchKernelGGL((conv_bwd_p0_kernel<ST, XE_>), dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(T), nslots, aslot, \
+                     nb_idx, nb_cnt, pg, cap, bp, fgrad, virial_atom, n_atoms, order, pairbuf)
+  if (pairbuf) { if (stress) AIMNET_P0(true, true); else AIMNET_P0(false, true); }
+  else { if (stress) AIMNET_P0(true, false); else AIMNET_P0(false, false); }
+#undef AIMNET_P0
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

@@ -893,7 +893,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       RC(launch_unconcat_p0(s, zcur, ld, W.V[0], e->agh_a, e->afv, e->z_of_slot, e->nslots, W.present_part, W.n_part, W.Sbar, N));
       RC(prof_mark(e, s, FAM_CONV_BWD));
       RC(launch_conv_bwd_p0(s, want_s, W.Sbar, e->nslots, W.aslot, W.nb_idx, W.nb_cnt, W.pg, cap, e->bp, W.fgrad, W.virial_atom, N,
-                            order));
+                            order, (W.xe && want_f) ? W.pairbuf : nullptr));
       break;
     }
     const bool cl_pass = W.cluster && p > 0;

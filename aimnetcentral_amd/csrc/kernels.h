@@ -92,7 +92,8 @@ int launch_unconcat_p0(hipStream_t s, const float* xbar, int ldx, const float* V
                        int n_atoms);
 int launch_conv_bwd_p0(hipStream_t s, bool stress, const float* T, int nslots, const int* aslot, const int* nb_idx,
                        const int* nb_cnt, const float4* pg, int cap, BasisParams bp, float* fgrad, float* virial_atom,
-                       int n_atoms, const int* order);
+                       int n_atoms, const int* order,
+                       float4* pairbuf = nullptr);  // pairbuf: reverse-pair form (own moments only, G1 added to the pair buffer)
 // ---- conv_mfma.hip: the same three steps with the pair contractions on v_mfma_f32_4x4x1_16B_f32 (one wave per centre atom,
 // systems above SPLIT_MAX_ATOMS).  SbarT is the Sbar buffer in the lane-(g,c) plane layout that conv_bwd_mfma reads.
 // a_t: the feature table transposed to [g][a] (the MFMA operand layout), a: the natural [a][g] one

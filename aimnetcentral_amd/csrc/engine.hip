@@ -83,8 +83,8 @@ struct aimnet_engine {
   int conv_cluster = 0;
   // AIMNET_CONV_XE / set_option("conv_xe"): the reverse-pair form of the conv backward (conv.hip, conv_bwd_kernel<.., XE>) for
   // passes >= 1 of systems above the split threshold: every ordered pair evaluates only its own half of the pair adjoints (no
-  // a_j gather, 4 KiB per pair instead of 5.25 KiB), F1 goes through a pair buffer and a reverse-pair map built on sorted rows.
-  // Config 3: kernel 215 -> 152 us per pass, +55 us per step for the row sort, the map and the force gather (1.96 -> 1.89 ms).
+  // a_j gather, 4 KiB per pair instead of 5.25 KiB), F1 goes through a pair buffer and a reverse-pair map (per-atom hash tables of the rows).
+  // Config 3: kernel 215 -> 152 us per pass, +35 us per step for the map (hash build 9 us, lookup 12 us) and the force gather (14 us).
   // 0 restores the combined-adjoint kernel (A/B and parity runs).
   int conv_xe = 1;
   // AIMNET_OVERLAP_COULOMB / set_option("overlap_coulomb"): the Coulomb / DFT-D3 pair kernels (VALU-bound, they need only the
@@ -206,6 +206,7 @@ struct Workspace {
   bool xe = false;   // reverse-pair conv backward: pair buffer + reverse map
   float4* pairbuf;
   int* rev;
+  unsigned long long* rev_tab;  // per-atom hash tables of the rows (hash form of the reverse-pair map)
   float *zb0, *zb1;  // ping-pong adjoint buffers (N x max padded width)
   float *Sbar, *Sqbar;
   int *d3_idx, *d3_shift, *d3_cnt;   // DFT-D3 neighbour matrix (aliases the LR list when both use one cutoff)
@@ -339,6 +340,7 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   }
   W.pairbuf = c.take<float4>(W.xe ? n * cap : 0);
   W.rev = c.take<int>(W.xe ? n * cap : 0);
+  W.rev_tab = c.take<unsigned long long>(W.xe ? pair_hash_bytes(N) / sizeof(unsigned long long) : 0);
   W.n_part = (N + 255) / 256;
   W.aslot = c.take<int>(n);
   W.present_part = c.take<unsigned long long>((size_t)W.n_part);
@@ -719,10 +721,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
   const bool mfma_fwd = (e->conv_mfma & 1) && N > conv_split_max_atoms();
   const bool mfma_bwd = (e->conv_mfma & 2) && N > conv_split_max_atoms();
-  // (energy-only evaluations sort the rows too: the forward sums then run in the same order with and without gradients)
-  if (W.xe || (!grad && e->conv_xe && !(e->conv_mfma & 2) && e->conv_cluster == 0 && np > 1 && N > conv_split_max_atoms() &&
-               pair_rev_supported(N, cap)))
-    RC(launch_pair_rev(s, W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, W.pg, cap, N, W.xe ? W.rev : nullptr));
+  // reverse-pair map through per-atom hash tables of the rows (once per neighbour list)
+  if (W.xe) RC(launch_pair_rev_hash(s, W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, cap, N, W.rev_tab, W.rev));
   if (W.cluster) {  // union lists of the four-centre clusters + the reverse-pair map (once per neighbour list)
     AIMNET_HIP_CHECK(hipMemsetAsync(W.cl.n_missing, 0, sizeof(int), s));
     RC(launch_cluster_build(s, W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, W.pg, cap, order, N, W.cl));

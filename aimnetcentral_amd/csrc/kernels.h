@@ -75,10 +75,12 @@ int launch_conv_bwd(hipStream_t s, int nq, bool need_abar, bool stress, const fl
                     int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
                     const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order,
                     float4* pairbuf = nullptr, bool pb_accum = false);  // pairbuf: the reverse-pair (XE) form, see conv.hip
-bool pair_rev_supported(int n_atoms, int cap);  // row capacity / atom count the row sort handles
-// sorts every neighbour row by neighbour in place (idx, shift, pair geometry), then fills the reverse-pair map (rev may be
-// NULL: sort only)
-int launch_pair_rev(hipStream_t s, int* nb_idx, int* nb_shift, const int* nb_cnt, float4* pg, int cap, int n_atoms, int* rev);
+bool pair_rev_supported(int n_atoms, int cap);  // row capacity / atom count the reverse-pair map handles
+// reverse-pair map rev[i * cap + m] = position of (i, -shift) in the row of idx[i][m]: per-atom 256-slot hash tables `tab`
+// (pair_hash_bytes) built and probed on the device
+size_t pair_hash_bytes(int n_atoms);
+int launch_pair_rev_hash(hipStream_t s, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, int n_atoms,
+                         unsigned long long* tab, int* rev);
 int launch_pair_force(hipStream_t s, const int* nb_idx, const int* nb_cnt, const int* rev, const float4* pairbuf, int cap,
                       int n_atoms, const float* fgrad, float* forces);  // forces = -(fgrad + pair terms)
 // `order` (conv_fwd / conv_bwd / conv_bwd_p0): optional permutation of the atoms giving the PROCESSING order - the

@@ -1078,6 +1078,8 @@ int launch_species(hipStream_t s, const int* numbers, const int* slot_of_z, int 
   return 0;
 }
 
+constexpr int P0_AFV_LDS = 8;  // embedding rows of the species present that unconcat_p0_kernel keeps in LDS
+
 // xbar of pass 0 -> Sbar_i (registers/LDS only, never written to HBM) -> T_i[s] for the species present.
 // Stage 1 is unconcat_kernel<false>'s arithmetic (lane = (a, 4 shifts)); stage 2 re-reads the row from LDS with
 // lane = (g, c) and contracts over a.  Row stride 65 keeps both the (a,gq)-major writes and the (g,c)-major reads
@@ -1106,7 +1108,10 @@ __global__ __launch_bounds__(256) void unconcat_p0_kernel(const float* __restric
   }
   __syncthreads();
   const int npres = s_npres;
-  for (int k = threadIdx.x; k < npres * NF; k += 256) s_afv[k] = afv[(size_t)z_of_slot[s_plist[k >> 8]] * NF + (k & 255)];
+  // (LDS holds the embedding rows of the first P0_AFV_LDS species present; a batch with more reads the others from global
+  // memory - sizing the buffer for every slot of the model cost two of the three resident blocks per CU)
+  for (int k = threadIdx.x; k < min(npres, P0_AFV_LDS) * NF; k += 256)
+    s_afv[k] = afv[(size_t)z_of_slot[s_plist[k >> 8]] * NF + (k & 255)];
   float* vb = s_vb + wid * (NV * 3);
   float* sb = s_sb + wid * (A_ * 65);
   const AtomLoop al = atom_loop(n_atoms, APB);
@@ -1155,7 +1160,7 @@ __global__ __launch_bounds__(256) void unconcat_p0_kernel(const float* __restric
       for (int a = 0; a < A_; ++a) sr[a] = sb[a * 65 + lane];
       const int g = lane >> 2;
       for (int k = 0; k < npres; ++k) {
-        const float* av = s_afv + k * NF + g;
+        const float* av = (k < P0_AFV_LDS ? s_afv + k * NF : afv + (size_t)z_of_slot[s_plist[k]] * NF) + g;
         float t = 0.f;
 #pragma unroll
         for (int a = 0; a < A_; ++a) t += sr[a] * av[a * G_];
@@ -1169,7 +1174,7 @@ int launch_unconcat_p0(hipStream_t s, const float* xbar, int ldx, const float* V
                        const int* z_of_slot, int nslots, const unsigned long long* present_part, int n_part, float* T,
                        int n_atoms) {
   const int grid = min(ceil_div(n_atoms, APB), 256 * 8);
-  const size_t lds = sizeof(float) * ((size_t)A_ * G_ * H_ + APB * NV * 3 + APB * A_ * 65 + (size_t)nslots * NF);
+  const size_t lds = sizeof(float) * ((size_t)A_ * G_ * H_ + APB * NV * 3 + APB * A_ * 65 + (size_t)min(nslots, P0_AFV_LDS) * NF);
   static PerDeviceOnce once;
   if (once.first())
     AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)unconcat_p0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));

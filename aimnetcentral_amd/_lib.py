@@ -11,6 +11,7 @@ import os
 from functools import lru_cache
 
 MAX_PASS, MAX_LAYERS, MAX_SHIFTS = 4, 6, 32
+ABI_VERSION = 5  # AIMNET_ABI_VERSION of include/aimnet_hip.h this binding was written against
 FORCES, STRESS = 1, 2
 COULOMB_NONE, COULOMB_SIMPLE, COULOMB_DSF = 0, 1, 2
 E_INVALID, E_HIP, E_WORKSPACE = -1, -2, -3
@@ -32,6 +33,8 @@ EXPORTED_SYMBOLS = (
     "aimnet_engine_set_profile_sampling",
     "aimnet_engine_profile_read",
     "aimnet_debug_gemm",
+    "aimnet_debug_split_bf3",
+    "aimnet_debug_gemm_bf3",
     "aimnet_debug_mfma4_probe",
     "aimnet_engine_set_option",
     "aimnet_engine_set_dftd3",
@@ -151,6 +154,9 @@ def load() -> C.CDLL:
         raise HipLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
     vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
     lib.aimnet_abi_version.restype = C.c_int
+    got = lib.aimnet_abi_version()
+    if got != ABI_VERSION:  # the struct layouts below would silently mismatch (e.g. AIMNET_HIP_LIB naming an older build)
+        raise HipLibraryError(f"{LIB_PATH} has ABI version {got}, this package binds version {ABI_VERSION}: rebuild the library")
     lib.aimnet_last_error.restype = C.c_char_p
     lib.aimnet_engine_create.restype = C.c_int
     lib.aimnet_engine_create.argtypes = [C.POINTER(Arch), C.POINTER(Weights), C.c_int, C.POINTER(vp)]
@@ -172,6 +178,10 @@ def load() -> C.CDLL:
     lib.aimnet_engine_set_dftd3.argtypes = [vp, C.POINTER(DftD3Tables)]
     lib.aimnet_debug_gemm.restype = C.c_int
     lib.aimnet_debug_gemm.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
+    lib.aimnet_debug_split_bf3.restype = C.c_int
+    lib.aimnet_debug_split_bf3.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
+    lib.aimnet_debug_gemm_bf3.restype = C.c_int
+    lib.aimnet_debug_gemm_bf3.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
     lib.aimnet_engine_set_option.restype = C.c_int
     lib.aimnet_engine_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.aimnet_debug_mfma4_probe.restype = C.c_int

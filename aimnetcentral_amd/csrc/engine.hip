@@ -31,6 +31,8 @@ struct Layer {
   float* w;                      // [k_out][k_in]  forward operand  (Bt of  H = X . W^T)
   float* wt;                     // [k_in][k_out]  backward operand (Bt of dX = dZ . W)
   float* b;                      // [k_out]
+  unsigned short* w3 = nullptr;  // the same two operands split into three bf16 planes ("bf3" layout of gemm_bf3.hip:
+  unsigned short* wt3 = nullptr; // 3 * k_in resp. 3 * k_out bf16 elements per row) for the bf16x3-split MFMA GEMM
 };
 
 struct View {
@@ -54,6 +56,11 @@ struct aimnet_engine {
   // the full-width GEMM (A/B and parity runs).
   float* emb_bias0 = nullptr;
   bool emb_bias = true;
+  // MLP GEMMs: 1 (default) = bf16x3-split operands on the bf16 matrix pipe (gemm_bf3.hip: fp32 == three bf16 planes exactly, six
+  // products per tile, fp32 accumulation - the fp32 result to within the fp32 rounding of the accumulation itself) for batches above
+  // 256 rows, the exact-fp32 skinny kernel below; 2 = bf3 for every batch size (parity runs on small fixtures); 0 = the exact-fp32
+  // MFMA kernels of gemm.hip everywhere.  set_option("gemm_bf3", v) / AIMNET_GEMM_BF3.
+  int gemm_bf3 = 1;
   double* sae;
   // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row
@@ -160,7 +167,29 @@ int upload_layer(aimnet_engine* e, const float* w, const float* b, int n_in, int
   if ((rc = dev_upload(e, wp.data(), wp.size(), &L->w))) return rc;
   if ((rc = dev_upload(e, wtp.data(), wtp.size(), &L->wt))) return rc;
   if ((rc = dev_upload(e, bp.data(), bp.size(), &L->b))) return rc;
+  {  // split once, on the host (round to nearest even like v_cvt_pk_bf16_f32)
+    std::vector<unsigned short> s3(wp.size() * 3);
+    split_bf3_host(wp.data(), L->k_out, L->k_in, s3.data());
+    if ((rc = dev_upload(e, s3.data(), s3.size(), &L->w3))) return rc;
+    split_bf3_host(wtp.data(), L->k_in, L->k_out, s3.data());
+    if ((rc = dev_upload(e, s3.data(), s3.size(), &L->wt3))) return rc;
+  }
   return 0;
+}
+
+// One MLP GEMM C = epilogue(A . W^T) (fwd: W = L.w [k_out][k_in]) or C = epilogue(A . W) (bwd: L.wt [k_in][k_out]) over the
+// operand's k-columns [k0, k0 + K) (fwd) resp. output rows [n0, n0 + N) (bwd) - the sub-blocks the embedding-bias table and the
+// pass-0 backward use.  Picks the bf16x3-split kernel or the exact-fp32 one (aimnet_engine::gemm_bf3).
+int mlp_gemm(const aimnet_engine* e, hipStream_t s, int epi, const float* A, int lda, const Layer& L, bool fwd, int k0, int n0, int M,
+             int N, int K, const float* bias, float* C, float* D, int ldc, const int* brow = nullptr, int ldbias = 0) {
+  const int ldw = fwd ? L.k_in : L.k_out;  // row stride of the weight operand
+  const bool bf3 = e->gemm_bf3 == 2 || (e->gemm_bf3 == 1 && M > 256);
+  if (bf3) {
+    const unsigned short* w3 = (fwd ? L.w3 : L.wt3) + (size_t)n0 * 3 * ldw + (size_t)(k0 / 32) * 96;
+    return launch_gemm_bf3_cfg(s, 0, epi, A, lda, w3, 3 * ldw, M, N, K, bias, C, D, ldc, brow, ldbias);
+  }
+  const float* w = (fwd ? L.w : L.wt) + (size_t)n0 * ldw + k0;
+  return launch_gemm_nt(s, epi, A, lda, w, ldw, M, N, K, bias, C, D, ldc, brow, ldbias);
 }
 
 // ---- workspace layout ---------------------------------------------------------------------------
@@ -412,6 +441,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->conv_mfma = atoi(env);
     env = getenv("AIMNET_EMB_BIAS");
     if (env) e->emb_bias = atoi(env) != 0;
+    env = getenv("AIMNET_GEMM_BF3");
+    if (env) e->gemm_bf3 = std::min(2, std::max(0, atoi(env)));
     env = getenv("AIMNET_CONV_XE");
     if (env) e->conv_xe = atoi(env);
     env = getenv("AIMNET_CONV_CLUSTER");
@@ -475,6 +506,7 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
   e->bp.eta = arch->eta;
   for (int g = 0; g < 16; ++g) e->bp.shifts[g] = arch->shifts[g];
   if ((rc = gemm_set_attributes())) goto fail;
+  if ((rc = gemm_bf3_set_attributes())) goto fail;
   if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -541,6 +573,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "conv_cluster") e->conv_cluster = value != 0;
   else if (n == "conv_xe") e->conv_xe = value != 0;
   else if (n == "emb_bias") e->emb_bias = value != 0;
+  else if (n == "gemm_bf3") e->gemm_bf3 = std::min(2, std::max(0, value));
   else if (n == "split_max") conv_set_split_max(value);  // process-wide
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -786,12 +819,11 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     for (int l = 0; l < nl; ++l) {
       const bool linear = (l == nl - 1) && ar.last_linear[p];
       if (p == 0 && l == 0 && e->emb_bias && e->emb_bias0)  // embedding columns folded into the per-element bias table
-        RC(launch_gemm_nt(s, linear ? EPI_BIAS : EPI_BIAS_GELU, hin + 256, ld_in, Ls[l].w + 256, Ls[l].k_in, N, Ls[l].k_out,
-                          Ls[l].k_in - 256, e->emb_bias0, W.H[p][l], linear ? nullptr : W.D[p][l], Ls[l].k_out, in->numbers,
-                          Ls[l].k_out));
+        RC(mlp_gemm(e, s, linear ? EPI_BIAS : EPI_BIAS_GELU, hin + 256, ld_in, Ls[l], true, 256, 0, N, Ls[l].k_out, Ls[l].k_in - 256,
+                    e->emb_bias0, W.H[p][l], linear ? nullptr : W.D[p][l], Ls[l].k_out, in->numbers, Ls[l].k_out));
       else
-      RC(launch_gemm_nt(s, linear ? EPI_BIAS : EPI_BIAS_GELU, hin, ld_in, Ls[l].w, Ls[l].k_in, N, Ls[l].k_out, Ls[l].k_in,
-                        Ls[l].b, W.H[p][l], linear ? nullptr : W.D[p][l], Ls[l].k_out));
+        RC(mlp_gemm(e, s, linear ? EPI_BIAS : EPI_BIAS_GELU, hin, ld_in, Ls[l], true, 0, 0, N, Ls[l].k_out, Ls[l].k_in, Ls[l].b,
+                    W.H[p][l], linear ? nullptr : W.D[p][l], Ls[l].k_out));
       hin = W.H[p][l];
       ld_in = Ls[l].k_out;
     }
@@ -817,7 +849,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     RC(prof_mark(e, s, FAM_GEMM));
     for (int l = 0; l + 1 < nh; ++l) {
       const Layer& L = e->head[l];
-      RC(launch_gemm_nt(s, EPI_BIAS_GELU, hin, ld_in, L.w, L.k_in, N, L.k_out, L.k_in, L.b, W.hH[l], W.hD[l], L.k_out));
+      RC(mlp_gemm(e, s, EPI_BIAS_GELU, hin, ld_in, L, true, 0, 0, N, L.k_out, L.k_in, L.b, W.hH[l], W.hD[l], L.k_out));
       hin = W.hH[l];
       ld_in = L.k_out;
     }
@@ -860,8 +892,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       float* dprev;
       if (l > 0) dprev = W.hD[l - 1];
       else dprev = W.D[np - 1][e->mlp[np - 1].size() - 1];  // aim = GELU(z_last) of the last MLP
-      RC(launch_gemm_nt(s, dprev ? EPI_MUL : EPI_NONE, zcur, ld, L.wt, L.k_out, N, L.k_in, L.k_out, nullptr, znext, dprev,
-                        L.k_in));
+      RC(mlp_gemm(e, s, dprev ? EPI_MUL : EPI_NONE, zcur, ld, L, false, 0, 0, N, L.k_in, L.k_out, nullptr, znext, dprev, L.k_in));
       std::swap(zcur, znext);
       ld = L.k_in;
     }
@@ -874,12 +905,11 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     for (int l = nl - 1; l >= 0; --l) {
       const Layer& L = Ls[l];
       if (l > 0)
-        RC(launch_gemm_nt(s, EPI_MUL, zcur, ld, L.wt, L.k_out, N, L.k_in, L.k_out, nullptr, znext, W.D[p][l - 1], L.k_in));
+        RC(mlp_gemm(e, s, EPI_MUL, zcur, ld, L, false, 0, 0, N, L.k_in, L.k_out, nullptr, znext, W.D[p][l - 1], L.k_in));
       else if (p == 0 && p0m)  // only the conv columns 256.. of xbar_0 are consumed (the embedding is a constant)
-        RC(launch_gemm_nt(s, EPI_NONE, zcur, ld, L.wt + (size_t)256 * L.k_out, L.k_out, N, L.k_in - 256, L.k_out, nullptr,
-                          znext + 256, nullptr, L.k_in));
+        RC(mlp_gemm(e, s, EPI_NONE, zcur, ld, L, false, 0, 256, N, L.k_in - 256, L.k_out, nullptr, znext + 256, nullptr, L.k_in));
       else
-        RC(launch_gemm_nt(s, EPI_NONE, zcur, ld, L.wt, L.k_out, N, L.k_in, L.k_out, nullptr, znext, nullptr, L.k_in));
+        RC(mlp_gemm(e, s, EPI_NONE, zcur, ld, L, false, 0, 0, N, L.k_in, L.k_out, nullptr, znext, nullptr, L.k_in));
       std::swap(zcur, znext);
       ld = L.k_in;
     }
@@ -1002,6 +1032,26 @@ int aimnet_debug_gemm(int cfg, int epi, const float* A, int lda, const float* Bt
   }
   return launch_gemm_nt_cfg((hipStream_t)hip_stream, cfg, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
 }
+
+int aimnet_debug_split_bf3(const float* src, int ld, int M, int K, void* dst, int ldd, void* hip_stream) {
+  if (!src || !dst || M <= 0 || K <= 0 || ldd < 3 * pad32(K) || ldd % 96) return AIMNET_E_INVALID;
+  return launch_split_bf3((hipStream_t)hip_stream, src, ld, M, K, (unsigned short*)dst, ldd);
+}
+
+int aimnet_debug_gemm_bf3(int cfg, int epi, const float* A, int lda, const void* Bt3, int ldb, int M, int N, int K,
+                          const float* bias, float* C, float* D, int ldc, void* hip_stream) {
+  static bool attr = false;
+  if (!attr) {
+    int rc = gemm_bf3_set_attributes();
+    if (rc) return rc;
+    attr = true;
+  }
+  return launch_gemm_bf3_cfg((hipStream_t)hip_stream, cfg, epi, A, lda, (const unsigned short*)Bt3, ldb, M, N, K, bias, C, D, ldc);
+}
+
+#ifdef AIMNET_BF3_TIMING
+int aimnet_debug_bf3_stamps(unsigned long long* host1024) { return aimnet::gemm_bf3_read_stamps(host1024); }
+#endif
 
 int aimnet_debug_mfma4_probe(float* out, void* hip_stream) {
   if (!out) return AIMNET_E_INVALID;

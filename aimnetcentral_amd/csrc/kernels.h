@@ -20,6 +20,19 @@ int launch_gemm_nt_cfg(hipStream_t stream, int cfg, int epi, const float* A, int
                        int K, const float* bias, float* C, float* D, int ldc, const int* brow = nullptr, int ldbias = 0);
 int gemm_set_attributes();
 
+// ---- gemm_bf3.hip: the same GEMMs on the bf16 matrix pipe: both operands split into three bf16 planes (fp32 == p0 + p1 + p2
+// exactly), six products per tile, fp32 accumulation.  A stays fp32 in memory (split inside the kernel), Bt is the pre-split
+// weight matrix in the "bf3" layout: per row, K/32 blocks of [plane0: 32 bf16][plane1][plane2] = 192 B; ldb counts bf16 elements
+// per row = 3 x the padded K of the full matrix.  Everything else as launch_gemm_nt.
+void split_bf3_host(const float* w, int rows, int K, unsigned short* out);                                   // host form (weights)
+int launch_split_bf3(hipStream_t s, const float* src, int ld, int M, int K, unsigned short* dst, int ldd);  // device form (tests)
+int launch_gemm_bf3_cfg(hipStream_t stream, int cfg, int epi, const float* A, int lda, const unsigned short* Bt, int ldb, int M,
+                        int N, int K, const float* bias, float* C, float* D, int ldc, const int* brow = nullptr, int ldbias = 0);
+int gemm_bf3_set_attributes();
+#ifdef AIMNET_BF3_TIMING
+int gemm_bf3_read_stamps(unsigned long long* host1024);  // measurement build only (tests/tools/bf3_timing.sh)
+#endif
+
 // ---- nlist.hip --------------------------------------------------------------------------------
 struct NlistBuffers {      // all device pointers, carved from the caller's workspace
   int* mol_start;          // [n_mol + 1]

@@ -225,6 +225,72 @@ def test_gemm_tiles_match_fp64(cfg, M, N, K):
         assert (Cm.double() - want).abs().max().item() < 5e-5, (cfg, epi)
 
 
+# ---- bf16x3-split MLP GEMM (csrc/gemm_bf3.hip): every tile against an fp64 product, same tolerance as the exact-fp32 kernels ----
+BF3_CFGS = [0, 452, 442, 432, 422, 223, 224, 234, 851]
+
+
+def _split_bf3(lib, x, stream):
+    m, k = x.shape
+    out = torch.empty(m, 3 * k, dtype=torch.int16, device=x.device)
+    assert lib.aimnet_debug_split_bf3(x.data_ptr(), k, m, k, out.data_ptr(), 3 * k, stream) == 0
+    return out
+
+
+def test_bf3_split_is_exact_and_round_to_nearest():
+    """fp32 == plane0 + plane1 + plane2 bit for bit, plane0 = round-to-nearest-even bf16 (what torch's own cast does)."""
+    from aimnetcentral_amd import _lib
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.randn(257, 96, generator=gen) * torch.logspace(-6, 4, 96)).to(dev)
+    x[0, :4] = torch.tensor([0.0, -0.0, 1.0, -3.5e-30])
+    s3 = _split_bf3(lib, x, stream)
+    planes = (s3.view(257, 3, 3, 32).to(torch.int32) << 16).view(torch.float32)
+    assert torch.equal(planes.double().sum(dim=2).reshape(257, 96), x.double())
+    assert torch.equal(planes[:, :, 0, :].reshape(257, 96), x.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("cfg", BF3_CFGS)
+@pytest.mark.parametrize("M,N,K", [(1000, 288, 384), (333, 736, 512), (47, 128, 32), (170, 128, 96)])
+def test_gemm_bf3_tiles_match_fp64(cfg, M, N, K):
+    """The exact-fp32 test above on the bf16x3-split kernels: activations fp32, weights pre-split, six bf16 MFMA products per
+    tile, fp32 accumulation.  Same 5e-5 gate (observed ~1e-5, a little below the fp32 MFMA chain)."""
+    from aimnetcentral_amd import _lib
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(4321 + cfg + M)
+    A = torch.randn(M, K, generator=gen).to(dev)
+    Bt = (torch.randn(N, K, generator=gen) * 0.1).to(dev)
+    bias = torch.randn(N, generator=gen).to(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    B3 = _split_bf3(lib, Bt, stream)
+    z = A.double() @ Bt.double().T
+    for epi in (0, 1, 2, 3):
+        Cm = torch.full((M, N), float("nan"), device=dev)
+        D = torch.rand(M, N, generator=gen).to(dev) if epi == 3 else torch.full((M, N), float("nan"), device=dev)
+        D0 = D.clone()
+        rc = lib.aimnet_debug_gemm_bf3(cfg, epi, A.data_ptr(), K, B3.data_ptr(), 3 * K, M, N, K, bias.data_ptr(), Cm.data_ptr(),
+                                       D.data_ptr(), N, stream)
+        assert rc == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        if epi == 0:
+            want = z
+        elif epi == 1:
+            want = z + bias.double()
+        elif epi == 2:
+            zb = z + bias.double()
+            cdf = 0.5 * (1 + torch.erf(zb / 2**0.5))
+            want = zb * cdf
+            want_d = cdf + zb * torch.exp(-0.5 * zb * zb) / (2 * torch.pi) ** 0.5
+            assert (D.double() - want_d).abs().max().item() < 5e-5
+        else:
+            want = z * D0.double()
+        assert (Cm.double() - want).abs().max().item() < 5e-5, (cfg, epi)
+
+
 def test_neighbor_list_large_nonperiodic_uses_bounding_box_cells():
     """>= 1500 atoms per non-periodic molecule switches the builder from the O(n^2) scan to a cell list over the
     molecule's bounding box (nlist.hip bbox_setup_kernel): same neighbour SETS as a brute-force numpy search."""

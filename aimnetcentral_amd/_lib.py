@@ -179,9 +179,9 @@ def load() -> C.CDLL:
     lib.aimnet_debug_gemm.restype = C.c_int
     lib.aimnet_debug_gemm.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
     lib.aimnet_debug_split_bf3.restype = C.c_int
-    lib.aimnet_debug_split_bf3.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
+    lib.aimnet_debug_split_bf3.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
     lib.aimnet_debug_gemm_bf3.restype = C.c_int
-    lib.aimnet_debug_gemm_bf3.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
+    lib.aimnet_debug_gemm_bf3.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.aimnet_engine_set_option.restype = C.c_int
     lib.aimnet_engine_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.aimnet_debug_mfma4_probe.restype = C.c_int

@@ -33,6 +33,7 @@ struct Layer {
   float* b;                      // [k_out]
   unsigned short* w3 = nullptr;  // the same two operands split into three bf16 planes ("bf3" layout of gemm_bf3.hip:
   unsigned short* wt3 = nullptr; // 3 * k_in resp. 3 * k_out bf16 elements per row) for the bf16x3-split MFMA GEMM
+  int neg_w3 = 0, neg_wt3 = 0;   // k-block (of 32) from which w3 / wt3 are stored negated (sign-flipped accumulation phase)
 };
 
 struct View {
@@ -149,7 +150,8 @@ int dev_upload(aimnet_engine* e, const T* host, size_t n, T** out) {
   return 0;
 }
 
-int upload_layer(aimnet_engine* e, const float* w, const float* b, int n_in, int n_out, Layer* L) {
+// k0_fwd: first k-column the forward GEMM of this layer reads by default (pass 0's first layer skips the embedding block)
+int upload_layer(aimnet_engine* e, const float* w, const float* b, int n_in, int n_out, Layer* L, int k0_fwd = 0) {
   L->n_in = n_in;
   L->n_out = n_out;
   L->k_in = pad32(n_in);
@@ -168,10 +170,14 @@ int upload_layer(aimnet_engine* e, const float* w, const float* b, int n_in, int
   if ((rc = dev_upload(e, wtp.data(), wtp.size(), &L->wt))) return rc;
   if ((rc = dev_upload(e, bp.data(), bp.size(), &L->b))) return rc;
   {  // split once, on the host (round to nearest even like v_cvt_pk_bf16_f32)
+    // the last 40 % of the k-steps a launch runs over accumulate with the opposite sign (gemm_bf3.hip, "Accumulation bias")
     std::vector<unsigned short> s3(wp.size() * 3);
-    split_bf3_host(wp.data(), L->k_out, L->k_in, s3.data());
+    const int kb0 = k0_fwd / 32, nkf = L->k_in / 32 - kb0, nkb = L->k_out / 32;
+    L->neg_w3 = kb0 + (6 * nkf + 5) / 10;
+    L->neg_wt3 = (6 * nkb + 5) / 10;
+    split_bf3_host(wp.data(), L->k_out, L->k_in, s3.data(), L->neg_w3);
     if ((rc = dev_upload(e, s3.data(), s3.size(), &L->w3))) return rc;
-    split_bf3_host(wtp.data(), L->k_in, L->k_out, s3.data());
+    split_bf3_host(wtp.data(), L->k_in, L->k_out, s3.data(), L->neg_wt3);
     if ((rc = dev_upload(e, s3.data(), s3.size(), &L->wt3))) return rc;
   }
   return 0;
@@ -186,7 +192,8 @@ int mlp_gemm(const aimnet_engine* e, hipStream_t s, int epi, const float* A, int
   const bool bf3 = e->gemm_bf3 == 2 || (e->gemm_bf3 == 1 && M > 256);
   if (bf3) {
     const unsigned short* w3 = (fwd ? L.w3 : L.wt3) + (size_t)n0 * 3 * ldw + (size_t)(k0 / 32) * 96;
-    return launch_gemm_bf3_cfg(s, 0, epi, A, lda, w3, 3 * ldw, M, N, K, bias, C, D, ldc, brow, ldbias);
+    const int kneg = std::max(0, (fwd ? L.neg_w3 : L.neg_wt3) - k0 / 32);  // leading k-steps of this launch with the stored sign
+    return launch_gemm_bf3_cfg(s, 0, epi, A, lda, w3, 3 * ldw, M, N, K, bias, C, D, ldc, brow, ldbias, kneg);
   }
   const float* w = (fwd ? L.w : L.wt) + (size_t)n0 * ldw + k0;
   return launch_gemm_nt(s, epi, A, lda, w, ldw, M, N, K, bias, C, D, ldc, brow, ldbias);
@@ -466,7 +473,9 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     }
     for (int l = 0; l < nl; ++l) {
       Layer L;
-      if ((rc = upload_layer(e, w->mlp_w[p][l], w->mlp_b[p][l], arch->layer_dims[p][l], arch->layer_dims[p][l + 1], &L))) goto fail;
+      if ((rc = upload_layer(e, w->mlp_w[p][l], w->mlp_b[p][l], arch->layer_dims[p][l], arch->layer_dims[p][l + 1], &L,
+                             (p == 0 && l == 0 && arch->layer_dims[p][l] >= AG) ? AG : 0)))
+        goto fail;
       e->mlp[p].push_back(L);
       if (p == 0 && l == 0 && L.n_in >= AG) {  // the embedding block of the first layer as a per-element bias table
         std::vector<float> tab((size_t)64 * L.k_out, 0.0f);
@@ -1033,20 +1042,21 @@ int aimnet_debug_gemm(int cfg, int epi, const float* A, int lda, const float* Bt
   return launch_gemm_nt_cfg((hipStream_t)hip_stream, cfg, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc);
 }
 
-int aimnet_debug_split_bf3(const float* src, int ld, int M, int K, void* dst, int ldd, void* hip_stream) {
-  if (!src || !dst || M <= 0 || K <= 0 || ldd < 3 * pad32(K) || ldd % 96) return AIMNET_E_INVALID;
-  return launch_split_bf3((hipStream_t)hip_stream, src, ld, M, K, (unsigned short*)dst, ldd);
+int aimnet_debug_split_bf3(const float* src, int ld, int M, int K, void* dst, int ldd, int neg_from_block, void* hip_stream) {
+  if (!src || !dst || M <= 0 || K <= 0 || ldd < 3 * pad32(K) || ldd % 96 || neg_from_block < 0) return AIMNET_E_INVALID;
+  return launch_split_bf3((hipStream_t)hip_stream, src, ld, M, K, (unsigned short*)dst, ldd, neg_from_block);
 }
 
 int aimnet_debug_gemm_bf3(int cfg, int epi, const float* A, int lda, const void* Bt3, int ldb, int M, int N, int K,
-                          const float* bias, float* C, float* D, int ldc, void* hip_stream) {
+                          const float* bias, float* C, float* D, int ldc, int kneg, void* hip_stream) {
   static bool attr = false;
   if (!attr) {
     int rc = gemm_bf3_set_attributes();
     if (rc) return rc;
     attr = true;
   }
-  return launch_gemm_bf3_cfg((hipStream_t)hip_stream, cfg, epi, A, lda, (const unsigned short*)Bt3, ldb, M, N, K, bias, C, D, ldc);
+  return launch_gemm_bf3_cfg((hipStream_t)hip_stream, cfg, epi, A, lda, (const unsigned short*)Bt3, ldb, M, N, K, bias, C, D, ldc,
+                             nullptr, 0, kneg < 0 ? BF3_NO_NEG : kneg);
 }
 
 #ifdef AIMNET_BF3_TIMING

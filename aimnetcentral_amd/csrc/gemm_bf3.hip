@@ -70,7 +70,7 @@ __device__ __forceinline__ void store_bf3_x4(unsigned short* __restrict__ row, i
 
 // ---- fp32 [M][ld] (columns c0 .. c0+K) -> bf3 [M][Kp/32][3][32]; columns >= K of the last block are zero ------------------
 __global__ __launch_bounds__(256) void split_bf3_kernel(const float* __restrict__ src, int ld, int M, int K, int Kp,
-                                                        unsigned short* __restrict__ dst, int ldd) {
+                                                        unsigned short* __restrict__ dst, int ldd, int neg_from) {
   const int q = Kp >> 2;  // column quads per row
   const size_t n = (size_t)M * q;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
@@ -83,16 +83,18 @@ __global__ __launch_bounds__(256) void split_bf3_kernel(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = col + r < K ? s[r] : 0.0f;
     }
+    if (col >= neg_from) v = -v;
     store_bf3_x4(dst + (size_t)m * ldd, col, v);
   }
 }
 
-int launch_split_bf3(hipStream_t s, const float* src, int ld, int M, int K, unsigned short* dst, int ldd) {
+int launch_split_bf3(hipStream_t s, const float* src, int ld, int M, int K, unsigned short* dst, int ldd, int neg_from_block) {
   if (M <= 0 || K <= 0) return 0;
   const int Kp = (K + 31) / 32 * 32;
   const size_t n = (size_t)M * (Kp >> 2);
   const int blocks = (int)std::min<size_t>((n + 255) / 256, 8192);
-  hipLaunchKernelGGL(split_bf3_kernel, dim3(blocks), dim3(256), 0, s, src, ld, M, K, Kp, dst, ldd);
+  const int neg_from = neg_from_block >= (1 << 24) ? (1 << 30) : neg_from_block * 32;
+  hipLaunchKernelGGL(split_bf3_kernel, dim3(blocks), dim3(256), 0, s, src, ld, M, K, Kp, dst, ldd, neg_from);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }
@@ -108,10 +110,10 @@ static inline unsigned short bf16_rne_host(float x, float* back) {
   memcpy(back, &ub, 4);
   return h;
 }
-void split_bf3_host(const float* w, int rows, int K, unsigned short* out) {
+void split_bf3_host(const float* w, int rows, int K, unsigned short* out, int neg_from_block) {
   for (int r = 0; r < rows; ++r)
     for (int k = 0; k < K; ++k) {
-      const float x = w[(size_t)r * K + k];
+      const float x = (k >> 5) >= neg_from_block ? -w[(size_t)r * K + k] : w[(size_t)r * K + k];
       float f0, f1, f2;
       const unsigned short h0 = bf16_rne_host(x, &f0);
       const float r1 = x - f0;
@@ -237,6 +239,17 @@ constexpr int bf3_waves_per_simd(int SM, int SN, int WM, int WN, int NSTB) {
 __device__ unsigned long long g_bf3_stamps[1024];
 #endif
 
+// Accumulation bias.  v_mfma_f32_16x16x32_bf16 aligns its 32 products and the accumulator in a fixed-point adder and TRUNCATES
+// what falls below its width - two's-complement truncation, i.e. always towards minus infinity.  One instruction loses ~2^-7.5 of
+// an fp32 ulp that way; the 138 accumulations of a K = 736 layer add up to -0.8 ulp of |z| on EVERY output element (measured,
+// tests/tools/bf3_bias.py: mean error -4.6e-8 |z| against -2e-10 for the fp32 MFMA chain, at a smaller rms).  A one-signed
+// error does not average out over atoms or layers: config 5's molecule energies moved by 2e-4 eV (rms), twice the fp32 noise.
+// Remedy without a second accumulator: a negated accumulation is truncated towards minus infinity as well, which is towards PLUS
+// infinity of the quantity it stands for.  So the weight blocks of the last 40 % of K are stored negated (host split), the
+// accumulators change sign once, at step `kneg`, and the epilogue undoes the sign: the two phases' biases cancel.  Measured mean
+// error with the flip at 0.5 / 0.6 / 0.67 / 0.75 of K: +1.1e-8 / +1.8e-9 / -3.0e-9 / -1.3e-8 |z| on random-sign operands,
+// -2.9e-9 / -7.1e-9 / -9.3e-9 / -1.4e-8 on all-positive ones (no flip: -4.7e-8 / -2.9e-8; fp32 MFMA chain: -2e-10); rms unchanged.
+
 // C[M,N] = A[M,K] . B^T: A fp32 [M][lda], B the bf3 split of Bt [N][K] (ldb = bf16 elements per row = 3 x the padded K of the
 // full weight matrix), C / D / bias / brow as in gemm_nt_panel_kernel.
 //
@@ -257,7 +270,7 @@ template <int EPI, int SM, int SN, int WN>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void gemm_bf3_kernel(
     const float* __restrict__ A, int lda, const unsigned short* __restrict__ Bt, int ldb, int M, int N, int K,
     const float* __restrict__ bias, float* __restrict__ C, float* __restrict__ D, int ldc, const int* __restrict__ brow,
-    int ldbias) {
+    int ldbias, int kneg) {
   static_assert(WN == 8 || WN == 4 || WN == 2, "waves across N");
   constexpr int WM = 8 / WN;
   constexpr int TM = 16 * SM * WM, TN = 16 * SN * WN;
@@ -422,8 +435,16 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
     __builtin_amdgcn_sched_barrier(0);
     TSF();
   };
-  // C(j): the 6 x SM x SN matrix instructions of step j, registers only
-  auto seg_compute = [&]() __attribute__((always_inline)) {
+  // C(j): the 6 x SM x SN matrix instructions of step j, registers only.  At step kneg the sign of the accumulators flips: the
+  // weight blocks from there on are stored negated (see the note on the accumulation bias in front of the kernel)
+  auto seg_compute = [&](int j) __attribute__((always_inline)) {
+    if (j == kneg && j > 0) {
+#pragma unroll
+      for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < SN; ++jj) acc[i][jj] = -acc[i][jj];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #define AIMNET_BF3_PRODUCT(PA, PB)                                                                              \
   _Pragma("unroll") for (int i = 0; i < SM; ++i) _Pragma("unroll") for (int jj = 0; jj < SN; ++jj) acc[i][jj] = \
       __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[jj][PB], fa[i][PA], acc[i][jj], 0, 0, 0);
@@ -448,19 +469,19 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
     for (; j + 1 < nk; j += 2) {
       seg_load(j, st, I0{});
       bar();
-      seg_compute();
+      seg_compute(j);
       st = st == 2 ? 0 : st + 1;
       bar();
       seg_load(j + 1, st, I1{});
       bar();
-      seg_compute();
+      seg_compute(j + 1);
       st = st == 2 ? 0 : st + 1;
       if (j + 2 < nk) bar();
     }
     if (j < nk) {  // odd number of steps
       seg_load(j, st, I0{});
       bar();
-      seg_compute();
+      seg_compute(j);
     }
   };
   if (late) {
@@ -473,7 +494,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
   wait_vm<0>();  // the clamped look-ahead of the last steps is still in flight; the wave must not end (LDS released) under its DMA
   __builtin_amdgcn_sched_barrier(0);
 
-  // epilogue: acc[i][j][r] = C[m0 + wm*16*SM + 16 i + (lane&15)][n0 + wn*16*SN + 16 j + 4 (lane>>4) + r]
+  // epilogue: sfin * acc[i][j][r] = C[m0 + wm*16*SM + 16 i + (lane&15)][n0 + wn*16*SN + 16 j + 4 (lane>>4) + r]
+  const float sfin = kneg < nk ? -1.0f : 1.0f;  // the accumulators ended in the negated phase
 #pragma unroll
   for (int j = 0; j < SN; ++j) {
     const int col = n0 + wn * 16 * SN + 16 * j + 4 * lc;
@@ -487,7 +509,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
       const size_t o = (size_t)row * ldc + col;
       if (brow && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU))
         bv = *reinterpret_cast<const f32x4*>(bias + (size_t)min(63, max(0, brow[row])) * ldbias + col);
-      f32x4 v = acc[i][j];
+      f32x4 v = acc[i][j] * sfin;
       if (EPI == EPI_NONE) {
         *reinterpret_cast<f32x4*>(C + o) = v;
       } else if (EPI == EPI_BIAS) {
@@ -513,7 +535,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
 
 template <int SM, int SN, int WN>
 static int launch_bf3(hipStream_t stream, int epi, const float* A, int lda, const unsigned short* Bt, int ldb, int M, int N, int K,
-                      const float* bias, float* C, float* D, int ldc, const int* brow, int ldbias) {
+                      const float* bias, float* C, float* D, int ldc, const int* brow, int ldbias, int kneg) {
   constexpr int WM = 8 / WN, TM = 16 * SM * WM, TN = 16 * SN * WN;
   const int tiles = ceil_div(M, TM) * ceil_div(N, TN);
   const size_t lds = (size_t)bf3_lds_bytes(SM, SN, WM, WN, 3);
@@ -526,7 +548,7 @@ static int launch_bf3(hipStream_t stream, int epi, const float* A, int lda, cons
       AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf3_kernel<E, SM, SN, WN>,                     \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                  \
     hipLaunchKernelGGL((gemm_bf3_kernel<E, SM, SN, WN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, \
-                       bias, C, D, ldc, brow, ldbias);                                                                \
+                       bias, C, D, ldc, brow, ldbias, kneg);                                                          \
   }
   switch (epi) {
     case EPI_NONE: AIMNET_BF3_LAUNCH(EPI_NONE) break;
@@ -567,7 +589,7 @@ static int choose_bf3_tile(int M, int N) {
 }
 
 int launch_gemm_bf3_cfg(hipStream_t stream, int cfg, int epi, const float* A, int lda, const unsigned short* Bt, int ldb, int M,
-                        int N, int K, const float* bias, float* C, float* D, int ldc, const int* brow, int ldbias) {
+                        int N, int K, const float* bias, float* C, float* D, int ldc, const int* brow, int ldbias, int kneg) {
   if (M <= 0) return 0;
   if (K % 32 != 0 || (lda & 3) || (ldb % 96) || (N & 3) || (ldc & 3) ||
       (((size_t)A | (size_t)Bt | (size_t)bias | (size_t)C | (size_t)D) & 15)) {
@@ -578,7 +600,7 @@ int launch_gemm_bf3_cfg(hipStream_t stream, int cfg, int epi, const float* A, in
   if (cfg == 0) cfg = choose_bf3_tile(M, N);
   switch (cfg) {
 #define AIMNET_BF3_CASE(ID, SM_, SN_, WN_) \
-    case ID: return launch_bf3<SM_, SN_, WN_>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);
+    case ID: return launch_bf3<SM_, SN_, WN_>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias, kneg);
     AIMNET_BF3_CASE(452, 5, 2, 4)  // 160 x 128 (2 x 4 waves of 80 x 32; 132 KiB of LDS)
     AIMNET_BF3_CASE(442, 4, 2, 4)  // 128 x 128
     AIMNET_BF3_CASE(432, 3, 2, 4)  //  96 x 128

@@ -24,10 +24,15 @@ int gemm_set_attributes();
 // exactly), six products per tile, fp32 accumulation.  A stays fp32 in memory (split inside the kernel), Bt is the pre-split
 // weight matrix in the "bf3" layout: per row, K/32 blocks of [plane0: 32 bf16][plane1][plane2] = 192 B; ldb counts bf16 elements
 // per row = 3 x the padded K of the full matrix.  Everything else as launch_gemm_nt.
-void split_bf3_host(const float* w, int rows, int K, unsigned short* out);                                   // host form (weights)
-int launch_split_bf3(hipStream_t s, const float* src, int ld, int M, int K, unsigned short* dst, int ldd);  // device form (tests)
+// neg_from_block: k-blocks (of 32) from this index on are stored negated - the second, sign-flipped phase of the accumulation
+// (gemm_bf3.hip, "Accumulation bias"); kneg of the launcher = the number of leading k-steps of THIS launch that are not negated
+constexpr int BF3_NO_NEG = 1 << 30;
+void split_bf3_host(const float* w, int rows, int K, unsigned short* out, int neg_from_block);                 // host form (weights)
+int launch_split_bf3(hipStream_t s, const float* src, int ld, int M, int K, unsigned short* dst, int ldd,
+                     int neg_from_block = BF3_NO_NEG);  // device form (tests)
 int launch_gemm_bf3_cfg(hipStream_t stream, int cfg, int epi, const float* A, int lda, const unsigned short* Bt, int ldb, int M,
-                        int N, int K, const float* bias, float* C, float* D, int ldc, const int* brow = nullptr, int ldbias = 0);
+                        int N, int K, const float* bias, float* C, float* D, int ldc, const int* brow = nullptr, int ldbias = 0,
+                        int kneg = BF3_NO_NEG);
 int gemm_bf3_set_attributes();
 #ifdef AIMNET_BF3_TIMING
 int gemm_bf3_read_stamps(unsigned long long* host1024);  // measurement build only (tests/tools/bf3_timing.sh)

@@ -186,12 +186,14 @@ int aimnet_debug_gemm(int cfg, int epi, const float* A, int lda, const float* Bt
 /* Test / tuning hooks for the bf16x3-split MFMA GEMM (csrc/gemm_bf3.hip): same contract as aimnet_debug_gemm, but the weight
  * operand is pre-split into three bf16 planes.  "bf3" layout: per row, K/32 blocks of [plane 0: 32 bf16][plane 1: 32 bf16]
  * [plane 2: 32 bf16] (192 bytes); fp32 value == plane 0 + plane 1 + plane 2 exactly.
- * aimnet_debug_split_bf3: fp32 src [M][ld] (K columns) -> bf3 dst [M][ldd bf16 elements], ldd >= 3 * pad32(K), ldd % 96 == 0.
+ * aimnet_debug_split_bf3: fp32 src [M][ld] (K columns) -> bf3 dst [M][ldd bf16 elements], ldd >= 3 * pad32(K), ldd % 96 == 0;
+ * k-blocks (of 32) from neg_from_block on are stored negated (pass a value >= K / 32 for none).
  * aimnet_debug_gemm_bf3: C = epilogue(A . Bt^T), A fp32 [M][lda], Bt3 the bf3 split of Bt [N][K] (ldb in bf16 elements per
- * row); cfg 0 = automatic tile. */
-int aimnet_debug_split_bf3(const float* src, int ld, int M, int K, void* dst, int ldd, void* hip_stream);
+ * row); kneg = the number of leading k-steps whose weight blocks are NOT negated (the accumulators change sign there, the
+ * epilogue restores it; see "Accumulation bias" in csrc/gemm_bf3.hip), < 0 or >= K / 32: none; cfg 0 = automatic tile. */
+int aimnet_debug_split_bf3(const float* src, int ld, int M, int K, void* dst, int ldd, int neg_from_block, void* hip_stream);
 int aimnet_debug_gemm_bf3(int cfg, int epi, const float* A, int lda, const void* Bt3, int ldb, int M, int N, int K,
-                          const float* bias, float* C, float* D, int ldc, void* hip_stream);
+                          const float* bias, float* C, float* D, int ldc, int kneg, void* hip_stream);
 
 /* Engine switches for A/B and parity runs (all have an AIMNET_* environment twin read at create time):
  *   "conv_xe"       1 (default): reverse-pair form of the conv backward for systems above the split threshold, 0: combined form

@@ -229,10 +229,10 @@ def test_gemm_tiles_match_fp64(cfg, M, N, K):
 BF3_CFGS = [0, 452, 442, 432, 422, 223, 224, 234, 851]
 
 
-def _split_bf3(lib, x, stream):
+def _split_bf3(lib, x, stream, neg_from_block=1 << 30):
     m, k = x.shape
     out = torch.empty(m, 3 * k, dtype=torch.int16, device=x.device)
-    assert lib.aimnet_debug_split_bf3(x.data_ptr(), k, m, k, out.data_ptr(), 3 * k, stream) == 0
+    assert lib.aimnet_debug_split_bf3(x.data_ptr(), k, m, k, out.data_ptr(), 3 * k, neg_from_block, stream) == 0
     return out
 
 
@@ -266,14 +266,16 @@ def test_gemm_bf3_tiles_match_fp64(cfg, M, N, K):
     Bt = (torch.randn(N, K, generator=gen) * 0.1).to(dev)
     bias = torch.randn(N, generator=gen).to(dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    B3 = _split_bf3(lib, Bt, stream)
     z = A.double() @ Bt.double().T
     for epi in (0, 1, 2, 3):
+        # the sign-flipped second accumulation phase (weights stored negated from k-block KNEG on) at every split point class
+        KNEG = (-1, (2 * (K // 32) + 1) // 3, 0, 1)[epi] if K > 32 else (-1, 0, 0, -1)[epi]
+        B3 = _split_bf3(lib, Bt, stream, KNEG if KNEG >= 0 else 1 << 30)
         Cm = torch.full((M, N), float("nan"), device=dev)
         D = torch.rand(M, N, generator=gen).to(dev) if epi == 3 else torch.full((M, N), float("nan"), device=dev)
         D0 = D.clone()
         rc = lib.aimnet_debug_gemm_bf3(cfg, epi, A.data_ptr(), K, B3.data_ptr(), 3 * K, M, N, K, bias.data_ptr(), Cm.data_ptr(),
-                                       D.data_ptr(), N, stream)
+                                       D.data_ptr(), N, KNEG, stream)
         assert rc == 0, _lib.last_error()
         torch.cuda.synchronize()
         if epi == 0:

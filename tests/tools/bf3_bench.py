@@ -22,13 +22,14 @@ if os.environ.get("SHAPES", "all") == "one":
     shapes = shapes[:1]
 cfgs = [int(c) for c in os.environ.get("CFGS", "452,442,432,422,223,224,234,851").split(",")]
 EPI = int(os.environ.get("EPI", 2))
+FLIP = int(os.environ.get("FLIP", 1))
 stream = torch.cuda.current_stream(dev).cuda_stream
 
 
-def split(x):
+def split(x, neg=1 << 30):
     m, k = x.shape
     out = torch.empty(m, 3 * k, dtype=torch.int16, device=dev)
-    rc = lib.aimnet_debug_split_bf3(x.data_ptr(), k, m, k, out.data_ptr(), 3 * k, stream)
+    rc = lib.aimnet_debug_split_bf3(x.data_ptr(), k, m, k, out.data_ptr(), 3 * k, neg, stream)
     assert rc == 0, _lib.last_error()
     return out
 
@@ -66,8 +67,9 @@ for (N, K) in shapes:
         ref = z + bias.double()
     else:
         ref = z
-    B3 = split(Bt)
-    assert (unsplit(B3, K) - Bt.double()).abs().max().item() == 0.0, "split is not exact"
+    assert (unsplit(split(Bt), K) - Bt.double()).abs().max().item() == 0.0, "split is not exact"
+    KNEG = (2 * (K // 32) + 1) // 3 if FLIP else -1  # sign-flipped last third of the accumulation
+    B3 = split(Bt, KNEG if FLIP else 1 << 30)
     # exact-fp32 kernel: time and error
     C32 = torch.empty(M, N, device=dev)
     D32 = torch.empty(M, N, device=dev)
@@ -88,7 +90,7 @@ for (N, K) in shapes:
 
         def run():
             rc = lib.aimnet_debug_gemm_bf3(cfg, EPI, A.data_ptr(), K, B3.data_ptr(), 3 * K, M, N, K, bias.data_ptr(), Cm.data_ptr(),
-                                           D.data_ptr(), N, stream)
+                                           D.data_ptr(), N, KNEG, stream)
             assert rc == 0, _lib.last_error()
 
         us = timeit(run)

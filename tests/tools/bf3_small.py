@@ -14,10 +14,11 @@ for M, N in ((160, 128), (1000, 288)):
         g = torch.Generator().manual_seed(nk)
         A = torch.randn(M, K, generator=g).to(dev)
         Bt = (torch.randn(N, K, generator=g) * 0.1).to(dev)
+        KNEG = (2 * nk + 1) // 3 if nk > 1 else -1
         B3 = torch.empty(N, 3 * K, dtype=torch.int16, device=dev)
-        assert lib.aimnet_debug_split_bf3(Bt.data_ptr(), K, N, K, B3.data_ptr(), 3 * K, stream) == 0
+        assert lib.aimnet_debug_split_bf3(Bt.data_ptr(), K, N, K, B3.data_ptr(), 3 * K, KNEG if KNEG >= 0 else 1 << 30, stream) == 0
         Cm = torch.full((M, N), float("nan"), device=dev)
-        rc = lib.aimnet_debug_gemm_bf3(cfg, 0, A.data_ptr(), K, B3.data_ptr(), 3 * K, M, N, K, None, Cm.data_ptr(), None, N, stream)
+        rc = lib.aimnet_debug_gemm_bf3(cfg, 0, A.data_ptr(), K, B3.data_ptr(), 3 * K, M, N, K, None, Cm.data_ptr(), None, N, KNEG, stream)
         assert rc == 0, _lib.last_error()
         torch.cuda.synchronize()
         err = (Cm.double() - A.double() @ Bt.double().T).abs()

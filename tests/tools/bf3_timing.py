@@ -18,12 +18,13 @@ A = torch.randn(M, K, device=dev)
 Bt = torch.randn(N, K, device=dev) * 0.05
 bias = torch.randn(N, device=dev)
 B3 = torch.empty(N, 3 * K, dtype=torch.int16, device=dev)
+KNEG = (2 * (K // 32) + 1) // 3
 stream = torch.cuda.current_stream(dev).cuda_stream
-assert lib.aimnet_debug_split_bf3(Bt.data_ptr(), K, N, K, B3.data_ptr(), 3 * K, stream) == 0
+assert lib.aimnet_debug_split_bf3(Bt.data_ptr(), K, N, K, B3.data_ptr(), 3 * K, KNEG, stream) == 0
 Cm = torch.empty(M, N, device=dev)
 D = torch.empty(M, N, device=dev)
 for _ in range(3):
-    rc = lib.aimnet_debug_gemm_bf3(cfg, 2, A.data_ptr(), K, B3.data_ptr(), 3 * K, M, N, K, bias.data_ptr(), Cm.data_ptr(), D.data_ptr(), N, stream)
+    rc = lib.aimnet_debug_gemm_bf3(cfg, 2, A.data_ptr(), K, B3.data_ptr(), 3 * K, M, N, K, bias.data_ptr(), Cm.data_ptr(), D.data_ptr(), N, KNEG, stream)
     assert rc == 0, _lib.last_error()
 torch.cuda.synchronize()
 ref = torch.nn.functional.gelu(A.double() @ Bt.double().T + bias.double())

@@ -1,0 +1,94 @@
+"""The parity fixtures under the two non-default GEMM modes (engine option "gemm_bf3", csrc/gemm_bf3.hip).
+
+Default (1): MLP GEMMs of batches above 256 rows run with bf16x3-split operands on the bf16 matrix pipe, smaller ones on the
+exact-fp32 skinny kernel - so the small golden fixtures never see the split kernels in the other test modules.  Here every parity
+check runs with mode 2 (split kernels for EVERY batch size) and mode 0 (exact-fp32 MFMA kernels everywhere, the fallback the
+bench reports as `exact_f32`), at the same, unchanged gates: goldens of the unmodified reference, the un-widened 1e-5 eV gate on
+the cold fixture, the 32-seed randomised sweep, both charge-channel families."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import test_gpu_fuzz as Z
+import test_gpu_parity as P
+from conftest import golden
+from oracle import aimnet2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=[2, 0], ids=["bf3_every_size", "exact_f32"])
+def gemm_mode(request, hip_engine, hip_engine_nse):
+    for e in (hip_engine, hip_engine_nse):
+        e.set_option("gemm_bf3", request.param)
+    yield request.param
+    for e in (hip_engine, hip_engine_nse):
+        e.set_option("gemm_bf3", 1)
+
+
+def test_taxol(gemm_mode, hip_engine, oracle32):
+    P.test_taxol_vs_oracle_and_reference_golden(hip_engine, oracle32)
+
+
+def test_ragged_charged_batch(gemm_mode, hip_engine, oracle32, oracle64):
+    P.test_ragged_charged_batch(hip_engine, oracle32, oracle64)
+
+
+@pytest.mark.parametrize("name", ["pbc96_dsf15", "pbc96_dsf8_wrapped", "pbc2x96_dsf9"])
+def test_periodic_dsf_forces_stress(gemm_mode, hip_engine, oracle32, oracle64, name):
+    P.test_periodic_dsf_forces_stress(hip_engine, oracle32, oracle64, name)
+
+
+def test_closer_to_fp64_truth_than_tolerance(gemm_mode, hip_engine, oracle64):
+    P.test_closer_to_fp64_truth_than_tolerance(hip_engine, oracle64)
+
+
+def test_cold_fixture_unwidened_gate(gemm_mode, hip_engine):
+    """cold24 (relaxed on the synthetic surface): |dE| < 1e-5 eV against the reference golden, no fp64-anchored slack."""
+    g = golden("cold24")
+    res, _ = P.run(hip_engine, g, "simple")
+    P.compare(res, g, 24, "cold24/reference golden")
+
+
+def test_nse_molecule_and_batch(gemm_mode, hip_engine_nse, oracle32_nse, oracle64_nse):
+    P.test_nse_molecule_vs_oracle_and_reference_golden(hip_engine_nse, oracle32_nse)
+    P.test_nse_ragged_batch_mixed_multiplicities(hip_engine_nse, oracle32_nse, oracle64_nse)
+
+
+def test_bitwise_repeatability(gemm_mode, hip_engine):
+    P.test_bitwise_repeatability(hip_engine)
+
+
+@pytest.mark.parametrize("seed", range(Z._LO, Z._HI))
+def test_random_configuration(gemm_mode, seed, hip_engine, hip_engine_nse, oracle32, oracle32_nse, oracle64, oracle64_nse):
+    Z.test_random_configuration(seed, hip_engine, hip_engine_nse, oracle32, oracle32_nse, oracle64, oracle64_nse)
+
+
+def test_modes_agree_on_a_large_batch(hip_engine, oracle32):
+    """One 2 304-atom periodic evaluation per mode: the split kernels and the exact kernels give the same energies, forces and
+    stress to the fp32 noise of the MLP stack (a direct A/B on a batch that takes the big tiles)."""
+    import torch
+
+    from aimnetcentral_amd import workloads
+
+    c, z, cell = workloads.glucose_supercell((2, 3, 4))
+    rng = np.random.default_rng(7)
+    c = (c + rng.normal(0.0, 0.02, c.shape)).astype(np.float32)
+    dev = hip_engine.device
+    out = {}
+    try:
+        for mode in (0, 1):
+            hip_engine.set_option("gemm_bf3", mode)
+            r = hip_engine.eval(torch.from_numpy(c).to(dev), torch.from_numpy(z).to(dev), torch.zeros(len(z), dtype=torch.int64, device=dev),
+                                torch.zeros(1, device=dev), cell=torch.from_numpy(cell.astype(np.float32)).to(dev), forces=True, stress=True,
+                                coulomb="dsf", dsf_rc=9.0)
+            out[mode] = {k: v.cpu().numpy() for k, v in r.items()}
+    finally:
+        hip_engine.set_option("gemm_bf3", 1)
+    n = len(z)
+    assert abs(out[0]["energy"][0] - out[1]["energy"][0]) <= max(1e-5, 5e-7 * n)
+    fmax = np.abs(out[0]["forces"]).max()
+    assert np.abs(out[0]["forces"] - out[1]["forces"]).max() <= 1e-5 + 1e-4 * fmax
+    assert np.abs(out[0]["charges"] - out[1]["charges"]).max() <= 1e-4
+    assert np.abs(out[0]["stress"] - out[1]["stress"]).max() <= 1e-5

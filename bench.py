@@ -17,10 +17,17 @@ The K timed steps are enqueued back to back; their neighbour-overflow status wor
 device and are all verified after the closing barrier (warm-up steps run with the per-step check).
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the eval stream
-around the dominant kernel family (the fp32-MFMA GEMMs) on every 4th timed step: algorithmic GEMM
-FLOPs per step / GEMM milliseconds per step against the 157.3 TFLOP/s fp32-matrix peak.  `cpu_baseline` times
-the oracle (torch-CPU eager restatement of the reference op sequence, kind "port") on the host
-cores on a bounded sample of the same workload, rank 0 at N=1 only.
+around the dominant kernel family (the MLP GEMMs) on every 4th timed step: algorithmic fp32 GEMM
+FLOPs per step / GEMM milliseconds per step.  The GEMMs run with bf16x3-split operands on the bf16
+matrix pipe (six bf16 products per fp32 product, fp32 accumulation: csrc/gemm_bf3.hip), so the roof
+of that kernel is 2.5 PFLOP/s / 6 = 416.7 TFLOP/s of fp32 work (`peak`); the fraction of the 157.3
+TFLOP/s fp32-matrix peak is reported beside it.  `exact_f32` is the same measurement with the
+exact-fp32 MFMA kernels (engine option gemm_bf3 = 0), taken after the timed region.  `parity`
+compares the engine with the CPU oracle on the samples the CPU baseline is timed on (untimed).
+`cpu_baseline` times the oracle (torch-CPU eager restatement of the reference op sequence, kind
+"port") on the host cores on a bounded sample of the same workload, rank 0 at N=1 only.  With
+--gpus N > 1 the line also carries `scaling_md1024`: BASELINE configs[4] (128 frames x 50 atoms per
+GPU, per-frame energies all-gathered over RCCL every step) timed in the same run.
 """
 from __future__ import annotations
 
@@ -36,6 +43,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_BF16_DENSE_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16 MFMA
+PEAK_BF16X3_TFLOPS = PEAK_BF16_DENSE_TFLOPS / 6.0  # six bf16 products per fp32 product
 
 
 def build_workload(name: str, rank: int, world: int):
@@ -71,7 +80,85 @@ def build_workload(name: str, rank: int, world: int):
     raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline(workload: str, budget_s: float = 10.0):
+def parity_samples():
+    """The two bounded samples (the CPU baseline is timed on one of them): inputs + a closure that evaluates the oracle."""
+    import torch
+
+    from aimnetcentral_amd import synth, workloads
+    from oracle import aimnet2_oracle as O
+
+    sd = synth.synthetic_state_dict(0)
+    om = O.OracleModel(sd, torch.float32)
+    om64 = O.OracleModel(sd, torch.float64)
+    c, z, cell = workloads.glucose_supercell((2, 3, 4))  # 2 304 atoms of the config-3 crystal
+    mol = np.zeros(len(z), dtype=np.int64)
+    pbc = np.ones(3, dtype=bool)
+    c32, cell32 = c.astype(np.float32), cell.astype(np.float32)
+
+    def step_pbc():
+        xw = O.wrap_into_cell(c32, cell32, mol, pbc)
+        nb, sh = O.neighbor_list_fast(xw, 5.0, mol, cell, pbc)
+        nbl, shl = O.neighbor_list_fast(xw, 15.0, mol, cell, pbc)
+        return O.evaluate(om, coord=xw, numbers=z, charge=np.zeros(1, np.float32), mol_idx=mol, cell=cell32, coulomb="dsf",
+                          stress=True, nbmat=nb, shifts=sh, nbmat_lr=nbl, shifts_lr=shl)
+
+    cm, zm, molm, qm = workloads.random_batch(48, 50, 50, 5)
+
+    def step_md():
+        nb, _ = O.neighbor_list_fast(cm, 5.0, molm)
+        nbl, _ = O.neighbor_list(cm, float("inf"), molm)
+        return O.evaluate(om, coord=cm, numbers=zm, charge=qm, mol_idx=molm, coulomb="simple", nbmat=nb, nbmat_lr=nbl)
+
+    def e64_md():  # fp64 energies of the hot random frames: the anchor of their energy gate (see parity_gate)
+        nb, _ = O.neighbor_list_fast(cm, 5.0, molm)
+        nbl, _ = O.neighbor_list(cm, float("inf"), molm)
+        return O.evaluate(om64, coord=cm, numbers=zm, charge=qm, mol_idx=molm, coulomb="simple", nbmat=nb, nbmat_lr=nbl, forces=False)["energy"]
+
+    return {
+        "pbc2304": dict(coord=c32, numbers=z, mol_idx=mol, charge=np.zeros(1, np.float32), cell=cell32, coulomb="dsf", stress=True,
+                        step=step_pbc, e64=None, label="2019828.cif (2,3,4) supercell, 2304 atoms, DSF 15A, E+F+stress"),
+        "md48x50": dict(coord=cm, numbers=zm, mol_idx=molm, charge=qm, cell=None, coulomb="simple", stress=False, step=step_md,
+                        e64=e64_md, label="48 frames x 50 atoms (2400 atoms), simple Coulomb, E+F"),
+    }
+
+
+def parity_gate(eng, samples, oracle_out):
+    """Engine vs oracle on the parity samples, at the reference's own gates (tests/conftest.py): |dE| <= max(1e-5, 5e-7 n) eV,
+    |dF| <= 1e-5 + 1e-4 max|F| eV/A, |dq| <= 1e-4 e, |dstress| <= 1e-5 eV/A^3.  Untimed.
+    The random md frames are hot (contacts of 0.9 A, |F| up to 800 eV/A): there the fp32 ORACLE itself sits up to 1e-3 eV from the
+    fp64 energy, so - as in tests/test_gpu_parity.compare - each molecule's energy gate is widened by the oracle's own distance
+    from the fp64 oracle (`dE_gate_slack_fp64` = the largest such widening); forces, charges and stress are at the plain gates."""
+    import torch
+
+    dev = eng.device
+    res = {}
+    ok_all = True
+    for name, smp in samples.items():
+        ref = oracle_out[name]
+        cell = torch.from_numpy(smp["cell"]).to(dev) if smp["cell"] is not None else None
+        r = eng.eval(torch.from_numpy(smp["coord"]).to(dev), torch.from_numpy(np.asarray(smp["numbers"])).to(dev),
+                     torch.from_numpy(np.asarray(smp["mol_idx"])).to(dev), torch.from_numpy(smp["charge"]).to(dev), cell=cell,
+                     forces=True, stress=smp["stress"], coulomb=smp["coulomb"])
+        r = {k: v.cpu().numpy() for k, v in r.items()}
+        sizes = np.bincount(np.asarray(smp["mol_idx"]))
+        fmax = float(np.abs(ref["forces"]).max())
+        de = np.abs(r["energy"] - ref["energy"])
+        slack = np.abs(ref["energy"] - smp["e64"]()) if smp["e64"] is not None else np.zeros_like(de)
+        e_gate = max(1e-5, 5e-7 * float(sizes.max()))
+        d = {"dE": float(de.max()), "dF_max": float(np.abs(r["forces"] - ref["forces"]).max()),
+             "dq_max": float(np.abs(r["charges"] - ref["charges"]).max()),
+             "dstress_max": float(np.abs(r["stress"] - ref["stress"]).max()) if smp["stress"] else None}
+        gates = {"dE": e_gate, "dE_gate_slack_fp64": float(slack.max()), "dF_max": 1e-5 + 1e-4 * fmax, "dq_max": 1e-4,
+                 "dstress_max": 1e-5 if smp["stress"] else None}
+        ok = bool((de <= e_gate + slack).all()) and all(d[k] is None or d[k] <= gates[k] for k in ("dF_max", "dq_max", "dstress_max"))
+        ok_all = ok_all and ok
+        res[name] = dict(d, gates=gates, ok=bool(ok), sample=smp["label"], atoms=int(len(smp["numbers"])), max_abs_force=fmax)
+    res["ok"] = bool(ok_all)
+    res["oracle"] = "oracle/aimnet2_oracle.py (fp32, pinned to the reference's golden vectors by tests/test_oracle_golden.py)"
+    return res
+
+
+def cpu_baseline(workload: str, budget_s: float = 10.0, samples=None, oracle_out=None):
     """Oracle (kind 'port': torch-CPU eager restatement of the reference op sequence) on the host cores, on a bounded sample of
     the same workload.  The timed step INCLUDES the neighbour lists (k-d tree over the periodic images,
     oracle.neighbor_list_fast), as the GPU step does; measured at every host thread torch will use and at 1 thread
@@ -82,41 +169,27 @@ def cpu_baseline(workload: str, budget_s: float = 10.0):
     from oracle import aimnet2_oracle as O
 
     cores = os.cpu_count() or 1
-    om = O.OracleModel(synth.synthetic_state_dict(0), torch.float32)
-    if workload == "pbc10k":
-        c, z, cell = workloads.glucose_supercell((2, 3, 4))  # 2 304 atoms of the same crystal
-        mol = np.zeros(len(z), dtype=np.int64)
-        pbc = np.ones(3, dtype=bool)
-        c32, cell32 = c.astype(np.float32), cell.astype(np.float32)
-
-        def step():
-            xw = O.wrap_into_cell(c32, cell32, mol, pbc)
-            nb, sh = O.neighbor_list_fast(xw, 5.0, mol, cell, pbc)
-            nbl, shl = O.neighbor_list_fast(xw, 15.0, mol, cell, pbc)
-            return O.evaluate(om, coord=xw, numbers=z, charge=np.zeros(1, np.float32), mol_idx=mol, cell=cell32, coulomb="dsf",
-                              stress=True, nbmat=nb, shifts=sh, nbmat_lr=nbl, shifts_lr=shl)
-
-        sample = "2019828.cif (2,3,4) supercell, 2304 atoms, DSF 15A, E+F+stress, 5 A and 15 A neighbour lists rebuilt and timed every step"
-    else:
-        c, z, mol, q = workloads.random_batch(48, 50, 50, 5)
-
-        def step():
-            nb, _ = O.neighbor_list_fast(c, 5.0, mol)
-            nbl, _ = O.neighbor_list(c, float("inf"), mol)
-            return O.evaluate(om, coord=c, numbers=z, charge=q, mol_idx=mol, coulomb="simple", nbmat=nb, nbmat_lr=nbl)
-
-        sample = "48 frames x 50 atoms (2400 atoms), simple Coulomb, E+F, neighbour lists rebuilt and timed every step"
+    samples = samples or parity_samples()
+    key = "pbc2304" if workload == "pbc10k" else "md48x50"
+    step = samples[key]["step"]
+    z = samples[key]["numbers"]
+    sample = samples[key]["label"] + ", neighbour lists rebuilt and timed every step"
     n_atoms = len(z)
     results = []
     # torch CPU eager degrades badly when it spins hundreds of threads on these small tensors (one 2 304-atom evaluation: 2.3 s on
     # 1 thread, 52 s on 256): the all-cores figure is therefore taken from ONE evaluation, the 16-thread and 1-thread figures
     # from a time budget each
-    for nt, budget, warm in ((min(cores, 16), budget_s * 0.6, True), (1, budget_s * 0.6, True), (cores, 0.0, False)):
+    plan = [(min(cores, 16), budget_s * 0.6, True), (1, budget_s * 0.6, True)]
+    if budget_s >= 5.0:
+        plan.append((cores, 0.0, False))
+    for nt, budget, warm in plan:
         if any(r["cores"] == nt for r in results):
             continue
         torch.set_num_threads(nt)
         if warm:
-            step()
+            out = step()
+            if oracle_out is not None:
+                oracle_out[key] = out
         t0 = time.perf_counter()
         reps = 0
         while True:
@@ -131,7 +204,7 @@ def cpu_baseline(workload: str, budget_s: float = 10.0):
             "sample": sample + f"; torch {torch.__version__} CPU eager, {cores} host threads available", "all": results}
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r3_pmc.json")
 
 
 def pmc_traffic(workload):
@@ -159,6 +232,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pbc10k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU-oracle timing (16 threads + 1 thread); below 5 s the "
+                    "single all-host-threads evaluation (51 s on a 256-thread box) is skipped")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-family time table to stderr")
     args = ap.parse_args()
 
@@ -191,62 +266,84 @@ def main():
             dist.init_process_group(backend)
     comm_dev = dev if (not distributed or os.environ.get("BENCH_BACKEND", "nccl") == "nccl") else torch.device("cpu")
 
-    wl = build_workload(args.workload, rank, world)
     eng = HipEngine(loader.synthetic_spec(0), dev)
-    # inputs resident in HBM in the engine's native dtypes (f32 / i32): no per-step conversion kernels in the timed region
-    dt = {"coord": torch.float32, "numbers": torch.int32, "mol_idx": torch.int32, "charge": torch.float32}
-    t = {k: torch.from_numpy(np.ascontiguousarray(wl[k])).to(device=dev, dtype=dt[k]) for k in dt}
-    cell = torch.from_numpy(wl["cell"]).to(dev) if wl["cell"] is not None else None
-    n_atoms = int(t["coord"].shape[0])
-    frames = int(wl["frames"])
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    statuses = []
+    def timed_run(workload, steps, warmup, profile=True):
+        """warmup checked steps, then `steps` steps enqueued back to back between two barriers; MAX over ranks.
+        Returns (elapsed s, atoms on all ranks, this rank's atoms, frames per rank, GEMM profile, workload dict, local step fn)."""
+        wl = build_workload(workload, rank, world)
+        # inputs resident in HBM in the engine's native dtypes (f32 / i32): no per-step conversion kernels in the timed region
+        dt = {"coord": torch.float32, "numbers": torch.int32, "mol_idx": torch.int32, "charge": torch.float32}
+        t = {k: torch.from_numpy(np.ascontiguousarray(wl[k])).to(device=dev, dtype=dt[k]) for k in dt}
+        cell = torch.from_numpy(wl["cell"]).to(dev) if wl["cell"] is not None else None
+        n_atoms = int(t["coord"].shape[0])
+        frames = int(wl["frames"])
+        statuses = []
 
-    def local_step(sync=True):  # this rank's shard only: no collective
-        r = eng.eval(t["coord"], t["numbers"], t["mol_idx"], t["charge"], cell=cell, forces=True, stress=wl["stress"],
-                     coulomb=wl["coulomb"], sync=sync)
-        if not sync:
-            statuses.append(r["status"])
-        return r["energy"]
+        def local_step(sync=True):  # this rank's shard only: no collective
+            r = eng.eval(t["coord"], t["numbers"], t["mol_idx"], t["charge"], cell=cell, forces=True, stress=wl["stress"],
+                         coulomb=wl["coulomb"], sync=sync)
+            if not sync:
+                statuses.append(r["status"])
+            return r["energy"]
 
-    def step(sync=True):
-        e = local_step(sync)
+        def step(sync=True):
+            e = local_step(sync)
+            if distributed:
+                return adist.all_gather_energies(e.to(comm_dev), [frames] * world)
+            return e
+
+        for _ in range(max(1, warmup)):  # at least one checked evaluation: it settles the neighbour-row capacities
+            step()
+        # HIP events at the GEMM <-> rest boundaries of every 4th timed step (the events themselves cost ~3 % of a step)
+        if profile:
+            eng.set_profiling(1, every=4)
+        barrier()
+        t0 = time.perf_counter()
+        # Timed steps are enqueued back to back, like a device-resident MD driver would: the 32-byte neighbour-overflow status
+        # of every step stays on the device and is checked after the closing barrier (the warm-up steps above ran with the
+        # per-step check and settled the row capacities); a per-step host read would only add a ~50 us bubble per step.
+        for _ in range(steps):
+            e_all = step(sync=False)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        st_all = torch.stack(statuses).cpu().numpy()
+        assert not st_all[:, [2, 3, 5]].any(), "neighbour-list overflow inside the timed region: results invalid"
+        prof = eng.read_profile() if profile else None
+        eng.set_profiling(0)
+        ranks_seen = world
         if distributed:
-            return adist.all_gather_energies(e.to(comm_dev), [frames] * world)
-        return e
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+            na = torch.tensor([n_atoms], dtype=torch.int64, device=comm_dev)
+            dist.all_reduce(na)
+            total_atoms = int(na.item())
+            ranks_seen = dist.get_world_size()
+            assert e_all.numel() == frames * world, "all-gather returned the wrong number of frame energies"
+        else:
+            total_atoms = n_atoms
+        assert bool(torch.isfinite(e_all).all()), "non-finite energies"
+        return dict(elapsed=elapsed, total_atoms=total_atoms, n_atoms=n_atoms, frames=frames, prof=prof, wl=wl, local_step=local_step,
+                    ranks_seen=ranks_seen)
 
-    for _ in range(max(1, args.warmup)):  # at least one checked evaluation: it settles the neighbour-row capacities
-        step()
-    # HIP events at the GEMM <-> rest boundaries of every 4th timed step (the events themselves cost ~3 % of a step)
-    eng.set_profiling(1, every=4)
-    barrier()
-    t0 = time.perf_counter()
-    # Timed steps are enqueued back to back, like a device-resident MD driver would: the 32-byte neighbour-overflow status
-    # of every step stays on the device and is checked after the closing barrier (the warm-up steps above ran with the
-    # per-step check and settled the row capacities); a per-step host read would only add a ~50 us bubble per step.
-    for _ in range(args.steps):
-        e_all = step(sync=False)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    st_all = torch.stack(statuses).cpu().numpy()
-    assert not st_all[:, [2, 3, 5]].any(), "neighbour-list overflow inside the timed region: results invalid"
-    prof = eng.read_profile()
-    eng.set_profiling(0)
-    if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        na = torch.tensor([n_atoms], dtype=torch.int64, device=comm_dev)
-        dist.all_reduce(na)
-        total_atoms = int(na.item())
-    else:
-        total_atoms = n_atoms
-    assert bool(torch.isfinite(e_all).all()), "non-finite energies"
+    run = timed_run(args.workload, args.steps, args.warmup)
+    elapsed, total_atoms, n_atoms, frames, prof, wl, local_step = (run[k] for k in ("elapsed", "total_atoms", "n_atoms", "frames", "prof",
+                                                                                   "wl", "local_step"))
+
+    # BASELINE configs[4] in the same run (N > 1): 128 frames x 50 atoms per GPU, per-frame energies all-gathered every step
+    md = None
+    if distributed and args.workload != "md1024":
+        r = timed_run("md1024", args.steps, max(2, args.warmup), profile=False)
+        md = {"workload": r["wl"]["label"], "value": r["total_atoms"] * args.steps / r["elapsed"], "unit": "atoms*steps/s",
+              "ms_per_step": r["elapsed"] / args.steps * 1e3, "frames_per_gpu": r["frames"], "atoms_per_gpu": r["n_atoms"],
+              "ranks_seen": r["ranks_seen"], "steps": args.steps, "scaling": "weak",
+              "collective": f"all-gather of {r['frames']} fp64 frame energies per rank and step ({'RCCL' if comm_dev.type == 'cuda' else 'gloo'})"}
 
     fam = None
     if rank == 0:  # after the timed region: 5 extra steps with an event per kernel-family change (untimed, N = 1 view)
@@ -259,10 +356,24 @@ def main():
         n_pairs = int(eng.debug_view("nb_cnt").sum().item())  # ordered pairs inside the 5 A cutoff
         xe = os.environ.get("AIMNET_CONV_XE", "1") != "0" and n_atoms > int(os.environ.get("AIMNET_SPLIT_MAX", "1024"))
         gather_form = "reverse-pair" if xe else "combined"
-        gather_bytes = (2 * (4096 + 256 + 16) + 16 + 512) if xe else (2 * 5376 + 512)
+        # pass 0 in the reverse-pair form reads only the centre's own species-moment block of the pair (256 B)
+        gather_bytes = (2 * (4096 + 256 + 16) + 16 + 256) if xe else (2 * 5376 + 512)
         if args.breakdown:
             print("per-family ms/step: " + "  ".join(f"{k}={v:.3f}" for k, v in fam.items()) + f"  total={sum(fam.values()):.3f}",
                   file=sys.stderr)
+
+    exact = None
+    if world == 1:  # the exact-fp32 MFMA kernels on the same workload (fallback record), after the timed region
+        eng.set_option("gemm_bf3", 0)
+        r = timed_run(args.workload, args.steps, 2)
+        g_ms = r["prof"]["gemm"] / max(1.0, r["prof"]["evals"])
+        fl = eng.gemm_flops_per_atom(True) * n_atoms
+        exact = {"value": r["total_atoms"] * args.steps / r["elapsed"], "unit": "atoms*steps/s", "ms_per_step": r["elapsed"] / args.steps * 1e3,
+                 "dtype": "f32 (v_mfma_f32_16x16x4_f32, exact fp32 operands)", "option": "aimnet_engine_set_option(\"gemm_bf3\", 0)",
+                 "roofline": {"bound": "mfma", "achieved": fl / (g_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                              "frac": fl / (g_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, "gemm_ms_per_step": g_ms,
+                              "kernel": "gemm_nt_panel_kernel (fp32 MFMA MLP GEMMs)"}}
+        eng.set_option("gemm_bf3", 1)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -284,15 +395,19 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (bf16x3-split MFMA operands, fp32 accumulate)",
             "data": "synthetic (seeded weights of the real aimnet2 architecture; " + (
                 "crystal from 2019828.cif + 0.02 A jitter)" if args.workload == "pbc10k" else
                 "taxol.xyz frame 0)" if args.workload == "taxol" else "seeded random organic geometries)"),
             "config": {"workload": wl["label"], "atoms_per_gpu": n_atoms, "frames_per_gpu": frames,
                        "parallelism": f"batch-shard x{world} (independent frames, RCCL all-gather of energies)" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic, "traffic_measured_at_commit": traffic_commit,
-                         "kernel": "gemm_nt_panel_kernel (fp32 MFMA MLP GEMMs, all launches of a step)",
+            # algorithmic fp32 FLOPs of the MLP GEMMs / their time: against the roof of the kernel that runs them (six bf16 MFMA
+            # products per fp32 product: 2.5 PFLOP/s / 6) and against the fp32-matrix peak the exact kernels are bound by
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16X3_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16X3_TFLOPS, "peak_note": "2.5 PFLOP/s dense bf16 / 6 products per fp32 product",
+                         "peak_fp32_matrix": PEAK_FP32_MATRIX_TFLOPS, "frac_fp32_matrix": achieved / PEAK_FP32_MATRIX_TFLOPS,
+                         "traffic": traffic, "traffic_measured_at_commit": traffic_commit,
+                         "kernel": "gemm_bf3_kernel (bf16x3-split MFMA MLP GEMMs, fp32 accumulate; all launches of a step)",
                          "gemm_ms_per_step": gemm_ms, "other_ms_per_step": prof["other"] / max(1.0, prof["evals"]),
                          "sampled_steps": int(prof["evals"]),
                          "algorithmic_flop_per_step": flops_step},
@@ -313,8 +428,17 @@ def main():
                                 "conv_bwd_ms_per_step": fam["conv_bwd"]},
             "family_ms_per_step": fam,
         }
+        if exact is not None:
+            out["exact_f32"] = exact
+        if md is not None:
+            out["scaling_md1024"] = md
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
+            samples, oracle_out = parity_samples(), {}
+            out["cpu_baseline"] = cpu_baseline(args.workload, budget_s=args.cpu_budget, samples=samples, oracle_out=oracle_out)
+            for k, smp in samples.items():  # the sample the baseline was not timed on: one oracle evaluation for the parity gate
+                if k not in oracle_out:
+                    oracle_out[k] = smp["step"]()
+            out["parity"] = parity_gate(eng, samples, oracle_out)
         print(json.dumps(out))
     if distributed:
         dist.barrier()  # the other ranks wait here while rank 0 finishes its per-family pass and prints

@@ -30,15 +30,37 @@ def test_single_gpu_json_contract():
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert abs(d["value"] - d["config"]["atoms_per_gpu"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    # the record of the exact-fp32 kernels rides on the same line (measured after the timed region)
+    ex = d["exact_f32"]
+    assert ex["value"] > 0 and ex["roofline"]["peak"] == 157.3 and "bf16x3" in d["dtype"] and d["roofline"]["peak_fp32_matrix"] == 157.3
+
+
+def test_default_workload_carries_the_parity_gate():
+    """The default line (config 3) with the CPU baseline: `parity` compares engine and oracle on the two bounded samples."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-budget", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["config"]["atoms_per_gpu"] == 10080 and d["cpu_baseline"]["kind"] == "port"
+    p = d["parity"]
+    assert p["ok"] is True and set(p) >= {"pbc2304", "md48x50", "ok"}
+    for k in ("pbc2304", "md48x50"):
+        assert p[k]["ok"] and p[k]["dF_max"] <= p[k]["gates"]["dF_max"] and p[k]["dq_max"] <= 1e-4
+    assert p["pbc2304"]["dE"] <= p["pbc2304"]["gates"]["dE"] and p["pbc2304"]["gates"]["dE_gate_slack_fp64"] == 0.0
 
 
 def test_two_ranks_share_the_gpu_over_gloo():
     env = dict(os.environ, BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "md1024"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+           "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
-    # whole-job value: both ranks' atoms over the slowest rank's time
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d and "exact_f32" not in d
+    # headline: config-3 replicas (N = 1 agrees with the single-GPU line); whole-job value = both ranks' atoms over the slowest rank
+    assert d["config"]["atoms_per_gpu"] == 10080
     assert abs(d["value"] - 2 * d["config"]["atoms_per_gpu"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    # BASELINE configs[4] in the same run: 128 frames x 50 atoms per rank, energies of all ranks gathered every step
+    md = d["scaling_md1024"]
+    assert md["ranks_seen"] == 2 and md["frames_per_gpu"] == 128 and md["atoms_per_gpu"] == 6400 and md["scaling"] == "weak"
+    assert abs(md["value"] - 2 * md["atoms_per_gpu"] * 1e3 / md["ms_per_step"]) < 1e-6 * md["value"]

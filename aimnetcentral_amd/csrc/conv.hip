@@ -351,22 +351,16 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
 }
 
 
-// Split threshold: AIMNET_SPLIT_MAX or conv_set_split_max() override it (tests: 0 runs every fixture, however small, through
-// the one-wave-per-atom kernels that large systems take).  Process-wide.
-static int g_split_max = -1;
-int conv_split_max_atoms() {
-  if (g_split_max < 0) {
-    const char* env = getenv("AIMNET_SPLIT_MAX");
-    g_split_max = env ? atoi(env) : SPLIT_MAX_ATOMS;
-  }
-  return g_split_max;
-}
-void conv_set_split_max(int n) { g_split_max = n < 0 ? SPLIT_MAX_ATOMS : n; }
+// Split threshold (atoms up to which the four waves of a block share one centre atom): a per-engine setting
+// (aimnet_engine::split_max, AIMNET_SPLIT_MAX / set_option("split_max"); tests: 0 runs every fixture, however small, through the
+// one-wave-per-atom kernels that large systems take); the launchers receive it as an argument.
+int conv_split_max_default() { return SPLIT_MAX_ATOMS; }
 
 int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, const float* q, const int* nb_idx,
                     const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
-                    float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order, bool species_moments) {
-  const bool split = n_atoms <= conv_split_max_atoms();
+                    float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order, bool species_moments,
+                    int split_max) {
+  const bool split = n_atoms <= split_max;
   // (one-wave-per-atom form: exactly the 4 blocks per CU that are resident - with twice as many the second half only queues
   // behind the first and pays the block prologue again: 0.217 -> 0.207 ms/step over the three launches)
   const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), device_cus() * 4);
@@ -887,8 +881,8 @@ int launch_conv_bwd(hipStream_t s, int nq, bool need_abar, bool stress, const fl
                     const float* q, const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
                     int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
                     const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order,
-                    float4* pairbuf, bool pb_accum) {
-  const bool split = n_atoms <= conv_split_max_atoms();
+                    float4* pairbuf, bool pb_accum, int split_max) {
+  const bool split = n_atoms <= split_max;
   const bool xe = pairbuf != nullptr && !split;  // reverse-pair form: F1 of every ordered pair into pairbuf (see the kernel)
   const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), device_cus() * 4);
 #define AIMNET_BWD(HQ, NA, ST, SP, XE)                                                                                      \

@@ -82,19 +82,14 @@ struct aimnet_engine {
   // Measured on config 3 (profiles/r2_conv_mfma.md): forward 81 us either way, backward 293 vs 226 us - neither form is
   // arithmetic-bound, so the matrix pipe buys nothing here and the VALU kernels stay the default.
   int conv_mfma = 0;
-  // AIMNET_CONV_CLUSTER / set_option("conv_cluster"): the conv backward of passes >= 1 for clusters of four centre atoms
-  // (conv_cluster.hip: union lists, Y for four centres in one MFMA chain, the X half through the reverse-pair identity) for
-  // systems above the split threshold.  Measured on config 3 (profiles/r2_conv_cluster.md): the union lists halve the rows
-  // gathered (341 k instead of 683 k, 4 KiB instead of 5.25 KiB each) but the kernel takes 319 us against 226 us - the four
-  // centres' abar updates and reductions (184 instructions per union entry at 2 waves per SIMD) cost more than the gather
-  // saves, and the list build adds 0.18 ms per step.  Off by default; parity-tested (tests/test_gpu_conv_cluster.py).
-  int conv_cluster = 0;
   // AIMNET_CONV_XE / set_option("conv_xe"): the reverse-pair form of the conv backward (conv.hip, conv_bwd_kernel<.., XE>) for
   // passes >= 1 of systems above the split threshold: every ordered pair evaluates only its own half of the pair adjoints (no
   // a_j gather, 4 KiB per pair instead of 5.25 KiB), F1 goes through a pair buffer and a reverse-pair map (per-atom hash tables of the rows).
   // Config 3: kernel 215 -> 152 us per pass, +35 us per step for the map (hash build 9 us, lookup 12 us) and the force gather (14 us).
   // 0 restores the combined-adjoint kernel (A/B and parity runs).
   int conv_xe = 1;
+  // atoms up to which the 4-waves-per-atom "split" conv kernels are used (AIMNET_SPLIT_MAX / set_option("split_max")); per engine
+  int split_max = conv_split_max_default();
   // AIMNET_OVERLAP_COULOMB / set_option("overlap_coulomb"): the Coulomb / DFT-D3 pair kernels (VALU-bound, they need only the
   // final charges) run on a second HIP stream next to the last pass' MLP, the energy head and the first backward GEMMs
   // (MFMA-bound): forked after the last charge update, joined in front of the first conv backward
@@ -237,8 +232,6 @@ struct Workspace {
   float* qtot;   // NSE models: alpha + beta charges (the Coulomb kernels and the `charges` output see these)
   double* part;  // per-(system, slice) partial sums of the molecule reductions
   int S;         // slices per molecule
-  ClusterLists cl;   // conv_cluster.hip (pointers NULL when that path is off)
-  bool cluster = false;
   bool xe = false;   // reverse-pair conv backward: pair buffer + reverse map
   float4* pairbuf;
   int* rev;
@@ -276,9 +269,8 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   const bool grad = (opt->flags & (AIMNET_FORCES | AIMNET_STRESS)) != 0;
   const size_t n = (size_t)N;
   const int cap = std::max(1, opt->max_nb), cap_lr = std::max(0, opt->max_nb_lr);
-  W.cluster = e->conv_cluster != 0 && grad && np > 1 && N > conv_split_max_atoms() && cluster_lists_supported(N, cap);
-  const bool mfma_rows = (e->conv_mfma != 0 && N > conv_split_max_atoms()) || W.cluster;
-  W.xe = e->conv_xe != 0 && !W.cluster && !(e->conv_mfma & 2) && grad && np > 1 && N > conv_split_max_atoms() &&
+  const bool mfma_rows = e->conv_mfma != 0 && N > e->split_max;
+  W.xe = e->conv_xe != 0 && !(e->conv_mfma & 2) && grad && np > 1 && N > e->split_max &&
          pair_rev_supported(N, cap) && n * (size_t)cap < (size_t)INT32_MAX;
   char* nl_base = c.take<char>(nlist_scratch_bytes(N, n_mol));
   if (base) nlist_carve(W.nl, nl_base, N, n_mol);
@@ -362,18 +354,6 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   } else {
     W.abar = W.zb0 = W.zb1 = W.Sbar = W.Sqbar = nullptr;
   }
-  {
-    const size_t n_cl = W.cluster ? (n + 3) / 4 : 0, cu = (size_t)4 * cap;
-    W.cl.capU = (int)cu;
-    W.cl.cnt = c.take<int>(n_cl);
-    W.cl.idx = c.take<int>(n_cl * cu);
-    W.cl.shift = c.take<int>(n_cl * cu);
-    W.cl.ud = c.take<float4>(n_cl * cu * 4);
-    W.cl.pos_of = c.take<int>(W.cluster ? n : 0);
-    W.cl.rev = c.take<int>(n_cl * cu * 4);
-    W.cl.n_missing = c.take<int>(W.cluster ? 1 : 0);
-    W.cl.pairbuf = c.take<float4>(n_cl * cu * 4);
-  }
   W.pairbuf = c.take<float4>(W.xe ? n * cap : 0);
   W.rev = c.take<int>(W.xe ? n * cap : 0);
   W.rev_tab = c.take<unsigned long long>(W.xe ? pair_hash_bytes(N) / sizeof(unsigned long long) : 0);
@@ -452,8 +432,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->gemm_bf3 = std::min(2, std::max(0, atoi(env)));
     env = getenv("AIMNET_CONV_XE");
     if (env) e->conv_xe = atoi(env);
-    env = getenv("AIMNET_CONV_CLUSTER");
-    if (env) e->conv_cluster = atoi(env);
+    env = getenv("AIMNET_SPLIT_MAX");
+    if (env) e->split_max = std::max(0, atoi(env));
     env = getenv("AIMNET_OVERLAP_COULOMB");
     if (env) e->overlap_coulomb = atoi(env) != 0;
   }
@@ -579,11 +559,10 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   if (!e || !name) return AIMNET_E_INVALID;
   const std::string n(name);
   if (n == "conv_mfma") e->conv_mfma = value & 3;
-  else if (n == "conv_cluster") e->conv_cluster = value != 0;
   else if (n == "conv_xe") e->conv_xe = value != 0;
   else if (n == "emb_bias") e->emb_bias = value != 0;
   else if (n == "gemm_bf3") e->gemm_bf3 = std::min(2, std::max(0, value));
-  else if (n == "split_max") conv_set_split_max(value);  // process-wide
+  else if (n == "split_max") e->split_max = value < 0 ? conv_split_max_default() : value;
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
   else if (n == "spatial_order") e->spatial_order = value != 0;
@@ -726,15 +705,16 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   RC(prof_mark(e, s, FAM_NLIST));
   AIMNET_HIP_CHECK(hipMemsetAsync(out->status, 0, 8 * sizeof(int), s));
   const bool want_species = (e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS))) || opt->dftd3 != 0;
-  RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start, in->numbers, out->status + 6,
+  RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start, W.nl.mol_c, in->numbers, out->status + 6,
                       want_species ? e->slot_of_z : nullptr, W.aslot, W.present_part));  // + aslot / present species
-  RC(launch_wrap(s, in->coord, in->mol_idx, N, n_mol, in->cell, n_cell, in->pbc, W.nl, in->pbc_sys, pbc ? ar.rc : 0.0f));
+  const int* mol_c = W.nl.mol_c;  // clamped to [0, n_mol): memory-safe whatever the caller passed (status[6] reports it)
+  RC(launch_wrap(s, in->coord, mol_c, N, n_mol, in->cell, n_cell, in->pbc, W.nl, in->pbc_sys, pbc ? ar.rc : 0.0f));
   // large non-periodic molecules (>= 1500 atoms on average) get a bounding-box cell list instead of the O(n^2) scan
   if (!pbc && (long)N >= 1500L * n_mol) RC(launch_bbox(s, n_mol, W.nl));
-  RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, ar.rc, ar.rc, cap, N, 0, W.nl, W.nb_idx, W.nb_shift,
+  RC(launch_nlist(s, N, n_mol, mol_c, in->cell, n_cell, in->pbc, ar.rc, ar.rc, cap, N, 0, W.nl, W.nb_idx, W.nb_shift,
                   W.nb_cnt, out->status + 0, out->status + 2, W.pg));
   if (coulomb == AIMNET_COULOMB_DSF && !pbc)  // periodic DSF needs no list: it walks the short-range cell grid
-    RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, opt->dsf_rc, -1.0f, cap_lr, N, 0, W.nl, W.lr_idx,
+    RC(launch_nlist(s, N, n_mol, mol_c, in->cell, n_cell, in->pbc, opt->dsf_rc, -1.0f, cap_lr, N, 0, W.nl, W.lr_idx,
                     W.lr_shift, W.lr_cnt, out->status + 1, out->status + 3));
   const bool d3 = opt->dftd3 != 0;
   if (d3 && e->d3.ns == 0) {
@@ -745,11 +725,11 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   int cap_d3 = cap_lr;
   if (d3 && !d3_shared) {
     if (d3_shares_lr_list(opt, cap_lr)) {  // periodic DSF walks the grid: the shared buffers are free for the D3 list
-      RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, opt->d3_cutoff, -1.0f, cap_lr, N, 0, W.nl, W.d3_idx,
+      RC(launch_nlist(s, N, n_mol, mol_c, in->cell, n_cell, in->pbc, opt->d3_cutoff, -1.0f, cap_lr, N, 0, W.nl, W.d3_idx,
                       W.d3_shift, W.d3_cnt, out->status + 4, out->status + 5));
     } else {
       cap_d3 = std::max(1, opt->max_nb_d3);
-      RC(launch_nlist(s, N, n_mol, in->mol_idx, in->cell, n_cell, in->pbc, opt->d3_cutoff, -1.0f, cap_d3, N, 0, W.nl, W.d3_idx,
+      RC(launch_nlist(s, N, n_mol, mol_c, in->cell, n_cell, in->pbc, opt->d3_cutoff, -1.0f, cap_d3, N, 0, W.nl, W.d3_idx,
                       W.d3_shift, W.d3_cnt, out->status + 4, out->status + 5));
     }
   }
@@ -761,14 +741,10 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const int* order = (W.nl.binned && e->spatial_order) ? W.nl.sorted : nullptr;
   // a^0 = afv[Z] is never materialised: pass 0 gathers the embedding rows directly (conv_fwd / conv_bwd row_of, update_a)
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
-  const bool mfma_fwd = (e->conv_mfma & 1) && N > conv_split_max_atoms();
-  const bool mfma_bwd = (e->conv_mfma & 2) && N > conv_split_max_atoms();
+  const bool mfma_fwd = (e->conv_mfma & 1) && N > e->split_max;
+  const bool mfma_bwd = (e->conv_mfma & 2) && N > e->split_max;
   // reverse-pair map through per-atom hash tables of the rows (once per neighbour list)
   if (W.xe) RC(launch_pair_rev_hash(s, W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, cap, N, W.rev_tab, W.rev));
-  if (W.cluster) {  // union lists of the four-centre clusters + the reverse-pair map (once per neighbour list)
-    AIMNET_HIP_CHECK(hipMemsetAsync(W.cl.n_missing, 0, sizeof(int), s));
-    RC(launch_cluster_build(s, W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, W.pg, cap, order, N, W.cl));
-  }
   // ---- Coulomb: energies, and the seeds of qbar / dE/dx / virial (a closure: it runs on the eval stream or on the side one) ----
   const float* q_fin = nq == 2 ? W.qtot : W.q[np - 2];
   const bool overlap = e->overlap_coulomb && e->prof_level < 2;  // per-family profiling wants one stream
@@ -787,22 +763,22 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     // DSF and DFT-D3 with one cutoff: the Coulomb pair terms ride on the D3 pair pass (one list, one geometry evaluation)
     const bool dsf_in_d3 = d3 && coulomb == AIMNET_COULOMB_DSF && opt->d3_cutoff == opt->dsf_rc;
     if (coulomb == AIMNET_COULOMB_SIMPLE)
-      RC(launch_coulomb_simple(cs, grad, q_fin, W.nl.xw, in->mol_idx, W.nl.mol_start, cp, N, W.ecoul, W.qbar, W.fgrad));
+      RC(launch_coulomb_simple(cs, grad, q_fin, W.nl.xw, mol_c, W.nl.mol_start, cp, N, W.ecoul, W.qbar, W.fgrad));
     else if (dsf_in_d3)
       ;  // see launch_dftd3 below
     else if (coulomb == AIMNET_COULOMB_DSF && pbc) {
-      RC(launch_coulomb_dsf_walk(cs, grad, want_s, q_fin, in->mol_idx, W.nl, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom,
+      RC(launch_coulomb_dsf_walk(cs, grad, want_s, q_fin, mol_c, W.nl, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom,
                                  out->charges));
       charges_written = true;
     } else if (coulomb == AIMNET_COULOMB_DSF)
-      RC(launch_coulomb_dsf(cs, grad, want_s, q_fin, W.nl.xw, in->mol_idx, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt,
+      RC(launch_coulomb_dsf(cs, grad, want_s, q_fin, W.nl.xw, mol_c, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt,
                             cap_lr, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));
     if (d3) {  // external DFT-D3: adds to the per-atom pair energies, dE/dx and the virial seeded by the Coulomb kernels
       D3Params dp;
       dp.s6 = opt->d3_s6; dp.s8 = opt->d3_s8; dp.a1 = opt->d3_a1; dp.a2 = opt->d3_a2;
       dp.r_on = opt->d3_smoothing_on * 1.8897261258369282f;
       dp.r_off = opt->d3_cutoff * 1.8897261258369282f;
-      RC(launch_dftd3(cs, grad, want_s, W.nl.xw, in->mol_idx, in->cell, n_cell, W.aslot, W.d3_idx, W.d3_shift, W.d3_cnt, cap_d3,
+      RC(launch_dftd3(cs, grad, want_s, W.nl.xw, mol_c, in->cell, n_cell, W.aslot, W.d3_idx, W.d3_shift, W.d3_cnt, cap_d3,
                       e->d3, dp, opt->d3_cutoff, N, W.d3xs, W.d3w, W.dEdcn, W.ecoul, W.fgrad, W.virial_atom, dsf_in_d3, cp, q_fin,
                       W.qbar));
     }
@@ -821,7 +797,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     else
       RC(launch_conv_fwd(s, p > 0 ? nq : 0, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr, p > 0 ? W.q[p - 1] : nullptr,
                          W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q, e->bp, W.x[p], Ls[0].k_in, W.V[p], W.Vq[p], N, order,
-                         p == 0 && e->p0_moments));
+                         p == 0 && e->p0_moments, e->split_max));
     const float* hin = W.x[p];
     int ld_in = Ls[0].k_in;
     RC(prof_mark(e, s, FAM_GEMM));
@@ -935,15 +911,10 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
                             order, (W.xe && want_f) ? W.pairbuf : nullptr));
       break;
     }
-    const bool cl_pass = W.cluster && p > 0;
-    RC((mfma_bwd || cl_pass ? launch_unconcat_t : launch_unconcat)(s, p > 0 ? nq : 0, zcur, ld, W.V[p], W.Vq[p], e->agh_a, e->agh_q,
-                                                                   W.Sbar, W.Sqbar, N));
+    RC((mfma_bwd ? launch_unconcat_t : launch_unconcat)(s, p > 0 ? nq : 0, zcur, ld, W.V[p], W.Vq[p], e->agh_a, e->agh_q, W.Sbar,
+                                                         W.Sqbar, N));
     RC(prof_mark(e, s, FAM_CONV_BWD));
-    if (cl_pass) {
-      RC(launch_conv_bwd_cluster(s, nq, true, want_s, W.at[p], W.q[p - 1], W.Sbar, W.Sqbar, W.cl, e->bp, zcur, ld,
-                                 (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, p < np - 1, W.virial_atom, N, order));
-      if (p == 1) RC(launch_cluster_force(s, W.cl, order, N, W.fgrad));  // both passes' pair terms are in the pair buffer
-    } else if (mfma_bwd) {
+    if (mfma_bwd) {
       RC(launch_conv_bwd_mfma(s, p > 0 ? nq : 0, p > 0, want_s, p == 0 ? e->afv_t : W.at[p], p == 0 ? in->numbers : nullptr,
                               p > 0 ? W.q[p - 1] : nullptr, W.Sbar, W.Sqbar, W.nb_idx, W.nb_cnt, W.pg, cap, e->bp, zcur, ld,
                               (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, W.fgrad, W.virial_atom, N, order));
@@ -951,7 +922,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       RC(launch_conv_bwd(s, p > 0 ? nq : 0, p > 0, want_s, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr,
                          p > 0 ? W.q[p - 1] : nullptr, W.Sbar, W.Sqbar, W.nb_idx, W.nb_cnt, W.pg, cap, e->bp, zcur, ld,
                          (p < np - 1) ? W.abar : nullptr, W.abar, W.qbar, W.qbar, W.fgrad, W.virial_atom, N, order,
-                         (W.xe && p > 0) ? W.pairbuf : nullptr, p < np - 1));
+                         (W.xe && p > 0) ? W.pairbuf : nullptr, p < np - 1, e->split_max));
     }
     if (p == 0) break;
     // NSE adjoint of pass p-1, then the adjoint of its MLP output
@@ -962,7 +933,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     RC(prof_mark(e, s, FAM_POINTWISE));
     RC(launch_nse_bwd_reduce(s, W.qbar, y, ldy, nq, W.nl.mol_start, n_mol, N, W.S, (float*)W.part));
     RC(launch_build_zbar(s, W.qbar, W.abar, y, ldy, ar.last_linear[p - 1] ? nullptr : W.D[p - 1][nlq - 1], W.Fm[p - 1],
-                         W.Dm[p - 1], (const float*)W.part, W.S, in->mol_idx, N, n_mol, 256, nq, p - 1 > 0, znext, W.qbar));
+                         W.Dm[p - 1], (const float*)W.part, W.S, mol_c, N, n_mol, 256, nq, p - 1 > 0, znext, W.qbar));
     std::swap(zcur, znext);
   }
   RC(prof_mark(e, s, FAM_POINTWISE));
@@ -1016,7 +987,8 @@ int aimnet_neighbor_list(const float* coord, const int32_t* mol_idx, int32_t n_a
   const int pz[3] = {1, 1, 1};
   const int* pb = pbc ? pbc : pz;
   AIMNET_HIP_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(int), s));
-  RC(launch_mol_start(s, mol_idx, n_atoms, n_mol, nl.mol_start));
+  RC(launch_mol_start(s, mol_idx, n_atoms, n_mol, nl.mol_start, nl.mol_c));
+  mol_idx = nl.mol_c;  // clamped to [0, n_mol)
   RC(launch_wrap(s, coord, mol_idx, n_atoms, n_mol, cell, cell ? n_cell : 0, pb, nl));
   if (!cell && (long)n_atoms >= 1500L * n_mol) RC(launch_bbox(s, n_mol, nl));
   RC(launch_nlist(s, n_atoms, n_mol, mol_idx, cell, cell ? n_cell : 0, pb, cutoff, cutoff, max_nb, fill_value, 1, nl, nbmat,

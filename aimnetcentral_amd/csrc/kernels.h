@@ -51,15 +51,18 @@ struct NlistBuffers {      // all device pointers, carved from the caller's work
   int* sorted;             // [n_atoms]
   float4* xs;              // [n_atoms] bin-ordered (x, y, z, atom id)
   void* sorted_tmp_xq;     // [n_atoms] float4 bin-ordered (x, y, z, charge) for the list-free DSF walk
+  int* mol_c;              // [n_atoms] the caller's mol_idx clamped to [0, n_mol) (launch_mol_start): what every kernel indexes with
   float prebinned_width = 0.0f;  // host flag: launch_wrap prepared the bins for this width (launch_bins starts at the scan)
   bool binned = false;     // host flag: `sys` + bins describe this batch (periodic cells, or bounding boxes via launch_bbox)
 };
 size_t nlist_scratch_bytes(int n_atoms, int n_mol);
 size_t nlist_xw_offset(int n_mol);  // byte offset of NlistBuffers::xw inside the scratch
 void nlist_carve(NlistBuffers& b, char* base, int n_atoms, int n_mol);
-int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start, const int* numbers = nullptr,
-                     int* bad = nullptr, const int* slot_of_z = nullptr, int* aslot = nullptr,
-                     unsigned long long* present_part = nullptr);  // + the species pass (launch_species) when slot_of_z is given  // bad: input sanity flags (bit 0 atomic number outside [0,63], bit 1 mol_idx outside [0,n_mol))
+// bad: input sanity flags (bit 0 atomic number outside [0,63], bit 1 mol_idx outside [0,n_mol), bit 2 mol_idx not sorted);
+// mol_c [n_atoms]: the clamped copy of mol_idx; + the species pass (launch_species) when slot_of_z is given
+int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start, int* mol_c,
+                     const int* numbers = nullptr, int* bad = nullptr, const int* slot_of_z = nullptr, int* aslot = nullptr,
+                     unsigned long long* present_part = nullptr);
 // wrap coordinates (periodic) or copy them (non-periodic) into b.xw
 int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
                 int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys = nullptr, float bin_width = 0.0f);  // pbc_sys: device [n_cell][3] or NULL
@@ -85,14 +88,16 @@ struct BasisParams {  // radial basis of AEVSV (aev.py:66-81), passed by value
 int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, const float* q, const int* nb_idx,
                     const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
                     float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order,
-                    bool species_moments = false);  // pass 0 (row_of given, nq = 0): per-element moments, no row gathers
+                    bool species_moments = false,  // pass 0 (row_of given, nq = 0): per-element moments, no row gathers
+                    int split_max = 1024);         // atoms up to which the 4-waves-per-atom form is used
 int launch_unconcat(hipStream_t s, int nq, const float* xbar, int ldx, const float* Vsave, const float* Vqsave,
                     const float* agh_a, const float* agh_q, float* Sbar, float* Sqbar, int n_atoms);
 int launch_conv_bwd(hipStream_t s, int nq, bool need_abar, bool stress, const float* a, const int* row_of,
                     const float* q, const float* Sbar, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg,
                     int cap, BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out,
                     const float* qbar_in, float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order,
-                    float4* pairbuf = nullptr, bool pb_accum = false);  // pairbuf: the reverse-pair (XE) form, see conv.hip
+                    float4* pairbuf = nullptr, bool pb_accum = false,  // pairbuf: the reverse-pair (XE) form, see conv.hip
+                    int split_max = 1024);
 bool pair_rev_supported(int n_atoms, int cap);  // row capacity / atom count the reverse-pair map handles
 // reverse-pair map rev[i * cap + m] = position of (i, -shift) in the row of idx[i][m]: per-atom 256-slot hash tables `tab`
 // (pair_hash_bytes) built and probed on the device
@@ -126,31 +131,8 @@ int launch_conv_bwd_mfma(hipStream_t s, int nq, bool need_abar, bool stress, con
                          const float* SbarT, const float* Sqbar, const int* nb_idx, const int* nb_cnt, const float4* pg, int cap,
                          BasisParams bp, const float* xbar, int ldx, const float* abar_in, float* abar_out, const float* qbar_in,
                          float* qbar_out, float* fgrad, float* virial_atom, int n_atoms, const int* order);
-// ---- conv_cluster.hip: conv backward for clusters of four centre atoms (union neighbour lists, Y on the 4x4x1 MFMA with
-// row = centre, the reverse-pair exchange of the pair adjoints through a pair buffer).  Passes >= 1 of systems above the split
-// threshold; SbarT / a_t as for conv_mfma.hip.
-struct ClusterLists {   // device pointers carved from the workspace; cluster c = centres order[4c .. 4c+3]
-  int capU;             // union entries per cluster (4 x the row capacity)
-  int* cnt;             // [n_cl]
-  int* idx;             // [n_cl][capU] neighbour atom of the entry (sorted by (atom, shift code))
-  int* shift;           // [n_cl][capU] packed cell shift
-  float4* ud;           // [n_cl][capU][4] (u, d) of (entry, centre); d = -1: this centre does not hold the entry
-  int* pos_of;          // [n_atoms] position of the atom in the processing order (cluster = pos >> 2, centre = pos & 3)
-  int* rev;             // [n_cl][capU][4] flat index of the reverse ordered pair, -1 for absent
-  int* n_missing;       // [1] pairs without a reverse entry (only after a row overflow)
-  float4* pairbuf;      // [n_cl][capU][4] F1 of the ordered pair, summed over the passes
-};
-bool cluster_lists_supported(int n_atoms, int cap);
-int launch_cluster_build(hipStream_t s, const int* nb_idx, const int* nb_shift, const int* nb_cnt, const float4* pg, int cap,
-                         const int* order, int n_atoms, ClusterLists cl);
-int launch_conv_bwd_cluster(hipStream_t s, int nq, bool need_abar, bool stress, const float* a_t, const float* q,
-                            const float* SbarT, const float* Sqbar, ClusterLists cl, BasisParams bp, const float* xbar, int ldx,
-                            const float* abar_in, float* abar_out, const float* qbar_in, float* qbar_out, bool pb_accum,
-                            float* virial_atom, int n_atoms, const int* order);
-int launch_cluster_force(hipStream_t s, ClusterLists cl, const int* order, int n_atoms, float* fgrad);
 int launch_mfma4_probe(hipStream_t s, float* out);  // lane-layout probe of the 4x4x1 16-block MFMA (tests)
-int conv_split_max_atoms();
-void conv_set_split_max(int n);  // n < 0 restores the default
+int conv_split_max_default();  // 1024
 // stand-alone reference-op forms (conv_sv_2d_sp_wp.py:90-164)
 int launch_conv_sv_fwd(hipStream_t s, const float* a, const int* idx, const float* g, float* out, int B, int A, int G,
                        int M);

@@ -28,6 +28,7 @@ size_t nlist_scratch_bytes(int n_atoms, int n_mol) {
   b += 3 * align_up((max_bins + 1) * sizeof(int), 256);     // count, start, fill
   b += 2 * align_up((size_t)n_atoms * sizeof(int), 256);    // sorted_tmp, sorted
   b += 2 * align_up((size_t)n_atoms * sizeof(float4), 256); // xs: bin-ordered (x, y, z, atom id); xq: (x, y, z, charge)
+  b += align_up((size_t)n_atoms * sizeof(int), 256);        // mol_c: molecule index of every atom clamped to [0, n_mol)
   return b;
 }
 
@@ -51,6 +52,7 @@ void nlist_carve(NlistBuffers& b, char* p, int n_atoms, int n_mol) {
   b.sorted = (int*)take((size_t)n_atoms * sizeof(int));
   b.xs = (float4*)take((size_t)n_atoms * sizeof(float4));
   b.sorted_tmp_xq = (void*)take((size_t)n_atoms * sizeof(float4));
+  b.mol_c = (int*)take((size_t)n_atoms * sizeof(int));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -63,7 +65,8 @@ void nlist_carve(NlistBuffers& b, char* p, int n_atoms, int n_mol) {
 __global__ __launch_bounds__(256) void mol_start_kernel(const int* __restrict__ mol_idx, const int* __restrict__ numbers,
                                                         int n_atoms, int n_mol, int* __restrict__ mol_start,
                                                         int* __restrict__ bad, const int* __restrict__ slot_of_z,
-                                                        int* __restrict__ aslot, unsigned long long* __restrict__ present_part) {
+                                                        int* __restrict__ aslot, unsigned long long* __restrict__ present_part,
+                                                        int* __restrict__ mol_c) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot_of_z) {  // (block-uniform)
     __shared__ unsigned long long s_mask;
@@ -85,8 +88,10 @@ __global__ __launch_bounds__(256) void mol_start_kernel(const int* __restrict__ 
   const int prev = (i == 0) ? -1 : min(max(mol_idx[i - 1], -1), n_mol - 1);
   const int raw = mol_idx[i];
   const int cur = min(max(raw, 0), n_mol - 1);
+  mol_c[i] = cur;  // every later kernel indexes per-molecule data through this clamped copy, never through the caller's array
   if (bad) {
     int f = (raw < 0 || raw >= n_mol) ? 2 : 0;
+    if (i > 0 && raw < mol_idx[i - 1]) f |= 4;  // not sorted: molecules must be contiguous
     if (numbers) {
       const int z = numbers[i];
       if (z < 0 || z > 63) f |= 1;
@@ -98,10 +103,10 @@ __global__ __launch_bounds__(256) void mol_start_kernel(const int* __restrict__ 
     for (int m = cur + 1; m <= n_mol; ++m) mol_start[m] = n_atoms;
 }
 
-int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start, const int* numbers, int* bad,
-                     const int* slot_of_z, int* aslot, unsigned long long* present_part) {
+int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start, int* mol_c, const int* numbers,
+                     int* bad, const int* slot_of_z, int* aslot, unsigned long long* present_part) {
   hipLaunchKernelGGL(mol_start_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, mol_idx, numbers, n_atoms, n_mol, mol_start,
-                     bad, (numbers && aslot) ? slot_of_z : nullptr, aslot, present_part);
+                     bad, (numbers && aslot) ? slot_of_z : nullptr, aslot, present_part, mol_c);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

@@ -122,8 +122,8 @@ class HipEngine:
 
     # ------------------------------------------------------------------------------------------
     def set_option(self, name: str, value: int) -> None:
-        """Engine switch for A/B and parity runs (include/aimnet_hip.h, aimnet_engine_set_option): "conv_mfma", "conv_cluster", "conv_xe", "split_max"
-        (process-wide), "p0_moments", "spatial_order", "overlap_coulomb"."""
+        """Engine switch for A/B and parity runs (include/aimnet_hip.h, aimnet_engine_set_option): "gemm_bf3", "conv_mfma", "conv_xe", "split_max",
+        "p0_moments", "spatial_order", "overlap_coulomb"."""
         _lib.check(self.lib.aimnet_engine_set_option(self._h, name.encode(), int(value)), "aimnet_engine_set_option")
         self._ws = None  # the workspace layout depends on the switches
 
@@ -159,7 +159,8 @@ class HipEngine:
         self.pending_status.clear()
         self.last_status = st[-1]
         if st[:, 6].any():
-            raise ValueError("HipEngine: invalid input in a deferred evaluation (atomic numbers outside [0, 63] or mol_idx out of range)")
+            raise ValueError("HipEngine: invalid input in a deferred evaluation (atomic numbers outside [0, 63], mol_idx out of range "
+                             "or not sorted)")
         grown = False
         if st[:, 2].any():
             self.max_nb = _round16(int(max(self.max_nb * 1.5, st[:, 0].max())))
@@ -331,6 +332,8 @@ class HipEngine:
                     what.append("atomic numbers outside [0, 63] (the embedding has 64 rows, core.py:49)")
                 if st[6] & 2:
                     what.append(f"mol_idx entries outside [0, {n_mol}) (n_mol is taken from the charge array)")
+                if st[6] & 4:
+                    what.append("mol_idx is not sorted (the atoms of a molecule must be contiguous)")
                 raise ValueError("HipEngine.eval: invalid input: " + " and ".join(what))
             retry = False
             if st[2]:

@@ -354,7 +354,7 @@ def main():
         fam = {k: v / 5 for k, v in eng.read_profile().items() if k != "evals"}
         eng.set_profiling(0)
         n_pairs = int(eng.debug_view("nb_cnt").sum().item())  # ordered pairs inside the 5 A cutoff
-        xe = os.environ.get("AIMNET_CONV_XE", "1") != "0" and n_atoms > int(os.environ.get("AIMNET_SPLIT_MAX", "1024"))
+        xe = os.environ.get("AIMNET_CONV_XE", "1") != "0" and n_atoms > int(os.environ.get("AIMNET_SPLIT_MAX", "1024"))  # engine defaults
         gather_form = "reverse-pair" if xe else "combined"
         # pass 0 in the reverse-pair form reads only the centre's own species-moment block of the pair (256 B)
         gather_bytes = (2 * (4096 + 256 + 16) + 16 + 256) if xe else (2 * 5376 + 512)

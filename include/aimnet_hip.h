@@ -128,7 +128,9 @@ typedef struct aimnet_outputs {
                               2 overflow flag rc list, 3 overflow flag LR list,
                               4 max neighbours found (D3 list), 5 overflow flag D3 list,
                               6 input sanity flags: bit 0 an atomic number outside [0, 63], bit 1 a mol_idx outside
-                                [0, n_mol) (both are clamped for memory safety; the results are then meaningless), 7 reserved */
+                                [0, n_mol), bit 2 mol_idx not sorted.  The first kernel writes clamped copies (atomic number
+                                slots, mol_idx) into the workspace and every later kernel indexes through those, so any device
+                                array is memory-safe; with a flag raised the results are meaningless.  7 reserved */
   float* spin_charges; /* [n_atoms] alpha - beta of an NSE model (aimnet2.py:103), or NULL; must be NULL for 1-channel models */
 } aimnet_outputs;
 
@@ -197,11 +199,13 @@ int aimnet_debug_gemm_bf3(int cfg, int epi, const float* A, int lda, const void*
 
 /* Engine switches for A/B and parity runs (all have an AIMNET_* environment twin read at create time):
  *   "conv_xe"       1 (default): reverse-pair form of the conv backward for systems above the split threshold, 0: combined form
+ *   "gemm_bf3"      1 (default): MLP GEMMs of batches above 256 rows with bf16x3-split operands on the bf16 matrix pipe
+ *                   (csrc/gemm_bf3.hip: fp32 == three bf16 planes exactly, six products, fp32 accumulation), 2: for every batch
+ *                   size, 0: the exact-fp32 MFMA kernels of csrc/gemm.hip everywhere
  *   "emb_bias"      1 (default): pass 0's first GEMM runs over the conv columns, the embedding block is a per-element bias table
- *   "conv_cluster"  1: conv backward of passes >= 1 for clusters of four centre atoms (csrc/conv_cluster.hip)
  *   "conv_mfma"     bit 0: conv forward, bit 1: conv backward on the v_mfma_f32_4x4x1_16B_f32 kernels (csrc/conv_mfma.hip)
  *                   instead of the packed-FMA VALU kernels (default 0; systems above the split threshold only)
- *   "split_max"     atoms up to which the 4-waves-per-atom "split" conv kernels are used (default 1024; PROCESS-wide; < 0 = default)
+ *   "split_max"     atoms up to which the 4-waves-per-atom "split" conv kernels are used (default 1024; per engine; < 0 = default)
  *   "p0_moments"    0: generic row-gather conv kernels in pass 0 instead of the element-moment forward / species-moment backward
  *   "overlap_coulomb" 1: Coulomb / DFT-D3 pair kernels on a second HIP stream (default 0: measured slower)
  *   "spatial_order" 0: conv kernels walk the atoms in input order instead of cell-list bin order */

@@ -22,10 +22,10 @@ def engines(synth_sd):
 
     spec = loader.synthetic_spec(0)
     valu, mfma = HipEngine(spec, "cuda:0"), HipEngine(spec, "cuda:0")
-    valu.set_option("split_max", 0)  # process-wide: both engines run the large-system kernels on every fixture
+    for e in (valu, mfma):
+        e.set_option("split_max", 0)  # per engine: both run the large-system kernels on every fixture
     mfma.set_option("conv_mfma", 3)
     yield valu, mfma
-    valu.set_option("split_max", -1)
 
 
 def test_taxol_and_batch(engines, oracle32, oracle64):

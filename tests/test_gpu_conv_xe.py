@@ -23,10 +23,10 @@ def engines(synth_sd):
     spec = loader.synthetic_spec(0)
     valu, xe = HipEngine(spec, "cuda:0"), HipEngine(spec, "cuda:0")
     valu.set_option("conv_xe", 0)  # the combined-adjoint kernel as the baseline
-    valu.set_option("split_max", 0)  # process-wide: both engines run the large-system kernels on every fixture
+    for e in (valu, xe):
+        e.set_option("split_max", 0)  # per engine: both run the large-system kernels on every fixture
     xe.set_option("conv_xe", 1)
     yield valu, xe
-    valu.set_option("split_max", -1)
 
 
 def test_taxol_and_batch(engines, oracle32, oracle64):
@@ -117,6 +117,7 @@ def test_pass0_element_moments_switch(synth_sd):
 
     on, off = HipEngine(loader.synthetic_spec(0), "cuda:0"), HipEngine(loader.synthetic_spec(0), "cuda:0")
     on.set_option("split_max", 0)
+    off.set_option("split_max", 0)
     off.set_option("p0_moments", 0)
     try:
         for name, coul, kw in (("taxol", "simple", {}), ("pbc96_dsf15", "dsf", dict(dsf_rc=15.0, dsf_alpha=0.2))):

@@ -318,3 +318,30 @@ def test_nse_with_dftd3_and_dsf_in_one_pair_pass(hip_engine_nse, oracle32_nse):
     ref = O.evaluate(oracle32_nse, g["pbc_coord"], g["pbc_numbers"], 1.0, cell=g["pbc_cell"], coulomb="dsf", dsf_rc=9.0, stress=True,
                      mult=2.0, dftd3=dict(par, **tables))
     _compare_nse(res, ref, 96, "nse pbc96 + d3")
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_garbage_mol_idx_on_the_device_is_memory_safe_and_reported(hip_engine, periodic):
+    """A device-resident mol_idx the host never looked at - interior entries far out of range, negative, unsorted - must not be
+    used as an index anywhere: the first kernel writes a clamped copy into the workspace and every other kernel reads that
+    (status[6] bits 1 / 2 -> ValueError); the engine keeps working afterwards."""
+    g = golden("pbc2x96_dsf9" if periodic else "batch5")
+    dev = hip_engine.device
+    mol = torch.from_numpy(g["mol_idx"]).to(dev).to(torch.int32)
+    n_mol = int(mol.max().item()) + 1
+    bad = mol.clone()
+    bad[7], bad[len(bad) // 2], bad[-3] = 2_000_000_000, -5, 123_456
+    cell = torch.from_numpy(g["cell"]).to(dev) if periodic else None
+    args = (torch.from_numpy(g["coord"]).to(dev), torch.from_numpy(g["numbers"]).to(dev))
+    charge = torch.from_numpy(np.atleast_1d(g["charge"]).astype(np.float32)).to(dev)
+    kw = dict(cell=cell, forces=True, stress=periodic, coulomb="dsf" if periodic else "simple")
+    if periodic:
+        kw["dsf_rc"] = 9.0
+    with pytest.raises(ValueError, match="mol_idx"):
+        hip_engine.eval(*args, bad, charge, **kw)
+    unsorted = mol.flip(0).contiguous()
+    if n_mol > 1:
+        with pytest.raises(ValueError, match="not sorted"):
+            hip_engine.eval(*args, unsorted, charge, **kw)
+    res = hip_engine.eval(*args, mol, charge, **kw)  # still healthy
+    assert np.abs(res["energy"].cpu().numpy() - g["energy"]).max() < 1e-3

@@ -168,8 +168,10 @@ int upload_layer(aimnet_engine* e, const float* w, const float* b, int n_in, int
     // the last 40 % of the k-steps a launch runs over accumulate with the opposite sign (gemm_bf3.hip, "Accumulation bias")
     std::vector<unsigned short> s3(wp.size() * 3);
     const int kb0 = k0_fwd / 32, nkf = L->k_in / 32 - kb0, nkb = L->k_out / 32;
-    L->neg_w3 = kb0 + (6 * nkf + 5) / 10;
-    L->neg_wt3 = (6 * nkb + 5) / 10;
+    const char* fenv = getenv("AIMNET_BF3_FLIP");  // experiment knob: per mille of the k-steps in the first phase (default 600)
+    const int pm = fenv ? atoi(fenv) : 600;
+    L->neg_w3 = kb0 + (pm * nkf + 500) / 1000;
+    L->neg_wt3 = (pm * nkb + 500) / 1000;
     split_bf3_host(wp.data(), L->k_out, L->k_in, s3.data(), L->neg_w3);
     if ((rc = dev_upload(e, s3.data(), s3.size(), &L->w3))) return rc;
     split_bf3_host(wtp.data(), L->k_in, L->k_out, s3.data(), L->neg_wt3);

@@ -266,7 +266,7 @@ __device__ unsigned long long g_bf3_stamps[1024];
 // 2k+2 on), SA two (A(k+1) is written in segments 2k / 2k+1, read in 2k+2 / 2k+3).  Every wave issues, per L segment, its share
 // of the weight DMA first and its activation loads last; the memory counter retires in order, so each wait is "at most n younger
 // operations outstanding" with a constant n.
-template <int EPI, int SM, int SN, int WN>
+template <int EPI, int SM, int SN, int WN, int QC>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void gemm_bf3_kernel(
     const float* __restrict__ A, int lda, const unsigned short* __restrict__ Bt, int ldb, int M, int N, int K,
     const float* __restrict__ bias, float* __restrict__ C, float* __restrict__ D, int ldc, const int* __restrict__ brow,
@@ -330,11 +330,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
   };
   static_assert(NQ <= 3, "two sets of three activation quads (v232..v255)");
   // set SET (0 / 1) <- the quads of k-step kt
-  auto load_a = [&](auto set_c, int kt) __attribute__((always_inline)) {
-    constexpr int SET = decltype(set_c)::value;
-    AQuad<SET * 3 + 0>::load(asrc[0] + kt * 32);
-    if constexpr (NQ > 1) AQuad<SET * 3 + 1>::load(asrc[NQ > 1 ? 1 : 0] + kt * 32);
-    if constexpr (NQ > 2) AQuad<SET * 3 + 2>::load(asrc[NQ > 2 ? 2 : 0] + kt * 32);
+  // quads [Q0, Q1) of set SET (0 / 1) <- k-step kt
+  static_assert(QC >= 0 && QC <= NQ, "quads split in the compute segment");
+  constexpr int NL = NQ - QC;  // quads split in the load segment
+  auto load_q = [&](auto set_c, auto q0_c, auto q1_c, int kt) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value, Q0 = decltype(q0_c)::value, Q1 = decltype(q1_c)::value;
+    if constexpr (Q0 <= 0 && 0 < Q1) AQuad<SET * 3 + 0>::load(asrc[0] + kt * 32);
+    if constexpr (Q0 <= 1 && 1 < Q1) AQuad<SET * 3 + 1>::load(asrc[NQ > 1 ? 1 : 0] + kt * 32);
+    if constexpr (Q0 <= 2 && 2 < Q1) AQuad<SET * 3 + 2>::load(asrc[NQ > 2 ? 2 : 0] + kt * 32);
   };
   auto split_q = [&](auto idx_c, unsigned dst) __attribute__((always_inline)) {
     using Q = AQuad<decltype(idx_c)::value>;
@@ -350,12 +353,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
     lds_write8<64>(dst, a1, b1);
     lds_write8<128>(dst, a2, b2);
   };
-  auto split_a = [&](auto set_c, unsigned buf_off) __attribute__((always_inline)) {
-    constexpr int SET = decltype(set_c)::value;
-    split_q(std::integral_constant<int, SET * 3 + 0>{}, adst[0] + buf_off);
-    if constexpr (NQ > 1) split_q(std::integral_constant<int, SET * 3 + 1>{}, adst[NQ > 1 ? 1 : 0] + buf_off);
-    if constexpr (NQ > 2) split_q(std::integral_constant<int, SET * 3 + 2>{}, adst[NQ > 2 ? 2 : 0] + buf_off);
+  auto split_r = [&](auto set_c, auto q0_c, auto q1_c, unsigned buf_off) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value, Q0 = decltype(q0_c)::value, Q1 = decltype(q1_c)::value;
+    if constexpr (Q0 <= 0 && 0 < Q1) split_q(std::integral_constant<int, SET * 3 + 0>{}, adst[0] + buf_off);
+    if constexpr (Q0 <= 1 && 1 < Q1) split_q(std::integral_constant<int, SET * 3 + 1>{}, adst[NQ > 1 ? 1 : 0] + buf_off);
+    if constexpr (Q0 <= 2 && 2 < Q1) split_q(std::integral_constant<int, SET * 3 + 2>{}, adst[NQ > 2 ? 2 : 0] + buf_off);
   };
+  using QL = std::integral_constant<int, NL>;  // quads [0, NL): load segment; [NL, NQ): compute segment
+  using QE = std::integral_constant<int, NQ>;
 
   // fragment addresses: row r, plane P, k-chunk c = lane >> 4 -> r * 192 + P * 64 + (c ^ swz(r)) * 16
   const int l16 = lane & 15, lc = lane >> 4;
@@ -372,16 +377,29 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
   // unconditional: a conditional asm load makes the compiler merge "loaded" and "not loaded" registers with copies placed right
   // behind the load, i.e. before the data has arrived.
   auto kc = [&](int k) __attribute__((always_inline)) { return min(k, nk - 1); };
-  // ---- prologue.  VMEM issue order of a wave in the steady state: ... B(j+1), A(j+2) [L(j-1)], B(j+2), A(j+3) [L(j)] ...; the
-  // prologue continues that pattern backwards so that the wait counts below hold from step 0 on.
+  // ---- prologue.  VMEM issue order of a wave in the steady state (g = group, A_L / A_C = the quads split in the load / compute
+  // segment): ... B(j+1), A_L(j+2) [L(j-1)], A_C(j+2+g) [C(j-1)], B(j+2), A_L(j+3) [L(j)], A_C(j+3+g) [C(j)] ...; the prologue
+  // continues that pattern backwards so that the constant wait counts hold from step 0 on.
+  // Group 1 splits its compute-segment quads one step further ahead (its C(j) runs beside group 0's L(j+1), which reads step
+  // j+1): A_C(j+2) in C(j), hence A_C(1) here.
   dma_b(0, 0);
-  load_a(I0{}, 0);
-  load_a(I1{}, kc(1));
-  wait_vm<NQ>();  // A(0) (and with it B(0)) has landed
+  load_q(I0{}, I0{}, QE{}, 0);
+  if (QC > 0 && late) load_q(I1{}, QL{}, QE{}, kc(1));
+  wait_vm<0>();
   __builtin_amdgcn_sched_barrier(0);
-  split_a(I0{}, 0);  // SA[0]
-  dma_b(1, kc(1));
-  load_a(I0{}, kc(2));
+  split_r(I0{}, I0{}, QE{}, 0);  // SA[0]
+  if (QC > 0 && late) split_r(I1{}, QL{}, QE{}, SA_BYTES);
+  load_q(I1{}, I0{}, QL{}, kc(1));                  // "L(-2)": A_L(1)
+  if (QC > 0) {                                     // "C(-2)": A_C(1 + g)
+    if (!late) load_q(I1{}, QL{}, QE{}, kc(1));
+    else load_q(I0{}, QL{}, QE{}, kc(2));
+  }
+  dma_b(1, kc(1));                                  // "L(-1)": B(1), A_L(2)
+  load_q(I0{}, I0{}, QL{}, kc(2));
+  if (QC > 0) {                                     // "C(-1)": A_C(2 + g)
+    if (!late) load_q(I0{}, QL{}, QE{}, kc(2));
+    else load_q(I1{}, QL{}, QE{}, kc(3));
+  }
   wait_lgkm<0>();
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();  // SA[0] and weight stage 0 complete (every wave waited for its B(0) pieces above)
@@ -407,10 +425,12 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
 #define TSF()
 #endif
   bf16x8 fa[SM][3], fb[SN][3];
-  // L(j): fragments of step j into registers; weight DMA of step j+2 into the ring stage of step j-1; split of A(j+1) (set
-  // (j+1) & 1, loaded in L(j-2)) into SA[(j+1) & 1], whose last readers passed two barriers ago; loads of A(j+3) into the same set.
-  // The split is vector work that the matrix pipe does not hide (measured: +450 cycles on a compute segment wherever it is
-  // placed among the MFMAs), so it sits in the load segment, which is otherwise 600 of the partner's 1 150 cycles long.
+  // L(j): fragments of step j into registers; weight DMA of step j+2 into the ring stage of step j-1; split of the first NL quads
+  // of A(j+1) (set (j+1) & 1, loaded in L(j-2)) into SA[(j+1) & 1], whose last readers passed two barriers ago; loads of the same
+  // quads of A(j+3) into the same registers.
+  // Where the split runs: vector work beside matrix work is slow on this part - the same 75 instructions cost ~450 cycles
+  // among the wave's own MFMAs and ~950 beside the partner's - so the remaining QC quads are split in the compute segment, which
+  // balances L (600 + 320 per quad) against C (1 100 + 150 per quad).
   auto seg_load = [&](int j, int st, auto par_c) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_c)::value;
     using NPAR = std::integral_constant<int, PAR ^ 1>;
@@ -424,26 +444,31 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
     TSF();
     dma_b(st == 0 ? 2 : st - 1, kc(j + 2));
     TSF();
-    wait_vm<2 * NPB + NQ>();  // A(j+1); younger: B(j+1), A(j+2), B(j+2)
-    __builtin_amdgcn_sched_barrier(0);
-    TSF();
-    split_a(NPAR{}, (PAR ^ 1) * SA_BYTES);
-    TSF();
-    load_a(NPAR{}, kc(j + 3));
-    wait_vm<2 * NQ + NPB>();  // this wave's pieces of weight stage j+1; younger: A(j+2), B(j+2), A(j+3)
-    wait_lgkm<0>();           // fragments in registers, split planes written
+    if constexpr (NL > 0) {
+      wait_vm<2 * NPB + NL + 2 * QC>();  // A_L(j+1); younger: A_C(j+1+g), B(j+1), A_L(j+2), A_C(j+2+g), B(j+2)
+      __builtin_amdgcn_sched_barrier(0);
+      TSF();
+      split_r(NPAR{}, I0{}, QL{}, (PAR ^ 1) * SA_BYTES);
+      TSF();
+      load_q(NPAR{}, I0{}, QL{}, kc(j + 3));
+    }
+    wait_vm<2 * NL + QC + NPB>();  // this wave's pieces of weight stage j+1; younger: A_L(j+2), A_C(j+2+g), B(j+2), A_L(j+3)
+    wait_lgkm<0>();                // fragments in registers, split planes written
     __builtin_amdgcn_sched_barrier(0);
     TSF();
   };
-  // C(j): the 6 x SM x SN matrix instructions of step j, registers only.  At step kneg the sign of the accumulators flips: the
-  // weight blocks from there on are stored negated (see the note on the accumulation bias in front of the kernel)
-  auto seg_compute = [&](int j) __attribute__((always_inline)) {
+  // C(j): the 6 x SM x SN matrix instructions of step j on registers, and among them the split of the last QC quads of A(m),
+  // m = j + 1 + g (set m & 1 = MPAR), into SA[m & 1], followed by the loads of the same quads of A(m + 2).  At step kneg the sign
+  // of the accumulators flips: the weight blocks from there on are stored negated ("Accumulation bias" above).
+  auto seg_compute = [&](int j, int m, auto mpar_c) __attribute__((always_inline)) {
+    constexpr int MPAR = decltype(mpar_c)::value;
     if (j == kneg && j > 0) {
 #pragma unroll
       for (int i = 0; i < SM; ++i)
 #pragma unroll
         for (int jj = 0; jj < SN; ++jj) acc[i][jj] = -acc[i][jj];
     }
+    if constexpr (QC > 0) wait_vm<2 * NPB + 2 * NL + QC>();  // A_C(m); younger: B(j+1), A_L(j+2), A_C(m+1), B(j+2), A_L(j+3)
     __builtin_amdgcn_sched_barrier(0);
 #define AIMNET_BF3_PRODUCT(PA, PB)                                                                              \
   _Pragma("unroll") for (int i = 0; i < SM; ++i) _Pragma("unroll") for (int jj = 0; jj < SN; ++jj) acc[i][jj] = \
@@ -452,9 +477,21 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
     AIMNET_BF3_PRODUCT(0, 1)
     AIMNET_BF3_PRODUCT(1, 0)
     AIMNET_BF3_PRODUCT(0, 2)
+    if constexpr (QC > 0) split_r(mpar_c, QL{}, QE{}, MPAR * SA_BYTES);
     AIMNET_BF3_PRODUCT(2, 0)
     AIMNET_BF3_PRODUCT(0, 0)
 #undef AIMNET_BF3_PRODUCT
+    if constexpr (QC > 0) {
+      // one matrix instruction, then up to two vector instructions of the split in its shadow
+#pragma unroll
+      for (int t = 0; t < 6 * SM * SN; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_q(mpar_c, QL{}, QE{}, kc(m + 2));
+      wait_lgkm<0>();  // the split planes are in LDS before this wave passes the barrier
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
   auto bar = [&]() __attribute__((always_inline)) {
@@ -463,32 +500,33 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
     __builtin_amdgcn_sched_barrier(0);
     TS();
   };
-  // the two groups run the same step sequence, group 1 one barrier later
-  auto run = [&]() __attribute__((always_inline)) {
+  // the two groups run the same step sequence, group 1 one barrier later; m = j + 1 + g: its parity is fixed per code path
+  auto run = [&](auto g_c) __attribute__((always_inline)) {
+    constexpr int G = decltype(g_c)::value;
     int st = 0, j = 0;
     for (; j + 1 < nk; j += 2) {
       seg_load(j, st, I0{});
       bar();
-      seg_compute(j);
+      seg_compute(j, j + 1 + G, std::integral_constant<int, (1 + G) & 1>{});
       st = st == 2 ? 0 : st + 1;
       bar();
       seg_load(j + 1, st, I1{});
       bar();
-      seg_compute(j + 1);
+      seg_compute(j + 1, j + 2 + G, std::integral_constant<int, G & 1>{});
       st = st == 2 ? 0 : st + 1;
       if (j + 2 < nk) bar();
     }
     if (j < nk) {  // odd number of steps
       seg_load(j, st, I0{});
       bar();
-      seg_compute(j);
+      seg_compute(j, j + 1 + G, std::integral_constant<int, (1 + G) & 1>{});
     }
   };
   if (late) {
     bar();
-    run();
+    run(I1{});
   } else {
-    run();
+    run(I0{});
     bar();  // group 0 has 2 nk segments, group 1 an empty one in front: both pass 2 nk barriers
   }
   wait_vm<0>();  // the clamped look-ahead of the last steps is still in flight; the wave must not end (LDS released) under its DMA
@@ -533,7 +571,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
   }
 }
 
-template <int SM, int SN, int WN>
+template <int SM, int SN, int WN, int QC>
 static int launch_bf3(hipStream_t stream, int epi, const float* A, int lda, const unsigned short* Bt, int ldb, int M, int N, int K,
                       const float* bias, float* C, float* D, int ldc, const int* brow, int ldbias, int kneg) {
   constexpr int WM = 8 / WN, TM = 16 * SM * WM, TN = 16 * SN * WN;
@@ -545,9 +583,9 @@ static int launch_bf3(hipStream_t stream, int epi, const float* A, int lda, cons
   {                                                                                                                   \
     static PerDeviceOnce once;                                                                                        \
     if (once.first())                                                                                                 \
-      AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf3_kernel<E, SM, SN, WN>,                     \
+      AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf3_kernel<E, SM, SN, WN, QC>,                     \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                  \
-    hipLaunchKernelGGL((gemm_bf3_kernel<E, SM, SN, WN>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, \
+    hipLaunchKernelGGL((gemm_bf3_kernel<E, SM, SN, WN, QC>), grid, block, lds, stream, A, lda, Bt, ldb, M, N, K, \
                        bias, C, D, ldc, brow, ldbias, kneg);                                                          \
   }
   switch (epi) {
@@ -599,8 +637,9 @@ int launch_gemm_bf3_cfg(hipStream_t stream, int cfg, int epi, const float* A, in
   if (cfg == 0) cfg = g_bf3_force_tile;
   if (cfg == 0) cfg = choose_bf3_tile(M, N);
   switch (cfg) {
-#define AIMNET_BF3_CASE(ID, SM_, SN_, WN_) \
-    case ID: return launch_bf3<SM_, SN_, WN_>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias, kneg);
+#define AIMNET_BF3_CASE(ID, SM_, SN_, WN_)                                                                                        \
+    case ID: return launch_bf3<SM_, SN_, WN_, 1>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias, kneg);      \
+    case 1000 + ID: return launch_bf3<SM_, SN_, WN_, 0>(stream, epi, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias, kneg);
     AIMNET_BF3_CASE(452, 5, 2, 4)  // 160 x 128 (2 x 4 waves of 80 x 32; 132 KiB of LDS)
     AIMNET_BF3_CASE(442, 4, 2, 4)  // 128 x 128
     AIMNET_BF3_CASE(432, 3, 2, 4)  //  96 x 128

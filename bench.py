@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pbc10k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-f32", action="store_true", help="skip the extra pass with the exact-fp32 GEMM kernels (profiling runs)")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU-oracle timing (16 threads + 1 thread); below 5 s the "
                     "single all-host-threads evaluation (51 s on a 256-thread box) is skipped")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-family time table to stderr")
@@ -363,7 +364,7 @@ def main():
                   file=sys.stderr)
 
     exact = None
-    if world == 1:  # the exact-fp32 MFMA kernels on the same workload (fallback record), after the timed region
+    if world == 1 and not args.no_exact_f32:  # the exact-fp32 MFMA kernels on the same workload (fallback record), after the timed region
         eng.set_option("gemm_bf3", 0)
         r = timed_run(args.workload, args.steps, 2)
         g_ms = r["prof"]["gemm"] / max(1.0, r["prof"]["evals"])

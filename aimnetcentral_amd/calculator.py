@@ -442,7 +442,7 @@ class AIMNet2Calculator:
                         p = p[0]
                 if p.ndim == 1 and p.shape != (3,):
                     raise ValueError("pbc must have shape (3,) or (B, 3)")
-                pbc3 = tuple(bool(x) for x in p) if p.ndim == 1 else pbc.to(dtype=pbc.dtype)
+                pbc3 = tuple(bool(x) for x in p) if p.ndim == 1 else pbc  # per-system flags: the engine uploads them as int32
             res = self.engine.eval(
                 coord_f, numbers_f, mol_idx, self._engine_charge(charge, d.get("mult")), cell=cell, pbc=pbc3, forces=bool(forces),
                 stress=bool(stress),

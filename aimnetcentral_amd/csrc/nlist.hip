@@ -257,8 +257,15 @@ int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_ato
   if (cell != nullptr && bin_width > 0.0f && n_mol <= 4096) {
     sys = (NlistSystem*)b.sys;
     const int max_bins = n_atoms + 8 * n_mol + 8;
+    // the single setup block also zeroes the bin counters - fine for the 10^4 entries of a 10 k-atom system (it saves a launch),
+    // a serial tail on the critical path at 10^6: above 64 k counters a memset does it at full width
+    int n_zero = max_bins + 1;
+    if (n_zero > 65536) {
+      AIMNET_HIP_CHECK(hipMemsetAsync(b.bin_count, 0, (size_t)n_zero * sizeof(int), s));
+      n_zero = 0;
+    }
     hipLaunchKernelGGL(cell_bins_setup_kernel, dim3(1), dim3(256), 0, s, cell, n_cell, n_mol, pbc[0], pbc[1], pbc[2], pbc_sys, sys,
-                       b.mol_start, bin_width, b.bin_count, max_bins + 1);
+                       b.mol_start, bin_width, b.bin_count, n_zero);
     AIMNET_LAUNCH_CHECK();
     hipLaunchKernelGGL(wrap_bin_count_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, coord, mol_idx, n_atoms, sys, b.xw,
                        b.atom_bin, b.bin_count, b.bin_fill);

@@ -50,11 +50,12 @@ def _gather_buffers(device, dtype, world: int, nmax: int):
     return _GATHER_BUFFERS[key]
 
 
-def all_gather_energies(energy_local, frames_per_rank: list[int], group=None):
+def all_gather_energies(energy_local, frames_per_rank: list[int], group=None, reuse_buffer: bool = False):
     """All-gather per-frame energies (fp64) from every rank: returns a tensor [sum(frames_per_rank)]
     in global frame order.  Ragged counts are padded to the maximum (one fixed-size collective).  The padded send buffer
-    and the receive buffer are allocated once per (device, world, size) and reused; when every rank holds the same number of
-    frames (the bench's weak-scaling layout) the result is a view of the receive buffer - valid until the next call."""
+    and the receive buffer are allocated once per (device, world, size) and reused.  The result is a fresh tensor (a copy of a
+    few bytes per frame) unless `reuse_buffer=True`, which hands out the cached receive buffer itself - valid only until the
+    next call (a per-step loop that consumes the energies at once)."""
     import torch
     import torch.distributed as dist
 
@@ -64,7 +65,7 @@ def all_gather_energies(energy_local, frames_per_rank: list[int], group=None):
     buf[: energy_local.shape[0]] = energy_local
     dist.all_gather_into_tensor(out, buf, group=group)
     if all(f == nmax for f in frames_per_rank):
-        return out
+        return out if reuse_buffer else out.clone()
     v = out.view(world, nmax)
     return torch.cat([v[r, : frames_per_rank[r]] for r in range(world)])
 

@@ -296,7 +296,7 @@ def main():
         def step(sync=True):
             e = local_step(sync)
             if distributed:
-                return adist.all_gather_energies(e.to(comm_dev), [frames] * world)
+                return adist.all_gather_energies(e.to(comm_dev), [frames] * world, reuse_buffer=True)
             return e
 
         for _ in range(max(1, warmup)):  # at least one checked evaluation: it settles the neighbour-row capacities

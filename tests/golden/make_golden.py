@@ -177,6 +177,66 @@ def make_cold(path: str, meta_common: dict) -> None:
                         energy=out["energy"], forces=out["forces"], charges=out["charges"], **meta_common)
 
 
+def make_relaxed256(path: str, meta_common: dict) -> None:
+    """G12: a "cold" stand-in for BASELINE config 2 (256 organics of 20-60 atoms, one batch): 16 fragments of 20-60 atoms cut from
+    taxol are relaxed together on the synthetic model's own surface (fp64 oracle, steepest descent with the capped step of the
+    cold24 fixture) until max|F| < 0.5 eV/A, the relaxed ones are then placed 256 times in turn with random rigid rotations and
+    translations (different fp32 inputs, the same physics), and the unmodified reference evaluates the 256 molecules as one flat batch.
+    The random geometries of the full-size config-2 test have contacts of 0.9 A and |F| up to 800 eV/A, which puts the fp32 energy
+    noise of ANY implementation 100-1000x above the reference's 1e-5 eV gate (and they do not relax: the synthetic surface is too
+    stiff for any affordable number of steps); on this set the un-widened gate max(1e-5, 5e-7 n) eV has to hold for every molecule."""
+    from oracle import aimnet2_oracle as O
+
+    coord, numbers = read_taxol()
+    rng = np.random.default_rng(256)
+    sizes = np.linspace(20, 60, 16).round().astype(int)
+    xs, zs, ms = [], [], []
+    for k, n in enumerate(sizes):
+        s0 = int(rng.integers(0, len(numbers) - n + 1))
+        xs.append(coord[s0:s0 + n].astype(np.float64))
+        zs.append(numbers[s0:s0 + n])
+        ms.append(np.full(n, k, dtype=np.int64))
+    x, z, mol = np.concatenate(xs), np.concatenate(zs), np.concatenate(ms)
+    q = np.zeros(16, dtype=np.float32)
+    starts = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    om = O.OracleModel(synth.synthetic_state_dict(SEED), torch.float64)
+    for it in range(int(os.environ.get("RELAX_STEPS", "2500"))):
+        r = O.evaluate(om, x, z, q.astype(np.float64), mol, coulomb="simple")
+        f = r["forces"].astype(np.float64)
+        fm = np.maximum.reduceat(np.abs(f).max(axis=1), starts)
+        if it % 200 == 0:
+            print("relax step %4d: max|F| %.3f, fragments above 0.5 eV/A: %d" % (it, fm.max(), (fm > 0.5).sum()), flush=True)
+        if fm.max() < 0.5:
+            break
+        scale = np.where(fm > 0.5, np.minimum(0.02 / np.maximum(fm, 1e-12), 2e-3), 0.0)[mol]  # converged fragments rest
+        x = x + f * scale[:, None]
+    ok = np.nonzero(fm < 0.5)[0]  # a cut through taxol can leave a fragment that does not settle: only relaxed ones are used
+    print("relaxed: %d steps, %d of 16 fragments below 0.5 eV/A (sizes %s)" % (it, len(ok), sizes[ok].tolist()))
+    assert len(ok) >= 12 and sizes[ok].min() <= 25 and sizes[ok].max() >= 55
+    cs, zz, mm = [], [], []
+    for rep in range(16):
+        for slot in range(16):
+            k = int(ok[(rep * 16 + slot) % len(ok)])
+            n = int(sizes[k])
+            xk = x[starts[k]:starts[k] + n]
+            a = rng.standard_normal((3, 3))
+            qm, rm = np.linalg.qr(a)
+            qm = qm * np.sign(np.diag(rm))
+            if np.linalg.det(qm) < 0:
+                qm[:, 0] = -qm[:, 0]
+            cs.append((xk - xk.mean(0)) @ qm.T + rng.uniform(-20.0, 20.0, 3))
+            zz.append(z[starts[k]:starts[k] + n])
+            mm.append(np.full(n, rep * 16 + slot, dtype=np.int64))
+    c256, z256, m256 = np.concatenate(cs).astype(np.float32), np.concatenate(zz), np.concatenate(mm)
+    data = {"coord": c256, "numbers": z256, "mol_idx": m256, "charge": np.zeros(256, dtype=np.float32)}
+    calc = make_calc(path)
+    out = to_np(calc(data, forces=True))
+    print("relaxed256 reference: %d atoms, max|F| %.3f eV/A, E range %.3f .. %.3f" % (len(z256), np.abs(out["forces"]).max(), out["energy"].min(),
+                                                                                    out["energy"].max()))
+    np.savez_compressed(os.path.join(HERE, "relaxed256.npz"), coord=c256, numbers=z256.astype(np.int16), mol_idx=m256.astype(np.int16),
+                        charge=data["charge"], energy=out["energy"], forces=out["forces"], charges=out["charges"], **meta_common)
+
+
 D3_PARAMS = {"s8": 0.3908, "a1": 0.566, "a2": 3.128, "s6": 1.0}  # wB97M-D3(BJ), the shipped aimnet2 family (docs/models)
 D3_ZMAX = 17  # fixture keeps the reference table rows/columns for Z <= 17 (H..Cl)
 
@@ -296,6 +356,9 @@ def main() -> None:
         return
     if "--only-cold" in sys.argv:
         make_cold(path, meta_common)
+        return
+    if "--only-relaxed256" in sys.argv:
+        make_relaxed256(path, meta_common)
         return
 
     # ---- G1: taxol, config 1 -------------------------------------------------------------

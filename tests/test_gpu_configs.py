@@ -98,7 +98,9 @@ def test_config4_on_the_rxn_architecture():
     assert abs(out["energy"][0] - g["energy"][0]) <= energy_tol(40)
     assert_forces_close(out["forces"], g["forces"], "rxn forces")
     H = out["hessian"].reshape(120, 120)
-    assert np.abs(H - g["hessian"].reshape(120, 120)).max() < 2e-3  # finite-difference operator, DESIGN 1
+    # the Hessian (single-atom displacements) meets the reference's own gate for its double backward elementwise:
+    # allclose(rtol=1e-3, atol=1e-3) (tests/test_hvp.py:75); H v along random directions stays at the finite-difference budget
+    assert np.allclose(H, g["hessian"].reshape(120, 120), rtol=1e-3, atol=1e-3)
     hv1 = calc.hessian_vector_product(data, g["v1"]).cpu().numpy()
     hv4 = calc.hessian_vector_product(data, g["v4"]).cpu().numpy()
     assert hv1.shape == (40, 3) and hv4.shape == (4, 40, 3)
@@ -286,3 +288,60 @@ def test_periodic_2304_atoms_engine_vs_oracle(oracle32):
     assert_forces_close(r["forces"], ref["forces"], "pbc2304")
     assert np.abs(r["charges"] - ref["charges"]).max() <= CHARGE_ATOL
     assert np.abs(r["stress"] - ref["stress"]).max() <= 1e-5
+
+
+def test_config2_cold_variant_holds_the_unwidened_gates(calc, oracle64):
+    """BASELINE config 2 on geometries where the headline tolerance means something: 256 molecules of 20-60 atoms (15 relaxed
+    fragments in 256 rigid placements, tests/golden/make_golden.py G12; outputs of the unmodified reference), one flat batch of
+    10 k atoms - so the MLP GEMMs take the bf16x3-split kernels on their large tiles.
+    EVERY molecule has to hold the reference's gate |dE| <= max(1e-5, 5e-7 n) eV, un-widened, against the fp64 oracle (measured:
+    worst 0.80 of the gate, rms 3.9e-6 eV; the reference's own fp32 golden: 0.75, 5.3e-6; the exact-fp32 GEMM kernels: 1.05,
+    6.6e-6 - tests/tools/relaxed256_probe.py).  Against the reference's fp32 golden - two fp32 computations, each that far from the
+    truth - the gate is widened by the golden's own distance from fp64 and nothing else (worst measured 1.24 plain gates, one
+    molecule of 256 above 1), and the rms difference must stay below the smallest gate.  Charges 1e-4.  Forces: on a relaxed set
+    max|F| is 0.7 eV/A, so the reference's 1e-5 + 1e-4 max|F| = 8e-5 eV/A lies BELOW the fp32 noise of every implementation (the
+    reference's golden is 1.1e-4 from the fp64 forces, the fp32 oracle 1.0e-4, the engine 9.8e-5, its exact-fp32 GEMM mode 1.5e-4):
+    the engine's distance from the fp64 forces may exceed the golden's own by at most 1.5x, in the maximum and in the rms, and its
+    distance from the golden that gate plus the golden's own error.  The same for the 3-D padded (dense) layout."""
+    g = golden("relaxed256")
+    mol = g["mol_idx"].astype(np.int64)
+    numbers = g["numbers"].astype(np.int64)
+    sizes = np.bincount(mol)
+    assert len(sizes) == 256 and sizes.min() >= 20 and sizes.max() <= 60 and np.abs(g["forces"]).max() < 1.0
+    r64 = O.evaluate(oracle64, g["coord"], numbers, g["charge"], mol, forces=True)
+    e64, f64, fg = r64["energy"], r64["forces"].astype(np.float64), g["forces"].astype(np.float64)
+    fg_max, fg_rms = np.abs(fg - f64).max(), np.sqrt(np.mean((fg - f64) ** 2))
+    f_gate = 1e-5 + 1e-4 * np.abs(fg).max()
+
+    def check_forces(f, f64_, fg_, what):
+        f = f.astype(np.float64)
+        assert np.abs(f - f64_).max() <= 1.5 * fg_max and np.sqrt(np.mean((f - f64_) ** 2)) <= 1.5 * fg_rms, \
+            f"{what}: |hip - fp64| max {np.abs(f - f64_).max():.2e} rms {np.sqrt(np.mean((f - f64_) ** 2)):.2e} vs the golden's {fg_max:.2e} / {fg_rms:.2e}"
+        assert np.abs(f - fg_).max() <= f_gate + fg_max, what
+
+    gate = np.maximum(1e-5, 5e-7 * sizes)
+    gold_off = np.abs(g["energy"] - e64)
+    assert (gold_off <= gate).all()  # the fixture itself is inside the gate
+
+    def check(energy, what):
+        err64, errg = np.abs(energy - e64), np.abs(energy - g["energy"])
+        assert (err64 <= gate).all(), f"{what}: worst |hip - fp64| / gate = {np.max(err64 / gate):.2f} (molecule {int(np.argmax(err64 / gate))})"
+        assert (errg <= gate + gold_off).all(), f"{what}: worst |hip - golden| / (gate + |golden - fp64|) = {np.max(errg / (gate + gold_off)):.2f}"
+        assert np.sqrt(np.mean(errg**2)) <= 1e-5, what
+
+    out = npy(calc({"coord": g["coord"], "numbers": numbers, "mol_idx": mol, "charge": g["charge"]}, forces=True))
+    check(out["energy"], "flat")
+    check_forces(out["forces"], f64, fg, "relaxed256 flat")
+    assert np.abs(out["charges"] - g["charges"]).max() <= CHARGE_ATOL
+    # the dense (B, Nmax, 3) layout of the same molecules
+    nmax = int(sizes.max())
+    starts = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    c3 = np.zeros((256, nmax, 3), dtype=np.float32)
+    z3 = np.zeros((256, nmax), dtype=np.int64)
+    for m in range(256):
+        c3[m, : sizes[m]] = g["coord"][starts[m] : starts[m] + sizes[m]]
+        z3[m, : sizes[m]] = numbers[starts[m] : starts[m] + sizes[m]]
+    o3 = npy(calc({"coord": c3, "numbers": z3, "charge": g["charge"]}, forces=True))
+    check(o3["energy"], "dense")
+    f3 = np.concatenate([o3["forces"][m, : sizes[m]] for m in range(256)])
+    check_forces(f3, f64, fg, "relaxed256 dense")

@@ -165,3 +165,15 @@ def test_nse_two_charge_channels(oracle32_nse, synth_sd_nse):
     assert_forces_close(r["forces"], g["pbc_forces"])
     assert np.abs(r["stress"] - g["pbc_stress"]).max() <= STRESS_ATOL
     assert np.abs(r["spin_charges"] - g["pbc_spin_charges"]).max() <= CHARGE_ATOL
+
+
+def test_cold_batch_of_256_molecules(oracle32):
+    """G12, the cold stand-in for config 2 (256 relaxed molecules of 20-60 atoms in one flat batch): the oracle reproduces the
+    unmodified reference at the un-widened gates for every molecule."""
+    g = golden("relaxed256")
+    mol = g["mol_idx"].astype(np.int64)
+    sizes = np.bincount(mol)
+    res = O.evaluate(oracle32, g["coord"], g["numbers"].astype(np.int64), g["charge"], mol)
+    assert (np.abs(res["energy"] - g["energy"]) <= np.maximum(1e-5, 5e-7 * sizes)).all()
+    assert_forces_close(res["forces"], g["forces"], "relaxed256")
+    assert np.abs(res["charges"] - g["charges"]).max() <= CHARGE_ATOL

@@ -19,7 +19,7 @@ for name in ("hvp40", "hvp40_rxn"):
     q = torch.full((1,), float(g["charge"]), device=dev)
     ref = g["hv4"].reshape(K, n, 3)
     for order, (ks, ws) in ST.items():
-        for h in (2.5e-3, 5e-3, 1e-2, 2e-2, 4e-2):
+        for h in (2.5e-3, 5e-3, 7e-3, 1e-2, 1.4e-2, 2e-2, 4e-2):
             offs = torch.tensor([s * k for k in ks for s in (1.0, -1.0)], device=dev) * h
             wts = torch.tensor([s * w for w in ws for s in (1.0, -1.0)], device=dev) / h
             m = len(offs)
@@ -29,4 +29,6 @@ for name in ("hvp40", "hvp40_rxn"):
             f = res["forces"].view(K, m, n, 3)
             hv = -(f * wts.view(1, m, 1, 1)).sum(1) * scale.view(K, 1, 1)   # H v = -dF/dx . v
             err = np.abs(hv.cpu().numpy() - ref)
-            print(f"{name} order {order} h={h:7.4f}: max {err.max():.2e}  rms {np.sqrt((err**2).mean()):.2e}  (|Hv|max {np.abs(ref).max():.1f})")
+            viol = err - (1e-3 + 1e-3 * np.abs(ref))  # the reference's gate: allclose(rtol=1e-3, atol=1e-3), tests/test_hvp.py:75
+            print(f"{name} order {order} h={h:7.4f}: max {err.max():.2e}  rms {np.sqrt((err**2).mean()):.2e}  (|Hv|max {np.abs(ref).max():.1f})"
+                  f"  worst err-atol-rtol|ref| {viol.max():+.2e}  over the gate {(viol > 0).sum()}/{viol.size}")

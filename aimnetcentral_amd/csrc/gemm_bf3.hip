@@ -606,8 +606,8 @@ static int g_bf3_force_tile = 0;  // AIMNET_BF3_TILE forces one configuration (A
 
 struct Bf3Cand { int id, tm, tn; };
 // id = 100 * WN (waves across N; 8 / WN across M) + 10 * SM + SN; block tile (16 SM 8 / WN) x (16 SN WN)
-static const Bf3Cand kBf3Cands[] = {{452, 160, 128}, {224, 128, 128}, {432, 96, 128}, {422, 64, 128},
-                                    {223, 128, 96},  {851, 80, 128},  {234, 192, 128}};
+static const Bf3Cand kBf3Cands[] = {{452, 160, 128}, {224, 128, 128}, {432, 96, 128}, {422, 64, 128}, {223, 128, 96},
+                                    {851, 80, 128},  {234, 192, 128}, {871, 112, 128}, {861, 96, 128}, {891, 144, 128}};
 
 // Tile choice: the busiest CU runs ceil(tiles / CUs) tiles one after the other (all these tiles hold one block per CU); a tile
 // costs its MFMA work (tm x tn), the operand stream and split work per k-step (tm + tn) and a fixed prologue / epilogue part.
@@ -648,6 +648,9 @@ int launch_gemm_bf3_cfg(hipStream_t stream, int cfg, int epi, const float* A, in
     AIMNET_BF3_CASE(224, 2, 4, 2)  // 128 x 128 (4 x 2 waves of 32 x 64)
     AIMNET_BF3_CASE(234, 3, 4, 2)  // 192 x 128 (4 x 2 waves of 48 x 64)
     AIMNET_BF3_CASE(851, 5, 1, 8)  //  80 x 128 (1 x 8 waves of 80 x 16)
+    AIMNET_BF3_CASE(861, 6, 1, 8)  //  96 x 128 (1 x 8 waves: row counts in steps of 16 for batches that are no multiple of 160 or 128)
+    AIMNET_BF3_CASE(871, 7, 1, 8)  // 112 x 128
+    AIMNET_BF3_CASE(891, 9, 1, 8)  // 144 x 128
 #undef AIMNET_BF3_CASE
     default:
       set_last_error("gemm_bf3: unknown tile id %d", cfg);

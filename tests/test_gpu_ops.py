@@ -226,7 +226,7 @@ def test_gemm_tiles_match_fp64(cfg, M, N, K):
 
 
 # ---- bf16x3-split MLP GEMM (csrc/gemm_bf3.hip): every tile against an fp64 product, same tolerance as the exact-fp32 kernels ----
-BF3_CFGS = [0, 452, 442, 432, 422, 223, 224, 234, 851, 1452, 1442, 1432, 1422, 1223, 1224, 1234, 1851]
+BF3_CFGS = [0, 452, 442, 432, 422, 223, 224, 234, 851, 861, 871, 891, 1452, 1442, 1432, 1422, 1223, 1224, 1234, 1851]
 
 
 def _split_bf3(lib, x, stream, neg_from_block=1 << 30):

@@ -165,11 +165,15 @@ int upload_layer(aimnet_engine* e, const float* w, const float* b, int n_in, int
   if ((rc = dev_upload(e, wtp.data(), wtp.size(), &L->wt))) return rc;
   if ((rc = dev_upload(e, bp.data(), bp.size(), &L->b))) return rc;
   {  // split once, on the host (round to nearest even like v_cvt_pk_bf16_f32)
-    // the last 40 % of the k-steps a launch runs over accumulate with the opposite sign (gemm_bf3.hip, "Accumulation bias")
+    // the last 44 % of the k-steps a launch runs over accumulate with the opposite sign (gemm_bf3.hip, "Accumulation bias").
+    // 0.56 from the end-to-end energy error against the fp64 oracle (tests/tools/cfg5_ratio.py, relaxed256_probe.py): on the hot
+    // config-5 frames the engine's rms distance from fp64 is 1.03 / 1.05 / 1.30 / 1.37 / 1.92 x the fp32 oracle's with the flip
+    // at 0.50 / 0.56 / 0.60 / 0.64 / none (exact-fp32 kernels: 0.97); on the relaxed 256-molecule set 0.56 gives the smallest
+    // worst-case error (0.66 of the un-widened gate; exact-fp32 kernels 1.05).
     std::vector<unsigned short> s3(wp.size() * 3);
     const int kb0 = k0_fwd / 32, nkf = L->k_in / 32 - kb0, nkb = L->k_out / 32;
-    const char* fenv = getenv("AIMNET_BF3_FLIP");  // experiment knob: per mille of the k-steps in the first phase (default 600)
-    const int pm = fenv ? atoi(fenv) : 600;
+    const char* fenv = getenv("AIMNET_BF3_FLIP");  // experiment knob: per mille of the k-steps in the first phase
+    const int pm = fenv ? atoi(fenv) : 560;
     L->neg_w3 = kb0 + (pm * nkf + 500) / 1000;
     L->neg_wt3 = (pm * nkb + 500) / 1000;
     split_bf3_host(wp.data(), L->k_out, L->k_in, s3.data(), L->neg_w3);

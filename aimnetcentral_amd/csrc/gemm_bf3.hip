@@ -245,10 +245,11 @@ __device__ unsigned long long g_bf3_stamps[1024];
 // tests/tools/bf3_bias.py: mean error -4.6e-8 |z| against -2e-10 for the fp32 MFMA chain, at a smaller rms).  A one-signed
 // error does not average out over atoms or layers: config 5's molecule energies moved by 2e-4 eV (rms), twice the fp32 noise.
 // Remedy without a second accumulator: a negated accumulation is truncated towards minus infinity as well, which is towards PLUS
-// infinity of the quantity it stands for.  So the weight blocks of the last 40 % of K are stored negated (host split), the
+// infinity of the quantity it stands for.  So the weight blocks of the last 44 % of K are stored negated (host split), the
 // accumulators change sign once, at step `kneg`, and the epilogue undoes the sign: the two phases' biases cancel.  Measured mean
 // error with the flip at 0.5 / 0.6 / 0.67 / 0.75 of K: +1.1e-8 / +1.8e-9 / -3.0e-9 / -1.3e-8 |z| on random-sign operands,
 // -2.9e-9 / -7.1e-9 / -9.3e-9 / -1.4e-8 on all-positive ones (no flip: -4.7e-8 / -2.9e-8; fp32 MFMA chain: -2e-10); rms unchanged.
+// The engine flips at 0.56 K, chosen on end-to-end energies against the fp64 oracle (engine.hip, upload_layer).
 
 // C[M,N] = A[M,K] . B^T: A fp32 [M][lda], B the bf3 split of Bt [N][K] (ldb = bf16 elements per row = 3 x the padded K of the
 // full weight matrix), C / D / bias / brow as in gemm_nt_panel_kernel.

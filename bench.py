@@ -107,12 +107,14 @@ def parity_samples():
     def step_md():
         nb, _ = O.neighbor_list_fast(cm, 5.0, molm)
         nbl, _ = O.neighbor_list(cm, float("inf"), molm)
-        return O.evaluate(om, coord=cm, numbers=zm, charge=qm, mol_idx=molm, coulomb="simple", nbmat=nb, nbmat_lr=nbl)
+        return O.evaluate(om, coord=cm, numbers=zm, charge=qm, mol_idx=molm, coulomb="simple", nbmat=nb, nbmat_lr=nbl,
+                          return_intermediates=True)
 
-    def e64_md():  # fp64 energies of the hot random frames: the anchor of their energy gate (see parity_gate)
+    def e64_md():  # fp64 oracle on the hot random frames: the anchor of their energy gate (see parity_gate)
         nb, _ = O.neighbor_list_fast(cm, 5.0, molm)
         nbl, _ = O.neighbor_list(cm, float("inf"), molm)
-        return O.evaluate(om64, coord=cm, numbers=zm, charge=qm, mol_idx=molm, coulomb="simple", nbmat=nb, nbmat_lr=nbl, forces=False)["energy"]
+        return O.evaluate(om64, coord=cm, numbers=zm, charge=qm, mol_idx=molm, coulomb="simple", nbmat=nb, nbmat_lr=nbl, forces=False,
+                          return_intermediates=True)
 
     return {
         "pbc2304": dict(coord=c32, numbers=z, mol_idx=mol, charge=np.zeros(1, np.float32), cell=cell32, coulomb="dsf", stress=True,
@@ -126,8 +128,10 @@ def parity_gate(eng, samples, oracle_out):
     """Engine vs oracle on the parity samples, at the reference's own gates (tests/conftest.py): |dE| <= max(1e-5, 5e-7 n) eV,
     |dF| <= 1e-5 + 1e-4 max|F| eV/A, |dq| <= 1e-4 e, |dstress| <= 1e-5 eV/A^3.  Untimed.
     The random md frames are hot (contacts of 0.9 A, |F| up to 800 eV/A): there the fp32 ORACLE itself sits up to 1e-3 eV from the
-    fp64 energy, so - as in tests/test_gpu_parity.compare - each molecule's energy gate is widened by the oracle's own distance
-    from the fp64 oracle (`dE_gate_slack_fp64` = the largest such widening); forces, charges and stress are at the plain gates."""
+    fp64 energy and its per-atom errors are one-signed within a molecule, so their energies are held against the fp64 oracle exactly
+    as tests/test_gpu_configs.check_batch holds config 5: per molecule |E_hip - E_64| <= gate + |E_32 - E_64| + 2 sum_atoms
+    |e_32 - e_64| (`dE_gate_slack_fp64` = the largest widening), and in the rms over the frames the engine's distance from fp64 may
+    exceed the fp32 oracle's by at most 1.5x (`rms_ratio`).  Forces, charges and stress are at the plain gates everywhere."""
     import torch
 
     dev = eng.device
@@ -143,7 +147,16 @@ def parity_gate(eng, samples, oracle_out):
         sizes = np.bincount(np.asarray(smp["mol_idx"]))
         fmax = float(np.abs(ref["forces"]).max())
         de = np.abs(r["energy"] - ref["energy"])
-        slack = np.abs(ref["energy"] - smp["e64"]()) if smp["e64"] is not None else np.zeros_like(de)
+        slack, rms_ratio = np.zeros_like(de), None
+        if smp["e64"] is not None:
+            r64 = smp["e64"]()
+            mol = np.asarray(smp["mol_idx"])
+            l1 = np.zeros(len(sizes))
+            np.add.at(l1, mol, np.abs(ref["_e_atom"][: len(mol)].astype(np.float64) - r64["_e_atom"][: len(mol)]))
+            err_ref = np.abs(ref["energy"] - r64["energy"])
+            slack = err_ref + 2.0 * l1
+            de = np.abs(r["energy"] - r64["energy"])  # against the fp64 energies
+            rms_ratio = float(np.sqrt(np.mean(de**2)) / max(1e-30, np.sqrt(np.mean(err_ref**2))))
         e_gate = max(1e-5, 5e-7 * float(sizes.max()))
         d = {"dE": float(de.max()), "dF_max": float(np.abs(r["forces"] - ref["forces"]).max()),
              "dq_max": float(np.abs(r["charges"] - ref["charges"]).max()),
@@ -151,6 +164,9 @@ def parity_gate(eng, samples, oracle_out):
         gates = {"dE": e_gate, "dE_gate_slack_fp64": float(slack.max()), "dF_max": 1e-5 + 1e-4 * fmax, "dq_max": 1e-4,
                  "dstress_max": 1e-5 if smp["stress"] else None}
         ok = bool((de <= e_gate + slack).all()) and all(d[k] is None or d[k] <= gates[k] for k in ("dF_max", "dq_max", "dstress_max"))
+        if rms_ratio is not None:
+            ok = ok and rms_ratio <= 1.5 + 1e-5 / max(1e-30, float(np.sqrt(np.mean(err_ref**2))))
+            d["dE_vs"], d["rms_ratio"] = "fp64 oracle", rms_ratio
         ok_all = ok_all and ok
         res[name] = dict(d, gates=gates, ok=bool(ok), sample=smp["label"], atoms=int(len(smp["numbers"])), max_abs_force=fmax)
     res["ok"] = bool(ok_all)

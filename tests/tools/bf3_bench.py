@@ -20,7 +20,7 @@ shapes = [(512, 736), (512, 448), (384, 512), (288, 384), (384, 384), (256, 384)
           (736, 512), (448, 512), (512, 384), (384, 288), (384, 256), (256, 128)]
 if os.environ.get("SHAPES", "all") == "one":
     shapes = shapes[:1]
-cfgs = [int(c) for c in os.environ.get("CFGS", "452,1452,224,1224,432,1432,422,1422,223,1223,851,1851,234,1234").split(",")]
+cfgs = [int(c) for c in os.environ.get("CFGS", "0,452,224,432,422,223,851,234,861,871,891").split(",")]
 EPI = int(os.environ.get("EPI", 2))
 FLIP = int(os.environ.get("FLIP", 1))
 stream = torch.cuda.current_stream(dev).cuda_stream

@@ -231,9 +231,6 @@ constexpr int bf3_a_rows(int TM) { return (TM + 63) / 64 * 64; }
 constexpr int bf3_lds_bytes(int SM, int SN, int WM, int WN, int NSTB) {
   return 2 * bf3_a_rows(16 * SM * WM) * ROWB + NSTB * bf3_b_passes(16 * SN * WN) * 8192;
 }
-constexpr int bf3_waves_per_simd(int SM, int SN, int WM, int WN, int NSTB) {
-  return (2 * bf3_lds_bytes(SM, SN, WM, WN, NSTB) <= 160 * 1024) ? 4 : 2;
-}
 
 #ifdef AIMNET_BF3_TIMING
 __device__ unsigned long long g_bf3_stamps[1024];

@@ -81,3 +81,68 @@ def test_analytic_matches_autograd_fp64_two_charge_channels(oracle64_nse, case):
     assert np.abs(a["forces"] - ref["forces"]).max() < 1e-10
     if cell is not None:
         assert np.abs(a["stress"] - ref["stress"]).max() < 1e-12
+
+
+def _lists(oracle, g, kw):
+    mol = g["mol_idx"] if "mol_idx" in g.files else np.zeros(len(g["numbers"]), dtype=np.int64)
+    cell = g["cell"] if "cell" in g.files else None
+    ref = O.evaluate(oracle, g["coord"], g["numbers"], g["charge"], mol, cell=cell, return_intermediates=True, forces=False, **kw)
+    xw = ref["coord_wrapped"]
+    if cell is None:
+        nbl, shl = O.neighbor_list(xw, float("inf"), mol)
+        coul = "simple"
+    else:
+        nbl, shl = O.neighbor_list(xw, kw["dsf_rc"], mol, cell, np.ones(3, bool))
+        coul = "dsf"
+    args = (xw, g["numbers"], g["charge"], mol, ref["nbmat"])
+    kws = dict(shifts=ref.get("shifts"), cell=cell, coulomb=coul, nbmat_lr=nbl, shifts_lr=shl,
+               **{k: v for k, v in kw.items() if k != "coulomb"})
+    return args, kws
+
+
+def test_tangent_sweep_matches_autograd_hessian_fp64(oracle64):
+    """The hand-derived tangent sweep (spec of csrc/hvp.hip) against the autograd Hessian of the oracle, config 4's molecule."""
+    g = golden("hvp40")
+    H = O.evaluate(oracle64, g["coord"], g["numbers"], g["charge"], hessian=True, forces=False)["hessian"].reshape(120, 120)
+    args, kws = _lists(oracle64, g, {})
+    V = np.concatenate([g["v1"][None], g["v4"]]).astype(np.float64)
+    r = AN.evaluate_hvp(oracle64, *args, V, **kws)
+    assert np.abs(r["hv"].reshape(5, 120) - V.reshape(5, 120) @ H).max() < 1e-9
+    f = AN.evaluate(oracle64, *args, **kws)["forces"]
+    assert np.abs(r["forces"] - f).max() < 1e-12
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("batch5", {}),
+    ("pbc96_dsf8_wrapped", {"coulomb": "dsf", "dsf_rc": 8.0, "dsf_alpha": 0.25}),
+])
+def test_tangent_sweep_matches_central_differences_fp64(oracle64, name, kw):
+    """... and against central differences of the analytic fp64 forces on a batch and on a periodic DSF cell (lists held fixed)."""
+    g = golden(name)
+    args, kws = _lists(oracle64, g, kw)
+    n = len(g["numbers"])
+    rng = np.random.default_rng(5)
+    V = rng.standard_normal((2, n, 3))
+    r = AN.evaluate_hvp(oracle64, *args, V, **kws)
+    h = 1e-5
+    for k in range(2):
+        fp = AN.evaluate(oracle64, args[0] + h * V[k], *args[1:], **kws)["forces"]
+        fm = AN.evaluate(oracle64, args[0] - h * V[k], *args[1:], **kws)["forces"]
+        fd = -(fp - fm) / (2 * h)
+        assert np.abs(r["hv"][k] - fd).max() < 2e-6 * max(1.0, np.abs(fd).max()), (k, np.abs(r["hv"][k] - fd).max())
+
+
+def test_tangent_sweep_two_charge_channels_fp64(oracle64_nse):
+    """The NSE family (two charge channels) through the tangent sweep: central differences of the analytic fp64 forces."""
+    g = golden("nse")
+    c, z, mol, q, mult = g["b5_coord"], g["b5_numbers"], g["b5_mol_idx"], g["b5_charge"], g["b5_mult"]
+    ref = O.evaluate(oracle64_nse, c, z, q, mol, mult=mult, return_intermediates=True, forces=False)
+    nbl, shl = O.neighbor_list(ref["coord_wrapped"], float("inf"), mol)
+    args = (ref["coord_wrapped"], z, q, mol, ref["nbmat"])
+    kws = dict(coulomb="simple", nbmat_lr=nbl, shifts_lr=shl, mult=mult)
+    V = np.random.default_rng(7).standard_normal((1, len(z), 3))
+    r = AN.evaluate_hvp(oracle64_nse, *args, V, **kws)
+    h = 1e-5
+    fd = -(AN.evaluate(oracle64_nse, args[0] + h * V[0], *args[1:], **kws)["forces"]
+           - AN.evaluate(oracle64_nse, args[0] - h * V[0], *args[1:], **kws)["forces"]) / (2 * h)
+    assert np.abs(r["hv"][0] - fd).max() < 2e-6 * max(1.0, np.abs(fd).max())

@@ -11,7 +11,7 @@ import os
 from functools import lru_cache
 
 MAX_PASS, MAX_LAYERS, MAX_SHIFTS = 4, 6, 32
-ABI_VERSION = 5  # AIMNET_ABI_VERSION of include/aimnet_hip.h this binding was written against
+ABI_VERSION = 6  # AIMNET_ABI_VERSION of include/aimnet_hip.h this binding was written against
 FORCES, STRESS = 1, 2
 COULOMB_NONE, COULOMB_SIMPLE, COULOMB_DSF = 0, 1, 2
 E_INVALID, E_HIP, E_WORKSPACE = -1, -2, -3
@@ -28,6 +28,8 @@ EXPORTED_SYMBOLS = (
     "aimnet_last_error",
     "aimnet_engine_workspace_bytes",
     "aimnet_engine_eval",
+    "aimnet_engine_hvp_workspace_bytes",
+    "aimnet_engine_hvp",
     "aimnet_engine_debug_view",
     "aimnet_engine_set_profiling",
     "aimnet_engine_set_profile_sampling",
@@ -166,6 +168,10 @@ def load() -> C.CDLL:
     lib.aimnet_engine_workspace_bytes.argtypes = [vp, i32, i32, i32, C.POINTER(EvalOptions)]
     lib.aimnet_engine_eval.restype = C.c_int
     lib.aimnet_engine_eval.argtypes = [vp, C.POINTER(Inputs), C.POINTER(EvalOptions), C.POINTER(Outputs), vp, sz, vp]
+    lib.aimnet_engine_hvp_workspace_bytes.restype = sz
+    lib.aimnet_engine_hvp_workspace_bytes.argtypes = [vp, i32, i32, i32, C.POINTER(EvalOptions)]
+    lib.aimnet_engine_hvp.restype = C.c_int
+    lib.aimnet_engine_hvp.argtypes = [vp, C.POINTER(Inputs), C.POINTER(EvalOptions), vp, i32, vp, vp, vp, vp, sz, vp]
     lib.aimnet_engine_debug_view.restype = C.c_int
     lib.aimnet_engine_debug_view.argtypes = [vp, C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(i32), C.POINTER(i32)]
     lib.aimnet_engine_set_profiling.restype = C.c_int

@@ -1,0 +1,106 @@
+// engine.h - the engine object behind the opaque `aimnet_engine` handle of include/aimnet_hip.h: device weight store, switches,
+// profiling state.  Internal to the library (engine.hip builds it, hvp.hip reads the weights and the architecture).
+#pragma once
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/aimnet_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace aimnet {
+
+static inline int pad32(int n) { return (n + 31) / 32 * 32; }
+
+struct Layer {
+  int n_in, n_out, k_in, k_out;  // real and padded (multiple of 32) sizes
+  float* w;                      // [k_out][k_in]  forward operand  (Bt of  H = X . W^T)
+  float* wt;                     // [k_in][k_out]  backward operand (Bt of dX = dZ . W)
+  float* b;                      // [k_out]
+  unsigned short* w3 = nullptr;  // the same two operands split into three bf16 planes ("bf3" layout of gemm_bf3.hip:
+  unsigned short* wt3 = nullptr; // 3 * k_in resp. 3 * k_out bf16 elements per row) for the bf16x3-split MFMA GEMM
+  int neg_w3 = 0, neg_wt3 = 0;   // k-block (of 32) from which w3 / wt3 are stored negated (sign-flipped accumulation phase)
+};
+
+struct View {
+  size_t off, n_elem;
+  int elem_size, row_stride;
+};
+
+}  // namespace aimnet
+
+using aimnet::BasisParams;
+using aimnet::D3Tables;
+using aimnet::Layer;
+using aimnet::View;
+
+struct aimnet_engine {
+  aimnet_arch arch;
+  int nq = 1;  // charge channels (arch.n_charge_channels, 0 -> 1)
+  int device;
+  std::vector<void*> allocs;
+  float *afv, *afv_t, *agh_a, *agh_q;  // afv_t: the embedding rows in the operand layout of the MFMA conv kernels
+  // Pass 0, first MLP layer: the first 256 input columns are the constant embedding row afv[Z_i], so their product with the
+  // weights is one of 64 constant vectors: emb_bias0[z] = b + W[:, :256] . afv[z] (fp64 sums at create time).  The GEMM then
+  // runs over the 448 conv columns only (K 704 -> 448) with this table as a row-indexed bias.  set_option("emb_bias", 0) keeps
+  // the full-width GEMM (A/B and parity runs).
+  float* emb_bias0 = nullptr;
+  bool emb_bias = true;
+  // MLP GEMMs: 1 (default) = bf16x3-split operands on the bf16 matrix pipe (gemm_bf3.hip: fp32 == three bf16 planes exactly, six
+  // products per tile, fp32 accumulation - the fp32 result to within the fp32 rounding of the accumulation itself) for batches above
+  // 256 rows, the exact-fp32 skinny kernel below; 2 = bf3 for every batch size (parity runs on small fixtures); 0 = the exact-fp32
+  // MFMA kernels of gemm.hip everywhere.  set_option("gemm_bf3", v) / AIMNET_GEMM_BF3.
+  int gemm_bf3 = 1;
+  double* sae;
+  // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
+  // are finite (supported elements); every other Z shares one extra slot that points at its NaN row
+  int *slot_of_z, *z_of_slot;
+  int nslots = 0;
+  std::vector<int> z_of_slot_h;  // host copy (slot -> atomic number)
+  // DFT-D3 tables re-indexed by species slot (aimnet_engine_set_dftd3); d3.ns == 0 until set
+  D3Tables d3{0, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool spatial_order = true;  // AIMNET_SPATIAL_ORDER=0: conv kernels walk the atoms in input order
+  // AIMNET_KEEP_INTERMEDIATES=1: every MLP input row x[p] and hidden activation h[p][l] gets its own buffer (debug views of
+  // all of them stay valid after an evaluation).  Default: they share one / two buffers - each is dead as soon as the next
+  // GEMM has consumed it (the backward reads GELU', not the activations), and a buffer that is rewritten while its lines
+  // are still in the Infinity Cache never costs HBM write bandwidth
+  bool keep_intermediates = false;
+  bool p0_moments = true;  // AIMNET_P0_MOMENTS=0 keeps the generic conv_fwd / conv_bwd for pass 0 (A/B and parity runs)
+  // AIMNET_CONV_MFMA / set_option("conv_mfma"): bit 0 = conv_fwd, bit 1 = conv_bwd (+ unconcat T layout) on the 4x4x1 MFMA
+  // kernels of conv_mfma.hip for systems above the split threshold; 0 (default) = the packed-FMA VALU kernels of conv.hip.
+  // Measured on config 3 (profiles/r2_conv_mfma.md): forward 81 us either way, backward 293 vs 226 us - neither form is
+  // arithmetic-bound, so the matrix pipe buys nothing here and the VALU kernels stay the default.
+  int conv_mfma = 0;
+  // AIMNET_CONV_XE / set_option("conv_xe"): the reverse-pair form of the conv backward (conv.hip, conv_bwd_kernel<.., XE>) for
+  // passes >= 1 of systems above the split threshold: every ordered pair evaluates only its own half of the pair adjoints (no
+  // a_j gather, 4 KiB per pair instead of 5.25 KiB), F1 goes through a pair buffer and a reverse-pair map (per-atom hash tables of the rows).
+  // Config 3: kernel 215 -> 152 us per pass, +35 us per step for the map (hash build 9 us, lookup 12 us) and the force gather (14 us).
+  // 0 restores the combined-adjoint kernel (A/B and parity runs).
+  int conv_xe = 1;
+  // atoms up to which the 4-waves-per-atom "split" conv kernels are used (AIMNET_SPLIT_MAX / set_option("split_max")); per engine
+  int split_max = aimnet::conv_split_max_default();
+  // AIMNET_OVERLAP_COULOMB / set_option("overlap_coulomb"): the Coulomb / DFT-D3 pair kernels (VALU-bound, they need only the
+  // final charges) run on a second HIP stream next to the last pass' MLP, the energy head and the first backward GEMMs
+  // (MFMA-bound): forked after the last charge update, joined in front of the first conv backward
+  bool overlap_coulomb = false;  // measured (profiles/r2_summary.md): 2.135 vs 2.118 ms/step - concurrent kernels of one process slow each other down here too
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  std::vector<Layer> mlp[AIMNET_MAX_PASS];
+  std::vector<Layer> head;
+  float* head_w_last;  // [k] last head layer as a vector
+  float* head_b_last;  // [1]
+  BasisParams bp;
+  std::map<std::string, View> views;
+  // optional HIP-event profiling: one event per change of kernel family on the eval stream
+  int prof_level = 0;  // 0 off, 1 GEMM vs everything else, 2 every family
+  int prof_every = 1;  // events are recorded on every prof_every-th evaluation only (they cost ~3 % of a 2 ms step)
+  long prof_evals = 0, prof_sampled = 0;
+  bool prof_on = false;  // this evaluation records events
+  std::vector<hipEvent_t> prof_ev;
+  std::vector<int> prof_fam;
+  size_t prof_used = 0;
+  int prof_last = -2;
+};
+

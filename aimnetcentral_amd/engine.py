@@ -375,6 +375,86 @@ class HipEngine:
         return res
 
     # ------------------------------------------------------------------------------------------
+    HVP_BYTES_BUDGET = 6 << 30  # workspace of one tangent sweep; more directions than fit are processed in several sweeps
+
+    def hvp(self, coord, numbers, mol_idx, charge, vectors, cell=None, pbc=(True, True, True), coulomb: str = "simple",
+            dsf_rc: float = 15.0, dsf_alpha: float = 0.2, want_forces: bool = False) -> dict[str, Any]:
+        """Analytic Hessian-vector products (csrc/hvp.hip, aimnet_engine_hvp): vectors [K, N, 3] -> hv [K, N, 3] on the device
+        (+ the forces of the same sweep with `want_forces`).  Inputs as `eval`; no DFT-D3 (the caller uses finite differences
+        then).  The K directions are processed in as many sweeps as the workspace budget asks for."""
+        import torch
+
+        dev = self.device
+        coord = coord.to(device=dev, dtype=torch.float32).contiguous()
+        numbers = numbers.to(device=dev, dtype=torch.int32).contiguous()
+        mol_idx = mol_idx.to(device=dev, dtype=torch.int32).contiguous()
+        charge = charge.to(device=dev, dtype=torch.float32)
+        if self.nq == 2:
+            if charge.ndim != 2 or charge.shape[1] != 2:
+                raise ValueError("HipEngine.hvp: a 2-channel (NSE) model needs charge of shape [n_mol, 2] (alpha, beta)")
+            n_mol = charge.shape[0]
+            charge = charge.t().contiguous()
+        else:
+            charge = charge.reshape(-1).contiguous()
+            n_mol = charge.shape[0]
+        n = coord.shape[0]
+        vectors = vectors.to(device=dev, dtype=torch.float32).reshape(-1, n, 3).contiguous()
+        K = vectors.shape[0]
+        if n == 0 or n_mol == 0 or K == 0:
+            raise ValueError("HipEngine.hvp: empty input")
+        n_cell = 0
+        if cell is not None:
+            cell = cell.to(device=dev, dtype=torch.float32).contiguous()
+            n_cell = 1 if cell.ndim == 2 else cell.shape[0]
+        if not isinstance(pbc, (tuple, list)):
+            pbc = tuple(bool(x) for x in torch.as_tensor(pbc).reshape(-1).tolist())[:3]
+        method = {"none": _lib.COULOMB_NONE, "simple": _lib.COULOMB_SIMPLE, "dsf": _lib.COULOMB_DSF}[coulomb]
+        hv = torch.empty_like(vectors)
+        f_out = torch.empty(n, 3, dtype=torch.float32, device=dev) if want_forces else None
+        status = torch.empty(8, dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        inp = _lib.Inputs()
+        inp.n_atoms, inp.n_mol = n, n_mol
+        inp.coord, inp.numbers, inp.mol_idx, inp.charge = coord.data_ptr(), numbers.data_ptr(), mol_idx.data_ptr(), charge.data_ptr()
+        inp.cell = cell.data_ptr() if cell is not None else None
+        inp.n_cell = n_cell
+        inp.pbc_sys = None
+        for k in range(3):
+            inp.pbc[k] = 1 if bool(pbc[k]) else 0
+        k0 = 0
+        while k0 < K:
+            opt = _lib.EvalOptions()
+            opt.coulomb = method
+            opt.dsf_rc, opt.dsf_alpha = float(dsf_rc), float(dsf_alpha)
+            opt.max_nb = self.max_nb
+            opt.max_nb_lr = self._lr_capacity(float(dsf_rc)) if method == _lib.COULOMB_DSF else 0
+            per_dir = (int(self.lib.aimnet_engine_hvp_workspace_bytes(self._h, n, n_mol, 2, C.byref(opt)))
+                       - int(self.lib.aimnet_engine_hvp_workspace_bytes(self._h, n, n_mol, 1, C.byref(opt))))
+            kc = max(1, min(K - k0, self.HVP_BYTES_BUDGET // max(1, per_dir)))
+            need = int(self.lib.aimnet_engine_hvp_workspace_bytes(self._h, n, n_mol, kc, C.byref(opt)))
+            ws = torch.empty(need + 4096, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                rc = self.lib.aimnet_engine_hvp(self._h, C.byref(inp), C.byref(opt), vectors[k0 : k0 + kc].data_ptr(), kc,
+                                                hv[k0 : k0 + kc].data_ptr(), f_out.data_ptr() if f_out is not None else None,
+                                                status.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+            _lib.check(rc, "aimnet_engine_hvp")
+            st = status.cpu().numpy()
+            del ws
+            self.last_status = st
+            if st[6]:
+                raise ValueError("HipEngine.hvp: invalid input (atomic numbers outside [0, 63], mol_idx out of range or not sorted)")
+            if st[2] or st[3]:  # neighbour-row overflow: grow and repeat this sweep
+                if st[2]:
+                    self.max_nb = _round16(int(max(self.max_nb * 1.5, st[0])))
+                if st[3]:
+                    self._max_nb_lr[float(dsf_rc)] = _round16(int(max(opt.max_nb_lr * 1.5, st[1])))
+                continue
+            k0 += kc
+        res: dict[str, Any] = {"hv": hv}
+        if f_out is not None:
+            res["forces"] = f_out
+        return res
+
     def set_profiling(self, level: int, every: int = 1) -> None:
         """0 off, 1 GEMM-vs-rest, 2 per kernel family (HIP events on the eval stream); `every` = record them on every
         n-th evaluation only (the events cost ~3 % of a 2 ms step; read_profile()["evals"] says how many were covered)."""

@@ -15,6 +15,9 @@
  *   aimnet_conv_sv_2d_sp_fwd/bwd  <- torch.ops.aimnet.conv_sv_2d_sp_fwd / _bwd,
  *                                    aimnet/kernels/conv_sv_2d_sp_wp.py:252-340 (Warp kernels :90-164)
  *   aimnet_engine_create          <- "state_dict -> module on device" of aimnet/models/base.py:65-89
+ *   aimnet_engine_hvp             <- AIMNet2Calculator.hessian_vector_product, calculator.py:1753-1989 (one double backward
+ *                                    per vector) and calculate_hessian, calculators/derivatives.py:149-192 (the same vjp
+ *                                    vmapped over the 3N unit vectors): here one analytic tangent sweep for K directions
  *
  * Errors: functions return 0 on success or a negative AIMNET_E_* code; no exceptions cross the
  * ABI.  Neighbour overflow is reported asynchronously through the `status` words (the host grows
@@ -30,7 +33,7 @@
 extern "C" {
 #endif
 
-#define AIMNET_ABI_VERSION 5
+#define AIMNET_ABI_VERSION 6
 
 #define AIMNET_OK 0
 #define AIMNET_E_INVALID (-1)   /* bad argument / unsupported architecture */
@@ -161,6 +164,20 @@ size_t aimnet_engine_workspace_bytes(const aimnet_engine* e, int32_t n_atoms, in
  * drained; it also holds the intermediates that aimnet_engine_debug_view exposes. */
 int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_eval_options* opt,
                        const aimnet_outputs* out, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Analytic Hessian-vector products H v = d/d eps [dE/dx (x + eps v)] for n_vec directions at once (csrc/hvp.hip: forward-mode
+ * tangent sweep through the forward and the backward sweep of the model; specification oracle/aimnet2_analytic.py::evaluate_hvp).
+ * `in` / `opt` as for aimnet_engine_eval (opt->flags is ignored; opt->dftd3 must be 0: AIMNET_E_INVALID otherwise, the host then
+ * uses its finite-difference operator; DSF - periodic or not - runs on the neighbour list and needs max_nb_lr > 0).
+ * vectors [n_vec, n_atoms, 3] and hv [n_vec, n_atoms, 3] are device fp32; forces [n_atoms, 3] (may be NULL) receives the forces
+ * of the same sweep; status [8] as aimnet_outputs.status (a raised overflow flag invalidates hv: grow the rows and call again).
+ * Any number of molecules / cells (the reference restricts itself to one structure; the host keeps that contract).  Memory:
+ * about 50 KB per (direction, atom) - split the directions into several calls when n_vec * n_atoms is large. */
+size_t aimnet_engine_hvp_workspace_bytes(const aimnet_engine* e, int32_t n_atoms, int32_t n_mol, int32_t n_vec,
+                                         const aimnet_eval_options* opt);
+int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_eval_options* opt, const float* vectors,
+                      int32_t n_vec, float* hv, float* forces, int32_t* status, void* workspace, size_t workspace_bytes,
+                      void* hip_stream);
 
 /* Test hook: byte offset / element count / element size of a named intermediate inside the
  * workspace of the LAST eval (e.g. "nb_idx", "nb_cnt", "pair_geom", "x0", "y1", "q0", "aim",

@@ -189,27 +189,41 @@ def test_maximum_size_80k_atoms_stays_periodic(calc):
     assert np.abs(out["stress"] - g["stress"]).max() < 2e-5
 
 
-def test_config4_hessian_and_hvp_by_finite_differences(calc):
+def test_config4_hessian_and_hvp_analytic(calc):
     """BASELINE config 4 shape: dense Hessian and H @ v of a 40-atom geometry against the reference's double-backward
-    results (tests/golden/hvp40.npz).  The engine's operator is a 4th-order central difference of its analytic fp32
-    forces (calculator._fd_hvp, h = 5e-3 A), so the gate is the FD budget: truncation ~2e-4 + 190 x force noise;
-    measured 4.6e-4 eV/A^2 on |H| <= 11.5 and 2.2e-3 on |Hv| <= 32 (tests/tools/fd_hessian_check.py).
-    Gates: |dH| <= 2e-3 eV/A^2, |d(Hv)| <= 2e-3 + 2e-4 max|Hv|."""
+    results (tests/golden/hvp40.npz) at the reference's own gate for itself, allclose(rtol = atol = 1e-3) elementwise
+    (tests/test_hvp.py:75), and at the tighter 1e-4 / 2e-4 eV/A^2 the analytic tangent sweep (csrc/hvp.hip) delivers
+    (measured 6.1e-5 on |H| <= 11.5 and 1.7e-4 on |Hv| <= 32: two fp32 evaluations of the same second derivative).
+    The finite-difference operator over the forces stays as the independent cross-check at its own budget."""
     g = golden("hvp40")
     data = {"coord": g["coord"], "numbers": g["numbers"], "charge": float(g["charge"])}
+    assert calc.hvp_method == "analytic"
     out = calc(data, forces=True, hessian=True)
     H = out["hessian"].cpu().numpy().reshape(120, 120)
     Href = g["hessian"].reshape(120, 120)
-    assert np.abs(H - Href).max() <= 2e-3, np.abs(H - Href).max()
+    assert np.allclose(H, Href, rtol=1e-3, atol=1e-3)
+    assert np.abs(H - Href).max() <= 1e-4, np.abs(H - Href).max()
     assert np.abs(H - H.T).max() == 0.0
     assert_forces_close(out["forces"].cpu().numpy(), g["forces"], "hvp40")
     hv1 = calc.hessian_vector_product(data, torch.from_numpy(g["v1"])).cpu().numpy()
     hv4 = calc.hessian_vector_product(data, torch.from_numpy(g["v4"])).cpu().numpy()
     assert hv1.shape == (40, 3) and hv4.shape == (4, 40, 3)
-    assert np.abs(hv1 - g["hv1"]).max() <= 2e-3 + 2e-4 * np.abs(g["hv1"]).max(), np.abs(hv1 - g["hv1"]).max()
-    assert np.abs(hv4 - g["hv4"]).max() <= 2e-3 + 2e-4 * np.abs(g["hv4"]).max(), np.abs(hv4 - g["hv4"]).max()
+    for got, ref in ((hv1, g["hv1"]), (hv4, g["hv4"])):
+        assert np.allclose(got, ref, rtol=1e-3, atol=1e-3)
+        assert np.abs(got - ref).max() <= 1e-4 + 1e-5 * np.abs(ref).max(), np.abs(got - ref).max()
+    # the matrix-free products and the dense Hessian are the same operator
+    assert np.abs(hv1.reshape(120) - H @ g["v1"].reshape(120)).max() < 2e-4
     # translation invariance of the energy: every row of H sums to zero over the atoms (size-independent property)
-    assert np.abs(H.reshape(40, 3, 40, 3).sum(axis=2)).max() < 1e-2
+    assert np.abs(H.reshape(40, 3, 40, 3).sum(axis=2)).max() < 2e-4
+    # cross-check: the 4th-order central difference of the analytic forces (h = 5e-3 A) agrees within ITS budget
+    # (truncation ~2e-4 + 190 x force noise: 4.6e-4 on H, 2.3e-3 on H v measured)
+    calc.hvp_method = "fd"
+    try:
+        Hfd = calc(data, hessian=True)["hessian"].cpu().numpy().reshape(120, 120)
+        hv1_fd = calc.hessian_vector_product(data, torch.from_numpy(g["v1"])).cpu().numpy()
+    finally:
+        calc.hvp_method = "analytic"
+    assert np.abs(Hfd - H).max() <= 2e-3 and np.abs(hv1_fd - hv1).max() <= 2e-3 + 2e-4 * np.abs(hv1).max()
 
 
 def test_calculator_with_external_dftd3(oracle_d3):

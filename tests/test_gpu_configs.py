@@ -98,13 +98,16 @@ def test_config4_on_the_rxn_architecture():
     assert abs(out["energy"][0] - g["energy"][0]) <= energy_tol(40)
     assert_forces_close(out["forces"], g["forces"], "rxn forces")
     H = out["hessian"].reshape(120, 120)
-    # the Hessian (single-atom displacements) meets the reference's own gate for its double backward elementwise:
-    # allclose(rtol=1e-3, atol=1e-3) (tests/test_hvp.py:75); H v along random directions stays at the finite-difference budget
-    assert np.allclose(H, g["hessian"].reshape(120, 120), rtol=1e-3, atol=1e-3)
+    # Hessian and H v (analytic tangent sweep) at the reference's own gate for its double backward, elementwise
+    # allclose(rtol=1e-3, atol=1e-3) (tests/test_hvp.py:75), and at the 1e-4 eV/A^2 of two fp32 evaluations of one operator
+    Href = g["hessian"].reshape(120, 120)
+    assert np.allclose(H, Href, rtol=1e-3, atol=1e-3) and np.abs(H - Href).max() <= 1e-4
     hv1 = calc.hessian_vector_product(data, g["v1"]).cpu().numpy()
     hv4 = calc.hessian_vector_product(data, g["v4"]).cpu().numpy()
     assert hv1.shape == (40, 3) and hv4.shape == (4, 40, 3)
-    assert np.abs(hv1 - g["hv1"]).max() < 5e-3 and np.abs(hv4 - g["hv4"]).max() < 5e-3
+    for got, ref in ((hv1, g["hv1"]), (hv4, g["hv4"])):
+        assert np.allclose(got, ref, rtol=1e-3, atol=1e-3)
+        assert np.abs(got - ref).max() <= 1e-4 + 1e-5 * np.abs(ref).max(), np.abs(got - ref).max()
 
 
 def test_cold_fixture_holds_the_unwidened_energy_gate(calc):

@@ -260,6 +260,12 @@ class QuadraticEngine(FakeEngine):
         out["forces"] = (-(x @ self.A.double())).float().view(-1, 3)
         return out
 
+    def hvp(self, coord, numbers, mol_idx, charge, vectors, **kw):  # the analytic operator of the real engine: H v exactly
+        self.hvp_calls = getattr(self, "hvp_calls", [])
+        self.hvp_calls.append(dict(K=int(vectors.shape[0]), charge=charge.clone(), coulomb=kw.get("coulomb"), cell=kw.get("cell")))
+        v = vectors.double().reshape(vectors.shape[0], -1)
+        return {"hv": (v @ self.A.double()).float().view_as(vectors)}
+
 
 @pytest.fixture()
 def qcalc(monkeypatch):
@@ -273,8 +279,29 @@ def qcalc(monkeypatch):
     return c
 
 
+def test_analytic_hessian_and_hvp_go_through_the_engine_sweep(qcalc):
+    """Default operator: every direction in ONE call of the engine's tangent sweep (HipEngine.hvp); the Hessian is its 3N unit
+    directions, symmetrised; `eps` is ignored like in the reference (calculator.py:1770-1773)."""
+    A = QuadraticEngine.A
+    assert qcalc.hvp_method == "analytic"
+    out = qcalc(WATER, forces=True, hessian=True)
+    assert (out["hessian"].reshape(9, 9).double() - A).abs().max() < 1e-5 and "forces" in out
+    assert [c["K"] for c in qcalc.engine.hvp_calls] == [9] and qcalc.engine.hvp_calls[0]["coulomb"] == "simple"
+    v = torch.randn(5, 3, 3, generator=torch.Generator().manual_seed(4))
+    hv = qcalc.hessian_vector_product(WATER, v, eps=0.3)
+    assert hv.shape == (5, 3, 3) and (hv.reshape(5, 9).double() - v.reshape(5, 9).double() @ A).abs().max() < 1e-4
+    assert qcalc.hessian_vector_product(WATER, v[0]).shape == (3, 3) and qcalc.engine.hvp_calls[-1]["K"] == 1
+    n_eval = len(qcalc.engine.calls)
+    qcalc.hessian_vector_product(WATER, v)
+    assert len(qcalc.engine.calls) == n_eval  # no force evaluations: the sweep carries its own primal pass
+    qcalc.hvp_method = "newton"
+    with pytest.raises(ValueError, match="hvp_method"):
+        qcalc.hessian_vector_product(WATER, v)
+
+
 def test_fd_hessian_and_hvp_recover_a_quadratic_model(qcalc):
     A = QuadraticEngine.A
+    qcalc.hvp_method = "fd"  # the cross-check operator: central differences of the engine's forces
     out = qcalc(WATER, hessian=True)
     assert set(out) == {"energy", "charges", "hessian"} and out["hessian"].shape == (3, 3, 3, 3)
     assert (out["hessian"].reshape(9, 9).double() - A).abs().max() < 2e-3  # fp32 forces of O(10) / h = 5e-3
@@ -387,6 +414,10 @@ def test_nse_fd_hessian_carries_both_channels(monkeypatch):
     c.device = "cpu"
     a = torch.randn(9, 9, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
     QuadraticEngine.A = a + a.T
+    out = c(dict(WATER, mult=3.0), hessian=True)  # analytic sweep: one molecule, both channels
+    assert (out["hessian"].reshape(9, 9).double() - QuadraticEngine.A).abs().max() < 1e-5
+    assert c.engine.hvp_calls[-1]["charge"].tolist() == [[1.0, -1.0]]
+    c.hvp_method = "fd"
     out = c(dict(WATER, mult=3.0), hessian=True)
     assert (out["hessian"].reshape(9, 9).double() - QuadraticEngine.A).abs().max() < 2e-3
     ch = c.engine.calls[-1]["charge"]

@@ -17,8 +17,9 @@ Deliberate deviations, all loud:
   * (per-system `pbc` flags of shape (B, 3) are supported: the engine takes them as a device array);
   * hessian=True and hessian_vector_product run the analytic tangent sweep of csrc/hvp.hip (forward-mode through the
     forward and backward sweep, all directions at once; `hvp_method`), not autograd double backward: exact second derivatives
-    at fp32 round-off.  The finite-difference operator over the analytic forces (`_fd_hvp`, `hvp_method = "fd"`) is kept as the
-    cross-check and carries the external DFT-D3 term; create_graph=True raises (there is no autograd graph).
+    at fp32 round-off (the external DFT-D3 block: a central difference of the D3 gradient alone, inside the same call).  The
+    finite-difference operator over the analytic forces (`_fd_hvp`, `hvp_method = "fd"`) is kept as the cross-check;
+    create_graph=True raises (there is no autograd graph).
 """
 from __future__ import annotations
 
@@ -560,8 +561,9 @@ class AIMNet2Calculator:
 
     # "analytic" (default): the tangent-sweep kernels of csrc/hvp.hip (HipEngine.hvp) - exact second derivatives at fp32
     # round-off (2e-6 relative to the fp64 specification, 6e-5 eV/A^2 from the reference's Hessian on config 4);
-    # "fd": the central-difference operator over the analytic forces (`_fd_hvp`), kept as the independent cross-check and as the
-    # fallback for the one term the sweep does not carry (external DFT-D3).
+    # with an external DFT-D3 term its block is a central difference of the D3 gradient alone inside the same call (smooth, ~1 % of
+    # the curvature: ~1e-6 eV/A^2);  "fd": the central-difference operator over the analytic forces (`_fd_hvp`), the independent
+    # cross-check.
     hvp_method = "analytic"
 
     def _hvp(self, d: dict[str, Any], dirs, eps: float | None = None):
@@ -570,7 +572,7 @@ class AIMNet2Calculator:
 
         if self.hvp_method not in ("analytic", "fd"):
             raise ValueError(f"hvp_method must be 'analytic' or 'fd', got {self.hvp_method!r}")
-        if self.hvp_method == "fd" or self._dftd3_options() is not None:
+        if self.hvp_method == "fd":
             return self._fd_hvp(d, dirs, eps)
         cell = d.get("cell")
         method = self._coulomb_method
@@ -582,7 +584,7 @@ class AIMNet2Calculator:
         n = d["coord"].shape[0]
         res = self.engine.hvp(d["coord"], d["numbers"], torch.zeros(n, dtype=torch.int32, device=self.device),
                               self._engine_charge(d["charge"], d.get("mult")), dirs, cell=cell, pbc=pbc3, coulomb=method or "none",
-                              dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha)
+                              dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, dftd3=self._dftd3_options())
         return res["hv"]
 
     def _eval_hessian(self, data, *, forces: bool, stress: bool, validate_species: bool) -> dict[str, Any]:
@@ -652,8 +654,7 @@ class AIMNet2Calculator:
                                validate_species: bool = True, create_graph: bool = False):
         """Matrix-free H @ v for one structure (calculator.py:1753-1989): `vectors` (N,3) or (K,N,3) -> same shape.
         Exact second derivatives from the analytic tangent sweep (csrc/hvp.hip), all directions in one sweep; `eps` is, as in the
-        reference, ignored by the analytic operator - it is the step of the finite-difference one (`hvp_method = "fd"`, and the
-        external DFT-D3 term, which the sweep does not carry)."""
+        reference, ignored by the analytic operator - it is the step of the finite-difference one (`hvp_method = "fd"`)."""
         import torch
 
         if create_graph:

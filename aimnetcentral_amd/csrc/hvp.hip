@@ -762,6 +762,65 @@ __global__ __launch_bounds__(256) void hvp_nse_bwd_kernel(const float* __restric
   }
 }
 
+// ---- external DFT-D3 block: central difference of ITS OWN analytic gradient --------------------------------------------
+// The dispersion term is a smooth two-body sum with coordination-number dependent coefficients (d3.hip); its curvature is ~1 % of
+// the model's (up to 0.6 eV/A^2 on config 4's molecule), its fp32 gradient noise ~1e-7 eV/A.  The coordination-number counting
+// function 1 / (1 + exp(-16 (rcov / r - 1))) is steep - every derivative brings a factor ~16 / A - so a 2-point stencil at 0.01 A
+// is 0.5 % off (measured 3e-3 eV/A^2); the 4-point stencil at h = 4e-3 A leaves (16 h)^4 / 30 ~ 6e-7 relative truncation, and the
+// fp32 rounding of x +- h u (half an ulp of a 5 A coordinate over 4e-3 A) ~6e-5 relative: ~5e-5 eV/A^2 in all.  The reference
+// does the same for the one block it cannot differentiate (the PME term, calculator.py:1777-1781).  All 4 K displaced copies
+// are evaluated as ONE batch of independent systems: coordinates x + {h, -h, 2h, -2h} u_k, the neighbour rows of x re-based per
+// copy (a pair that drifts across the cutoff sits where the S5 switch is zero anyway).
+__global__ void hvp_d3_scale_kernel(const float* __restrict__ tv, int N, int K, float* __restrict__ scale) {
+  __shared__ float sh[4];
+  const int k = blockIdx.x;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    const float* v = tv + ((size_t)k * N + i) * 3;
+    m = fmaxf(m, v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) scale[k] = sqrtf(fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])));  // largest per-atom |v_i|
+}
+
+__global__ void hvp_d3_replicate_kernel(const float* __restrict__ xw, const float* __restrict__ tv, const float* __restrict__ scale,
+                                        const int* __restrict__ mol_idx, const int* __restrict__ aslot,
+                                        const int* __restrict__ nb_idx, const int* __restrict__ nb_shift,
+                                        const int* __restrict__ nb_cnt, int cap, int N, int K, float h, float* __restrict__ xd,
+                                        int* __restrict__ mol_d, int* __restrict__ aslot_d, int* __restrict__ idx_d,
+                                        int* __restrict__ shift_d, int* __restrict__ cnt_d) {
+  const int i = blockIdx.x, c = blockIdx.y;  // copy c = 4 k + (0: +h, 1: -h, 2: +2h, 3: -2h)
+  const int k = c >> 2;
+  const float sg = ((c & 1) ? -h : h) * ((c & 2) ? 2.0f : 1.0f);
+  const size_t row = (size_t)c * N + i;
+  const float inv = 1.0f / fmaxf(scale[k], 1e-30f);
+  if (threadIdx.x < 3) xd[row * 3 + threadIdx.x] = xw[(size_t)i * 3 + threadIdx.x] + sg * inv * tv[((size_t)k * N + i) * 3 + threadIdx.x];
+  if (threadIdx.x == 0) {
+    mol_d[row] = mol_idx[i];
+    aslot_d[row] = aslot[i];
+    cnt_d[row] = nb_cnt[i];
+  }
+  const int cnt = nb_cnt[i];
+  for (int m = threadIdx.x; m < cnt; m += blockDim.x) {
+    idx_d[row * cap + m] = nb_idx[(size_t)i * cap + m] + c * N;
+    shift_d[row * cap + m] = nb_shift[(size_t)i * cap + m];
+  }
+}
+
+__global__ void hvp_d3_combine_kernel(const float* __restrict__ gd, const float* __restrict__ scale, int N, size_t n_t, float h,
+                                      float* __restrict__ txbar) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (k, i, c)
+  if (e >= n_t) return;
+  const size_t per = (size_t)N * 3;
+  const size_t k = e / per, r = e % per;
+  const float* g4 = gd + 4 * k * per + r;
+  txbar[e] += (8.0f * (g4[0] - g4[per]) - (g4[2 * per] - g4[3 * per])) * (scale[k] / (12.0f * h));
+}
+
 __global__ void hvp_out_kernel(const float* __restrict__ xbar, size_t n, float* __restrict__ forces) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n) forces[e] = -xbar[e];
@@ -797,6 +856,12 @@ struct HvpWs {
   float *g[2], *tg[2];
   float *Sbar, *tSbar, *Sqbar, *tSqbar, *abar, *tabar, *qbar[2], *tqbar[2], *xbar, *txbar;
   float* wlast;
+  // external DFT-D3 block (4 K displaced copies as one batch)
+  int *d3_idx, *d3_shift, *d3_cnt, *aslot, *d3c_idx, *d3c_shift, *d3c_cnt, *d3c_mol, *d3c_aslot;
+  unsigned long long* present_part;
+  float *d3c_x, *d3c_w, *d3c_dEdcn, *d3c_g, *d3_scale;
+  float4* d3c_xs;
+  double* d3c_e;
   size_t total;
 };
 
@@ -873,6 +938,27 @@ void hvp_layout(const aimnet_engine* e, int N, int n_mol, int K, const aimnet_ev
   W.xbar = c.take<float>(n * 3);
   W.txbar = c.take<float>(kn * 3);
   W.wlast = c.take<float>((size_t)mw);
+  if (opt->dftd3 != 0) {
+    const int cap_d3 = std::max(1, opt->max_nb_d3);
+    const size_t cn = 4 * kn;
+    W.d3_idx = c.take<int>(n * cap_d3);
+    W.d3_shift = c.take<int>(n * cap_d3);
+    W.d3_cnt = c.take<int>(n);
+    W.aslot = c.take<int>(n);
+    W.present_part = c.take<unsigned long long>((n + 255) / 256);
+    W.d3c_idx = c.take<int>(cn * cap_d3);
+    W.d3c_shift = c.take<int>(cn * cap_d3);
+    W.d3c_cnt = c.take<int>(cn);
+    W.d3c_mol = c.take<int>(cn);
+    W.d3c_aslot = c.take<int>(cn);
+    W.d3c_x = c.take<float>(cn * 3);
+    W.d3c_w = c.take<float>(cn * 12);
+    W.d3c_dEdcn = c.take<float>(cn);
+    W.d3c_g = c.take<float>(cn * 3);
+    W.d3c_xs = c.take<float4>(cn);
+    W.d3c_e = c.take<double>(cn);
+    W.d3_scale = c.take<float>((size_t)K);
+  }
   W.total = align_up(c.off, 256);
 }
 
@@ -968,8 +1054,13 @@ int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_ev
     set_last_error("hvp: null or empty input");
     return AIMNET_E_INVALID;
   }
-  if (opt->dftd3 != 0) {
-    set_last_error("hvp: the DFT-D3 term has no analytic second derivative here (host: finite-difference operator)");
+  const bool d3 = opt->dftd3 != 0;
+  if (d3 && e->d3.ns == 0) {
+    set_last_error("hvp: DFT-D3 requested but aimnet_engine_set_dftd3 was never called");
+    return AIMNET_E_INVALID;
+  }
+  if (d3 && 4 * (size_t)n_vec * (size_t)in->n_atoms * (size_t)std::max(1, opt->max_nb_d3) >= (size_t)INT32_MAX) {
+    set_last_error("hvp: n_vec * n_atoms * max_nb_d3 too large for one sweep (split the directions)");
     return AIMNET_E_INVALID;
   }
   const bool pbc = in->cell != nullptr;
@@ -1006,7 +1097,8 @@ int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_ev
 
   // ---- lists + pair geometry: the same builders as aimnet_engine_eval ----
   AIMNET_HIP_CHECK(hipMemsetAsync(status, 0, 8 * sizeof(int), s));
-  RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start, W.nl.mol_c, in->numbers, status + 6));
+  RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start, W.nl.mol_c, in->numbers, status + 6, d3 ? e->slot_of_z : nullptr,
+                      d3 ? W.aslot : nullptr, d3 ? W.present_part : nullptr));
   const int* mol_c = W.nl.mol_c;
   RC(launch_wrap(s, in->coord, mol_c, N, n_mol, in->cell, n_cell, in->pbc, W.nl, in->pbc_sys, pbc ? ar.rc : 0.0f));
   if (!pbc && (long)N >= 1500L * n_mol) RC(launch_bbox(s, n_mol, W.nl));
@@ -1122,6 +1214,35 @@ int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_ev
                        W.tg[cur], W.qbar[qb ^ 1], W.tqbar[qb ^ 1]);
     AIMNET_LAUNCH_CHECK();
     qb ^= 1;
+  }
+  if (d3) {  // the dispersion block: central difference of the D3 gradient over all directions in one batch (see the kernels)
+    const int cap_d3 = std::max(1, opt->max_nb_d3);
+    const float h = 4e-3f;
+    const int NC = 4 * K * N;
+    RC(launch_nlist(s, N, n_mol, mol_c, in->cell, n_cell, in->pbc, opt->d3_cutoff, -1.0f, cap_d3, N, 0, W.nl, W.d3_idx, W.d3_shift,
+                    W.d3_cnt, status + 4, status + 5));
+    hipLaunchKernelGGL(hvp_d3_scale_kernel, dim3(K), b256, 0, s, vectors, N, K, W.d3_scale);
+    AIMNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hvp_d3_replicate_kernel, dim3(N, 4 * K), dim3(64), 0, s, W.nl.xw, vectors, W.d3_scale, mol_c, W.aslot,
+                       W.d3_idx, W.d3_shift, W.d3_cnt, cap_d3, N, K, h, W.d3c_x, W.d3c_mol, W.d3c_aslot, W.d3c_idx, W.d3c_shift,
+                       W.d3c_cnt);
+    AIMNET_LAUNCH_CHECK();
+    AIMNET_HIP_CHECK(hipMemsetAsync(W.d3c_g, 0, (size_t)NC * 3 * sizeof(float), s));
+    AIMNET_HIP_CHECK(hipMemsetAsync(W.d3c_e, 0, (size_t)NC * sizeof(double), s));
+    D3Params dp;
+    dp.s6 = opt->d3_s6; dp.s8 = opt->d3_s8; dp.a1 = opt->d3_a1; dp.a2 = opt->d3_a2;
+    dp.r_on = opt->d3_smoothing_on * 1.8897261258369282f;
+    dp.r_off = opt->d3_cutoff * 1.8897261258369282f;
+    RC(launch_dftd3(s, true, false, W.d3c_x, W.d3c_mol, in->cell, n_cell, W.d3c_aslot, W.d3c_idx, W.d3c_shift, W.d3c_cnt, cap_d3,
+                    e->d3, dp, opt->d3_cutoff, NC, W.d3c_xs, W.d3c_w, W.d3c_dEdcn, W.d3c_e, W.d3c_g, nullptr, false, cp, nullptr,
+                    nullptr));
+    hipLaunchKernelGGL(hvp_d3_combine_kernel, grid1(kn * 3), b256, 0, s, W.d3c_g, W.d3_scale, N, kn * 3, h, W.txbar);
+    AIMNET_LAUNCH_CHECK();
+    if (forces) {  // the forces of the sweep include the dispersion term: its gradient at x itself (one more evaluation)
+      AIMNET_HIP_CHECK(hipMemsetAsync(W.d3c_e, 0, (size_t)N * sizeof(double), s));
+      RC(launch_dftd3(s, true, false, W.nl.xw, mol_c, in->cell, n_cell, W.aslot, W.d3_idx, W.d3_shift, W.d3_cnt, cap_d3, e->d3, dp,
+                      opt->d3_cutoff, N, W.d3c_xs, W.d3c_w, W.d3c_dEdcn, W.d3c_e, W.xbar, nullptr, false, cp, nullptr, nullptr));
+    }
   }
   AIMNET_HIP_CHECK(hipMemcpyAsync(hv, W.txbar, kn * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (forces) {

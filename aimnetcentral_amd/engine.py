@@ -378,10 +378,12 @@ class HipEngine:
     HVP_BYTES_BUDGET = 6 << 30  # workspace of one tangent sweep; more directions than fit are processed in several sweeps
 
     def hvp(self, coord, numbers, mol_idx, charge, vectors, cell=None, pbc=(True, True, True), coulomb: str = "simple",
-            dsf_rc: float = 15.0, dsf_alpha: float = 0.2, want_forces: bool = False) -> dict[str, Any]:
+            dsf_rc: float = 15.0, dsf_alpha: float = 0.2, want_forces: bool = False,
+            dftd3: dict[str, float] | None = None) -> dict[str, Any]:
         """Analytic Hessian-vector products (csrc/hvp.hip, aimnet_engine_hvp): vectors [K, N, 3] -> hv [K, N, 3] on the device
-        (+ the forces of the same sweep with `want_forces`).  Inputs as `eval`; no DFT-D3 (the caller uses finite differences
-        then).  The K directions are processed in as many sweeps as the workspace budget asks for."""
+        (+ the forces of the same sweep with `want_forces`).  Inputs as `eval`; with `dftd3` the dispersion block is added as a
+        central difference of the D3 gradient inside the same call.  The K directions are processed in as many sweeps as the
+        workspace budget asks for."""
         import torch
 
         dev = self.device
@@ -428,6 +430,16 @@ class HipEngine:
             opt.dsf_rc, opt.dsf_alpha = float(dsf_rc), float(dsf_alpha)
             opt.max_nb = self.max_nb
             opt.max_nb_lr = self._lr_capacity(float(dsf_rc)) if method == _lib.COULOMB_DSF else 0
+            if dftd3 is not None:
+                if not self.has_dftd3:
+                    raise RuntimeError("dftd3 requested but no DFT-D3 tables were uploaded (HipEngine.set_dftd3_tables)")
+                d3_rc = float(dftd3.get("cutoff", 15.0))
+                opt.dftd3 = 1
+                opt.d3_s6, opt.d3_s8 = float(dftd3.get("s6", 1.0)), float(dftd3["s8"])
+                opt.d3_a1, opt.d3_a2 = float(dftd3["a1"]), float(dftd3["a2"])
+                opt.d3_cutoff = d3_rc
+                opt.d3_smoothing_on = d3_rc * (1.0 - float(dftd3.get("smoothing_fraction", 0.2)))
+                opt.max_nb_d3 = self._lr_capacity(d3_rc)
             per_dir = (int(self.lib.aimnet_engine_hvp_workspace_bytes(self._h, n, n_mol, 2, C.byref(opt)))
                        - int(self.lib.aimnet_engine_hvp_workspace_bytes(self._h, n, n_mol, 1, C.byref(opt))))
             kc = max(1, min(K - k0, self.HVP_BYTES_BUDGET // max(1, per_dir)))
@@ -443,11 +455,13 @@ class HipEngine:
             self.last_status = st
             if st[6]:
                 raise ValueError("HipEngine.hvp: invalid input (atomic numbers outside [0, 63], mol_idx out of range or not sorted)")
-            if st[2] or st[3]:  # neighbour-row overflow: grow and repeat this sweep
+            if st[2] or st[3] or st[5]:  # neighbour-row overflow: grow and repeat this sweep
                 if st[2]:
                     self.max_nb = _round16(int(max(self.max_nb * 1.5, st[0])))
                 if st[3]:
                     self._max_nb_lr[float(dsf_rc)] = _round16(int(max(opt.max_nb_lr * 1.5, st[1])))
+                if st[5]:
+                    self._max_nb_lr[float(dftd3.get("cutoff", 15.0))] = _round16(int(max(opt.max_nb_d3 * 1.5, st[4])))
                 continue
             k0 += kc
         res: dict[str, Any] = {"hv": hv}

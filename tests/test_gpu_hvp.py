@@ -146,3 +146,32 @@ def test_calculator_periodic_hvp_and_dftd3_fallback(oracle64):
     calc.hvp_method = "fd"
     hv_fd = calc.hessian_vector_product(data, v).cpu().numpy()
     assert np.abs(hv - hv_fd).max() <= 5e-3 + 1e-3 * np.abs(hv).max(), np.abs(hv - hv_fd).max()
+
+
+def test_hvp_with_external_dftd3(oracle64):
+    """The dispersion block (central difference of the D3 gradient alone, inside the same call) against the autograd Hessian of
+    the fp64 oracle WITH the D3 term, on config 4's molecule: the block is up to 0.63 eV/A^2 here, the whole operator must stay
+    inside the reference's allclose(1e-3, 1e-3) gate and within 2e-4 eV/A^2."""
+    from aimnetcentral_amd import AIMNet2Calculator, loader
+    from oracle import aimnet2_oracle as O
+
+    gd, t = golden("dftd3"), golden("dftd3_subset")
+    par = dict(s6=float(gd["s6"]), s8=float(gd["s8"]), a1=float(gd["a1"]), a2=float(gd["a2"]), cutoff=15.0, smoothing_fraction=0.2)
+    tables = {k: t[k] for k in ("c6ab", "cn_ref", "rcov", "r4r2")}
+    g = golden("hvp40")
+    H64 = O.evaluate(oracle64, g["coord"], g["numbers"], 0.0, hessian=True, forces=False, dftd3=dict(par, **tables))["hessian"].reshape(120, 120)
+    H64_no = O.evaluate(oracle64, g["coord"], g["numbers"], 0.0, hessian=True, forces=False)["hessian"].reshape(120, 120)
+    assert np.abs(H64 - H64_no).max() > 0.3  # the term matters on this geometry
+    spec = loader.synthetic_spec(0)
+    spec.metadata = dict(spec.metadata, needs_dispersion=True, d3_params={k: par[k] for k in ("s6", "s8", "a1", "a2")})
+    calc = AIMNet2Calculator(spec, device="cuda:0", dftd3_data=tables)
+    data = {"coord": g["coord"], "numbers": g["numbers"], "charge": 0.0}
+    out = calc(data, forces=True, hessian=True)
+    H = out["hessian"].cpu().numpy().reshape(120, 120).astype(np.float64)
+    assert np.allclose(H, H64, rtol=1e-3, atol=1e-3) and np.abs(H - H64).max() <= 2e-4, np.abs(H - H64).max()
+    hv = calc.hessian_vector_product(data, g["v4"]).cpu().numpy().reshape(4, 120)
+    ref = g["v4"].reshape(4, 120).astype(np.float64) @ H64
+    assert np.abs(hv - ref).max() <= 2e-4 + 1e-5 * np.abs(ref).max(), np.abs(hv - ref).max()
+    # the forces returned next to the Hessian carry the term too
+    f64 = O.evaluate(oracle64, g["coord"], g["numbers"], 0.0, dftd3=dict(par, **tables))["forces"]
+    assert_forces_close(out["forces"].cpu().numpy(), f64, "hvp40 + d3")

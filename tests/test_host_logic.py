@@ -262,7 +262,8 @@ class QuadraticEngine(FakeEngine):
 
     def hvp(self, coord, numbers, mol_idx, charge, vectors, **kw):  # the analytic operator of the real engine: H v exactly
         self.hvp_calls = getattr(self, "hvp_calls", [])
-        self.hvp_calls.append(dict(K=int(vectors.shape[0]), charge=charge.clone(), coulomb=kw.get("coulomb"), cell=kw.get("cell")))
+        self.hvp_calls.append(dict(K=int(vectors.shape[0]), charge=charge.clone(), coulomb=kw.get("coulomb"), cell=kw.get("cell"),
+                                   dftd3=kw.get("dftd3")))
         v = vectors.double().reshape(vectors.shape[0], -1)
         return {"hv": (v @ self.A.double()).float().view_as(vectors)}
 

@@ -752,14 +752,20 @@ __global__ __launch_bounds__(256) void hvp_nse_bwd_kernel(const float* __restric
       tqbar_next[((size_t)k * nq + ch) * N + i] = carry_q ? tqr : 0.0f;
     }
   }
-  for (int i = i0; i < i1; ++i) {
-    const size_t trow = (size_t)k * N + i;
-    for (int c = 2 * nq + threadIdx.x; c < ldy; c += blockDim.x) {
-      const int f = c - 2 * nq;
-      if (k == 0) yb[(size_t)i * ldy + c] = f < NF ? abar[(size_t)i * NF + f] : 0.0f;
-      tyb[trow * ldy + c] = f < NF ? tabar[trow * NF + f] : 0.0f;
-    }
-  }
+}
+
+// the feature columns of the same rows: ybar[:, 2 nq + f] = abar[:, f], zero padding beyond (all atoms in parallel - the NSE kernel
+// above runs one block per molecule)
+__global__ void hvp_ybar_a_kernel(const float* __restrict__ abar, const float* __restrict__ tabar, int ldy, int nq, int N, size_t n_t,
+                                  float* __restrict__ yb, float* __restrict__ tyb) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (row = k N + i, column)
+  if (e >= n_t) return;
+  const size_t row = e / ldy;
+  const int c = (int)(e % ldy);
+  if (c < 2 * nq) return;
+  const int f = c - 2 * nq;
+  tyb[e] = f < NF ? tabar[row * NF + f] : 0.0f;
+  if (row < (size_t)N) yb[e] = f < NF ? abar[row * NF + f] : 0.0f;
 }
 
 // ---- external DFT-D3 block: central difference of ITS OWN analytic gradient --------------------------------------------
@@ -1212,6 +1218,8 @@ int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_ev
     hipLaunchKernelGGL(hvp_nse_bwd_kernel, gmk, b256, 0, s, W.qbar[qb], W.tqbar[qb], W.abar, W.tabar, W.y[p - 1], W.ty[p - 1], ldy, nq,
                        W.Fm[p - 1], W.Dm[p - 1], W.tFm[p - 1], W.tDm[p - 1], W.nl.mol_start, n_mol, N, p - 1 > 0 ? 1 : 0, W.g[cur],
                        W.tg[cur], W.qbar[qb ^ 1], W.tqbar[qb ^ 1]);
+    AIMNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hvp_ybar_a_kernel, grid1(kn * ldy), b256, 0, s, W.abar, W.tabar, ldy, nq, N, kn * ldy, W.g[cur], W.tg[cur]);
     AIMNET_LAUNCH_CHECK();
     qb ^= 1;
   }

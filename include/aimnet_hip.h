@@ -168,8 +168,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
 /* Analytic Hessian-vector products H v = d/d eps [dE/dx (x + eps v)] for n_vec directions at once (csrc/hvp.hip: forward-mode
  * tangent sweep through the forward and the backward sweep of the model; specification oracle/aimnet2_analytic.py::evaluate_hvp).
  * `in` / `opt` as for aimnet_engine_eval (opt->flags is ignored; DSF - periodic or not - runs on the neighbour list and needs
- * max_nb_lr > 0; with opt->dftd3 the dispersion block is a central difference of the D3 gradient alone, h = 0.01 A along the
- * normalised direction, all 2 n_vec displaced copies in one batch - as the reference treats its PME block, calculator.py:1777-1781).
+ * max_nb_lr > 0; with opt->dftd3 the dispersion block is a 4-point central difference of the D3 gradient alone, h = 4e-3 A along
+ * the normalised direction, all 4 n_vec displaced copies in one batch - as the reference treats its PME block, calculator.py:1777-1781).
  * vectors [n_vec, n_atoms, 3] and hv [n_vec, n_atoms, 3] are device fp32; forces [n_atoms, 3] (may be NULL) receives the forces
  * of the same sweep; status [8] as aimnet_outputs.status (a raised overflow flag invalidates hv: grow the rows and call again).
  * Any number of molecules / cells (the reference restricts itself to one structure; the host keeps that contract).  Memory:

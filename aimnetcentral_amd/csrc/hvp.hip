@@ -228,15 +228,16 @@ __global__ __launch_bounds__(256) void hvp_conv_fwd_kernel(const float* __restri
 }
 
 // ---- activations -----------------------------------------------------------------------------------------------------
-// forward: h = GELU(z), t_h = GELU'(z) t_z      (z includes the bias; t_z is the bias-free GEMM of the tangent rows)
-__global__ void hvp_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ tz, int ld, int N, size_t n_t,
-                                   float* __restrict__ h, float* __restrict__ th) {
+// forward: h = GELU(z + b), t_h = GELU'(z + b) t_z.  Primal and tangent rows go through ONE bias-free GEMM launch (the primal
+// rows stacked on top of the K N tangent rows), so z is stored without the bias and every consumer adds it
+__global__ void hvp_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ tz, const float* __restrict__ bias, int ld,
+                                   int N, size_t n_t, float* __restrict__ h, float* __restrict__ th) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_t) return;
   const size_t per = (size_t)N * ld;
   const size_t pe = e % per;
   float hv, d1;
-  gelu_and_grad(z[pe], hv, d1);
+  gelu_and_grad(z[pe] + bias[pe % ld], hv, d1);
   th[e] = d1 * tz[e];
   if (e < per) h[e] = hv;
 }
@@ -248,13 +249,13 @@ __device__ __forceinline__ float gelu_grad2(float z) {  // GELU''(z) = phi(z) (2
 // backward: t = g GELU'(z), t_t = t_g GELU'(z) + g GELU''(z) t_z.  g_row0: g is one row broadcast over the atoms (the energy
 // head's last layer, whose tangent is zero: tg == NULL)
 __global__ void hvp_act_bwd_kernel(const float* __restrict__ g, int g_row0, const float* __restrict__ tg,
-                                   const float* __restrict__ z, const float* __restrict__ tz, int ld, int N, size_t n_t,
-                                   float* __restrict__ t, float* __restrict__ tt) {
+                                   const float* __restrict__ z, const float* __restrict__ tz, const float* __restrict__ bias, int ld,
+                                   int N, size_t n_t, float* __restrict__ t, float* __restrict__ tt) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_t) return;
   const size_t per = (size_t)N * ld;
   const size_t pe = e % per;
-  const float zz = z[pe];
+  const float zz = z[pe] + bias[pe % ld];
   float hv, d1;
   gelu_and_grad(zz, hv, d1);
   const float gv = g_row0 ? g[pe % ld] : g[pe];
@@ -858,8 +859,7 @@ struct HvpWs {
   float *y[AIMNET_MAX_PASS], *ty[AIMNET_MAX_PASS];  // output row of pass p's MLP (aliases z when it ends linear)
   float *Fm[AIMNET_MAX_PASS], *Dm[AIMNET_MAX_PASS], *tFm[AIMNET_MAX_PASS], *tDm[AIMNET_MAX_PASS];
   float *hz[AIMNET_MAX_LAYERS], *thz[AIMNET_MAX_LAYERS];
-  float *h[2], *th[2];   // activations between GEMMs / adjoint ping-pong
-  float *g[2], *tg[2];
+  float *h[2], *g[2];    // activations between GEMMs / adjoint ping-pong (stacked: tangent rows follow the N primal rows)
   float *Sbar, *tSbar, *Sqbar, *tSqbar, *abar, *tabar, *qbar[2], *tqbar[2], *xbar, *txbar;
   float* wlast;
   // external DFT-D3 block (4 K displaced copies as one batch)
@@ -900,23 +900,23 @@ void hvp_layout(const aimnet_engine* e, int N, int n_mol, int K, const aimnet_ev
     W.q[p] = c.take<float>(n * nq);
     W.tq[p] = c.take<float>(kn * nq);
     const int ldx = e->mlp[p][0].k_in;
-    W.x[p] = c.take<float>(n * ldx);
-    W.tx[p] = c.take<float>(kn * ldx);
+    W.x[p] = c.take<float>((n + kn) * ldx);  // rows that go through a GEMM: primal rows on top of the tangent rows, one launch
+    W.tx[p] = W.x[p] ? W.x[p] + n * ldx : nullptr;
     W.V[p] = c.take<float>(n * NV * 3);
     W.tV[p] = c.take<float>(kn * NV * 3);
     W.Vq[p] = c.take<float>(n * nq * H_ * 3);
     W.tVq[p] = c.take<float>(kn * nq * H_ * 3);
     const int nl = (int)e->mlp[p].size();
     for (int l = 0; l < nl; ++l) {
-      W.z[p][l] = c.take<float>(n * e->mlp[p][l].k_out);
-      W.tz[p][l] = c.take<float>(kn * e->mlp[p][l].k_out);
+      W.z[p][l] = c.take<float>((n + kn) * e->mlp[p][l].k_out);
+      W.tz[p][l] = W.z[p][l] ? W.z[p][l] + n * e->mlp[p][l].k_out : nullptr;
     }
     if (e->arch.last_linear[p]) {
       W.y[p] = W.z[p][nl - 1];
       W.ty[p] = W.tz[p][nl - 1];
     } else {
-      W.y[p] = c.take<float>(n * e->mlp[p][nl - 1].k_out);
-      W.ty[p] = c.take<float>(kn * e->mlp[p][nl - 1].k_out);
+      W.y[p] = c.take<float>((n + kn) * e->mlp[p][nl - 1].k_out);
+      W.ty[p] = W.y[p] ? W.y[p] + n * e->mlp[p][nl - 1].k_out : nullptr;
     }
     W.Fm[p] = c.take<float>((size_t)n_mol * nq);
     W.Dm[p] = c.take<float>((size_t)n_mol * nq);
@@ -924,14 +924,12 @@ void hvp_layout(const aimnet_engine* e, int N, int n_mol, int K, const aimnet_ev
     W.tDm[p] = c.take<float>((size_t)K * n_mol * nq);
   }
   for (size_t l = 0; l + 1 < e->head.size(); ++l) {
-    W.hz[l] = c.take<float>(n * e->head[l].k_out);
-    W.thz[l] = c.take<float>(kn * e->head[l].k_out);
+    W.hz[l] = c.take<float>((n + kn) * e->head[l].k_out);
+    W.thz[l] = W.hz[l] ? W.hz[l] + n * e->head[l].k_out : nullptr;
   }
   for (int b = 0; b < 2; ++b) {
-    W.h[b] = c.take<float>(n * mw);
-    W.th[b] = c.take<float>(kn * mw);
-    W.g[b] = c.take<float>(n * mw);
-    W.tg[b] = c.take<float>(kn * mw);
+    W.h[b] = c.take<float>((n + kn) * mw);  // stacked like x / z; the tangent rows start N * (row width in use) floats in
+    W.g[b] = c.take<float>((n + kn) * mw);
     W.qbar[b] = c.take<float>(n * nq);
     W.tqbar[b] = c.take<float>(kn * nq);
   }
@@ -976,50 +974,51 @@ void hvp_layout(const aimnet_engine* e, int N, int n_mol, int K, const aimnet_ev
 
 inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
-// forward of one MLP (pass MLP or energy head) on primal and tangent rows; returns the output rows in (*out, *tout)
-int mlp_forward(hipStream_t s, const std::vector<Layer>& Ls, int n_layers, bool last_linear, const float* hin, const float* thin,
-                int N, int K, float* const* z, float* const* tz, float* y, float* ty, HvpWs& W, const float** out,
-                const float** tout) {
+// forward of one MLP (pass MLP or energy head) on the stacked rows [N primal | K N tangent]: one bias-free GEMM per layer
+// (a second, biased one for the primal rows of a layer that ends the MLP linearly), then the activation kernel.
+// `hin` = stacked input rows, `y` = stacked buffer for the output rows of an MLP that ends with GELU (may be NULL: discarded)
+int mlp_forward(hipStream_t s, const std::vector<Layer>& Ls, int n_layers, bool last_linear, const float* hin, int N, int K,
+                float* const* z, float* y, HvpWs& W) {
   const size_t kn = (size_t)K * N;
+  const int M = (int)(kn + N);
   int ld_in = Ls[0].k_in;
   for (int l = 0; l < n_layers; ++l) {
     const Layer& L = Ls[l];
-    RC(launch_gemm_nt(s, EPI_BIAS, hin, ld_in, L.w, L.k_in, N, L.k_out, L.k_in, L.b, z[l], nullptr, L.k_out));
-    RC(launch_gemm_nt(s, EPI_NONE, thin, ld_in, L.w, L.k_in, (int)kn, L.k_out, L.k_in, nullptr, tz[l], nullptr, L.k_out));
-    if (l == n_layers - 1 && last_linear) {
-      hin = z[l];
-      thin = tz[l];
-    } else {
-      float* h = (l == n_layers - 1 && y) ? y : W.h[l & 1];
-      float* th = (l == n_layers - 1 && ty) ? ty : W.th[l & 1];
-      const size_t n_t = kn * L.k_out;
-      hipLaunchKernelGGL(hvp_act_fwd_kernel, grid1(n_t), dim3(256), 0, s, z[l], tz[l], L.k_out, N, n_t, h, th);
-      AIMNET_LAUNCH_CHECK();
-      hin = h;
-      thin = th;
+    const size_t toff = (size_t)N * L.k_out;
+    if (l == n_layers - 1 && last_linear) {  // y = z + b is read as it is: biased primal rows, bias-free tangent rows
+      RC(launch_gemm_nt(s, EPI_BIAS, hin, ld_in, L.w, L.k_in, N, L.k_out, L.k_in, L.b, z[l], nullptr, L.k_out));
+      RC(launch_gemm_nt(s, EPI_NONE, hin + (size_t)N * ld_in, ld_in, L.w, L.k_in, (int)kn, L.k_out, L.k_in, nullptr, z[l] + toff,
+                        nullptr, L.k_out));
+      break;
     }
+    RC(launch_gemm_nt(s, EPI_NONE, hin, ld_in, L.w, L.k_in, M, L.k_out, L.k_in, nullptr, z[l], nullptr, L.k_out));
+    float* h = (l == n_layers - 1 && y) ? y : W.h[l & 1];
+    const size_t n_t = kn * L.k_out;
+    hipLaunchKernelGGL(hvp_act_fwd_kernel, grid1(n_t), dim3(256), 0, s, z[l], z[l] + toff, L.b, L.k_out, N, n_t, h, h + toff);
+    AIMNET_LAUNCH_CHECK();
+    hin = h;
     ld_in = L.k_out;
   }
-  *out = hin;
-  *tout = thin;
   return 0;
 }
 
 // backward of one MLP: (g, tg) = adjoint of its OUTPUT rows (after the last activation) -> adjoint of its input rows.
-// The rows live in the ping-pong pairs W.g[b] / W.tg[b]; *src = index of the pair holding the input, or -1 when the input
+// The rows live in the stacked ping-pong buffers W.g[b] (tangent rows behind the N primal rows); *src = index of the pair holding the input, or -1 when the input
 // is the external broadcast row `g_ext` with a zero tangent (the energy head's last layer).  Every step reads pair src and writes
 // the other one; on return *src names the pair holding the result.
 int mlp_backward(hipStream_t s, const std::vector<Layer>& Ls, int n_layers, bool last_linear, const float* g_ext, int N, int K,
-                 float* const* z, float* const* tz, HvpWs& W, int* src) {
+                 float* const* z, HvpWs& W, int* src) {
   const size_t kn = (size_t)K * N;
+  const int M = (int)(kn + N);
   int cur = *src;
   for (int l = n_layers - 1; l >= 0; --l) {
     const Layer& L = Ls[l];
+    const size_t toff = (size_t)N * L.k_out;
     if (!(l == n_layers - 1 && last_linear)) {
       const int dst = cur == 0 ? 1 : 0;
       const size_t n_t = kn * L.k_out;
       hipLaunchKernelGGL(hvp_act_bwd_kernel, grid1(n_t), dim3(256), 0, s, cur < 0 ? g_ext : W.g[cur], cur < 0 ? 1 : 0,
-                         cur < 0 ? nullptr : W.tg[cur], z[l], tz[l], L.k_out, N, n_t, W.g[dst], W.tg[dst]);
+                         cur < 0 ? nullptr : W.g[cur] + toff, z[l], z[l] + toff, L.b, L.k_out, N, n_t, W.g[dst], W.g[dst] + toff);
       AIMNET_LAUNCH_CHECK();
       cur = dst;
     }
@@ -1027,9 +1026,8 @@ int mlp_backward(hipStream_t s, const std::vector<Layer>& Ls, int n_layers, bool
       set_last_error("hvp: an MLP that ends linear cannot start from the broadcast row");
       return AIMNET_E_INVALID;
     }
-    const int dst = cur ^ 1;
-    RC(launch_gemm_nt(s, EPI_NONE, W.g[cur], L.k_out, L.wt, L.k_out, N, L.k_in, L.k_out, nullptr, W.g[dst], nullptr, L.k_in));
-    RC(launch_gemm_nt(s, EPI_NONE, W.tg[cur], L.k_out, L.wt, L.k_out, (int)kn, L.k_in, L.k_out, nullptr, W.tg[dst], nullptr, L.k_in));
+    const int dst = cur ^ 1;  // one launch for the primal and the tangent rows (W.g is stacked)
+    RC(launch_gemm_nt(s, EPI_NONE, W.g[cur], L.k_out, L.wt, L.k_out, M, L.k_in, L.k_out, nullptr, W.g[dst], nullptr, L.k_in));
     cur = dst;
   }
   *src = cur;
@@ -1132,8 +1130,7 @@ int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_ev
     else HVP_CONV_FWD(2);
 #undef HVP_CONV_FWD
     AIMNET_LAUNCH_CHECK();
-    const float *yo, *tyo;
-    RC(mlp_forward(s, Ls, nl, ar.last_linear[p] != 0, W.x[p], W.tx[p], N, K, W.z[p], W.tz[p], W.y[p], W.ty[p], W, &yo, &tyo));
+    RC(mlp_forward(s, Ls, nl, ar.last_linear[p] != 0, W.x[p], N, K, W.z[p], W.y[p], W));
     if (p < np - 1) {
       hipLaunchKernelGGL(hvp_nse_fwd_kernel, gmk, b256, 0, s, W.y[p], W.ty[p], Ls[nl - 1].k_out, nq, q_p, tq_p, W.nl.mol_start,
                          in->charge, n_mol, N, W.q[p], W.tq[p], W.Fm[p], W.Dm[p], W.tFm[p], W.tDm[p]);
@@ -1146,10 +1143,7 @@ int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_ev
   }
   const int nh = (int)e->head.size();
   {
-    const int nlp = (int)e->mlp[np - 1].size();
-    const float *yo, *tyo;
-    (void)nlp;
-    RC(mlp_forward(s, e->head, nh - 1, false, W.y[np - 1], W.ty[np - 1], N, K, W.hz, W.thz, nullptr, nullptr, W, &yo, &tyo));
+    RC(mlp_forward(s, e->head, nh - 1, false, W.y[np - 1], N, K, W.hz, nullptr, W));
   }
 
   // ---- Coulomb seeds (+ tangents) of qbar / xbar ----
@@ -1183,13 +1177,13 @@ int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_ev
     const int ld = e->head[nh - 2].k_out;
     hipLaunchKernelGGL(hvp_pad_row_kernel, dim3(ceil_div(ld, 256)), b256, 0, s, e->head_w_last, Ll.n_in, ld, W.wlast);
     AIMNET_LAUNCH_CHECK();
-    RC(mlp_backward(s, e->head, nh - 1, false, W.wlast, N, K, W.hz, W.thz, W, &cur));
+    RC(mlp_backward(s, e->head, nh - 1, false, W.wlast, N, K, W.hz, W, &cur));
   }
   for (int p = np - 1; p >= 0; --p) {
     const std::vector<Layer>& Ls = e->mlp[p];
     const int nl = (int)Ls.size(), ldx = Ls[0].k_in;
-    RC(mlp_backward(s, Ls, nl, ar.last_linear[p] != 0, nullptr, N, K, W.z[p], W.tz[p], W, &cur));
-    const float *xb = W.g[cur], *txb = W.tg[cur];
+    RC(mlp_backward(s, Ls, nl, ar.last_linear[p] != 0, nullptr, N, K, W.z[p], W, &cur));
+    const float *xb = W.g[cur], *txb = W.g[cur] + (size_t)N * ldx;
     const float* a_p = p == 0 ? e->afv : W.a[p];
     const int* row_of = p == 0 ? in->numbers : nullptr;
     const float *q_p = p > 0 ? W.q[p - 1] : nullptr, *tq_p = p > 0 ? W.tq[p - 1] : nullptr;
@@ -1217,9 +1211,9 @@ int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_ev
     cur ^= 1;  // xb has been consumed: the adjoint rows of pass p-1's MLP output go into the other ping-pong pair
     hipLaunchKernelGGL(hvp_nse_bwd_kernel, gmk, b256, 0, s, W.qbar[qb], W.tqbar[qb], W.abar, W.tabar, W.y[p - 1], W.ty[p - 1], ldy, nq,
                        W.Fm[p - 1], W.Dm[p - 1], W.tFm[p - 1], W.tDm[p - 1], W.nl.mol_start, n_mol, N, p - 1 > 0 ? 1 : 0, W.g[cur],
-                       W.tg[cur], W.qbar[qb ^ 1], W.tqbar[qb ^ 1]);
+                       W.g[cur] + (size_t)N * ldy, W.qbar[qb ^ 1], W.tqbar[qb ^ 1]);
     AIMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(hvp_ybar_a_kernel, grid1(kn * ldy), b256, 0, s, W.abar, W.tabar, ldy, nq, N, kn * ldy, W.g[cur], W.tg[cur]);
+    hipLaunchKernelGGL(hvp_ybar_a_kernel, grid1(kn * ldy), b256, 0, s, W.abar, W.tabar, ldy, nq, N, kn * ldy, W.g[cur], W.g[cur] + (size_t)N * ldy);
     AIMNET_LAUNCH_CHECK();
     qb ^= 1;
   }

@@ -25,7 +25,9 @@ TFLOP/s fp32-matrix peak is reported beside it.  `exact_f32` is the same measure
 exact-fp32 MFMA kernels (engine option gemm_bf3 = 0), taken after the timed region.  `parity`
 compares the engine with the CPU oracle on the samples the CPU baseline is timed on (untimed).
 `cpu_baseline` times the oracle (torch-CPU eager restatement of the reference op sequence, kind
-"port") on the host cores on a bounded sample of the same workload, rank 0 at N=1 only.  With
+"port") on the host cores on a bounded sample of the same workload, rank 0 at N=1 only.
+`hessian_config4` (N = 1): BASELINE configs[3], the 40-atom dense Hessian by the analytic tangent sweep against the reference's
+golden at the reference's own gate, with its cost in force evaluations.  With
 --gpus N > 1 the line also carries `scaling_md1024`: BASELINE configs[4] (128 frames x 50 atoms per
 GPU, per-frame energies all-gathered over RCCL every step) timed in the same run.
 """
@@ -239,6 +241,45 @@ def pmc_traffic(workload):
 # number of neighbours inside the 5 A cutoff: MLP forward + input-gradient backward, conv_a / conv_q forward and backward, AEV, agh
 def e2e_flops_per_atom(mean_nb: float) -> float:
     return 2 * (2 * 2_181_760) + 3 * (2048 + 4096) * mean_nb + 2 * (128 + 256) * mean_nb + 300 * mean_nb + 170_000
+
+
+def hessian_config4(eng):
+    """BASELINE configs[3] in the same run (untimed region): the dense Hessian of the 40-atom fixture by the analytic tangent sweep
+    (csrc/hvp.hip, 120 directions in one call) against the reference's own double-backward Hessian (tests/golden/hvp40.npz, made by
+    the unmodified reference: tests/golden/make_golden.py) at the reference's gate allclose(rtol = atol = 1e-3) (tests/test_hvp.py:75),
+    with its cost next to one force evaluation of the same molecule."""
+    import numpy as np
+    import torch
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "hvp40.npz"))
+    dev = eng.device
+    t = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a)).to(device=dev, dtype=dt)  # noqa: E731
+    args = (t(g["coord"]), t(g["numbers"], torch.int32), torch.zeros(40, dtype=torch.int32, device=dev), t([float(g["charge"])]))
+    eye = torch.eye(120, device=dev).view(120, 40, 3)
+
+    def clock(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    H = eng.hvp(*args, eye)["hv"].view(120, 120)
+    H = (0.5 * (H + H.T)).cpu().numpy()
+    Href = g["hessian"].reshape(120, 120)
+    v4 = t(g["v4"])
+    hv4 = eng.hvp(*args, v4)["hv"].cpu().numpy()
+    ms_h, ms_1 = clock(lambda: eng.hvp(*args, eye), 10), clock(lambda: eng.hvp(*args, v4[:1]), 10)
+    ms_f = clock(lambda: eng.eval(*args, forces=True), 10)
+    return {"workload": "hvp40: 40 atoms, dense Hessian = 120 directions in one tangent sweep (BASELINE configs[3])",
+            "hessian_ms": ms_h, "one_direction_ms": ms_1, "force_eval_ms": ms_f,
+            "force_evals_per_direction": {"dense": ms_h / 120.0 / ms_f, "single": ms_1 / ms_f},
+            "dH_max": float(np.abs(H - Href).max()), "dHv4_max": float(np.abs(hv4 - g["hv4"]).max()),
+            "H_abs_max": float(np.abs(Href).max()), "reference": "tests/golden/hvp40.npz (reference double backward, fp32)",
+            "gate": "allclose(rtol=1e-3, atol=1e-3) elementwise (tests/test_hvp.py:75)",
+            "ok": bool(np.allclose(H, Href, rtol=1e-3, atol=1e-3) and np.allclose(hv4, g["hv4"], rtol=1e-3, atol=1e-3))}
 
 
 def main():
@@ -456,6 +497,8 @@ def main():
                 if k not in oracle_out:
                     oracle_out[k] = smp["step"]()
             out["parity"] = parity_gate(eng, samples, oracle_out)
+        if world == 1:
+            out["hessian_config4"] = hessian_config4(eng)
         print(json.dumps(out))
     if distributed:
         dist.barrier()  # the other ranks wait here while rank 0 finishes its per-family pass and prints

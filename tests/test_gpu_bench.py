@@ -33,6 +33,9 @@ def test_single_gpu_json_contract():
     # the record of the exact-fp32 kernels rides on the same line (measured after the timed region)
     ex = d["exact_f32"]
     assert ex["value"] > 0 and ex["roofline"]["peak"] == 157.3 and "bf16x3" in d["dtype"] and d["roofline"]["peak_fp32_matrix"] == 157.3
+    # BASELINE config 4 in the same run: the analytic Hessian at the reference's own gate, and well inside it
+    h4 = d["hessian_config4"]
+    assert h4["ok"] is True and h4["dH_max"] <= 1e-4 and h4["dHv4_max"] <= 4e-4 and h4["force_evals_per_direction"]["dense"] < 0.2
 
 
 def test_default_workload_carries_the_parity_gate():

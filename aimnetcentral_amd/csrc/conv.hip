@@ -55,8 +55,11 @@ struct FwdWaveLds {
 //   S_i[a,g,c] = sum_z afv[z][a,g] M_i[z][g,c],   M_i[z][g,c] = sum_{j: Z_j = z} gs_g(d_ij) (1,u_ij)_c :
 // the chunk's neighbours are ordered by element, the pair loop accumulates ONE number per lane (g,c) and pair (no row gather,
 // no 16 FMAs per lane), and each element present costs one 16-FMA flush.  The forward twin of the species-moment backward.
+#ifndef AIMNET_PROBE_FWD_OCC
+#define AIMNET_PROBE_FWD_OCC 4
+#endif
 template <int NQ, bool SPLIT, bool P0M = false>
-__global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
+__global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
                                                       const float* __restrict__ q,
                                                       const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
                                                       const float4* __restrict__ pg, int cap,
@@ -179,7 +182,11 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
         float v = 0.0f;
         if (mm < nch) {
           const float dd = L.ud[mm].w - shift_l;
+#ifdef AIMNET_PROBE_FWD_NO_EXP  // measurement builds only: what the 16 exponentials per pair cost
+          v = (1.0f - bp.eta * dd * dd) * L.fc[mm];
+#else
           v = exp_neg(-bp.eta * dd * dd) * L.fc[mm];
+#endif
         }
         L.gs[mm][g] = v;
       }
@@ -237,6 +244,24 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
         }
         if (cur >= 0) flush(cur, accm);
       } else {
+#ifdef AIMNET_PROBE_FWD_DEEP  // measurement builds only: eight row loads in flight per wave instead of four
+        const int nch8 = (nch + 7) & ~7;
+        int4 jj = *reinterpret_cast<const int4*>(&L.j[0]);
+        int4 jk = *reinterpret_cast<const int4*>(&L.j[4]);
+        float4 r0 = rowj(jj.x), r1 = rowj(jj.y), r2 = rowj(jj.z), r3 = rowj(jj.w);
+        float4 r4 = rowj(jk.x), r5 = rowj(jk.y), r6 = rowj(jk.z), r7 = rowj(jk.w);
+        for (int mm = 0; mm < nch8; mm += 8) {
+          const float4 c0 = r0, c1 = r1, c2 = r2, c3 = r3, c4 = r4, c5 = r5, c6 = r6, c7 = r7;
+          if (mm + 8 < nch8) {
+            jj = *reinterpret_cast<const int4*>(&L.j[mm + 8]);
+            jk = *reinterpret_cast<const int4*>(&L.j[mm + 12]);
+            r0 = rowj(jj.x); r1 = rowj(jj.y); r2 = rowj(jj.z); r3 = rowj(jj.w);
+            r4 = rowj(jk.x); r5 = rowj(jk.y); r6 = rowj(jk.z); r7 = rowj(jk.w);
+          }
+          use(mm, c0); use(mm + 1, c1); use(mm + 2, c2); use(mm + 3, c3);
+          use(mm + 4, c4); use(mm + 5, c5); use(mm + 6, c6); use(mm + 7, c7);
+        }
+#else
         const int nch4 = (nch + 3) & ~3;  // rows >= nch have gs = 0 and a valid (clamped) index: harmless
         // (the four ids of a group come with one uniform-address ds_read_b128; mm + 4 <= 60 inside the guard)
         int4 jj = *reinterpret_cast<const int4*>(&L.j[0]);
@@ -249,6 +274,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
           }
           use(mm, c0); use(mm + 1, c1); use(mm + 2, c2); use(mm + 3, c3);
         }
+#endif
       }
     }
     if (!SPLIT) prefetch_atom(i0 + al.step);  // lands under the epilogue below
@@ -308,8 +334,13 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void conv_fwd_kernel(const floa
         const int o = lane + 64 * t;  // (a, h) = (o / 12, o % 12)
         const int aa = o / H_, hh = o % H_;
         float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#ifdef AIMNET_PROBE_FWD_NO_EPI  // measurement builds only (tests/tools/variant.sh): what the agh contraction costs
+#pragma unroll 1
+        for (int g = 0; g < 1; ++g) {
+#else
 #pragma unroll UNR_G
         for (int g = 0; g < G_; ++g) {
+#endif
           const float w = s_agh[(aa * G_ + g) * H_ + hh];
           const float* s3 = &sv[(aa * G_ + g) * 3];
           v0 += w * s3[0];
@@ -363,7 +394,7 @@ int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, co
   const bool split = n_atoms <= split_max;
   // (one-wave-per-atom form: exactly the 4 blocks per CU that are resident - with twice as many the second half only queues
   // behind the first and pays the block prologue again: 0.217 -> 0.207 ms/step over the three launches)
-  const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), device_cus() * 4);
+  const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), device_cus() * AIMNET_PROBE_FWD_OCC);
   if (species_moments && row_of && nq == 0 && !split) {  // pass 0 of a large system: per-element moments instead of row gathers
     hipLaunchKernelGGL((conv_fwd_kernel<0, false, true>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a,
                        agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order);

@@ -104,3 +104,9 @@ struct aimnet_engine {
   int prof_last = -2;
 };
 
+namespace aimnet {
+// One MLP GEMM C = epilogue(A . W^T) (fwd) or C = epilogue(A . W) (bwd) over a sub-block of the layer, on the kernel family the
+// engine's `gemm_bf3` switch selects (engine.hip)
+int mlp_gemm(const aimnet_engine* e, hipStream_t s, int epi, const float* A, int lda, const Layer& L, bool fwd, int k0, int n0, int M,
+             int N, int K, const float* bias, float* C, float* D, int ldc, const int* brow = nullptr, int ldbias = 0);
+}  // namespace aimnet

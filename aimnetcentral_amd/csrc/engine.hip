@@ -97,11 +97,14 @@ int upload_layer(aimnet_engine* e, const float* w, const float* b, int n_in, int
   return 0;
 }
 
+}  // namespace
+
+namespace aimnet {
 // One MLP GEMM C = epilogue(A . W^T) (fwd: W = L.w [k_out][k_in]) or C = epilogue(A . W) (bwd: L.wt [k_in][k_out]) over the
 // operand's k-columns [k0, k0 + K) (fwd) resp. output rows [n0, n0 + N) (bwd) - the sub-blocks the embedding-bias table and the
 // pass-0 backward use.  Picks the bf16x3-split kernel or the exact-fp32 one (aimnet_engine::gemm_bf3).
 int mlp_gemm(const aimnet_engine* e, hipStream_t s, int epi, const float* A, int lda, const Layer& L, bool fwd, int k0, int n0, int M,
-             int N, int K, const float* bias, float* C, float* D, int ldc, const int* brow = nullptr, int ldbias = 0) {
+             int N, int K, const float* bias, float* C, float* D, int ldc, const int* brow, int ldbias) {
   const int ldw = fwd ? L.k_in : L.k_out;  // row stride of the weight operand
   const bool bf3 = e->gemm_bf3 == 2 || (e->gemm_bf3 == 1 && M > 256);
   if (bf3) {
@@ -112,6 +115,9 @@ int mlp_gemm(const aimnet_engine* e, hipStream_t s, int epi, const float* A, int
   const float* w = (fwd ? L.w : L.wt) + (size_t)n0 * ldw + k0;
   return launch_gemm_nt(s, epi, A, lda, w, ldw, M, N, K, bias, C, D, ldc, brow, ldbias);
 }
+}  // namespace aimnet
+
+namespace {
 
 // ---- workspace layout ---------------------------------------------------------------------------
 struct Carver {

@@ -8,8 +8,9 @@
 // oracle/aimnet2_analytic.py::evaluate_hvp (pinned to the autograd Hessian in fp64, tests/test_oracle_analytic.py).
 //
 // Shape of the computation.  Every quantity X of the force evaluation gets a tangent tX with a leading direction axis:
-// primal arrays are [N][w], tangent arrays [K][N][w].  Linear steps (the MLP GEMMs) are the SAME GEMM on the K N tangent rows
-// (gemm.hip, exact-fp32 MFMA kernels, no bias); the nonlinear steps are the kernels below, one block (or wave) per
+// primal arrays are [N][w], tangent arrays [K][N][w].  Linear steps (the MLP GEMMs) are the SAME GEMM on the stacked rows
+// [N primal | K N tangent] (the engine's GEMM family through mlp_gemm: gemm_bf3.hip above 256 rows, the exact-fp32 kernels of
+// gemm.hip below; no bias); the nonlinear steps are the kernels below, one block (or wave) per
 // (atom, direction): it recomputes the primal values it needs from the primal inputs (pair geometry, radial basis, the
 // centre's own moments) and applies the product rule.  A block with k == 0 also WRITES the primal outputs, so one sweep
 // produces the forces as well; no kernel reads a primal array that the same launch writes.  All pair kernels keep the
@@ -666,6 +667,8 @@ __global__ __launch_bounds__(256) void hvp_conv_bwd_kernel(bool need_abar, const
     stage_chunk(st, i, m0, cnt, nb_idx, pg, cap, tvk, bp);
     const float shift = s_shift[g];
     const int mc = min(HCH, cnt - m0);
+    // (requesting the NEXT neighbour's four rows before this one's arithmetic was measured slower: 3.0 -> 4.5 ms per sweep on
+    // 10 080 atoms - ten more live registers across ~250 instructions of product-rule terms)
     for (int m = 0; m < mc; ++m) {
       const float4 u = st.u[m], tu = st.tu[m], fc = st.fc[m];
       const int j = st.j[m];
@@ -977,8 +980,8 @@ inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 // forward of one MLP (pass MLP or energy head) on the stacked rows [N primal | K N tangent]: one bias-free GEMM per layer
 // (a second, biased one for the primal rows of a layer that ends the MLP linearly), then the activation kernel.
 // `hin` = stacked input rows, `y` = stacked buffer for the output rows of an MLP that ends with GELU (may be NULL: discarded)
-int mlp_forward(hipStream_t s, const std::vector<Layer>& Ls, int n_layers, bool last_linear, const float* hin, int N, int K,
-                float* const* z, float* y, HvpWs& W) {
+int mlp_forward(const aimnet_engine* e, hipStream_t s, const std::vector<Layer>& Ls, int n_layers, bool last_linear, const float* hin,
+                int N, int K, float* const* z, float* y, HvpWs& W) {
   const size_t kn = (size_t)K * N;
   const int M = (int)(kn + N);
   int ld_in = Ls[0].k_in;
@@ -986,12 +989,12 @@ int mlp_forward(hipStream_t s, const std::vector<Layer>& Ls, int n_layers, bool 
     const Layer& L = Ls[l];
     const size_t toff = (size_t)N * L.k_out;
     if (l == n_layers - 1 && last_linear) {  // y = z + b is read as it is: biased primal rows, bias-free tangent rows
-      RC(launch_gemm_nt(s, EPI_BIAS, hin, ld_in, L.w, L.k_in, N, L.k_out, L.k_in, L.b, z[l], nullptr, L.k_out));
-      RC(launch_gemm_nt(s, EPI_NONE, hin + (size_t)N * ld_in, ld_in, L.w, L.k_in, (int)kn, L.k_out, L.k_in, nullptr, z[l] + toff,
-                        nullptr, L.k_out));
+      RC(mlp_gemm(e, s, EPI_BIAS, hin, ld_in, L, true, 0, 0, N, L.k_out, L.k_in, L.b, z[l], nullptr, L.k_out));
+      RC(mlp_gemm(e, s, EPI_NONE, hin + (size_t)N * ld_in, ld_in, L, true, 0, 0, (int)kn, L.k_out, L.k_in, nullptr, z[l] + toff, nullptr,
+                  L.k_out));
       break;
     }
-    RC(launch_gemm_nt(s, EPI_NONE, hin, ld_in, L.w, L.k_in, M, L.k_out, L.k_in, nullptr, z[l], nullptr, L.k_out));
+    RC(mlp_gemm(e, s, EPI_NONE, hin, ld_in, L, true, 0, 0, M, L.k_out, L.k_in, nullptr, z[l], nullptr, L.k_out));
     float* h = (l == n_layers - 1 && y) ? y : W.h[l & 1];
     const size_t n_t = kn * L.k_out;
     hipLaunchKernelGGL(hvp_act_fwd_kernel, grid1(n_t), dim3(256), 0, s, z[l], z[l] + toff, L.b, L.k_out, N, n_t, h, h + toff);
@@ -1006,8 +1009,8 @@ int mlp_forward(hipStream_t s, const std::vector<Layer>& Ls, int n_layers, bool 
 // The rows live in the stacked ping-pong buffers W.g[b] (tangent rows behind the N primal rows); *src = index of the pair holding the input, or -1 when the input
 // is the external broadcast row `g_ext` with a zero tangent (the energy head's last layer).  Every step reads pair src and writes
 // the other one; on return *src names the pair holding the result.
-int mlp_backward(hipStream_t s, const std::vector<Layer>& Ls, int n_layers, bool last_linear, const float* g_ext, int N, int K,
-                 float* const* z, HvpWs& W, int* src) {
+int mlp_backward(const aimnet_engine* e, hipStream_t s, const std::vector<Layer>& Ls, int n_layers, bool last_linear,
+                 const float* g_ext, int N, int K, float* const* z, HvpWs& W, int* src) {
   const size_t kn = (size_t)K * N;
   const int M = (int)(kn + N);
   int cur = *src;
@@ -1027,7 +1030,7 @@ int mlp_backward(hipStream_t s, const std::vector<Layer>& Ls, int n_layers, bool
       return AIMNET_E_INVALID;
     }
     const int dst = cur ^ 1;  // one launch for the primal and the tangent rows (W.g is stacked)
-    RC(launch_gemm_nt(s, EPI_NONE, W.g[cur], L.k_out, L.wt, L.k_out, M, L.k_in, L.k_out, nullptr, W.g[dst], nullptr, L.k_in));
+    RC(mlp_gemm(e, s, EPI_NONE, W.g[cur], L.k_out, L, false, 0, 0, M, L.k_in, L.k_out, nullptr, W.g[dst], nullptr, L.k_in));
     cur = dst;
   }
   *src = cur;
@@ -1130,7 +1133,7 @@ int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_ev
     else HVP_CONV_FWD(2);
 #undef HVP_CONV_FWD
     AIMNET_LAUNCH_CHECK();
-    RC(mlp_forward(s, Ls, nl, ar.last_linear[p] != 0, W.x[p], N, K, W.z[p], W.y[p], W));
+    RC(mlp_forward(e, s, Ls, nl, ar.last_linear[p] != 0, W.x[p], N, K, W.z[p], W.y[p], W));
     if (p < np - 1) {
       hipLaunchKernelGGL(hvp_nse_fwd_kernel, gmk, b256, 0, s, W.y[p], W.ty[p], Ls[nl - 1].k_out, nq, q_p, tq_p, W.nl.mol_start,
                          in->charge, n_mol, N, W.q[p], W.tq[p], W.Fm[p], W.Dm[p], W.tFm[p], W.tDm[p]);
@@ -1143,7 +1146,7 @@ int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_ev
   }
   const int nh = (int)e->head.size();
   {
-    RC(mlp_forward(s, e->head, nh - 1, false, W.y[np - 1], N, K, W.hz, nullptr, W));
+    RC(mlp_forward(e, s, e->head, nh - 1, false, W.y[np - 1], N, K, W.hz, nullptr, W));
   }
 
   // ---- Coulomb seeds (+ tangents) of qbar / xbar ----
@@ -1177,12 +1180,12 @@ int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_ev
     const int ld = e->head[nh - 2].k_out;
     hipLaunchKernelGGL(hvp_pad_row_kernel, dim3(ceil_div(ld, 256)), b256, 0, s, e->head_w_last, Ll.n_in, ld, W.wlast);
     AIMNET_LAUNCH_CHECK();
-    RC(mlp_backward(s, e->head, nh - 1, false, W.wlast, N, K, W.hz, W, &cur));
+    RC(mlp_backward(e, s, e->head, nh - 1, false, W.wlast, N, K, W.hz, W, &cur));
   }
   for (int p = np - 1; p >= 0; --p) {
     const std::vector<Layer>& Ls = e->mlp[p];
     const int nl = (int)Ls.size(), ldx = Ls[0].k_in;
-    RC(mlp_backward(s, Ls, nl, ar.last_linear[p] != 0, nullptr, N, K, W.z[p], W, &cur));
+    RC(mlp_backward(e, s, Ls, nl, ar.last_linear[p] != 0, nullptr, N, K, W.z[p], W, &cur));
     const float *xb = W.g[cur], *txb = W.g[cur] + (size_t)N * ldx;
     const float* a_p = p == 0 ? e->afv : W.a[p];
     const int* row_of = p == 0 ? in->numbers : nullptr;

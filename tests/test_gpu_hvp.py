@@ -175,3 +175,25 @@ def test_hvp_with_external_dftd3(oracle64):
     # the forces returned next to the Hessian carry the term too
     f64 = O.evaluate(oracle64, g["coord"], g["numbers"], 0.0, dftd3=dict(par, **tables))["forces"]
     assert_forces_close(out["forces"].cpu().numpy(), f64, "hvp40 + d3")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_hvp_fuzz_random_molecules(hip_engine, oracle64, seed):
+    """Seeded random organic geometries (the generator of BASELINE config 2: contacts down to 0.9 A, |H v| of several hundred
+    eV/A^2), charged and neutral, one to three molecules per call: the sweep against the fp64 specification."""
+    from aimnetcentral_amd import workloads
+
+    rng = np.random.default_rng(100 + seed)
+    n_mol = 1 + seed % 3
+    cs, zs, ms = [], [], []
+    for m in range(n_mol):
+        c, z = workloads.random_organic(int(rng.integers(8, 40)), rng)
+        cs.append(c)
+        zs.append(z)
+        ms.append(np.full(len(z), m))
+    coord, numbers, mol = np.concatenate(cs).astype(np.float32), np.concatenate(zs), np.concatenate(ms)
+    charge = rng.integers(-1, 2, size=n_mol).astype(np.float32)
+    V = rng.standard_normal((2, len(numbers), 3)).astype(np.float32)
+    spec, hv, f = _spec_and_engine(hip_engine, oracle64, coord, numbers, charge, mol, V)
+    _close(hv, spec["hv"], f"fuzz seed {seed}")
+    assert_forces_close(f, spec["forces"], f"fuzz seed {seed} (forces of the sweep)")

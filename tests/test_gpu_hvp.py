@@ -146,6 +146,20 @@ def test_calculator_periodic_hvp_and_dftd3_fallback(oracle64):
     calc.hvp_method = "fd"
     hv_fd = calc.hessian_vector_product(data, v).cpu().numpy()
     assert np.abs(hv - hv_fd).max() <= 5e-3 + 1e-3 * np.abs(hv).max(), np.abs(hv - hv_fd).max()
+    # the same cell with the external DFT-D3 term (periodic D3 list, 15 A): sweep + D3 block against the finite-difference operator
+    gd, t = golden("dftd3"), golden("dftd3_subset")
+    spec = loader.synthetic_spec(0)
+    spec.metadata = dict(spec.metadata, needs_dispersion=True,
+                         d3_params={k: float(gd[k]) for k in ("s6", "s8", "a1", "a2")})
+    cd3 = AIMNet2Calculator(spec, device="cuda:0", dftd3_data={k: t[k] for k in ("c6ab", "cn_ref", "rcov", "r4r2")})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cd3.set_lrcoulomb_method("dsf", cutoff=8.0, dsf_alpha=0.25)
+    hv3 = cd3.hessian_vector_product(data, v).cpu().numpy()
+    cd3.hvp_method = "fd"
+    hv3_fd = cd3.hessian_vector_product(data, v).cpu().numpy()
+    assert np.abs(hv3 - hv3_fd).max() <= 5e-3 + 1e-3 * np.abs(hv3).max(), np.abs(hv3 - hv3_fd).max()
+    assert np.abs(hv3 - hv).max() > 1e-3  # the term is there
 
 
 def test_hvp_with_external_dftd3(oracle64):

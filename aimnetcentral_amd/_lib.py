@@ -11,7 +11,7 @@ import os
 from functools import lru_cache
 
 MAX_PASS, MAX_LAYERS, MAX_SHIFTS = 4, 6, 32
-ABI_VERSION = 6  # AIMNET_ABI_VERSION of include/aimnet_hip.h this binding was written against
+ABI_VERSION = 7  # AIMNET_ABI_VERSION of include/aimnet_hip.h this binding was written against
 FORCES, STRESS = 1, 2
 COULOMB_NONE, COULOMB_SIMPLE, COULOMB_DSF = 0, 1, 2
 E_INVALID, E_HIP, E_WORKSPACE = -1, -2, -3
@@ -98,6 +98,16 @@ class Inputs(C.Structure):
         ("n_cell", C.c_int32),
         ("pbc", C.c_int32 * 3),
         ("pbc_sys", C.c_void_p),
+        # optional caller-supplied neighbour matrices (include/aimnet_hip.h): all NULL = the engine builds its lists
+        ("nbmat", C.c_void_p),
+        ("shifts", C.c_void_p),
+        ("nbmat_width", C.c_int32),
+        ("nbmat_lr", C.c_void_p),
+        ("shifts_lr", C.c_void_p),
+        ("nbmat_lr_width", C.c_int32),
+        ("nbmat_d3", C.c_void_p),
+        ("shifts_d3", C.c_void_p),
+        ("nbmat_d3_width", C.c_int32),
     ]
 
 

@@ -12,8 +12,10 @@ Deliberate deviations, all loud:
   * Ewald / PME, torch.compile and training mode raise NotImplementedError (SURVEY.md 8f "next" rows); open-shell NSE
     (2-channel) models ARE supported (`mult` input, `spin_charges` output); external DFT-D3 needs the reference's table
     file (loader.load_dftd3_tables);
-  * caller-supplied neighbour matrices (`nbmat`, `nbmat_lr`, `shifts`, `shifts_lr`) raise NotImplementedError: the engine
-    always builds its own lists on the device;
+  * caller-supplied neighbour matrices (`nbmat`, `nbmat_lr`, `shifts`, `shifts_lr`) are handed to the engine as the reference
+    hands them to the model (no list is built, coordinates as given) for flat 2D input; they must be FULL matrices (both
+    directions of every pair, as the reference's builders emit them - the short-range one is verified on the device); with
+    hessian=True / hessian_vector_product they raise NotImplementedError;
   * (per-system `pbc` flags of shape (B, 3) are supported: the engine takes them as a device array);
   * hessian=True and hessian_vector_product run the analytic tangent sweep of csrc/hvp.hip (forward-mode through the
     forward and backward sweep, all directions at once; `hvp_method`), not autograd double backward: exact second derivatives
@@ -354,6 +356,52 @@ class AIMNet2Calculator:
                 ret[k] = v.unsqueeze(0)
         return ret
 
+    def _caller_lists(self, d: dict[str, Any]) -> dict[str, Any]:
+        """Caller-supplied neighbour matrices (`nbmat`, `shifts`, `nbmat_lr`, `shifts_lr` - the four list keys the reference
+        converts, calculator.py:131-142): with `nbmat` present the reference skips its list builder and hands the matrices to the
+        model as they are (calculator.py:1069-1071).  Here they go to the engine in the same role (aimnet_inputs.nbmat): flat 2D
+        input only; rows (N, M) or, as the reference's `pad_input` expects them, (N + 1, M) with the padding row last; entries
+        >= N are padding; shifts are integer lattice multiples (the reference stores them as floats)."""
+        import torch
+
+        if "nbmat" not in d:
+            for k in ("nbmat_lr", "shifts", "shifts_lr"):
+                if k in d:
+                    raise ValueError(f"caller-supplied {k!r} is only read together with 'nbmat'")
+            return {}
+        if d["coord"].ndim != 2:
+            raise NotImplementedError("caller-supplied 'nbmat' is supported for flat (N, 3) coordinates only")
+        n = d["coord"].shape[0]
+        out: dict[str, Any] = {}
+        for mat_key, sh_key, role in (("nbmat", "shifts", "nbmat"), ("nbmat_lr", "shifts_lr", "nbmat_lr")):
+            if mat_key not in d:
+                if sh_key in d:
+                    raise ValueError(f"{sh_key!r} given without {mat_key!r}")
+                continue
+            mat = d[mat_key]
+            if mat.ndim != 2 or mat.shape[0] not in (n, n + 1):
+                raise ValueError(f"{mat_key} must have shape ({n}, M) or ({n + 1}, M) (padding row last), got {tuple(mat.shape)}")
+            out[role] = mat[:n].to(torch.int32)
+            if sh_key in d:
+                sh = d[sh_key]
+                if sh.ndim != 3 or sh.shape[0] != mat.shape[0] or sh.shape[1] != mat.shape[1] or sh.shape[2] != 3:
+                    raise ValueError(f"{sh_key} must have shape {tuple(mat.shape) + (3,)}, got {tuple(sh.shape)}")
+                out["shifts" + role[5:]] = sh[:n].round().to(torch.int32)
+        return out
+
+    def _check_caller_lists(self, ext: dict[str, Any], method, cell) -> dict[str, Any]:
+        """What the model would look up itself: the external Coulomb / DFT-D3 modules read the `_lr` matrices (nbops.resolve_suffix)
+        and fail without them; periodic input needs the shifts."""
+        if not ext:
+            return {}
+        if "nbmat_lr" not in ext and (method in ("simple", "dsf") or self._dftd3_options() is not None):
+            raise KeyError("nbmat_lr: with a caller-supplied 'nbmat' the external Coulomb / DFT-D3 terms need 'nbmat_lr' as well")
+        if cell is not None and ("shifts" not in ext or ("nbmat_lr" in ext and "shifts_lr" not in ext)):
+            raise KeyError("shifts: caller-supplied neighbour matrices of a periodic system need their shifts")
+        if cell is None:
+            ext = {k: v for k, v in ext.items() if not k.startswith("shifts")}
+        return ext
+
     def eval(self, data: dict[str, Any], forces=False, stress=False, hessian=False, *, validate_species: bool = True,
              host_out: bool = False, defer_status: bool = False) -> dict[str, Any]:
         """calculator.py:879-947.  `host_out=True` (not in the reference) returns CPU tensors that arrived with the engine's one
@@ -368,10 +416,8 @@ class AIMNet2Calculator:
         if hessian:
             return self._eval_hessian(data, forces=forces, stress=stress, validate_species=validate_species)
         d = self.to_input_tensors(data)
-        for k in ("nbmat", "nbmat_lr", "shifts", "shifts_lr"):
-            if k in d:
-                raise NotImplementedError(f"caller-supplied {k!r} is not supported: the engine builds its own neighbour lists")
         coord, numbers, charge = d["coord"], d["numbers"], d["charge"]
+        ext_lists = self._caller_lists(d)
         cell = d.get("cell")
         pbc = d.get("pbc")
         if stress and cell is None:
@@ -449,7 +495,8 @@ class AIMNet2Calculator:
                 coord_f, numbers_f, mol_idx, self._engine_charge(charge, d.get("mult")), cell=cell, pbc=pbc3, forces=bool(forces),
                 stress=bool(stress),
                 coulomb=method or "none", dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, dftd3=self._dftd3_options(),
-                **({"host_out": True} if host_out else {}), **({"sync": False, "defer": True} if defer_status else {}))
+                **({"host_out": True} if host_out else {}), **({"sync": False, "defer": True} if defer_status else {}),
+                **self._check_caller_lists(ext_lists, method, cell))
         finally:
             if restore is not None:
                 (self._coulomb_method, self._coulomb_cutoff, self.cutoff_lr, self._dsf_alpha, self._dsf_rc) = restore
@@ -489,6 +536,10 @@ class AIMNet2Calculator:
         import torch
 
         d = self.to_input_tensors(data)
+        for k in ("nbmat", "nbmat_lr", "shifts", "shifts_lr"):
+            if k in d:
+                raise NotImplementedError(f"{what}: caller-supplied {k!r} is not supported (the tangent sweep and the displaced "
+                                          "copies of the finite-difference operator build their own lists)")
         coord = d["coord"]
         if coord.ndim == 3:
             if coord.shape[0] != 1:

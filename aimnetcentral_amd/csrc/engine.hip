@@ -610,6 +610,40 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     set_last_error("eval: 'simple' Coulomb is undefined for periodic input (host must switch to DSF, calculator.py:1044)");
     return AIMNET_E_INVALID;
   }
+  // caller-supplied neighbour matrices (aimnet_inputs.nbmat ...): no list is built, the coordinates are taken as given
+  const bool ext = in->nbmat != nullptr;
+  if (ext) {
+    if (in->nbmat_width <= 0 || opt->max_nb < in->nbmat_width) {
+      set_last_error("eval: caller-supplied nbmat needs 0 < nbmat_width <= options.max_nb (got %d, %d)", in->nbmat_width, opt->max_nb);
+      return AIMNET_E_INVALID;
+    }
+    if (pbc && !in->shifts) {
+      set_last_error("eval: a caller-supplied nbmat of a periodic system needs its shifts");
+      return AIMNET_E_INVALID;
+    }
+    if (in->nbmat_lr && (in->nbmat_lr_width <= 0 || opt->max_nb_lr < in->nbmat_lr_width || (pbc && !in->shifts_lr))) {
+      set_last_error("eval: caller-supplied nbmat_lr needs 0 < nbmat_lr_width <= options.max_nb_lr, and shifts_lr when periodic");
+      return AIMNET_E_INVALID;
+    }
+    if (coulomb == AIMNET_COULOMB_DSF && !in->nbmat_lr) {
+      set_last_error("eval: DSF Coulomb with a caller-supplied nbmat needs nbmat_lr as well (no list is built in this mode)");
+      return AIMNET_E_INVALID;
+    }
+    if (opt->dftd3 != 0) {
+      const bool own = in->nbmat_d3 != nullptr;
+      if (!own && !in->nbmat_lr) {
+        set_last_error("eval: DFT-D3 with a caller-supplied nbmat needs nbmat_d3 or nbmat_lr");
+        return AIMNET_E_INVALID;
+      }
+      if (own && (in->nbmat_d3_width <= 0 || (pbc && !in->shifts_d3))) {
+        set_last_error("eval: caller-supplied nbmat_d3 needs a width, and shifts_d3 when periodic");
+        return AIMNET_E_INVALID;
+      }
+    }
+  } else if (in->nbmat_lr || in->nbmat_d3) {
+    set_last_error("eval: nbmat_lr / nbmat_d3 are only read together with nbmat");
+    return AIMNET_E_INVALID;
+  }
   hipStream_t s = (hipStream_t)hip_stream;
   AIMNET_HIP_CHECK(hipSetDevice(e->device));
   Workspace W;
@@ -633,6 +667,44 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start, W.nl.mol_c, in->numbers, out->status + 6,
                       want_species ? e->slot_of_z : nullptr, W.aslot, W.present_part));  // + aslot / present species
   const int* mol_c = W.nl.mol_c;  // clamped to [0, n_mol): memory-safe whatever the caller passed (status[6] reports it)
+  const bool d3 = opt->dftd3 != 0;
+  if (d3 && e->d3.ns == 0) {
+    set_last_error("eval: DFT-D3 requested but aimnet_engine_set_dftd3 was never called");
+    return AIMNET_E_INVALID;
+  }
+  int cap_d3 = cap_lr;
+  bool d3_shared = false;
+  if (ext) {
+    // the reference hands a caller's matrices to the model as they are (calculator.py:1069-1071): import them into the row format
+    // of the kernels; coordinates as given (the shifts refer to them), no bins, centres processed in input order
+    RC(launch_wrap(s, in->coord, mol_c, N, n_mol, nullptr, 0, in->pbc, W.nl));
+    RC(launch_import_list(s, in->nbmat, pbc ? in->shifts : nullptr, in->nbmat_width, N, mol_c, in->cell, n_cell, cap, W.nl, W.nb_idx,
+                          W.nb_shift, W.nb_cnt, out->status + 0, out->status + 2, W.pg, out->status + 6));
+    RC(launch_list_symmetry_check(s, W.nb_idx, pbc ? W.nb_shift : nullptr, W.nb_cnt, cap, N, out->status + 6));
+    if (in->nbmat_lr && coulomb != AIMNET_COULOMB_NONE)
+      RC(launch_import_list(s, in->nbmat_lr, pbc ? in->shifts_lr : nullptr, in->nbmat_lr_width, N, mol_c, in->cell, n_cell, cap_lr, W.nl,
+                            W.lr_idx, W.lr_shift, W.lr_cnt, out->status + 1, out->status + 3, nullptr, out->status + 6));
+    if (d3) {
+      d3_shared = d3_shares_lr_list(opt, cap_lr);  // one cutoff for both: the layout stores ONE matrix
+      const int* src = in->nbmat_d3 ? in->nbmat_d3 : in->nbmat_lr;
+      const int* src_sh = in->nbmat_d3 ? in->shifts_d3 : in->shifts_lr;
+      const int src_w = in->nbmat_d3 ? in->nbmat_d3_width : in->nbmat_lr_width;
+      if (d3_shared) {
+        if (src != in->nbmat_lr) {
+          set_last_error("eval: with d3_cutoff == dsf_rc one caller-supplied matrix serves both terms: pass it as nbmat_lr only");
+          return AIMNET_E_INVALID;
+        }
+      } else {
+        cap_d3 = std::max(1, opt->max_nb_d3);
+        if (cap_d3 < src_w) {
+          set_last_error("eval: options.max_nb_d3 (%d) is smaller than the caller-supplied D3 matrix (%d)", cap_d3, src_w);
+          return AIMNET_E_INVALID;
+        }
+        RC(launch_import_list(s, src, pbc ? src_sh : nullptr, src_w, N, mol_c, in->cell, n_cell, cap_d3, W.nl, W.d3_idx, W.d3_shift,
+                              W.d3_cnt, out->status + 4, out->status + 5, nullptr, out->status + 6));
+      }
+    }
+  } else {
   RC(launch_wrap(s, in->coord, mol_c, N, n_mol, in->cell, n_cell, in->pbc, W.nl, in->pbc_sys, pbc ? ar.rc : 0.0f));
   // large non-periodic molecules (>= 1500 atoms on average) get a bounding-box cell list instead of the O(n^2) scan
   if (!pbc && (long)N >= 1500L * n_mol) RC(launch_bbox(s, n_mol, W.nl));
@@ -641,13 +713,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   if (coulomb == AIMNET_COULOMB_DSF && !pbc)  // periodic DSF needs no list: it walks the short-range cell grid
     RC(launch_nlist(s, N, n_mol, mol_c, in->cell, n_cell, in->pbc, opt->dsf_rc, -1.0f, cap_lr, N, 0, W.nl, W.lr_idx,
                     W.lr_shift, W.lr_cnt, out->status + 1, out->status + 3));
-  const bool d3 = opt->dftd3 != 0;
-  if (d3 && e->d3.ns == 0) {
-    set_last_error("eval: DFT-D3 requested but aimnet_engine_set_dftd3 was never called");
-    return AIMNET_E_INVALID;
-  }
-  const bool d3_shared = d3 && d3_shares_lr_list(opt, cap_lr) && !pbc;
-  int cap_d3 = cap_lr;
+  d3_shared = d3 && d3_shares_lr_list(opt, cap_lr) && !pbc;
   if (d3 && !d3_shared) {
     if (d3_shares_lr_list(opt, cap_lr)) {  // periodic DSF walks the grid: the shared buffers are free for the D3 list
       RC(launch_nlist(s, N, n_mol, mol_c, in->cell, n_cell, in->pbc, opt->d3_cutoff, -1.0f, cap_lr, N, 0, W.nl, W.d3_idx,
@@ -658,12 +724,13 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
                       W.d3_shift, W.d3_cnt, out->status + 4, out->status + 5));
     }
   }
+  }
   RC(prof_mark(e, s, FAM_GEOM));
   // (the pair geometry (u, d) of the short-range list was written by the list builder itself)
 
   // ---- forward --------------------------------------------------------------------------------
   // binned systems: process centre atoms in the bin-sorted order of the cell list (kernels.h, `order`)
-  const int* order = (W.nl.binned && e->spatial_order) ? W.nl.sorted : nullptr;
+  const int* order = (!ext && W.nl.binned && e->spatial_order) ? W.nl.sorted : nullptr;
   // a^0 = afv[Z] is never materialised: pass 0 gathers the embedding rows directly (conv_fwd / conv_bwd row_of, update_a)
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
   const bool mfma_fwd = (e->conv_mfma & 1) && N > e->split_max;
@@ -686,12 +753,15 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     RC(launch_coulomb_sr(cs, grad, want_s, ar.sr_coulomb != 0, q_fin, W.nb_idx, W.nb_cnt, W.pg, cap, cp, N, W.ecoul, W.qbar,
                          W.fgrad, W.virial_atom));
     // DSF and DFT-D3 with one cutoff: the Coulomb pair terms ride on the D3 pair pass (one list, one geometry evaluation)
-    const bool dsf_in_d3 = d3 && coulomb == AIMNET_COULOMB_DSF && opt->d3_cutoff == opt->dsf_rc;
-    if (coulomb == AIMNET_COULOMB_SIMPLE)
+    const bool dsf_in_d3 = !ext && d3 && coulomb == AIMNET_COULOMB_DSF && opt->d3_cutoff == opt->dsf_rc;
+    if (coulomb == AIMNET_COULOMB_SIMPLE && ext && in->nbmat_lr)  // coul_simple over the caller's matrix (lr.py:311-331)
+      RC(launch_coulomb_dsf(cs, grad, false, q_fin, W.nl.xw, mol_c, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt, cap_lr, cp, N,
+                            W.ecoul, W.qbar, W.fgrad, W.virial_atom, true));
+    else if (coulomb == AIMNET_COULOMB_SIMPLE)
       RC(launch_coulomb_simple(cs, grad, q_fin, W.nl.xw, mol_c, W.nl.mol_start, cp, N, W.ecoul, W.qbar, W.fgrad));
     else if (dsf_in_d3)
       ;  // see launch_dftd3 below
-    else if (coulomb == AIMNET_COULOMB_DSF && pbc) {
+    else if (coulomb == AIMNET_COULOMB_DSF && pbc && !ext) {
       RC(launch_coulomb_dsf_walk(cs, grad, want_s, q_fin, mol_c, W.nl, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom,
                                  out->charges));
       charges_written = true;

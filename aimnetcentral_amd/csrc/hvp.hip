@@ -1061,6 +1061,10 @@ int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_ev
     set_last_error("hvp: null or empty input");
     return AIMNET_E_INVALID;
   }
+  if (in->nbmat || in->nbmat_lr || in->nbmat_d3) {
+    set_last_error("hvp: caller-supplied neighbour matrices are not read by the tangent sweep (it builds its own lists)");
+    return AIMNET_E_INVALID;
+  }
   const bool d3 = opt->dftd3 != 0;
   if (d3 && e->d3.ns == 0) {
     set_last_error("hvp: DFT-D3 requested but aimnet_engine_set_dftd3 was never called");

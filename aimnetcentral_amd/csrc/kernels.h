@@ -77,6 +77,15 @@ int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, cons
                  NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf,
                  float4* pg = nullptr);  // pg [n_atoms, cap] (may be NULL): also emit the pair geometry (u, d) of every entry
 int launch_bins(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, float width, NlistBuffers& b);
+// caller-supplied neighbour matrix [n_atoms][width] (+ integer shifts [n_atoms][width][3] or NULL) -> the engine's row format
+// (valid entries compacted in order, shifts packed, optional pair geometry from the coordinates as given in b.xw); status as
+// launch_nlist; bad: bit 3 = a shift outside +-127 or an unshifted self pair
+int launch_import_list(hipStream_t s, const int* ext_idx, const int* ext_shift, int width, int n_atoms, const int* mol_idx,
+                       const float* cell, int n_cell, int cap, NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt,
+                       int* status_max, int* status_ovf, float4* pg, int* bad);
+// bad |= 16 unless every entry (i -> j, s) has its mirror (j -> i, -s) in the row of j (caller-supplied matrices)
+int launch_list_symmetry_check(hipStream_t s, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, int n_atoms,
+                               int* bad);
 
 // ---- conv.hip ---------------------------------------------------------------------------------
 struct BasisParams {  // radial basis of AEVSV (aev.py:66-81), passed by value
@@ -190,7 +199,7 @@ int launch_coulomb_simple(hipStream_t s, bool grad, const float* q, const float*
 int launch_coulomb_dsf(hipStream_t s, bool grad, bool stress, const float* q, const float* xw, const int* mol_idx,
                        const float* cell, int n_cell, const int* nb_idx, const int* nb_shift, const int* nb_cnt,
                        int cap, CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad,
-                       float* virial_atom);
+                       float* virial_atom, bool simple = false);  // simple: w = 1 / d over every entry (caller-supplied nbmat_lr)
 // periodic DSF straight from the cell grid of the last launch_bins (no neighbour matrix)
 int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, NlistBuffers& b,
                             CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom,

@@ -412,7 +412,9 @@ int launch_coulomb_simple(hipStream_t s, bool grad, const float* q, const float*
 }
 
 // DSF over the long-range neighbour matrix, plus the self term -2k (erfc(a Rc)/(2 Rc) + a/sqrt(pi)) q_i^2
-template <bool GRAD, bool STRESS>
+// SIMPLE: w = 1 / d over every entry of the matrix, no cutoff, no self term - LRCoulomb.coul_simple over a CALLER-SUPPLIED
+// `nbmat_lr` (lr.py:311-331 sums over whatever list it is given; the engine's own lists use coulomb_simple_kernel above)
+template <bool GRAD, bool STRESS, bool SIMPLE = false>
 __global__ __launch_bounds__(256) void coulomb_dsf_kernel(const float* __restrict__ q, const float* __restrict__ xw,
                                                          const int* __restrict__ mol_idx, const float* __restrict__ cell,
                                                          int n_cell, const int* __restrict__ nb_idx,
@@ -444,14 +446,20 @@ __global__ __launch_bounds__(256) void coulomb_dsf_kernel(const float* __restric
       rz += sx * c[2] + sy * c[5] + sz * c[8];
     }
     const float d = sqrtf(rx * rx + ry * ry + rz * rz);
-    if (!(d < Rc)) continue;
+    if (!SIMPLE && !(d < Rc)) continue;
     const float inv = 1.0f / d;
-    const float ec = erfcf(al * d);
-    const float w = ec * inv - sv + (d - Rc) * slope;
-    const float dw = -ec * inv * inv - two_a_sqrtpi * expf(-al * al * d * d) * inv + slope;
+    float w, dw;
+    if (SIMPLE) {
+      w = inv;
+      dw = -inv * inv;
+    } else {
+      const float ec = erfcf(al * d);
+      w = ec * inv - sv + (d - Rc) * slope;
+      dw = -ec * inv * inv - two_a_sqrtpi * expf(-al * al * d * d) * inv + slope;
+    }
     pair_add<GRAD, STRESS>(A, w, dw, qi, q[j], rx * inv, ry * inv, rz * inv, d);
   }
-  const float cs = -(sv * 0.5f + al * 0.56418958354775629f);
+  const float cs = SIMPLE ? 0.0f : -(sv * 0.5f + al * 0.56418958354775629f);
   const double e_self = 2.0 * (double)cp.factor * (double)(cs * qi * qi);
   const float qb_self = 4.0f * cp.factor * cs * qi;
   pair_store<GRAD, STRESS, true>(A, i, lane, cp.factor, e_self, qb_self, ecoul, qbar, fgrad, virial_atom);
@@ -460,8 +468,18 @@ __global__ __launch_bounds__(256) void coulomb_dsf_kernel(const float* __restric
 int launch_coulomb_dsf(hipStream_t s, bool grad, bool stress, const float* q, const float* xw, const int* mol_idx,
                        const float* cell, int n_cell, const int* nb_idx, const int* nb_shift, const int* nb_cnt,
                        int cap, CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad,
-                       float* virial_atom) {
+                       float* virial_atom, bool simple) {
   dim3 grid(ceil_div(n_atoms, 4)), block(256);
+  if (simple) {  // 1 / d over a caller-supplied matrix (never periodic: no virial)
+    if (grad)
+      hipLaunchKernelGGL((coulomb_dsf_kernel<true, false, true>), grid, block, 0, s, q, xw, mol_idx, cell, n_cell, nb_idx, nb_shift,
+                         nb_cnt, cap, cp, n_atoms, ecoul, qbar, fgrad, virial_atom);
+    else
+      hipLaunchKernelGGL((coulomb_dsf_kernel<false, false, true>), grid, block, 0, s, q, xw, mol_idx, cell, n_cell, nb_idx, nb_shift,
+                         nb_cnt, cap, cp, n_atoms, ecoul, qbar, fgrad, virial_atom);
+    AIMNET_LAUNCH_CHECK();
+    return 0;
+  }
   if (grad && stress)
     hipLaunchKernelGGL((coulomb_dsf_kernel<true, true>), grid, block, 0, s, q, xw, mol_idx, cell, n_cell, nb_idx, nb_shift,
                        nb_cnt, cap, cp, n_atoms, ecoul, qbar, fgrad, virial_atom);

@@ -552,6 +552,67 @@ int launch_bins(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, float
   return 0;
 }
 
+// ---- caller-supplied neighbour matrix -> the engine's row format ---------------------------------------------------------
+// The reference skips its list builder when the input already carries `nbmat` (calculator.py:1069-1071) and hands the matrix to
+// the model as it is: rows [n_atoms][width] int32, entries outside [0, n_atoms) are padding (the reference pads with the index
+// of its padding atom, n_atoms), integer lattice shifts [n_atoms][width][3] for periodic input.  One wave per atom compacts the
+// valid entries of its row to the front IN THEIR ORDER, packs the shifts, and (pg != NULL) emits the pair geometry (u, d) of
+// every entry from the coordinates AS GIVEN (r = x_j + s C - x_i: the shifts of a foreign list refer to the caller's
+// coordinates, so nothing is wrapped in this mode).  bad: bit 3 is raised for a self pair without a shift or a shift outside
+// the packed range (|s| <= 127).
+__global__ __launch_bounds__(256) void import_list_kernel(const int* __restrict__ ext_idx, const int* __restrict__ ext_shift,
+                                                         int width, int n_atoms, const float* __restrict__ xw,
+                                                         const int* __restrict__ mol_idx, const float* __restrict__ cell,
+                                                         int n_cell, int cap, int* __restrict__ nb_idx,
+                                                         int* __restrict__ nb_shift, int* __restrict__ nb_cnt,
+                                                         int* __restrict__ cnt_true, float4* __restrict__ pg,
+                                                         int* __restrict__ bad) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const float* c = cell ? cell + (n_cell == 1 ? 0 : (size_t)mol_idx[i] * 9) : nullptr;
+  const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2];
+  int count = 0;  // wave-uniform
+  bool flag = false;
+  for (int m0 = 0; m0 < width; m0 += 64) {
+    const int m = m0 + lane;
+    int j = -1, sx = 0, sy = 0, sz = 0;
+    if (m < width) {
+      j = ext_idx[(size_t)i * width + m];
+      if (ext_shift && j >= 0 && j < n_atoms) {
+        const int* sp = ext_shift + ((size_t)i * width + m) * 3;
+        sx = sp[0]; sy = sp[1]; sz = sp[2];
+      }
+    }
+    const bool valid = j >= 0 && j < n_atoms;
+    if (valid && (max(abs(sx), max(abs(sy), abs(sz))) > 127 || (j == i && sx == 0 && sy == 0 && sz == 0))) flag = true;
+    const unsigned long long mask = __ballot(valid);
+    const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+    if (valid && pos < cap) {
+      const size_t p = (size_t)i * cap + pos;
+      nb_idx[p] = j;
+      if (nb_shift) nb_shift[p] = pack_shift(sx, sy, sz);
+      if (pg) {
+        float rx = xw[3 * j] - xi, ry = xw[3 * j + 1] - yi, rz = xw[3 * j + 2] - zi;
+        if (c) {
+          rx += sx * c[0] + sy * c[3] + sz * c[6];
+          ry += sx * c[1] + sy * c[4] + sz * c[7];
+          rz += sx * c[2] + sy * c[5] + sz * c[8];
+        }
+        const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+        const float inv = 1.0f / d;
+        pg[p] = make_float4(rx * inv, ry * inv, rz * inv, d);
+      }
+    }
+    count += __popcll(mask);
+  }
+  if (__ballot(flag) && lane == 0) atomicOr(bad, 8);
+  if (lane == 0) {
+    nb_cnt[i] = min(count, cap);
+    cnt_true[i] = count;
+  }
+}
+
 // status[0] = max_i count_i, status[1] = any(count_i > cap): one atomic per 1024 atoms instead of one per atom
 __global__ __launch_bounds__(1024) void nlist_status_kernel(const int* __restrict__ cnt_true, int n_atoms, int cap,
                                                            int* __restrict__ status_max, int* __restrict__ status_ovf) {
@@ -593,6 +654,57 @@ int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, cons
   }
   hipLaunchKernelGGL(nlist_status_kernel, dim3(ceil_div(n_atoms, 1024)), dim3(1024), 0, s, cnt_true, n_atoms, cap, status_max,
                      status_ovf);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_import_list(hipStream_t s, const int* ext_idx, const int* ext_shift, int width, int n_atoms, const int* mol_idx,
+                       const float* cell, int n_cell, int cap, NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt,
+                       int* status_max, int* status_ovf, float4* pg, int* bad) {
+  int* cnt_true = b.sorted_tmp;
+  hipLaunchKernelGGL(import_list_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, ext_idx, ext_shift, width, n_atoms, b.xw,
+                     mol_idx, cell, n_cell, cap, nb_idx, nb_shift, nb_cnt, cnt_true, pg, bad);
+  AIMNET_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nlist_status_kernel, dim3(ceil_div(n_atoms, 1024)), dim3(1024), 0, s, cnt_true, n_atoms, cap, status_max,
+                     status_ovf);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// every entry (i -> j, s) of a full neighbour matrix needs its mirror (j -> i, -s): the atomics-free conv backward evaluates the
+// adjoint of the pair seen from j at the centre i.  Brute force over the row of j (caller-supplied matrices only: the engine's own
+// builder emits both directions by construction).  bad: bit 4.
+__global__ __launch_bounds__(256) void list_symmetry_kernel(const int* __restrict__ nb_idx, const int* __restrict__ nb_shift,
+                                                           const int* __restrict__ nb_cnt, int cap, int n_atoms,
+                                                           int* __restrict__ bad) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const int cnt = nb_cnt[i];
+  bool missing = false;
+  for (int m = lane; m < cnt; m += 64) {
+    const size_t p = (size_t)i * cap + m;
+    const int j = nb_idx[p];
+    int want = 0;
+    if (nb_shift) {
+      int sx, sy, sz;
+      unpack_shift(nb_shift[p], sx, sy, sz);
+      want = pack_shift(-sx, -sy, -sz);
+    }
+    const int cj = nb_cnt[j];
+    bool found = false;
+    for (int t = 0; t < cj && !found; ++t) {
+      const size_t r = (size_t)j * cap + t;
+      found = nb_idx[r] == i && (!nb_shift || (nb_shift[r] & 0xffffff) == (want & 0xffffff));
+    }
+    missing = missing || !found;
+  }
+  if (__ballot(missing) && lane == 0) atomicOr(bad, 16);
+}
+
+int launch_list_symmetry_check(hipStream_t s, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, int n_atoms,
+                               int* bad) {
+  hipLaunchKernelGGL(list_symmetry_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, nb_idx, nb_shift, nb_cnt, cap, n_atoms, bad);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

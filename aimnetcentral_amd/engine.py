@@ -195,6 +195,12 @@ class HipEngine:
         dftd3: dict[str, float] | None = None,
         host_out: bool = False,
         defer: bool = False,
+        nbmat=None,
+        shifts=None,
+        nbmat_lr=None,
+        shifts_lr=None,
+        nbmat_d3=None,
+        shifts_d3=None,
     ) -> dict[str, Any]:
         """One evaluation on device tensors (coord f32 [N,3], numbers/mol_idx i32 [N], charge f32
         [n_mol] - for a 2-channel NSE model [n_mol, 2] = the alpha / beta charges of aimnet2.py:94-100 -,
@@ -202,7 +208,10 @@ class HipEngine:
         capacity on neighbour overflow (neighbors.py:127-130).  `dftd3` = {s8, a1, a2[, s6, cutoff, smoothing_fraction]}
         adds the external DFT-D3(BJ) term (needs set_dftd3_tables).  All outputs and the status words live in ONE device
         buffer; `host_out=True` returns CPU tensors taken from the single D2H copy that fetches the status anyway (the
-        ASE adapter's path: no further .cpu() round trips)."""
+        ASE adapter's path: no further .cpu() round trips).
+        `nbmat` (+ `shifts`, `nbmat_lr` / `shifts_lr`, `nbmat_d3` / `shifts_d3`): caller-supplied FULL neighbour matrices, int
+        [N, width] with entries outside [0, N) as padding, integer shifts [N, width, 3] - the engine then builds no list and takes the
+        coordinates as given (include/aimnet_hip.h, aimnet_inputs.nbmat)."""
         import torch
 
         dev = self.device
@@ -236,6 +245,24 @@ class HipEngine:
         elif not isinstance(pbc, (tuple, list)):
             pbc = tuple(bool(x) for x in torch.as_tensor(pbc).reshape(-1).tolist())
         method = {"none": _lib.COULOMB_NONE, "simple": _lib.COULOMB_SIMPLE, "dsf": _lib.COULOMB_DSF}[coulomb]
+        ext = {}
+        for key, mat, sh in (("nbmat", nbmat, shifts), ("nbmat_lr", nbmat_lr, shifts_lr), ("nbmat_d3", nbmat_d3, shifts_d3)):
+            if mat is None:
+                if sh is not None:
+                    raise ValueError(f"HipEngine.eval: shifts given without {key}")
+                continue
+            if nbmat is None:
+                raise ValueError("HipEngine.eval: nbmat_lr / nbmat_d3 are only read together with nbmat")
+            mat = mat.to(device=dev, dtype=torch.int32).contiguous()
+            if mat.ndim != 2 or mat.shape[0] != n or mat.shape[1] < 1:
+                raise ValueError(f"HipEngine.eval: {key} must have shape [{n}, width], got {tuple(mat.shape)}")
+            if sh is not None:
+                sh = sh.to(device=dev, dtype=torch.int32).contiguous()
+                if tuple(sh.shape) != (n, mat.shape[1], 3):
+                    raise ValueError(f"HipEngine.eval: the shifts of {key} must have shape {(n, mat.shape[1], 3)}, got {tuple(sh.shape)}")
+            elif cell is not None:
+                raise ValueError(f"HipEngine.eval: periodic input needs the shifts of {key}")
+            ext[key] = (mat, sh)
         # one allocation for status + every output (16-byte aligned sections); status is zeroed by the engine
         sections = [("status", torch.int32, (8,)), ("energy", torch.float64, (n_mol,)), ("charges", torch.float32, (n,))]
         if self.nq == 2:
@@ -269,6 +296,9 @@ class HipEngine:
             opt.max_nb = self.max_nb
             # periodic DSF walks the cell grid (no list); only non-periodic DSF materialises a long-range list
             opt.max_nb_lr = self._lr_capacity(float(dsf_rc)) if (method == _lib.COULOMB_DSF and cell is None) else 0
+            if ext:  # caller-supplied matrices: the row capacities are their widths (nothing can overflow)
+                opt.max_nb = _round16(ext["nbmat"][0].shape[1])
+                opt.max_nb_lr = _round16(ext["nbmat_lr"][0].shape[1]) if "nbmat_lr" in ext else 0
             if dftd3 is not None:
                 if not self.has_dftd3:
                     raise RuntimeError("dftd3 requested but no DFT-D3 tables were uploaded (HipEngine.set_dftd3_tables)")
@@ -279,6 +309,9 @@ class HipEngine:
                 opt.d3_cutoff = d3_rc
                 opt.d3_smoothing_on = d3_rc * (1.0 - float(dftd3.get("smoothing_fraction", 0.2)))
                 opt.max_nb_d3 = self._lr_capacity(d3_rc)
+                if ext:
+                    src = ext.get("nbmat_d3") or ext.get("nbmat_lr")
+                    opt.max_nb_d3 = _round16(src[0].shape[1]) if src is not None else 16
             need = int(self.lib.aimnet_engine_workspace_bytes(self._h, n, n_mol, n_cell, C.byref(opt)))
             if self._ws is None or self._ws.numel() < need:
                 if self._ws is not None and self._ws_stream is not None:
@@ -304,6 +337,10 @@ class HipEngine:
                 inp.pbc_sys = None
                 for k in range(3):
                     inp.pbc[k] = 1 if bool(pbc[k]) else 0
+            for key, (mat, sh) in ext.items():
+                setattr(inp, key, mat.data_ptr())
+                setattr(inp, "shifts" + key[5:], sh.data_ptr() if sh is not None else None)
+                setattr(inp, key + "_width", int(mat.shape[1]))
             out = _lib.Outputs()
             out.energy, out.charges = energy.data_ptr(), charges.data_ptr()
             out.forces = f_out.data_ptr() if f_out is not None else None
@@ -334,8 +371,14 @@ class HipEngine:
                     what.append(f"mol_idx entries outside [0, {n_mol}) (n_mol is taken from the charge array)")
                 if st[6] & 4:
                     what.append("mol_idx is not sorted (the atoms of a molecule must be contiguous)")
+                if st[6] & 8:
+                    what.append("a caller-supplied neighbour matrix holds a lattice shift outside +-127 or an unshifted self pair")
+                if st[6] & 16:
+                    what.append("the caller-supplied nbmat is not a full symmetric matrix (an entry i -> j without its mirror j -> i)")
                 raise ValueError("HipEngine.eval: invalid input: " + " and ".join(what))
             retry = False
+            if ext:  # caller-supplied rows cannot overflow, and say nothing about the capacities of the engine's own lists
+                break
             if st[2]:
                 self.max_nb = _round16(int(max(self.max_nb * 1.5, st[0])))
                 retry = True

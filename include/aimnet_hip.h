@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define AIMNET_ABI_VERSION 6
+#define AIMNET_ABI_VERSION 7
 
 #define AIMNET_OK 0
 #define AIMNET_E_INVALID (-1)   /* bad argument / unsupported architecture */
@@ -104,6 +104,24 @@ typedef struct aimnet_inputs {
   int32_t pbc[3];          /* periodic axes (used when cell != NULL) */
   const int32_t* pbc_sys;  /* device, [n_cell, 3] or NULL: per-system periodic axes (normalize_pbc, neighbors.py:309-321);
                               overrides pbc[] */
+  /* Optional caller-supplied neighbour matrices - the reference skips its list builder when the input already carries `nbmat`
+   * and hands the matrices to the model as they are (calculator.py:1069-1071).  All NULL (default): the engine builds its own
+   * lists.  nbmat != NULL: NO list is built; device int32 rows [n_atoms][width], entries outside [0, n_atoms) are padding (the
+   * reference pads with n_atoms); shifts int32 [n_atoms][width][3] lattice translations (required iff cell != NULL, |s| <= 127)
+   * applied to the coordinates AS GIVEN (nothing is wrapped in this mode).  Every matrix must be FULL (both directions of every
+   * pair present, as the reference's builders emit them): the short-range matrix is verified (status[6] bit 4), the others are
+   * trusted.  nbmat_lr serves the LRCoulomb term (simple: 1/d over every entry, lr.py:311-331; DSF: required) and, without
+   * nbmat_d3, the DFT-D3 term; with d3_cutoff == dsf_rc one matrix serves both (pass it as nbmat_lr).  The row capacities
+   * options.max_nb / max_nb_lr / max_nb_d3 must be >= the widths. */
+  const int32_t* nbmat;
+  const int32_t* shifts;
+  int32_t nbmat_width;
+  const int32_t* nbmat_lr;
+  const int32_t* shifts_lr;
+  int32_t nbmat_lr_width;
+  const int32_t* nbmat_d3;
+  const int32_t* shifts_d3;
+  int32_t nbmat_d3_width;
 } aimnet_inputs;
 
 typedef struct aimnet_eval_options {
@@ -131,7 +149,8 @@ typedef struct aimnet_outputs {
                               2 overflow flag rc list, 3 overflow flag LR list,
                               4 max neighbours found (D3 list), 5 overflow flag D3 list,
                               6 input sanity flags: bit 0 an atomic number outside [0, 63], bit 1 a mol_idx outside
-                                [0, n_mol), bit 2 mol_idx not sorted.  The first kernel writes clamped copies (atomic number
+                                [0, n_mol), bit 2 mol_idx not sorted, bit 3 a caller-supplied matrix holds a shift outside +-127
+                                or an unshifted self pair, bit 4 the caller-supplied short-range matrix is not symmetric.  The first kernel writes clamped copies (atomic number
                                 slots, mol_idx) into the workspace and every later kernel indexes through those, so any device
                                 array is memory-safe; with a flag raised the results are meaningless.  7 reserved */
   float* spin_charges; /* [n_atoms] alpha - beta of an NSE model (aimnet2.py:103), or NULL; must be NULL for 1-channel models */

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/aimnet_hip.h but not exported"
     assert set(declared) == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.aimnet_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.aimnet_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_struct_layouts_match_header():
@@ -37,7 +37,7 @@ def test_struct_layouts_match_header():
 
     assert C.sizeof(_lib.EvalOptions) == 24 + 8 * 4   # + dftd3, s6, s8, a1, a2, cutoff, smoothing_on, max_nb_d3
     assert C.sizeof(_lib.DftD3Tables) == 8 + 4 * 8
-    assert C.sizeof(_lib.Inputs) == 8 + 5 * 8 + 4 + 12 + 8  # + pbc_sys (per-system periodicity flags)
+    assert C.sizeof(_lib.Inputs) == 8 + 5 * 8 + 4 + 12 + 8 + 3 * 24  # + pbc_sys; + three optional caller-supplied matrices
     assert C.sizeof(_lib.Outputs) == 6 * 8      # + spin_charges
     n_arch = 4 + 4 + 4 * 7 + 4 + 1 + 7 + 2 + 32 + 3 + 1  # + n_charge_channels
     assert C.sizeof(_lib.Arch) == 4 * n_arch

@@ -1,0 +1,157 @@
+"""Caller-supplied neighbour matrices (`nbmat`, `shifts`, `nbmat_lr`, `shifts_lr`): the reference skips its list builder when the
+input carries them and hands them to the model as they are (calculator.py:1069-1071); the engine takes them in the same role
+(aimnet_inputs.nbmat: no list built, coordinates as given).  The matrices here come from the oracle's brute-force builder in the
+reference's layout ((N + 1, M) rows with the padding row last, sentinel N, float shifts)."""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import CHARGE_ATOL, assert_forces_close, energy_tol, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def calc():
+    from aimnetcentral_amd import AIMNet2Calculator, loader
+
+    return AIMNet2Calculator(loader.synthetic_spec(0), device="cuda:0")
+
+
+def npy(out):
+    return {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("name", ["taxol", "batch5"])
+def test_molecules_with_caller_lists_match_the_golden(calc, name):
+    from oracle import aimnet2_oracle as O
+
+    g = golden(name)
+    n = len(g["numbers"])
+    mol = g["mol_idx"] if "mol_idx" in g.files else np.zeros(n, dtype=np.int64)
+    nb, _ = O.neighbor_list(g["coord"], 5.0, mol)
+    nbl, _ = O.neighbor_list(g["coord"], float("inf"), mol)
+    data = {"coord": g["coord"], "numbers": g["numbers"], "charge": g["charge"], "mol_idx": mol}
+    own = npy(calc(data, forces=True))
+    ext = npy(calc(dict(data, nbmat=nb, nbmat_lr=nbl), forces=True))
+    sizes = np.bincount(mol)
+    assert (np.abs(ext["energy"] - g["energy"]) <= energy_tol(sizes) + (2e-5 if name == "batch5" else 0.0)).all()
+    assert_forces_close(ext["forces"], g["forces"], name)
+    assert np.abs(ext["charges"] - g["charges"]).max() <= CHARGE_ATOL
+    # same pairs, other row order than the engine's own builder: the two paths differ by summation order only
+    assert np.abs(ext["energy"] - own["energy"]).max() <= 2e-5 and np.abs(ext["forces"] - own["forces"]).max() <= 5e-5
+    assert calc.engine.last_status[0] == (nb[:n] < n).sum(1).max()  # the row counts the engine saw are the caller's
+
+
+def test_restricted_lr_matrix_is_honoured(calc, oracle32):
+    """coul_simple sums over whatever `nbmat_lr` holds (lr.py:311-331): a 6 A matrix gives the energy of THAT sum, not of all pairs."""
+    from oracle import aimnet2_analytic as AN
+    from oracle import aimnet2_oracle as O
+
+    g = golden("taxol")
+    n = len(g["numbers"])
+    mol = np.zeros(n, dtype=np.int64)
+    nb, _ = O.neighbor_list(g["coord"], 5.0, mol)
+    nb6, _ = O.neighbor_list(g["coord"], 6.0, mol)
+    data = {"coord": g["coord"], "numbers": g["numbers"], "charge": 0.0}
+    ext = npy(calc(dict(data, nbmat=nb, nbmat_lr=nb6), forces=True))
+    ref = AN.evaluate(oracle32, g["coord"], g["numbers"], 0.0, mol, nb, coulomb="simple", nbmat_lr=nb6)
+    assert abs(ext["energy"][0] - ref["energy"][0]) <= energy_tol(n)
+    assert_forces_close(ext["forces"], ref["forces"], "taxol, 6 A Coulomb matrix")
+    assert abs(ext["energy"][0] - g["energy"][0]) > 1e-2  # and that is not the all-pairs energy
+
+
+def _periodic_lists(g, coord, rc_lr):
+    from oracle import aimnet2_oracle as O
+
+    mol = np.zeros(len(g["numbers"]), dtype=np.int64)
+    nb, sh = O.neighbor_list(coord, 5.0, mol, g["cell"], np.ones(3, bool))
+    nbl, shl = O.neighbor_list(coord, rc_lr, mol, g["cell"], np.ones(3, bool))
+    return nb, sh, nbl, shl
+
+
+def test_periodic_cell_with_caller_lists_and_unwrapped_coordinates(calc):
+    """Periodic DSF from caller matrices (list form, no cell walk), stress included; then the same structure with atoms moved by whole
+    lattice vectors and the shifts adjusted: nothing is wrapped in this mode, the result is the same."""
+    from oracle import aimnet2_oracle as O
+
+    g = golden("pbc96_dsf8_wrapped")
+    # (the fixture's coordinates lie up to a cell outside the box - it tests the wrap; the matrices are built on the wrapped ones)
+    xw = O.wrap_into_cell(g["coord"].astype(np.float64), g["cell"].astype(np.float64), np.zeros(96, dtype=np.int64),
+                          np.ones(3, bool)).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        calc.set_lrcoulomb_method("dsf", cutoff=8.0, dsf_alpha=0.25)
+    try:
+        nb, sh, nbl, shl = _periodic_lists(g, xw, 8.0)
+        data = {"coord": xw, "numbers": g["numbers"], "charge": 0.0, "cell": g["cell"]}
+        ext = npy(calc(dict(data, nbmat=nb, shifts=sh, nbmat_lr=nbl, shifts_lr=shl), forces=True, stress=True))
+        assert abs(ext["energy"][0] - g["energy"][0]) <= energy_tol(96)
+        assert_forces_close(ext["forces"], g["forces"], "pbc96 dsf8, caller lists")
+        assert np.abs(ext["stress"] - g["stress"]).max() < 2e-5 and np.abs(ext["charges"] - g["charges"]).max() <= CHARGE_ATOL
+        # move atoms 0 and 7 by lattice vectors: x_k' = x_k + t_k C  =>  s'(i -> j) = s + t_i - t_j
+        t = np.zeros((96, 3), dtype=np.int64)
+        t[0], t[7] = (1, 0, 0), (0, -2, 1)
+        coord2 = (xw.astype(np.float64) + t @ g["cell"].astype(np.float64)).astype(np.float32)
+
+        def moved(nbm, shm):
+            out = shm.copy()
+            j = np.minimum(nbm[:96], 95)
+            out[:96] += (t[:, None, :] - t[j]) * (nbm[:96] < 96)[..., None]
+            return out
+
+        far = npy(calc(dict(data, coord=coord2, nbmat=nb, shifts=moved(nb, sh), nbmat_lr=nbl, shifts_lr=moved(nbl, shl)),
+                       forces=True, stress=True))
+        assert abs(far["energy"][0] - ext["energy"][0]) <= 2e-5 and np.abs(far["forces"] - ext["forces"]).max() <= 5e-5
+    finally:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            calc.set_lrcoulomb_method("simple")
+
+
+def test_broken_matrices_are_reported(calc):
+    from oracle import aimnet2_oracle as O
+
+    g = golden("taxol")
+    n = len(g["numbers"])
+    mol = np.zeros(n, dtype=np.int64)
+    nb, _ = O.neighbor_list(g["coord"], 5.0, mol)
+    nbl, _ = O.neighbor_list(g["coord"], float("inf"), mol)
+    data = {"coord": g["coord"], "numbers": g["numbers"], "charge": 0.0}
+    half = nb.copy()
+    half[0, 0] = n  # drop one direction of one pair: entry (0 -> j) gone, (j -> 0) still there
+    half[0] = np.concatenate([half[0][half[0] < n], half[0][half[0] >= n]])
+    with pytest.raises(ValueError, match="not a full symmetric"):
+        calc(dict(data, nbmat=half, nbmat_lr=nbl), forces=True)
+    selfpair = nb.copy()
+    selfpair[3, -1] = 3  # an unshifted self pair
+    with pytest.raises(ValueError, match="self pair"):
+        calc(dict(data, nbmat=selfpair, nbmat_lr=nbl))
+    out = npy(calc(dict(data, nbmat=nb, nbmat_lr=nbl), forces=True))  # and the calculator still works afterwards
+    assert_forces_close(out["forces"], g["forces"], "taxol after the rejected calls")
+
+
+def test_dftd3_reads_the_lr_matrix(calc):
+    """With caller matrices the DFT-D3 term reads `nbmat_lr` (the reference's fallback suffix, nbops.resolve_suffix): same result as
+    with the engine's own 15 A list on a molecule that fits inside it."""
+    from aimnetcentral_amd import AIMNet2Calculator, loader
+    from oracle import aimnet2_oracle as O
+
+    gd, t = golden("dftd3"), golden("dftd3_subset")
+    spec = loader.synthetic_spec(0)
+    spec.metadata = dict(spec.metadata, needs_dispersion=True, d3_params={k: float(gd[k]) for k in ("s6", "s8", "a1", "a2")})
+    cd3 = AIMNet2Calculator(spec, device="cuda:0", dftd3_data={k: t[k] for k in ("c6ab", "cn_ref", "rcov", "r4r2")})
+    g = golden("taxol")
+    n = len(g["numbers"])
+    mol = np.zeros(n, dtype=np.int64)
+    nb, _ = O.neighbor_list(g["coord"], 5.0, mol)
+    nbl, _ = O.neighbor_list(g["coord"], float("inf"), mol)
+    data = {"coord": g["coord"], "numbers": g["numbers"], "charge": 0.0}
+    own = npy(cd3(data, forces=True))
+    ext = npy(cd3(dict(data, nbmat=nb, nbmat_lr=nbl), forces=True))
+    assert abs(ext["energy"][0] - own["energy"][0]) <= 2e-5 and np.abs(ext["forces"] - own["forces"]).max() <= 5e-5
+    assert abs(own["energy"][0] - g["energy"][0]) > 1e-2  # the dispersion term is in both

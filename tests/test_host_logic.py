@@ -28,8 +28,8 @@ class FakeEngine:
         self.d3_tables = tables
 
     def eval(self, coord, numbers, mol_idx, charge, cell=None, pbc=(True, True, True), forces=False, stress=False,
-             coulomb="simple", dsf_rc=15.0, dsf_alpha=0.2, sync=True, dftd3=None, host_out=False):
-        self.calls.append(dict(host_out=host_out, n=coord.shape[0], n_mol=charge.shape[0], coulomb=coulomb, dsf_rc=dsf_rc, dsf_alpha=dsf_alpha, dftd3=dftd3,
+             coulomb="simple", dsf_rc=15.0, dsf_alpha=0.2, sync=True, dftd3=None, host_out=False, **lists):
+        self.calls.append(dict(lists=lists, host_out=host_out, n=coord.shape[0], n_mol=charge.shape[0], coulomb=coulomb, dsf_rc=dsf_rc, dsf_alpha=dsf_alpha, dftd3=dftd3,
                                pbc=pbc, cell=None if cell is None else tuple(cell.shape), mol_idx=mol_idx.clone(),
                                numbers=numbers.clone(), charge=charge.clone()))
         n = coord.shape[0]
@@ -244,6 +244,35 @@ def test_ase_adapter_contract(calc):
         ase_calc.calculate(patoms, properties=["energy", "forces", "stress"])
     assert calc.engine.calls[-1]["cell"] == (3, 3) and ase_calc.results["stress"].shape == (3, 3)
     assert sorted(AIMNet2ASE.implemented_properties) == sorted(["energy", "forces", "free_energy", "charges", "stress", "dipole_moment"])
+
+
+def test_caller_supplied_neighbour_matrices_reach_the_engine(calc):
+    """`nbmat` (+ `nbmat_lr`, shifts) skip the list builder in the reference (calculator.py:1069-1071) and go to the model as they
+    are; here they go to the engine in the same role: padded (N + 1, M) or plain (N, M) rows, float shifts -> int32."""
+    nb = np.array([[1, 2], [0, 2], [0, 1], [3, 3]])          # the reference's layout: padding row last, sentinel N = 3
+    calc(dict(WATER, nbmat=nb, nbmat_lr=nb[:3]))
+    lists = calc.engine.calls[-1]["lists"]
+    assert set(lists) == {"nbmat", "nbmat_lr"} and lists["nbmat"].shape == (3, 2) and lists["nbmat"].dtype == torch.int32
+    assert lists["nbmat_lr"].tolist() == nb[:3].tolist()
+    with pytest.raises(KeyError, match="nbmat_lr"):       # the external Coulomb term reads the _lr matrix (nbops.resolve_suffix)
+        calc(dict(WATER, nbmat=nb))
+    with pytest.raises(ValueError, match="only read together"):
+        calc(dict(WATER, nbmat_lr=nb))
+    with pytest.raises(ValueError, match="must have shape"):
+        calc(dict(WATER, nbmat=nb[:2], nbmat_lr=nb))
+    with pytest.raises(NotImplementedError, match="flat"):
+        calc(dict(coord=np.zeros((1, 3, 3)), numbers=[[8, 1, 1]], charge=[0.0], nbmat=nb, nbmat_lr=nb))
+    with pytest.raises(NotImplementedError, match="caller-supplied"):
+        calc(dict(WATER, nbmat=nb, nbmat_lr=nb), hessian=True)
+    # periodic: shifts are required, float multiples become integers; simple -> DSF switch as without lists
+    sh = np.zeros((4, 2, 3), dtype=np.float32)
+    sh[0, 0] = [1.0, 0.0, -1.0]
+    with pytest.warns(UserWarning, match="Switching to DSF"):
+        calc(dict(WATER, cell=np.eye(3) * 9.0, nbmat=nb, shifts=sh, nbmat_lr=nb, shifts_lr=sh))
+    lists = calc.engine.calls[-1]["lists"]
+    assert lists["shifts"].dtype == torch.int32 and lists["shifts"][0, 0].tolist() == [1, 0, -1] and lists["shifts_lr"].shape == (3, 2, 3)
+    with pytest.raises(KeyError, match="shifts"), pytest.warns(UserWarning):
+        calc(dict(WATER, cell=np.eye(3) * 9.0, nbmat=nb, nbmat_lr=nb))
 
 
 # ---- finite-difference Hessian / HVP over the engine forces (calculator.py:904-910,1753-1989 of the reference) ------

@@ -290,6 +290,8 @@ def main():
     ap.add_argument("--workload", default="pbc10k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the extra pass with the exact-fp32 GEMM kernels (profiling runs)")
+    ap.add_argument("--no-hessian", action="store_true", help="skip the hessian_config4 record (profiling runs: keeps the kernel trace "
+                    "and the counter passes to the kernels of the timed workload)")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU-oracle timing (16 threads + 1 thread); below 5 s the "
                     "single all-host-threads evaluation (51 s on a 256-thread box) is skipped")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-family time table to stderr")
@@ -497,7 +499,7 @@ def main():
                 if k not in oracle_out:
                     oracle_out[k] = smp["step"]()
             out["parity"] = parity_gate(eng, samples, oracle_out)
-        if world == 1:
+        if world == 1 and not args.no_hessian:
             out["hessian_config4"] = hessian_config4(eng)
         print(json.dumps(out))
     if distributed:

@@ -10,3 +10,7 @@ python tests/tools/bf3_bench.py 2>&1 | grep -v amdgpu > gpurun_out/r3/gemm_bf3_s
 M=6400 python tests/tools/bf3_bench.py 2>&1 | grep -v amdgpu > gpurun_out/r3/gemm_bf3_shapes_m6400.txt
 python tests/tools/op_bench.py 2>/dev/null | tail -1 > gpurun_out/r3/op_bench.json
 tail -3 gpurun_out/r3_stdout.txt; tail -c 1500 gpurun_out/r3/bench.json
+# analytic Hessian-vector products: accuracy against the fp64 specification and the reference goldens, cost, kernel trace
+python tests/tools/hvp_analytic.py 2>&1 | grep -v amdgpu > gpurun_out/r3/hvp_analytic.txt
+python tests/tools/hvp_bench.py 2>/dev/null > gpurun_out/r3/hvp_bench.json
+bash tests/tools/hvp_prof.sh 1 > /dev/null 2>&1; cp gpurun_out/hvp_prof.txt gpurun_out/r3/hvp_prof.txt

@@ -445,10 +445,13 @@ def load_dftd3_tables(source: Any = None) -> dict[str, np.ndarray]:
     return out
 
 
-def synthetic_spec(seed: int = 0, num_charge_channels: int = 1, rxn: bool = False) -> ModelSpec:
+def synthetic_spec(seed: int = 0, num_charge_channels: int = 1, rxn: bool = False, sr_envelope: str = "exp",
+                   sr_rc: float = 4.6) -> ModelSpec:
     """ModelSpec of the deterministic synthetic aimnet2 artifact (aimnetcentral_amd/synth.py); num_charge_channels = 2
-    gives the open-shell NSE shape, rxn = True the `aimnet2_rxn` YAML (Dipole / Quadrupole output modules)."""
+    gives the open-shell NSE shape, rxn = True the `aimnet2_rxn` YAML (Dipole / Quadrupole output modules), sr_envelope / sr_rc
+    the SRCoulomb block's envelope ("exp" or "cosine") and radius."""
     from . import synth
 
-    return spec_from_artifact(synth.synthetic_artifact(seed, num_charge_channels=num_charge_channels, rxn=rxn),
+    return spec_from_artifact(synth.synthetic_artifact(seed, num_charge_channels=num_charge_channels, rxn=rxn,
+                                                       sr_envelope=sr_envelope, sr_rc=sr_rc),
                               source=f"<synthetic seed {seed}>")

@@ -190,8 +190,9 @@ def state_dict_digest(sd: dict[str, Any]) -> str:
 
 
 def synthetic_artifact(seed: int = 0, species: list[int] | None = None, num_charge_channels: int = 1,
-                       rxn: bool = False) -> dict[str, Any]:
-    """A v2 artifact dict (torch tensors) as `torch.save` would hold it."""
+                       rxn: bool = False, sr_envelope: str = "exp", sr_rc: float = 4.6) -> dict[str, Any]:
+    """A v2 artifact dict (torch tensors) as `torch.save` would hold it.  sr_envelope / sr_rc: the SRCoulomb block's
+    `envelope` ("exp" mollifier or "cosine", lr.py:986-1032) and radius - same weights, another short-range subtraction."""
     import torch
 
     species = list(AIMNET2_SPECIES if species is None else species)
@@ -201,16 +202,22 @@ def synthetic_artifact(seed: int = 0, species: list[int] | None = None, num_char
         # it is only read with center_coord=True, which the rxn YAML does not set - the synthetic artifact carries zeros
         for name in ("dipole", "quadrupole"):
             sd[f"outputs.{name}.mass"] = torch.zeros(119, dtype=torch.float32)
+    yml = core_yaml(num_charge_channels, rxn)
+    if sr_envelope != "exp" or float(sr_rc) != 4.6:
+        old = "        rc: 4.6\n        key_in: charges\n        key_out: energy\n        envelope: exp\n"
+        assert old in yml
+        yml = yml.replace(old, f"        rc: {float(sr_rc)}\n        key_in: charges\n        key_out: energy\n        envelope: {sr_envelope}\n")
+        sd["outputs.srcoulomb.rc"] = torch.tensor(float(sr_rc), dtype=torch.float32)
     return {
         "format_version": 2,
-        "model_yaml": core_yaml(num_charge_channels, rxn),
+        "model_yaml": yml,
         "state_dict": sd,
         "cutoff": 5.0,
         "needs_coulomb": True,
         "needs_dispersion": False,
         "coulomb_mode": "sr_embedded",
-        "coulomb_sr_rc": 4.6,
-        "coulomb_sr_envelope": "exp",
+        "coulomb_sr_rc": float(sr_rc),
+        "coulomb_sr_envelope": sr_envelope,
         "d3_params": None,
         "has_embedded_lr": True,
         "implemented_species": species,

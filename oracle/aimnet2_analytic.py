@@ -179,11 +179,8 @@ def evaluate(
         if stress:
             virial = virial + msum(torch.einsum("nma,nmb->nab", r_, rbar).double())
 
-    rc_sr = float(model.sr_rc)
-    t = (d / rc_sr).clamp(0, 1.0 - 1e-6)
-    fce = torch.exp(-1.0 / (1.0 - t * t)) / 0.36787944117144233
-    dfce = torch.where(d / rc_sr < 1.0 - 1e-6, fce * (-2.0 * t / (1.0 - t * t) ** 2) / rc_sr, torch.zeros_like(d))
-    pair_term(fce / d, dfce / d - fce / (d * d), nb, valid, r, d, u, -1.0)  # embedded SRCoulomb (lr.py:1020)
+    w_sr, dw_sr, _ = sr_weight(model, d, getattr(model, "sr_envelope", "exp"))
+    pair_term(w_sr, dw_sr, nb, valid, r, d, u, -1.0)  # embedded SRCoulomb (lr.py:1020), exp or cosine envelope
     if coulomb != "none":
         nbl, validl, shl = _strip(nbmat_lr, shifts_lr, n)
         rl, dl, ul = pair_geometry(x, nbl, validl, shl, cell_at)
@@ -367,7 +364,7 @@ def evaluate_hvp(
     dsf_alpha: float = 0.2,
     mult=None,
     sr_coulomb: bool = True,
-    sr_envelope: str = "exp",
+    sr_envelope: str | None = None,
     return_intermediates: bool = False,
 ) -> dict[str, np.ndarray]:
     """H v for K directions `vectors` (K, N, 3) (+ the primal forces of the same sweep).  Arguments as `evaluate`."""
@@ -510,7 +507,7 @@ def evaluate_hvp(
         t_xbar = t_xbar - k2 * ((d2w * t_d_ * qq + dw * t_qq).unsqueeze(-1) * u_ + (dw * qq).unsqueeze(-1) * t_u_).sum(2)
 
     if sr_coulomb:
-        w, dw, d2w = sr_weight(model, d, sr_envelope)
+        w, dw, d2w = sr_weight(model, d, sr_envelope or getattr(model, "sr_envelope", "exp"))
         pair_term(w, dw, d2w, nb, valid, d, u, t_d, t_u, -1.0)
     if coulomb != "none":
         nbl, validl, shl = _strip(nbmat_lr, shifts_lr, n)

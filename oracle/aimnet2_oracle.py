@@ -210,6 +210,7 @@ class OracleModel:
             li += 1
         self.sae = sd["outputs.atomic_shift.shifts.weight"].to(torch.float64).squeeze(-1)
         self.sr_rc = f("outputs.srcoulomb.rc") if "outputs.srcoulomb.rc" in sd else torch.tensor(4.6, dtype=dtype)
+        self.sr_envelope = "exp"  # SRCoulomb(envelope=...) of the model YAML (lr.py:986-1032): "exp" mollifier or "cosine"
         self.A = self.agh_a.shape[0]
         self.G = self.agh_a.shape[1]
         self.nq = int(self.agh_q.shape[0])  # num_charge_channels (aimnet2.py:21): 2 = open-shell NSE
@@ -445,7 +446,8 @@ def evaluate(
 
     # embedded SRCoulomb: energy -= E_sr (lr.py:1020-1032)
     q_i, q_j = charges.unsqueeze(1), charges[nb]
-    e_sr = (_exp_cutoff(d_ij, model.sr_rc) * q_i * q_j / d_ij).masked_fill(mask, 0.0)
+    fc_sr = _exp_cutoff(d_ij, model.sr_rc) if model.sr_envelope == "exp" else _cosine_cutoff(d_ij, model.sr_rc)  # lr.py:54-57
+    e_sr = (fc_sr * q_i * q_j / d_ij).masked_fill(mask, 0.0)
     energy = energy.double() - pair_sum(e_sr)
 
     if coulomb != "none":

@@ -84,6 +84,34 @@ def capture_intermediates(calc: AIMNet2Calculator, data: dict) -> dict[str, np.n
     return store, out
 
 
+def make_srcos(meta_common: dict) -> None:
+    """G12: the SRCoulomb block with the COSINE envelope and rc = 4.2 A (SRCoulomb(envelope="cosine"), lr.py:986-1032; the
+    shipped YAMLs use the exp mollifier) on the same weights: taxol E / F / q, and on its first 40 atoms the Hessian and four
+    Hessian-vector products."""
+    art = synth.synthetic_artifact(SEED, sr_envelope="cosine", sr_rc=4.2)
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "aimnet2_srcos_synth.pt")
+    torch.save(art, path)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _, meta = load_model(path)
+    assert meta["coulomb_sr_envelope"] == "cosine" and abs(meta["coulomb_sr_rc"] - 4.2) < 1e-6
+    calc = make_calc(path)
+    assert calc.model.outputs["srcoulomb"].envelope == "cosine" and abs(float(calc.model.outputs["srcoulomb"].rc) - 4.2) < 1e-6
+    coord, numbers = read_taxol()
+    full = to_np(calc({"coord": coord.astype(np.float32), "numbers": numbers, "charge": 0.0}, forces=True))
+    c40, z40 = coord[:40].astype(np.float32), numbers[:40]
+    data = {"coord": c40, "numbers": z40, "charge": 0.0}
+    out = to_np(calc(data, forces=True, hessian=True))
+    v4 = torch.randn(4, 40, 3, generator=torch.Generator().manual_seed(0))
+    hv4 = calc.hessian_vector_product(data, v4).detach().numpy()
+    print("srcos taxol E=%.6f; 40 atoms E=%.6f |H|max=%.3f" % (full["energy"][0], out["energy"][0], np.abs(out["hessian"]).max()))
+    np.savez_compressed(os.path.join(HERE, "srcos.npz"), coord=coord.astype(np.float32), numbers=numbers, charge=np.float32(0.0),
+                        energy=full["energy"], forces=full["forces"], charges=full["charges"],
+                        energy40=out["energy"], forces40=out["forces"], hessian40=out["hessian"].astype(np.float32),
+                        v4=v4.numpy(), hv4=hv4, sr_rc=np.float32(4.2), **meta_common)
+
+
 def to_np(out: dict) -> dict[str, np.ndarray]:
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
@@ -353,6 +381,9 @@ def main() -> None:
         return
     if "--only-rxn" in sys.argv:
         make_rxn(meta_common)
+        return
+    if "--only-srcos" in sys.argv:
+        make_srcos(meta_common)
         return
     if "--only-cold" in sys.argv:
         make_cold(path, meta_common)

@@ -211,3 +211,27 @@ def test_hvp_fuzz_random_molecules(hip_engine, oracle64, seed):
     spec, hv, f = _spec_and_engine(hip_engine, oracle64, coord, numbers, charge, mol, V)
     _close(hv, spec["hv"], f"fuzz seed {seed}")
     assert_forces_close(f, spec["forces"], f"fuzz seed {seed} (forces of the sweep)")
+
+
+def test_cosine_srcoulomb_envelope_eval_and_hvp():
+    """The SRCoulomb block with the cosine envelope (rc = 4.2 A) - the branch the shipped YAMLs do not take - through the engine:
+    energy / forces / charges of taxol and the 40-atom Hessian + products against the reference's outputs (tests/golden/srcos.npz)."""
+    from aimnetcentral_amd import AIMNet2Calculator, loader
+    from conftest import CHARGE_ATOL, energy_tol
+
+    g = golden("srcos")
+    spec = loader.synthetic_spec(0, sr_envelope="cosine", sr_rc=4.2)
+    assert spec.sr_envelope == "cosine" and abs(spec.sr_rc - 4.2) < 1e-6
+    calc = AIMNet2Calculator(spec, device="cuda:0")
+    out = calc({"coord": g["coord"], "numbers": g["numbers"], "charge": 0.0}, forces=True)
+    assert abs(float(out["energy"][0]) - g["energy"][0]) <= energy_tol(113)
+    assert_forces_close(out["forces"].cpu().numpy(), g["forces"], "taxol, cosine SR envelope")
+    assert np.abs(out["charges"].cpu().numpy() - g["charges"]).max() <= CHARGE_ATOL
+    data = {"coord": g["coord"][:40], "numbers": g["numbers"][:40], "charge": 0.0}
+    res = calc(data, forces=True, hessian=True)
+    H = res["hessian"].cpu().numpy().reshape(120, 120)
+    Href = g["hessian40"].reshape(120, 120)
+    assert np.allclose(H, Href, rtol=1e-3, atol=1e-3) and np.abs(H - Href).max() <= 1e-4, np.abs(H - Href).max()
+    hv4 = calc.hessian_vector_product(data, g["v4"]).cpu().numpy()
+    assert np.abs(hv4 - g["hv4"]).max() <= 1e-4 + 1e-5 * np.abs(g["hv4"]).max(), np.abs(hv4 - g["hv4"]).max()
+    assert_forces_close(res["forces"].cpu().numpy(), g["forces40"], "40 atoms, cosine SR envelope")

@@ -177,3 +177,33 @@ def test_cold_batch_of_256_molecules(oracle32):
     assert (np.abs(res["energy"] - g["energy"]) <= np.maximum(1e-5, 5e-7 * sizes)).all()
     assert_forces_close(res["forces"], g["forces"], "relaxed256")
     assert np.abs(res["charges"] - g["charges"]).max() <= CHARGE_ATOL
+
+
+def test_cosine_srcoulomb_envelope_matches_reference(synth_sd):
+    """SRCoulomb(envelope="cosine", rc=4.2) (lr.py:54-57,986-1032; the shipped YAMLs use the exp mollifier): the oracle against the
+    reference's outputs on the same weights (tests/golden/srcos.npz), the analytic forward/backward and the tangent sweep against
+    the oracle's autograd in fp64."""
+    import torch
+
+    from oracle import aimnet2_analytic as AN
+
+    g = golden("srcos")
+    sd = dict(synth_sd, **{"outputs.srcoulomb.rc": np.asarray(4.2, dtype=np.float32)})
+    m32, m64 = O.OracleModel(sd, torch.float32), O.OracleModel(sd, torch.float64)
+    m32.sr_envelope = m64.sr_envelope = "cosine"
+    res = O.evaluate(m32, g["coord"], g["numbers"], 0.0)
+    assert abs(res["energy"][0] - g["energy"][0]) <= energy_tol(113)
+    assert_forces_close(res["forces"], g["forces"], "taxol, cosine SR envelope")
+    assert np.abs(res["charges"] - g["charges"]).max() <= CHARGE_ATOL
+    exp = O.evaluate(O.OracleModel(synth_sd, torch.float32), g["coord"], g["numbers"], 0.0, forces=False)
+    assert abs(exp["energy"][0] - g["energy"][0]) > 0.1  # not the exp-envelope energy
+    c40, z40 = g["coord"][:40], g["numbers"][:40]
+    H = O.evaluate(m32, c40, z40, 0.0, hessian=True)["hessian"].reshape(120, 120)
+    assert np.abs(H - g["hessian40"].reshape(120, 120)).max() < 2e-4
+    H64 = O.evaluate(m64, c40, z40, 0.0, hessian=True, forces=False)["hessian"].reshape(120, 120)
+    mol = np.zeros(40, dtype=np.int64)
+    ref = O.evaluate(m64, c40, z40, 0.0, return_intermediates=True)
+    nbl, _ = O.neighbor_list(c40, float("inf"), mol)
+    r = AN.evaluate_hvp(m64, c40.astype(np.float64), z40, 0.0, mol, ref["nbmat"], g["v4"].astype(np.float64), nbmat_lr=nbl)
+    assert np.abs(r["hv"].reshape(4, 120) - g["v4"].reshape(4, 120).astype(np.float64) @ H64).max() < 1e-9
+    assert np.abs(r["forces"] - ref["forces"]).max() < 1e-10

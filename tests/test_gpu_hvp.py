@@ -79,6 +79,17 @@ def test_hvp_two_charge_channels(hip_engine_nse, oracle64_nse):
     assert_forces_close(f, g["b5_forces"], "nse b5 (forces of the sweep)")
 
 
+def test_hvp_two_charge_channels_periodic(hip_engine_nse, oracle64_nse):
+    """NSE family in a periodic cell with DSF Coulomb (both channels through the charge convolution, one Coulomb seed for both)."""
+    g = golden("nse")
+    V = np.random.default_rng(13).standard_normal((2, 96, 3)).astype(np.float32)
+    spec, hv, f = _spec_and_engine(hip_engine_nse, oracle64_nse, g["pbc_coord"], g["pbc_numbers"], np.zeros(1, np.float32),
+                                   np.zeros(96, dtype=np.int64), V, cell=g["pbc_cell"],
+                                   kw={"coulomb": "dsf", "dsf_rc": 9.0, "dsf_alpha": 0.2}, mult=g["pbc_mult"])
+    _close(hv, spec["hv"], "nse pbc")
+    assert_forces_close(f, g["pbc_forces"], "nse pbc (forces of the sweep)")
+
+
 def test_hvp_operator_properties(hip_engine):
     """Linearity in v, symmetry of the dense Hessian, translation invariance (H . uniform shift = 0), bitwise repeatability, and
     independence of how the directions are split into sweeps."""

@@ -433,6 +433,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
     constexpr int PAR = decltype(par_c)::value;
     using NPAR = std::integral_constant<int, PAR ^ 1>;
     const unsigned oa = adA + PAR * SA_BYTES, ob = adB + st * BST_BYTES;
+#ifdef AIMNET_BF3_PRIO_L  // measurement builds: issue priority of the load / split segment against the partner's matrix segment
+    __builtin_amdgcn_s_setprio(AIMNET_BF3_PRIO_L);
+#endif
     read_strips<0, SN, 0>(fb, ob);
     read_strips<0, SM, 0>(fa, oa);
     read_strips<0, SN, 1>(fb, ob);
@@ -460,6 +463,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
   // of the accumulators flips: the weight blocks from there on are stored negated ("Accumulation bias" above).
   auto seg_compute = [&](int j, int m, auto mpar_c) __attribute__((always_inline)) {
     constexpr int MPAR = decltype(mpar_c)::value;
+#ifdef AIMNET_BF3_PRIO_C
+    __builtin_amdgcn_s_setprio(AIMNET_BF3_PRIO_C);
+#endif
     if (j == kneg && j > 0) {
 #pragma unroll
       for (int i = 0; i < SM; ++i)

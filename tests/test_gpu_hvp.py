@@ -1,8 +1,8 @@
 """Analytic Hessian-vector products (csrc/hvp.hip, aimnet_engine_hvp through the C ABI) against the hand-derived fp64 tangent
 sweep of the oracle (oracle/aimnet2_analytic.py::evaluate_hvp, itself pinned to the autograd Hessian in
 tests/test_oracle_analytic.py), plus the size-independent properties of the operator.  Tolerance: the sweep is fp32 arithmetic on
-second derivatives of up to several hundred eV/A^2 - 1e-5 relative to the largest element of the product plus 1e-5 absolute
-(measured 2-3e-6 relative), an order of magnitude inside the reference's allclose(1e-3, 1e-3) gate for its own operator
+second derivatives of up to several hundred eV/A^2 - 3e-5 relative to the largest element of the product plus 1e-5 absolute
+(measured 2-3e-6 relative on the fixtures; worst of a 100-seed sweep of random molecules 1.3e-5, tests/tools/hvp_soak.py), well inside the reference's allclose(1e-3, 1e-3) gate for its own operator
 (tests/test_hvp.py:75)."""
 from __future__ import annotations
 
@@ -47,7 +47,7 @@ def _spec_and_engine(eng, om64, coord, numbers, charge, mol, V, cell=None, kw=No
 
 def _close(hv, ref, what):
     err, top = np.abs(hv - ref).max(), np.abs(ref).max()
-    assert err <= 1e-5 + 1e-5 * top, f"{what}: max|d(Hv)| = {err:.3e} on max|Hv| = {top:.3e}"
+    assert err <= 1e-5 + 3e-5 * top, f"{what}: max|d(Hv)| = {err:.3e} on max|Hv| = {top:.3e}"
 
 
 @pytest.mark.parametrize("name,kw", [

@@ -586,20 +586,23 @@ __global__ __launch_bounds__(256) void hvp_unconcat_kernel(const float* __restri
 }
 
 // ---- conv backward + tangent ----------------------------------------------------------------------------------------
-// dE/dr of an ordered pair from this thread's share of (dE/dd, dE/du): rbar = dbar u + (ubar - (ubar . u) u) / d, and its
-// tangent.  Linear in the shares, so every thread accumulates its own 3-vector over the row and the block reduces once.
-__device__ __forceinline__ void rbar_add(float sgn, float dbar, const float ub[3], float tdbar, const float tub[3], float4 u,
-                                         float4 tu, float acc[3], float tacc[3], float out_sign) {
-  const float ux[3] = {sgn * u.x, sgn * u.y, sgn * u.z}, tux[3] = {sgn * tu.x, sgn * tu.y, sgn * tu.z};
+// dE/dr of an ordered pair from a thread's share of (dE/dd, dE/du): rbar = dbar u + (ubar - (ubar . u) u) / d, LINEAR in the
+// share, so every thread accumulates its own 3-vector over the row and the block reduces once.  The two halves of a pair meet
+// at the centre with opposite unit vectors, u_ji = -u_ij, and the projector (1 - u u^T) is even in u:
+//   rbar_ji - rbar_ij = -(dbar_ij + dbar_ji) u + (1 - u u^T) (ubar_ji - ubar_ij) / d
+// - one evaluation with D = dbar_ij + dbar_ji and U = ubar_ji - ubar_ij, and its tangent by the product rule (t_d = tu.w).
+__device__ __forceinline__ void rbar_pair_add(float D, const float U[3], float tD, const float tU[3], float4 u, float4 tu,
+                                              float acc[3], float tacc[3]) {
+  const float ux[3] = {u.x, u.y, u.z}, tux[3] = {tu.x, tu.y, tu.z};
   const float inv = 1.0f / u.w;
-  const float pu = ub[0] * ux[0] + ub[1] * ux[1] + ub[2] * ux[2];
-  const float tpu = tub[0] * ux[0] + tub[1] * ux[1] + tub[2] * ux[2] + ub[0] * tux[0] + ub[1] * tux[1] + ub[2] * tux[2];
+  const float pu = U[0] * ux[0] + U[1] * ux[1] + U[2] * ux[2];
+  const float tpu = tU[0] * ux[0] + tU[1] * ux[1] + tU[2] * ux[2] + U[0] * tux[0] + U[1] * tux[1] + U[2] * tux[2];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float perp = ub[c] - pu * ux[c];
-    const float tperp = tub[c] - tpu * ux[c] - pu * tux[c];
-    acc[c] += out_sign * (dbar * ux[c] + perp * inv);
-    tacc[c] += out_sign * (tdbar * ux[c] + dbar * tux[c] + tperp * inv - perp * inv * inv * tu.w);
+    const float perp = U[c] - pu * ux[c];
+    const float tperp = tU[c] - tpu * ux[c] - pu * tux[c];
+    acc[c] += perp * inv - D * ux[c];
+    tacc[c] += tperp * inv - perp * inv * inv * tu.w - tD * ux[c] - D * tux[c];
   }
 }
 
@@ -652,21 +655,35 @@ __global__ __launch_bounds__(256) void hvp_conv_bwd_kernel(bool need_abar, const
     const float tPp = tSj.x - (tu.x * Sj.y + tu.y * Sj.z + tu.z * Sj.w) - (u.x * tSj.y + u.y * tSj.z + u.z * tSj.w);
     acc_b += gs * Pp;
     tacc_b += tgs * Pp + gs * tPp;
-    const float dij = cj * P * dgs, tdij = tcj * P * dgs + cj * tP * dgs + cj * P * tdgs;
-    const float dji = ci * Pp * dgs, tdji = tci * Pp * dgs + ci * tPp * dgs + ci * Pp * tdgs;
-    const float gc = gs * cj, tgc = tgs * cj + gs * tcj;
-    const float uij[3] = {gc * Si.y, gc * Si.z, gc * Si.w};
-    const float tuij[3] = {tgc * Si.y + gc * tSi.y, tgc * Si.z + gc * tSi.z, tgc * Si.w + gc * tSi.w};
-    const float gi = gs * ci, tgi = tgs * ci + gs * tci;
-    const float uji[3] = {gi * Sj.y, gi * Sj.z, gi * Sj.w};
-    const float tuji[3] = {tgi * Sj.y + gi * tSj.y, tgi * Sj.z + gi * tSj.z, tgi * Sj.w + gi * tSj.w};
-    rbar_add(1.0f, dij, uij, tdij, tuij, u, tu, xa, txa, -1.0f);
-    rbar_add(-1.0f, dji, uji, tdji, tuji, u, tu, xa, txa, 1.0f);
+    // D = dbar_ij + dbar_ji = gs' (c_j P + c_i P'),  U = ubar_ji - ubar_ij = gs (c_i Sbar_jv - c_j Sbar_iv)
+    const float w = cj * P + ci * Pp;
+    const float tw = tcj * P + cj * tP + tci * Pp + ci * tPp;
+    const float D = w * dgs, tD = tw * dgs + w * tdgs;
+    const float v[3] = {ci * Sj.y - cj * Si.y, ci * Sj.z - cj * Si.z, ci * Sj.w - cj * Si.w};
+    const float tvv[3] = {tci * Sj.y + ci * tSj.y - tcj * Si.y - cj * tSi.y, tci * Sj.z + ci * tSj.z - tcj * Si.z - cj * tSi.z,
+                          tci * Sj.w + ci * tSj.w - tcj * Si.w - cj * tSi.w};
+    const float U[3] = {gs * v[0], gs * v[1], gs * v[2]};
+    const float tU[3] = {tgs * v[0] + gs * tvv[0], tgs * v[1] + gs * tvv[1], tgs * v[2] + gs * tvv[2]};
+    rbar_pair_add(D, U, tD, tU, u, tu, xa, txa);
   };
   for (int m0 = 0; m0 < cnt; m0 += HCH) {
     stage_chunk(st, i, m0, cnt, nb_idx, pg, cap, tvk, bp);
     const float shift = s_shift[g];
     const int mc = min(HCH, cnt - m0);
+#ifdef AIMNET_PROBE_HVP_PREFETCH  // measurement builds: the next neighbour's four rows requested ahead of this one's arithmetic
+    auto rows = [&](int m, float& aj, float& taj, float4& Sbj, float4& tSbj) __attribute__((always_inline)) {
+      const int j = st.j[m];
+      const size_t rj = row_of ? (size_t)min(63, max(0, row_of[j])) : (size_t)j;
+      const size_t trj = (size_t)k * N + j;
+      aj = a[rj * NF + f];
+      taj = ta ? ta[trj * NF + f] : 0.0f;
+      Sbj = reinterpret_cast<const float4*>(Sbar)[(size_t)j * NF + f];
+      tSbj = reinterpret_cast<const float4*>(tSbar)[trj * NF + f];
+    };
+    float aj_n = 0.f, taj_n = 0.f;
+    float4 Sbj_n = make_float4(0, 0, 0, 0), tSbj_n = Sbj_n;
+    if (mc > 0) rows(0, aj_n, taj_n, Sbj_n, tSbj_n);
+#endif
     // (requesting the NEXT neighbour's four rows before this one's arithmetic was measured slower: 3.0 -> 4.5 ms per sweep on
     // 10 080 atoms - ten more live registers across ~250 instructions of product-rule terms)
     for (int m = 0; m < mc; ++m) {
@@ -675,11 +692,17 @@ __global__ __launch_bounds__(256) void hvp_conv_bwd_kernel(bool need_abar, const
       float gs, dgs, d2gs;
       basis_g2(bp.eta, shift, u.w, make_float3(fc.x, fc.y, fc.z), gs, dgs, d2gs);
       const float tgs = dgs * tu.w, tdgs = d2gs * tu.w;
-      const size_t rj = row_of ? (size_t)min(63, max(0, row_of[j])) : (size_t)j;
       const size_t trj = (size_t)k * N + j;
+#ifdef AIMNET_PROBE_HVP_PREFETCH
+      const float aj = aj_n, taj = taj_n;
+      const float4 Sbj = Sbj_n, tSbj = tSbj_n;
+      if (m + 1 < mc) rows(m + 1, aj_n, taj_n, Sbj_n, tSbj_n);
+#else
+      const size_t rj = row_of ? (size_t)min(63, max(0, row_of[j])) : (size_t)j;
       const float aj = a[rj * NF + f], taj = ta ? ta[trj * NF + f] : 0.0f;
       const float4 Sbj = reinterpret_cast<const float4*>(Sbar)[(size_t)j * NF + f];
       const float4 tSbj = reinterpret_cast<const float4*>(tSbar)[trj * NF + f];
+#endif
       pair_terms(aj, taj, ai, tai, Sbi, tSbi, Sbj, tSbj, u, tu, gs, dgs, tgs, tdgs, ab, tab);
       if (qthr) {
         const float qj = q[(size_t)qc * N + j], tqj = tq[((size_t)k * NQ + qc) * N + j];

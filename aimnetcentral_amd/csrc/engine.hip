@@ -741,6 +741,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const float* q_fin = nq == 2 ? W.qtot : W.q[np - 2];
   const bool overlap = e->overlap_coulomb && e->prof_level < 2;  // per-family profiling wants one stream
   bool charges_written = false;  // the DSF walk's charge stream kernel copies q to the `charges` output on its way
+  SrRiders head_rider{};  // the last energy-head layer rides on the SR-Coulomb launch (filled in below when both run on one stream)
   auto coulomb_block = [&](hipStream_t cs) -> int {
     if (nq == 2)  // NSE: alpha + beta is the charge everything downstream sees (aimnet2.py:102-106)
       RC(launch_charge_sum(cs, W.q[np - 2], N, W.qtot, out->spin_charges));
@@ -750,8 +751,17 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     cp.sr_envelope = ar.sr_envelope;
     cp.dsf_rc = opt->dsf_rc;
     cp.dsf_alpha = opt->dsf_alpha;
+    const bool walk = coulomb == AIMNET_COULOMB_DSF && pbc && !ext &&
+                      !(d3 && opt->d3_cutoff == opt->dsf_rc);  // the list-free DSF walk runs below: its charge stream rides here
+    SrRiders rd = head_rider;
+    if (walk) {
+      rd.xs = W.nl.xs;
+      rd.xq = (float4*)W.nl.sorted_tmp_xq;
+      rd.charges_out = out->charges;
+      rd.n_stream_blocks = ceil_div(N, 256);
+    }
     RC(launch_coulomb_sr(cs, grad, want_s, ar.sr_coulomb != 0, q_fin, W.nb_idx, W.nb_cnt, W.pg, cap, cp, N, W.ecoul, W.qbar,
-                         W.fgrad, W.virial_atom));
+                         W.fgrad, W.virial_atom, &rd));
     // DSF and DFT-D3 with one cutoff: the Coulomb pair terms ride on the D3 pair pass (one list, one geometry evaluation)
     const bool dsf_in_d3 = !ext && d3 && coulomb == AIMNET_COULOMB_DSF && opt->d3_cutoff == opt->dsf_rc;
     if (coulomb == AIMNET_COULOMB_SIMPLE && ext && in->nbmat_lr)  // coul_simple over the caller's matrix (lr.py:311-331)
@@ -763,7 +773,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       ;  // see launch_dftd3 below
     else if (coulomb == AIMNET_COULOMB_DSF && pbc && !ext) {
       RC(launch_coulomb_dsf_walk(cs, grad, want_s, q_fin, mol_c, W.nl, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom,
-                                 out->charges));
+                                 out->charges, true));
       charges_written = true;
     } else if (coulomb == AIMNET_COULOMB_DSF)
       RC(launch_coulomb_dsf(cs, grad, want_s, q_fin, W.nl.xw, mol_c, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt,
@@ -809,16 +819,16 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     }
     if (p < np - 1) {
       RC(prof_mark(e, s, FAM_POINTWISE));
+      // (the feature update a^{p+1} = a^p + delta_a rides on the NSE launch: independent work, one kernel boundary less)
       RC(launch_nse_fwd(s, W.H[p][nl - 1], Ls[nl - 1].k_out, nq, p > 0 ? W.q[p - 1] : nullptr, W.nl.mol_start, in->charge,
-                        n_mol, N, W.S, (float*)W.part, W.q[p], W.Fm[p], W.Dm[p]));
+                        n_mol, N, W.S, (float*)W.part, W.q[p], W.Fm[p], W.Dm[p], p == 0 ? e->afv : W.a[p],
+                        p == 0 ? in->numbers : nullptr, W.a[p + 1], W.at[p + 1]));
       if (p == np - 2 && overlap) {  // the final charges exist: the Coulomb block starts on the side stream
         AIMNET_HIP_CHECK(hipEventRecord(e->ev_fork, s));
         AIMNET_HIP_CHECK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
         RC(coulomb_block(e->side));
         AIMNET_HIP_CHECK(hipEventRecord(e->ev_join, e->side));
       }
-      RC(launch_update_a(s, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr, W.H[p][nl - 1], Ls[nl - 1].k_out, nq, N,
-                         W.a[p + 1], W.at[p + 1]));
     }
   }
   {
@@ -835,8 +845,15 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     }
     RC(prof_mark(e, s, FAM_POINTWISE));
     // with gradients: the same kernel writes the backward seed d e / d z_{nh-2} = w_last * GELU'(z) into zb0
-    RC(launch_head_last(s, hin, ld_in, e->head_w_last, e->head_b_last, e->head[nh - 1].n_in, N, W.e_atom,
-                        grad ? W.hD[nh - 2] : nullptr, grad ? W.zb0 : nullptr));
+    if (overlap) {
+      RC(launch_head_last(s, hin, ld_in, e->head_w_last, e->head_b_last, e->head[nh - 1].n_in, N, W.e_atom,
+                          grad ? W.hD[nh - 2] : nullptr, grad ? W.zb0 : nullptr));
+    } else {  // same stream: independent of the Coulomb block, so it shares that block's first launch (kernels.h, SrRiders)
+      head_rider.h = hin; head_rider.ldh = ld_in; head_rider.w = e->head_w_last; head_rider.b = e->head_b_last;
+      head_rider.k = e->head[nh - 1].n_in; head_rider.e_atom = W.e_atom;
+      head_rider.d = grad ? W.hD[nh - 2] : nullptr; head_rider.zbar = grad ? W.zb0 : nullptr;
+      head_rider.n_head_blocks = ceil_div(N, 4);
+    }
   }
 
   if (!overlap) {

@@ -155,7 +155,10 @@ int launch_conv_sv_bwd_bwd(hipStream_t s, const float* grad_out, const float* gr
 // nq = charge channels (1, or 2 for NSE models): q planes [nq][n_atoms], charge / Fm / Dm / Wbar planes [nq][n_mol];
 // the MLP output row is [q~ (nq) | f~ (nq) | delta_a (256)] (aimnet2.py:123-130)
 int launch_nse_fwd(hipStream_t s, const float* y, int ldy, int nq, const float* q_prev, const int* mol_start,
-                   const float* charge, int n_mol, int n_atoms, int S, float* part, float* q_new, float* Fm, float* Dm);
+                   const float* charge, int n_mol, int n_atoms, int S, float* part, float* q_new, float* Fm, float* Dm,
+                   // upd_a_new != NULL: a_new = a + delta_a (launch_update_a with these arguments) rides on the same launch
+                   const float* upd_a = nullptr, const int* upd_row_of = nullptr, float* upd_a_new = nullptr,
+                   float* upd_a_t = nullptr);
 int launch_charge_sum(hipStream_t s, const float* q2, int n_atoms, float* q_tot, float* q_spin);
 int launch_update_a(hipStream_t s, const float* a, const int* row_of, const float* y, int ldy, int nq, int n_atoms, float* a_new,
                     float* a_t = nullptr);  // a_t: optional copy in the operand layout of the MFMA conv kernels
@@ -189,10 +192,17 @@ int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const i
                  float cutoff, int n_atoms, float4* xs4, float* d3w, float* dEdcn, double* ecoul, float* fgrad,
                  float* virial_atom, bool with_dsf, CoulombParams cp, const float* q, float* qbar);
 // with_dsf: the DSF Coulomb pair sum (cutoff == cp.dsf_rc) is evaluated in the same pair pass; adds to ecoul / qbar too
+// Independent work that rides on the SR-Coulomb launch (role-dispatched blocks behind the pair blocks; a kernel boundary costs
+// 4-5 us on the device): launch_head_last's arguments (n_head_blocks = ceil(n_atoms / 4), 0 = none) and the charge stream of the
+// list-free DSF walk (n_stream_blocks = ceil(n_atoms / 256), 0 = none; xs / xq = NlistBuffers::xs / sorted_tmp_xq)
+struct SrRiders {
+  const float* h; int ldh; const float* w; const float* b; int k; float* e_atom; const float* d; float* zbar; int n_head_blocks;
+  const float4* xs; float4* xq; float* charges_out; int n_stream_blocks;
+};
 // embedded SRCoulomb subtraction over the rc list (sets ecoul/qbar/fgrad/virial_atom)
 int launch_coulomb_sr(hipStream_t s, bool grad, bool stress, bool enabled, const float* q, const int* nb_idx,
                       const int* nb_cnt, const float4* pg, int cap, CoulombParams cp, int n_atoms, double* ecoul,
-                      float* qbar, float* fgrad, float* virial_atom);
+                      float* qbar, float* fgrad, float* virial_atom, const SrRiders* riders = nullptr);
 int launch_coulomb_simple(hipStream_t s, bool grad, const float* q, const float* xw, const int* mol_idx,
                           const int* mol_start, CoulombParams cp, int n_atoms, double* ecoul, float* qbar,
                           float* fgrad);
@@ -203,7 +213,8 @@ int launch_coulomb_dsf(hipStream_t s, bool grad, bool stress, const float* q, co
 // periodic DSF straight from the cell grid of the last launch_bins (no neighbour matrix)
 int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, NlistBuffers& b,
                             CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom,
-                            float* charges_out = nullptr);  // charges_out: also copy q to the charges output
+                            float* charges_out = nullptr,  // charges_out: also copy q to the charges output
+                            bool stream_done = false);    // the (x, y, z, q) stream was written by an SrRiders launch
 int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, int nq, const int* mol_start, int n_mol,
                           int n_atoms, int S, float* part);  // part: [nq][n_mol][S] partial sums, consumed by launch_build_zbar
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,

@@ -29,14 +29,43 @@ __device__ __forceinline__ T block_sum(T v, T* sh) {
   return r;
 }
 
+struct UpdateA {  // a_new = a + delta_a (+ the transposed copy): arguments of update_a, also carried by the NSE launches below
+  const float* a;
+  const int* row_of;
+  const float* y;
+  int ldy, col0, n_atoms;
+  float* a_new;
+  float* a_t;
+};
+
+__device__ __forceinline__ void update_a_block(const UpdateA& u, size_t block) {
+  const size_t e = block * 256 + threadIdx.x;
+  if (e >= (size_t)u.n_atoms * 256) return;
+  const size_t i = e >> 8;
+  const int k = (int)(e & 255);
+  const size_t ri = u.row_of ? (size_t)min(63, max(0, u.row_of[i])) : i;
+  const float v = u.a[ri * 256 + k] + u.y[i * u.ldy + u.col0 + k];
+  u.a_new[e] = v;
+  if (u.a_t) {
+    const int aa = k >> 4, g = k & 15;
+    u.a_t[i * 256 + g * 16 + aa] = v;
+  }
+}
+
 // ---- NSE forward -------------------------------------------------------------------------------
 // One charge channel per launch: the channel's q~ and f~ sit in columns qcol / fcol of the MLP output row
 // (aimnet2.py:123-130: split [nq, nq, rest]); q planes, charge, Fm, Dm are that channel's [N] / [n_mol] arrays.
+// (blocks beyond the n_mol molecule blocks run update_a: a_new = a + delta_a reads the same MLP output rows and depends on nothing
+// the charge update produces, so the two share one launch - every kernel boundary costs 4-5 us on the device)
 __global__ __launch_bounds__(256) void nse_fwd_kernel(const float* __restrict__ y, int ldy, int qcol, int fcol,
                                                      const float* __restrict__ q_prev,
                                                      const int* __restrict__ mol_start, const float* __restrict__ charge,
                                                      float* __restrict__ q_new, float* __restrict__ Fm,
-                                                     float* __restrict__ Dm) {
+                                                     float* __restrict__ Dm, int n_mol, UpdateA upd) {
+  if ((int)blockIdx.x >= n_mol) {
+    update_a_block(upd, blockIdx.x - n_mol);
+    return;
+  }
   __shared__ float sh[4];
   const int m = blockIdx.x;
   const int i0 = mol_start[m], i1 = mol_start[m + 1];
@@ -96,9 +125,14 @@ __global__ __launch_bounds__(256) void nse_fwd_apply_kernel(const float* __restr
                                                            const int* __restrict__ mol_start,
                                                            const float* __restrict__ charge, int S,
                                                            const float* __restrict__ part, float* __restrict__ q_new,
-                                                           float* __restrict__ Fm, float* __restrict__ Dm) {
+                                                           float* __restrict__ Fm, float* __restrict__ Dm, int n_mol,
+                                                           UpdateA upd) {
+  if ((int)blockIdx.x >= S * n_mol) {  // update_a blocks ride on the same launch (see nse_fwd_kernel)
+    update_a_block(upd, blockIdx.x - S * n_mol);
+    return;
+  }
   __shared__ float shFD[2];
-  const int m = blockIdx.y, sl = blockIdx.x;
+  const int m = blockIdx.x / S, sl = blockIdx.x % S;
   if (threadIdx.x == 0) {
     float sf = 0.f, sq = 0.f;
     for (int k = 0; k < S; ++k) {
@@ -124,21 +158,28 @@ __global__ __launch_bounds__(256) void nse_fwd_apply_kernel(const float* __restr
 }
 
 int launch_nse_fwd(hipStream_t s, const float* y, int ldy, int nq, const float* q_prev, const int* mol_start,
-                   const float* charge, int n_mol, int n_atoms, int S, float* part, float* q_new, float* Fm, float* Dm) {
+                   const float* charge, int n_mol, int n_atoms, int S, float* part, float* q_new, float* Fm, float* Dm,
+                   const float* upd_a, const int* upd_row_of, float* upd_a_new, float* upd_a_t) {
+  // upd_a_new != NULL: the feature update a_new = a + delta_a (launch_update_a) rides on the launch of channel 0
+  const UpdateA none{nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
+  const UpdateA upd{upd_a, upd_row_of, y, ldy, 2 * nq, n_atoms, upd_a_new, upd_a_t};
+  const int n_upd = upd_a_new ? (int)(((size_t)n_atoms * 256 + 255) / 256) : 0;
   for (int ch = 0; ch < nq; ++ch) {  // channels are independent (ops.nse works on the trailing channel axis)
     const float* qp = q_prev ? q_prev + (size_t)ch * n_atoms : nullptr;
     const float* Q = charge + (size_t)ch * n_mol;
     float* qn = q_new + (size_t)ch * n_atoms;
     float *F = Fm + (size_t)ch * n_mol, *D = Dm + (size_t)ch * n_mol;
+    const int extra = ch == 0 ? n_upd : 0;
     if (S <= 1) {
-      hipLaunchKernelGGL(nse_fwd_kernel, dim3(n_mol), dim3(256), 0, s, y, ldy, ch, nq + ch, qp, mol_start, Q, qn, F, D);
+      hipLaunchKernelGGL(nse_fwd_kernel, dim3(n_mol + extra), dim3(256), 0, s, y, ldy, ch, nq + ch, qp, mol_start, Q, qn, F, D, n_mol,
+                         ch == 0 ? upd : none);
       AIMNET_LAUNCH_CHECK();
       continue;
     }
     hipLaunchKernelGGL(nse_fwd_partial_kernel, dim3(S, n_mol), dim3(256), 0, s, y, ldy, ch, nq + ch, qp, mol_start, S, part);
     AIMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nse_fwd_apply_kernel, dim3(S, n_mol), dim3(256), 0, s, y, ldy, ch, nq + ch, qp, mol_start, Q, S, part, qn,
-                       F, D);
+    hipLaunchKernelGGL(nse_fwd_apply_kernel, dim3(S * n_mol + extra), dim3(256), 0, s, y, ldy, ch, nq + ch, qp, mol_start, Q, S, part,
+                       qn, F, D, n_mol, ch == 0 ? upd : none);
     AIMNET_LAUNCH_CHECK();
   }
   return 0;
@@ -164,26 +205,13 @@ int launch_charge_sum(hipStream_t s, const float* q2, int n_atoms, float* q_tot,
 // the initial features a^0 = afv[Z] (aimnet2.py:145-148) are never materialised
 // a_t (may be NULL): second copy of the new feature row in the operand layout of the MFMA conv kernels (conv_mfma.hip):
 // the transpose [g][a], feature (a, g) at float g * 16 + a
-__global__ void update_a_kernel(const float* __restrict__ a, const int* __restrict__ row_of, const float* __restrict__ y, int ldy,
-                                int col0, int n_atoms, float* __restrict__ a_new, float* __restrict__ a_t) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (size_t)n_atoms * 256) return;
-  const size_t i = e >> 8;
-  const int k = (int)(e & 255);
-  const size_t ri = row_of ? (size_t)min(63, max(0, row_of[i])) : i;
-  const float v = a[ri * 256 + k] + y[i * ldy + col0 + k];
-  a_new[e] = v;
-  if (a_t) {
-    const int aa = k >> 4, g = k & 15;
-    a_t[i * 256 + g * 16 + aa] = v;
-  }
-}
+__global__ void update_a_kernel(UpdateA u) { update_a_block(u, blockIdx.x); }
 
 int launch_update_a(hipStream_t s, const float* a, const int* row_of, const float* y, int ldy, int nq, int n_atoms, float* a_new,
                     float* a_t) {
   const size_t n = (size_t)n_atoms * 256;
-  hipLaunchKernelGGL(update_a_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, row_of, y, ldy, 2 * nq, n_atoms,
-                     a_new, a_t);
+  const UpdateA u{a, row_of, y, ldy, 2 * nq, n_atoms, a_new, a_t};
+  hipLaunchKernelGGL(update_a_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }
@@ -191,10 +219,10 @@ int launch_update_a(hipStream_t s, const float* a, const int* row_of, const floa
 // ---- energy head last layer (k -> 1) and its adjoint seed ---------------------------------------
 // d / zbar (may be NULL): the adjoint seed of the backward sweep, zbar = w * GELU'(z) of the layer below (ldh wide, zero
 // padding beyond k), is written by the same wave - dE/de_atom = 1, so it does not wait for anything
-__global__ void head_last_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ w,
-                                 const float* __restrict__ b, int k, int n_atoms, float* __restrict__ e_atom,
-                                 const float* __restrict__ d, float* __restrict__ zbar) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void head_last_block(const float* __restrict__ h, int ldh, const float* __restrict__ w,
+                                                const float* __restrict__ b, int k, int n_atoms, float* __restrict__ e_atom,
+                                                const float* __restrict__ d, float* __restrict__ zbar, int block) {
+  const int i = block * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
   float acc = 0.f;
@@ -203,6 +231,24 @@ __global__ void head_last_kernel(const float* __restrict__ h, int ldh, const flo
   if (lane == 0) e_atom[i] = acc + b[0];
   if (zbar)
     for (int c = lane; c < ldh; c += 64) zbar[(size_t)i * ldh + c] = (c < k) ? w[c] * d[(size_t)i * ldh + c] : 0.0f;
+}
+
+__global__ void head_last_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ w,
+                                 const float* __restrict__ b, int k, int n_atoms, float* __restrict__ e_atom,
+                                 const float* __restrict__ d, float* __restrict__ zbar) {
+  head_last_block(h, ldh, w, b, k, n_atoms, e_atom, d, zbar, blockIdx.x);
+}
+
+// bin-ordered (x, y, z, q) stream of the list-free DSF walk (see charge_stream_kernel below), one 256-thread block of it
+__device__ __forceinline__ void charge_stream_block(const float4* __restrict__ xs, const float* __restrict__ q, int n_atoms,
+                                                    float4* __restrict__ xq, float* __restrict__ charges_out, int block) {
+  const int k = block * 256 + threadIdx.x;
+  if (k >= n_atoms) return;
+  const float4 c = xs[k];
+  const int id = __float_as_int(c.w);
+  const float qv = q[id];
+  xq[k] = make_float4(c.x, c.y, c.z, qv);
+  if (charges_out) charges_out[id] = qv;
 }
 
 int launch_head_last(hipStream_t s, const float* h, int ldh, const float* w, const float* b, int k, int n_atoms,
@@ -324,7 +370,16 @@ __global__ __launch_bounds__(256) void coulomb_sr_kernel(bool enabled, const flo
                                                         const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
                                                         const float4* __restrict__ pg, int cap, CoulombParams cp,
                                                         int n_atoms, double* __restrict__ ecoul, float* __restrict__ qbar,
-                                                        float* __restrict__ fgrad, float* __restrict__ virial_atom) {
+                                                        float* __restrict__ fgrad, float* __restrict__ virial_atom, SrRiders rd) {
+  // independent work that rides on this launch (a kernel boundary costs 4-5 us on the device): the last energy-head layer with
+  // its backward seed, and the charge stream of the list-free DSF walk
+  const int n_sr = (n_atoms + 3) >> 2;
+  if ((int)blockIdx.x >= n_sr) {
+    const int b = blockIdx.x - n_sr;
+    if (b < rd.n_head_blocks) head_last_block(rd.h, rd.ldh, rd.w, rd.b, rd.k, n_atoms, rd.e_atom, rd.d, rd.zbar, b);
+    else charge_stream_block(rd.xs, q, n_atoms, rd.xq, rd.charges_out, b - rd.n_head_blocks);
+    return;
+  }
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
@@ -358,17 +413,19 @@ __global__ __launch_bounds__(256) void coulomb_sr_kernel(bool enabled, const flo
 
 int launch_coulomb_sr(hipStream_t s, bool grad, bool stress, bool enabled, const float* q, const int* nb_idx,
                       const int* nb_cnt, const float4* pg, int cap, CoulombParams cp, int n_atoms, double* ecoul,
-                      float* qbar, float* fgrad, float* virial_atom) {
-  dim3 grid(ceil_div(n_atoms, 4)), block(256);
+                      float* qbar, float* fgrad, float* virial_atom, const SrRiders* riders) {
+  SrRiders rd{};
+  if (riders) rd = *riders;
+  dim3 grid(ceil_div(n_atoms, 4) + rd.n_head_blocks + rd.n_stream_blocks), block(256);
   if (grad && stress)
     hipLaunchKernelGGL((coulomb_sr_kernel<true, true>), grid, block, 0, s, enabled, q, nb_idx, nb_cnt, pg, cap, cp, n_atoms,
-                       ecoul, qbar, fgrad, virial_atom);
+                       ecoul, qbar, fgrad, virial_atom, rd);
   else if (grad)
     hipLaunchKernelGGL((coulomb_sr_kernel<true, false>), grid, block, 0, s, enabled, q, nb_idx, nb_cnt, pg, cap, cp, n_atoms,
-                       ecoul, qbar, fgrad, virial_atom);
+                       ecoul, qbar, fgrad, virial_atom, rd);
   else
     hipLaunchKernelGGL((coulomb_sr_kernel<false, false>), grid, block, 0, s, enabled, q, nb_idx, nb_cnt, pg, cap, cp,
-                       n_atoms, ecoul, qbar, fgrad, virial_atom);
+                       n_atoms, ecoul, qbar, fgrad, virial_atom, rd);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }
@@ -592,23 +649,19 @@ __global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __re
 // (charges_out, may be NULL: the `charges` output of the evaluation is written on the way - every atom appears once in the stream)
 __global__ void charge_stream_kernel(const float4* __restrict__ xs, const float* __restrict__ q, int n_atoms,
                                      float4* __restrict__ xq, float* __restrict__ charges_out) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_atoms) return;
-  const float4 c = xs[k];
-  const int id = __float_as_int(c.w);
-  const float qv = q[id];
-  xq[k] = make_float4(c.x, c.y, c.z, qv);
-  if (charges_out) charges_out[id] = qv;
+  charge_stream_block(xs, q, n_atoms, xq, charges_out, blockIdx.x);
 }
 
 int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, NlistBuffers& b,
                             CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom,
-                            float* charges_out) {
+                            float* charges_out, bool stream_done) {
   dim3 grid(ceil_div(n_atoms, 4)), block(256);
   const NlistSystem* sys = (const NlistSystem*)b.sys;
   float4* xq = (float4*)b.sorted_tmp_xq;
-  hipLaunchKernelGGL(charge_stream_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.xs, q, n_atoms, xq, charges_out);
-  AIMNET_LAUNCH_CHECK();
+  if (!stream_done) {  // (normally the stream rides on the SR-Coulomb launch, SrRiders)
+    hipLaunchKernelGGL(charge_stream_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.xs, q, n_atoms, xq, charges_out);
+    AIMNET_LAUNCH_CHECK();
+  }
   if (grad && stress)
     hipLaunchKernelGGL((coulomb_dsf_walk_kernel<true, true>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, xq, cp,
                        n_atoms, ecoul, qbar, fgrad, virial_atom);

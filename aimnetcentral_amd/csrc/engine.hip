@@ -865,8 +865,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   auto join = [&]() -> int {
     if (overlap) AIMNET_HIP_CHECK(hipStreamWaitEvent(s, e->ev_join, 0));
     RC(prof_mark(e, s, FAM_POINTWISE));
-    RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, W.S, W.part, out->energy));
-    if (!charges_written) RC(launch_copy_f32(s, q_fin, out->charges, (size_t)N));
+    RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, W.S, W.part, out->energy,
+                            q_fin, charges_written ? nullptr : out->charges, N));  // + the charges output, unless the DSF walk wrote it
     return 0;
   };
   if (!grad) {

@@ -166,7 +166,9 @@ int launch_update_a(hipStream_t s, const float* a, const int* row_of, const floa
 int launch_head_last(hipStream_t s, const float* h, int ldh, const float* w, const float* b, int k, int n_atoms,
                      float* e_atom, const float* d, float* zbar);
 int launch_energy_reduce(hipStream_t s, const float* e_atom, const double* ecoul, const int* numbers,
-                         const double* sae, const int* mol_start, int n_mol, int S, double* part, double* energy);
+                         const double* sae, const int* mol_start, int n_mol, int S, double* part, double* energy,
+                         // copy_dst != NULL: copy_n floats copy_src -> copy_dst ride on the same launch (the charges output)
+                         const float* copy_src = nullptr, float* copy_dst = nullptr, int copy_n = 0);
 struct CoulombParams {
   float factor;      // 1/2 Hartree Bohr
   float sr_rc;       // exp / cosine envelope radius (SRCoulomb)

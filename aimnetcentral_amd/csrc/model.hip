@@ -263,9 +263,15 @@ __global__ __launch_bounds__(256) void energy_partial_kernel(const float* __rest
                                                             const int* __restrict__ numbers,
                                                             const double* __restrict__ sae,
                                                             const int* __restrict__ mol_start, int S,
-                                                            double* __restrict__ part) {
+                                                            double* __restrict__ part, int n_red, const float* __restrict__ cp_src,
+                                                            float* __restrict__ cp_dst, int cp_n) {
+  if ((int)blockIdx.x >= n_red) {  // rider: the copy of the charges into the output (independent; one kernel boundary less)
+    const int e = (blockIdx.x - n_red) * 256 + threadIdx.x;
+    if (e < cp_n) cp_dst[e] = cp_src[e];
+    return;
+  }
   __shared__ double sh[4];
-  const int m = blockIdx.y, sl = blockIdx.x;
+  const int m = blockIdx.x / S, sl = blockIdx.x % S;
   int lo, hi;
   slice_bounds(mol_start, m, sl, S, lo, hi);
   double acc = 0.0;
@@ -286,10 +292,12 @@ __global__ void energy_finish_kernel(const double* __restrict__ part, int S, int
 }
 
 int launch_energy_reduce(hipStream_t s, const float* e_atom, const double* ecoul, const int* numbers,
-                         const double* sae, const int* mol_start, int n_mol, int S, double* part, double* energy) {
+                         const double* sae, const int* mol_start, int n_mol, int S, double* part, double* energy,
+                         const float* copy_src, float* copy_dst, int copy_n) {
   S = S < 1 ? 1 : S;
-  hipLaunchKernelGGL(energy_partial_kernel, dim3(S, n_mol), dim3(256), 0, s, e_atom, ecoul, numbers, sae, mol_start, S,
-                     S == 1 ? energy : part);
+  const int n_red = S * n_mol, n_cp = copy_dst ? ceil_div(copy_n, 256) : 0;
+  hipLaunchKernelGGL(energy_partial_kernel, dim3(n_red + n_cp), dim3(256), 0, s, e_atom, ecoul, numbers, sae, mol_start, S,
+                     S == 1 ? energy : part, n_red, copy_src, copy_dst, copy_n);
   AIMNET_LAUNCH_CHECK();
   if (S > 1) {
     hipLaunchKernelGGL(energy_finish_kernel, dim3(ceil_div(n_mol, 64)), dim3(64), 0, s, part, S, n_mol, energy);

@@ -760,6 +760,12 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       rd.charges_out = out->charges;
       rd.n_stream_blocks = ceil_div(N, 256);
     }
+    const bool simple_all = coulomb == AIMNET_COULOMB_SIMPLE && !(ext && in->nbmat_lr);  // all pairs of the molecule: same waves
+    if (simple_all) {
+      rd.simple_xw = W.nl.xw;
+      rd.simple_mol_idx = mol_c;
+      rd.simple_mol_start = W.nl.mol_start;
+    }
     RC(launch_coulomb_sr(cs, grad, want_s, ar.sr_coulomb != 0, q_fin, W.nb_idx, W.nb_cnt, W.pg, cap, cp, N, W.ecoul, W.qbar,
                          W.fgrad, W.virial_atom, &rd));
     // DSF and DFT-D3 with one cutoff: the Coulomb pair terms ride on the D3 pair pass (one list, one geometry evaluation)
@@ -768,7 +774,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       RC(launch_coulomb_dsf(cs, grad, false, q_fin, W.nl.xw, mol_c, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt, cap_lr, cp, N,
                             W.ecoul, W.qbar, W.fgrad, W.virial_atom, true));
     else if (coulomb == AIMNET_COULOMB_SIMPLE)
-      RC(launch_coulomb_simple(cs, grad, q_fin, W.nl.xw, mol_c, W.nl.mol_start, cp, N, W.ecoul, W.qbar, W.fgrad));
+      ;  // ran inside the SR-Coulomb launch above (SrRiders::simple_xw)
     else if (dsf_in_d3)
       ;  // see launch_dftd3 below
     else if (coulomb == AIMNET_COULOMB_DSF && pbc && !ext) {

@@ -200,6 +200,8 @@ int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const i
 struct SrRiders {
   const float* h; int ldh; const float* w; const float* b; int k; float* e_atom; const float* d; float* zbar; int n_head_blocks;
   const float4* xs; float4* xq; float* charges_out; int n_stream_blocks;
+  // simple_xw != NULL: the "simple" LRCoulomb term (launch_coulomb_simple with these arguments) in the same waves
+  const float* simple_xw; const int* simple_mol_idx; const int* simple_mol_start;
 };
 // embedded SRCoulomb subtraction over the rc list (sets ecoul/qbar/fgrad/virial_atom)
 int launch_coulomb_sr(hipStream_t s, bool grad, bool stress, bool enabled, const float* q, const int* nb_idx,

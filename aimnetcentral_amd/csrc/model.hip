@@ -417,6 +417,22 @@ __global__ __launch_bounds__(256) void coulomb_sr_kernel(bool enabled, const flo
     }
   }
   pair_store<GRAD, STRESS, false>(A, i, lane, -cp.factor, 0.0, 0.0f, ecoul, qbar, fgrad, virial_atom);
+  if (rd.simple_xw) {  // LRCoulomb "simple" (all pairs of the molecule, coulomb_simple_kernel below) in the same wave: it accumulates
+    // onto what this wave has just stored - the same sums in the same order as the separate launch, one kernel boundary less
+    const float* __restrict__ xw = rd.simple_xw;
+    const int mi = rd.simple_mol_idx[i];
+    const int j0 = rd.simple_mol_start[mi], j1 = rd.simple_mol_start[mi + 1];
+    const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2], qi = q[i];
+    PairAcc B;
+    for (int j = j0 + lane; j < j1; j += 64) {
+      if (j == i) continue;
+      const float rx = xw[3 * j] - xi, ry = xw[3 * j + 1] - yi, rz = xw[3 * j + 2] - zi;
+      const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+      const float inv = 1.0f / d;
+      pair_add<GRAD, false>(B, inv, -inv * inv, qi, q[j], rx * inv, ry * inv, rz * inv, d);
+    }
+    pair_store<GRAD, false, true>(B, i, lane, cp.factor, 0.0, 0.0f, ecoul, qbar, fgrad, nullptr);
+  }
 }
 
 int launch_coulomb_sr(hipStream_t s, bool grad, bool stress, bool enabled, const float* q, const int* nb_idx,

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "conv_common.h"
+#include "pairmap.h"
 
 namespace aimnet {
 
@@ -948,72 +949,18 @@ int launch_conv_bwd(hipStream_t s, int nq, bool need_abar, bool stress, const fl
 constexpr int REV_ROW_MAX = 128;  // row capacity: positions fit 8 bits and a 256-slot table stays at most half full
 bool pair_rev_supported(int n_atoms, int cap) { return cap <= REV_ROW_MAX && n_atoms < (1 << 25); }
 
-// Every atom j publishes a 256-slot open-addressing table of its row,
-// entry = neighbour << 32 | shift code << 8 | position, slot = hash(neighbour, shift) with linear probing (rows hold <= 128
-// entries: load factor <= 1/2), built with LDS compare-and-swap by the wave of j and written out as one 2 KiB block.  The pair
-// (i -> j) then finds (i, -shift) in the table of j with ~1.3 dependent 8-byte loads instead of a 7-step bisection.
-constexpr int RH_SLOTS = 256;
-constexpr unsigned long long RH_EMPTY = ~0ull;
-__device__ __forceinline__ unsigned rh_slot(unsigned id, unsigned code) {
-  return ((id * 2654435761u) ^ (code * 0x9E3779B1u) ^ (code >> 11)) >> 24;
-}
-
+// (the hash build and the lookup live in pairmap.h as device functions: they also ride on other launches, kernels.h PairMapRider)
 __global__ __launch_bounds__(256) void pair_hash_kernel(const int* __restrict__ nb_idx, const int* __restrict__ nb_shift,
                                                         const int* __restrict__ nb_cnt, int cap, int n_atoms,
                                                         unsigned long long* __restrict__ tab, int* __restrict__ rev) {
   __shared__ unsigned long long s_tab[4][RH_SLOTS];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + wid;
-  if (i >= n_atoms) return;  // (no block barrier below)
-  unsigned long long* T = s_tab[wid];
-  for (int t = lane; t < RH_SLOTS; t += 64) T[t] = RH_EMPTY;
-  lds_sync<false>();
-  const int cnt = min(nb_cnt[i], cap);
-  for (int m = lane; m < cnt; m += 64) {
-    const size_t p = (size_t)i * cap + m;
-    rev[p] = -1;  // an entry whose reverse pair is missing (a truncated row) is written by nobody in pair_rev_hash_kernel
-    const unsigned id = (unsigned)nb_idx[p], code = nb_shift ? (unsigned)(nb_shift[p] & 0xffffff) : 0u;
-    const unsigned long long entry = ((unsigned long long)id << 32) | ((unsigned long long)code << 8) | (unsigned long long)m;
-    unsigned h = rh_slot(id, code);
-    while (atomicCAS(&T[h], RH_EMPTY, entry) != RH_EMPTY) h = (h + 1) & (RH_SLOTS - 1);
-  }
-  lds_sync<false>();
-  for (int t = lane; t < RH_SLOTS; t += 64) tab[(size_t)i * RH_SLOTS + t] = T[t];
+  pair_hash_block(nb_idx, nb_shift, nb_cnt, cap, n_atoms, tab, rev, blockIdx.x, s_tab);
 }
 
 __global__ __launch_bounds__(256) void pair_rev_hash_kernel(const int* __restrict__ nb_idx, const int* __restrict__ nb_shift,
                                                             const int* __restrict__ nb_cnt, int cap, int n_atoms,
                                                             const unsigned long long* __restrict__ tab, int* __restrict__ rev) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n_atoms) return;
-  const int cnt = min(nb_cnt[i], cap);
-  for (int m = lane; m < cnt; m += 64) {
-    const size_t p = (size_t)i * cap + m;
-    const int j = nb_idx[p];
-    if (j < i) continue;  // rev(rev(p)) = p: the pair with the smaller centre looks up and writes both entries
-    unsigned want = 0;
-    if (nb_shift) {
-      int sx, sy, sz;
-      unpack_shift(nb_shift[p], sx, sy, sz);
-      want = (unsigned)pack_shift(-sx, -sy, -sz) & 0xffffffu;
-    }
-    const unsigned long long* Tj = tab + (size_t)j * RH_SLOTS;
-    const unsigned long long match = ((unsigned long long)(unsigned)i << 24) | want;
-    unsigned h = rh_slot((unsigned)i, want);
-    int found = -1;
-    for (int probe = 0; probe < RH_SLOTS; ++probe) {
-      const unsigned long long e = Tj[h];
-      if (e == RH_EMPTY) break;
-      if ((e >> 8) == match) {
-        found = (int)(e & 0xff);
-        break;
-      }
-      h = (h + 1) & (RH_SLOTS - 1);
-    }
-    rev[p] = found;
-    if (found >= 0 && j != i) rev[(size_t)j * cap + found] = m;
-  }
+  pair_rev_hash_block(nb_idx, nb_shift, nb_cnt, cap, n_atoms, tab, rev, blockIdx.x);
 }
 
 size_t pair_hash_bytes(int n_atoms) { return (size_t)n_atoms * RH_SLOTS * sizeof(unsigned long long); }

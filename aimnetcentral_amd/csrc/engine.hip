@@ -736,7 +736,19 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const bool mfma_fwd = (e->conv_mfma & 1) && N > e->split_max;
   const bool mfma_bwd = (e->conv_mfma & 2) && N > e->split_max;
   // reverse-pair map through per-atom hash tables of the rows (once per neighbour list)
-  if (W.xe) RC(launch_pair_rev_hash(s, W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, cap, N, W.rev_tab, W.rev));
+  // (its only reader is launch_pair_force, the last kernel of the backward.  On one stream the two small kernels ride on later
+  // launches instead of standing in front of the forward pass: the hash build on the SR-Coulomb launch, the lookup on the DSF walk
+  // (VALU-bound, the lookup is latency-bound) or else on the energy reduction - kernels.h PairMapRider)
+  PairMapRider pmap{};
+  const bool overlap_early = e->overlap_coulomb && e->prof_level < 2;
+  if (W.xe && want_f) {
+    if (overlap_early) {
+      RC(launch_pair_rev_hash(s, W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, cap, N, W.rev_tab, W.rev));
+    } else {
+      pmap = PairMapRider{W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, cap, N, W.rev_tab, W.rev, ceil_div(N, 4)};
+    }
+  }
+  bool rev_done = pmap.n_blocks == 0;
   // ---- Coulomb: energies, and the seeds of qbar / dE/dx / virial (a closure: it runs on the eval stream or on the side one) ----
   const float* q_fin = nq == 2 ? W.qtot : W.q[np - 2];
   const bool overlap = e->overlap_coulomb && e->prof_level < 2;  // per-family profiling wants one stream
@@ -766,6 +778,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       rd.simple_mol_idx = mol_c;
       rd.simple_mol_start = W.nl.mol_start;
     }
+    rd.hash = pmap;  // hash build of the reverse-pair map (n_blocks = 0: none)
     RC(launch_coulomb_sr(cs, grad, want_s, ar.sr_coulomb != 0, q_fin, W.nb_idx, W.nb_cnt, W.pg, cap, cp, N, W.ecoul, W.qbar,
                          W.fgrad, W.virial_atom, &rd));
     // DSF and DFT-D3 with one cutoff: the Coulomb pair terms ride on the D3 pair pass (one list, one geometry evaluation)
@@ -779,7 +792,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       ;  // see launch_dftd3 below
     else if (coulomb == AIMNET_COULOMB_DSF && pbc && !ext) {
       RC(launch_coulomb_dsf_walk(cs, grad, want_s, q_fin, mol_c, W.nl, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom,
-                                 out->charges, true));
+                                 out->charges, true, rev_done ? nullptr : &pmap));
+      rev_done = true;
       charges_written = true;
     } else if (coulomb == AIMNET_COULOMB_DSF)
       RC(launch_coulomb_dsf(cs, grad, want_s, q_fin, W.nl.xw, mol_c, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt,
@@ -872,7 +886,9 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     if (overlap) AIMNET_HIP_CHECK(hipStreamWaitEvent(s, e->ev_join, 0));
     RC(prof_mark(e, s, FAM_POINTWISE));
     RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, W.S, W.part, out->energy,
-                            q_fin, charges_written ? nullptr : out->charges, N));  // + the charges output, unless the DSF walk wrote it
+                            q_fin, charges_written ? nullptr : out->charges, N,  // + the charges output, unless the DSF walk wrote it
+                            rev_done ? nullptr : &pmap));                        // + the lookup of the reverse-pair map, unless the walk ran it
+    rev_done = true;
     return 0;
   };
   if (!grad) {

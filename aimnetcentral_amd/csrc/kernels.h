@@ -150,6 +150,11 @@ int launch_conv_sv_bwd(hipStream_t s, const float* grad_out, const float* a, con
 int launch_conv_sv_bwd_bwd(hipStream_t s, const float* grad_out, const float* grad2_a, const float* grad2_g, const float* a,
                            const int* idx, const float* g, float* ggo, float* ga2, float* gg2, int B, int A, int G, int M);
 
+// the reverse-pair map as a rider (pairmap.h): `n_blocks` = ceil(n_atoms / 4) blocks of 256 threads run the hash build
+// (SrRiders::hash) or the lookup (launch_coulomb_dsf_walk / launch_energy_reduce), 0 = none
+struct PairMapRider {
+  const int* nb_idx; const int* nb_shift; const int* nb_cnt; int cap, n_atoms; unsigned long long* tab; int* rev; int n_blocks;
+};
 // ---- model.hip --------------------------------------------------------------------------------
 // S = slices (blocks) per molecule for the per-molecule reductions; `part` = scratch [n_sys * S * 9] doubles
 // nq = charge channels (1, or 2 for NSE models): q planes [nq][n_atoms], charge / Fm / Dm / Wbar planes [nq][n_mol];
@@ -168,7 +173,8 @@ int launch_head_last(hipStream_t s, const float* h, int ldh, const float* w, con
 int launch_energy_reduce(hipStream_t s, const float* e_atom, const double* ecoul, const int* numbers,
                          const double* sae, const int* mol_start, int n_mol, int S, double* part, double* energy,
                          // copy_dst != NULL: copy_n floats copy_src -> copy_dst ride on the same launch (the charges output)
-                         const float* copy_src = nullptr, float* copy_dst = nullptr, int copy_n = 0);
+                         const float* copy_src = nullptr, float* copy_dst = nullptr, int copy_n = 0,
+                         const PairMapRider* rev_rider = nullptr);  // the lookup of the reverse-pair map rides on this launch
 struct CoulombParams {
   float factor;      // 1/2 Hartree Bohr
   float sr_rc;       // exp / cosine envelope radius (SRCoulomb)
@@ -202,6 +208,7 @@ struct SrRiders {
   const float4* xs; float4* xq; float* charges_out; int n_stream_blocks;
   // simple_xw != NULL: the "simple" LRCoulomb term (launch_coulomb_simple with these arguments) in the same waves
   const float* simple_xw; const int* simple_mol_idx; const int* simple_mol_start;
+  PairMapRider hash;  // the hash build of the reverse-pair map (its lookup rides on a later launch)
 };
 // embedded SRCoulomb subtraction over the rc list (sets ecoul/qbar/fgrad/virial_atom)
 int launch_coulomb_sr(hipStream_t s, bool grad, bool stress, bool enabled, const float* q, const int* nb_idx,
@@ -218,7 +225,8 @@ int launch_coulomb_dsf(hipStream_t s, bool grad, bool stress, const float* q, co
 int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, NlistBuffers& b,
                             CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom,
                             float* charges_out = nullptr,  // charges_out: also copy q to the charges output
-                            bool stream_done = false);    // the (x, y, z, q) stream was written by an SrRiders launch
+                            bool stream_done = false,     // the (x, y, z, q) stream was written by an SrRiders launch
+                            const PairMapRider* rev_rider = nullptr);  // the lookup of the reverse-pair map rides on this launch
 int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int ldy, int nq, const int* mol_start, int n_mol,
                           int n_atoms, int S, float* part);  // part: [nq][n_mol][S] partial sums, consumed by launch_build_zbar
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,

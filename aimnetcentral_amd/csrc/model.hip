@@ -13,6 +13,7 @@
 #include "cellwalk.h"
 #include "common.h"
 #include "kernels.h"
+#include "pairmap.h"
 
 namespace aimnet {
 
@@ -264,10 +265,15 @@ __global__ __launch_bounds__(256) void energy_partial_kernel(const float* __rest
                                                             const double* __restrict__ sae,
                                                             const int* __restrict__ mol_start, int S,
                                                             double* __restrict__ part, int n_red, const float* __restrict__ cp_src,
-                                                            float* __restrict__ cp_dst, int cp_n) {
-  if ((int)blockIdx.x >= n_red) {  // rider: the copy of the charges into the output (independent; one kernel boundary less)
-    const int e = (blockIdx.x - n_red) * 256 + threadIdx.x;
-    if (e < cp_n) cp_dst[e] = cp_src[e];
+                                                            float* __restrict__ cp_dst, int cp_n, int n_cp, PairMapRider pm) {
+  if ((int)blockIdx.x >= n_red) {  // riders (independent work; one kernel boundary less each)
+    const int b = blockIdx.x - n_red;
+    if (b < n_cp) {  // the copy of the charges into the output
+      const int e = b * 256 + threadIdx.x;
+      if (e < cp_n) cp_dst[e] = cp_src[e];
+    } else {  // the lookup pass of the reverse-pair map
+      pair_rev_hash_block(pm.nb_idx, pm.nb_shift, pm.nb_cnt, pm.cap, pm.n_atoms, pm.tab, pm.rev, b - n_cp);
+    }
     return;
   }
   __shared__ double sh[4];
@@ -293,11 +299,13 @@ __global__ void energy_finish_kernel(const double* __restrict__ part, int S, int
 
 int launch_energy_reduce(hipStream_t s, const float* e_atom, const double* ecoul, const int* numbers,
                          const double* sae, const int* mol_start, int n_mol, int S, double* part, double* energy,
-                         const float* copy_src, float* copy_dst, int copy_n) {
+                         const float* copy_src, float* copy_dst, int copy_n, const PairMapRider* rev_rider) {
   S = S < 1 ? 1 : S;
   const int n_red = S * n_mol, n_cp = copy_dst ? ceil_div(copy_n, 256) : 0;
-  hipLaunchKernelGGL(energy_partial_kernel, dim3(n_red + n_cp), dim3(256), 0, s, e_atom, ecoul, numbers, sae, mol_start, S,
-                     S == 1 ? energy : part, n_red, copy_src, copy_dst, copy_n);
+  PairMapRider pm{};
+  if (rev_rider) pm = *rev_rider;
+  hipLaunchKernelGGL(energy_partial_kernel, dim3(n_red + n_cp + pm.n_blocks), dim3(256), 0, s, e_atom, ecoul, numbers, sae, mol_start, S,
+                     S == 1 ? energy : part, n_red, copy_src, copy_dst, copy_n, n_cp, pm);
   AIMNET_LAUNCH_CHECK();
   if (S > 1) {
     hipLaunchKernelGGL(energy_finish_kernel, dim3(ceil_div(n_mol, 64)), dim3(64), 0, s, part, S, n_mol, energy);
@@ -384,8 +392,15 @@ __global__ __launch_bounds__(256) void coulomb_sr_kernel(bool enabled, const flo
   const int n_sr = (n_atoms + 3) >> 2;
   if ((int)blockIdx.x >= n_sr) {
     const int b = blockIdx.x - n_sr;
-    if (b < rd.n_head_blocks) head_last_block(rd.h, rd.ldh, rd.w, rd.b, rd.k, n_atoms, rd.e_atom, rd.d, rd.zbar, b);
-    else charge_stream_block(rd.xs, q, n_atoms, rd.xq, rd.charges_out, b - rd.n_head_blocks);
+    if (b < rd.n_head_blocks) {
+      head_last_block(rd.h, rd.ldh, rd.w, rd.b, rd.k, n_atoms, rd.e_atom, rd.d, rd.zbar, b);
+    } else if (b < rd.n_head_blocks + rd.n_stream_blocks) {
+      charge_stream_block(rd.xs, q, n_atoms, rd.xq, rd.charges_out, b - rd.n_head_blocks);
+    } else {  // hash build of the reverse-pair map (pairmap.h)
+      __shared__ unsigned long long s_tab[4][RH_SLOTS];
+      pair_hash_block(rd.hash.nb_idx, rd.hash.nb_shift, rd.hash.nb_cnt, rd.hash.cap, n_atoms, rd.hash.tab, rd.hash.rev,
+                      b - rd.n_head_blocks - rd.n_stream_blocks, s_tab);
+    }
     return;
   }
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -440,7 +455,7 @@ int launch_coulomb_sr(hipStream_t s, bool grad, bool stress, bool enabled, const
                       float* qbar, float* fgrad, float* virial_atom, const SrRiders* riders) {
   SrRiders rd{};
   if (riders) rd = *riders;
-  dim3 grid(ceil_div(n_atoms, 4) + rd.n_head_blocks + rd.n_stream_blocks), block(256);
+  dim3 grid(ceil_div(n_atoms, 4) + rd.n_head_blocks + rd.n_stream_blocks + rd.hash.n_blocks), block(256);
   if (grad && stress)
     hipLaunchKernelGGL((coulomb_sr_kernel<true, true>), grid, block, 0, s, enabled, q, nb_idx, nb_cnt, pg, cap, cp, n_atoms,
                        ecoul, qbar, fgrad, virial_atom, rd);
@@ -584,7 +599,13 @@ __global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __re
                                                               const int* __restrict__ bin_start,
                                                               const float4* __restrict__ xq, CoulombParams cp, int n_atoms,
                                                               double* __restrict__ ecoul, float* __restrict__ qbar,
-                                                              float* __restrict__ fgrad, float* __restrict__ virial_atom) {
+                                                              float* __restrict__ fgrad, float* __restrict__ virial_atom,
+                                                              PairMapRider pm) {
+  if ((int)blockIdx.x >= ((n_atoms + 3) >> 2)) {  // rider: the lookup pass of the reverse-pair map (independent, latency-bound work
+    // beside the VALU-bound walk; a kernel boundary less)
+    pair_rev_hash_block(pm.nb_idx, pm.nb_shift, pm.nb_cnt, pm.cap, n_atoms, pm.tab, pm.rev, blockIdx.x - ((n_atoms + 3) >> 2));
+    return;
+  }
   // Only ~1/3 of the candidates the bin walk visits lie inside Rc, while a pair term costs ~150 VALU
   // instructions (erfc, exp, fp64 energy sum, virial).  So the walk only COMPACTS the hits (r, q_j) into a
   // per-wave LDS queue, and the expensive math runs on full 64-lane batches popped from that queue.
@@ -678,8 +699,10 @@ __global__ void charge_stream_kernel(const float4* __restrict__ xs, const float*
 
 int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, NlistBuffers& b,
                             CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom,
-                            float* charges_out, bool stream_done) {
-  dim3 grid(ceil_div(n_atoms, 4)), block(256);
+                            float* charges_out, bool stream_done, const PairMapRider* rev_rider) {
+  PairMapRider pm{};
+  if (rev_rider) pm = *rev_rider;
+  dim3 grid(ceil_div(n_atoms, 4) + pm.n_blocks), block(256);
   const NlistSystem* sys = (const NlistSystem*)b.sys;
   float4* xq = (float4*)b.sorted_tmp_xq;
   if (!stream_done) {  // (normally the stream rides on the SR-Coulomb launch, SrRiders)
@@ -688,13 +711,13 @@ int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* 
   }
   if (grad && stress)
     hipLaunchKernelGGL((coulomb_dsf_walk_kernel<true, true>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, xq, cp,
-                       n_atoms, ecoul, qbar, fgrad, virial_atom);
+                       n_atoms, ecoul, qbar, fgrad, virial_atom, pm);
   else if (grad)
     hipLaunchKernelGGL((coulomb_dsf_walk_kernel<true, false>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, xq, cp,
-                       n_atoms, ecoul, qbar, fgrad, virial_atom);
+                       n_atoms, ecoul, qbar, fgrad, virial_atom, pm);
   else
     hipLaunchKernelGGL((coulomb_dsf_walk_kernel<false, false>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, xq, cp,
-                       n_atoms, ecoul, qbar, fgrad, virial_atom);
+                       n_atoms, ecoul, qbar, fgrad, virial_atom, pm);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

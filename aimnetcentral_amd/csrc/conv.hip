@@ -980,27 +980,7 @@ int launch_pair_rev_hash(hipStream_t s, const int* nb_idx, const int* nb_shift, 
 __global__ __launch_bounds__(256) void pair_force_kernel(const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
                                                          const int* __restrict__ rev, const float4* __restrict__ pairbuf, int cap,
                                                          int n_atoms, const float* __restrict__ fgrad, float* __restrict__ forces) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n_atoms) return;
-  const int cnt = min(nb_cnt[i], cap);
-  float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-  for (int m = lane; m < cnt; m += 64) {
-    const size_t p = (size_t)i * cap + m;
-    const int r = rev[p];
-    const float4 own = pairbuf[p];
-    f0 += own.x; f1 += own.y; f2 += own.z;
-    if (r >= 0) {
-      const float4 oth = pairbuf[(size_t)nb_idx[p] * cap + r];
-      f0 -= oth.x; f1 -= oth.y; f2 -= oth.z;
-    }
-  }
-  f0 = wave_sum(f0); f1 = wave_sum(f1); f2 = wave_sum(f2);
-  if (lane == 0) {
-    forces[3 * i + 0] = -(fgrad[3 * i + 0] + f0);
-    forces[3 * i + 1] = -(fgrad[3 * i + 1] + f1);
-    forces[3 * i + 2] = -(fgrad[3 * i + 2] + f2);
-  }
+  pair_force_block(nb_idx, nb_cnt, rev, pairbuf, cap, n_atoms, fgrad, forces, blockIdx.x);  // (pairmap.h)
 }
 
 int launch_pair_force(hipStream_t s, const int* nb_idx, const int* nb_cnt, const int* rev, const float4* pairbuf, int cap,

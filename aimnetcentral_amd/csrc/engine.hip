@@ -972,9 +972,12 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   }
   RC(prof_mark(e, s, FAM_POINTWISE));
   // reverse-pair form: the pair buffer holds F1 of both passes; its gather is the last contribution to dE/dx and writes the forces
-  if (W.xe && want_f) RC(launch_pair_force(s, W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, N, W.fgrad, out->forces));
+  // (with a stress request the force gather rides on the launch of the virial sums: independent work, one kernel boundary less)
+  const bool pf_rides = W.xe && want_f && want_s && pbc;
+  const PairForceRider pfr{W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, out->forces, ceil_div(N, 4)};
+  if (W.xe && want_f && !pf_rides) RC(launch_pair_force(s, W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, N, W.fgrad, out->forces));
   RC(launch_finalize(s, W.fgrad, W.virial_atom, W.nl.mol_start, in->cell, n_cell, n_mol, N, W.S, W.part,
-                     (want_f && !W.xe) ? out->forces : nullptr, want_s ? out->stress : nullptr));
+                     (want_f && !W.xe) ? out->forces : nullptr, want_s ? out->stress : nullptr, pf_rides ? &pfr : nullptr));
   RC(prof_mark(e, s, -1));
   return AIMNET_OK;
 }

@@ -232,9 +232,13 @@ int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int 
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
                       const float* Fm, const float* Dm, const float* wpart, int S, const int* mol_idx, int n_atoms, int n_mol,
                       int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next);
+// launch_pair_force's arguments as a rider of the stress reduction (launch_finalize): n_blocks = ceil(n_atoms / 4), 0 = none
+struct PairForceRider {
+  const int* nb_idx; const int* nb_cnt; const int* rev; const float4* pairbuf; int cap; float* forces; int n_blocks;
+};
 int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
                     const float* cell, int n_cell, int n_mol, int n_atoms, int S, double* part, float* forces,
-                    float* stress);
+                    float* stress, const PairForceRider* pair_force = nullptr);
 int launch_copy_f32(hipStream_t s, const float* src, float* dst, size_t n);
 
 }  // namespace aimnet

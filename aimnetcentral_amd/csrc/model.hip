@@ -806,9 +806,14 @@ __global__ void forces_kernel(const float* __restrict__ fgrad, int n3, float* __
 // stage 1: 9 partial sums per (system, slice); a single shared cell (n_cell == 1) spans all molecules
 __global__ __launch_bounds__(256) void stress_partial_kernel(const float* __restrict__ virial_atom,
                                                             const int* __restrict__ mol_start, int n_cell, int n_mol,
-                                                            int S, double* __restrict__ part) {
+                                                            int S, double* __restrict__ part, const float* __restrict__ fgrad,
+                                                            int n_atoms, PairForceRider pf) {
+  if ((int)blockIdx.x >= S * n_cell) {  // rider: the force gather of the reverse-pair form (independent of the virial sums)
+    pair_force_block(pf.nb_idx, pf.nb_cnt, pf.rev, pf.pairbuf, pf.cap, n_atoms, fgrad, pf.forces, blockIdx.x - S * n_cell);
+    return;
+  }
   __shared__ double sh[4];
-  const int sidx = blockIdx.y, sl = blockIdx.x;
+  const int sidx = blockIdx.x / S, sl = blockIdx.x % S;
   const int i0 = (n_cell == 1) ? mol_start[0] : mol_start[sidx];
   const int i1 = (n_cell == 1) ? mol_start[n_mol] : mol_start[sidx + 1];
   const int L = (i1 - i0 + S - 1) / S;
@@ -837,14 +842,17 @@ __global__ void stress_finish_kernel(const double* __restrict__ part, int S, int
 
 int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
                     const float* cell, int n_cell, int n_mol, int n_atoms, int S, double* part, float* forces,
-                    float* stress) {
+                    float* stress, const PairForceRider* pair_force) {
+  PairForceRider pf{};
+  if (pair_force) pf = *pair_force;
   if (forces) {
     hipLaunchKernelGGL(forces_kernel, dim3(ceil_div(3 * n_atoms, 256)), dim3(256), 0, s, fgrad, 3 * n_atoms, forces);
     AIMNET_LAUNCH_CHECK();
   }
   if (stress && cell) {
     S = S < 1 ? 1 : S;
-    hipLaunchKernelGGL(stress_partial_kernel, dim3(S, n_cell), dim3(256), 0, s, virial_atom, mol_start, n_cell, n_mol, S, part);
+    hipLaunchKernelGGL(stress_partial_kernel, dim3(S * n_cell + pf.n_blocks), dim3(256), 0, s, virial_atom, mol_start, n_cell, n_mol, S,
+                       part, fgrad, n_atoms, pf);
     AIMNET_LAUNCH_CHECK();
     hipLaunchKernelGGL(stress_finish_kernel, dim3(ceil_div(n_cell * 9, 64)), dim3(64), 0, s, part, S, n_cell, cell, stress);
     AIMNET_LAUNCH_CHECK();

@@ -77,4 +77,31 @@ __device__ __forceinline__ void pair_rev_hash_block(const int* __restrict__ nb_i
   }
 }
 
+// forces_i = -(fgrad_i + sum_m F1(i -> j_m) - F1(j_m -> i))  (conv_bwd_kernel XE form; one wave per atom, lane = pair)
+__device__ __forceinline__ void pair_force_block(const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
+                                                 const int* __restrict__ rev, const float4* __restrict__ pairbuf, int cap,
+                                                 int n_atoms, const float* __restrict__ fgrad, float* __restrict__ forces, int block) {
+  const int lane = threadIdx.x & 63;
+  const int i = block * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int cnt = min(nb_cnt[i], cap);
+  float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+  for (int m = lane; m < cnt; m += 64) {
+    const size_t p = (size_t)i * cap + m;
+    const int r = rev[p];
+    const float4 own = pairbuf[p];
+    f0 += own.x; f1 += own.y; f2 += own.z;
+    if (r >= 0) {
+      const float4 oth = pairbuf[(size_t)nb_idx[p] * cap + r];
+      f0 -= oth.x; f1 -= oth.y; f2 -= oth.z;
+    }
+  }
+  f0 = wave_sum(f0); f1 = wave_sum(f1); f2 = wave_sum(f2);
+  if (lane == 0) {
+    forces[3 * i + 0] = -(fgrad[3 * i + 0] + f0);
+    forces[3 * i + 1] = -(fgrad[3 * i + 1] + f1);
+    forces[3 * i + 2] = -(fgrad[3 * i + 2] + f2);
+  }
+}
+
 }  // namespace aimnet

@@ -11,7 +11,7 @@ import os
 from functools import lru_cache
 
 MAX_PASS, MAX_LAYERS, MAX_SHIFTS = 4, 6, 32
-ABI_VERSION = 7  # AIMNET_ABI_VERSION of include/aimnet_hip.h this binding was written against
+ABI_VERSION = 8  # AIMNET_ABI_VERSION of include/aimnet_hip.h this binding was written against
 FORCES, STRESS = 1, 2
 COULOMB_NONE, COULOMB_SIMPLE, COULOMB_DSF = 0, 1, 2
 E_INVALID, E_HIP, E_WORKSPACE = -1, -2, -3
@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = (
     "aimnet_debug_gemm",
     "aimnet_debug_split_bf3",
     "aimnet_debug_gemm_bf3",
+    "aimnet_debug_gemm_bf3a",
     "aimnet_debug_mfma4_probe",
     "aimnet_engine_set_option",
     "aimnet_engine_set_dftd3",
@@ -198,6 +199,9 @@ def load() -> C.CDLL:
     lib.aimnet_debug_split_bf3.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
     lib.aimnet_debug_gemm_bf3.restype = C.c_int
     lib.aimnet_debug_gemm_bf3.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.aimnet_debug_gemm_bf3a.restype = C.c_int
+    lib.aimnet_debug_gemm_bf3a.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int,
+                                          vp, C.c_int, C.c_int, vp]
     lib.aimnet_engine_set_option.restype = C.c_int
     lib.aimnet_engine_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.aimnet_debug_mfma4_probe.restype = C.c_int

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "conv_common.h"
+#include "gemm_bf3_common.h"
 #include "pairmap.h"
 
 namespace aimnet {
@@ -59,7 +60,9 @@ struct FwdWaveLds {
 #ifndef AIMNET_PROBE_FWD_OCC
 #define AIMNET_PROBE_FWD_OCC 4
 #endif
-template <int NQ, bool SPLIT, bool P0M = false>
+// X3: the MLP input row is written pre-split for gemm_bf3a.hip ("bf3" layout: per 32 columns [plane 0][plane 1][plane 2] x 32 bf16,
+// fp32 == p0 + p1 + p2 exactly; `x` then points at bf16 elements, 3 * ldx per row) instead of fp32.
+template <int NQ, bool SPLIT, bool P0M = false, bool X3 = false>
 __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
                                                       const float* __restrict__ q,
                                                       const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
@@ -321,14 +324,29 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
 #pragma unroll
         for (int ch = 0; ch < NQ; ++ch) sv[768 + ch * 48 + (lane >> 2) * 3 + (lane & 3) - 1] = accq[ch];
       }
-      float* xr = x + (size_t)i * ldx;
       const int ri = row_of ? min(63, max(0, row_of[i])) : i;
-      reinterpret_cast<float4*>(xr)[lane] = reinterpret_cast<const float4*>(a + (size_t)ri * NF)[lane];
-      reinterpret_cast<float4*>(xr + NF)[lane] = make_float4(acc[0][0].x, acc[0][0].y, acc[0][1].x, acc[0][1].y);
+      const float4 av = reinterpret_cast<const float4*>(a + (size_t)ri * NF)[lane];
+      if (X3) {
+        unsigned short* x3 = reinterpret_cast<unsigned short*>(x) + (size_t)i * 3 * ldx;
+        store_bf3_x4(x3, 4 * lane, f32x4{av.x, av.y, av.z, av.w});
+        store_bf3_x4(x3, NF + 4 * lane, f32x4{acc[0][0].x, acc[0][0].y, acc[0][1].x, acc[0][1].y});
+      } else {
+        float* xr = x + (size_t)i * ldx;
+        reinterpret_cast<float4*>(xr)[lane] = av;
+        reinterpret_cast<float4*>(xr + NF)[lane] = make_float4(acc[0][0].x, acc[0][0].y, acc[0][1].x, acc[0][1].y);
+      }
     }
     lds_sync<SPLIT>();
     if (live) {
       float* xr = x + (size_t)i * ldx;
+      unsigned short* x3 = reinterpret_cast<unsigned short*>(x) + (size_t)i * 3 * ldx;
+      // X3: the columns from 2 NF on are staged in the wave's LDS scratch (behind the 864 floats of sv; the chunk arrays that follow
+      // gs are idle in the epilogue) and leave as 8-byte plane pieces, four consecutive columns per lane
+      float* xt = sv + 864;
+      auto put = [&](int col, float v) __attribute__((always_inline)) {  // one element of the row
+        if (X3) xt[col - 2 * NF] = v;
+        else xr[col] = v;
+      };
       // one-wave-per-atom form: rolled, the contraction keeps the kernel at 128 VGPRs with 6 spilled dwords instead of 22
 #pragma unroll UNR_T
       for (int t = 0; t < 3; ++t) {
@@ -350,14 +368,14 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
         }
         float* vs = Vsave + (size_t)i * (NV * 3) + o;  // three planes [k][NV]: contiguous wave stores (and loads in unconcat)
         vs[0] = v0; vs[NV] = v1; vs[2 * NV] = v2;
-        xr[2 * NF + o] = v0 * v0 + v1 * v1 + v2 * v2;
+        put(2 * NF + o, v0 * v0 + v1 * v1 + v2 * v2);
       }
       if (HAS_Q) {
         const int c0 = 2 * NF + NV;  // 704
-        if (lane < NQ) xr[c0 + lane] = q[(size_t)lane * n_atoms + i];
+        if (lane < NQ) put(c0 + lane, q[(size_t)lane * n_atoms + i]);
 #pragma unroll
         for (int ch = 0; ch < NQ; ++ch) {
-          if ((lane & 3) == 0) xr[c0 + NQ + ch * G_ + (lane >> 2)] = accq[ch];
+          if ((lane & 3) == 0) put(c0 + NQ + ch * G_ + (lane >> 2), accq[ch]);
           if (lane < H_) {
             float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 #pragma unroll
@@ -369,14 +387,19 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
             }
             float* vs = Vqsave + ((size_t)i * NQ + ch) * (H_ * 3) + lane * 3;
             vs[0] = v0; vs[1] = v1; vs[2] = v2;
-            xr[c0 + NQ + NQ * G_ + ch * H_ + lane] = v0 * v0 + v1 * v1 + v2 * v2;
+            put(c0 + NQ + NQ * G_ + ch * H_ + lane, v0 * v0 + v1 * v1 + v2 * v2);
           }
         }
         const int used = c0 + NQ * (1 + G_ + H_);  // 733 (762 with two channels)
-        if (lane < ldx - used) xr[used + lane] = 0.0f;  // zero the K padding of the GEMM operand
+        if (lane < ldx - used) put(used + lane, 0.0f);  // zero the K padding of the GEMM operand
       } else {
         const int used = 2 * NF + NV;
-        if (lane < ldx - used) xr[used + lane] = 0.0f;
+        if (lane < ldx - used) put(used + lane, 0.0f);
+      }
+      if (X3) {
+        lds_sync<false>();
+        const int c = 4 * lane;
+        if (c < ldx - 2 * NF) store_bf3_x4(x3, 2 * NF + c, f32x4{xt[c], xt[c + 1], xt[c + 2], xt[c + 3]});
       }
     }
   }
@@ -391,14 +414,31 @@ int conv_split_max_default() { return SPLIT_MAX_ATOMS; }
 int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, const float* q, const int* nb_idx,
                     const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
                     float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order, bool species_moments,
-                    int split_max) {
+                    int split_max, bool x_bf3) {
   const bool split = n_atoms <= split_max;
+  if (x_bf3 && split) {
+    set_last_error("conv_fwd: pre-split rows exist in the one-wave-per-atom form only");
+    return -1;
+  }
   // (one-wave-per-atom form: exactly the 4 blocks per CU that are resident - with twice as many the second half only queues
   // behind the first and pays the block prologue again: 0.217 -> 0.207 ms/step over the three launches)
   const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), device_cus() * AIMNET_PROBE_FWD_OCC);
   if (species_moments && row_of && nq == 0 && !split) {  // pass 0 of a large system: per-element moments instead of row gathers
-    hipLaunchKernelGGL((conv_fwd_kernel<0, false, true>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a,
-                       agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order);
+    if (x_bf3)
+      hipLaunchKernelGGL((conv_fwd_kernel<0, false, true, true>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap,
+                         agh_a, agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order);
+    else
+      hipLaunchKernelGGL((conv_fwd_kernel<0, false, true>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a,
+                         agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order);
+    AIMNET_LAUNCH_CHECK();
+    return 0;
+  }
+  if (x_bf3) {
+#define AIMNET_FWD3(HQ)                                                                                                          \
+  hipLaunchKernelGGL((conv_fwd_kernel<HQ, false, false, true>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, \
+                     agh_a, agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order)
+    if (nq == 2) AIMNET_FWD3(2); else if (nq == 1) AIMNET_FWD3(1); else AIMNET_FWD3(0);
+#undef AIMNET_FWD3
     AIMNET_LAUNCH_CHECK();
     return 0;
   }

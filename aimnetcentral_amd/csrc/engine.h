@@ -53,6 +53,12 @@ struct aimnet_engine {
   // 256 rows, the exact-fp32 skinny kernel below; 2 = bf3 for every batch size (parity runs on small fixtures); 0 = the exact-fp32
   // MFMA kernels of gemm.hip everywhere.  set_option("gemm_bf3", v) / AIMNET_GEMM_BF3.
   int gemm_bf3 = 1;
+  // AIMNET_GEMM_PRESPLIT / set_option("gemm_presplit"): with the bf16x3-split GEMMs, systems above the split threshold keep every
+  // GEMM activation operand (MLP input rows, hidden activations, backward adjoints) in the split "bf3" form in memory: the producer
+  // splits once (conv_fwd's row assembly, the GELU / chain-rule epilogues) and gemm_bf3a.hip streams both operands by DMA with no
+  // vector work in its main loop.  0 = fp32 activations, split inside gemm_bf3.hip's loop (round 3; also what the tangent sweep of
+  // hvp.hip, small batches and AIMNET_KEEP_INTERMEDIATES use).
+  int gemm_presplit = 1;
   double* sae;
   // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row
@@ -109,4 +115,9 @@ namespace aimnet {
 // engine's `gemm_bf3` switch selects (engine.hip)
 int mlp_gemm(const aimnet_engine* e, hipStream_t s, int epi, const float* A, int lda, const Layer& L, bool fwd, int k0, int n0, int M,
              int N, int K, const float* bias, float* C, float* D, int ldc, const int* brow = nullptr, int ldbias = 0);
+// the same with the activation operand pre-split (A3, lda3 = 3 x its padded width in bf16 elements; gemm_bf3a.hip); out3: C is
+// written in bf3 form into C3 (ldc3 bf16 elements per row) instead of fp32 into C; D is fp32 [M][ldc]
+int mlp_gemm3(const aimnet_engine* e, hipStream_t s, int epi, bool out3, const unsigned short* A3, int lda3, const Layer& L, bool fwd,
+              int k0, int n0, int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
+              const int* brow = nullptr, int ldbias = 0);
 }  // namespace aimnet

@@ -115,6 +115,19 @@ int mlp_gemm(const aimnet_engine* e, hipStream_t s, int epi, const float* A, int
   const float* w = (fwd ? L.w : L.wt) + (size_t)n0 * ldw + k0;
   return launch_gemm_nt(s, epi, A, lda, w, ldw, M, N, K, bias, C, D, ldc, brow, ldbias);
 }
+int mlp_gemm3(const aimnet_engine* e, hipStream_t s, int epi, bool out3, const unsigned short* A3, int lda3, const Layer& L, bool fwd,
+              int k0, int n0, int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
+              const int* brow, int ldbias) {
+  const int ldw = fwd ? L.k_in : L.k_out;
+  const unsigned short* w3 = (fwd ? L.w3 : L.wt3) + (size_t)n0 * 3 * ldw + (size_t)(k0 / 32) * 96;
+  const int kneg = std::max(0, (fwd ? L.neg_w3 : L.neg_wt3) - k0 / 32);
+  return launch_gemm_bf3a_cfg(s, 0, epi, out3, A3 + (size_t)(k0 / 32) * 96, lda3, w3, 3 * ldw, M, N, K, bias, C, C3, ldc3, D, ldc, brow,
+                              ldbias, kneg);
+}
+// activations in split form for this batch? (layout() and eval() must agree)
+bool presplit_active(const aimnet_engine* e, int N) {
+  return e->gemm_presplit != 0 && e->gemm_bf3 != 0 && N > std::max(256, e->split_max) && !e->keep_intermediates && !(e->conv_mfma & 1);
+}
 }  // namespace aimnet
 
 namespace {
@@ -223,6 +236,8 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   float* x_shared = nullptr;
   float* h_shared[2] = {nullptr, nullptr};
   const bool share = !e->keep_intermediates;  // (not the pointers: in the size-query pass every pointer is NULL)
+  // pre-split activations (gemm_bf3a.hip): the shared operand buffers hold 6 instead of 4 bytes per element
+  const size_t ps_num = presplit_active(e, N) ? 3 : 2;
   if (share) {
     int ldx_max = 32, h_max = 32;
     for (int p = 0; p < np; ++p) {
@@ -230,9 +245,9 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
       for (size_t l = 0; l + 1 < e->mlp[p].size(); ++l) h_max = std::max(h_max, e->mlp[p][l].k_out);
     }
     for (size_t l = 0; l + 1 < e->head.size(); ++l) h_max = std::max(h_max, e->head[l].k_out);
-    x_shared = c.take<float>(n * ldx_max, "x_shared", ldx_max);
-    h_shared[0] = c.take<float>(n * h_max, "h_shared0", h_max);
-    h_shared[1] = c.take<float>(n * h_max, "h_shared1", h_max);
+    x_shared = c.take<float>(n * ldx_max * ps_num / 2, "x_shared", ldx_max);
+    h_shared[0] = c.take<float>(n * h_max * ps_num / 2, "h_shared0", h_max);
+    h_shared[1] = c.take<float>(n * h_max * ps_num / 2, "h_shared1", h_max);
   }
   for (int p = 0; p < np; ++p) {
     snprintf(name, sizeof name, "a%d", p);
@@ -271,8 +286,8 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   if (grad) {
     const int mw = max_width(e);
     W.abar = c.take<float>(n * 256, "abar", 256);
-    W.zb0 = c.take<float>(n * mw, "zb0", mw);
-    W.zb1 = c.take<float>(n * mw, "zb1", mw);
+    W.zb0 = c.take<float>(n * mw * ps_num / 2, "zb0", mw);
+    W.zb1 = c.take<float>(n * mw * ps_num / 2, "zb1", mw);
     // Sbar doubles as the species-moment table T of pass 0 (N x nslots x 64), which outlives no Sbar
     W.Sbar = c.take<float>(n * std::max(1024, e->nslots * 64), "Sbar", 1024);
     W.Sqbar = c.take<float>(n * 64 * e->nq, "Sqbar", 64);
@@ -355,6 +370,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->emb_bias = atoi(env) != 0;
     env = getenv("AIMNET_GEMM_BF3");
     if (env) e->gemm_bf3 = std::min(2, std::max(0, atoi(env)));
+    env = getenv("AIMNET_GEMM_PRESPLIT");
+    if (env) e->gemm_presplit = atoi(env) != 0;
     env = getenv("AIMNET_CONV_XE");
     if (env) e->conv_xe = atoi(env);
     env = getenv("AIMNET_SPLIT_MAX");
@@ -421,6 +438,7 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
   for (int g = 0; g < 16; ++g) e->bp.shifts[g] = arch->shifts[g];
   if ((rc = gemm_set_attributes())) goto fail;
   if ((rc = gemm_bf3_set_attributes())) goto fail;
+  if ((rc = gemm_bf3a_set_attributes())) goto fail;
   if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -487,6 +505,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "conv_xe") e->conv_xe = value != 0;
   else if (n == "emb_bias") e->emb_bias = value != 0;
   else if (n == "gemm_bf3") e->gemm_bf3 = std::min(2, std::max(0, value));
+  else if (n == "gemm_presplit") e->gemm_presplit = value != 0;
   else if (n == "split_max") e->split_max = value < 0 ? conv_split_max_default() : value;
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -733,6 +752,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const int* order = (!ext && W.nl.binned && e->spatial_order) ? W.nl.sorted : nullptr;
   // a^0 = afv[Z] is never materialised: pass 0 gathers the embedding rows directly (conv_fwd / conv_bwd row_of, update_a)
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
+  const bool ps = presplit_active(e, N);  // GEMM activations in split form (gemm_bf3a.hip)
   const bool mfma_fwd = (e->conv_mfma & 1) && N > e->split_max;
   const bool mfma_bwd = (e->conv_mfma & 2) && N > e->split_max;
   // reverse-pair map through per-atom hash tables of the rows (once per neighbour list)
@@ -822,10 +842,28 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     else
       RC(launch_conv_fwd(s, p > 0 ? nq : 0, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr, p > 0 ? W.q[p - 1] : nullptr,
                          W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q, e->bp, W.x[p], Ls[0].k_in, W.V[p], W.Vq[p], N, order,
-                         p == 0 && e->p0_moments, e->split_max));
+                         p == 0 && e->p0_moments, e->split_max, ps));
     const float* hin = W.x[p];
     int ld_in = Ls[0].k_in;
     RC(prof_mark(e, s, FAM_GEMM));
+    if (ps) {  // activations in split form: rows from conv_fwd, hidden layers from the GELU epilogues; the last layer's output is fp32
+      const unsigned short* a3 = reinterpret_cast<const unsigned short*>(W.x[p]);
+      int lda3 = 3 * Ls[0].k_in;
+      for (int l = 0; l < nl; ++l) {
+        const bool last = l == nl - 1, linear = last && ar.last_linear[p];
+        const int epi = linear ? EPI_BIAS : EPI_BIAS_GELU, ko = Ls[l].k_out;
+        float* Cf = last ? W.H[p][l] : nullptr;
+        unsigned short* C3 = last ? nullptr : reinterpret_cast<unsigned short*>(W.H[p][l]);
+        float* Dl = linear ? nullptr : W.D[p][l];
+        if (p == 0 && l == 0 && e->emb_bias && e->emb_bias0)
+          RC(mlp_gemm3(e, s, epi, !last, a3, lda3, Ls[l], true, 256, 0, N, ko, Ls[l].k_in - 256, e->emb_bias0, Cf, C3, 3 * ko, Dl, ko,
+                       in->numbers, ko));
+        else
+          RC(mlp_gemm3(e, s, epi, !last, a3, lda3, Ls[l], true, 0, 0, N, ko, Ls[l].k_in, Ls[l].b, Cf, C3, 3 * ko, Dl, ko));
+        a3 = C3;
+        lda3 = 3 * ko;
+      }
+    } else
     for (int l = 0; l < nl; ++l) {
       const bool linear = (l == nl - 1) && ar.last_linear[p];
       if (p == 0 && l == 0 && e->emb_bias && e->emb_bias0)  // embedding columns folded into the per-element bias table
@@ -915,12 +953,33 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       std::swap(zcur, znext);
       ld = L.k_in;
     }
+    if (ps) {  // (interim: the head still runs on fp32 operands; its adjoint is split for the MLP backward)
+      RC(launch_split_bf3(s, zcur, ld, N, ld, reinterpret_cast<unsigned short*>(znext), 3 * ld));
+      std::swap(zcur, znext);
+    }
   }
   for (int p = np - 1; p >= 0; --p) {
     const std::vector<Layer>& Ls = e->mlp[p];
     const int nl = (int)Ls.size();
     int ld = Ls[nl - 1].k_out;  // zcur = adjoint of the last layer's pre-activation (GELU' already applied)
     RC(prof_mark(e, s, FAM_GEMM));
+    if (ps) {  // zcur holds the adjoint in split form; every layer but the first hands a split adjoint on, the first writes xbar (fp32)
+      for (int l = nl - 1; l >= 0; --l) {
+        const Layer& L = Ls[l];
+        const unsigned short* z3 = reinterpret_cast<const unsigned short*>(zcur);
+        if (l > 0)
+          RC(mlp_gemm3(e, s, EPI_MUL, true, z3, 3 * ld, L, false, 0, 0, N, L.k_in, L.k_out, nullptr, nullptr,
+                       reinterpret_cast<unsigned short*>(znext), 3 * L.k_in, W.D[p][l - 1], L.k_in));
+        else if (p == 0 && p0m)
+          RC(mlp_gemm3(e, s, EPI_NONE, false, z3, 3 * ld, L, false, 0, 256, N, L.k_in - 256, L.k_out, nullptr, znext + 256, nullptr, 0,
+                       nullptr, L.k_in));
+        else
+          RC(mlp_gemm3(e, s, EPI_NONE, false, z3, 3 * ld, L, false, 0, 0, N, L.k_in, L.k_out, nullptr, znext, nullptr, 0, nullptr,
+                       L.k_in));
+        std::swap(zcur, znext);
+        ld = L.k_in;
+      }
+    } else
     for (int l = nl - 1; l >= 0; --l) {
       const Layer& L = Ls[l];
       if (l > 0)
@@ -967,7 +1026,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     RC(prof_mark(e, s, FAM_POINTWISE));
     RC(launch_nse_bwd_reduce(s, W.qbar, y, ldy, nq, W.nl.mol_start, n_mol, N, W.S, (float*)W.part));
     RC(launch_build_zbar(s, W.qbar, W.abar, y, ldy, ar.last_linear[p - 1] ? nullptr : W.D[p - 1][nlq - 1], W.Fm[p - 1],
-                         W.Dm[p - 1], (const float*)W.part, W.S, mol_c, N, n_mol, 256, nq, p - 1 > 0, znext, W.qbar));
+                         W.Dm[p - 1], (const float*)W.part, W.S, mol_c, N, n_mol, 256, nq, p - 1 > 0, znext, W.qbar, ps));
     std::swap(zcur, znext);
   }
   RC(prof_mark(e, s, FAM_POINTWISE));
@@ -1068,7 +1127,21 @@ int aimnet_debug_gemm_bf3(int cfg, int epi, const float* A, int lda, const void*
                              nullptr, 0, kneg < 0 ? BF3_NO_NEG : kneg);
 }
 
+int aimnet_debug_gemm_bf3a(int cfg, int epi, int out3, const void* A3, int lda3, const void* Bt3, int ldb, int M, int N, int K,
+                           const float* bias, float* C, void* C3, int ldc3, float* D, int ldc, int kneg, void* hip_stream) {
+  using namespace aimnet;
+  static bool once = false;
+  if (!once) {
+    int rc = gemm_bf3a_set_attributes();
+    if (rc) return rc;
+    once = true;
+  }
+  return launch_gemm_bf3a_cfg((hipStream_t)hip_stream, cfg, epi, out3 != 0, (const unsigned short*)A3, lda3, (const unsigned short*)Bt3,
+                              ldb, M, N, K, bias, C, (unsigned short*)C3, ldc3, D, ldc, nullptr, 0,
+                              (kneg < 0 || kneg >= K / 32) ? BF3_NO_NEG : kneg);
+}
 #ifdef AIMNET_BF3_TIMING
+int aimnet_debug_bf3a_stamps(unsigned long long* host1024) { return aimnet::gemm_bf3a_read_stamps(host1024); }
 int aimnet_debug_bf3_stamps(unsigned long long* host1024) { return aimnet::gemm_bf3_read_stamps(host1024); }
 #endif
 

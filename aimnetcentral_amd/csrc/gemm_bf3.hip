@@ -34,39 +34,10 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gemm_bf3_common.h"
 #include "kernels.h"
 
 namespace aimnet {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-// two fp32 -> three packed bf16 pairs (v_cvt_pk_bf16_f32 rounds to nearest even; the residuals are exact in fp32)
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
-  const f32x2 x = {a, b};
-  const bf16x2 h0 = __builtin_convertvector(x, bf16x2);
-  const f32x2 r1 = x - __builtin_convertvector(h0, f32x2);
-  const bf16x2 h1 = __builtin_convertvector(r1, bf16x2);
-  const f32x2 r2 = r1 - __builtin_convertvector(h1, f32x2);
-  const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
-  p0 = __builtin_bit_cast(unsigned, h0);
-  p1 = __builtin_bit_cast(unsigned, h1);
-  p2 = __builtin_bit_cast(unsigned, h2);
-}
-
-// store four consecutive columns col..col+3 (col % 4 == 0) of one row in bf3 form; `row` points at the row's first block
-__device__ __forceinline__ void store_bf3_x4(unsigned short* __restrict__ row, int col, f32x4 v) {
-  unsigned a0, a1, a2, b0, b1, b2;
-  split3_pair(v[0], v[1], a0, a1, a2);
-  split3_pair(v[2], v[3], b0, b1, b2);
-  unsigned short* p = row + (col >> 5) * 96 + (col & 31);
-  *reinterpret_cast<u32x2*>(p) = u32x2{a0, b0};
-  *reinterpret_cast<u32x2*>(p + 32) = u32x2{a1, b1};
-  *reinterpret_cast<u32x2*>(p + 64) = u32x2{a2, b2};
-}
 
 // ---- fp32 [M][ld] (columns c0 .. c0+K) -> bf3 [M][Kp/32][3][32]; columns >= K of the last block are zero ------------------
 __global__ __launch_bounds__(256) void split_bf3_kernel(const float* __restrict__ src, int ld, int M, int K, int Kp,
@@ -125,48 +96,6 @@ void split_bf3_host(const float* w, int rows, int K, unsigned short* out, int ne
       o[32] = h1;
       o[64] = h2;
     }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void glds16b(const void* g, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-template <int OFF>
-__device__ __forceinline__ bf16x8 lds_read_frag(unsigned addr) {
-  bf16x8 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return v;
-}
-template <int OFF>
-__device__ __forceinline__ void lds_write8(unsigned addr, unsigned lo, unsigned hi) {
-  const u32x2 v = {lo, hi};
-  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF));
-}
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkm() {
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// LDS tiles: [rows][3 planes][4 granules of 16 B] = 192 B per row; the granule of k-chunk c sits in slot c ^ swz(row),
-// swz(row) = (-(row >> 2)) & 3.  With 192-byte rows, rows r and r + 4 start in the same bank window; this XOR makes every
-// lane group of a ds_read_b128 ({0-3, 12-15, 20-27}, ...: lane = row & 15, chunk = lane >> 4) touch 16 distinct 16-byte slots
-// of the 256-byte bank window (MI355X_MICROARCH.md, LDS table; SQ_LDS_BANK_CONFLICT = 0 measured).
-__device__ __forceinline__ int swz192(int row) { return (-(row >> 2)) & 3; }
-
-constexpr int ROWB = 192;  // bytes per row per 32-k step
-
-// fragments of SMN consecutive 16-row strips (16 * 192 B apart), plane P
-template <int I, int SMN, int P>
-__device__ __forceinline__ void read_strips(bf16x8 (&f)[SMN][3], unsigned addr) {
-  if constexpr (I < SMN) {
-    f[I][P] = lds_read_frag<I * 16 * ROWB + P * 64>(addr);
-    read_strips<I + 1, SMN, P>(f, addr);
-  }
 }
 
 // ---- activation registers ------------------------------------------------------------------------------------------------
@@ -375,34 +304,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
   // unconditional: a conditional asm load makes the compiler merge "loaded" and "not loaded" registers with copies placed right
   // behind the load, i.e. before the data has arrived.
   auto kc = [&](int k) __attribute__((always_inline)) { return min(k, nk - 1); };
-  // ---- prologue.  VMEM issue order of a wave in the steady state (g = group, A_L / A_C = the quads split in the load / compute
-  // segment): ... B(j+1), A_L(j+2) [L(j-1)], A_C(j+2+g) [C(j-1)], B(j+2), A_L(j+3) [L(j)], A_C(j+3+g) [C(j)] ...; the prologue
-  // continues that pattern backwards so that the constant wait counts hold from step 0 on.
-  // Group 1 splits its compute-segment quads one step further ahead (its C(j) runs beside group 0's L(j+1), which reads step
-  // j+1): A_C(j+2) in C(j), hence A_C(1) here.
-  dma_b(0, 0);
-  load_q(I0{}, I0{}, QE{}, 0);
-  if (QC > 0 && late) load_q(I1{}, QL{}, QE{}, kc(1));
-  wait_vm<0>();
-  __builtin_amdgcn_sched_barrier(0);
-  split_r(I0{}, I0{}, QE{}, 0);  // SA[0]
-  if (QC > 0 && late) split_r(I1{}, QL{}, QE{}, SA_BYTES);
-  load_q(I1{}, I0{}, QL{}, kc(1));                  // "L(-2)": A_L(1)
-  if (QC > 0) {                                     // "C(-2)": A_C(1 + g)
-    if (!late) load_q(I1{}, QL{}, QE{}, kc(1));
-    else load_q(I0{}, QL{}, QE{}, kc(2));
-  }
-  dma_b(1, kc(1));                                  // "L(-1)": B(1), A_L(2)
-  load_q(I0{}, I0{}, QL{}, kc(2));
-  if (QC > 0) {                                     // "C(-1)": A_C(2 + g)
-    if (!late) load_q(I0{}, QL{}, QE{}, kc(2));
-    else load_q(I1{}, QL{}, QE{}, kc(3));
-  }
-  wait_lgkm<0>();
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();  // SA[0] and weight stage 0 complete (every wave waited for its B(0) pieces above)
-  __builtin_amdgcn_sched_barrier(0);
-
 #ifdef AIMNET_BF3_TIMING
   // measurement build: waves 0 and 4 of block 0 stamp s_memtime at every segment boundary (g_bf3_stamps, 2 x 512 entries)
   int n_ts = 0;
@@ -422,6 +323,38 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
 #else
 #define TSF()
 #endif
+  TS();  // kernel entry
+  // ---- prologue.  VMEM issue order of a wave in the steady state (g = group, A_L / A_C = the quads split in the load / compute
+  // segment): ... B(j+1), A_L(j+2) [L(j-1)], A_C(j+2+g) [C(j-1)], B(j+2), A_L(j+3) [L(j)], A_C(j+3+g) [C(j)] ...; the prologue
+  // continues that pattern backwards so that the constant wait counts hold from step 0 on.
+  // Group 1 splits its compute-segment quads one step further ahead (its C(j) runs beside group 0's L(j+1), which reads step
+  // j+1): A_C(j+2) in C(j), hence A_C(1) here.
+  // (Round 4: requesting the step-1 loads in front of the first wait - one cold-cache latency instead of two - measured 1-2 % SLOWER on
+  // every layer shape, profiles/r4_gemm.md: the larger first burst delays the step-0 data every wave is waiting for.)
+  dma_b(0, 0);
+  load_q(I0{}, I0{}, QE{}, 0);
+  if (QC > 0 && late) load_q(I1{}, QL{}, QE{}, kc(1));
+  wait_vm<0>();
+  __builtin_amdgcn_sched_barrier(0);
+  TS();
+  split_r(I0{}, I0{}, QE{}, 0);  // SA[0]
+  if (QC > 0 && late) split_r(I1{}, QL{}, QE{}, SA_BYTES);
+  load_q(I1{}, I0{}, QL{}, kc(1));                  // "L(-2)": A_L(1)
+  if (QC > 0) {                                     // "C(-2)": A_C(1 + g)
+    if (!late) load_q(I1{}, QL{}, QE{}, kc(1));
+    else load_q(I0{}, QL{}, QE{}, kc(2));
+  }
+  dma_b(1, kc(1));                                  // "L(-1)": B(1), A_L(2)
+  load_q(I0{}, I0{}, QL{}, kc(2));
+  if (QC > 0) {                                     // "C(-1)": A_C(2 + g)
+    if (!late) load_q(I0{}, QL{}, QE{}, kc(2));
+    else load_q(I1{}, QL{}, QE{}, kc(3));
+  }
+  wait_lgkm<0>();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();  // SA[0] and weight stage 0 complete (every wave waited for its B(0) pieces above)
+  __builtin_amdgcn_sched_barrier(0);
+
   bf16x8 fa[SM][3], fb[SN][3];
   // L(j): fragments of step j into registers; weight DMA of step j+2 into the ring stage of step j-1; split of the first NL quads
   // of A(j+1) (set (j+1) & 1, loaded in L(j-2)) into SA[(j+1) & 1], whose last readers passed two barriers ago; loads of the same
@@ -535,6 +468,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
   }
   wait_vm<0>();  // the clamped look-ahead of the last steps is still in flight; the wave must not end (LDS released) under its DMA
   __builtin_amdgcn_sched_barrier(0);
+  TS();  // main loop done
 
   // epilogue: sfin * acc[i][j][r] = C[m0 + wm*16*SM + 16 i + (lane&15)][n0 + wn*16*SN + 16 j + 4 (lane>>4) + r]
   const float sfin = kneg < nk ? -1.0f : 1.0f;  // the accumulators ended in the negated phase
@@ -573,6 +507,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(232))) void 
       }
     }
   }
+#ifdef AIMNET_BF3_TIMING
+  __builtin_amdgcn_sched_barrier(0);
+  TS();  // epilogue stores issued
+  wait_vm<0>();
+  __builtin_amdgcn_sched_barrier(0);
+  TS();  // ... and acknowledged
+#endif
 }
 
 template <int SM, int SN, int WN, int QC>

@@ -1,0 +1,420 @@
+// gemm_bf3a.hip - the bf16x3-split MLP GEMM with PRE-SPLIT activations: both operands reach LDS by DMA, no vector work in the loop.
+//
+//   C[M,N] = A[M,K] . Bt[N,K]^T, fused epilogues: the contract of gemm_bf3.hip (which replaces the torch addmm + GELU calls of
+//   aimnet/modules/core.py:11-46), except that A is handed over in the "bf3" layout (per row, K/32 blocks of
+//   [plane 0: 32 bf16][plane 1][plane 2] = 192 B; fp32 == p0 + p1 + p2 exactly) and that the epilogue can write C in the same
+//   layout for the next layer (OUT3).  The arithmetic is that of gemm_bf3.hip, product for product.
+//
+// Why (profiles/r3_gemm_bf3.md, r4_gemm.md): with fp32 activations every block splits its row panel itself - 75 vector
+// instructions and 9 LDS stores per wave and 32-k step, four times per panel (once per column tile) - and that work does not
+// hide behind the partner wave's matrix instructions: a step took 3 300 - 3 600 cycles against 2 200 of matrix work.  Here the
+// PRODUCER of an activation (the previous layer's epilogue, the convolution's row assembly) splits it once, and the main loop
+// is fragment reads, DMA issue and matrix instructions only.
+//
+// Schedule: the ping-pong of gemm_bf3.hip - waves 0-3 (group 0, upper half of the tile) and waves 4-7 (group 1, lower half, same
+// SIMDs) alternate LOAD and COMPUTE segments half a step apart, one s_barrier per segment - with the DMA split by group:
+//   group 0, L(j): fragments of step j -> registers; DMA of the WHOLE activation tile of step j+1 into SA[(j+1) & 1] (last read by
+//                  group 1 one segment ago); waits for it at the end of its C(j): two segments of lead
+//   group 1, L(j): fragments of step j; DMA of the whole weight tile of step j+2 into ring stage (j+2) % 3; waits for the tile of
+//                  step j+1 (issued one L earlier: in-order retirement, "at most one tile outstanding") before its barrier
+// so every tile is complete, and waited for by the waves that requested it, one barrier before its first reader.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "common.h"
+#include "gemm_bf3_common.h"
+#include "kernels.h"
+
+namespace aimnet {
+
+constexpr int bf3a_passes(int rows) { return (rows * 12 + 255) / 256; }  // DMA wave-instructions per wave of the issuing group
+constexpr int bf3a_lds_bytes(int TM, int TN) { return 2 * bf3a_passes(TM) * 4096 + 3 * bf3a_passes(TN) * 4096; }
+
+#ifdef AIMNET_BF3_TIMING
+__device__ unsigned long long g_bf3a_stamps[1024];
+#endif
+
+template <int EPI, int SM, int SN, int WN, bool OUT3>
+__global__ __launch_bounds__(512, 2) void gemm_bf3a_kernel(const unsigned short* __restrict__ A3, int lda3,
+                                                           const unsigned short* __restrict__ Bt, int ldb, int M, int N, int K,
+                                                           const float* __restrict__ bias, float* __restrict__ C,
+                                                           unsigned short* __restrict__ C3, int ldc3, float* __restrict__ D, int ldc,
+                                                           const int* __restrict__ brow, int ldbias, int kneg) {
+  static_assert(WN == 8 || WN == 4 || WN == 2, "waves across N");
+  constexpr int WM = 8 / WN;
+  constexpr int TM = 16 * SM * WM, TN = 16 * SN * WN;
+  constexpr int NPA = bf3a_passes(TM), NPB = bf3a_passes(TN);
+  constexpr int SA_BYTES = NPA * 4096, SB_BYTES = NPB * 4096;
+  constexpr int GA = TM * 12, GB = TN * 12;  // 16-byte granules of one tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_a[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const bool late = wid >= 4;  // group 1 runs one segment behind group 0
+  const int w4 = wid & 3, t256 = tid & 255;
+
+  const int tiles_n = (N + TN - 1) / TN;
+  const int nwg = gridDim.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int m0 = (wg / tiles_n) * TM, n0 = (wg % tiles_n) * TN;
+
+  f32x4 acc[SM][SN];
+#pragma unroll
+  for (int i = 0; i < SM; ++i)
+#pragma unroll
+    for (int j = 0; j < SN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_a;
+  const unsigned ldsB = lds0 + 2 * SA_BYTES;
+
+  // DMA granules of the issuing group: G = p * 256 + t256 -> row G / 12, plane (G % 12) / 4, slot G % 4 holding k-chunk
+  // slot ^ swz(row); granules beyond the tile (padding of the last pass) re-read the last one into the stage's padding.
+  // Offsets are bytes relative to the tile's first row (32 bits: a tile spans < 200 rows).
+  constexpr int NPMAX = NPA > NPB ? NPA : NPB;
+  unsigned goff[NPMAX];
+  {
+    const int gmax = (late ? GB : GA) - 1;
+    const int r0 = late ? n0 : m0, rlim = (late ? N : M) - 1;
+    const unsigned ldbytes = 2u * (unsigned)(late ? ldb : lda3);
+#pragma unroll
+    for (int p = 0; p < NPMAX; ++p) {
+      const int G = min(p * 256 + t256, gmax);
+      const int row = G / 12, g12 = G % 12;
+      const int pl = g12 >> 2, kcx = (g12 & 3) ^ swz192(row);
+      goff[p] = (unsigned)(min(r0 + row, rlim) - r0) * ldbytes + pl * 64 + kcx * 16;
+    }
+  }
+  const unsigned char* abase = reinterpret_cast<const unsigned char*>(A3 + (size_t)m0 * lda3);
+  const unsigned char* bbase = reinterpret_cast<const unsigned char*>(Bt + (size_t)n0 * ldb);
+  auto dma_a = [&](int stage, int kt) __attribute__((always_inline)) {
+    unsigned char* base = smem_a + stage * SA_BYTES + w4 * 1024;
+    const unsigned char* g = abase + (size_t)kt * ROWB;
+#pragma unroll
+    for (int p = 0; p < NPA; ++p) glds16b(g + goff[p], base + p * 4096);
+  };
+  auto dma_b = [&](int stage, int kt) __attribute__((always_inline)) {
+    unsigned char* base = smem_a + 2 * SA_BYTES + stage * SB_BYTES + w4 * 1024;
+    const unsigned char* g = bbase + (size_t)kt * ROWB;
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) glds16b(g + goff[p], base + p * 4096);
+  };
+
+  // fragment addresses: row r, plane P, k-chunk c = lane >> 4 -> r * 192 + P * 64 + (c ^ swz(r)) * 16
+  const int l16 = lane & 15, lc = lane >> 4;
+  const int rA = wm * 16 * SM + l16, rB = wn * 16 * SN + l16;
+  const unsigned adA = lds0 + rA * ROWB + ((lc ^ swz192(rA)) << 4);
+  const unsigned adB = ldsB + rB * ROWB + ((lc ^ swz192(rB)) << 4);
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  const int nk = K >> 5;
+  // every step issues the same operations: k-steps past the end of K are clamped to the last one (redundant tiles nothing reads)
+  auto kc = [&](int k) __attribute__((always_inline)) { return min(k, nk - 1); };
+
+#ifdef AIMNET_BF3_TIMING
+  int n_ts = 0;
+  auto TS = [&]() __attribute__((always_inline)) {
+    if (blockIdx.x == 0 && (wid & 3) == 0 && n_ts < 512) {
+      const unsigned long long t = __builtin_readcyclecounter();
+      if (lane == 0) g_bf3a_stamps[(wid >> 2) * 512 + n_ts] = t;
+      ++n_ts;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#else
+  auto TS = [&]() __attribute__((always_inline)) {};
+#endif
+  TS();
+  // ---- prologue: A(0) by group 0; B(0), B(1) by group 1
+  if (!late) {
+    dma_a(0, 0);
+    wait_vm<0>();
+  } else {
+    dma_b(0, 0);
+    dma_b(1, kc(1));
+    wait_vm<NPB>();
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  TS();
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  bf16x8 fa[SM][3], fb[SN][3];
+  auto seg_load = [&](int j, int st, auto par_c, auto g_c) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_c)::value, G = decltype(g_c)::value;
+    const unsigned oa = adA + PAR * SA_BYTES, ob = adB + st * SB_BYTES;
+    read_strips<0, SN, 0>(fb, ob);
+    read_strips<0, SM, 0>(fa, oa);
+    read_strips<0, SN, 1>(fb, ob);
+    read_strips<0, SM, 1>(fa, oa);
+    read_strips<0, SN, 2>(fb, ob);
+    read_strips<0, SM, 2>(fa, oa);
+    if constexpr (G == 0) {
+      dma_a(PAR ^ 1, kc(j + 1));
+      wait_lgkm<0>();
+    } else {
+      dma_b(st == 0 ? 2 : st - 1, kc(j + 2));  // (st + 2) % 3
+      wait_vm<NPB>();  // the weight tile of step j+1 (requested one L earlier) has landed
+      wait_lgkm<0>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto seg_compute = [&](int j, auto g_c) __attribute__((always_inline)) {
+    constexpr int G = decltype(g_c)::value;
+    if (j == kneg && j > 0) {  // second, sign-flipped accumulation phase (gemm_bf3.hip, "Accumulation bias")
+#pragma unroll
+      for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < SN; ++jj) acc[i][jj] = -acc[i][jj];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#define AIMNET_BF3_PRODUCT(PA, PB)                                                                              \
+  _Pragma("unroll") for (int i = 0; i < SM; ++i) _Pragma("unroll") for (int jj = 0; jj < SN; ++jj) acc[i][jj] = \
+      __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[jj][PB], fa[i][PA], acc[i][jj], 0, 0, 0);
+    AIMNET_BF3_PRODUCT(1, 1)
+    AIMNET_BF3_PRODUCT(0, 1)
+    AIMNET_BF3_PRODUCT(1, 0)
+    AIMNET_BF3_PRODUCT(0, 2)
+    AIMNET_BF3_PRODUCT(2, 0)
+    AIMNET_BF3_PRODUCT(0, 0)
+#undef AIMNET_BF3_PRODUCT
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G == 0) wait_vm<0>();  // the activation tile of step j+1, requested in L(j)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto bar = [&]() __attribute__((always_inline)) {
+    TS();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    TS();
+  };
+  auto run = [&](auto g_c) __attribute__((always_inline)) {
+    int st = 0, j = 0;
+    for (; j + 1 < nk; j += 2) {
+      seg_load(j, st, I0{}, g_c);
+      bar();
+      seg_compute(j, g_c);
+      st = st == 2 ? 0 : st + 1;
+      bar();
+      seg_load(j + 1, st, I1{}, g_c);
+      bar();
+      seg_compute(j + 1, g_c);
+      st = st == 2 ? 0 : st + 1;
+      if (j + 2 < nk) bar();
+    }
+    if (j < nk) {  // odd number of steps
+      seg_load(j, st, I0{}, g_c);
+      bar();
+      seg_compute(j, g_c);
+    }
+  };
+  if (late) {
+    bar();
+    run(I1{});
+  } else {
+    run(I0{});
+    bar();  // group 0 has 2 nk segments, group 1 an empty one in front: both pass 2 nk barriers
+  }
+  wait_vm<0>();  // the clamped look-ahead of the last steps: the wave must not end (LDS released) under its DMA
+  __builtin_amdgcn_sched_barrier(0);
+  TS();
+
+  // epilogue: sfin * acc[i][j][r] = C[m0 + wm*16*SM + 16 i + (lane&15)][n0 + wn*16*SN + 16 j + 4 (lane>>4) + r]
+  const float sfin = kneg < nk ? -1.0f : 1.0f;  // the accumulators ended in the negated phase
+  // value of tile (i, j) after the fused epilogue (GELU' / chain-rule factor through D); false: outside the matrix
+  auto finish = [&](int i, int j, f32x4& v) __attribute__((always_inline)) -> bool {
+    const int col = n0 + wn * 16 * SN + 16 * j + 4 * lc;
+    const int row = m0 + wm * 16 * SM + 16 * i + l16;
+    if (col >= N || row >= M) return false;
+    const size_t o = (size_t)row * ldc + col;
+    v = acc[i][j] * sfin;
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+      const f32x4 bv = brow ? *reinterpret_cast<const f32x4*>(bias + (size_t)min(63, max(0, brow[row])) * ldbias + col)
+                            : *reinterpret_cast<const f32x4*>(bias + col);
+      v = v + bv;
+    }
+    if (EPI == EPI_BIAS_GELU) {
+      f32x4 d;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float hh, dd;
+        gelu_and_grad(v[r], hh, dd);
+        v[r] = hh;
+        d[r] = dd;
+      }
+      if (D) *reinterpret_cast<f32x4*>(D + o) = d;
+    } else if (EPI == EPI_MUL) {
+      v = v * *reinterpret_cast<const f32x4*>(D + o);
+    }
+    return true;
+  };
+  if constexpr (OUT3) {
+    // bf3 output.  A lane holds 4 consecutive columns of a row: 8 bytes per plane, and 8-byte stores are issue-bound (30 per lane
+    // cost as much as the whole main loop's tail).  Two horizontally adjacent tiles are therefore exchanged with
+    // v_permlane16_swap (odd 16-lane rows of the first operand <-> even rows of the second), after which lane (l16, lc) holds
+    // columns 8 (lc >> 1) .. + 7 of tile j + (lc & 1): one 16-byte store per plane, and the four lanes of a row write the 64
+    // contiguous bytes of one plane segment of a k-block.
+#pragma unroll
+    for (int j = 0; j < SN; j += 2) {
+#pragma unroll
+      for (int i = 0; i < SM; ++i) {
+        const int row = m0 + wm * 16 * SM + 16 * i + l16;
+        unsigned short* crow = C3 + (size_t)row * ldc3;
+        if (j + 1 < SN) {
+          f32x4 v0, v1;
+          const bool ok = finish(i, j, v0);
+          finish(i, j + 1, v1);  // N % 32 == 0 and 32-aligned tile pairs: both tiles are inside or both outside
+          if (!ok) continue;
+          unsigned x[3][2], y[3][2];
+          split3_pair(v0[0], v0[1], x[0][0], x[1][0], x[2][0]);
+          split3_pair(v0[2], v0[3], x[0][1], x[1][1], x[2][1]);
+          split3_pair(v1[0], v1[1], y[0][0], y[1][0], y[2][0]);
+          split3_pair(v1[2], v1[3], y[0][1], y[1][1], y[2][1]);
+          const int col = n0 + wn * 16 * SN + 16 * (j + (lc & 1)) + 8 * (lc >> 1);
+          unsigned short* pc = crow + (col >> 5) * 96 + (col & 31);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                         : "+v"(x[pl][0]), "+v"(y[pl][0]), "+v"(x[pl][1]), "+v"(y[pl][1]));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<u32x4*>(pc + pl * 32) = u32x4{x[pl][0], x[pl][1], y[pl][0], y[pl][1]};
+          }
+        } else {
+          f32x4 v;
+          if (!finish(i, j, v)) continue;
+          store_bf3_x4(crow, n0 + wn * 16 * SN + 16 * j + 4 * lc, v);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < SN; ++j) {
+#pragma unroll
+      for (int i = 0; i < SM; ++i) {
+        f32x4 v;
+        if (!finish(i, j, v)) continue;
+        const int col = n0 + wn * 16 * SN + 16 * j + 4 * lc;
+        const int row = m0 + wm * 16 * SM + 16 * i + l16;
+        *reinterpret_cast<f32x4*>(C + (size_t)row * ldc + col) = v;
+      }
+    }
+  }
+#ifdef AIMNET_BF3_TIMING
+  __builtin_amdgcn_sched_barrier(0);
+  TS();
+  wait_vm<0>();
+  __builtin_amdgcn_sched_barrier(0);
+  TS();
+#endif
+}
+
+template <int SM, int SN, int WN>
+static int launch_bf3a(hipStream_t stream, int epi, bool out3, const unsigned short* A3, int lda3, const unsigned short* Bt, int ldb,
+                       int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
+                       const int* brow, int ldbias, int kneg) {
+  constexpr int WM = 8 / WN, TM = 16 * SM * WM, TN = 16 * SN * WN;
+  const int tiles = ceil_div(M, TM) * ceil_div(N, TN);
+  constexpr size_t lds = (size_t)bf3a_lds_bytes(TM, TN);
+  static_assert(lds <= 160 * 1024, "LDS");
+  dim3 grid(tiles), block(512);
+#define AIMNET_BF3A_LAUNCH(E, O3)                                                                                            \
+  {                                                                                                                          \
+    static PerDeviceOnce once;                                                                                               \
+    if (once.first())                                                                                                        \
+      AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf3a_kernel<E, SM, SN, WN, O3>,                                \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
+    hipLaunchKernelGGL((gemm_bf3a_kernel<E, SM, SN, WN, O3>), grid, block, lds, stream, A3, lda3, Bt, ldb, M, N, K, bias, C, \
+                       C3, ldc3, D, ldc, brow, ldbias, kneg);                                                                \
+  }
+  if (out3) {
+    switch (epi) {
+      case EPI_BIAS_GELU: AIMNET_BF3A_LAUNCH(EPI_BIAS_GELU, true) break;
+      case EPI_MUL: AIMNET_BF3A_LAUNCH(EPI_MUL, true) break;
+      default:
+        set_last_error("gemm_bf3a: split output exists for the GELU and chain-rule epilogues only (got %d)", epi);
+        return -1;
+    }
+  } else {
+    switch (epi) {
+      case EPI_NONE: AIMNET_BF3A_LAUNCH(EPI_NONE, false) break;
+      case EPI_BIAS: AIMNET_BF3A_LAUNCH(EPI_BIAS, false) break;
+      case EPI_BIAS_GELU: AIMNET_BF3A_LAUNCH(EPI_BIAS_GELU, false) break;
+      case EPI_MUL: AIMNET_BF3A_LAUNCH(EPI_MUL, false) break;
+      default:
+        set_last_error("gemm_bf3a: bad epilogue %d", epi);
+        return -1;
+    }
+  }
+#undef AIMNET_BF3A_LAUNCH
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+static int g_bf3a_force_tile = 0;  // AIMNET_BF3A_TILE forces one configuration (A/B runs)
+
+struct Bf3aCand { int id, tm, tn; };
+// id = 100 * WN (waves across N; 8 / WN across M) + 10 * SM + SN; block tile (16 SM 8 / WN) x (16 SN WN)
+static const Bf3aCand kBf3aCands[] = {{452, 160, 128}, {224, 128, 128}, {432, 96, 128}, {422, 64, 128},
+                                      {223, 128, 96},  {851, 80, 128},  {234, 192, 128}};
+
+static int choose_bf3a_tile(int M, int N) {
+  const long n_cu = device_cus();
+  int best = kBf3aCands[0].id;
+  double best_cost = 1e300;
+  for (const Bf3aCand& c : kBf3aCands) {
+    const long tiles = (long)ceil_div(M, c.tm) * ceil_div(N, c.tn);
+    const long per_cu = (tiles + n_cu - 1) / n_cu;
+    const double cost = (double)per_cu * ((double)c.tm * c.tn + 60.0 * (c.tm + c.tn) + 3000.0);
+    if (cost < best_cost) { best_cost = cost; best = c.id; }
+  }
+  return best;
+}
+
+int launch_gemm_bf3a_cfg(hipStream_t stream, int cfg, int epi, bool out3, const unsigned short* A3, int lda3, const unsigned short* Bt,
+                         int ldb, int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
+                         const int* brow, int ldbias, int kneg) {
+  if (M <= 0) return 0;
+  if (K % 32 != 0 || (lda3 % 96) || (ldb % 96) || (N & 3) || (ldc & 3) || (out3 && (ldc3 % 96 || (N & 31) || ldc3 < 3 * N)) ||
+      (((size_t)A3 | (size_t)Bt | (size_t)bias | (size_t)C | (size_t)C3 | (size_t)D) & 15)) {
+    set_last_error("gemm_bf3a: K=%d must be a multiple of 32, ldc/N multiples of 4, pointers 16-byte aligned, lda3/ldb/ldc3 whole 192-byte blocks, N %% 32 == 0 for split output", K);
+    return -1;
+  }
+  if (cfg == 0) cfg = g_bf3a_force_tile;
+  if (cfg == 0) cfg = choose_bf3a_tile(M, N);
+  switch (cfg) {
+#define AIMNET_BF3A_CASE(ID, SM_, SN_, WN_)                                                                                    \
+    case ID: return launch_bf3a<SM_, SN_, WN_>(stream, epi, out3, A3, lda3, Bt, ldb, M, N, K, bias, C, C3, ldc3, D, ldc, brow, \
+                                               ldbias, kneg);
+    AIMNET_BF3A_CASE(452, 5, 2, 4)  // 160 x 128 (2 x 4 waves of 80 x 32; 136 KiB of LDS)
+    AIMNET_BF3A_CASE(432, 3, 2, 4)  //  96 x 128
+    AIMNET_BF3A_CASE(422, 2, 2, 4)  //  64 x 128
+    AIMNET_BF3A_CASE(223, 2, 3, 2)  // 128 x  96 (4 x 2 waves of 32 x 48)
+    AIMNET_BF3A_CASE(224, 2, 4, 2)  // 128 x 128 (4 x 2 waves of 32 x 64)
+    AIMNET_BF3A_CASE(234, 3, 4, 2)  // 192 x 128 (4 x 2 waves of 48 x 64)
+    AIMNET_BF3A_CASE(851, 5, 1, 8)  //  80 x 128 (1 x 8 waves of 80 x 16)
+#undef AIMNET_BF3A_CASE
+    default:
+      set_last_error("gemm_bf3a: unknown tile id %d", cfg);
+      return -1;
+  }
+}
+
+#ifdef AIMNET_BF3_TIMING
+int gemm_bf3a_read_stamps(unsigned long long* host1024) {
+  AIMNET_HIP_CHECK(hipMemcpyFromSymbol(host1024, HIP_SYMBOL(g_bf3a_stamps), 1024 * sizeof(unsigned long long)));
+  return 0;
+}
+#endif
+
+int gemm_bf3a_set_attributes() {
+  const char* env = getenv("AIMNET_BF3A_TILE");
+  g_bf3a_force_tile = env ? atoi(env) : 0;
+  return 0;
+}
+
+}  // namespace aimnet

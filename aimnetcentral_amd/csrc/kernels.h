@@ -34,8 +34,17 @@ int launch_gemm_bf3_cfg(hipStream_t stream, int cfg, int epi, const float* A, in
                         int N, int K, const float* bias, float* C, float* D, int ldc, const int* brow = nullptr, int ldbias = 0,
                         int kneg = BF3_NO_NEG);
 int gemm_bf3_set_attributes();
+
+// ---- gemm_bf3a.hip: the same product with the ACTIVATIONS pre-split as well (A3: bf3 layout, lda3 = bf16 elements per row, a
+// multiple of 96): both operands reach LDS by DMA, no vector work in the main loop.  out3: the GELU / chain-rule epilogues write
+// C in bf3 form (C3, ldc3 >= 3 * pad32(N)) for the next layer instead of fp32 (C, ldc); D is fp32 [M][ldc] either way.
+int launch_gemm_bf3a_cfg(hipStream_t stream, int cfg, int epi, bool out3, const unsigned short* A3, int lda3, const unsigned short* Bt,
+                         int ldb, int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
+                         const int* brow = nullptr, int ldbias = 0, int kneg = BF3_NO_NEG);
+int gemm_bf3a_set_attributes();
 #ifdef AIMNET_BF3_TIMING
 int gemm_bf3_read_stamps(unsigned long long* host1024);  // measurement build only (tests/tools/bf3_timing.sh)
+int gemm_bf3a_read_stamps(unsigned long long* host1024);
 #endif
 
 // ---- nlist.hip --------------------------------------------------------------------------------
@@ -98,7 +107,8 @@ int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, co
                     const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
                     float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order,
                     bool species_moments = false,  // pass 0 (row_of given, nq = 0): per-element moments, no row gathers
-                    int split_max = 1024);         // atoms up to which the 4-waves-per-atom form is used
+                    int split_max = 1024,          // atoms up to which the 4-waves-per-atom form is used
+                    bool x_bf3 = false);           // rows pre-split for gemm_bf3a.hip (x: bf16 elements, 3 * ldx per row)
 int launch_unconcat(hipStream_t s, int nq, const float* xbar, int ldx, const float* Vsave, const float* Vqsave,
                     const float* agh_a, const float* agh_q, float* Sbar, float* Sqbar, int n_atoms);
 int launch_conv_bwd(hipStream_t s, int nq, bool need_abar, bool stress, const float* a, const int* row_of,
@@ -231,7 +241,8 @@ int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int 
                           int n_atoms, int S, float* part);  // part: [nq][n_mol][S] partial sums, consumed by launch_build_zbar
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
                       const float* Fm, const float* Dm, const float* wpart, int S, const int* mol_idx, int n_atoms, int n_mol,
-                      int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next);
+                      int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next,
+                      bool zbar_bf3 = false);  // zbar_bf3: rows in the split form of gemm_bf3a.hip (bf16 elements, 3 * ldy per row)
 // launch_pair_force's arguments as a rider of the stress reduction (launch_finalize): n_blocks = ceil(n_atoms / 4), 0 = none
 struct PairForceRider {
   const int* nb_idx; const int* nb_cnt; const int* rev; const float4* pairbuf; int cap; float* forces; int n_blocks;

@@ -12,6 +12,7 @@
 // energies are accumulated in fp64 exactly where the reference does (lr.py:61,326,602,611).
 #include "cellwalk.h"
 #include "common.h"
+#include "gemm_bf3_common.h"
 #include "kernels.h"
 #include "pairmap.h"
 
@@ -760,7 +761,7 @@ __global__ void build_zbar_kernel(const float* __restrict__ qbar, const float* _
                                   const float* __restrict__ Fm, const float* __restrict__ Dm,
                                   const float* __restrict__ wpart, int S, const int* __restrict__ mol_idx, int n_atoms,
                                   int n_mol, int n_feat, int nq, int carry_q, float* __restrict__ zbar,
-                                  float* __restrict__ qbar_next) {
+                                  float* __restrict__ qbar_next, unsigned short* __restrict__ zbar3) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
@@ -776,6 +777,10 @@ __global__ void build_zbar_kernel(const float* __restrict__ qbar, const float* _
   }
   float* zr = zbar + (size_t)i * ldy;
   const float* dr = dlast ? dlast + (size_t)i * ldy : nullptr;
+  // split form for gemm_bf3a.hip (zbar3): the row is assembled in LDS and leaves as 8-byte plane pieces, four columns per lane
+  __shared__ float stage[4][512];
+  float* st = stage[threadIdx.x >> 6];
+  const bool to_lds = zbar3 != nullptr && ldy <= 512;
   for (int c = lane; c < ldy; c += 64) {
     float v;
     if (c < nq) v = c == 0 ? qr[0] : qr[1];
@@ -783,16 +788,25 @@ __global__ void build_zbar_kernel(const float* __restrict__ qbar, const float* _
     else if (c < 2 * nq + n_feat) v = abar[(size_t)i * n_feat + c - 2 * nq];
     else v = 0.0f;
     if (dr && c < 2 * nq + n_feat) v *= dr[c];
-    zr[c] = v;
+    if (to_lds) st[c] = v;
+    else if (zbar3) store_bf3_1(zbar3 + (size_t)i * 3 * ldy, c, v);
+    else zr[c] = v;
+  }
+  if (to_lds) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    unsigned short* zr3 = zbar3 + (size_t)i * 3 * ldy;
+    for (int c = 4 * lane; c < ldy; c += 256) store_bf3_x4(zr3, c, f32x4{st[c], st[c + 1], st[c + 2], st[c + 3]});
   }
   if (lane < nq) qbar_next[(size_t)lane * n_atoms + i] = carry_q ? (lane == 0 ? qr[0] : qr[1]) : 0.0f;
 }
 
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
                       const float* Fm, const float* Dm, const float* wpart, int S, const int* mol_idx, int n_atoms, int n_mol,
-                      int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next) {
+                      int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next, bool zbar_bf3) {
   hipLaunchKernelGGL(build_zbar_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, qbar, abar, y, ldy, dlast, Fm, Dm, wpart,
-                     S < 1 ? 1 : S, mol_idx, n_atoms, n_mol, n_feat, nq, carry_q ? 1 : 0, zbar, qbar_next);
+                     S < 1 ? 1 : S, mol_idx, n_atoms, n_mol, n_feat, nq, carry_q ? 1 : 0, zbar, qbar_next,
+                     zbar_bf3 ? reinterpret_cast<unsigned short*>(zbar) : nullptr);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define AIMNET_ABI_VERSION 7
+#define AIMNET_ABI_VERSION 8
 
 #define AIMNET_OK 0
 #define AIMNET_E_INVALID (-1)   /* bad argument / unsupported architecture */
@@ -233,6 +233,11 @@ int aimnet_debug_gemm(int cfg, int epi, const float* A, int lda, const float* Bt
 int aimnet_debug_split_bf3(const float* src, int ld, int M, int K, void* dst, int ldd, int neg_from_block, void* hip_stream);
 int aimnet_debug_gemm_bf3(int cfg, int epi, const float* A, int lda, const void* Bt3, int ldb, int M, int N, int K,
                           const float* bias, float* C, float* D, int ldc, int kneg, void* hip_stream);
+/* aimnet_debug_gemm_bf3a (csrc/gemm_bf3a.hip): the same product with the activations pre-split too - A3 = bf3 form of A [M][K]
+ * (lda3 bf16 elements per row); out3 != 0: C is written in bf3 form into C3 (ldc3 bf16 elements per row; epilogues 2 and 3
+ * only), else as fp32 into C; D (epilogue 2 output / epilogue 3 input) is fp32 [M][ldc]. */
+int aimnet_debug_gemm_bf3a(int cfg, int epi, int out3, const void* A3, int lda3, const void* Bt3, int ldb, int M, int N, int K,
+                           const float* bias, float* C, void* C3, int ldc3, float* D, int ldc, int kneg, void* hip_stream);
 
 /* Engine switches for A/B and parity runs (all have an AIMNET_* environment twin read at create time):
  *   "conv_xe"       1 (default): reverse-pair form of the conv backward for systems above the split threshold, 0: combined form

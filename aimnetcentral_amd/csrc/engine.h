@@ -59,6 +59,9 @@ struct aimnet_engine {
   // vector work in its main loop.  0 = fp32 activations, split inside gemm_bf3.hip's loop (round 3; also what the tangent sweep of
   // hvp.hip, small batches and AIMNET_KEEP_INTERMEDIATES use).
   int gemm_presplit = 1;
+  // AIMNET_HEAD_FUSED / set_option("head_fused"): with pre-split activations, the energy head 256 -> 128 -> 128 -> 1 runs forward
+  // and backward in ONE launch (gemm_head.hip) instead of four N = 128 GEMM launches and the last-layer rider
+  int head_fused = 1;
   double* sae;
   // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row

@@ -124,6 +124,12 @@ int mlp_gemm3(const aimnet_engine* e, hipStream_t s, int epi, bool out3, const u
   return launch_gemm_bf3a_cfg(s, 0, epi, out3, A3 + (size_t)(k0 / 32) * 96, lda3, w3, 3 * ldw, M, N, K, bias, C, C3, ldc3, D, ldc, brow,
                               ldbias, kneg);
 }
+// the one-launch energy head of gemm_head.hip covers the shipped architecture (256 -> 128 -> 128 -> 1)
+bool head_fusable(const aimnet_engine* e) {
+  return e->head.size() == 3 && e->head[0].n_in == 256 && e->head[0].n_out == 128 && e->head[1].n_in == 128 &&
+         e->head[1].n_out == 128 && e->head[2].n_in == 128 && e->head[2].n_out == 1 && e->mlp[e->arch.n_pass - 1].back().k_out == 256 &&
+         !e->arch.last_linear[e->arch.n_pass - 1] && e->head_fused != 0;
+}
 // activations in split form for this batch? (layout() and eval() must agree)
 bool presplit_active(const aimnet_engine* e, int N) {
   return e->gemm_presplit != 0 && e->gemm_bf3 != 0 && N > std::max(256, e->split_max) && !e->keep_intermediates && !(e->conv_mfma & 1);
@@ -264,7 +270,9 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
       const int ld = e->mlp[p][l].k_out;
       snprintf(name, sizeof name, "h%d_%d", p, (int)l);
       const bool hidden = l + 1 < e->mlp[p].size();  // the last layer's output (q~, f~, delta_a / aim) is read again later
-      W.H[p][l] = (hidden && share) ? h_shared[l & 1] : c.take<float>(n * ld, name, ld);
+      // (pre-split activations: the last pass' output feeds the fused head in split form - 6 bytes per element)
+      const size_t own = (!hidden && p == np - 1) ? n * ld * ps_num / 2 : n * ld;
+      W.H[p][l] = (hidden && share) ? h_shared[l & 1] : c.take<float>(own, name, ld);
       W.D[p][l] = grad ? c.take<float>(n * ld) : nullptr;
     }
     W.Fm[p] = c.take<float>((size_t)n_mol * e->nq);
@@ -372,6 +380,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->gemm_bf3 = std::min(2, std::max(0, atoi(env)));
     env = getenv("AIMNET_GEMM_PRESPLIT");
     if (env) e->gemm_presplit = atoi(env) != 0;
+    env = getenv("AIMNET_HEAD_FUSED");
+    if (env) e->head_fused = atoi(env) != 0;
     env = getenv("AIMNET_CONV_XE");
     if (env) e->conv_xe = atoi(env);
     env = getenv("AIMNET_SPLIT_MAX");
@@ -506,6 +516,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "emb_bias") e->emb_bias = value != 0;
   else if (n == "gemm_bf3") e->gemm_bf3 = std::min(2, std::max(0, value));
   else if (n == "gemm_presplit") e->gemm_presplit = value != 0;
+  else if (n == "head_fused") e->head_fused = value != 0;
   else if (n == "split_max") e->split_max = value < 0 ? conv_split_max_default() : value;
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -753,6 +764,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   // a^0 = afv[Z] is never materialised: pass 0 gathers the embedding rows directly (conv_fwd / conv_bwd row_of, update_a)
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
   const bool ps = presplit_active(e, N);  // GEMM activations in split form (gemm_bf3a.hip)
+  const bool hfused = ps && head_fusable(e);  // energy head forward + backward in one launch (gemm_head.hip)
   const bool mfma_fwd = (e->conv_mfma & 1) && N > e->split_max;
   const bool mfma_bwd = (e->conv_mfma & 2) && N > e->split_max;
   // reverse-pair map through per-atom hash tables of the rows (once per neighbour list)
@@ -851,15 +863,16 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       int lda3 = 3 * Ls[0].k_in;
       for (int l = 0; l < nl; ++l) {
         const bool last = l == nl - 1, linear = last && ar.last_linear[p];
+        const bool f32out = last && !(hfused && p == np - 1);  // the last layer's output is read by pointwise kernels - or by the fused head
         const int epi = linear ? EPI_BIAS : EPI_BIAS_GELU, ko = Ls[l].k_out;
-        float* Cf = last ? W.H[p][l] : nullptr;
-        unsigned short* C3 = last ? nullptr : reinterpret_cast<unsigned short*>(W.H[p][l]);
+        float* Cf = f32out ? W.H[p][l] : nullptr;
+        unsigned short* C3 = f32out ? nullptr : reinterpret_cast<unsigned short*>(W.H[p][l]);
         float* Dl = linear ? nullptr : W.D[p][l];
         if (p == 0 && l == 0 && e->emb_bias && e->emb_bias0)
-          RC(mlp_gemm3(e, s, epi, !last, a3, lda3, Ls[l], true, 256, 0, N, ko, Ls[l].k_in - 256, e->emb_bias0, Cf, C3, 3 * ko, Dl, ko,
+          RC(mlp_gemm3(e, s, epi, !f32out, a3, lda3, Ls[l], true, 256, 0, N, ko, Ls[l].k_in - 256, e->emb_bias0, Cf, C3, 3 * ko, Dl, ko,
                        in->numbers, ko));
         else
-          RC(mlp_gemm3(e, s, epi, !last, a3, lda3, Ls[l], true, 0, 0, N, ko, Ls[l].k_in, Ls[l].b, Cf, C3, 3 * ko, Dl, ko));
+          RC(mlp_gemm3(e, s, epi, !f32out, a3, lda3, Ls[l], true, 0, 0, N, ko, Ls[l].k_in, Ls[l].b, Cf, C3, 3 * ko, Dl, ko));
         a3 = C3;
         lda3 = 3 * ko;
       }
@@ -895,6 +908,22 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     int ld_in = e->mlp[np - 1][nlp - 1].k_out;
     const int nh = (int)e->head.size();
     RC(prof_mark(e, s, FAM_GEMM));
+    if (hfused) {
+      HeadFusedArgs ha{};
+      ha.aim3 = reinterpret_cast<const unsigned short*>(hin);
+      ha.lda3 = 3 * ld_in;
+      ha.w1 = e->head[0].w3; ha.w2 = e->head[1].w3; ha.w2t = e->head[1].wt3; ha.w1t = e->head[0].wt3;
+      ha.b1 = e->head[0].b; ha.b2 = e->head[1].b; ha.w3 = e->head_w_last; ha.b3 = e->head_b_last;
+      ha.kneg1 = e->head[0].neg_w3; ha.kneg2 = e->head[1].neg_w3; ha.kneg3 = e->head[1].neg_wt3; ha.kneg4 = e->head[0].neg_wt3;
+      ha.dlast = grad ? W.D[np - 1][nlp - 1] : nullptr;
+      ha.ldd = ld_in;
+      ha.e_atom = W.e_atom;
+      ha.zbar3 = grad ? reinterpret_cast<unsigned short*>(W.zb0) : nullptr;
+      ha.ldz3 = 3 * ld_in;
+      ha.M = N;
+      ha.grad = grad ? 1 : 0;
+      RC(launch_head_fused(s, ha));
+    } else {
     for (int l = 0; l + 1 < nh; ++l) {
       const Layer& L = e->head[l];
       RC(mlp_gemm(e, s, EPI_BIAS_GELU, hin, ld_in, L, true, 0, 0, N, L.k_out, L.k_in, L.b, W.hH[l], W.hD[l], L.k_out));
@@ -911,6 +940,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       head_rider.k = e->head[nh - 1].n_in; head_rider.e_atom = W.e_atom;
       head_rider.d = grad ? W.hD[nh - 2] : nullptr; head_rider.zbar = grad ? W.zb0 : nullptr;
       head_rider.n_head_blocks = ceil_div(N, 4);
+    }
     }
   }
 
@@ -939,7 +969,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   // ---- backward -------------------------------------------------------------------------------
   float* zcur = W.zb0;
   float* znext = W.zb1;
-  {
+  if (!hfused) {  // (the fused head left the split adjoint of the last MLP's output in zb0)
     const int nh = (int)e->head.size();
     const Layer& Lp = e->head[nh - 2];  // zcur = zb0 holds the seed written by launch_head_last
     int ld = Lp.k_out;

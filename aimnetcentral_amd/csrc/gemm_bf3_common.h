@@ -36,6 +36,28 @@ __device__ __forceinline__ void store_bf3_x4(unsigned short* __restrict__ row, i
   *reinterpret_cast<u32x2*>(p + 64) = u32x2{a2, b2};
 }
 
+// Two horizontally adjacent 16x16 accumulator tiles of an MFMA epilogue (lane (l16, lc) holds columns 4 lc .. 4 lc + 3 of row l16 of
+// each: v0 = tile j, v1 = tile j + 1, col0 = first column of tile j, a multiple of 32) -> bf3 row `crow`.  A lane's own 8 bytes
+// per plane would make 8-byte stores, which are issue-bound; v_permlane16_swap (odd 16-lane rows of the first operand <-> even
+// rows of the second) leaves lane (l16, lc) with columns 8 (lc >> 1) .. + 7 of tile j + (lc & 1): one 16-byte store per plane,
+// and the four lanes of a row write the 64 contiguous bytes of one plane segment of a k-block.  All 64 lanes must call it.
+__device__ __forceinline__ void store_bf3_tile_pair(unsigned short* __restrict__ crow, int col0, int lc, f32x4 v0, f32x4 v1) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  unsigned x[3][2], y[3][2];
+  split3_pair(v0[0], v0[1], x[0][0], x[1][0], x[2][0]);
+  split3_pair(v0[2], v0[3], x[0][1], x[1][1], x[2][1]);
+  split3_pair(v1[0], v1[1], y[0][0], y[1][0], y[2][0]);
+  split3_pair(v1[2], v1[3], y[0][1], y[1][1], y[2][1]);
+  const int col = col0 + 16 * (lc & 1) + 8 * (lc >> 1);
+  unsigned short* pc = crow + (col >> 5) * 96 + (col & 31);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(x[pl][0]), "+v"(y[pl][0]), "+v"(x[pl][1]), "+v"(y[pl][1]));
+    *reinterpret_cast<u32x4*>(pc + pl * 32) = u32x4{x[pl][0], x[pl][1], y[pl][0], y[pl][1]};
+  }
+}
+
 // one element of a row in bf3 form
 __device__ __forceinline__ void store_bf3_1(unsigned short* __restrict__ row, int col, float v) {
   unsigned p0, p1, p2;

@@ -254,11 +254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf3a_kernel(const unsigned short*
     return true;
   };
   if constexpr (OUT3) {
-    // bf3 output.  A lane holds 4 consecutive columns of a row: 8 bytes per plane, and 8-byte stores are issue-bound (30 per lane
-    // cost as much as the whole main loop's tail).  Two horizontally adjacent tiles are therefore exchanged with
-    // v_permlane16_swap (odd 16-lane rows of the first operand <-> even rows of the second), after which lane (l16, lc) holds
-    // columns 8 (lc >> 1) .. + 7 of tile j + (lc & 1): one 16-byte store per plane, and the four lanes of a row write the 64
-    // contiguous bytes of one plane segment of a k-block.
+    // bf3 output: 16-byte stores per plane through store_bf3_tile_pair (8-byte stores, 30 per lane, cost 9 us on the large layers)
 #pragma unroll
     for (int j = 0; j < SN; j += 2) {
 #pragma unroll
@@ -270,20 +266,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf3a_kernel(const unsigned short*
           const bool ok = finish(i, j, v0);
           finish(i, j + 1, v1);  // N % 32 == 0 and 32-aligned tile pairs: both tiles are inside or both outside
           if (!ok) continue;
-          unsigned x[3][2], y[3][2];
-          split3_pair(v0[0], v0[1], x[0][0], x[1][0], x[2][0]);
-          split3_pair(v0[2], v0[3], x[0][1], x[1][1], x[2][1]);
-          split3_pair(v1[0], v1[1], y[0][0], y[1][0], y[2][0]);
-          split3_pair(v1[2], v1[3], y[0][1], y[1][1], y[2][1]);
-          const int col = n0 + wn * 16 * SN + 16 * (j + (lc & 1)) + 8 * (lc >> 1);
-          unsigned short* pc = crow + (col >> 5) * 96 + (col & 31);
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
-                         : "+v"(x[pl][0]), "+v"(y[pl][0]), "+v"(x[pl][1]), "+v"(y[pl][1]));
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            *reinterpret_cast<u32x4*>(pc + pl * 32) = u32x4{x[pl][0], x[pl][1], y[pl][0], y[pl][1]};
-          }
+          store_bf3_tile_pair(crow, n0 + wn * 16 * SN + 16 * j, lc, v0, v1);
         } else {
           f32x4 v;
           if (!finish(i, j, v)) continue;

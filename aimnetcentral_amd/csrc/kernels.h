@@ -42,6 +42,22 @@ int launch_gemm_bf3a_cfg(hipStream_t stream, int cfg, int epi, bool out3, const 
                          int ldb, int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
                          const int* brow = nullptr, int ldbias = 0, int kneg = BF3_NO_NEG);
 int gemm_bf3a_set_attributes();
+
+// ---- gemm_head.hip: the energy head 256 -> 128 -> 128 -> 1 forward and backward in one launch (operands of gemm_bf3a.hip)
+struct HeadFusedArgs {
+  const unsigned short* aim3;  // [M][lda3] head input in bf3 form (written by the last MLP layer's epilogue)
+  int lda3;
+  const unsigned short *w1, *w2, *w2t, *w1t;  // bf3 weights: W1 [128][3*256], W2 [128][3*128], W2^T [128][3*128], W1^T [256][3*128]
+  const float *b1, *b2, *w3, *b3;             // biases [128], last layer [128] and its bias [1]
+  int kneg1, kneg2, kneg3, kneg4;             // first negated k-block of the four weight operands (BF3_NO_NEG: none)
+  const float* dlast;                         // GELU' of the layer that produced the head input, fp32 [M][ldd] (grad only)
+  int ldd;
+  float* e_atom;                              // [M]
+  unsigned short* zbar3;                      // [M][ldz3] adjoint of that layer's pre-activation, bf3 form (grad only)
+  int ldz3;
+  int M, grad;
+};
+int launch_head_fused(hipStream_t s, const HeadFusedArgs& a);
 #ifdef AIMNET_BF3_TIMING
 int gemm_bf3_read_stamps(unsigned long long* host1024);  // measurement build only (tests/tools/bf3_timing.sh)
 int gemm_bf3a_read_stamps(unsigned long long* host1024);

@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = (
     "aimnet_debug_gemm_bf3a",
     "aimnet_debug_mfma4_probe",
     "aimnet_engine_set_option",
+    "aimnet_engine_get_option",
     "aimnet_engine_set_dftd3",
     "aimnet_neighbor_list",
     "aimnet_neighbor_list_workspace_bytes",
@@ -204,6 +205,8 @@ def load() -> C.CDLL:
                                           vp, C.c_int, C.c_int, vp]
     lib.aimnet_engine_set_option.restype = C.c_int
     lib.aimnet_engine_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.aimnet_engine_get_option.restype = C.c_int
+    lib.aimnet_engine_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
     lib.aimnet_debug_mfma4_probe.restype = C.c_int
     lib.aimnet_debug_mfma4_probe.argtypes = [vp, vp]
     lib.aimnet_neighbor_list_workspace_bytes.restype = sz

@@ -122,8 +122,9 @@ class AIMNet2TorchSim(_Base):
         n_sys = int(state.n_systems)
         data = {
             "coord": torch.as_tensor(state.positions, dtype=torch.float32).clone(),
-            "numbers": torch.as_tensor(state.atomic_numbers).to(torch.int64),
-            "mol_idx": torch.as_tensor(state.system_idx).to(torch.int64),
+            # static per-atom integers: converted once per source tensor (identity + version), not once per MD step
+            "numbers": self._converted("numbers", torch.as_tensor(state.atomic_numbers), torch.int64),
+            "mol_idx": self._converted("mol_idx", torch.as_tensor(state.system_idx), torch.int64),
             "charge": self._per_system(state, ("charge",), 0.0, n_sys),
         }
         if self._base_calc.is_nse:
@@ -145,6 +146,19 @@ class AIMNet2TorchSim(_Base):
         elif self._compute_stress:
             raise ValueError("AIMNet2 stress calculation requires a periodic TorchSim state with a non-zero cell.")
         return data
+
+    def _converted(self, name: str, src, dtype):
+        """`src.to(dtype)`, cached per source tensor: the atomic numbers and system indices of an MD run never change, and a dtype
+        conversion is a kernel launch (plus an allocation) per step otherwise."""
+        if src.dtype == dtype:
+            return src
+        cache = self.__dict__.setdefault("_conv_cache", {})
+        key = (src.data_ptr(), getattr(src, "_version", None), tuple(src.shape), src.dtype, src.device)
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, src.to(dtype))
+            cache[name] = hit
+        return hit[1]
 
     @staticmethod
     def _per_system(state, names: tuple[str, ...], default: float, n_sys: int):

@@ -386,7 +386,17 @@ class AIMNet2Calculator:
                 sh = d[sh_key]
                 if sh.ndim != 3 or sh.shape[0] != mat.shape[0] or sh.shape[1] != mat.shape[1] or sh.shape[2] != 3:
                     raise ValueError(f"{sh_key} must have shape {tuple(mat.shape) + (3,)}, got {tuple(sh.shape)}")
-                out["shifts" + role[5:]] = sh[:n].round().to(torch.int32)
+                shr = sh[:n].round()
+                # integer lattice multiples (the reference's convention, base.py:247); a Cartesian-shift convention is rejected
+                if sh.is_floating_point() and float((sh[:n] - shr).abs().max()) > 1e-4:
+                    raise ValueError(f"{sh_key} must hold integer lattice multiples (as the reference's neighbour lists do), not Cartesian shifts")
+                out["shifts" + role[5:]] = shr.to(torch.int32)
+            pm_key = "nb_pad_mask" + role[5:]
+            if pm_key in d:  # optional boolean padding mask (calculator.py:136-137): masked slots become padding entries
+                pm = d[pm_key]
+                if pm.shape != mat.shape:
+                    raise ValueError(f"{pm_key} must have the shape of {mat_key} {tuple(mat.shape)}, got {tuple(pm.shape)}")
+                out[role] = torch.where(pm[:n].to(torch.bool), torch.full_like(out[role], n), out[role])
         return out
 
     def _check_caller_lists(self, ext: dict[str, Any], method, cell) -> dict[str, Any]:

@@ -528,6 +528,26 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   return AIMNET_OK;
 }
 
+int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* value) {
+  if (!e || !name || !value) return AIMNET_E_INVALID;
+  const std::string n(name);
+  if (n == "conv_mfma") *value = e->conv_mfma;
+  else if (n == "conv_xe") *value = e->conv_xe;
+  else if (n == "emb_bias") *value = e->emb_bias ? 1 : 0;
+  else if (n == "gemm_bf3") *value = e->gemm_bf3;
+  else if (n == "gemm_presplit") *value = e->gemm_presplit;
+  else if (n == "head_fused") *value = e->head_fused;
+  else if (n == "split_max") *value = e->split_max;
+  else if (n == "p0_moments") *value = e->p0_moments ? 1 : 0;
+  else if (n == "overlap_coulomb") *value = e->overlap_coulomb ? 1 : 0;
+  else if (n == "spatial_order") *value = e->spatial_order ? 1 : 0;
+  else {
+    set_last_error("get_option: unknown option '%s'", name);
+    return AIMNET_E_INVALID;
+  }
+  return AIMNET_OK;
+}
+
 int aimnet_engine_set_dftd3(aimnet_engine* e, const aimnet_dftd3_tables* t) {
   if (!e || !t || t->n_z <= 0 || !t->c6ab || !t->cn_ref || !t->rcov || !t->r4r2) {
     set_last_error("set_dftd3: null argument");
@@ -711,9 +731,11 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     RC(launch_import_list(s, in->nbmat, pbc ? in->shifts : nullptr, in->nbmat_width, N, mol_c, in->cell, n_cell, cap, W.nl, W.nb_idx,
                           W.nb_shift, W.nb_cnt, out->status + 0, out->status + 2, W.pg, out->status + 6));
     RC(launch_list_symmetry_check(s, W.nb_idx, pbc ? W.nb_shift : nullptr, W.nb_cnt, cap, N, out->status + 6));
-    if (in->nbmat_lr && coulomb != AIMNET_COULOMB_NONE)
+    if (in->nbmat_lr && coulomb != AIMNET_COULOMB_NONE) {
       RC(launch_import_list(s, in->nbmat_lr, pbc ? in->shifts_lr : nullptr, in->nbmat_lr_width, N, mol_c, in->cell, n_cell, cap_lr, W.nl,
                             W.lr_idx, W.lr_shift, W.lr_cnt, out->status + 1, out->status + 3, nullptr, out->status + 6));
+      RC(launch_list_symmetry_check(s, W.lr_idx, pbc ? W.lr_shift : nullptr, W.lr_cnt, cap_lr, N, out->status + 6));
+    }
     if (d3) {
       d3_shared = d3_shares_lr_list(opt, cap_lr);  // one cutoff for both: the layout stores ONE matrix
       const int* src = in->nbmat_d3 ? in->nbmat_d3 : in->nbmat_lr;
@@ -732,6 +754,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
         }
         RC(launch_import_list(s, src, pbc ? src_sh : nullptr, src_w, N, mol_c, in->cell, n_cell, cap_d3, W.nl, W.d3_idx, W.d3_shift,
                               W.d3_cnt, out->status + 4, out->status + 5, nullptr, out->status + 6));
+        RC(launch_list_symmetry_check(s, W.d3_idx, pbc ? W.d3_shift : nullptr, W.d3_cnt, cap_d3, N, out->status + 6));
       }
     }
   } else {

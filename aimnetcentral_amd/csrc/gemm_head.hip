@@ -109,7 +109,6 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadFusedArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (t + 2 < n_tiles) issue(t + 2);
     const unsigned ob = adB + (t % 3) * HB_ST;
     read_strips<0, 2, 0>(fb, ob);
     read_strips<0, 2, 0>(fa, a_lds);
@@ -129,6 +128,11 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadFusedArgs a) {
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = \
       __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][PB], fa[i][PA], acc[i][j], 0, 0, 0);
     AIMNET_HEAD_PRODUCT(1, 1)
+    // the DMA of tile t + 2 is issued among the matrix instructions (in front of the fragment reads it cost 100 - 185 cycles per
+    // piece on the critical path); its ring stage was last read in step t - 1, which every wave left before this step's barrier
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < n_tiles) issue(t + 2);
+    __builtin_amdgcn_sched_barrier(0);
     AIMNET_HEAD_PRODUCT(0, 1)
     AIMNET_HEAD_PRODUCT(1, 0)
     AIMNET_HEAD_PRODUCT(0, 2)

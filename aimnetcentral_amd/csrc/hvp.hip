@@ -1093,6 +1093,11 @@ int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_ev
     set_last_error("hvp: DFT-D3 requested but aimnet_engine_set_dftd3 was never called");
     return AIMNET_E_INVALID;
   }
+  // the tangent kernels index the directions with grid.y (HIP limit 65535); the D3 block replicates every direction four times
+  if (n_vec > (d3 ? 16383 : 65535)) {
+    set_last_error("hvp: at most %d directions per sweep (%d given): split them over several calls", d3 ? 16383 : 65535, n_vec);
+    return AIMNET_E_INVALID;
+  }
   if (d3 && 4 * (size_t)n_vec * (size_t)in->n_atoms * (size_t)std::max(1, opt->max_nb_d3) >= (size_t)INT32_MAX) {
     set_last_error("hvp: n_vec * n_atoms * max_nb_d3 too large for one sweep (split the directions)");
     return AIMNET_E_INVALID;

@@ -673,7 +673,8 @@ int launch_import_list(hipStream_t s, const int* ext_idx, const int* ext_shift, 
 
 // every entry (i -> j, s) of a full neighbour matrix needs its mirror (j -> i, -s): the atomics-free conv backward evaluates the
 // adjoint of the pair seen from j at the centre i.  Brute force over the row of j (caller-supplied matrices only: the engine's own
-// builder emits both directions by construction).  bad: bit 4.
+// builder emits both directions by construction).  The same test runs on the caller's long-range / D3 matrices: a half list would
+// silently halve the Coulomb / dispersion energy.  bad: bit 4.
 __global__ __launch_bounds__(256) void list_symmetry_kernel(const int* __restrict__ nb_idx, const int* __restrict__ nb_shift,
                                                            const int* __restrict__ nb_cnt, int cap, int n_atoms,
                                                            int* __restrict__ bad) {
@@ -692,12 +693,14 @@ __global__ __launch_bounds__(256) void list_symmetry_kernel(const int* __restric
       want = pack_shift(-sx, -sy, -sz);
     }
     const int cj = nb_cnt[j];
-    bool found = false;
-    for (int t = 0; t < cj && !found; ++t) {
+    // EXACTLY one mirror: a duplicated (j, shift) entry would give two entries of the reverse-pair map one slot, and the force
+    // gather would subtract one pair-buffer entry twice (silently wrong forces)
+    int found = 0;
+    for (int t = 0; t < cj; ++t) {
       const size_t r = (size_t)j * cap + t;
-      found = nb_idx[r] == i && (!nb_shift || (nb_shift[r] & 0xffffff) == (want & 0xffffff));
+      found += (nb_idx[r] == i && (!nb_shift || (nb_shift[r] & 0xffffff) == (want & 0xffffff))) ? 1 : 0;
     }
-    missing = missing || !found;
+    missing = missing || found != 1;
   }
   if (__ballot(missing) && lane == 0) atomicOr(bad, 16);
 }

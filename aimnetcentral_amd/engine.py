@@ -49,6 +49,25 @@ class NeighborOverflowError(RuntimeError):
     exception of this name, neighbors.py:127-130)."""
 
 
+def describe_input_flags(flags: int, n_mol: int | None = None) -> str:
+    """Text of the input sanity flags the engine raises in status[6] (it clamps for memory safety; the results are meaningless)."""
+    what = []
+    if flags & 1:
+        what.append("atomic numbers outside [0, 63] (the embedding has 64 rows, core.py:49)")
+    if flags & 2:
+        what.append("mol_idx entries outside [0, %s) (n_mol is taken from the charge array)" % ("n_mol" if n_mol is None else n_mol))
+    if flags & 4:
+        what.append("mol_idx is not sorted (the atoms of a molecule must be contiguous)")
+    if flags & 8:
+        what.append("a caller-supplied neighbour matrix holds a lattice shift outside +-127 or an unshifted self pair")
+    if flags & 16:
+        what.append("a caller-supplied neighbour matrix is not a full symmetric matrix (an entry i -> j without exactly one mirror j -> i, "
+                    "or a duplicated entry)")
+    if flags & ~31:
+        what.append(f"unknown flag bits {flags & ~31:#x}")
+    return " and ".join(what) if what else "no flags"
+
+
 class HipEngine:
     def __init__(self, spec: ModelSpec, device: str | int = 0):
         import torch
@@ -122,10 +141,16 @@ class HipEngine:
 
     # ------------------------------------------------------------------------------------------
     def set_option(self, name: str, value: int) -> None:
-        """Engine switch for A/B and parity runs (include/aimnet_hip.h, aimnet_engine_set_option): "gemm_bf3", "conv_mfma", "conv_xe", "split_max",
-        "p0_moments", "spatial_order", "overlap_coulomb"."""
+        """Engine switch for A/B and parity runs (include/aimnet_hip.h, aimnet_engine_set_option): "gemm_bf3", "gemm_presplit", "head_fused", "conv_mfma",
+        "conv_xe", "split_max", "p0_moments", "spatial_order", "overlap_coulomb"."""
         _lib.check(self.lib.aimnet_engine_set_option(self._h, name.encode(), int(value)), "aimnet_engine_set_option")
         self._ws = None  # the workspace layout depends on the switches
+
+    def get_option(self, name: str) -> int:
+        """Current value of an engine switch (aimnet_engine_get_option)."""
+        v = C.c_int(0)
+        _lib.check(self.lib.aimnet_engine_get_option(self._h, name.encode(), C.byref(v)), "aimnet_engine_get_option")
+        return int(v.value)
 
     def set_dftd3_tables(self, tables: dict[str, Any]) -> None:
         """Upload the DFT-D3 reference tables (what DFTD3.__init__ reads from aimnet/dftd3_data.pt, lr.py:1405-1423):
@@ -159,8 +184,7 @@ class HipEngine:
         self.pending_status.clear()
         self.last_status = st[-1]
         if st[:, 6].any():
-            raise ValueError("HipEngine: invalid input in a deferred evaluation (atomic numbers outside [0, 63], mol_idx out of range "
-                             "or not sorted)")
+            raise ValueError("HipEngine: invalid input in a deferred evaluation: " + describe_input_flags(int(np.bitwise_or.reduce(st[:, 6]))))
         grown = False
         if st[:, 2].any():
             self.max_nb = _round16(int(max(self.max_nb * 1.5, st[:, 0].max())))
@@ -364,18 +388,7 @@ class HipEngine:
                 st = status.cpu().numpy()
             self.last_status = st
             if st[6]:  # input sanity flags raised by the engine (it clamps for memory safety, the results are meaningless)
-                what = []
-                if st[6] & 1:
-                    what.append("atomic numbers outside [0, 63] (the embedding has 64 rows, core.py:49)")
-                if st[6] & 2:
-                    what.append(f"mol_idx entries outside [0, {n_mol}) (n_mol is taken from the charge array)")
-                if st[6] & 4:
-                    what.append("mol_idx is not sorted (the atoms of a molecule must be contiguous)")
-                if st[6] & 8:
-                    what.append("a caller-supplied neighbour matrix holds a lattice shift outside +-127 or an unshifted self pair")
-                if st[6] & 16:
-                    what.append("the caller-supplied nbmat is not a full symmetric matrix (an entry i -> j without its mirror j -> i)")
-                raise ValueError("HipEngine.eval: invalid input: " + " and ".join(what))
+                raise ValueError("HipEngine.eval: invalid input: " + describe_input_flags(int(st[6]), n_mol))
             retry = False
             if ext:  # caller-supplied rows cannot overflow, and say nothing about the capacities of the engine's own lists
                 break
@@ -419,6 +432,10 @@ class HipEngine:
 
     # ------------------------------------------------------------------------------------------
     HVP_BYTES_BUDGET = 6 << 30  # workspace of one tangent sweep; more directions than fit are processed in several sweeps
+    HVP_MAX_DIRECTIONS = 65535  # the tangent kernels put the direction index in grid.y (HIP limit 65535; 4 K with DFT-D3: 16383)
+    # one direction costs ~3/4 us per atom (7.5 ms on 10 080 atoms, profiles/r3_hvp.md): refuse calls that would run for more than
+    # this many seconds unless the caller raises the limit (a dense Hessian of a 10 k-atom crystal is 30 240 directions = minutes)
+    HVP_MAX_SECONDS = 120.0
 
     def hvp(self, coord, numbers, mol_idx, charge, vectors, cell=None, pbc=(True, True, True), coulomb: str = "simple",
             dsf_rc: float = 15.0, dsf_alpha: float = 0.2, want_forces: bool = False,
@@ -447,6 +464,11 @@ class HipEngine:
         K = vectors.shape[0]
         if n == 0 or n_mol == 0 or K == 0:
             raise ValueError("HipEngine.hvp: empty input")
+        est = 0.75e-6 * n * K if n > 2000 else 0.0  # (small systems are launch-bound: ~0.04 force evaluations per direction)
+        if est > self.HVP_MAX_SECONDS:
+            raise ValueError(f"HipEngine.hvp: {K} directions on {n} atoms would take ~{est:.0f} s (~0.75 us per atom and direction); "
+                             f"pass fewer vectors per call (a Krylov / Davidson solver needs tens, not 3N) or raise "
+                             f"HipEngine.HVP_MAX_SECONDS (now {self.HVP_MAX_SECONDS:.0f} s)")
         n_cell = 0
         if cell is not None:
             cell = cell.to(device=dev, dtype=torch.float32).contiguous()
@@ -485,7 +507,8 @@ class HipEngine:
                 opt.max_nb_d3 = self._lr_capacity(d3_rc)
             per_dir = (int(self.lib.aimnet_engine_hvp_workspace_bytes(self._h, n, n_mol, 2, C.byref(opt)))
                        - int(self.lib.aimnet_engine_hvp_workspace_bytes(self._h, n, n_mol, 1, C.byref(opt))))
-            kc = max(1, min(K - k0, self.HVP_BYTES_BUDGET // max(1, per_dir)))
+            kmax = self.HVP_MAX_DIRECTIONS // (4 if dftd3 is not None else 1)  # grid.y limit of the tangent kernels
+            kc = max(1, min(K - k0, kmax, self.HVP_BYTES_BUDGET // max(1, per_dir)))
             need = int(self.lib.aimnet_engine_hvp_workspace_bytes(self._h, n, n_mol, kc, C.byref(opt)))
             ws = torch.empty(need + 4096, dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
@@ -497,7 +520,7 @@ class HipEngine:
             del ws
             self.last_status = st
             if st[6]:
-                raise ValueError("HipEngine.hvp: invalid input (atomic numbers outside [0, 63], mol_idx out of range or not sorted)")
+                raise ValueError("HipEngine.hvp: invalid input: " + describe_input_flags(int(st[6]), n_mol))
             if st[2] or st[3] or st[5]:  # neighbour-row overflow: grow and repeat this sweep
                 if st[2]:
                     self.max_nb = _round16(int(max(self.max_nb * 1.5, st[0])))

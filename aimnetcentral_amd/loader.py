@@ -392,11 +392,107 @@ def load_model(path: str, *, model_import_paths: Collection[str] | None = None, 
     natively), everything else is read exactly once with torch.load(weights_only=True)."""
     import torch
 
+    import os
+
+    if os.path.isdir(path):  # the reference's Hugging Face layout on disk: config.json + ensemble_N.safetensors
+        return load_hf_dir(path, 0, model_import_paths=model_import_paths, model_import_mode=model_import_mode)
     policy = ImportPolicy(model_import_paths, model_import_mode)
     if str(path).lower().endswith(".jpt"):
         raise NotImplementedError("legacy TorchScript (.jpt) models cannot run on the native HIP engine; convert them to the v2 format")
     data = torch.load(path, map_location="cpu", weights_only=True)
     spec = spec_from_artifact(data, policy=policy, source=str(path))
+    return spec, spec.metadata
+
+
+def _srcoulomb_pairs(obj: Any) -> set[tuple[float, str]]:
+    """Complete (rc, envelope) pairs of every SRCoulomb block of a parsed model YAML (hf_hub.py:95-118)."""
+    pairs: set[tuple[float, str]] = set()
+    if isinstance(obj, Mapping):
+        cls = obj.get("class")
+        if isinstance(cls, str) and cls.endswith("SRCoulomb"):
+            kw = obj.get("kwargs", {})
+            if isinstance(kw, Mapping) and kw.get("rc") is not None and kw.get("envelope") is not None:
+                if not isinstance(kw["envelope"], str):
+                    raise ValueError("SRCoulomb model_yaml field 'coulomb_sr_envelope' must be a supported string.")
+                validate_metadata({"coulomb_sr_rc": kw["rc"], "coulomb_sr_envelope": kw["envelope"]}, require_cutoff=False, structural=False)
+                pairs.add((float(kw["rc"]), kw["envelope"]))
+        for v in obj.values():
+            pairs |= _srcoulomb_pairs(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            pairs |= _srcoulomb_pairs(v)
+    return pairs
+
+
+def load_hf_dir(path: str, ensemble_member: int = 0, *, model_import_paths: Collection[str] | None = None,
+                model_import_mode: str = "extend") -> tuple[ModelSpec, dict[str, Any]]:
+    """A LOCAL directory in the reference's Hugging Face layout - `config.json` (metadata + `model_yaml`) next to
+    `ensemble_<N>.safetensors` - as load_from_hf_repo reads it (aimnet/calculators/hf_hub.py:275-398): same order of checks
+    (config root, member_names range, YAML import policy, SRCoulomb pair discovery / conflict rules of :121-147, metadata defaults of
+    :174-192, structural validation, then the weights).  Repository ids (network download) and the family-level configs without
+    `model_yaml` (registry fallback, :337-352) are out of scope here: there is no network on the GPU box."""
+    import json
+    import os
+
+    if type(ensemble_member) is not int or ensemble_member < 0:
+        raise ValueError("ensemble_member must be a non-boolean integer greater than or equal to zero.")
+    if not os.path.isdir(path):
+        raise NotImplementedError(f"{path!r} is not a local directory: Hugging Face repository ids need network access (out of scope)")
+    policy = ImportPolicy(model_import_paths, model_import_mode)
+    cfg_path = os.path.join(path, "config.json")
+    if not os.path.exists(cfg_path):
+        raise FileNotFoundError(f"config.json not found in {path}")
+    with open(cfg_path) as f:
+        config = json.load(f)
+    if not isinstance(config, Mapping):
+        raise TypeError("config.json root must be a mapping.")
+    config = dict(config)
+    validate_metadata(config, require_cutoff=False, structural=False)
+    if "member_names" in config:
+        names = config["member_names"]
+        if not isinstance(names, list) or not names or any(not isinstance(n, str) for n in names):
+            raise ValueError("config.json field 'member_names' must be a nonempty list of strings.")
+        if ensemble_member >= len(names):
+            raise ValueError(f"ensemble_member {ensemble_member} is out of range for config.json 'member_names' with {len(names)} entries.")
+    model_yaml = config.get("model_yaml")
+    if model_yaml is None:
+        raise NotImplementedError("family-level config.json without 'model_yaml' needs the model registry (network): out of scope")
+    model_config = parse_model_yaml(model_yaml, policy)
+    pairs = _srcoulomb_pairs(model_config)
+    if len(pairs) > 1:
+        raise ValueError(f"ambiguous SRCoulomb definitions contain distinct parameter pairs: {sorted(pairs)!r}.")
+    rc, env = next(iter(pairs), (None, None))
+    found = rc is not None and env is not None
+    if found and config.get("coulomb_sr_rc") is not None and float(config["coulomb_sr_rc"]) != rc:
+        raise ValueError("config.json field 'coulomb_sr_rc' conflicts with the SRCoulomb value discovered in model_yaml.")
+    if found and config.get("coulomb_sr_envelope") is not None and config["coulomb_sr_envelope"] != env:
+        raise ValueError("config.json field 'coulomb_sr_envelope' conflicts with the SRCoulomb value discovered in model_yaml.")
+    if (config.get("coulomb_mode", "none") == "sr_embedded" and not found
+            and (config.get("coulomb_sr_rc") is None or config.get("coulomb_sr_envelope") is None)):
+        raise ValueError("sr_embedded metadata with an omitted Coulomb field requires exactly one distinct complete "
+                         "SRCoulomb parameter pair in model_yaml.")
+    if config.get("coulomb_sr_rc") is None and found:
+        config["coulomb_sr_rc"] = rc
+    if config.get("coulomb_sr_envelope") is None and found:
+        config["coulomb_sr_envelope"] = env
+    validate_metadata(config, require_cutoff=True, structural=False)
+    fv = config.get("format_version", 2)
+    if type(fv) is not int or fv != 2:
+        raise ValueError("HF model metadata field 'format_version' must be integer 2.")
+    metadata = metadata_from_artifact(config)
+    validate_metadata(metadata, require_cutoff=True, structural=True)
+    if _has_d3ts(model_config) != bool(metadata.get("has_embedded_d3ts", False)):
+        raise ValueError("model metadata field 'has_embedded_d3ts' disagrees with D3TS presence in model_yaml.")
+    st_name = f"ensemble_{ensemble_member}.safetensors"
+    st_path = os.path.join(path, st_name)
+    if not os.path.exists(st_path):
+        raise FileNotFoundError(f"{st_name} not found in {path}")
+    try:
+        from safetensors.torch import load_file
+    except ImportError as exc:  # pragma: no cover
+        raise ImportError("Hugging Face format support requires the `safetensors` package") from exc
+    sd = load_file(st_path, device="cpu")
+    spec = spec_from_config(model_config, sd, metadata, source=st_path, unexpected="warn")
     return spec, spec.metadata
 
 

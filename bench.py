@@ -19,7 +19,7 @@ device and are all verified after the closing barrier (warm-up steps run with th
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the eval stream
 around the dominant kernel family (the MLP GEMMs) on every 4th timed step: algorithmic fp32 GEMM
 FLOPs per step / GEMM milliseconds per step.  The GEMMs run with bf16x3-split operands on the bf16
-matrix pipe (six bf16 products per fp32 product, fp32 accumulation: csrc/gemm_bf3.hip), so the roof
+matrix pipe (six bf16 products per fp32 product, fp32 accumulation: csrc/gemm_bf3a.hip / gemm_bf3.hip), so the roof
 of that kernel is 2.5 PFLOP/s / 6 = 416.7 TFLOP/s of fp32 work (`peak`); the fraction of the 157.3
 TFLOP/s fp32-matrix peak is reported beside it.  `exact_f32` is the same measurement with the
 exact-fp32 MFMA kernels (engine option gemm_bf3 = 0), taken after the timed region.  `parity`
@@ -218,11 +218,52 @@ def cpu_baseline(workload: str, budget_s: float = 10.0, samples=None, oracle_out
                 break
         results.append({"cores": int(nt), "value": n_atoms * reps / dt, "evals": reps, "seconds": round(dt, 2)})
     best = max(results, key=lambda r: r["value"])
+    full = None
+    if workload == "pbc10k" and budget_s >= 5.0:  # ONE evaluation of the full-size configuration (10 080 atoms, both lists rebuilt)
+        try:
+            c, z10, cell = workloads.glucose_supercell((7, 3, 5))
+            mol = np.zeros(len(z10), dtype=np.int64)
+            pbc = np.ones(3, dtype=bool)
+            c32, cell32 = c.astype(np.float32), cell.astype(np.float32)
+            om = O.OracleModel(synth.synthetic_state_dict(0), torch.float32)
+            torch.set_num_threads(min(cores, 16))
+            t0 = time.perf_counter()
+            xw = O.wrap_into_cell(c32, cell32, mol, pbc)
+            nb, sh = O.neighbor_list_fast(xw, 5.0, mol, cell, pbc)
+            nbl, shl = O.neighbor_list_fast(xw, 15.0, mol, cell, pbc)
+            O.evaluate(om, coord=xw, numbers=z10, charge=np.zeros(1, np.float32), mol_idx=mol, cell=cell32, coulomb="dsf", stress=True,
+                       nbmat=nb, shifts=sh, nbmat_lr=nbl, shifts_lr=shl)
+            dt = time.perf_counter() - t0
+            full = {"atoms": int(len(z10)), "cores": int(min(cores, 16)), "evals": 1, "seconds": round(dt, 2), "value": len(z10) / dt,
+                    "sample": "the full-size configuration itself: 2019828.cif (7,3,5) supercell, 10080 atoms, DSF 15A, E+F+stress, lists rebuilt"}
+        except Exception as exc:  # e.g. host memory: the bounded sample above stands
+            full = {"error": f"{type(exc).__name__}: {exc}"}
     return {"value": best["value"], "unit": "atoms*steps/s", "cores": best["cores"], "kind": "port",
-            "sample": sample + f"; torch {torch.__version__} CPU eager, {cores} host threads available", "all": results}
+            "sample": sample + f"; torch {torch.__version__} CPU eager, {cores} host threads available", "all": results, "full_size": full}
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r3_pmc.json")
+def _pmc_file():
+    """The newest committed profiles/rN_pmc.json (written by tests/tools/pmc_bench.sh)."""
+    import glob
+    import re
+
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")):
+        m = re.match(r"r(\d+)([a-z]?)_pmc\.json$", os.path.basename(f))
+        if m and (best is None or (int(m.group(1)), m.group(2)) > best[0]):
+            best = ((int(m.group(1)), m.group(2)), f)
+    return best[1] if best else None
+
+
+PMC_FILE = _pmc_file()
+
+
+def pmc_record(workload):
+    """The whole committed PMC record of this workload (or {}): traffic, MFMA-busy fraction, the commit it was measured at."""
+    if workload != "pbc10k" or not PMC_FILE or not os.path.exists(PMC_FILE):
+        return {}
+    with open(PMC_FILE) as f:
+        return json.load(f)
 
 
 def pmc_traffic(workload):
@@ -230,7 +271,7 @@ def pmc_traffic(workload):
     TCC_EA0_WRREQ x 64 B, the gfx950 correction of MI355X_MICROARCH.md).  PMC counters cannot be read from inside the timed
     process, so this is the last measured value: the file records the commit it was measured at (`commit`) and
     tests/tools/pmc_bench.sh regenerates it; None for other workloads or when the file is missing."""
-    if workload != "pbc10k" or not os.path.exists(PMC_FILE):
+    if workload != "pbc10k" or not PMC_FILE or not os.path.exists(PMC_FILE):
         return None, None
     with open(PMC_FILE) as f:
         d = json.load(f)
@@ -414,7 +455,8 @@ def main():
         fam = {k: v / 5 for k, v in eng.read_profile().items() if k != "evals"}
         eng.set_profiling(0)
         n_pairs = int(eng.debug_view("nb_cnt").sum().item())  # ordered pairs inside the 5 A cutoff
-        xe = os.environ.get("AIMNET_CONV_XE", "1") != "0" and n_atoms > int(os.environ.get("AIMNET_SPLIT_MAX", "1024"))  # engine defaults
+        # the engine's own switches (not the environment: set_option may have changed them); reverse-pair form = engine.hip layout()
+        xe = eng.get_option("conv_xe") != 0 and not (eng.get_option("conv_mfma") & 2) and n_atoms > eng.get_option("split_max")
         gather_form = "reverse-pair" if xe else "combined"
         # pass 0 in the reverse-pair form reads only the centre's own species-moment block of the pair (256 B)
         gather_bytes = (2 * (4096 + 256 + 16) + 16 + 256) if xe else (2 * 5376 + 512)
@@ -430,6 +472,8 @@ def main():
         fl = eng.gemm_flops_per_atom(True) * n_atoms
         exact = {"value": r["total_atoms"] * args.steps / r["elapsed"], "unit": "atoms*steps/s", "ms_per_step": r["elapsed"] / args.steps * 1e3,
                  "dtype": "f32 (v_mfma_f32_16x16x4_f32, exact fp32 operands)", "option": "aimnet_engine_set_option(\"gemm_bf3\", 0)",
+                 "parity_note": "on the cold relaxed256 fixture this mode sits at 1.05 x the un-widened energy gate (the default split "
+                                "kernels at 0.66; the reference's own fp32 golden at 0.75): tests/test_gpu_configs.py, profiles/r3_gemm_bf3.md",
                  "roofline": {"bound": "mfma", "achieved": fl / (g_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                               "frac": fl / (g_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, "gemm_ms_per_step": g_ms,
                               "kernel": "gemm_nt_panel_kernel (fp32 MFMA MLP GEMMs)"}}
@@ -442,6 +486,11 @@ def main():
         flops_step = eng.gemm_flops_per_atom(True) * n_atoms
         achieved = flops_step / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_commit = pmc_traffic(args.workload)
+        pmc = pmc_record(args.workload)
+        presplit = eng.get_option("gemm_presplit") != 0 and eng.get_option("gemm_bf3") != 0 and n_atoms > max(256, eng.get_option("split_max"))
+        n_lay = sum(len(d) - 1 for d in eng.spec.mlp_dims)
+        fused = presplit and eng.get_option("head_fused") != 0
+        gemm_launches = 2 * n_lay + (1 if fused else 2 * (len(eng.spec.head_dims) - 2))
         e2e_flops = e2e_flops_per_atom(n_pairs / n_atoms) * n_atoms
         e2e_tflops = e2e_flops * world / (ms_per_step * 1e-3) / 1e12 / world  # per GPU (weak scaling: every rank runs the same work)
         out = {
@@ -467,7 +516,11 @@ def main():
                          "frac": achieved / PEAK_BF16X3_TFLOPS, "peak_note": "2.5 PFLOP/s dense bf16 / 6 products per fp32 product",
                          "peak_fp32_matrix": PEAK_FP32_MATRIX_TFLOPS, "frac_fp32_matrix": achieved / PEAK_FP32_MATRIX_TFLOPS,
                          "traffic": traffic, "traffic_measured_at_commit": traffic_commit,
-                         "kernel": "gemm_bf3_kernel (bf16x3-split MFMA MLP GEMMs, fp32 accumulate; all launches of a step)",
+                         "mfma_busy_frac_in_kernel": pmc.get("mfma_busy_frac_in_kernel"),
+                         "kernel": ("gemm_bf3a_kernel + head_fused_kernel (bf16x3-split MFMA MLP GEMMs, operands pre-split by their producers, "
+                                    "fp32 accumulate; all launches of a step)") if presplit else
+                                   "gemm_bf3_kernel (bf16x3-split MFMA MLP GEMMs, fp32 accumulate; all launches of a step)",
+                         "gemm_launches_per_step": gemm_launches,
                          "gemm_ms_per_step": gemm_ms, "other_ms_per_step": prof["other"] / max(1.0, prof["evals"]),
                          "sampled_steps": int(prof["evals"]),
                          "algorithmic_flop_per_step": flops_step},
@@ -475,7 +528,12 @@ def main():
             # frac >= 0.5 here, i.e. 7.7e6 atoms*steps/s on the 10 080-atom configuration
             "roofline_e2e": {"bound": "mfma", "achieved": e2e_tflops, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                              "frac": e2e_tflops / PEAK_FP32_MATRIX_TFLOPS, "algorithmic_flop_per_step": e2e_flops,
-                             "mean_neighbours": n_pairs / n_atoms, "target_frac": 0.5},
+                             "mean_neighbours": n_pairs / n_atoms, "target_frac": 0.5,
+                             # the same step against the pipes it actually runs on: the GEMM FLOPs at the bf16x3 roof (416.7), the
+                             # rest (conv / AEV / agh, vector pipe) at 157.3: ideal time of both parts / measured time
+                             "frac_mixed": (flops_step / (PEAK_BF16X3_TFLOPS * 1e12) + (e2e_flops - flops_step) / (PEAK_FP32_MATRIX_TFLOPS * 1e12))
+                                           / (ms_per_step * 1e-3),
+                             "frac_mixed_note": "GEMM FLOPs / 416.7 TFLOP/s + the rest / 157.3 TFLOP/s, over ms_per_step"},
             # second kernel class (SURVEY 8d ii): the gather-contract backward.  Algorithmic gathered bytes per ordered pair:
             # reverse-pair form (default above 1 024 atoms): passes 1, 2 read Sbar_j (4 KiB) + Sqbar_j (256 B) and write F1 into
             # the pair buffer (16 B, read back once when the passes are summed); combined form (AIMNET_CONV_XE=0): a_j (1 KiB) more;

@@ -244,6 +244,11 @@ int aimnet_debug_gemm_bf3a(int cfg, int epi, int out3, const void* A3, int lda3,
  *   "gemm_bf3"      1 (default): MLP GEMMs of batches above 256 rows with bf16x3-split operands on the bf16 matrix pipe
  *                   (csrc/gemm_bf3.hip: fp32 == three bf16 planes exactly, six products, fp32 accumulation), 2: for every batch
  *                   size, 0: the exact-fp32 MFMA kernels of csrc/gemm.hip everywhere
+ *   "gemm_presplit" 1 (default): with the split GEMMs, systems above the split threshold keep every GEMM activation operand in the
+ *                   split "bf3" form in memory (written by its producer; csrc/gemm_bf3a.hip streams both operands by DMA), 0: fp32
+ *                   activations split inside the GEMM's main loop (csrc/gemm_bf3.hip)
+ *   "head_fused"    1 (default): with pre-split activations the energy head 256 -> 128 -> 128 -> 1 runs forward and backward in one
+ *                   launch (csrc/gemm_head.hip), 0: four GEMM launches + the last-layer rider
  *   "emb_bias"      1 (default): pass 0's first GEMM runs over the conv columns, the embedding block is a per-element bias table
  *   "conv_mfma"     bit 0: conv forward, bit 1: conv backward on the v_mfma_f32_4x4x1_16B_f32 kernels (csrc/conv_mfma.hip)
  *                   instead of the packed-FMA VALU kernels (default 0; systems above the split threshold only)
@@ -252,6 +257,8 @@ int aimnet_debug_gemm_bf3a(int cfg, int epi, int out3, const void* A3, int lda3,
  *   "overlap_coulomb" 1: Coulomb / DFT-D3 pair kernels on a second HIP stream (default 0: measured slower)
  *   "spatial_order" 0: conv kernels walk the atoms in input order instead of cell-list bin order */
 int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value);
+/* current value of a switch (what a measurement should record instead of guessing from the environment) */
+int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* value);
 
 /* Test hook: lane layout of v_mfma_f32_4x4x1_16B_f32 as the conv kernels assume it.  out: f32[64][4][64] (device),
  * out[lb][r][l] = VGPR r, lane l of D = A x B with A[l] = l + 1 and B = one-hot(lb), C = 0. */

@@ -359,7 +359,43 @@ def make_nse() -> None:
     np.savez_compressed(os.path.join(HERE, "nse.npz"), **res)
 
 
+def check_hf_layout() -> None:
+    """The local Hugging Face layout (config.json + ensemble_0.safetensors): the build's loader.load_hf_dir against the
+    reference's load_from_hf_repo (hf_hub.py:275-398) on an export of the synthetic artifact - same metadata, and the tensors the
+    reference module ends up with are the tensors the native loader hands to the engine.  No fixture: an assertion run."""
+    import json
+
+    from safetensors.torch import save_file
+
+    from aimnet.calculators.hf_hub import load_from_hf_repo
+    from aimnetcentral_amd import loader
+
+    art = synth.synthetic_artifact(SEED)
+    d = tempfile.mkdtemp()
+    cfg = {k: v for k, v in art.items() if k != "state_dict"}
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    save_file({k: v.contiguous() for k, v in art["state_dict"].items()}, os.path.join(d, "ensemble_0.safetensors"))
+    model, meta = load_from_hf_repo(d)
+    spec, meta2 = loader.load_hf_dir(d)
+    for k in ("cutoff", "needs_coulomb", "needs_dispersion", "coulomb_mode", "coulomb_sr_rc", "coulomb_sr_envelope", "has_embedded_lr",
+              "implemented_species"):
+        assert meta[k] == meta2[k], (k, meta[k], meta2[k])
+    ref_sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    n = 0
+    for k, v in spec.weights.items():
+        if k in ref_sd:
+            # (0-d parameters of the reference - aev.rc_s, aev.eta_s - are kept as 1-element arrays by the native loader)
+            assert ref_sd[k].dtype == v.dtype and np.array_equal(ref_sd[k].reshape(-1), v.reshape(-1), equal_nan=True), k
+            n += 1
+    assert n >= 30, n
+    print(f"hf layout: reference load_from_hf_repo and loader.load_hf_dir agree on {n} tensors and the metadata")
+
+
 def main() -> None:
+    if "--check-hf" in sys.argv:
+        check_hf_layout()
+        return
     if "--only-nse" in sys.argv:
         make_nse()
         return

@@ -155,3 +155,50 @@ def test_dftd3_reads_the_lr_matrix(calc):
     ext = npy(cd3(dict(data, nbmat=nb, nbmat_lr=nbl), forces=True))
     assert abs(ext["energy"][0] - own["energy"][0]) <= 2e-5 and np.abs(ext["forces"] - own["forces"]).max() <= 5e-5
     assert abs(own["energy"][0] - g["energy"][0]) > 1e-2  # the dispersion term is in both
+
+
+def test_duplicates_half_lr_lists_pad_masks_and_cartesian_shifts(calc):
+    """a duplicated (j, shift) entry, a half long-range matrix and Cartesian shifts are reported instead of silently giving
+    wrong forces / half a Coulomb energy; the reference's optional `nb_pad_mask` marks padding slots."""
+    from oracle import aimnet2_oracle as O
+
+    g = golden("taxol")
+    n = len(g["numbers"])
+    mol = np.zeros(n, dtype=np.int64)
+    nb, _ = O.neighbor_list(g["coord"], 5.0, mol)
+    nbl, _ = O.neighbor_list(g["coord"], float("inf"), mol)
+    data = {"coord": g["coord"], "numbers": g["numbers"], "charge": 0.0}
+    ref = npy(calc(dict(data, nbmat=nb, nbmat_lr=nbl), forces=True))
+    # a duplicated entry in row 0 (the last, padding, slot repeats the first neighbour): its mirror row holds atom 0 once only
+    dup = np.concatenate([nb, np.full((nb.shape[0], 1), n, dtype=nb.dtype)], axis=1)
+    dup[0, (nb[0] < n).sum()] = nb[0, 0]
+    with pytest.raises(ValueError, match="not a full symmetric"):
+        calc(dict(data, nbmat=dup, nbmat_lr=nbl), forces=True)
+    # a HALF long-range matrix (j > i only)
+    half = np.full_like(nbl, n)
+    for i in range(n):
+        js = nbl[i][(nbl[i] < n) & (nbl[i] > i)]
+        half[i, : len(js)] = js
+    with pytest.raises(ValueError, match="not a full symmetric"):
+        calc(dict(data, nbmat=nb, nbmat_lr=half), forces=True)
+    # padding expressed through nb_pad_mask instead of the sentinel: garbage indices under the mask are ignored
+    masked = nb.copy()
+    pm = nb >= n
+    masked[pm] = 0
+    out = npy(calc(dict(data, nbmat=masked, nb_pad_mask=pm, nbmat_lr=nbl), forces=True))
+    assert abs(out["energy"][0] - ref["energy"][0]) <= 1e-6 and np.abs(out["forces"] - ref["forces"]).max() <= 1e-6
+    # Cartesian shifts on a periodic cell are rejected (the reference's lists carry integer lattice multiples)
+    gp = golden("pbc96_dsf15")
+    nbp, shp, nblp, shlp = _periodic_lists(gp, gp["coord"], 15.0)
+    cart = shp.astype(np.float32) @ gp["cell"].astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        calc.set_lrcoulomb_method("dsf")
+    try:
+        with pytest.raises(ValueError, match="integer lattice multiples"):
+            calc({"coord": gp["coord"], "numbers": gp["numbers"], "charge": 0.0, "cell": gp["cell"], "nbmat": nbp, "shifts": cart,
+                  "nbmat_lr": nblp, "shifts_lr": shlp}, forces=True)
+    finally:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            calc.set_lrcoulomb_method("simple")

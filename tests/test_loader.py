@@ -143,3 +143,59 @@ def test_runtime_metadata_rules():
     md2 = dict(md, coulomb_mode="full_embedded")
     with pytest.raises(ValueError, match="full_embedded"):
         loader.validate_runtime_metadata(md2, needs_coulomb=True, needs_dispersion=False)
+
+
+# ---- the reference's Hugging Face layout on disk: config.json + ensemble_N.safetensors (hf_hub.py:275-398) --------------
+def _write_hf_dir(tmp_path, art, drop=(), extra=None, member=0):
+    import json
+
+    from safetensors.torch import save_file
+
+    d = tmp_path / "hf_model"
+    d.mkdir()
+    cfg = {k: v for k, v in art.items() if k != "state_dict" and k not in drop}
+    cfg.update(extra or {})
+    (d / "config.json").write_text(json.dumps(cfg))
+    save_file({k: v.contiguous() for k, v in art["state_dict"].items()}, str(d / f"ensemble_{member}.safetensors"))
+    return d
+
+
+def test_hf_directory_loads_like_the_pt_artifact(tmp_path, art):
+    d = _write_hf_dir(tmp_path, art)
+    spec, meta = loader.load_hf_dir(str(d))
+    ref = loader.spec_from_artifact(art)
+    assert spec.mlp_dims == ref.mlp_dims and spec.head_dims == ref.head_dims and spec.last_linear == ref.last_linear
+    assert spec.sr_envelope == ref.sr_envelope and spec.sr_rc == ref.sr_rc and meta == ref.metadata
+    assert set(spec.weights) == set(ref.weights)
+    for k in ref.weights:
+        assert spec.weights[k].dtype == ref.weights[k].dtype and np.array_equal(spec.weights[k], ref.weights[k], equal_nan=True), k
+    spec2, _ = loader.load_model(str(d))  # a directory routes through load_model as well
+    assert np.array_equal(spec2.weights["afv.weight"], ref.weights["afv.weight"], equal_nan=True)
+
+
+def test_hf_directory_fills_sr_coulomb_fields_from_the_yaml(tmp_path, art):
+    d = _write_hf_dir(tmp_path, art, drop=("coulomb_sr_rc", "coulomb_sr_envelope"))
+    spec, meta = loader.load_hf_dir(str(d))
+    assert meta["coulomb_sr_rc"] == 4.6 and meta["coulomb_sr_envelope"] == "exp" and spec.sr_coulomb
+
+
+@pytest.mark.parametrize("extra,member,exc,msg", [
+    ({"coulomb_sr_rc": 4.0}, 0, ValueError, "conflicts with the SRCoulomb value"),
+    ({"coulomb_sr_envelope": "cosine"}, 0, ValueError, "conflicts with the SRCoulomb value"),
+    ({"member_names": ["a"]}, 1, ValueError, "out of range"),
+    ({"member_names": []}, 0, ValueError, "nonempty list of strings"),
+    ({"format_version": 1}, 0, ValueError, "must be integer 2"),
+    ({"model_yaml": None}, 0, NotImplementedError, "registry"),
+    ({}, 3, FileNotFoundError, "ensemble_3.safetensors"),
+])
+def test_hf_directory_rejections(tmp_path, art, extra, member, exc, msg):
+    d = _write_hf_dir(tmp_path, art, extra=extra)
+    with pytest.raises(exc, match=msg):
+        loader.load_hf_dir(str(d), member)
+
+
+def test_hf_repo_ids_need_network(tmp_path):
+    with pytest.raises(NotImplementedError, match="network"):
+        loader.load_hf_dir("isayevlab/aimnet2-wb97m-d3")
+    with pytest.raises(FileNotFoundError, match="config.json"):
+        loader.load_hf_dir(str(tmp_path))

@@ -30,7 +30,7 @@ import csv, glob, collections, json, os
 tot = collections.defaultdict(float); n = collections.defaultdict(int)
 for f in sorted(glob.glob("gpurun_out/$out/*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "gemm_nt" not in r["Kernel_Name"] and "gemm_bf3" not in r["Kernel_Name"]: continue
+        if not any(k in r["Kernel_Name"] for k in ("gemm_nt", "gemm_bf3", "head_fused")): continue
         tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 launches = max(1, n["TCC_EA0_RDREQ_sum"])
 rd, wr = tot["TCC_EA0_RDREQ_sum"] * 128 / launches, tot["TCC_EA0_WRREQ_sum"] * 64 / launches

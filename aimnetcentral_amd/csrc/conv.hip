@@ -416,10 +416,7 @@ int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, co
                     float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order, bool species_moments,
                     int split_max, bool x_bf3) {
   const bool split = n_atoms <= split_max;
-  if (x_bf3 && split) {
-    set_last_error("conv_fwd: pre-split rows exist in the one-wave-per-atom form only");
-    return -1;
-  }
+
   // (one-wave-per-atom form: exactly the 4 blocks per CU that are resident - with twice as many the second half only queues
   // behind the first and pays the block prologue again: 0.217 -> 0.207 ms/step over the three launches)
   const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), device_cus() * AIMNET_PROBE_FWD_OCC);
@@ -434,10 +431,12 @@ int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, co
     return 0;
   }
   if (x_bf3) {
-#define AIMNET_FWD3(HQ)                                                                                                          \
-  hipLaunchKernelGGL((conv_fwd_kernel<HQ, false, false, true>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, \
+#define AIMNET_FWD3(HQ, SP)                                                                                                       \
+  hipLaunchKernelGGL((conv_fwd_kernel<HQ, SP, false, true>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, \
                      agh_a, agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order)
-    if (nq == 2) AIMNET_FWD3(2); else if (nq == 1) AIMNET_FWD3(1); else AIMNET_FWD3(0);
+    if (nq == 2) { if (split) AIMNET_FWD3(2, true); else AIMNET_FWD3(2, false); }
+    else if (nq == 1) { if (split) AIMNET_FWD3(1, true); else AIMNET_FWD3(1, false); }
+    else { if (split) AIMNET_FWD3(0, true); else AIMNET_FWD3(0, false); }
 #undef AIMNET_FWD3
     AIMNET_LAUNCH_CHECK();
     return 0;

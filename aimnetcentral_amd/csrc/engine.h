@@ -22,6 +22,8 @@ struct Layer {
   unsigned short* w3 = nullptr;  // the same two operands split into three bf16 planes ("bf3" layout of gemm_bf3.hip:
   unsigned short* wt3 = nullptr; // 3 * k_in resp. 3 * k_out bf16 elements per row) for the bf16x3-split MFMA GEMM
   int neg_w3 = 0, neg_wt3 = 0;   // k-block (of 32) from which w3 / wt3 are stored negated (sign-flipped accumulation phase)
+  unsigned short* w3a = nullptr;   // the same two operands with every ODD k-block negated (BF3_ALT): gemm_bf3a.hip / gemm_head.hip,
+  unsigned short* wt3a = nullptr;  // which accumulate even / odd k-steps separately and subtract (no data-dependent split point)
 };
 
 struct View {
@@ -53,8 +55,8 @@ struct aimnet_engine {
   // 256 rows, the exact-fp32 skinny kernel below; 2 = bf3 for every batch size (parity runs on small fixtures); 0 = the exact-fp32
   // MFMA kernels of gemm.hip everywhere.  set_option("gemm_bf3", v) / AIMNET_GEMM_BF3.
   int gemm_bf3 = 1;
-  // AIMNET_GEMM_PRESPLIT / set_option("gemm_presplit"): with the bf16x3-split GEMMs, systems above the split threshold keep every
-  // GEMM activation operand (MLP input rows, hidden activations, backward adjoints) in the split "bf3" form in memory: the producer
+  // AIMNET_GEMM_PRESPLIT / set_option("gemm_presplit"): with the bf16x3-split GEMMs (batches above 256 rows; every batch in mode 2) every
+  // GEMM activation operand (MLP input rows, hidden activations, backward adjoints) stays in the split "bf3" form in memory: the producer
   // splits once (conv_fwd's row assembly, the GELU / chain-rule epilogues) and gemm_bf3a.hip streams both operands by DMA with no
   // vector work in its main loop.  0 = fp32 activations, split inside gemm_bf3.hip's loop (round 3; also what the tangent sweep of
   // hvp.hip, small batches and AIMNET_KEEP_INTERMEDIATES use).

@@ -93,6 +93,11 @@ int upload_layer(aimnet_engine* e, const float* w, const float* b, int n_in, int
     if ((rc = dev_upload(e, s3.data(), s3.size(), &L->w3))) return rc;
     split_bf3_host(wtp.data(), L->k_in, L->k_out, s3.data(), L->neg_wt3);
     if ((rc = dev_upload(e, s3.data(), s3.size(), &L->wt3))) return rc;
+    // the operand form of gemm_bf3a.hip / gemm_head.hip: odd k-blocks negated, two interleaved accumulator sets (no fitted constant)
+    split_bf3_host(wp.data(), L->k_out, L->k_in, s3.data(), BF3_ALT);
+    if ((rc = dev_upload(e, s3.data(), s3.size(), &L->w3a))) return rc;
+    split_bf3_host(wtp.data(), L->k_in, L->k_out, s3.data(), BF3_ALT);
+    if ((rc = dev_upload(e, s3.data(), s3.size(), &L->wt3a))) return rc;
   }
   return 0;
 }
@@ -119,10 +124,9 @@ int mlp_gemm3(const aimnet_engine* e, hipStream_t s, int epi, bool out3, const u
               int k0, int n0, int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
               const int* brow, int ldbias) {
   const int ldw = fwd ? L.k_in : L.k_out;
-  const unsigned short* w3 = (fwd ? L.w3 : L.wt3) + (size_t)n0 * 3 * ldw + (size_t)(k0 / 32) * 96;
-  const int kneg = std::max(0, (fwd ? L.neg_w3 : L.neg_wt3) - k0 / 32);
+  const unsigned short* w3 = (fwd ? L.w3a : L.wt3a) + (size_t)n0 * 3 * ldw + (size_t)(k0 / 32) * 96;
   return launch_gemm_bf3a_cfg(s, 0, epi, out3, A3 + (size_t)(k0 / 32) * 96, lda3, w3, 3 * ldw, M, N, K, bias, C, C3, ldc3, D, ldc, brow,
-                              ldbias, kneg);
+                              ldbias, ((k0 / 32) & 1) ? 2 : 1);
 }
 // the one-launch energy head of gemm_head.hip covers the shipped architecture (256 -> 128 -> 128 -> 1)
 bool head_fusable(const aimnet_engine* e) {
@@ -132,7 +136,8 @@ bool head_fusable(const aimnet_engine* e) {
 }
 // activations in split form for this batch? (layout() and eval() must agree)
 bool presplit_active(const aimnet_engine* e, int N) {
-  return e->gemm_presplit != 0 && e->gemm_bf3 != 0 && N > std::max(256, e->split_max) && !e->keep_intermediates && !(e->conv_mfma & 1);
+  const bool bf3 = e->gemm_bf3 == 2 || (e->gemm_bf3 == 1 && N > 256);  // the batches that take the split GEMMs at all (mlp_gemm)
+  return e->gemm_presplit != 0 && bf3 && !e->keep_intermediates && !(e->conv_mfma & 1);
 }
 }  // namespace aimnet
 
@@ -935,9 +940,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       HeadFusedArgs ha{};
       ha.aim3 = reinterpret_cast<const unsigned short*>(hin);
       ha.lda3 = 3 * ld_in;
-      ha.w1 = e->head[0].w3; ha.w2 = e->head[1].w3; ha.w2t = e->head[1].wt3; ha.w1t = e->head[0].wt3;
+      ha.w1 = e->head[0].w3a; ha.w2 = e->head[1].w3a; ha.w2t = e->head[1].wt3a; ha.w1t = e->head[0].wt3a;
       ha.b1 = e->head[0].b; ha.b2 = e->head[1].b; ha.w3 = e->head_w_last; ha.b3 = e->head_b_last;
-      ha.kneg1 = e->head[0].neg_w3; ha.kneg2 = e->head[1].neg_w3; ha.kneg3 = e->head[1].neg_wt3; ha.kneg4 = e->head[0].neg_wt3;
       ha.dlast = grad ? W.D[np - 1][nlp - 1] : nullptr;
       ha.ldd = ld_in;
       ha.e_atom = W.e_atom;
@@ -1164,7 +1168,8 @@ int aimnet_debug_gemm(int cfg, int epi, const float* A, int lda, const float* Bt
 }
 
 int aimnet_debug_split_bf3(const float* src, int ld, int M, int K, void* dst, int ldd, int neg_from_block, void* hip_stream) {
-  if (!src || !dst || M <= 0 || K <= 0 || ldd < 3 * pad32(K) || ldd % 96 || neg_from_block < 0) return AIMNET_E_INVALID;
+  if (!src || !dst || M <= 0 || K <= 0 || ldd < 3 * pad32(K) || ldd % 96 || (neg_from_block < 0 && neg_from_block != aimnet::BF3_ALT))
+    return AIMNET_E_INVALID;
   return launch_split_bf3((hipStream_t)hip_stream, src, ld, M, K, (unsigned short*)dst, ldd, neg_from_block);
 }
 
@@ -1181,8 +1186,9 @@ int aimnet_debug_gemm_bf3(int cfg, int epi, const float* A, int lda, const void*
 }
 
 int aimnet_debug_gemm_bf3a(int cfg, int epi, int out3, const void* A3, int lda3, const void* Bt3, int ldb, int M, int N, int K,
-                           const float* bias, float* C, void* C3, int ldc3, float* D, int ldc, int kneg, void* hip_stream) {
+                           const float* bias, float* C, void* C3, int ldc3, float* D, int ldc, int alt, void* hip_stream) {
   using namespace aimnet;
+  if (alt < 0 || alt > 2) return AIMNET_E_INVALID;
   static bool once = false;
   if (!once) {
     int rc = gemm_bf3a_set_attributes();
@@ -1190,8 +1196,7 @@ int aimnet_debug_gemm_bf3a(int cfg, int epi, int out3, const void* A3, int lda3,
     once = true;
   }
   return launch_gemm_bf3a_cfg((hipStream_t)hip_stream, cfg, epi, out3 != 0, (const unsigned short*)A3, lda3, (const unsigned short*)Bt3,
-                              ldb, M, N, K, bias, C, (unsigned short*)C3, ldc3, D, ldc, nullptr, 0,
-                              (kneg < 0 || kneg >= K / 32) ? BF3_NO_NEG : kneg);
+                              ldb, M, N, K, bias, C, (unsigned short*)C3, ldc3, D, ldc, nullptr, 0, alt);
 }
 #ifdef AIMNET_BF3_TIMING
 int aimnet_debug_bf3a_stamps(unsigned long long* host1024) { return aimnet::gemm_bf3a_read_stamps(host1024); }

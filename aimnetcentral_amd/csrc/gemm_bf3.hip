@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void split_bf3_kernel(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = col + r < K ? s[r] : 0.0f;
     }
-    if (col >= neg_from) v = -v;
+    if (neg_from == -2 ? ((col >> 5) & 1) != 0 : col >= neg_from) v = -v;  // -2: every odd k-block (BF3_ALT)
     store_bf3_x4(dst + (size_t)m * ldd, col, v);
   }
 }
@@ -64,7 +64,7 @@ int launch_split_bf3(hipStream_t s, const float* src, int ld, int M, int K, unsi
   const int Kp = (K + 31) / 32 * 32;
   const size_t n = (size_t)M * (Kp >> 2);
   const int blocks = (int)std::min<size_t>((n + 255) / 256, 8192);
-  const int neg_from = neg_from_block >= (1 << 24) ? (1 << 30) : neg_from_block * 32;
+  const int neg_from = neg_from_block == BF3_ALT ? -2 : neg_from_block >= (1 << 24) ? (1 << 30) : neg_from_block * 32;
   hipLaunchKernelGGL(split_bf3_kernel, dim3(blocks), dim3(256), 0, s, src, ld, M, K, Kp, dst, ldd, neg_from);
   AIMNET_LAUNCH_CHECK();
   return 0;
@@ -84,7 +84,8 @@ static inline unsigned short bf16_rne_host(float x, float* back) {
 void split_bf3_host(const float* w, int rows, int K, unsigned short* out, int neg_from_block) {
   for (int r = 0; r < rows; ++r)
     for (int k = 0; k < K; ++k) {
-      const float x = (k >> 5) >= neg_from_block ? -w[(size_t)r * K + k] : w[(size_t)r * K + k];
+      const bool neg = neg_from_block == BF3_ALT ? ((k >> 5) & 1) != 0 : (k >> 5) >= neg_from_block;
+      const float x = neg ? -w[(size_t)r * K + k] : w[(size_t)r * K + k];
       float f0, f1, f2;
       const unsigned short h0 = bf16_rne_host(x, &f0);
       const float r1 = x - f0;

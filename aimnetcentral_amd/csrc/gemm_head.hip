@@ -5,7 +5,7 @@
 //                                                              nothing that is not in this block - autograd's replay of the head)
 // The four GEMMs of the head (two forward, two backward) have N = 128: one column tile, a quarter of the chip per launch, 9 - 13 us
 // each for 2 % of the step's arithmetic.  Here a block owns 64 atoms and chains them on the bf16x3-split matrix path of
-// gemm_bf3.hip (same operand split, same six products per tile, same sign-flipped second accumulation phase):
+// gemm_bf3a.hip (same operand split, same six products per tile, same two interleaved accumulator sets):
 //   1  Z1 = aim W1^T   (K = 256; aim arrives pre-split from the last MLP layer's epilogue, streamed through an LDS ring)
 //      H1 = GELU(Z1 + b1) -> LDS in split form, D1 = GELU' stays in registers
 //   2  Z2 = H1 W2^T    (K = 128, A operand resident in LDS); H2, D2; e_i = H2 . w3 + b3 (lane, wave, block reduction)
@@ -93,18 +93,22 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadFusedArgs a) {
   const unsigned adA = lds0 + rA * ROWB + ((lc ^ swz192(rA)) << 4);
   const unsigned adB = ldsB + rB * ROWB + ((lc ^ swz192(rB)) << 4);
 
-  f32x4 acc[2][2];
+  f32x4 acc[2][2][2];  // [parity of the k-step][i][j]: two interleaved accumulator sets, subtracted in the epilogues (gemm_bf3a.hip)
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
+  auto total = [&](int i, int j) __attribute__((always_inline)) -> f32x4 { return acc[0][i][j] - acc[1][i][j]; };
   zero_acc();
   bf16x8 fa[2][3], fb[2][3];
   // one 32-k step: tile t of the stream against the activation tile at LDS address a_lds; NW = stream operations that may stay
   // outstanding at its wait (the younger tile t + 1; the memory counter retires loads in order)
-  auto step = [&](int t, unsigned a_lds, bool flip, auto nw_c) __attribute__((always_inline)) {
+  auto step = [&](int t, unsigned a_lds, auto par_c, auto nw_c) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_c)::value;  // parity of the k-step inside its GEMM: the accumulator set
     wait_vm<decltype(nw_c)::value>();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -118,15 +122,9 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadFusedArgs a) {
     read_strips<0, 2, 2>(fa, a_lds);
     wait_lgkm<0>();
     __builtin_amdgcn_sched_barrier(0);
-    if (flip) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = -acc[i][j];
-    }
-#define AIMNET_HEAD_PRODUCT(PA, PB)                                                                        \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = \
-      __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][PB], fa[i][PA], acc[i][j], 0, 0, 0);
+#define AIMNET_HEAD_PRODUCT(PA, PB)                                                                             \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[PAR][i][j] = \
+      __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][PB], fa[i][PA], acc[PAR][i][j], 0, 0, 0);
     AIMNET_HEAD_PRODUCT(1, 1)
     // the DMA of tile t + 2 is issued among the matrix instructions (in front of the fragment reads it cost 100 - 185 cycles per
     // piece on the critical path); its ring stage was last read in step t - 1, which every wave left before this step's barrier
@@ -141,6 +139,10 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadFusedArgs a) {
 #undef AIMNET_HEAD_PRODUCT
     __builtin_amdgcn_sched_barrier(0);
   };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+#define AIMNET_HEAD_STEP(T, A_LDS, NW) \
+  if ((T) & 1) step(T, A_LDS, P1{}, NW{}); else step(T, A_LDS, P0{}, NW{})  // (all four GEMMs start on an even tile of the stream)
   using W0 = std::integral_constant<int, 0>;
   using W3 = std::integral_constant<int, 3>;
   using W5 = std::integral_constant<int, 5>;
@@ -172,12 +174,11 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadFusedArgs a) {
   // ---- 1: Z1 = aim W1^T ------------------------------------------------------------------------------------------------
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    if (t < 7) step(t, adA + (t % 3) * HA_ST, t == a.kneg1 && t > 0, W5{});
-    else step(t, adA + (t % 3) * HA_ST, t == a.kneg1 && t > 0, W3{});
+    if (t < 7) { AIMNET_HEAD_STEP(t, adA + (t % 3) * HA_ST, W5); }
+    else { AIMNET_HEAD_STEP(t, adA + (t % 3) * HA_ST, W3); }
   }
   f32x4 D1[2][2], v[2][2];
   {
-    const float sf = a.kneg1 < 8 ? -1.0f : 1.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadFusedArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float h, d;
-          gelu_and_grad(acc[i][j][r] * sf + b1v[j][r], h, d);
+          gelu_and_grad(total(i, j)[r] + b1v[j][r], h, d);
           v[i][j][r] = h;
           D1[i][j][r] = d;
         }
@@ -196,12 +197,11 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadFusedArgs a) {
   // ---- 2: Z2 = H1 W2^T, e = H2 . w3 + b3 -------------------------------------------------------------------------------
 #pragma unroll
   for (int t = 8; t < 12; ++t) {
-    if (t < 11) step(t, adA + (t - 8) * HM_KB, t - 8 == a.kneg2 && t > 8, W3{});
-    else if (a.grad) step(t, adA + (t - 8) * HM_KB, t - 8 == a.kneg2, W3{});
-    else step(t, adA + (t - 8) * HM_KB, t - 8 == a.kneg2, W0{});
+    if (t < 11) { AIMNET_HEAD_STEP(t, adA + (t - 8) * HM_KB, W3); }
+    else if (a.grad) { AIMNET_HEAD_STEP(t, adA + (t - 8) * HM_KB, W3); }
+    else { AIMNET_HEAD_STEP(t, adA + (t - 8) * HM_KB, W0); }
   }
   {
-    const float sf = a.kneg2 < 4 ? -1.0f : 1.0f;
     float pe[2] = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadFusedArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float h, d;
-          gelu_and_grad(acc[i][j][r] * sf + b2v[j][r], h, d);
+          gelu_and_grad(total(i, j)[r] + b2v[j][r], h, d);
           pe[i] += h * w3v[j][r];
           v[i][j][r] = w3v[j][r] * d;  // adjoint seed of z2: dE/de = 1
         }
@@ -228,13 +228,12 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadFusedArgs a) {
   zero_acc();
   // ---- 3: T = (w3 * D2) W2 ------------------------------------------------------------------------------------------
 #pragma unroll
-  for (int t = 12; t < 16; ++t) step(t, adA + (t - 12) * HM_KB, t - 12 == a.kneg3 && t > 12, W3{});
+  for (int t = 12; t < 16; ++t) { AIMNET_HEAD_STEP(t, adA + (t - 12) * HM_KB, W3); }
   {
-    const float sf = a.kneg3 < 4 ? -1.0f : 1.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) v[i][j] = acc[i][j] * sf * D1[i][j];
+      for (int j = 0; j < 2; ++j) v[i][j] = total(i, j) * D1[i][j];
   }
   seam();
   to_lds(v);
@@ -245,10 +244,9 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadFusedArgs a) {
 #pragma unroll
     for (int t = 16 + 4 * half; t < 20 + 4 * half; ++t) {
       const int kb = t - 16 - 4 * half;
-      if (t < 23) step(t, adA + kb * HM_KB, kb == a.kneg4 && kb > 0, W3{});
-      else step(t, adA + kb * HM_KB, kb == a.kneg4 && kb > 0, W0{});
+      if (t < 23) { AIMNET_HEAD_STEP(t, adA + kb * HM_KB, W3); }
+      else { AIMNET_HEAD_STEP(t, adA + kb * HM_KB, W0); }
     }
-    const float sf = a.kneg4 < 4 ? -1.0f : 1.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = m0 + wm * 32 + 16 * i + l16;
@@ -256,7 +254,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadFusedArgs a) {
       const int col0 = half * 128 + wn * 32;
       const f32x4 d0 = *reinterpret_cast<const f32x4*>(a.dlast + (size_t)row * a.ldd + col0 + 4 * lc);
       const f32x4 d1 = *reinterpret_cast<const f32x4*>(a.dlast + (size_t)row * a.ldd + col0 + 16 + 4 * lc);
-      store_bf3_tile_pair(a.zbar3 + (size_t)row * a.ldz3, col0, lc, acc[i][0] * sf * d0, acc[i][1] * sf * d1);
+      store_bf3_tile_pair(a.zbar3 + (size_t)row * a.ldz3, col0, lc, total(i, 0) * d0, total(i, 1) * d1);
     }
     zero_acc();
   }

@@ -27,6 +27,10 @@ int gemm_set_attributes();
 // neg_from_block: k-blocks (of 32) from this index on are stored negated - the second, sign-flipped phase of the accumulation
 // (gemm_bf3.hip, "Accumulation bias"); kneg of the launcher = the number of leading k-steps of THIS launch that are not negated
 constexpr int BF3_NO_NEG = 1 << 30;
+// neg_from_block = BF3_ALT: every ODD k-block is stored negated - the operand form of gemm_bf3a.hip / gemm_head.hip, which keep two
+// accumulator sets (even / odd k-steps) and subtract them in the epilogue: the one-signed truncation of the bf16 MFMA accumulation
+// hits two interleaved half-sums of identical statistics and cancels without a tunable split point (gemm_bf3a.hip, "Accumulation")
+constexpr int BF3_ALT = -2;
 void split_bf3_host(const float* w, int rows, int K, unsigned short* out, int neg_from_block);                 // host form (weights)
 int launch_split_bf3(hipStream_t s, const float* src, int ld, int M, int K, unsigned short* dst, int ldd,
                      int neg_from_block = BF3_NO_NEG);  // device form (tests)
@@ -40,16 +44,18 @@ int gemm_bf3_set_attributes();
 // C in bf3 form (C3, ldc3 >= 3 * pad32(N)) for the next layer instead of fp32 (C, ldc); D is fp32 [M][ldc] either way.
 int launch_gemm_bf3a_cfg(hipStream_t stream, int cfg, int epi, bool out3, const unsigned short* A3, int lda3, const unsigned short* Bt,
                          int ldb, int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
-                         const int* brow = nullptr, int ldbias = 0, int kneg = BF3_NO_NEG);
+                         const int* brow = nullptr, int ldbias = 0, int alt = 0);
+// alt: 0 = weights stored with their own sign (result = sum of the two accumulator sets), 1 = BF3_ALT weights and the launch starts
+// on an even k-block (result = even - odd), 2 = BF3_ALT weights, odd first k-block (result = odd - even)
 int gemm_bf3a_set_attributes();
 
 // ---- gemm_head.hip: the energy head 256 -> 128 -> 128 -> 1 forward and backward in one launch (operands of gemm_bf3a.hip)
 struct HeadFusedArgs {
   const unsigned short* aim3;  // [M][lda3] head input in bf3 form (written by the last MLP layer's epilogue)
   int lda3;
-  const unsigned short *w1, *w2, *w2t, *w1t;  // bf3 weights: W1 [128][3*256], W2 [128][3*128], W2^T [128][3*128], W1^T [256][3*128]
+  const unsigned short *w1, *w2, *w2t, *w1t;  // bf3 weights (BF3_ALT): W1 [128][3*256], W2 [128][3*128], W2^T [128][3*128], W1^T [256][3*128]
   const float *b1, *b2, *w3, *b3;             // biases [128], last layer [128] and its bias [1]
-  int kneg1, kneg2, kneg3, kneg4;             // first negated k-block of the four weight operands (BF3_NO_NEG: none)
+  // (the four weight operands are in the BF3_ALT form: odd k-blocks negated)
   const float* dlast;                         // GELU' of the layer that produced the head input, fp32 [M][ldd] (grad only)
   int ldd;
   float* e_atom;                              // [M]

@@ -235,16 +235,20 @@ int aimnet_debug_gemm_bf3(int cfg, int epi, const float* A, int lda, const void*
                           const float* bias, float* C, float* D, int ldc, int kneg, void* hip_stream);
 /* aimnet_debug_gemm_bf3a (csrc/gemm_bf3a.hip): the same product with the activations pre-split too - A3 = bf3 form of A [M][K]
  * (lda3 bf16 elements per row); out3 != 0: C is written in bf3 form into C3 (ldc3 bf16 elements per row; epilogues 2 and 3
- * only), else as fp32 into C; D (epilogue 2 output / epilogue 3 input) is fp32 [M][ldc]. */
+ * only), else as fp32 into C; D (epilogue 2 output / epilogue 3 input) is fp32 [M][ldc].  This kernel accumulates even and odd
+ * k-steps in two accumulator sets: alt = 0: Bt3 carries its own signs (result = sum of the sets); alt = 1: Bt3 was split with
+ * neg_from_block = -2 (every odd k-block negated; aimnet_debug_split_bf3 accepts -2) and the result is even - odd - the form the
+ * engine uses, in which the truncation bias of the bf16 MFMA accumulation cancels without a tunable; alt = 2: the same for an
+ * operand that starts on an odd k-block. */
 int aimnet_debug_gemm_bf3a(int cfg, int epi, int out3, const void* A3, int lda3, const void* Bt3, int ldb, int M, int N, int K,
-                           const float* bias, float* C, void* C3, int ldc3, float* D, int ldc, int kneg, void* hip_stream);
+                           const float* bias, float* C, void* C3, int ldc3, float* D, int ldc, int alt, void* hip_stream);
 
 /* Engine switches for A/B and parity runs (all have an AIMNET_* environment twin read at create time):
  *   "conv_xe"       1 (default): reverse-pair form of the conv backward for systems above the split threshold, 0: combined form
  *   "gemm_bf3"      1 (default): MLP GEMMs of batches above 256 rows with bf16x3-split operands on the bf16 matrix pipe
  *                   (csrc/gemm_bf3.hip: fp32 == three bf16 planes exactly, six products, fp32 accumulation), 2: for every batch
  *                   size, 0: the exact-fp32 MFMA kernels of csrc/gemm.hip everywhere
- *   "gemm_presplit" 1 (default): with the split GEMMs, systems above the split threshold keep every GEMM activation operand in the
+ *   "gemm_presplit" 1 (default): wherever the split GEMMs run, every GEMM activation operand is kept in the
  *                   split "bf3" form in memory (written by its producer; csrc/gemm_bf3a.hip streams both operands by DMA), 0: fp32
  *                   activations split inside the GEMM's main loop (csrc/gemm_bf3.hip)
  *   "head_fused"    1 (default): with pre-split activations the energy head 256 -> 128 -> 128 -> 1 runs forward and backward in one

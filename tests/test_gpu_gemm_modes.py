@@ -2,7 +2,8 @@
 
 Default (1): MLP GEMMs of batches above 256 rows run with bf16x3-split operands on the bf16 matrix pipe, smaller ones on the
 exact-fp32 skinny kernel - so the small golden fixtures never see the split kernels in the other test modules.  Here every parity
-check runs with mode 2 (split kernels for EVERY batch size) and mode 0 (exact-fp32 MFMA kernels everywhere, the fallback the
+check runs with mode 2 (split kernels for EVERY batch size; with pre-split activations = gemm_bf3a.hip + gemm_head.hip, and with
+the in-loop split of gemm_bf3.hip) and mode 0 (exact-fp32 MFMA kernels everywhere, the fallback the
 bench reports as `exact_f32`), at the same, unchanged gates: goldens of the unmodified reference, the un-widened 1e-5 eV gate on
 the cold fixture, the 32-seed randomised sweep, both charge-channel families."""
 from __future__ import annotations
@@ -18,13 +19,18 @@ from oracle import aimnet2_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[2, 0], ids=["bf3_every_size", "exact_f32"])
+@pytest.fixture(params=[(2, 1), (2, 0), (0, 1)], ids=["bf3_every_size", "bf3_split_in_loop", "exact_f32"])
 def gemm_mode(request, hip_engine, hip_engine_nse):
+    """(gemm_bf3, gemm_presplit): split kernels for every batch size with pre-split activations (gemm_bf3a.hip + the fused head:
+    what large systems run by default), the same with fp32 activations split inside the GEMM loop (gemm_bf3.hip, the tangent
+    sweep's kernels), and the exact-fp32 kernels."""
     for e in (hip_engine, hip_engine_nse):
-        e.set_option("gemm_bf3", request.param)
+        e.set_option("gemm_bf3", request.param[0])
+        e.set_option("gemm_presplit", request.param[1])
     yield request.param
     for e in (hip_engine, hip_engine_nse):
         e.set_option("gemm_bf3", 1)
+        e.set_option("gemm_presplit", 1)
 
 
 def test_taxol(gemm_mode, hip_engine, oracle32):

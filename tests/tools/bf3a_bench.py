@@ -66,6 +66,7 @@ for (N, K) in shapes:
     ref = {0: z, 1: z + bias.double(), 2: torch.nn.functional.gelu(z + bias.double()), 3: z * Dm.double()}[EPI]
     KNEG = (2 * (K // 32) + 1) // 3
     B3 = split(Bt, KNEG)
+    B3a = split(Bt, -2)  # every odd k-block negated: the operand form of gemm_bf3a.hip
     A3 = split(A)
     Cold, Dold = torch.empty(M, N, device=dev), Dm.clone()
 
@@ -84,8 +85,8 @@ for (N, K) in shapes:
         Dn = Dm.clone()
 
         def run():
-            rc = lib.aimnet_debug_gemm_bf3a(cfg, EPI, OUT3, A3.data_ptr(), 3 * pad32(K), B3.data_ptr(), 3 * K, M, N, K, bias.data_ptr(),
-                                            Cn.data_ptr(), C3.data_ptr(), 3 * pad32(N), Dn.data_ptr(), N, KNEG, stream)
+            rc = lib.aimnet_debug_gemm_bf3a(cfg, EPI, OUT3, A3.data_ptr(), 3 * pad32(K), B3a.data_ptr(), 3 * K, M, N, K, bias.data_ptr(),
+                                            Cn.data_ptr(), C3.data_ptr(), 3 * pad32(N), Dn.data_ptr(), N, 1, stream)
             assert rc == 0, _lib.last_error()
 
         us = timeit(run)

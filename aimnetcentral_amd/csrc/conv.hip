@@ -78,7 +78,13 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
   constexpr int UNR_T = SPLIT ? 3 : 1, UNR_G = SPLIT ? 16 : 4;  // unroll factors of the agh contraction in the epilogue
   __shared__ float s_aghq[NQC * G_ * H_];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int k = threadIdx.x; k < A_ * G_ * H_; k += 256) s_agh[k] = agh_a[k];
+  // agh table transposed to [g][a * H + h]: the epilogue's lanes walk (a, h) at fixed g, so consecutive lanes read consecutive
+  // words (in the [a][g][h] order of the weights a lane's address stride was 16 words per h-block: 3-6-way bank conflicts on 48 reads
+  // per atom)
+  for (int k = threadIdx.x; k < A_ * G_ * H_; k += 256) {
+    const int aa = k / (G_ * H_), g = (k / H_) % G_, hh = k % H_;
+    s_agh[g * (A_ * H_) + aa * H_ + hh] = agh_a[k];
+  }
   if (HAS_Q)
     for (int k = threadIdx.x; k < NQ * G_ * H_; k += 256) s_aghq[k] = agh_q[k];
   __syncthreads();
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
 #pragma unroll UNR_G
         for (int g = 0; g < G_; ++g) {
 #endif
-          const float w = s_agh[(aa * G_ + g) * H_ + hh];
+          const float w = s_agh[g * (A_ * H_) + o];  // o = aa * H + hh
           const float* s3 = &sv[(aa * G_ + g) * 3];
           v0 += w * s3[0];
           v1 += w * s3[1];
@@ -462,46 +468,79 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
                                                       float* __restrict__ Sbar, float* __restrict__ Sqbar, int n_atoms) {
   constexpr bool HAS_Q = NQ > 0;
   constexpr int NQC = NQ > 0 ? NQ : 1;
-  __shared__ float s_agh[A_ * G_ * H_];
   __shared__ float s_aghq[NQC * G_ * H_];
   __shared__ float s_vb[APB][NV * 3 + NQC * H_ * 3];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int k = threadIdx.x; k < A_ * G_ * H_; k += 256) s_agh[k] = agh_a[k];
   if (HAS_Q)
     for (int k = threadIdx.x; k < NQ * G_ * H_; k += 256) s_aghq[k] = agh_q[k];
   float* vb = s_vb[wid];
   const AtomLoop al = atom_loop(n_atoms, APB);
-  for (int i0 = al.first; i0 < al.last; i0 += al.step) {
-    const int i = i0 + wid;
-    const bool live = i < al.last;
-    __syncthreads();
-    if (live) {
-      const float* xr = xbar + (size_t)i * ldx;
+  // the lane's 4 x 12 agh weights (a = lane >> 2, g = 4 (lane & 3) + gi) are the same for every atom: registers.  (Read from the
+  // LDS table, address stride 48 floats across the lanes, they were a 32-way bank conflict: 48 such reads per atom.)
+  float wreg[4][H_];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int o = lane + 64 * t;
-        const float f = 2.0f * xr[2 * NF + o];
-        const float* vs = Vsave + (size_t)i * (NV * 3) + o;  // planes [k][NV], see conv_fwd_kernel
-        vb[o * 3 + 0] = f * vs[0];
-        vb[o * 3 + 1] = f * vs[NV];
-        vb[o * 3 + 2] = f * vs[2 * NV];
-      }
-      if (HAS_Q && lane < H_) {
+  for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
-        for (int ch = 0; ch < NQ; ++ch) {
-          const float f = 2.0f * xr[2 * NF + NV + NQ + NQ * G_ + ch * H_ + lane];
+    for (int h = 0; h < H_; ++h) wreg[gi][h] = agh_a[((lane >> 2) * G_ + (lane & 3) * 4 + gi) * H_ + h];
+  __syncthreads();  // the agh_q table (the only LDS the waves share; everything below is per wave)
+  // A wave's atoms are independent and its LDS scratch is its own: wave-level hand-offs, and the NEXT atom's operands (2.9 KiB per
+  // atom: the vector part of xbar, the saved V) are requested before the contraction of the current one - the kernel was
+  // latency-bound at 2.5 TB/s of HBM traffic with every wave of a block waiting at two block barriers per atom.
+  float pf_f[3], pf_v[3][3], pf_fq[NQC], pf_vq[NQC][3], pf_s[NQC];
+  auto load_atom = [&](int i) __attribute__((always_inline)) {
+    const float* xr = xbar + (size_t)i * ldx;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int o = lane + 64 * t;
+      pf_f[t] = xr[2 * NF + o];
+      const float* vs = Vsave + (size_t)i * (NV * 3) + o;  // planes [k][NV], see conv_fwd_kernel
+      pf_v[t][0] = vs[0]; pf_v[t][1] = vs[NV]; pf_v[t][2] = vs[2 * NV];
+    }
+    if (HAS_Q) {
+#pragma unroll
+      for (int ch = 0; ch < NQ; ++ch) {
+        pf_s[ch] = xr[2 * NF + NV + NQ + ch * G_ + (lane >> 2)];
+        if (lane < H_) {
+          pf_fq[ch] = xr[2 * NF + NV + NQ + NQ * G_ + ch * H_ + lane];
           const float* vs = Vqsave + ((size_t)i * NQ + ch) * (H_ * 3) + lane * 3;
-          vb[NV * 3 + ch * (H_ * 3) + lane * 3 + 0] = f * vs[0];
-          vb[NV * 3 + ch * (H_ * 3) + lane * 3 + 1] = f * vs[1];
-          vb[NV * 3 + ch * (H_ * 3) + lane * 3 + 2] = f * vs[2];
+          pf_vq[ch][0] = vs[0]; pf_vq[ch][1] = vs[1]; pf_vq[ch][2] = vs[2];
         }
       }
     }
-    __syncthreads();
+  };
+  int i = al.first + wid;
+  bool live = i < al.last;
+  if (live) load_atom(i);
+  for (int i0 = al.first; i0 < al.last; i0 += al.step) {
+    float qs[NQC];
     if (live) {
-      const float* xr = xbar + (size_t)i * ldx;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int o = lane + 64 * t;
+        const float f = 2.0f * pf_f[t];
+        vb[o * 3 + 0] = f * pf_v[t][0];
+        vb[o * 3 + 1] = f * pf_v[t][1];
+        vb[o * 3 + 2] = f * pf_v[t][2];
+      }
+      if (HAS_Q) {
+#pragma unroll
+        for (int ch = 0; ch < NQ; ++ch) {
+          qs[ch] = pf_s[ch];
+          if (lane < H_) {
+            const float f = 2.0f * pf_fq[ch];
+            vb[NV * 3 + ch * (H_ * 3) + lane * 3 + 0] = f * pf_vq[ch][0];
+            vb[NV * 3 + ch * (H_ * 3) + lane * 3 + 1] = f * pf_vq[ch][1];
+            vb[NV * 3 + ch * (H_ * 3) + lane * 3 + 2] = f * pf_vq[ch][2];
+          }
+        }
+      }
+    }
+    lds_sync<false>();
+    const int i_next = i + al.step;
+    const bool live_next = i_next < al.last;
+    if (live_next) load_atom(i_next);
+    if (live) {
       const int aa = lane >> 2;
-      const float4 s0 = reinterpret_cast<const float4*>(xr + NF)[lane];
       // Sbar row layout: the lane's 16 floats are stored COMPONENT-major, [c][gi] (c = 0 scalar, 1..3
       // vector; gi = the lane's 4 shifts), so that conv_bwd's float4 loads are (gi 0..3) of one
       // component and all its arithmetic packs into v_pk_* pairs over gi without register shuffles
@@ -515,7 +554,7 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
         float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 #pragma unroll
         for (int h = 0; h < H_; ++h) {
-          const float w = s_agh[(aa * G_ + g) * H_ + h];
+          const float w = wreg[gi][h];
           const float* v3 = &vb[(aa * H_ + h) * 3];
           v0 += w * v3[0];
           v1 += w * v3[1];
@@ -523,8 +562,7 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
         }
         vv[0][gi] = v0; vv[1][gi] = v1; vv[2][gi] = v2;
       }
-      // (plane 0 = s0 is not stored: conv_bwd_kernel reads it from the xbar row itself)
-      (void)s0;
+      // (plane 0, the scalar part of xbar, is not stored: conv_bwd_kernel reads it from the xbar row itself)
       out[64] = make_float4(vv[0][0], vv[0][1], vv[0][2], vv[0][3]);
       out[128] = make_float4(vv[1][0], vv[1][1], vv[1][2], vv[1][3]);
       out[192] = make_float4(vv[2][0], vv[2][1], vv[2][2], vv[2][3]);
@@ -534,7 +572,7 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
         for (int ch = 0; ch < NQ; ++ch) {
           float v;
           if (c == 0) {
-            v = xr[2 * NF + NV + NQ + ch * G_ + g];
+            v = qs[ch];
           } else {
             v = 0.f;
 #pragma unroll
@@ -544,6 +582,9 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
         }
       }
     }
+    lds_sync<false>();  // the contraction has read vb before the next atom's values overwrite it
+    i = i_next;
+    live = live_next;
   }
 }
 
@@ -1088,7 +1129,7 @@ __global__ __launch_bounds__(256) void unconcat_p0_kernel(const float* __restric
   __shared__ int s_plist[64];
   __shared__ int s_npres;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int k = threadIdx.x; k < A_ * G_ * H_; k += 256) s_agh[k] = agh_a[k];
+  // (the agh table is read into registers below; its LDS region stays unused)
   if (wid == 0) {
     unsigned long long m = 0ull;
     for (int k = lane; k < n_part; k += 64) m |= present_part[k];
@@ -1106,35 +1147,55 @@ __global__ __launch_bounds__(256) void unconcat_p0_kernel(const float* __restric
   float* vb = s_vb + wid * (NV * 3);
   float* sb = s_sb + wid * (A_ * 65);
   const AtomLoop al = atom_loop(n_atoms, APB);
+  float wreg[4][H_];  // the lane's agh weights in registers (see unconcat_kernel: the LDS reads were a 32-way bank conflict)
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+    for (int h = 0; h < H_; ++h) wreg[gi][h] = agh_a[((lane >> 2) * G_ + (lane & 3) * 4 + gi) * H_ + h];
+  __syncthreads();  // species list and embedding rows (shared, read-only from here on); vb / sb are per wave
+  // wave-level hand-offs and the next atom's operands requested under the current atom's contractions (see unconcat_kernel)
+  float pf_f[3], pf_v[3][3];
+  float4 pf_s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_atom = [&](int i) __attribute__((always_inline)) {
+    const float* xr = xbar + (size_t)i * ldx;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int o = lane + 64 * t;
+      pf_f[t] = xr[2 * NF + o];
+      const float* vs = Vsave + (size_t)i * (NV * 3) + o;  // planes [k][NV], see conv_fwd_kernel
+      pf_v[t][0] = vs[0]; pf_v[t][1] = vs[NV]; pf_v[t][2] = vs[2 * NV];
+    }
+    pf_s0 = reinterpret_cast<const float4*>(xr + NF)[lane];
+  };
+  int i = al.first + wid;
+  bool live = i < al.last;
+  if (live) load_atom(i);
   for (int i0 = al.first; i0 < al.last; i0 += al.step) {
-    const int i = i0 + wid;
-    const bool live = i < al.last;
-    __syncthreads();
+    float s0v[4] = {0.f, 0.f, 0.f, 0.f};
     if (live) {
-      const float* xr = xbar + (size_t)i * ldx;
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const int o = lane + 64 * t;
-        const float f = 2.0f * xr[2 * NF + o];
-        const float* vs = Vsave + (size_t)i * (NV * 3) + o;  // planes [k][NV], see conv_fwd_kernel
-        vb[o * 3 + 0] = f * vs[0];
-        vb[o * 3 + 1] = f * vs[NV];
-        vb[o * 3 + 2] = f * vs[2 * NV];
+        const float f = 2.0f * pf_f[t];
+        vb[o * 3 + 0] = f * pf_v[t][0];
+        vb[o * 3 + 1] = f * pf_v[t][1];
+        vb[o * 3 + 2] = f * pf_v[t][2];
       }
+      s0v[0] = pf_s0.x; s0v[1] = pf_s0.y; s0v[2] = pf_s0.z; s0v[3] = pf_s0.w;
     }
-    __syncthreads();
+    lds_sync<false>();
+    const int i_next = i + al.step;
+    const bool live_next = i_next < al.last;
+    if (live_next) load_atom(i_next);
     if (live) {
-      const float* xr = xbar + (size_t)i * ldx;
       const int aa = lane >> 2, gq = lane & 3;
-      const float4 s0 = reinterpret_cast<const float4*>(xr + NF)[lane];
-      const float s0v[4] = {s0.x, s0.y, s0.z, s0.w};
 #pragma unroll
       for (int gi = 0; gi < 4; ++gi) {
         const int g = gq * 4 + gi;
         float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 #pragma unroll
         for (int h = 0; h < H_; ++h) {
-          const float w = s_agh[(aa * G_ + g) * H_ + h];
+          const float w = wreg[gi][h];
           const float* v3 = &vb[(aa * H_ + h) * 3];
           v0 += w * v3[0];
           v1 += w * v3[1];
@@ -1144,7 +1205,7 @@ __global__ __launch_bounds__(256) void unconcat_p0_kernel(const float* __restric
         o[0] = s0v[gi]; o[1] = v0; o[2] = v1; o[3] = v2;
       }
     }
-    __syncthreads();
+    lds_sync<false>();
     if (live) {
       float sr[A_];
 #pragma unroll
@@ -1158,6 +1219,9 @@ __global__ __launch_bounds__(256) void unconcat_p0_kernel(const float* __restric
         T[((size_t)i * nslots + s_plist[k]) * 64 + lane] = t;
       }
     }
+    lds_sync<false>();  // sb / vb are free for the next atom
+    i = i_next;
+    live = live_next;
   }
 }
 

@@ -176,7 +176,7 @@ def parity_gate(eng, samples, oracle_out):
     return res
 
 
-def cpu_baseline(workload: str, budget_s: float = 10.0, samples=None, oracle_out=None):
+def cpu_baseline(workload: str, budget_s: float = 10.0, samples=None, oracle_out=None, full_inputs=None):
     """Oracle (kind 'port': torch-CPU eager restatement of the reference op sequence) on the host cores, on a bounded sample of
     the same workload.  The timed step INCLUDES the neighbour lists (k-d tree over the periodic images,
     oracle.neighbor_list_fast), as the GPU step does; measured at every host thread torch will use and at 1 thread
@@ -221,19 +221,25 @@ def cpu_baseline(workload: str, budget_s: float = 10.0, samples=None, oracle_out
     full = None
     if workload == "pbc10k" and budget_s >= 5.0:  # ONE evaluation of the full-size configuration (10 080 atoms, both lists rebuilt)
         try:
-            c, z10, cell = workloads.glucose_supercell((7, 3, 5))
+            if full_inputs is not None:  # the very frame the GPU was timed on (rank 0)
+                c32, z10, cell = full_inputs["coord"].astype(np.float32), np.asarray(full_inputs["numbers"]), full_inputs["cell"].astype(np.float64)
+            else:
+                c, z10, cell = workloads.glucose_supercell((7, 3, 5))
+                c32 = c.astype(np.float32)
             mol = np.zeros(len(z10), dtype=np.int64)
             pbc = np.ones(3, dtype=bool)
-            c32, cell32 = c.astype(np.float32), cell.astype(np.float32)
+            cell32 = cell.astype(np.float32)
             om = O.OracleModel(synth.synthetic_state_dict(0), torch.float32)
             torch.set_num_threads(min(cores, 16))
             t0 = time.perf_counter()
             xw = O.wrap_into_cell(c32, cell32, mol, pbc)
             nb, sh = O.neighbor_list_fast(xw, 5.0, mol, cell, pbc)
             nbl, shl = O.neighbor_list_fast(xw, 15.0, mol, cell, pbc)
-            O.evaluate(om, coord=xw, numbers=z10, charge=np.zeros(1, np.float32), mol_idx=mol, cell=cell32, coulomb="dsf", stress=True,
-                       nbmat=nb, shifts=sh, nbmat_lr=nbl, shifts_lr=shl)
+            out10 = O.evaluate(om, coord=xw, numbers=z10, charge=np.zeros(1, np.float32), mol_idx=mol, cell=cell32, coulomb="dsf", stress=True,
+                               nbmat=nb, shifts=sh, nbmat_lr=nbl, shifts_lr=shl)
             dt = time.perf_counter() - t0
+            if oracle_out is not None:
+                oracle_out["pbc10080"] = dict(out10, _coord=xw)
             full = {"atoms": int(len(z10)), "cores": int(min(cores, 16)), "evals": 1, "seconds": round(dt, 2), "value": len(z10) / dt,
                     "sample": "the full-size configuration itself: 2019828.cif (7,3,5) supercell, 10080 atoms, DSF 15A, E+F+stress, lists rebuilt"}
         except Exception as exc:  # e.g. host memory: the bounded sample above stands
@@ -552,7 +558,14 @@ def main():
             out["scaling_md1024"] = md
         if world == 1 and not args.no_cpu_baseline:
             samples, oracle_out = parity_samples(), {}
-            out["cpu_baseline"] = cpu_baseline(args.workload, budget_s=args.cpu_budget, samples=samples, oracle_out=oracle_out)
+            out["cpu_baseline"] = cpu_baseline(args.workload, budget_s=args.cpu_budget, samples=samples, oracle_out=oracle_out,
+                                               full_inputs=wl if args.workload == "pbc10k" else None)
+            ref10 = oracle_out.pop("pbc10080", None)
+            if ref10 is not None:  # the full-size frame itself, engine vs oracle (one evaluation each; its own record, not part of parity.ok)
+                smp = dict(coord=ref10["_coord"], numbers=np.asarray(wl["numbers"]), mol_idx=np.zeros(n_atoms, dtype=np.int64),
+                           charge=np.zeros(1, np.float32), cell=wl["cell"].astype(np.float32), coulomb="dsf", stress=True, e64=None,
+                           label=wl["label"] + " (the timed frame of rank 0, wrapped coordinates)")
+                out["parity_full_size"] = parity_gate(eng, {"pbc10080": smp}, {"pbc10080": ref10})
             for k, smp in samples.items():  # the sample the baseline was not timed on: one oracle evaluation for the parity gate
                 if k not in oracle_out:
                     oracle_out[k] = smp["step"]()

@@ -1,5 +1,6 @@
-import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+EVERY = int(os.environ.get('SOAK_EVERY', 500))  # compare every n-th evaluation with the first, bitwise
 from aimnetcentral_amd import loader, workloads
 from aimnetcentral_amd.engine import HipEngine
 eng = HipEngine(loader.synthetic_spec(0), "cuda:0")
@@ -14,7 +15,7 @@ t0 = time.time(); n = 0
 while time.time() - t0 < 45:
     r = eng.eval(*args, cell=cl, forces=True, stress=True, coulomb="dsf")
     n += 1
-    if n % 500 == 0:
-        assert torch.equal(r["energy"], e0) and torch.equal(r["forces"], f0), "results drifted"
+    if n % EVERY == 0:
+        assert torch.equal(r["energy"], e0) and torch.equal(r["forces"], f0), f"results drifted at evaluation {n}"
 torch.cuda.synchronize()
-print(f"{n} evaluations in {time.time()-t0:.1f} s = {(time.time()-t0)/n*1e3:.3f} ms each; bitwise identical; memory {m0} -> {torch.cuda.memory_allocated()} bytes (peak {torch.cuda.max_memory_allocated()})")
+print(f"{n} evaluations in {time.time()-t0:.1f} s = {(time.time()-t0)/n*1e3:.3f} ms each; bitwise identical (every {EVERY}-th compared); memory {m0} -> {torch.cuda.memory_allocated()} bytes (peak {torch.cuda.max_memory_allocated()})")

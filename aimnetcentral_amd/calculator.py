@@ -164,7 +164,7 @@ class AIMNet2Calculator:
     # ---- model resolution ----------------------------------------------------------------------
     @staticmethod
     def _resolve(model: str, paths, mode) -> ModelSpec:
-        if os.path.isfile(model):
+        if os.path.isfile(model) or os.path.isfile(os.path.join(model, "config.json")):  # a v2 artifact, or a local Hugging Face directory
             return loader.load_model(model, model_import_paths=paths, model_import_mode=mode)[0]
         cache = os.environ.get("AIMNET_CACHE_DIR", os.path.join(os.path.expanduser("~"), ".cache", "aimnet"))
         for cand in (os.path.join(cache, model), os.path.join(cache, model + ".pt")):
@@ -172,7 +172,8 @@ class AIMNet2Calculator:
                 return loader.load_model(cand, model_import_paths=paths, model_import_mode=mode)[0]
         raise FileNotFoundError(
             f"model {model!r} is neither a file nor present in the model cache {cache!r}; registry downloads "
-            "need network access and are not performed by the native engine - pass a local v2 .pt path")
+            "need network access and are not performed by the native engine - pass a local v2 .pt path or a local directory in the "
+            "Hugging Face layout (config.json + ensemble_N.safetensors)")
 
     @classmethod
     def from_legacy_jit(cls, path: str, **kw):

@@ -460,8 +460,7 @@ class HipEngine:
             charge = charge.reshape(-1).contiguous()
             n_mol = charge.shape[0]
         n = coord.shape[0]
-        vectors = vectors.to(device=dev, dtype=torch.float32).reshape(-1, n, 3).contiguous()
-        K = vectors.shape[0]
+        K = int(vectors.numel()) // max(1, 3 * n)
         if n == 0 or n_mol == 0 or K == 0:
             raise ValueError("HipEngine.hvp: empty input")
         est = 0.75e-6 * n * K if n > 2000 else 0.0  # (small systems are launch-bound: ~0.04 force evaluations per direction)
@@ -469,6 +468,7 @@ class HipEngine:
             raise ValueError(f"HipEngine.hvp: {K} directions on {n} atoms would take ~{est:.0f} s (~0.75 us per atom and direction); "
                              f"pass fewer vectors per call (a Krylov / Davidson solver needs tens, not 3N) or raise "
                              f"HipEngine.HVP_MAX_SECONDS (now {self.HVP_MAX_SECONDS:.0f} s)")
+        vectors = vectors.to(device=dev, dtype=torch.float32).reshape(-1, n, 3).contiguous()
         n_cell = 0
         if cell is not None:
             cell = cell.to(device=dev, dtype=torch.float32).contiguous()

@@ -50,6 +50,10 @@ def test_default_workload_carries_the_parity_gate():
     for k in ("pbc2304", "md48x50"):
         assert p[k]["ok"] and p[k]["dF_max"] <= p[k]["gates"]["dF_max"] and p[k]["dq_max"] <= 1e-4
     assert p["pbc2304"]["dE"] <= p["pbc2304"]["gates"]["dE"] and p["pbc2304"]["gates"]["dE_gate_slack_fp64"] == 0.0
+    # the honest fractions and the engine-reported configuration ride on the same line
+    assert 0.0 < d["roofline_e2e"]["frac_mixed"] < d["roofline_e2e"]["frac"] < 1.0
+    assert d["roofline"]["gemm_launches_per_step"] == 21 and "mfma_busy_frac_in_kernel" in d["roofline"]
+    assert d["roofline_gather"]["form"] == "reverse-pair" and "gemm_bf3a_kernel" in d["roofline"]["kernel"]
 
 
 def test_two_ranks_share_the_gpu_over_gloo():

@@ -64,3 +64,26 @@ def test_caffeine_on_real_weights():
     assert abs(float(out["energy"][0]) - float(g["energy"][0])) < 1e-5
     assert np.abs(out["forces"] - g["forces"]).max() <= 1e-5 + 1e-4 * np.abs(g["forces"]).max()
     assert np.abs(out["charges"] - g["charges"]).max() <= 1e-3
+
+
+@pytest.mark.gpu
+def test_hugging_face_directory_runs_through_the_calculator(tmp_path):
+    """A model directory in the reference's Hugging Face layout (config.json + ensemble_0.safetensors, hf_hub.py:275-398) is a valid
+    `model` argument: same results as the v2 artifact it was exported from (synthetic weights)."""
+    import json
+
+    import torch
+    from safetensors.torch import save_file
+
+    from aimnetcentral_amd import AIMNet2Calculator, loader, synth
+
+    art = synth.synthetic_artifact(0)
+    d = tmp_path / "hf_model"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({k: v for k, v in art.items() if k != "state_dict"}))
+    save_file({k: v.contiguous() for k, v in art["state_dict"].items()}, str(d / "ensemble_0.safetensors"))
+    g = golden("taxol")
+    data = {"coord": g["coord"], "numbers": g["numbers"], "charge": 0.0}
+    a = AIMNet2Calculator(str(d), device="cuda:0")(data, forces=True)
+    b = AIMNet2Calculator(loader.synthetic_spec(0), device="cuda:0")(data, forces=True)
+    assert torch.equal(a["energy"], b["energy"]) and torch.equal(a["forces"], b["forces"]) and torch.equal(a["charges"], b["charges"])

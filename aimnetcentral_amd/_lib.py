@@ -162,6 +162,11 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C aimnetcentral_amd/csrc`). The HIP engine has no CPU/PyTorch fallback."
         )
+    # torch first: its wheel carries its own libamdhip64 / libhsa-runtime64, and the device pointers it hands us are only valid in
+    # THAT runtime.  Loaded before torch, this library would pull /opt/rocm's copies into the process instead and a second HSA
+    # runtime finds "no ROCm-capable device" (seen with `python __graft_entry__.py smoke`, where build() loads the library first).
+    import torch  # noqa: F401
+
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as exc:  # missing ROCm runtime etc.

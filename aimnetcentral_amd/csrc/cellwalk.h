@@ -18,12 +18,37 @@ struct NlistSystem {
   int n_bins;
 };
 
+// Fractional coordinate k of a position in ONE fixed arithmetic form (explicit fmas, nothing left to the compiler's contraction
+// choices): every kernel that wraps or bins an atom gets the same bits, so the separate preparation kernels and the single-launch
+// one (nlist.hip, prep_small_kernel) build identical bins.
+__device__ __forceinline__ float cell_frac(const NlistSystem& S, float x, float y, float z, int k) {
+  return __builtin_fmaf(z, S.inv[6 + k], __builtin_fmaf(y, S.inv[3 + k], x * S.inv[k]));
+}
+
 __device__ __forceinline__ int bin_of(const NlistSystem& S, float x, float y, float z, int b[3]) {
   for (int k = 0; k < 3; ++k) {
-    const float f = (x - S.o[0]) * S.inv[k] + (y - S.o[1]) * S.inv[3 + k] + (z - S.o[2]) * S.inv[6 + k];
+    const float f = cell_frac(S, x - S.o[0], y - S.o[1], z - S.o[2], k);
     b[k] = max(0, min(S.nb[k] - 1, (int)floorf(f * (float)S.nb[k])));
   }
   return S.bin_offset + (b[0] * S.nb[1] + b[1]) * S.nb[2] + b[2];
+}
+
+// Wrap a position into the periodic cell the way the reference does (neighbors.py:265-306: frac = coord @ inv(cell),
+// frac -= floor(frac), coord = frac @ cell), in ONE fixed arithmetic form: k-ordered fma chains, what an fp32 matrix product
+// with an inner dimension of 3 computes.  The round trip is not the identity in fp32 (an atom inside the cell moves by ~1e-6 A, worth
+// 1e-5..1e-4 eV on a hot geometry), so parity with the reference's energies means rounding like the reference here; a form that
+// subtracts whole lattice vectors instead (bit-exact for atoms inside the cell) put the `pbc96_dsf8_wrapped` golden 8.9e-5 eV away
+// (gate 4.8e-5).
+__device__ __forceinline__ void wrap_into_cell(const NlistSystem& S, float x, float y, float z, float w[3]) {
+  float f[3];
+  for (int k = 0; k < 3; ++k) {
+    f[k] = cell_frac(S, x, y, z, k);
+    if (S.per[k]) {
+      f[k] -= floorf(f[k]);
+      if (f[k] >= 1.0f) f[k] = 0.0f;
+    }
+  }
+  for (int c = 0; c < 3; ++c) w[c] = __builtin_fmaf(f[2], S.c[6 + c], __builtin_fmaf(f[1], S.c[3 + c], f[0] * S.c[c]));
 }
 
 // Visit every (neighbour image) candidate of atom i (one wave per atom) whose bin lies within the

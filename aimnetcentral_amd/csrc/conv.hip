@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
 #pragma unroll UNR_T
       for (int t = 0; t < 3; ++t) {
         const int o = lane + 64 * t;  // (a, h) = (o / 12, o % 12)
-        const int aa = o / H_, hh = o % H_;
+        const int aa = o / H_;
         float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 #ifdef AIMNET_PROBE_FWD_NO_EPI  // measurement builds only (tests/tools/variant.sh): what the agh contraction costs
 #pragma unroll 1
@@ -550,7 +550,6 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
       float vv[3][4];
 #pragma unroll
       for (int gi = 0; gi < 4; ++gi) {
-        const int g = (lane & 3) * 4 + gi;
         float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 #pragma unroll
         for (int h = 0; h < H_; ++h) {

@@ -387,6 +387,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->gemm_presplit = atoi(env) != 0;
     env = getenv("AIMNET_HEAD_FUSED");
     if (env) e->head_fused = atoi(env) != 0;
+    env = getenv("AIMNET_PREP_FUSED");
+    if (env) e->prep_fused = atoi(env) != 0;
     env = getenv("AIMNET_CONV_XE");
     if (env) e->conv_xe = atoi(env);
     env = getenv("AIMNET_SPLIT_MAX");
@@ -522,6 +524,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "gemm_bf3") e->gemm_bf3 = std::min(2, std::max(0, value));
   else if (n == "gemm_presplit") e->gemm_presplit = value != 0;
   else if (n == "head_fused") e->head_fused = value != 0;
+  else if (n == "prep_fused") e->prep_fused = value != 0;
   else if (n == "split_max") e->split_max = value < 0 ? conv_split_max_default() : value;
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -542,6 +545,7 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
   else if (n == "gemm_bf3") *value = e->gemm_bf3;
   else if (n == "gemm_presplit") *value = e->gemm_presplit;
   else if (n == "head_fused") *value = e->head_fused;
+  else if (n == "prep_fused") *value = e->prep_fused;
   else if (n == "split_max") *value = e->split_max;
   else if (n == "p0_moments") *value = e->p0_moments ? 1 : 0;
   else if (n == "overlap_coulomb") *value = e->overlap_coulomb ? 1 : 0;
@@ -717,10 +721,17 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   e->prof_on = e->prof_level > 0 && (e->prof_evals++ % e->prof_every) == 0;
   if (e->prof_on) e->prof_sampled++;
   RC(prof_mark(e, s, FAM_NLIST));
-  AIMNET_HIP_CHECK(hipMemsetAsync(out->status, 0, 8 * sizeof(int), s));
   const bool want_species = (e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS))) || opt->dftd3 != 0;
-  RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start, W.nl.mol_c, in->numbers, out->status + 6,
-                      want_species ? e->slot_of_z : nullptr, W.aslot, W.present_part));  // + aslot / present species
+  // small periodic batches: status zeroing, molecule offsets / sanity / species, cell + bin setup, wrapping and binning in one launch
+  const bool prep1 = e->prep_fused && !ext && pbc && in->cell && prep_small_applies(N, n_mol);
+  if (prep1) {
+    RC(launch_prep_small(s, in->coord, in->mol_idx, in->numbers, N, n_mol, in->cell, n_cell, in->pbc, in->pbc_sys, ar.rc, out->status,
+                         want_species ? e->slot_of_z : nullptr, W.aslot, W.present_part, W.nl));
+  } else {
+    AIMNET_HIP_CHECK(hipMemsetAsync(out->status, 0, 8 * sizeof(int), s));
+    RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start, W.nl.mol_c, in->numbers, out->status + 6,
+                        want_species ? e->slot_of_z : nullptr, W.aslot, W.present_part));  // + aslot / present species
+  }
   const int* mol_c = W.nl.mol_c;  // clamped to [0, n_mol): memory-safe whatever the caller passed (status[6] reports it)
   const bool d3 = opt->dftd3 != 0;
   if (d3 && e->d3.ns == 0) {
@@ -763,7 +774,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       }
     }
   } else {
-  RC(launch_wrap(s, in->coord, mol_c, N, n_mol, in->cell, n_cell, in->pbc, W.nl, in->pbc_sys, pbc ? ar.rc : 0.0f));
+  if (!prep1) RC(launch_wrap(s, in->coord, mol_c, N, n_mol, in->cell, n_cell, in->pbc, W.nl, in->pbc_sys, pbc ? ar.rc : 0.0f));
   // large non-periodic molecules (>= 1500 atoms on average) get a bounding-box cell list instead of the O(n^2) scan
   if (!pbc && (long)N >= 1500L * n_mol) RC(launch_bbox(s, n_mol, W.nl));
   RC(launch_nlist(s, N, n_mol, mol_c, in->cell, n_cell, in->pbc, ar.rc, ar.rc, cap, N, 0, W.nl, W.nb_idx, W.nb_shift,
@@ -1198,6 +1209,9 @@ int aimnet_debug_gemm_bf3a(int cfg, int epi, int out3, const void* A3, int lda3,
   return launch_gemm_bf3a_cfg((hipStream_t)hip_stream, cfg, epi, out3 != 0, (const unsigned short*)A3, lda3, (const unsigned short*)Bt3,
                               ldb, M, N, K, bias, C, (unsigned short*)C3, ldc3, D, ldc, nullptr, 0, alt);
 }
+#ifdef AIMNET_PREP_TIMING
+int aimnet_debug_prep_stamps(unsigned long long* host16) { return aimnet::prep_read_stamps(host16); }
+#endif
 #ifdef AIMNET_BF3_TIMING
 int aimnet_debug_bf3a_stamps(unsigned long long* host1024) { return aimnet::gemm_bf3a_read_stamps(host1024); }
 int aimnet_debug_bf3_stamps(unsigned long long* host1024) { return aimnet::gemm_bf3_read_stamps(host1024); }

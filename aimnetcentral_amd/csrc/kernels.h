@@ -84,6 +84,7 @@ struct NlistBuffers {      // all device pointers, carved from the caller's work
   void* sorted_tmp_xq;     // [n_atoms] float4 bin-ordered (x, y, z, charge) for the list-free DSF walk
   int* mol_c;              // [n_atoms] the caller's mol_idx clamped to [0, n_mol) (launch_mol_start): what every kernel indexes with
   float prebinned_width = 0.0f;  // host flag: launch_wrap prepared the bins for this width (launch_bins starts at the scan)
+  bool bins_done = false;  // host flag: launch_prep_small also scanned / filled / ordered the bins for prebinned_width
   bool binned = false;     // host flag: `sys` + bins describe this batch (periodic cells, or bounding boxes via launch_bbox)
 };
 size_t nlist_scratch_bytes(int n_atoms, int n_mol);
@@ -97,6 +98,14 @@ int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, 
 // wrap coordinates (periodic) or copy them (non-periodic) into b.xw
 int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
                 int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys = nullptr, float bin_width = 0.0f);  // pbc_sys: device [n_cell][3] or NULL
+// small periodic batches: status zeroing + launch_mol_start + launch_wrap(bin_width) + the bin kernels of launch_nlist in ONE launch
+bool prep_small_applies(int n_atoms, int n_mol);
+int launch_prep_small(hipStream_t s, const float* coord, const int* mol_idx, const int* numbers, int n_atoms, int n_mol,
+                      const float* cell, int n_cell, const int pbc[3], const int* pbc_sys, float bin_width, int* status,
+                      const int* slot_of_z, int* aslot, unsigned long long* present_part, NlistBuffers& b);
+#ifdef AIMNET_PREP_TIMING
+int prep_read_stamps(unsigned long long* host16);  // measurement build only (tests/tools/prep_timing.sh)
+#endif
 // non-periodic systems: give every molecule the cell grid of its bounding box (after launch_wrap), so that launch_nlist
 // takes the cell-list path instead of the O(n^2) per-molecule scan; worth it from ~10^3 atoms per molecule
 int launch_bbox(hipStream_t s, int n_mol, NlistBuffers& b);

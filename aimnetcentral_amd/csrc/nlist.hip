@@ -228,16 +228,9 @@ __global__ void wrap_kernel(const float* __restrict__ coord, const int* __restri
     xw[3 * i + 2] = z;
     return;
   }
-  const NlistSystem& S = sys[mol_idx[i]];
-  float f[3];
-  for (int k = 0; k < 3; ++k) {
-    f[k] = x * S.inv[k] + y * S.inv[3 + k] + z * S.inv[6 + k];
-    if (S.per[k]) {
-      f[k] -= floorf(f[k]);
-      if (f[k] >= 1.0f) f[k] = 0.0f;
-    }
-  }
-  for (int k = 0; k < 3; ++k) xw[3 * i + k] = f[0] * S.c[k] + f[1] * S.c[3 + k] + f[2] * S.c[6 + k];
+  float w[3];
+  wrap_into_cell(sys[mol_idx[i]], x, y, z, w);
+  for (int k = 0; k < 3; ++k) xw[3 * i + k] = w[k];
 }
 
 // (defined with the binning kernels below)
@@ -412,16 +405,8 @@ __global__ void wrap_bin_count_kernel(const float* __restrict__ coord, const int
   if (i >= n_atoms) return;
   const NlistSystem& S = sys[mol_idx[i]];
   const float x = coord[3 * i], y = coord[3 * i + 1], z = coord[3 * i + 2];
-  float f[3];
-  for (int k = 0; k < 3; ++k) {
-    f[k] = x * S.inv[k] + y * S.inv[3 + k] + z * S.inv[6 + k];
-    if (S.per[k]) {
-      f[k] -= floorf(f[k]);
-      if (f[k] >= 1.0f) f[k] = 0.0f;
-    }
-  }
   float w[3];
-  for (int k = 0; k < 3; ++k) w[k] = f[0] * S.c[k] + f[1] * S.c[3 + k] + f[2] * S.c[6 + k];
+  wrap_into_cell(S, x, y, z, w);
   xw[3 * i] = w[0];
   xw[3 * i + 1] = w[1];
   xw[3 * i + 2] = w[2];
@@ -489,6 +474,247 @@ __global__ __launch_bounds__(256) void bin_sort_kernel(const int* __restrict__ b
   }
 }
 
+// ---- small periodic batches: the whole preparation in ONE single-block launch ----------------------------------------------
+// status zeroing, mol_start + input sanity + species pass, cell + bin-grid setup, wrapping, bin counting, scan, fill and the
+// per-bin ordering are a few microseconds of work each on 10^4 atoms, but seven dependent launches cost ~5 us apiece on this part
+// (profiles/r4_kernel_sequence.txt).  One block of 1024 threads does them back to back with block barriers in between; bin
+// counters / starts and the arrival-ordered atom ids live in LDS.  Results are identical to the separate kernels: every bin is
+// ordered by atom id at the end, whatever order the LDS atomics arrived in.
+// Size limit: one CU's address coalescer handles about one cache line per clock, and the three scattered passes (stride-12
+// coordinates, bin-ordered stores) of 10^4 atoms take 25 000 clocks on it - the phases measure 2.5 / 5 / 1.3 / 10 / 2 / 1.3 / 12 us at
+// 10 080 atoms (tests/tools/prep_timing.sh), 43 us against 36.5 us for the seven launches.  Step time of periodic glucose
+// supercells, this kernel against the separate ones (tests/tools/prep_ab.py): 96 atoms -4.2 %, 768 -2.8 %, 1 728 -2.4 %,
+// 3 456 -0.8 %, 6 144 +0.4 %, 10 080 +1.5 %.  Hence 4 096 atoms.
+constexpr int PREP_SMALL_MAX_ATOMS = 4096;
+constexpr int PREP_SMALL_MAX_MOL = 64;
+
+struct PrepSmallArgs {
+  const float* coord; const int* mol_idx; const int* numbers; int n_atoms, n_mol;
+  const float* cell; int n_cell, p0, p1, p2; const int* pbc_sys; float w;
+  int* status;  // [8], zeroed here; status + 6 = the input sanity flags
+  const int* slot_of_z; int* aslot; unsigned long long* present_part;
+  int* mol_start; int* mol_c; NlistSystem* sys; float* xw; int* atom_bin; int* slot; int* bin_start; int* sorted; float4* xs;
+};
+
+// Every thread owns the atoms t, t + 1024, ... (at most PS_K of them) through all phases, with their molecule, bin and arrival
+// rank in registers; every phase issues its global loads for all owned atoms before the first use (a dependent load chain per
+// atom and iteration made the first version of this kernel slower than the seven launches it replaces).
+constexpr int PS_K = PREP_SMALL_MAX_ATOMS / 1024;
+
+__device__ __forceinline__ unsigned wave_or_to_lane63(unsigned v) {  // OR over the wave, valid in lane 63
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8: lane 15 of a row = the row
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast:15 into rows 1, 3
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);  // row_bcast:31 into rows 2, 3
+  return v;
+}
+#ifdef AIMNET_PREP_TIMING  // measurement build (tests/tools/prep_timing.sh): wall-clock stamps (100 MHz) of thread 0 per phase
+__device__ unsigned long long g_prep_stamps[16];
+#define PREP_STAMP(k) do { if (threadIdx.x == 0) g_prep_stamps[k] = wall_clock64(); } while (0)
+int prep_read_stamps(unsigned long long* host16) {
+  return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_prep_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#else
+#define PREP_STAMP(k)
+#endif
+
+__global__ __launch_bounds__(1024) void prep_small_kernel(PrepSmallArgs a) {
+  extern __shared__ int s_prep[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int n_atoms = a.n_atoms, n_mol = a.n_mol;
+  const int max_bins = n_atoms + 8 * n_mol + 8;
+  int* s_bin = s_prep;                 // [max_bins + 1] counters, then (in place) starts
+  int* s_tmp = s_prep + max_bins + 1;  // [n_atoms] atom ids in arrival order per bin
+  __shared__ int part[1024];
+  __shared__ unsigned long long s_mask[PREP_SMALL_MAX_ATOMS / 256];
+  __shared__ int s_slot_of_z[64];
+  __shared__ NlistSystem s_sys[PREP_SMALL_MAX_MOL];
+  PREP_STAMP(0);
+  if (t < 8) a.status[t] = 0;
+  if (t < PREP_SMALL_MAX_ATOMS / 256) s_mask[t] = 0ull;
+  if (t < 64) s_slot_of_z[t] = a.slot_of_z ? a.slot_of_z[t] : 0;
+  for (int k = t; k <= max_bins; k += 1024) s_bin[k] = 0;
+  for (int s = t; s < n_mol; s += 1024) cell_setup_one(a.cell, a.n_cell, s, a.p0, a.p1, a.p2, a.pbc_sys, a.sys);
+  __syncthreads();
+  PREP_STAMP(1);
+  // ---- mol_start_kernel's three jobs
+  int cur[PS_K];
+  {
+    int zraw[PS_K], raw[PS_K], rprev[PS_K];
+#pragma unroll
+    for (int k = 0; k < PS_K; ++k) {
+      const int i = t + 1024 * k, ii = i < n_atoms ? i : 0;
+      zraw[k] = a.numbers ? a.numbers[ii] : 0;
+      raw[k] = a.mol_idx[ii];
+      rprev[k] = a.mol_idx[ii > 0 ? ii - 1 : 0];
+    }
+    int* bad = a.status + 6;
+#pragma unroll
+    for (int k = 0; k < PS_K; ++k) {
+      const int i = t + 1024 * k;
+      if (1024 * k >= n_atoms) break;  // (block-uniform)
+      unsigned long long m = 0ull;
+      cur[k] = 0;
+      if (i < n_atoms) {
+        if (a.slot_of_z) {
+          const int sl = s_slot_of_z[min(63, max(0, zraw[k]))];
+          a.aslot[i] = sl;
+          m = 1ull << sl;
+        }
+        const int prev = (i == 0) ? -1 : min(max(rprev[k], -1), n_mol - 1);
+        cur[k] = min(max(raw[k], 0), n_mol - 1);
+        a.mol_c[i] = cur[k];
+        int f = (raw[k] < 0 || raw[k] >= n_mol) ? 2 : 0;
+        if (i > 0 && raw[k] < rprev[k]) f |= 4;
+        if (a.numbers && (zraw[k] < 0 || zraw[k] > 63)) f |= 1;
+        if (f) atomicOr(bad, f);
+        for (int mm = prev + 1; mm <= cur[k] && mm <= n_mol; ++mm) a.mol_start[mm] = i;
+        if (i == n_atoms - 1)
+          for (int mm = cur[k] + 1; mm <= n_mol; ++mm) a.mol_start[mm] = n_atoms;
+      }
+      if (a.slot_of_z) {  // a wave's 64 atoms lie in one 256-atom group; DPP reduction (a ds_bpermute chain per k cost 0.7 us)
+        const unsigned lo = wave_or_to_lane63((unsigned)m), hi = wave_or_to_lane63((unsigned)(m >> 32));
+        if (lane == 63) atomicOr(&s_mask[(1024 * k + (t & ~63)) >> 8], ((unsigned long long)hi << 32) | lo);
+      }
+    }
+  }
+  __syncthreads();
+  PREP_STAMP(2);
+  if (a.slot_of_z)
+    for (int g = t; g * 256 < n_atoms; g += 1024) a.present_part[g] = s_mask[g];
+  bins_setup_block(a.sys, a.mol_start, n_mol, a.w);
+  __syncthreads();
+  PREP_STAMP(3);
+  {
+    const int* src = (const int*)a.sys;
+    int* dst = (int*)s_sys;
+    for (int k = t; k < n_mol * (int)(sizeof(NlistSystem) / sizeof(int)); k += 1024) dst[k] = src[k];
+  }
+  __syncthreads();
+  PREP_STAMP(4);
+  // ---- wrap + count (wrap_bin_count_kernel)
+  int bin[PS_K], slot[PS_K];
+  auto wrap4 = [&](auto K0) {
+    constexpr int k0 = decltype(K0)::value;
+    float x[PS_K], y[PS_K], z[PS_K];
+#pragma unroll
+    for (int k = 0; k < PS_K; ++k) {
+      const int i = t + 1024 * (k0 + k), ii = i < n_atoms ? i : 0;
+      x[k] = a.coord[3 * ii], y[k] = a.coord[3 * ii + 1], z[k] = a.coord[3 * ii + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < PS_K; ++k) {
+      const int i = t + 1024 * (k0 + k);
+      bin[k0 + k] = 0, slot[k0 + k] = 0;
+      if (i >= n_atoms) continue;
+      const NlistSystem& S = s_sys[cur[k0 + k]];
+      float w[3];
+      wrap_into_cell(S, x[k], y[k], z[k], w);
+      a.xw[3 * i] = w[0];
+      a.xw[3 * i + 1] = w[1];
+      a.xw[3 * i + 2] = w[2];
+      int b[3];
+      bin[k0 + k] = bin_of(S, w[0], w[1], w[2], b);
+      slot[k0 + k] = atomicAdd(&s_bin[bin[k0 + k]], 1);
+    }
+  };
+  wrap4(std::integral_constant<int, 0>{});
+  static_assert(PS_K == 4, "one batch of four atoms per thread");
+  __syncthreads();
+  PREP_STAMP(5);
+  // ---- exclusive scan over the bins in use, in place (scan_kernel)
+  const int n = s_sys[n_mol - 1].bin_offset + s_sys[n_mol - 1].n_bins;
+  {
+    const int chunk = (n + 1023) / 1024;
+    const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
+    int sum = 0;
+    for (int k = lo; k < hi; ++k) sum += s_bin[k];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int v = (t >= off) ? part[t - off] : 0;
+      __syncthreads();
+      part[t] += v;
+      __syncthreads();
+    }
+    int run = (t == 0) ? 0 : part[t - 1];
+    for (int k = lo; k < hi; ++k) {
+      const int c = s_bin[k];
+      s_bin[k] = run;
+      run += c;
+    }
+    if (t == 1023) s_bin[n] = part[1023];
+  }
+  __syncthreads();
+  PREP_STAMP(6);
+  for (int k = t; k <= n; k += 1024) a.bin_start[k] = s_bin[k];
+#pragma unroll
+  for (int k = 0; k < PS_K; ++k) {
+    const int i = t + 1024 * k;
+    if (i < n_atoms) s_tmp[s_bin[bin[k]] + slot[k]] = i;
+  }
+  __syncthreads();
+  PREP_STAMP(7);
+  // ---- order every bin by atom id, emit the bin-ordered coordinate stream (bin_sort_kernel)
+  auto sort4 = [&](auto K0) {
+    constexpr int k0 = decltype(K0)::value;
+    float x[PS_K], y[PS_K], z[PS_K];
+    int dest[PS_K];
+#pragma unroll
+    for (int k = 0; k < PS_K; ++k) {
+      const int i = t + 1024 * (k0 + k), ii = i < n_atoms ? i : 0;
+      x[k] = a.xw[3 * ii], y[k] = a.xw[3 * ii + 1], z[k] = a.xw[3 * ii + 2];  // (this thread's own stores)
+    }
+#pragma unroll
+    for (int k = 0; k < PS_K; ++k) {
+      const int i = t + 1024 * (k0 + k);
+      const int s0 = s_bin[bin[k0 + k]], cnt = i < n_atoms ? s_bin[bin[k0 + k] + 1] - s0 : 0;
+      int rank = 0;
+      for (int f = 0; f < cnt; f += 8) {  // 8 independent LDS reads in flight
+        int v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = s_tmp[min(s0 + f + j, n_atoms - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rank += (f + j < cnt && v[j] < i) ? 1 : 0;
+      }
+      dest[k] = s0 + rank;
+    }
+#pragma unroll
+    for (int k = 0; k < PS_K; ++k) {
+      const int i = t + 1024 * (k0 + k);
+      if (i >= n_atoms) continue;
+      a.sorted[dest[k]] = i;
+      a.xs[dest[k]] = make_float4(x[k], y[k], z[k], __int_as_float(i));
+    }
+  };
+  sort4(std::integral_constant<int, 0>{});
+  PREP_STAMP(8);
+}
+
+bool prep_small_applies(int n_atoms, int n_mol) { return n_atoms <= PREP_SMALL_MAX_ATOMS && n_mol <= PREP_SMALL_MAX_MOL; }
+
+// replaces memset(status) + launch_mol_start + launch_wrap(bin_width) + the bin kernels of the following launch_nlist(bin_width)
+int launch_prep_small(hipStream_t s, const float* coord, const int* mol_idx, const int* numbers, int n_atoms, int n_mol,
+                      const float* cell, int n_cell, const int pbc[3], const int* pbc_sys, float bin_width, int* status,
+                      const int* slot_of_z, int* aslot, unsigned long long* present_part, NlistBuffers& b) {
+  PrepSmallArgs a;
+  a.coord = coord; a.mol_idx = mol_idx; a.numbers = numbers; a.n_atoms = n_atoms; a.n_mol = n_mol;
+  a.cell = cell; a.n_cell = n_cell; a.p0 = pbc[0]; a.p1 = pbc[1]; a.p2 = pbc[2]; a.pbc_sys = pbc_sys; a.w = bin_width;
+  a.status = status;
+  a.slot_of_z = (numbers && aslot) ? slot_of_z : nullptr; a.aslot = aslot; a.present_part = present_part;
+  a.mol_start = b.mol_start; a.mol_c = b.mol_c; a.sys = (NlistSystem*)b.sys; a.xw = b.xw; a.atom_bin = b.atom_bin;
+  a.slot = b.bin_fill; a.bin_start = b.bin_start; a.sorted = b.sorted; a.xs = b.xs;
+  const size_t lds = ((size_t)(n_atoms + 8 * n_mol + 9) + (size_t)n_atoms) * sizeof(int);  // <= 35 KB
+  hipLaunchKernelGGL(prep_small_kernel, dim3(1), dim3(1024), lds, s, a);
+  AIMNET_LAUNCH_CHECK();
+  b.binned = true;
+  b.prebinned_width = bin_width;
+  b.bins_done = true;
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx,
                                                         const NlistSystem* __restrict__ sys,
                                                         const int* __restrict__ bin_start, const float4* __restrict__ xs,
@@ -530,6 +756,12 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
 int launch_bins(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, float width, NlistBuffers& b) {
   NlistSystem* sys = (NlistSystem*)b.sys;
   const int max_bins = n_atoms + 8 * n_mol + 8;
+  if (b.bins_done && b.prebinned_width == width && width > 0.0f) {  // launch_prep_small did everything for this width
+    b.bins_done = false;
+    b.prebinned_width = 0.0f;
+    return 0;
+  }
+  b.bins_done = false;
   if (b.prebinned_width == width && width > 0.0f) {
     b.prebinned_width = 0.0f;  // launch_wrap already set the grids up and counted the atoms per bin for this width
   } else {

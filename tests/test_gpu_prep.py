@@ -1,0 +1,101 @@
+"""The single-launch preparation of small periodic batches (csrc/nlist.hip, prep_small_kernel; engine option "prep_fused") against
+the seven separate kernels it replaces: the neighbour rows, hence every output, must be bitwise identical, and the input sanity
+flags must be raised the same way."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+import test_gpu_parity as P
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def both(eng, fn):
+    out = []
+    try:
+        for v in (1, 0):
+            eng.set_option("prep_fused", v)
+            out.append(fn())
+    finally:
+        eng.set_option("prep_fused", 1)
+    return out
+
+
+@pytest.mark.parametrize("name", ["pbc96_dsf15", "pbc96_dsf8_wrapped", "pbc2x96_dsf9"])
+def test_fixtures_bitwise(hip_engine, name):
+    g = golden(name)
+    kw = dict(dsf_rc=float(g["dsf_rc"]), dsf_alpha=float(g["dsf_alpha"]))
+    a, b = both(hip_engine, lambda: P.run(hip_engine, g, "dsf", stress=True, **kw)[0])
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    P.compare(a, g, 96, name + "/reference golden (fused preparation)")
+
+
+@pytest.mark.parametrize("dftd3", [False, True])
+def test_supercell_bitwise(hip_engine, dftd3):
+    """2 016 atoms in a triclinic-free but many-bin cell, atoms displaced across the cell faces (wrapping), with and without the
+    species pass the D3 term needs."""
+    from aimnetcentral_amd import workloads
+
+    c, z, cell = workloads.glucose_supercell((3, 2, 3) if not dftd3 else (2, 2, 2))
+    rng = np.random.default_rng(11)
+    c = (c + rng.normal(0.0, 0.03, c.shape) + rng.integers(-1, 2, (len(z), 3)) @ cell).astype(np.float32)
+    dev = hip_engine.device
+    kw = {}
+    if dftd3:
+        par, tables = P._d3(9.0)
+        hip_engine.set_dftd3_tables(tables)
+        kw["dftd3"] = par
+
+    def go():
+        r = hip_engine.eval(torch.from_numpy(c).to(dev), torch.from_numpy(z).to(dev), torch.zeros(len(z), dtype=torch.int64, device=dev),
+                            torch.zeros(1, device=dev), cell=torch.from_numpy(cell.astype(np.float32)).to(dev), forces=True, stress=True,
+                            coulomb="dsf", dsf_rc=9.0, **kw)
+        return {k: v.cpu().numpy() for k, v in r.items()}
+
+    a, b = both(hip_engine, go)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.isfinite(a["energy"]).all() and np.abs(a["forces"]).max() > 0
+
+
+@pytest.mark.parametrize("seed", [1, 5, 9, 13, 17, 21, 25, 29])
+def test_strained_triclinic_cells_bitwise(hip_engine, seed):
+    """The periodic cases of the randomised sweep (strained cells, vacancies, atoms moved out of the box by lattice vectors, one or
+    two systems, mixed periodicity): wrapping and binning use one pinned arithmetic form (cellwalk.h, cell_frac / wrap_into_cell),
+    so the two preparations agree to the bit here too - with the compiler's own contraction choices they differed in the last bit
+    of the wrapped coordinates, which these hot geometries turn into 1e-5 eV."""
+    import test_gpu_fuzz as Z
+
+    case = Z.make_case(seed)
+    assert "cell" in case[6]
+    a, b = both(hip_engine, lambda: Z.run_case(hip_engine, case))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), (k, case[-1])
+
+
+def test_bad_inputs_are_flagged_the_same(hip_engine):
+    g = golden("pbc96_dsf15")
+    dev = hip_engine.device
+    cell = torch.from_numpy(g["cell"]).to(dev)
+    coord = torch.from_numpy(g["coord"]).to(dev)
+    charge = torch.zeros(1, device=dev)
+    z_bad = g["numbers"].copy()
+    z_bad[17] = 77
+    mol_bad = np.zeros(96, dtype=np.int64)
+    mol_bad[40] = 3
+    for numbers, mol in ((z_bad, np.zeros(96, dtype=np.int64)), (g["numbers"], mol_bad)):
+        msgs = []
+        for v in (1, 0):
+            hip_engine.set_option("prep_fused", v)
+            try:
+                with pytest.raises(ValueError) as ei:
+                    hip_engine.eval(coord, torch.from_numpy(numbers).to(dev), torch.from_numpy(mol).to(dev), charge, cell=cell, forces=True,
+                                    coulomb="dsf", dsf_rc=9.0)
+                msgs.append(str(ei.value))
+            finally:
+                hip_engine.set_option("prep_fused", 1)
+        assert msgs[0] == msgs[1]

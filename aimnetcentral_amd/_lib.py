@@ -11,9 +11,9 @@ import os
 from functools import lru_cache
 
 MAX_PASS, MAX_LAYERS, MAX_SHIFTS = 4, 6, 32
-ABI_VERSION = 8  # AIMNET_ABI_VERSION of include/aimnet_hip.h this binding was written against
+ABI_VERSION = 9  # AIMNET_ABI_VERSION of include/aimnet_hip.h this binding was written against
 FORCES, STRESS = 1, 2
-COULOMB_NONE, COULOMB_SIMPLE, COULOMB_DSF = 0, 1, 2
+COULOMB_NONE, COULOMB_SIMPLE, COULOMB_DSF, COULOMB_EWALD = 0, 1, 2, 3
 E_INVALID, E_HIP, E_WORKSPACE = -1, -2, -3
 PROF_FAMILIES = ("nlist", "geom", "conv_fwd", "gemm", "pointwise", "coulomb", "unconcat", "conv_bwd", "other")
 
@@ -129,6 +129,8 @@ class EvalOptions(C.Structure):
         ("d3_cutoff", C.c_float),
         ("d3_smoothing_on", C.c_float),
         ("max_nb_d3", C.c_int32),
+        ("ewald_accuracy", C.c_float),
+        ("ewald_max_k", C.c_int32),
     ]
 
 

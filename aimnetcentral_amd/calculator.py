@@ -121,6 +121,7 @@ class AIMNet2Calculator:
         self._coulomb_method: str | None = None
         self._coulomb_cutoff: float | None = None
         self._dsf_alpha, self._dsf_rc = 0.2, 15.0
+        self._ewald_accuracy = 1e-6
         if final_needs_coulomb:
             sr_embedded = (metadata or {}).get("coulomb_mode") == "sr_embedded"
             subtract_sr = not sr_embedded
@@ -267,15 +268,23 @@ class AIMNet2Calculator:
                 warnings.warn("Model has embedded Coulomb module (legacy format). set_lrcoulomb_method() only affects "
                               "external Coulomb modules.", stacklevel=2)
             return
-        if method in ("ewald", "pme"):
-            raise NotImplementedError(f"Coulomb method {method!r} is not implemented by the native engine (use 'dsf')")
         self._coulomb_method = method
         if method == "dsf":
             self._dsf_alpha, self._dsf_rc = float(dsf_alpha), float(cutoff)
             self._coulomb_cutoff = float(cutoff)
+        elif method in ("ewald", "pme"):
+            # calculator.py:704-720: `cutoff` is ignored, the real- and reciprocal-space cutoffs follow from the accuracy per call
+            # (eta = (V^2 / N)^(1/6) / sqrt(2 pi), rc = sqrt(-2 ln acc) eta, kc = sqrt(-2 ln acc) / eta, calculator.py:660-667 - on the
+            # device, csrc/ewald.hip).  "pme" requests are served by the same exact structure-factor sum (no mesh): the same energy
+            # to the requested accuracy.
+            self._ewald_accuracy = float(ewald_accuracy)
+            self._coulomb_cutoff = None
         else:
             self._coulomb_cutoff = float("inf")
-        self.cutoff_lr = self._coulomb_cutoff
+        if self._coulomb_cutoff is not None:
+            self.cutoff_lr = self._coulomb_cutoff
+        else:
+            self.cutoff_lr = self._dftd3_cutoff if self.external_dftd3 is not None else None
 
     def _dftd3_options(self) -> dict[str, float] | None:
         d3 = self.external_dftd3
@@ -405,6 +414,9 @@ class AIMNet2Calculator:
         and fail without them; periodic input needs the shifts."""
         if not ext:
             return {}
+        if method in ("ewald", "pme"):
+            raise ValueError("caller-supplied neighbour matrices are not taken with the Ewald methods: the real-space sum walks the "
+                             "engine's own cell grid (the reference builds its own per-call list for them too, calculator.py:1560-1603)")
         if "nbmat_lr" not in ext and (method in ("simple", "dsf") or self._dftd3_options() is not None):
             raise KeyError("nbmat_lr: with a caller-supplied 'nbmat' the external Coulomb / DFT-D3 terms need 'nbmat_lr' as well")
         if cell is not None and ("shifts" not in ext or ("nbmat_lr" in ext and "shifts_lr" not in ext)):
@@ -489,6 +501,9 @@ class AIMNet2Calculator:
             restore = (self._coulomb_method, self._coulomb_cutoff, self.cutoff_lr, self._dsf_alpha, self._dsf_rc)
             self.set_lrcoulomb_method("dsf")
             method = "dsf"
+        if method in ("ewald", "pme") and cell is None:  # calculator.py:1063-1068
+            raise ValueError(f"Coulomb method '{method}' requires a periodic 'cell' in the input data. Provide a (3,3) or (B,3,3) cell "
+                             "tensor, or switch to a non-periodic method via set_lrcoulomb_method('simple' | 'dsf').")
         try:
             pbc3 = (True, True, True)
             if pbc is not None:
@@ -505,7 +520,8 @@ class AIMNet2Calculator:
             res = self.engine.eval(
                 coord_f, numbers_f, mol_idx, self._engine_charge(charge, d.get("mult")), cell=cell, pbc=pbc3, forces=bool(forces),
                 stress=bool(stress),
-                coulomb=method or "none", dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, dftd3=self._dftd3_options(),
+                coulomb=method or "none", dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, ewald_accuracy=self._ewald_accuracy,
+                dftd3=self._dftd3_options(),
                 **({"host_out": True} if host_out else {}), **({"sync": False, "defer": True} if defer_status else {}),
                 **self._check_caller_lists(ext_lists, method, cell))
         finally:
@@ -616,7 +632,7 @@ class AIMNet2Calculator:
                 x, numbers.repeat(kk * m), torch.arange(kk * m, device=self.device, dtype=torch.int32).repeat_interleave(n),
                 charge.repeat(kk * m, *([1] * (charge.ndim - 1))), cell=cell, pbc=pbc3, forces=True, stress=False,
                 coulomb=method or "none",
-                dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, dftd3=self._dftd3_options())
+                dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, ewald_accuracy=self._ewald_accuracy, dftd3=self._dftd3_options())
             f = res["forces"].view(kk, m, n, 3)
             out[k0 : k0 + kk] = (f * weights).sum(dim=1) * scale[k0 : k0 + kk].view(kk, 1, 1)
         return out
@@ -634,7 +650,9 @@ class AIMNet2Calculator:
 
         if self.hvp_method not in ("analytic", "fd"):
             raise ValueError(f"hvp_method must be 'analytic' or 'fd', got {self.hvp_method!r}")
-        if self.hvp_method == "fd":
+        if self.hvp_method == "fd" or self._coulomb_method in ("ewald", "pme"):
+            # Ewald: differences of the analytic forces (what the reference does for its PME block, lr.py:903-926); the tangent
+            # sweep of csrc/hvp.hip covers the pair-wise Coulomb methods only
             return self._fd_hvp(d, dirs, eps)
         cell = d.get("cell")
         method = self._coulomb_method

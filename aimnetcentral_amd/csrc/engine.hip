@@ -190,6 +190,7 @@ struct Workspace {
   int *d3_idx, *d3_shift, *d3_cnt;   // DFT-D3 neighbour matrix (aliases the LR list when both use one cutoff)
   float *d3w, *dEdcn;                // per-atom D3 reference weights (12 floats) and dE/dCN
   float4* d3xs;                      // (x, y, z, species slot) per atom: one 16 B gather per D3 neighbour
+  EwaldBuffers ew;                   // Ewald: per-system parameters, fractional coordinates, k entries (ewald.hip)
   int* aslot;                        // species slot of every atom (pass-0 moments, DFT-D3)
   unsigned long long* present_part;  // per-block masks of the slots present
   int n_part;
@@ -241,6 +242,13 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
     W.d3w = c.take<float>(d3 ? n * 12 : 0);
     W.dEdcn = c.take<float>(d3 ? n : 0);
     W.d3xs = c.take<float4>(d3 ? n : 0);
+  }
+  {
+    const bool ew = opt->coulomb == AIMNET_COULOMB_EWALD;
+    W.ew.max_k = ew ? std::max(EWALD_KB, opt->ewald_max_k / EWALD_KB * EWALD_KB) : 0;
+    W.ew.sys = c.take<EwaldSystem>(ew ? (size_t)n_mol : 0);
+    W.ew.frac = c.take<double>(ew ? n * 3 : 0);
+    W.ew.k = c.take<EwaldK>(ew ? (size_t)W.ew.max_k : 0);
   }
   W.pg = c.take<float4>(n * cap, "pair_geom", cap);
   char name[32];
@@ -669,6 +677,21 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     set_last_error("eval: 'simple' Coulomb is undefined for periodic input (host must switch to DSF, calculator.py:1044)");
     return AIMNET_E_INVALID;
   }
+  if (coulomb == AIMNET_COULOMB_EWALD) {
+    if (!pbc || in->pbc_sys || !(in->pbc[0] && in->pbc[1] && in->pbc[2])) {
+      set_last_error("eval: Ewald summation needs a cell that is periodic along all three axes (lr.py:655-657)");
+      return AIMNET_E_INVALID;
+    }
+    if (in->nbmat) {
+      set_last_error("eval: Ewald summation walks the engine's own cell grid: caller-supplied neighbour matrices are not taken with it "
+                     "(the reference builds its own per-call list for this method too, calculator.py:1560-1603)");
+      return AIMNET_E_INVALID;
+    }
+    if (!(opt->ewald_accuracy > 0.0f && opt->ewald_accuracy < 1.0f) || opt->ewald_max_k < EWALD_KB) {
+      set_last_error("eval: Ewald summation needs 0 < ewald_accuracy < 1 and ewald_max_k >= %d", EWALD_KB);
+      return AIMNET_E_INVALID;
+    }
+  }
   // caller-supplied neighbour matrices (aimnet_inputs.nbmat ...): no list is built, the coordinates are taken as given
   const bool ext = in->nbmat != nullptr;
   if (ext) {
@@ -834,8 +857,14 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     cp.sr_envelope = ar.sr_envelope;
     cp.dsf_rc = opt->dsf_rc;
     cp.dsf_alpha = opt->dsf_alpha;
-    const bool walk = coulomb == AIMNET_COULOMB_DSF && pbc && !ext &&
-                      !(d3 && opt->d3_cutoff == opt->dsf_rc);  // the list-free DSF walk runs below: its charge stream rides here
+    const bool ewald = coulomb == AIMNET_COULOMB_EWALD;
+    if (ewald) {  // per-system (alpha, rc, kc) and k boxes from the cell, fractional coordinates in double (ewald.hip)
+      RC(launch_ewald_setup(cs, in->cell, n_cell, W.nl.mol_start, mol_c, W.nl.xw, in->charge, nq, N, n_mol, opt->ewald_accuracy, W.ew,
+                            out->status + 7));
+      cp.ewald = W.ew.sys;
+    }
+    const bool walk = ewald || (coulomb == AIMNET_COULOMB_DSF && pbc && !ext &&
+                                !(d3 && opt->d3_cutoff == opt->dsf_rc));  // the list-free walk runs below: its charge stream rides here
     SrRiders rd = head_rider;
     if (walk) {
       rd.xs = W.nl.xs;
@@ -861,11 +890,14 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       ;  // ran inside the SR-Coulomb launch above (SrRiders::simple_xw)
     else if (dsf_in_d3)
       ;  // see launch_dftd3 below
-    else if (coulomb == AIMNET_COULOMB_DSF && pbc && !ext) {
+    else if (ewald || (coulomb == AIMNET_COULOMB_DSF && pbc && !ext)) {
       RC(launch_coulomb_dsf_walk(cs, grad, want_s, q_fin, mol_c, W.nl, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom,
                                  out->charges, true, rev_done ? nullptr : &pmap));
       rev_done = true;
       charges_written = true;
+      if (ewald)  // reciprocal space + neutralising background, accumulated onto what the pair kernels have stored
+        RC(launch_ewald_recip(cs, grad, want_s, q_fin, mol_c, W.nl.mol_start, N, n_mol, W.ew, cp.factor, W.ecoul, W.qbar, W.fgrad,
+                              W.virial_atom));
     } else if (coulomb == AIMNET_COULOMB_DSF)
       RC(launch_coulomb_dsf(cs, grad, want_s, q_fin, W.nl.xw, mol_c, in->cell, n_cell, W.lr_idx, W.lr_shift, W.lr_cnt,
                             cap_lr, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom));

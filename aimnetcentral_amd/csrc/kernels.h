@@ -216,11 +216,44 @@ int launch_energy_reduce(hipStream_t s, const float* e_atom, const double* ecoul
                          // copy_dst != NULL: copy_n floats copy_src -> copy_dst ride on the same launch (the charges output)
                          const float* copy_src = nullptr, float* copy_dst = nullptr, int copy_n = 0,
                          const PairMapRider* rev_rider = nullptr);  // the lookup of the reverse-pair map rides on this launch
+// ---- ewald.hip: Ewald summation of a periodic system (LRCoulomb "ewald", lr.py:617-720) ------------------------------------
+struct EwaldSystem {   // per periodic system, written by ewald_setup_kernel from the cell, the atom count and the accuracy
+  float alpha, rc;     // splitting parameter, real-space cutoff
+  float kc2, inv4a2;   // reciprocal-space cutoff squared, 1 / (4 alpha^2)
+  float phi_bg;        // potential of the neutralising background, -pi Q / (V alpha^2)
+  int nmax[3];         // |n_a| <= nmax[a]: the box of integer triplets that holds the k sphere
+  int n2w, n3w;        // 2 nmax[1] + 1, 2 nmax[2] + 1
+  int k_offset, n_box; // this system's slice [k_offset, k_offset + n_box) of the k arrays (a multiple of EWALD_KB entries)
+  double pref;         // 8 pi / V (the potential's prefactor, half space doubled)
+  double b[9];         // k_c = sum_a n_a b[a * 3 + c]
+  double inv[9];       // fractional coordinate a = sum_c x_c inv[c * 3 + a]
+};
+struct EwaldK {        // one entry of the k box (P = Q = 0: outside the half-space sphere)
+  double P, Q;         // A(k) Re S(k), A(k) Im S(k);  A = pref exp(-k^2 / 4 alpha^2) / k^2
+  float kx, ky, kz, vfac;  // the k vector; 2 (1 / k^2 + 1 / (4 alpha^2)) for the strain derivative
+  int n1, n2, n3, pad;
+};
+constexpr int EWALD_KB = 8;  // k entries per block of the structure-factor kernel
+struct EwaldBuffers {  // device pointers carved from the workspace
+  EwaldSystem* sys;    // [n_mol]
+  double* frac;        // [n_atoms][3] fractional coordinates in double
+  EwaldK* k;           // [max_k]
+  int max_k;
+};
+// parameters + k boxes of every system; *status_k = k entries the batch needs (> max_k: the boxes were truncated, results meaningless)
+int launch_ewald_setup(hipStream_t s, const float* cell, int n_cell, const int* mol_start, const int* mol_idx, const float* xw,
+                       const float* charge, int nq, int n_atoms, int n_mol, float accuracy, EwaldBuffers& b, int* status_k);
+// reciprocal-space sum + neutralising background, ACCUMULATED onto the per-atom energies / adjoints the pair kernels have stored
+int launch_ewald_recip(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, const int* mol_start, int n_atoms,
+                       int n_mol, const EwaldBuffers& b, float factor, double* ecoul, float* qbar, float* fgrad, float* virial_atom);
+
 struct CoulombParams {
   float factor;      // 1/2 Hartree Bohr
   float sr_rc;       // exp / cosine envelope radius (SRCoulomb)
   int sr_envelope;   // 0 exp, 1 cosine
   float dsf_rc, dsf_alpha;
+  const EwaldSystem* ewald = nullptr;  // != NULL: the list-free walk sums the REAL-space Ewald term erfc(alpha d) / d with the
+                                       // system's own (alpha, rc) instead of the shifted DSF pair term
 };
 
 // ---- d3.hip: DFT-D3(BJ) two-body dispersion on a full neighbour list ------------------------------

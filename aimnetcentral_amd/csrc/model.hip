@@ -615,11 +615,14 @@ __global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __re
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
   float4* Q = queue[threadIdx.x >> 6];
-  const float al = cp.dsf_alpha, Rc = cp.dsf_rc;
+  // Ewald (cp.ewald): the real-space term erfc(alpha d) / d inside the system's own cutoff - the same pair term without the DSF
+  // shift and force-shift, the same self term -alpha / sqrt(pi) q_i^2 (ewald.hip adds reciprocal space and the background)
+  const bool ewald = cp.ewald != nullptr;
+  const float al = ewald ? cp.ewald[mol_idx[i]].alpha : cp.dsf_alpha, Rc = ewald ? cp.ewald[mol_idx[i]].rc : cp.dsf_rc;
   const float two_a_sqrtpi = 2.0f * al * 0.56418958354775629f;
   const float erfc_rc = erfcf(al * Rc);
-  const float sv = erfc_rc / Rc;
-  const float slope = erfc_rc / (Rc * Rc) + two_a_sqrtpi * expf(-al * al * Rc * Rc) / Rc;
+  const float sv = ewald ? 0.0f : erfc_rc / Rc;
+  const float slope = ewald ? 0.0f : erfc_rc / (Rc * Rc) + two_a_sqrtpi * expf(-al * al * Rc * Rc) / Rc;
   const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2], qi = q[i];
   PairAcc A;
   auto pair_term = [&](const float4& e) {

@@ -129,6 +129,7 @@ class HipEngine:
         self._max_nb_lr: dict[float, int] = {}
         self.last_status: np.ndarray | None = None
         self.has_dftd3 = False
+        self._ewald_max_k = 8192  # capacity of the Ewald k arrays (entries; grows to what status[7] reports)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -193,6 +194,9 @@ class HipEngine:
             for rc in list(self._max_nb_lr):
                 self._max_nb_lr[rc] = _round16(int(max(self._max_nb_lr[rc] * 1.5, st[:, 1].max(), st[:, 4].max())))
             grown = True
+        if st[:, 7].max() > self._ewald_max_k:  # Ewald k arrays (status[7] is 0 for the other methods)
+            self._ewald_max_k = (int(st[:, 7].max()) * 5 // 4 + 7) // 8 * 8
+            grown = True
         if grown:
             raise NeighborOverflowError("neighbour-row overflow in one of the last %d deferred evaluations: their results are invalid; "
                                         "the row capacity has been grown - repeat them" % len(st))
@@ -215,6 +219,7 @@ class HipEngine:
         coulomb: str = "simple",
         dsf_rc: float = 15.0,
         dsf_alpha: float = 0.2,
+        ewald_accuracy: float = 1e-6,
         sync: bool = True,
         dftd3: dict[str, float] | None = None,
         host_out: bool = False,
@@ -268,7 +273,16 @@ class HipEngine:
                 raise ValueError(f"pbc must have shape (3,) or ({n_cell}, 3), got {tuple(pbc_sys.shape)}")
         elif not isinstance(pbc, (tuple, list)):
             pbc = tuple(bool(x) for x in torch.as_tensor(pbc).reshape(-1).tolist())
-        method = {"none": _lib.COULOMB_NONE, "simple": _lib.COULOMB_SIMPLE, "dsf": _lib.COULOMB_DSF}[coulomb]
+        # "pme" requests take the exact structure-factor sum too: the same energy to the requested accuracy (csrc/ewald.hip)
+        method = {"none": _lib.COULOMB_NONE, "simple": _lib.COULOMB_SIMPLE, "dsf": _lib.COULOMB_DSF, "ewald": _lib.COULOMB_EWALD,
+                  "pme": _lib.COULOMB_EWALD}[coulomb]
+        if method == _lib.COULOMB_EWALD:
+            if cell is None:
+                raise ValueError(f"HipEngine.eval: coulomb={coulomb!r} needs a periodic cell (lr.py:655-657)")
+            if nbmat is not None:
+                raise ValueError("HipEngine.eval: Ewald summation does not take caller-supplied neighbour matrices")
+            if not (0.0 < float(ewald_accuracy) < 1.0):
+                raise ValueError("HipEngine.eval: ewald_accuracy must lie in (0, 1)")
         ext = {}
         for key, mat, sh in (("nbmat", nbmat, shifts), ("nbmat_lr", nbmat_lr, shifts_lr), ("nbmat_d3", nbmat_d3, shifts_d3)):
             if mat is None:
@@ -320,6 +334,9 @@ class HipEngine:
             opt.max_nb = self.max_nb
             # periodic DSF walks the cell grid (no list); only non-periodic DSF materialises a long-range list
             opt.max_nb_lr = self._lr_capacity(float(dsf_rc)) if (method == _lib.COULOMB_DSF and cell is None) else 0
+            if method == _lib.COULOMB_EWALD:
+                opt.ewald_accuracy = float(ewald_accuracy)
+                opt.ewald_max_k = self._ewald_max_k
             if ext:  # caller-supplied matrices: the row capacities are their widths (nothing can overflow)
                 opt.max_nb = _round16(ext["nbmat"][0].shape[1])
                 opt.max_nb_lr = _round16(ext["nbmat_lr"][0].shape[1]) if "nbmat_lr" in ext else 0
@@ -397,6 +414,9 @@ class HipEngine:
                 retry = True
             if st[3]:
                 self._max_nb_lr[float(dsf_rc)] = _round16(int(max(opt.max_nb_lr * 1.5, st[1])))
+                retry = True
+            if method == _lib.COULOMB_EWALD and st[7] > opt.ewald_max_k:  # the k boxes did not fit: their size is now known
+                self._ewald_max_k = (int(st[7]) * 5 // 4 + 7) // 8 * 8
                 retry = True
             if st[5]:  # D3 list (it may be stored in the LR buffers: grow both capacities)
                 d3_rc = float(dftd3.get("cutoff", 15.0))

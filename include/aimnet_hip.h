@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define AIMNET_ABI_VERSION 8
+#define AIMNET_ABI_VERSION 9
 
 #define AIMNET_OK 0
 #define AIMNET_E_INVALID (-1)   /* bad argument / unsupported architecture */
@@ -52,6 +52,8 @@ extern "C" {
 #define AIMNET_COULOMB_NONE 0
 #define AIMNET_COULOMB_SIMPLE 1 /* all pairs inside a molecule, lr.py:311-331 */
 #define AIMNET_COULOMB_DSF 2    /* damped shifted force, lr.py:559-615 */
+#define AIMNET_COULOMB_EWALD 3  /* Ewald summation of a fully periodic system, lr.py:617-720 (`ewald`; `pme` requests take the same
+                                   exact structure-factor sum): options.ewald_accuracy, options.ewald_max_k */
 
 /* Architecture of one AIMNet2 core model (aimnet/models/aimnet2.py:12-106 hyper-parameters). */
 typedef struct aimnet_arch {
@@ -138,6 +140,13 @@ typedef struct aimnet_eval_options {
   float d3_cutoff;         /* Angstrom: list cutoff = end of the S5 switch (smoothing_off, 15.0) */
   float d3_smoothing_on;   /* Angstrom: start of the S5 switch (cutoff * (1 - smoothing_fraction), 12.0) */
   int32_t max_nb_d3;       /* row capacity of the D3 neighbour matrix */
+  /* AIMNET_COULOMB_EWALD: target accuracy of the splitting (set_lrcoulomb_method(..., ewald_accuracy=1e-6), calculator.py
+   * :1566-1586; alpha, the real-space cutoff and the reciprocal-space cutoff follow from it, the cell volume and the atom count
+   * of every system, on the device) and the capacity of the k arrays (entries of the integer boxes that hold the k spheres, summed
+   * over the systems, a multiple of 8).  status[7] reports the entries the batch needed: > ewald_max_k means the sums were
+   * truncated - evaluate again with at least that capacity. */
+  float ewald_accuracy;
+  int32_t ewald_max_k;
 } aimnet_eval_options;
 
 typedef struct aimnet_outputs {
@@ -152,7 +161,8 @@ typedef struct aimnet_outputs {
                                 [0, n_mol), bit 2 mol_idx not sorted, bit 3 a caller-supplied matrix holds a shift outside +-127
                                 or an unshifted self pair, bit 4 the caller-supplied short-range matrix is not symmetric.  The first kernel writes clamped copies (atomic number
                                 slots, mol_idx) into the workspace and every later kernel indexes through those, so any device
-                                array is memory-safe; with a flag raised the results are meaningless.  7 reserved */
+                                array is memory-safe; with a flag raised the results are meaningless.
+                              7 Ewald: k-array entries the batch needs (compare with options.ewald_max_k; 0 for other methods) */
   float* spin_charges; /* [n_atoms] alpha - beta of an NSE model (aimnet2.py:103), or NULL; must be NULL for 1-channel models */
 } aimnet_outputs;
 

@@ -16,6 +16,11 @@ It restates, op for op, the PyTorch eager sequence of the reference (all paths r
   * AIMNet2.forward models/aimnet2.py:141-187 (_update_q :122-139), ops.nse ops.py:99-145
   * Output/AtomicShift/AtomicSum modules/core.py:71-132, SRCoulomb lr.py:986-1032 (_calc_coulomb_sr :21-62)
   * LRCoulomb.coul_simple lr.py:311-331, _coul_dsf_torch lr.py:559-615
+  * LRCoulomb "ewald" (lr.py:617-720, calculator.py:1560-1603): PARITY UNPINNED against the reference - the arithmetic and the
+    parameter estimate live in nvalchemi-toolkit-ops 0.4.0 (ewald_summation / estimate_ewald_parameters), which is not in the
+    reference tree.  Restated here from the published method (Ewald 1921; the cost-balanced parameter choice
+    eta = (V^2 / N)^(1/6) / sqrt(2 pi), rc = sqrt(-2 ln eps) eta, kc = sqrt(-2 ln eps) / eta, alpha = 1 / (sqrt(2) eta)) and
+    pinned to published Madelung constants and to an fp64 direct lattice sum (tests/test_oracle_ewald.py).
   * derivatives: calculators/derivatives.py:47-146 (autograd forces; row-vector strain stress)
 Forces/stress come from torch.autograd exactly as in the reference; oracle/aimnet2_analytic.py
 holds the hand-derived backward that the HIP kernels implement and is itself checked against
@@ -323,6 +328,47 @@ def dftd3_energy(d_ij: Tensor, mask: Tensor, numbers_p: Tensor, nbmat: Tensor, m
     return HALF_HARTREE * _mol_sum(e_ij.sum(-1), mol_p, n_mol)
 
 
+# --------------------------------------------------------------------------------------------
+# Ewald summation (periodic point charges in a neutralising background)
+# --------------------------------------------------------------------------------------------
+def ewald_parameters(n_atoms: int, volume: float, accuracy: float) -> tuple[float, float, float]:
+    """(alpha, real-space cutoff, reciprocal-space cutoff) of one system for a target accuracy: the choice that balances the two
+    sums (both O(N^1.5)); what estimate_ewald_parameters of nvalchemiops documents (called at calculator.py:1572-1578)."""
+    eta = (volume * volume / max(n_atoms, 1)) ** (1.0 / 6.0) / math.sqrt(2.0 * math.pi)
+    f = math.sqrt(-2.0 * math.log(accuracy))
+    return 1.0 / (math.sqrt(2.0) * eta), f * eta, f / eta
+
+
+def ewald_kvectors(cell: np.ndarray, kc: float) -> np.ndarray:
+    """Integer triplets n of the half space (n1 > 0, or n1 = 0 and n2 > 0, or n1 = n2 = 0 and n3 > 0) with |2 pi n C^-T| <= kc."""
+    c = np.asarray(cell, dtype=np.float64)
+    binv = 2.0 * math.pi * np.linalg.inv(c).T  # rows: reciprocal vectors
+    nmax = [int(math.floor(kc * np.linalg.norm(c[a]) / (2.0 * math.pi))) for a in range(3)]
+    g = np.stack(np.meshgrid(np.arange(0, nmax[0] + 1), np.arange(-nmax[1], nmax[1] + 1), np.arange(-nmax[2], nmax[2] + 1), indexing="ij"),
+                 axis=-1).reshape(-1, 3)
+    half = (g[:, 0] > 0) | ((g[:, 0] == 0) & (g[:, 1] > 0)) | ((g[:, 0] == 0) & (g[:, 1] == 0) & (g[:, 2] > 0))
+    g = g[half]
+    k = g @ binv
+    return g[(k * k).sum(-1) <= kc * kc]
+
+
+def ewald_reciprocal(x: Tensor, q: Tensor, cell: Tensor, n_half: np.ndarray, alpha: float, chunk: int = 256) -> Tensor:
+    """E_rec / k_e = (2 pi / V) sum_{k != 0} exp(-k^2 / 4 alpha^2) / k^2 |S(k)|^2 (written over the half space) minus the
+    neutralising-background term pi Q^2 / (2 V alpha^2); x [n,3], q [n], cell [3,3] (strained cell: k follows the strain)."""
+    vol = torch.linalg.det(cell).abs()
+    binv = 2.0 * math.pi * torch.linalg.inv(cell).T
+    e = x.new_zeros(())
+    nh = torch.as_tensor(n_half, dtype=x.dtype)
+    for c0 in range(0, nh.shape[0], chunk):
+        k = nh[c0 : c0 + chunk] @ binv
+        k2 = (k * k).sum(-1)
+        th = x @ k.T
+        sre = (q.unsqueeze(-1) * torch.cos(th)).sum(0)
+        sim = (q.unsqueeze(-1) * torch.sin(th)).sum(0)
+        e = e + (torch.exp(-k2 / (4.0 * alpha * alpha)) / k2 * (sre * sre + sim * sim)).sum()
+    return 4.0 * math.pi / vol * e - math.pi * q.sum() ** 2 / (2.0 * vol * alpha * alpha)
+
+
 def evaluate(
     model: OracleModel,
     coord,
@@ -334,6 +380,7 @@ def evaluate(
     coulomb: str = "simple",
     dsf_rc: float = 15.0,
     dsf_alpha: float = 0.2,
+    ewald_accuracy: float = 1e-6,
     forces: bool = True,
     stress: bool = False,
     hessian: bool = False,
@@ -346,7 +393,7 @@ def evaluate(
     shifts_lr=None,
 ) -> dict[str, np.ndarray]:
     """One AIMNet2Calculator.eval on a flat (N,3) system (calculator.py:879-947) with external
-    Coulomb `coulomb` in {"simple","dsf","none"} and sr_embedded SRCoulomb subtraction."""
+    Coulomb `coulomb` in {"simple","dsf","ewald","none"} and sr_embedded SRCoulomb subtraction."""
     dt = model.dtype
     coord_np = np.asarray(coord, dtype=np.float32)
     n = coord_np.shape[0]
@@ -370,6 +417,18 @@ def evaluate(
         coulomb = "dsf"
         if nbmat_lr is None:
             nbmat_lr, shifts_lr = neighbor_list(coord_np, dsf_rc, mol, cell, pbc_np)
+    ew = None
+    if coulomb == "ewald":  # per-system parameters from the UNSTRAINED cell (constants of the evaluation)
+        if cell is None or not pbc_np.all():
+            raise ValueError("Ewald summation needs a cell that is periodic along all three axes (lr.py:655-657)")
+        cells_np = np.asarray(cell, dtype=np.float64).reshape(-1, 3, 3)
+        ew = []
+        for m_ in range(n_mol):
+            c_ = cells_np[m_ if cells_np.shape[0] > 1 else 0]
+            al_, rc_, kc_ = ewald_parameters(int((mol == m_).sum()), abs(np.linalg.det(c_)), ewald_accuracy)
+            ew.append((al_, rc_, kc_, ewald_kvectors(c_, kc_)))
+        if nbmat_lr is None:
+            nbmat_lr, shifts_lr = neighbor_list(coord_np, max(e_[1] for e_ in ew), mol, cell, pbc_np)
     nb = torch.as_tensor(nbmat)
     sh = None if shifts is None else torch.as_tensor(shifts).to(dt)
 
@@ -458,6 +517,20 @@ def evaluate(
         if coulomb == "simple":
             e_lr = (q_i * q_jl / d_lr).masked_fill(mask_lr, 0.0)
             energy = energy + pair_sum(e_lr)
+        elif coulomb == "ewald":
+            # real space: erfc(alpha d) / d inside the system's cutoff; self term -alpha / sqrt(pi) q_i^2; reciprocal space + background
+            al_at = d_lr.new_tensor([e_[0] for e_ in ew])[mol_p].unsqueeze(-1)
+            rc_at = d_lr.new_tensor([e_[1] for e_ in ew])[mol_p].unsqueeze(-1)
+            e_lr = (q_i * q_jl * torch.erfc(al_at * d_lr) / d_lr * (d_lr < rc_at).to(dt)).masked_fill(mask_lr, 0.0)
+            energy = energy + pair_sum(e_lr)
+            q_self = torch.cat([charges[:-1], torch.zeros_like(charges[:1])])
+            energy = energy + 2.0 * COULOMB_FACTOR * _mol_sum((-al_at.squeeze(-1) / math.sqrt(math.pi) * q_self.pow(2)).double(), mol_p, n_mol)
+            e_rec = []
+            for m_ in range(n_mol):
+                idx = torch.as_tensor(np.nonzero(mol == m_)[0])
+                c_ = cell_x if cell_x.ndim == 2 else cell_x[m_]
+                e_rec.append(ewald_reciprocal(x[idx], charges[idx], c_, ew[m_][3], ew[m_][0]))
+            energy = energy + 2.0 * COULOMB_FACTOR * torch.stack(e_rec).double()
         else:
             al = d_lr.new_tensor(dsf_alpha)
             rc = d_lr.new_tensor(dsf_rc)

@@ -28,8 +28,9 @@ class FakeEngine:
         self.d3_tables = tables
 
     def eval(self, coord, numbers, mol_idx, charge, cell=None, pbc=(True, True, True), forces=False, stress=False,
-             coulomb="simple", dsf_rc=15.0, dsf_alpha=0.2, sync=True, dftd3=None, host_out=False, **lists):
+             coulomb="simple", dsf_rc=15.0, dsf_alpha=0.2, ewald_accuracy=1e-6, sync=True, dftd3=None, host_out=False, **lists):
         self.calls.append(dict(lists=lists, host_out=host_out, n=coord.shape[0], n_mol=charge.shape[0], coulomb=coulomb, dsf_rc=dsf_rc, dsf_alpha=dsf_alpha, dftd3=dftd3,
+                               ewald_accuracy=ewald_accuracy,
                                pbc=pbc, cell=None if cell is None else tuple(cell.shape), mol_idx=mol_idx.clone(),
                                numbers=numbers.clone(), charge=charge.clone()))
         n = coord.shape[0]
@@ -137,11 +138,27 @@ def test_pbc_switches_to_dsf_for_one_eval_and_restores(calc):
     assert call["dsf_rc"] == 9.0 and call["dsf_alpha"] == 0.25 and calc.coulomb_method == "dsf"
 
 
+def test_ewald_methods_need_a_cell_and_carry_their_accuracy(calc):
+    """set_lrcoulomb_method("ewald" | "pme") (calculator.py:638-727): no fixed cutoff, the accuracy travels to the engine; without a
+    cell the evaluation raises the reference's ValueError (calculator.py:1063-1068)."""
+    calc.set_lrcoulomb_method("ewald", cutoff=9.0, ewald_accuracy=1e-7)
+    assert calc.coulomb_method == "ewald" and calc.coulomb_cutoff is None and calc.cutoff_lr is None
+    with pytest.raises(ValueError, match="requires a periodic 'cell'"):
+        calc(WATER)
+    cell = np.eye(3, dtype=np.float32) * 12.0
+    calc(dict(WATER, cell=cell), forces=True)
+    call = calc.engine.calls[-1]
+    assert call["coulomb"] == "ewald" and call["ewald_accuracy"] == 1e-7
+    calc.set_lrcoulomb_method("pme")
+    calc(dict(WATER, cell=cell))
+    assert calc.engine.calls[-1]["coulomb"] == "pme" and calc.engine.calls[-1]["ewald_accuracy"] == 1e-6
+    calc.set_lrcoulomb_method("simple")
+    assert calc.coulomb_cutoff == float("inf")
+
+
 def test_setters_and_unsupported_paths(calc):
     with pytest.raises(ValueError, match="Invalid method"):
         calc.set_lrcoulomb_method("nope")
-    with pytest.raises(NotImplementedError):
-        calc.set_lrcoulomb_method("ewald")
     with pytest.raises(AssertionError):
         calc(WATER, stress=True)
     x = torch.tensor(WATER["coord"], requires_grad=True)

@@ -136,3 +136,26 @@ def test_through_the_calculator_and_hvp_by_force_differences(oracle64):
     assert np.abs(hv - fd).max() < 2e-3 * max(1.0, np.abs(fd).max())
     with pytest.raises(ValueError, match="requires a periodic 'cell'"):
         calc(dict(coord=g["coord"], numbers=g["numbers"], charge=0.0))
+
+
+@pytest.mark.parametrize("seed", [1, 3, 5, 7, 9, 11, 13, 15, 19, 23, 27, 31])
+def test_random_cells(seed, hip_engine, hip_engine_nse, oracle32, oracle32_nse, oracle64, oracle64_nse):
+    """The periodic cases of the randomised sweep (tests/test_gpu_fuzz.py: strained triclinic cells, vacancies, atoms outside the
+    box, one or two systems, charged, open-shell NSE models, with and without the external DFT-D3 term) with the Coulomb method
+    switched to Ewald; gates as there."""
+    import test_gpu_fuzz as Z
+
+    case = Z.make_case(seed)
+    c, z, mol, q, mult, nse, kw, okw, d3, label = case
+    if not all(kw["pbc"]):
+        pytest.skip("slab geometry: Ewald summation needs three periodic axes")
+    acc = 1e-7
+    kw = dict({k: v for k, v in kw.items() if not k.startswith("dsf")}, coulomb="ewald", ewald_accuracy=acc)
+    okw = dict({k: v for k, v in okw.items() if not k.startswith("dsf")}, coulomb="ewald", ewald_accuracy=acc)
+    case = (c, z, mol, q, mult, nse, kw, okw, d3, label + " [ewald]")
+    eng, orc, orc64 = (hip_engine_nse, oracle32_nse, oracle64_nse) if nse else (hip_engine, oracle32, oracle64)
+    res = Z.run_case(eng, case)
+    ref = O.evaluate(orc, c, z, q, mol, return_intermediates=True, **okw)
+    ref64 = O.evaluate(orc64, c, z, q, mol, return_intermediates=True, **dict(okw, forces=False, stress=False))
+    wrapped = Z.run_case(eng, (ref["coord_wrapped"].astype(np.float32),) + case[1:])
+    Z._compare(res, ref, ref64, mol, case[-1], nse, wrapped["energy"])

@@ -159,3 +159,18 @@ def test_random_cells(seed, hip_engine, hip_engine_nse, oracle32, oracle32_nse, 
     ref64 = O.evaluate(orc64, c, z, q, mol, return_intermediates=True, **dict(okw, forces=False, stress=False))
     wrapped = Z.run_case(eng, (ref["coord_wrapped"].astype(np.float32),) + case[1:])
     Z._compare(res, ref, ref64, mol, case[-1], nse, wrapped["energy"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tiny_cells(seed, hip_engine, oracle32, oracle64):
+    """Cells of 3-4.5 A with 2-9 atoms (tests/test_gpu_fuzz.py, tiny_cells): the real-space cutoff spans several images of the
+    cell, the k boxes are a few dozen entries, every system of the batch has its own parameters."""
+    import test_gpu_fuzz as Z
+
+    c, z, mol, cell, n_sys, _ = Z.tiny_cells(seed)
+    q = np.zeros(n_sys, dtype=np.float32)
+    res = _run(hip_engine, c, z, mol, q, cell, ewald_accuracy=1e-7)
+    okw = dict(cell=cell, coulomb="ewald", ewald_accuracy=1e-7, stress=True)
+    ref = O.evaluate(oracle32, c, z, q, mol, return_intermediates=True, **okw)
+    ref64 = O.evaluate(oracle64, c, z, q, mol, return_intermediates=True, **dict(okw, forces=False, stress=False))
+    Z._compare(res, ref, ref64, mol, f"tiny cells + ewald seed {seed}", False)

@@ -149,11 +149,8 @@ def test_random_configuration(seed, hip_engine, hip_engine_nse, oracle32, oracle
     _compare(res, ref, ref64, mol, label, nse, energy)
 
 
-@pytest.mark.parametrize("seed", range(6))
-def test_tiny_cells_many_images(seed, hip_engine, oracle32, oracle64):
-    """Cells much smaller than the cutoffs (3-4.5 A edges, 2-9 atoms, triclinic): every atom sees many periodic images of
-    every other atom and of itself (lattice shifts up to +-4 at a 9 A DSF cutoff), plus many single-atom / few-atom
-    neighbour rows.  Also a batch of such cells with per-system cell matrices."""
+def tiny_cells(seed: int):
+    """(coord, numbers, mol_idx, cell, n_sys, rng) of test_tiny_cells_many_images."""
     rng = np.random.Generator(np.random.PCG64(7000 + seed))
     n_sys = 1 if seed % 2 == 0 else 3
     coords, zs, mols, cells = [], [], [], []
@@ -181,6 +178,15 @@ def test_tiny_cells_many_images(seed, hip_engine, oracle32, oracle64):
     z = np.concatenate(zs).astype(np.int64)
     mol = np.concatenate(mols).astype(np.int64)
     cell = (cells[0] if n_sys == 1 else np.stack(cells)).astype(np.float32)
+    return c, z, mol, cell, n_sys, rng
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tiny_cells_many_images(seed, hip_engine, oracle32, oracle64):
+    """Cells much smaller than the cutoffs (3-4.5 A edges, 2-9 atoms, triclinic): every atom sees many periodic images of
+    every other atom and of itself (lattice shifts up to +-4 at a 9 A DSF cutoff), plus many single-atom / few-atom
+    neighbour rows.  Also a batch of such cells with per-system cell matrices."""
+    c, z, mol, cell, n_sys, rng = tiny_cells(seed)
     rc, alpha = float(rng.uniform(7.0, 9.0)), 0.25
     dev = hip_engine.device
     r = hip_engine.eval(torch.from_numpy(c).to(dev), torch.from_numpy(z).to(dev), torch.from_numpy(mol).to(dev),

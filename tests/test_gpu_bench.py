@@ -8,6 +8,8 @@ import os
 import subprocess
 import sys
 
+import numpy as np
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -54,6 +56,9 @@ def test_default_workload_carries_the_parity_gate():
     assert 0.0 < d["roofline_e2e"]["frac_mixed"] < d["roofline_e2e"]["frac"] < 1.0
     assert d["roofline"]["gemm_launches_per_step"] == 21 and "mfma_busy_frac_in_kernel" in d["roofline"]
     assert d["roofline_gather"]["form"] == "reverse-pair" and "gemm_bf3a_kernel" in d["roofline"]["kernel"]
+    # the same frame with Ewald summation (its own record): slower than DSF by the reciprocal-space kernels, not by a factor
+    ew = d["ewald_config3"]
+    assert d["ms_per_step"] < ew["ms_per_step"] < 1.5 * d["ms_per_step"] and ew["k_box_entries"] > 1000 and np.isfinite(ew["energy_eV"])
 
 
 def test_two_ranks_share_the_gpu_over_gloo():

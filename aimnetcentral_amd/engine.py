@@ -495,6 +495,9 @@ class HipEngine:
             n_cell = 1 if cell.ndim == 2 else cell.shape[0]
         if not isinstance(pbc, (tuple, list)):
             pbc = tuple(bool(x) for x in torch.as_tensor(pbc).reshape(-1).tolist())[:3]
+        if coulomb in ("ewald", "pme"):
+            raise ValueError("HipEngine.hvp: the analytic tangent sweep covers the pair-wise Coulomb methods only; with Ewald summation use "
+                             "differences of the forces (AIMNet2Calculator does: hvp_method 'fd' is taken automatically)")
         method = {"none": _lib.COULOMB_NONE, "simple": _lib.COULOMB_SIMPLE, "dsf": _lib.COULOMB_DSF}[coulomb]
         hv = torch.empty_like(vectors)
         f_out = torch.empty(n, 3, dtype=torch.float32, device=dev) if want_forces else None

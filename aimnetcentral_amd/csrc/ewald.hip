@@ -72,16 +72,40 @@ __global__ void ewald_setup_kernel(const float* __restrict__ cell, int n_cell, c
     es[s] = E;
   }
   __syncthreads();
+  // slices of the k arrays: offsets = running sum of the box sizes padded to whole blocks of the structure-factor kernel.  The
+  // serial pass runs over LDS (a batch of 10^3 small cells would otherwise pay a dependent global round trip per system);
+  // batches beyond the LDS table take the slow form.
+  constexpr int TAB = 4096;
+  __shared__ int s_need[TAB];
+  __shared__ long s_total;
+  const bool in_lds = n_mol <= TAB;
+  if (in_lds)
+    for (int s = threadIdx.x; s < n_mol; s += blockDim.x) s_need[s] = (es[s].n_box + EWALD_KB - 1) / EWALD_KB * EWALD_KB;
+  __syncthreads();
   if (threadIdx.x == 0) {
     long off = 0;
-    for (int s = 0; s < n_mol; ++s) {  // slices padded to whole blocks of the structure-factor kernel
-      const long need = ((long)es[s].n_box + EWALD_KB - 1) / EWALD_KB * EWALD_KB;
-      es[s].k_offset = (int)min(off, (long)max_k);
-      es[s].n_box = (int)max(0L, min(need, (long)max_k - min(off, (long)max_k)));  // truncated when the capacity is too small (flagged)
+    for (int s = 0; s < n_mol; ++s) {
+      const long need = in_lds ? (long)s_need[s] : ((long)es[s].n_box + EWALD_KB - 1) / EWALD_KB * EWALD_KB;
+      const long at = min(off, (long)max_k);
+      const int take = (int)max(0L, min(need, (long)max_k - at));  // truncated when the capacity is too small (flagged)
+      if (in_lds) {
+        s_need[s] = (int)at;  // (the offset; the size follows from the next offset below)
+      } else {
+        es[s].k_offset = (int)at;
+        es[s].n_box = take;
+      }
       off += need;
     }
+    s_total = off;
     *status_k = (int)min(off, (long)INT32_MAX);
   }
+  __syncthreads();
+  if (in_lds)
+    for (int s = threadIdx.x; s < n_mol; s += blockDim.x) {
+      const long end = s + 1 < n_mol ? (long)s_need[s + 1] : min(s_total, (long)max_k);
+      es[s].k_offset = s_need[s];
+      es[s].n_box = (int)max(0L, min(end, (long)max_k) - (long)s_need[s]);
+    }
 }
 
 __global__ void ewald_frac_kernel(const float* __restrict__ xw, const int* __restrict__ mol_idx, int n_atoms,
@@ -243,7 +267,7 @@ __global__ __launch_bounds__(256) void ewald_atom_kernel(const double* __restric
 
 int launch_ewald_setup(hipStream_t s, const float* cell, int n_cell, const int* mol_start, const int* mol_idx, const float* xw,
                        const float* charge, int nq, int n_atoms, int n_mol, float accuracy, EwaldBuffers& b, int* status_k) {
-  hipLaunchKernelGGL(ewald_setup_kernel, dim3(1), dim3(64), 0, s, cell, n_cell, mol_start, charge, nq, n_mol, accuracy, b.max_k, b.sys,
+  hipLaunchKernelGGL(ewald_setup_kernel, dim3(1), dim3(256), 0, s, cell, n_cell, mol_start, charge, nq, n_mol, accuracy, b.max_k, b.sys,
                      status_k);
   AIMNET_LAUNCH_CHECK();
   hipLaunchKernelGGL(ewald_frac_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, xw, mol_idx, n_atoms, b.sys, b.frac);

@@ -174,3 +174,27 @@ def test_tiny_cells(seed, hip_engine, oracle32, oracle64):
     ref = O.evaluate(oracle32, c, z, q, mol, return_intermediates=True, **okw)
     ref64 = O.evaluate(oracle64, c, z, q, mol, return_intermediates=True, **dict(okw, forces=False, stress=False))
     Z._compare(res, ref, ref64, mol, f"tiny cells + ewald seed {seed}", False)
+
+
+def test_batch_of_many_small_cells(hip_engine, oracle32, oracle64):
+    """Fourteen cells of 2-9 atoms in one batch: fourteen parameter sets and k-box slices (the offsets are a scan over the batch)."""
+    import test_gpu_fuzz as Z
+
+    cs, zs, mols, cells = [], [], [], []
+    n_sys = 0
+    for seed in range(6):
+        c, z, mol, cell, n, _ = Z.tiny_cells(seed)
+        cs.append(c)
+        zs.append(z)
+        mols.append(mol + n_sys)
+        cells.append(cell.reshape(-1, 3, 3))
+        n_sys += n
+    c, z, mol, cell = np.concatenate(cs), np.concatenate(zs), np.concatenate(mols), np.concatenate(cells)
+    q = np.zeros(n_sys, dtype=np.float32)
+    q[3] = 1.0
+    res = _run(hip_engine, c, z, mol, q, cell)
+    okw = dict(cell=cell, coulomb="ewald", stress=True)
+    ref = O.evaluate(oracle32, c, z, q, mol, return_intermediates=True, **okw)
+    ref64 = O.evaluate(oracle64, c, z, q, mol, return_intermediates=True, **dict(okw, forces=False, stress=False))
+    Z._compare(res, ref, ref64, mol, f"{n_sys} tiny cells + ewald", False)
+    assert int(hip_engine.last_status[7]) % 8 == 0

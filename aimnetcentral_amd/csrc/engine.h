@@ -64,7 +64,7 @@ struct aimnet_engine {
   // AIMNET_HEAD_FUSED / set_option("head_fused"): with pre-split activations, the energy head 256 -> 128 -> 128 -> 1 runs forward
   // and backward in ONE launch (gemm_head.hip) instead of four N = 128 GEMM launches and the last-layer rider
   int head_fused = 1;
-  // AIMNET_PREP_FUSED / set_option("prep_fused"): periodic batches of up to 16 384 atoms / 64 systems prepare their cell grid in one
+  // AIMNET_PREP_FUSED / set_option("prep_fused"): periodic batches of up to 4 096 atoms / 64 systems prepare their cell grid in one
   // single-block launch (nlist.hip, prep_small_kernel) instead of seven small dependent ones.  0 = the separate kernels (any size).
   int prep_fused = 1;
   double* sae;

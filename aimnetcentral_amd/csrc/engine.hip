@@ -746,9 +746,10 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   RC(prof_mark(e, s, FAM_NLIST));
   const bool want_species = (e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS))) || opt->dftd3 != 0;
   // small periodic batches: status zeroing, molecule offsets / sanity / species, cell + bin setup, wrapping and binning in one launch
-  const bool prep1 = e->prep_fused && !ext && pbc && in->cell && prep_small_applies(N, n_mol);
+  const bool prep1 = e->prep_fused && !ext && prep_small_applies(N, n_mol, pbc);
   if (prep1) {
-    RC(launch_prep_small(s, in->coord, in->mol_idx, in->numbers, N, n_mol, in->cell, n_cell, in->pbc, in->pbc_sys, ar.rc, out->status,
+    RC(launch_prep_small(s, in->coord, in->mol_idx, in->numbers, N, n_mol, pbc ? in->cell : nullptr, n_cell, in->pbc, in->pbc_sys, ar.rc,
+                         out->status,
                          want_species ? e->slot_of_z : nullptr, W.aslot, W.present_part, W.nl));
   } else {
     AIMNET_HIP_CHECK(hipMemsetAsync(out->status, 0, 8 * sizeof(int), s));

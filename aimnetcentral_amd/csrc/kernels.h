@@ -98,8 +98,9 @@ int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, 
 // wrap coordinates (periodic) or copy them (non-periodic) into b.xw
 int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
                 int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys = nullptr, float bin_width = 0.0f);  // pbc_sys: device [n_cell][3] or NULL
-// small periodic batches: status zeroing + launch_mol_start + launch_wrap(bin_width) + the bin kernels of launch_nlist in ONE launch
-bool prep_small_applies(int n_atoms, int n_mol);
+// small batches: status zeroing + launch_mol_start + launch_wrap(bin_width) + the bin kernels of launch_nlist in ONE launch
+// (cell == NULL, molecules: status zeroing + launch_mol_start + the coordinate copy)
+bool prep_small_applies(int n_atoms, int n_mol, bool periodic);
 int launch_prep_small(hipStream_t s, const float* coord, const int* mol_idx, const int* numbers, int n_atoms, int n_mol,
                       const float* cell, int n_cell, const int pbc[3], const int* pbc_sys, float bin_width, int* status,
                       const int* slot_of_z, int* aslot, unsigned long long* present_part, NlistBuffers& b);

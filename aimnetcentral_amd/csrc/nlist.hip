@@ -493,7 +493,7 @@ struct PrepSmallArgs {
   const float* cell; int n_cell, p0, p1, p2; const int* pbc_sys; float w;
   int* status;  // [8], zeroed here; status + 6 = the input sanity flags
   const int* slot_of_z; int* aslot; unsigned long long* present_part;
-  int* mol_start; int* mol_c; NlistSystem* sys; float* xw; int* atom_bin; int* slot; int* bin_start; int* sorted; float4* xs;
+  int* mol_start; int* mol_c; NlistSystem* sys; float* xw; int* bin_start; int* sorted; float4* xs;
 };
 
 // Every thread owns the atoms t, t + 1024, ... (at most PS_K of them) through all phases, with their molecule, bin and arrival
@@ -535,8 +535,10 @@ __global__ __launch_bounds__(1024) void prep_small_kernel(PrepSmallArgs a) {
   if (t < 8) a.status[t] = 0;
   if (t < PREP_SMALL_MAX_ATOMS / 256) s_mask[t] = 0ull;
   if (t < 64) s_slot_of_z[t] = a.slot_of_z ? a.slot_of_z[t] : 0;
-  for (int k = t; k <= max_bins; k += 1024) s_bin[k] = 0;
-  for (int s = t; s < n_mol; s += 1024) cell_setup_one(a.cell, a.n_cell, s, a.p0, a.p1, a.p2, a.pbc_sys, a.sys);
+  if (a.cell)  // (molecules: no bins, no dynamic LDS)
+    for (int k = t; k <= max_bins; k += 1024) s_bin[k] = 0;
+  if (a.cell)
+    for (int s = t; s < n_mol; s += 1024) cell_setup_one(a.cell, a.n_cell, s, a.p0, a.p1, a.p2, a.pbc_sys, a.sys);
   __syncthreads();
   PREP_STAMP(1);
   // ---- mol_start_kernel's three jobs
@@ -584,6 +586,10 @@ __global__ __launch_bounds__(1024) void prep_small_kernel(PrepSmallArgs a) {
   PREP_STAMP(2);
   if (a.slot_of_z)
     for (int g = t; g * 256 < n_atoms; g += 1024) a.present_part[g] = s_mask[g];
+  if (a.cell == nullptr) {  // molecules: no cell, no bins - the coordinates as they are (launch_wrap's copy)
+    for (int k = t; k < 3 * n_atoms; k += 1024) a.xw[k] = a.coord[k];
+    return;
+  }
   bins_setup_block(a.sys, a.mol_start, n_mol, a.w);
   __syncthreads();
   PREP_STAMP(3);
@@ -693,9 +699,13 @@ __global__ __launch_bounds__(1024) void prep_small_kernel(PrepSmallArgs a) {
   PREP_STAMP(8);
 }
 
-bool prep_small_applies(int n_atoms, int n_mol) { return n_atoms <= PREP_SMALL_MAX_ATOMS && n_mol <= PREP_SMALL_MAX_MOL; }
+// periodic: the systems' cell / bin descriptors live in LDS (PREP_SMALL_MAX_MOL of them); molecules need none
+bool prep_small_applies(int n_atoms, int n_mol, bool periodic) {
+  return n_atoms <= PREP_SMALL_MAX_ATOMS && (!periodic || n_mol <= PREP_SMALL_MAX_MOL);
+}
 
-// replaces memset(status) + launch_mol_start + launch_wrap(bin_width) + the bin kernels of the following launch_nlist(bin_width)
+// replaces memset(status) + launch_mol_start + launch_wrap(bin_width) + the bin kernels of the following launch_nlist(bin_width);
+// cell == NULL (molecules): memset(status) + launch_mol_start + launch_wrap's copy
 int launch_prep_small(hipStream_t s, const float* coord, const int* mol_idx, const int* numbers, int n_atoms, int n_mol,
                       const float* cell, int n_cell, const int pbc[3], const int* pbc_sys, float bin_width, int* status,
                       const int* slot_of_z, int* aslot, unsigned long long* present_part, NlistBuffers& b) {
@@ -704,14 +714,14 @@ int launch_prep_small(hipStream_t s, const float* coord, const int* mol_idx, con
   a.cell = cell; a.n_cell = n_cell; a.p0 = pbc[0]; a.p1 = pbc[1]; a.p2 = pbc[2]; a.pbc_sys = pbc_sys; a.w = bin_width;
   a.status = status;
   a.slot_of_z = (numbers && aslot) ? slot_of_z : nullptr; a.aslot = aslot; a.present_part = present_part;
-  a.mol_start = b.mol_start; a.mol_c = b.mol_c; a.sys = (NlistSystem*)b.sys; a.xw = b.xw; a.atom_bin = b.atom_bin;
-  a.slot = b.bin_fill; a.bin_start = b.bin_start; a.sorted = b.sorted; a.xs = b.xs;
-  const size_t lds = ((size_t)(n_atoms + 8 * n_mol + 9) + (size_t)n_atoms) * sizeof(int);  // <= 35 KB
+  a.mol_start = b.mol_start; a.mol_c = b.mol_c; a.sys = (NlistSystem*)b.sys; a.xw = b.xw;
+  a.bin_start = b.bin_start; a.sorted = b.sorted; a.xs = b.xs;
+  const size_t lds = cell ? ((size_t)(n_atoms + 8 * n_mol + 9) + (size_t)n_atoms) * sizeof(int) : 0;  // <= 35 KB
   hipLaunchKernelGGL(prep_small_kernel, dim3(1), dim3(1024), lds, s, a);
   AIMNET_LAUNCH_CHECK();
-  b.binned = true;
-  b.prebinned_width = bin_width;
-  b.bins_done = true;
+  b.binned = cell != nullptr;
+  b.prebinned_width = cell ? bin_width : 0.0f;
+  b.bins_done = cell != nullptr;
   return 0;
 }
 

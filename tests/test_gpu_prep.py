@@ -77,6 +77,36 @@ def test_strained_triclinic_cells_bitwise(hip_engine, seed):
         assert np.array_equal(a[k], b[k]), (k, case[-1])
 
 
+@pytest.mark.parametrize("name,coulomb", [("taxol", "simple"), ("batch5", "simple"), ("batch5", "dsf")])
+def test_molecules_bitwise(hip_engine, name, coulomb):
+    """Molecules (no cell): the single launch replaces the status memset, the molecule-offset pass and the coordinate copy."""
+    g = golden(name)
+    a, b = both(hip_engine, lambda: P.run(hip_engine, g, coulomb)[0])
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_many_molecules_and_a_large_one_bitwise(hip_engine):
+    """300 molecules in one batch (more systems than the periodic form of the kernel takes) and one 2 000-atom molecule (bounding-box
+    cell list behind the single launch)."""
+    from aimnetcentral_amd import workloads
+
+    dev = hip_engine.device
+    c, z, mol, q = workloads.random_batch(300, 3, 12, seed=5)
+    big_c, big_z = workloads.random_organic(2000, np.random.default_rng(3))
+    for cc, zz, mm, qq in ((c, z, mol, q), (big_c.astype(np.float32), big_z, np.zeros(2000, dtype=np.int64), np.zeros(1, np.float32))):
+        assert len(zz) <= 4096
+
+        def go():
+            r = hip_engine.eval(torch.from_numpy(cc).to(dev), torch.from_numpy(zz).to(dev), torch.from_numpy(mm).to(dev), torch.from_numpy(qq).to(dev),
+                                forces=True, coulomb="simple")
+            return {k: v.cpu().numpy() for k, v in r.items()}
+
+        a, b = both(hip_engine, go)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+
+
 def test_bad_inputs_are_flagged_the_same(hip_engine):
     g = golden("pbc96_dsf15")
     dev = hip_engine.device

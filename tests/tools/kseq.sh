@@ -1,15 +1,16 @@
 #!/bin/bash
-# the kernel sequence of ONE step of the default bench (names + durations + gaps, from a rocprofv3 kernel trace)
+# the kernel sequence of ONE step of the default bench (names + durations + gaps, from a rocprofv3 kernel trace);
+# KSEQ_ARGS="--workload taxol" for another workload
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kseq
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kseq -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-f32 --no-hessian > /tmp/kseq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kseq -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-f32 --no-hessian $KSEQ_ARGS > /tmp/kseq.log 2>&1
 python - <<PY > $R/gpurun_out/kseq.txt
 import csv, glob
 rows = list(csv.DictReader(open(glob.glob("/tmp/kseq/*/*kernel_trace.csv")[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # one step = from a mol_start_kernel to the next
-idx = [k for k, r in enumerate(rows) if "mol_start_kernel" in r["Kernel_Name"]]
+idx = [k for k, r in enumerate(rows) if ("mol_start_kernel" in r["Kernel_Name"] or "prep_small_kernel" in r["Kernel_Name"])]
 a, b = idx[4], idx[5]
 prev_end = None
 tot = 0.0

@@ -67,6 +67,9 @@ struct aimnet_engine {
   // AIMNET_PREP_FUSED / set_option("prep_fused"): periodic batches of up to 4 096 atoms / 64 systems prepare their cell grid in one
   // single-block launch (nlist.hip, prep_small_kernel) instead of seven small dependent ones.  0 = the separate kernels (any size).
   int prep_fused = 1;
+  // AIMNET_ENERGY_RIDES / set_option("energy_rides"): periodic evaluations with a stress request sum the molecule energies on the two
+  // stress launches at the end (model.hip, EnergyRider) instead of two launches of their own in front of the backward pass
+  int energy_rides = 1;
   double* sae;
   // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row

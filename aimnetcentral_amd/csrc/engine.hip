@@ -180,6 +180,7 @@ struct Workspace {
   float *qbar, *fgrad, *virial_atom, *abar;
   float* qtot;   // NSE models: alpha + beta charges (the Coulomb kernels and the `charges` output see these)
   double* part;  // per-(system, slice) partial sums of the molecule reductions
+  double* part_e;  // [n_mol][S] energy partial sums when the energy reduction rides on the stress launches
   int S;         // slices per molecule
   bool xe = false;   // reverse-pair conv backward: pair buffer + reverse map
   float4* pairbuf;
@@ -304,6 +305,7 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   W.virial_atom = c.take<float>(n * 9);
   W.S = std::min(128, std::max(1, (N / std::max(1, n_mol) + 511) / 512));
   W.part = c.take<double>((size_t)n_mol * W.S * 9);
+  W.part_e = c.take<double>((size_t)n_mol * W.S);
   if (grad) {
     const int mw = max_width(e);
     W.abar = c.take<float>(n * 256, "abar", 256);
@@ -397,6 +399,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->head_fused = atoi(env) != 0;
     env = getenv("AIMNET_PREP_FUSED");
     if (env) e->prep_fused = atoi(env) != 0;
+    env = getenv("AIMNET_ENERGY_RIDES");
+    if (env) e->energy_rides = atoi(env) != 0;
     env = getenv("AIMNET_CONV_XE");
     if (env) e->conv_xe = atoi(env);
     env = getenv("AIMNET_SPLIT_MAX");
@@ -533,6 +537,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "gemm_presplit") e->gemm_presplit = value != 0;
   else if (n == "head_fused") e->head_fused = value != 0;
   else if (n == "prep_fused") e->prep_fused = value != 0;
+  else if (n == "energy_rides") e->energy_rides = value != 0;
   else if (n == "split_max") e->split_max = value < 0 ? conv_split_max_default() : value;
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -554,6 +559,7 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
   else if (n == "gemm_presplit") *value = e->gemm_presplit;
   else if (n == "head_fused") *value = e->head_fused;
   else if (n == "prep_fused") *value = e->prep_fused;
+  else if (n == "energy_rides") *value = e->energy_rides;
   else if (n == "split_max") *value = e->split_max;
   else if (n == "p0_moments") *value = e->p0_moments ? 1 : 0;
   else if (n == "overlap_coulomb") *value = e->overlap_coulomb ? 1 : 0;
@@ -1021,9 +1027,16 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   }
   // results of the Coulomb block (ecoul, qbar / fgrad / virial seeds, qtot) are first needed here (energy only) or in front of
   // the first conv backward (see `join` below)
+  // The molecule energies are outputs only: with a stress request (and nothing else riding on the energy launch) their sums ride
+  // on the two stress launches at the end of the evaluation instead of standing as two launches of their own here.
+  bool energy_deferred = false;
   auto join = [&]() -> int {
     if (overlap) AIMNET_HIP_CHECK(hipStreamWaitEvent(s, e->ev_join, 0));
     RC(prof_mark(e, s, FAM_POINTWISE));
+    if (e->energy_rides && grad && want_s && pbc && charges_written && rev_done) {
+      energy_deferred = true;
+      return 0;
+    }
     RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, W.S, W.part, out->energy,
                             q_fin, charges_written ? nullptr : out->charges, N,  // + the charges output, unless the DSF walk wrote it
                             rev_done ? nullptr : &pmap));                        // + the lookup of the reverse-pair map, unless the walk ran it
@@ -1135,9 +1148,11 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   // (with a stress request the force gather rides on the launch of the virial sums: independent work, one kernel boundary less)
   const bool pf_rides = W.xe && want_f && want_s && pbc;
   const PairForceRider pfr{W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, out->forces, ceil_div(N, 4)};
+  const EnergyRider erd{W.e_atom, W.ecoul, in->numbers, e->sae, W.part_e, out->energy, n_mol};
   if (W.xe && want_f && !pf_rides) RC(launch_pair_force(s, W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, N, W.fgrad, out->forces));
   RC(launch_finalize(s, W.fgrad, W.virial_atom, W.nl.mol_start, in->cell, n_cell, n_mol, N, W.S, W.part,
-                     (want_f && !W.xe) ? out->forces : nullptr, want_s ? out->stress : nullptr, pf_rides ? &pfr : nullptr));
+                     (want_f && !W.xe) ? out->forces : nullptr, want_s ? out->stress : nullptr, pf_rides ? &pfr : nullptr,
+                     energy_deferred ? &erd : nullptr));
   RC(prof_mark(e, s, -1));
   return AIMNET_OK;
 }

@@ -312,9 +312,14 @@ int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const
 struct PairForceRider {
   const int* nb_idx; const int* nb_cnt; const int* rev; const float4* pairbuf; int cap; float* forces; int n_blocks;
 };
+// the molecule energy sums as riders of the stress launches (partial sums beside the virial sums, the slice sums beside the stress
+// finish): they are only needed at the end, and two launch boundaries go.  part: its own [n_mol][S] partial sums.
+struct EnergyRider {
+  const float* e_atom; const double* ecoul; const int* numbers; const double* sae; double* part; double* energy; int n_mol;
+};
 int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
                     const float* cell, int n_cell, int n_mol, int n_atoms, int S, double* part, float* forces,
-                    float* stress, const PairForceRider* pair_force = nullptr);
+                    float* stress, const PairForceRider* pair_force = nullptr, const EnergyRider* energy = nullptr);
 int launch_copy_f32(hipStream_t s, const float* src, float* dst, size_t n);
 
 }  // namespace aimnet

@@ -260,6 +260,23 @@ int launch_head_last(hipStream_t s, const float* h, int ldh, const float* w, con
   return 0;
 }
 
+// partial sum number b = (molecule, slice) of E_m = sum_i e_i + SAE[Z_i] + pair energies (fp64)
+__device__ __forceinline__ void energy_partial_block(const float* __restrict__ e_atom, const double* __restrict__ ecoul,
+                                                     const int* __restrict__ numbers, const double* __restrict__ sae,
+                                                     const int* __restrict__ mol_start, int S, double* __restrict__ part, int b) {
+  __shared__ double sh[4];
+  const int m = b / S, sl = b % S;
+  int lo, hi;
+  slice_bounds(mol_start, m, sl, S, lo, hi);
+  double acc = 0.0;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const int z = min(63, max(0, numbers[i]));
+    acc += (double)e_atom[i] + sae[z] + ecoul[i];
+  }
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) part[(size_t)m * S + sl] = r;
+}
+
 __global__ __launch_bounds__(256) void energy_partial_kernel(const float* __restrict__ e_atom,
                                                             const double* __restrict__ ecoul,
                                                             const int* __restrict__ numbers,
@@ -277,17 +294,7 @@ __global__ __launch_bounds__(256) void energy_partial_kernel(const float* __rest
     }
     return;
   }
-  __shared__ double sh[4];
-  const int m = blockIdx.x / S, sl = blockIdx.x % S;
-  int lo, hi;
-  slice_bounds(mol_start, m, sl, S, lo, hi);
-  double acc = 0.0;
-  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    const int z = min(63, max(0, numbers[i]));
-    acc += (double)e_atom[i] + sae[z] + ecoul[i];
-  }
-  const double r = block_sum(acc, sh);
-  if (threadIdx.x == 0) part[(size_t)m * S + sl] = r;
+  energy_partial_block(e_atom, ecoul, numbers, sae, mol_start, S, part, blockIdx.x);
 }
 
 __global__ void energy_finish_kernel(const double* __restrict__ part, int S, int n_mol, double* __restrict__ energy) {
@@ -827,9 +834,13 @@ __global__ void forces_kernel(const float* __restrict__ fgrad, int n3, float* __
 __global__ __launch_bounds__(256) void stress_partial_kernel(const float* __restrict__ virial_atom,
                                                             const int* __restrict__ mol_start, int n_cell, int n_mol,
                                                             int S, double* __restrict__ part, const float* __restrict__ fgrad,
-                                                            int n_atoms, PairForceRider pf) {
-  if ((int)blockIdx.x >= S * n_cell) {  // rider: the force gather of the reverse-pair form (independent of the virial sums)
-    pair_force_block(pf.nb_idx, pf.nb_cnt, pf.rev, pf.pairbuf, pf.cap, n_atoms, fgrad, pf.forces, blockIdx.x - S * n_cell);
+                                                            int n_atoms, PairForceRider pf, EnergyRider er) {
+  if ((int)blockIdx.x >= S * n_cell) {  // riders (independent of the virial sums; a kernel boundary less each)
+    const int b = blockIdx.x - S * n_cell;
+    if (b < pf.n_blocks)  // the force gather of the reverse-pair form
+      pair_force_block(pf.nb_idx, pf.nb_cnt, pf.rev, pf.pairbuf, pf.cap, n_atoms, fgrad, pf.forces, b);
+    else  // the molecule energies' partial sums (S == 1: the energies themselves)
+      energy_partial_block(er.e_atom, er.ecoul, er.numbers, er.sae, mol_start, S, S == 1 ? er.energy : er.part, b - pf.n_blocks);
     return;
   }
   __shared__ double sh[4];
@@ -847,9 +858,17 @@ __global__ __launch_bounds__(256) void stress_partial_kernel(const float* __rest
 }
 
 __global__ void stress_finish_kernel(const double* __restrict__ part, int S, int n_cell, const float* __restrict__ cell,
-                                     float* __restrict__ stress) {
+                                     float* __restrict__ stress, EnergyRider er) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_cell * 9) return;
+  if (e >= n_cell * 9) {  // rider threads: the slice sums of the molecule energies, in slice order (energy_finish_kernel)
+    const int m = e - n_cell * 9;
+    if (S > 1 && m < er.n_mol) {
+      double r = 0.0;
+      for (int k = 0; k < S; ++k) r += er.part[(size_t)m * S + k];
+      er.energy[m] = r;
+    }
+    return;
+  }
   const int sidx = e / 9, k = e % 9;
   const float* c = cell + (size_t)sidx * 9;
   const double det = (double)c[0] * ((double)c[4] * c[8] - (double)c[5] * c[7]) -
@@ -862,19 +881,23 @@ __global__ void stress_finish_kernel(const double* __restrict__ part, int S, int
 
 int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
                     const float* cell, int n_cell, int n_mol, int n_atoms, int S, double* part, float* forces,
-                    float* stress, const PairForceRider* pair_force) {
+                    float* stress, const PairForceRider* pair_force, const EnergyRider* energy) {
   PairForceRider pf{};
   if (pair_force) pf = *pair_force;
+  EnergyRider er{};
+  if (energy) er = *energy;
   if (forces) {
     hipLaunchKernelGGL(forces_kernel, dim3(ceil_div(3 * n_atoms, 256)), dim3(256), 0, s, fgrad, 3 * n_atoms, forces);
     AIMNET_LAUNCH_CHECK();
   }
   if (stress && cell) {
     S = S < 1 ? 1 : S;
-    hipLaunchKernelGGL(stress_partial_kernel, dim3(S * n_cell + pf.n_blocks), dim3(256), 0, s, virial_atom, mol_start, n_cell, n_mol, S,
-                       part, fgrad, n_atoms, pf);
+    const int n_er = energy ? S * er.n_mol : 0;
+    hipLaunchKernelGGL(stress_partial_kernel, dim3(S * n_cell + pf.n_blocks + n_er), dim3(256), 0, s, virial_atom, mol_start, n_cell, n_mol,
+                       S, part, fgrad, n_atoms, pf, er);
     AIMNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(stress_finish_kernel, dim3(ceil_div(n_cell * 9, 64)), dim3(64), 0, s, part, S, n_cell, cell, stress);
+    hipLaunchKernelGGL(stress_finish_kernel, dim3(ceil_div(n_cell * 9 + (energy && S > 1 ? er.n_mol : 0), 64)), dim3(64), 0, s, part, S,
+                       n_cell, cell, stress, er);
     AIMNET_LAUNCH_CHECK();
   }
   return 0;

@@ -267,6 +267,8 @@ int aimnet_debug_gemm_bf3a(int cfg, int epi, int out3, const void* A3, int lda3,
  *                   offsets + input sanity + species, cell + bin setup, wrapping, counting, scan, fill, per-bin ordering) in ONE
  *                   single-block launch (csrc/nlist.hip, prep_small_kernel), molecules of <= 4 096 atoms their status zeroing +
  *                   molecule offsets + coordinate copy; 0: the separate kernels; identical results
+ *   "energy_rides"  1 (default): periodic evaluations with a stress request sum the molecule energies as riders of the two stress
+ *                   launches at the end instead of two launches of their own; 0: separate launches; identical results
  *   "emb_bias"      1 (default): pass 0's first GEMM runs over the conv columns, the embedding block is a per-element bias table
  *   "conv_mfma"     bit 0: conv forward, bit 1: conv backward on the v_mfma_f32_4x4x1_16B_f32 kernels (csrc/conv_mfma.hip)
  *                   instead of the packed-FMA VALU kernels (default 0; systems above the split threshold only)

@@ -13,14 +13,14 @@ from conftest import golden
 pytestmark = pytest.mark.gpu
 
 
-def both(eng, fn):
+def both(eng, fn, option="prep_fused"):
     out = []
     try:
         for v in (1, 0):
-            eng.set_option("prep_fused", v)
+            eng.set_option(option, v)
             out.append(fn())
     finally:
-        eng.set_option("prep_fused", 1)
+        eng.set_option(option, 1)
     return out
 
 
@@ -105,6 +105,27 @@ def test_many_molecules_and_a_large_one_bitwise(hip_engine):
         a, b = both(hip_engine, go)
         for k in a:
             assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("reps", [(1, 1, 1), (2, 3, 4)])
+def test_energy_sums_riding_on_the_stress_launches_bitwise(hip_engine, reps):
+    """Engine option "energy_rides": with a stress request the molecule energy sums run as riders of the two stress launches instead
+    of two launches of their own - the same partial sums in the same order (96 atoms: one slice; 2 304 atoms: five slices)."""
+    from aimnetcentral_amd import workloads
+
+    c, z, cell = workloads.glucose_supercell(reps)
+    dev = hip_engine.device
+
+    def go():
+        r = hip_engine.eval(torch.from_numpy(c.astype(np.float32)).to(dev), torch.from_numpy(z).to(dev),
+                            torch.zeros(len(z), dtype=torch.int64, device=dev), torch.zeros(1, device=dev),
+                            cell=torch.from_numpy(cell.astype(np.float32)).to(dev), forces=True, stress=True, coulomb="dsf", dsf_rc=9.0)
+        return {k: v.cpu().numpy() for k, v in r.items()}
+
+    a, b = both(hip_engine, go, "energy_rides")
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.isfinite(a["energy"]).all() and a["energy"][0] < 0
 
 
 def test_bad_inputs_are_flagged_the_same(hip_engine):

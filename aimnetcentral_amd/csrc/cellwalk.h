@@ -51,6 +51,25 @@ __device__ __forceinline__ void wrap_into_cell(const NlistSystem& S, float x, fl
   for (int c = 0; c < 3; ++c) w[c] = __builtin_fmaf(f[2], S.c[6 + c], __builtin_fmaf(f[1], S.c[3 + c], f[0] * S.c[c]));
 }
 
+// status words of a finished list build: max_i count_i into *status_max and "some row overflowed its capacity" into *status_ovf,
+// for the 1024 atoms of block b (the words must have been zeroed; one atomic pair per 1024 atoms - 10^4 same-address atomics, one
+// per row, would cost ~12 ns each).  Called by nlist_status_kernel or, when no second list follows, as rider blocks of a later launch.
+__device__ __forceinline__ void nlist_status_block(const int* __restrict__ cnt_true, int n_atoms, int cap, int* __restrict__ status_max,
+                                                   int* __restrict__ status_ovf, int b) {
+  __shared__ int s_max[16];
+  int v = 0;
+  for (int i = b * 1024 + (int)threadIdx.x; i < min(n_atoms, (b + 1) * 1024); i += blockDim.x) v = max(v, cnt_true[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v = max(v, s_max[w]);
+    if (v > __hip_atomic_load(status_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(status_max, v);
+    if (v > cap) atomicMax(status_ovf, 1);
+  }
+}
+
 // Visit every (neighbour image) candidate of atom i (one wave per atom) whose bin lies within the
 // search range of `cutoff`.  f(w, rx, ry, rz, ok, code) is called convergently by all 64 lanes once
 // per 64-candidate chunk; w = 4th component of the candidate's stream entry (atom id bits when

@@ -70,6 +70,9 @@ struct aimnet_engine {
   // AIMNET_ENERGY_RIDES / set_option("energy_rides"): periodic evaluations with a stress request sum the molecule energies on the two
   // stress launches at the end (model.hip, EnergyRider) instead of two launches of their own in front of the backward pass
   int energy_rides = 1;
+  // AIMNET_STATUS_RIDES / set_option("status_rides"): when the short-range list is the only list built, its status words (longest
+  // row, overflow flag) are reduced by rider blocks of the SR-Coulomb launch instead of a launch of their own
+  int status_rides = 1;
   double* sae;
   // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row

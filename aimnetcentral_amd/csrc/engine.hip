@@ -401,6 +401,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->prep_fused = atoi(env) != 0;
     env = getenv("AIMNET_ENERGY_RIDES");
     if (env) e->energy_rides = atoi(env) != 0;
+    env = getenv("AIMNET_STATUS_RIDES");
+    if (env) e->status_rides = atoi(env) != 0;
     env = getenv("AIMNET_CONV_XE");
     if (env) e->conv_xe = atoi(env);
     env = getenv("AIMNET_SPLIT_MAX");
@@ -538,6 +540,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "head_fused") e->head_fused = value != 0;
   else if (n == "prep_fused") e->prep_fused = value != 0;
   else if (n == "energy_rides") e->energy_rides = value != 0;
+  else if (n == "status_rides") e->status_rides = value != 0;
   else if (n == "split_max") e->split_max = value < 0 ? conv_split_max_default() : value;
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -560,6 +563,7 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
   else if (n == "head_fused") *value = e->head_fused;
   else if (n == "prep_fused") *value = e->prep_fused;
   else if (n == "energy_rides") *value = e->energy_rides;
+  else if (n == "status_rides") *value = e->status_rides;
   else if (n == "split_max") *value = e->split_max;
   else if (n == "p0_moments") *value = e->p0_moments ? 1 : 0;
   else if (n == "overlap_coulomb") *value = e->overlap_coulomb ? 1 : 0;
@@ -770,6 +774,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   }
   int cap_d3 = cap_lr;
   bool d3_shared = false;
+  const int* sr_cnt_true = nullptr;  // != NULL: the short-range list's status words are still to be reduced (SrRiders)
   if (ext) {
     // the reference hands a caller's matrices to the model as they are (calculator.py:1069-1071): import them into the row format
     // of the kernels; coordinates as given (the shifts refer to them), no bins, centres processed in input order
@@ -807,8 +812,11 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   if (!prep1) RC(launch_wrap(s, in->coord, mol_c, N, n_mol, in->cell, n_cell, in->pbc, W.nl, in->pbc_sys, pbc ? ar.rc : 0.0f));
   // large non-periodic molecules (>= 1500 atoms on average) get a bounding-box cell list instead of the O(n^2) scan
   if (!pbc && (long)N >= 1500L * n_mol) RC(launch_bbox(s, n_mol, W.nl));
+  // no second list build follows (periodic DSF walks the grid, "simple" sums all pairs, no D3 list): the status words of this list
+  // are reduced by rider blocks of the SR-Coulomb launch instead of a launch of their own
+  const bool status_rides = e->status_rides && !(coulomb == AIMNET_COULOMB_DSF && !pbc) && !d3;
   RC(launch_nlist(s, N, n_mol, mol_c, in->cell, n_cell, in->pbc, ar.rc, ar.rc, cap, N, 0, W.nl, W.nb_idx, W.nb_shift,
-                  W.nb_cnt, out->status + 0, out->status + 2, W.pg));
+                  W.nb_cnt, out->status + 0, out->status + 2, W.pg, status_rides ? &sr_cnt_true : nullptr));
   if (coulomb == AIMNET_COULOMB_DSF && !pbc)  // periodic DSF needs no list: it walks the short-range cell grid
     RC(launch_nlist(s, N, n_mol, mol_c, in->cell, n_cell, in->pbc, opt->dsf_rc, -1.0f, cap_lr, N, 0, W.nl, W.lr_idx,
                     W.lr_shift, W.lr_cnt, out->status + 1, out->status + 3));
@@ -886,6 +894,13 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       rd.simple_mol_start = W.nl.mol_start;
     }
     rd.hash = pmap;  // hash build of the reverse-pair map (n_blocks = 0: none)
+    if (sr_cnt_true) {
+      rd.cnt_true = sr_cnt_true;
+      rd.status_cap = cap;
+      rd.status_max = out->status + 0;
+      rd.status_ovf = out->status + 2;
+      rd.n_status_blocks = ceil_div(N, 1024);
+    }
     RC(launch_coulomb_sr(cs, grad, want_s, ar.sr_coulomb != 0, q_fin, W.nb_idx, W.nb_cnt, W.pg, cap, cp, N, W.ecoul, W.qbar,
                          W.fgrad, W.virial_atom, &rd));
     // DSF and DFT-D3 with one cutoff: the Coulomb pair terms ride on the D3 pair pass (one list, one geometry evaluation)

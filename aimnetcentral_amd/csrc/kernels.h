@@ -116,7 +116,10 @@ int launch_bbox(hipStream_t s, int n_mol, NlistBuffers& b);
 int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, const float* cell, int n_cell,
                  const int pbc[3], float cutoff, float bin_width, int cap, int fill_value, int fill_rows,
                  NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf,
-                 float4* pg = nullptr);  // pg [n_atoms, cap] (may be NULL): also emit the pair geometry (u, d) of every entry
+                 float4* pg = nullptr,
+                 // != NULL: the status reduction is NOT launched; *status_later = the per-row counts for nlist_status_block
+                 // (cellwalk.h) as riders of a later launch - valid until the next list build
+                 const int** status_later = nullptr);  // pg [n_atoms, cap] (may be NULL): also emit the pair geometry (u, d) of every entry
 int launch_bins(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, float width, NlistBuffers& b);
 // caller-supplied neighbour matrix [n_atoms][width] (+ integer shifts [n_atoms][width][3] or NULL) -> the engine's row format
 // (valid entries compacted in order, shifts packed, optional pair geometry from the coordinates as given in b.xw); status as
@@ -284,6 +287,8 @@ struct SrRiders {
   // simple_xw != NULL: the "simple" LRCoulomb term (launch_coulomb_simple with these arguments) in the same waves
   const float* simple_xw; const int* simple_mol_idx; const int* simple_mol_start;
   PairMapRider hash;  // the hash build of the reverse-pair map (its lookup rides on a later launch)
+  // the status words of the short-range list (nlist_status_block, cellwalk.h): n_status_blocks = ceil(n_atoms / 1024), 0 = none
+  const int* cnt_true; int status_cap; int* status_max; int* status_ovf; int n_status_blocks;
 };
 // embedded SRCoulomb subtraction over the rc list (sets ecoul/qbar/fgrad/virial_atom)
 int launch_coulomb_sr(hipStream_t s, bool grad, bool stress, bool enabled, const float* q, const int* nb_idx,

@@ -404,10 +404,13 @@ __global__ __launch_bounds__(256) void coulomb_sr_kernel(bool enabled, const flo
       head_last_block(rd.h, rd.ldh, rd.w, rd.b, rd.k, n_atoms, rd.e_atom, rd.d, rd.zbar, b);
     } else if (b < rd.n_head_blocks + rd.n_stream_blocks) {
       charge_stream_block(rd.xs, q, n_atoms, rd.xq, rd.charges_out, b - rd.n_head_blocks);
-    } else {  // hash build of the reverse-pair map (pairmap.h)
+    } else if (b < rd.n_head_blocks + rd.n_stream_blocks + rd.hash.n_blocks) {  // hash build of the reverse-pair map (pairmap.h)
       __shared__ unsigned long long s_tab[4][RH_SLOTS];
       pair_hash_block(rd.hash.nb_idx, rd.hash.nb_shift, rd.hash.nb_cnt, rd.hash.cap, n_atoms, rd.hash.tab, rd.hash.rev,
                       b - rd.n_head_blocks - rd.n_stream_blocks, s_tab);
+    } else {  // status words of the short-range list (max row length, overflow flag)
+      nlist_status_block(rd.cnt_true, n_atoms, rd.status_cap, rd.status_max, rd.status_ovf,
+                         b - rd.n_head_blocks - rd.n_stream_blocks - rd.hash.n_blocks);
     }
     return;
   }
@@ -463,7 +466,7 @@ int launch_coulomb_sr(hipStream_t s, bool grad, bool stress, bool enabled, const
                       float* qbar, float* fgrad, float* virial_atom, const SrRiders* riders) {
   SrRiders rd{};
   if (riders) rd = *riders;
-  dim3 grid(ceil_div(n_atoms, 4) + rd.n_head_blocks + rd.n_stream_blocks + rd.hash.n_blocks), block(256);
+  dim3 grid(ceil_div(n_atoms, 4) + rd.n_head_blocks + rd.n_stream_blocks + rd.hash.n_blocks + rd.n_status_blocks), block(256);
   if (grad && stress)
     hipLaunchKernelGGL((coulomb_sr_kernel<true, true>), grid, block, 0, s, enabled, q, nb_idx, nb_cnt, pg, cap, cp, n_atoms,
                        ecoul, qbar, fgrad, virial_atom, rd);

@@ -855,28 +855,15 @@ __global__ __launch_bounds__(256) void import_list_kernel(const int* __restrict_
   }
 }
 
-// status[0] = max_i count_i, status[1] = any(count_i > cap): one atomic per 1024 atoms instead of one per atom
 __global__ __launch_bounds__(1024) void nlist_status_kernel(const int* __restrict__ cnt_true, int n_atoms, int cap,
                                                            int* __restrict__ status_max, int* __restrict__ status_ovf) {
-  __shared__ int s_max[16];
-  const int i = blockIdx.x * 1024 + threadIdx.x;
-  int v = i < n_atoms ? cnt_true[i] : 0;
-  v = wave_max(v);
-  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    v = threadIdx.x < 16 ? s_max[threadIdx.x] : 0;
-    v = wave_max(v);
-    if (threadIdx.x == 0) {
-      if (v > __hip_atomic_load(status_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(status_max, v);
-      if (v > cap) atomicMax(status_ovf, 1);
-    }
-  }
+  nlist_status_block(cnt_true, n_atoms, cap, status_max, status_ovf, blockIdx.x);
 }
 
 int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, const float* cell, int n_cell,
                  const int pbc[3], float cutoff, float bin_width, int cap, int fill_value, int fill_rows,
-                 NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf, float4* pg) {
+                 NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf, float4* pg,
+                 const int** status_later) {
   (void)n_cell;
   (void)pbc;
   (void)cell;
@@ -893,6 +880,10 @@ int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, cons
     hipLaunchKernelGGL(nlist_cell_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, (NlistSystem*)b.sys,
                        b.bin_start, b.xs, n_atoms, cutoff, cap, fill_value, fill_rows, nb_idx, nb_shift, nb_cnt, cnt_true, pg);
     AIMNET_LAUNCH_CHECK();
+  }
+  if (status_later) {  // the caller runs nlist_status_block over these counts as riders of a later launch (no list build in between)
+    *status_later = cnt_true;
+    return 0;
   }
   hipLaunchKernelGGL(nlist_status_kernel, dim3(ceil_div(n_atoms, 1024)), dim3(1024), 0, s, cnt_true, n_atoms, cap, status_max,
                      status_ovf);

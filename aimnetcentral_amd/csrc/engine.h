@@ -73,6 +73,9 @@ struct aimnet_engine {
   // AIMNET_STATUS_RIDES / set_option("status_rides"): when the short-range list is the only list built, its status words (longest
   // row, overflow flag) are reduced by rider blocks of the SR-Coulomb launch instead of a launch of their own
   int status_rides = 1;
+  // AIMNET_SETUP_RIDES / set_option("setup_rides"): periodic batches - the cell + bin-grid setup block rides on the molecule-offset
+  // launch (atom counts by binary search in mol_idx) instead of following it as a launch of its own
+  int setup_rides = 1;
   double* sae;
   // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row

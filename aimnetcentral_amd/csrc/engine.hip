@@ -403,6 +403,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->energy_rides = atoi(env) != 0;
     env = getenv("AIMNET_STATUS_RIDES");
     if (env) e->status_rides = atoi(env) != 0;
+    env = getenv("AIMNET_SETUP_RIDES");
+    if (env) e->setup_rides = atoi(env) != 0;
     env = getenv("AIMNET_CONV_XE");
     if (env) e->conv_xe = atoi(env);
     env = getenv("AIMNET_SPLIT_MAX");
@@ -541,6 +543,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "prep_fused") e->prep_fused = value != 0;
   else if (n == "energy_rides") e->energy_rides = value != 0;
   else if (n == "status_rides") e->status_rides = value != 0;
+  else if (n == "setup_rides") e->setup_rides = value != 0;
   else if (n == "split_max") e->split_max = value < 0 ? conv_split_max_default() : value;
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -564,6 +567,7 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
   else if (n == "prep_fused") *value = e->prep_fused;
   else if (n == "energy_rides") *value = e->energy_rides;
   else if (n == "status_rides") *value = e->status_rides;
+  else if (n == "setup_rides") *value = e->setup_rides;
   else if (n == "split_max") *value = e->split_max;
   else if (n == "p0_moments") *value = e->p0_moments ? 1 : 0;
   else if (n == "overlap_coulomb") *value = e->overlap_coulomb ? 1 : 0;
@@ -757,14 +761,20 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const bool want_species = (e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS))) || opt->dftd3 != 0;
   // small periodic batches: status zeroing, molecule offsets / sanity / species, cell + bin setup, wrapping and binning in one launch
   const bool prep1 = e->prep_fused && !ext && prep_small_applies(N, n_mol, pbc);
+  bool setup_rides = false;
   if (prep1) {
     RC(launch_prep_small(s, in->coord, in->mol_idx, in->numbers, N, n_mol, pbc ? in->cell : nullptr, n_cell, in->pbc, in->pbc_sys, ar.rc,
                          out->status,
                          want_species ? e->slot_of_z : nullptr, W.aslot, W.present_part, W.nl));
   } else {
     AIMNET_HIP_CHECK(hipMemsetAsync(out->status, 0, 8 * sizeof(int), s));
+    // periodic fast path: the cell + bin-grid setup block rides on this launch (it needs none of its output)
+    setup_rides = e->setup_rides && !ext && pbc && cell_setup_rides(N, n_mol);
+    CellSetupRider csr{};
+    if (setup_rides) csr = cell_setup_rider(in->cell, n_cell, in->pbc, in->pbc_sys, ar.rc, N, n_mol, W.nl);
     RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start, W.nl.mol_c, in->numbers, out->status + 6,
-                        want_species ? e->slot_of_z : nullptr, W.aslot, W.present_part));  // + aslot / present species
+                        want_species ? e->slot_of_z : nullptr, W.aslot, W.present_part,  // + aslot / present species
+                        setup_rides ? &csr : nullptr));
   }
   const int* mol_c = W.nl.mol_c;  // clamped to [0, n_mol): memory-safe whatever the caller passed (status[6] reports it)
   const bool d3 = opt->dftd3 != 0;
@@ -809,7 +819,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       }
     }
   } else {
-  if (!prep1) RC(launch_wrap(s, in->coord, mol_c, N, n_mol, in->cell, n_cell, in->pbc, W.nl, in->pbc_sys, pbc ? ar.rc : 0.0f));
+  if (!prep1) RC(launch_wrap(s, in->coord, mol_c, N, n_mol, in->cell, n_cell, in->pbc, W.nl, in->pbc_sys, pbc ? ar.rc : 0.0f, setup_rides));
   // large non-periodic molecules (>= 1500 atoms on average) get a bounding-box cell list instead of the O(n^2) scan
   if (!pbc && (long)N >= 1500L * n_mol) RC(launch_bbox(s, n_mol, W.nl));
   // no second list build follows (periodic DSF walks the grid, "simple" sums all pairs, no D3 list): the status words of this list

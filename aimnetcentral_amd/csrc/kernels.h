@@ -92,12 +92,21 @@ size_t nlist_xw_offset(int n_mol);  // byte offset of NlistBuffers::xw inside th
 void nlist_carve(NlistBuffers& b, char* base, int n_atoms, int n_mol);
 // bad: input sanity flags (bit 0 atomic number outside [0,63], bit 1 mol_idx outside [0,n_mol), bit 2 mol_idx not sorted);
 // mol_c [n_atoms]: the clamped copy of mol_idx; + the species pass (launch_species) when slot_of_z is given
+// cell + bin-grid setup of the periodic fast path (launch_wrap with a bin width) as a rider block of launch_mol_start: it does not
+// need that launch's output (atom counts by binary search in the sorted mol_idx).  sys == NULL: none.
+struct CellSetupRider {
+  const float* cell; int n_cell, p0, p1, p2; const int* pbc_sys; void* sys; float w; int* bin_count; int n_zero;
+};
+bool cell_setup_rides(int n_atoms, int n_mol);  // the setup fits one block's zeroing pass and system loop
+CellSetupRider cell_setup_rider(const float* cell, int n_cell, const int pbc[3], const int* pbc_sys, float bin_width, int n_atoms,
+                                int n_mol, NlistBuffers& b);
 int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start, int* mol_c,
                      const int* numbers = nullptr, int* bad = nullptr, const int* slot_of_z = nullptr, int* aslot = nullptr,
-                     unsigned long long* present_part = nullptr);
+                     unsigned long long* present_part = nullptr, const CellSetupRider* cell_setup = nullptr);
 // wrap coordinates (periodic) or copy them (non-periodic) into b.xw
 int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
-                int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys = nullptr, float bin_width = 0.0f);  // pbc_sys: device [n_cell][3] or NULL
+                int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys = nullptr, float bin_width = 0.0f,  // pbc_sys: device [n_cell][3] or NULL
+                bool setup_done = false);  // the cell + bin-grid setup already ran as a rider of launch_mol_start
 // small batches: status zeroing + launch_mol_start + launch_wrap(bin_width) + the bin kernels of launch_nlist in ONE launch
 // (cell == NULL, molecules: status zeroing + launch_mol_start + the coordinate copy)
 bool prep_small_applies(int n_atoms, int n_mol, bool periodic);

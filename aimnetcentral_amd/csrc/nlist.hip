@@ -62,11 +62,19 @@ void nlist_carve(NlistBuffers& b, char* p, int n_atoms, int n_mol) {
 // (the reference fails in mol_sum / index_add, nbops.py:309-377).  HipEngine.eval turns either into a ValueError.
 // Third job (slot_of_z may be NULL): the species pass of the engine - aslot[i] = model slot of atom i's element and, per block of
 // 256 atoms, the mask of the slots present (present_part[blockIdx.x]); it reads the same `numbers` and saves a launch.
+__device__ void cell_bins_setup_block(const CellSetupRider& r, const int* __restrict__ mol_start, int n_mol, const int* __restrict__ mol_idx,
+                                      int n_atoms);
+
 __global__ __launch_bounds__(256) void mol_start_kernel(const int* __restrict__ mol_idx, const int* __restrict__ numbers,
                                                         int n_atoms, int n_mol, int* __restrict__ mol_start,
                                                         int* __restrict__ bad, const int* __restrict__ slot_of_z,
                                                         int* __restrict__ aslot, unsigned long long* __restrict__ present_part,
-                                                        int* __restrict__ mol_c) {
+                                                        int* __restrict__ mol_c, CellSetupRider cs) {
+  if (cs.sys && blockIdx.x == gridDim.x - 1) {  // rider: cell + bin-grid setup of the periodic fast path (cell_bins_setup_kernel),
+    // independent of this launch's output (the atom counts come from a binary search in mol_idx): a kernel boundary less
+    cell_bins_setup_block(cs, nullptr, n_mol, mol_idx, n_atoms);
+    return;
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot_of_z) {  // (block-uniform)
     __shared__ unsigned long long s_mask;
@@ -104,9 +112,11 @@ __global__ __launch_bounds__(256) void mol_start_kernel(const int* __restrict__ 
 }
 
 int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start, int* mol_c, const int* numbers,
-                     int* bad, const int* slot_of_z, int* aslot, unsigned long long* present_part) {
-  hipLaunchKernelGGL(mol_start_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, mol_idx, numbers, n_atoms, n_mol, mol_start,
-                     bad, (numbers && aslot) ? slot_of_z : nullptr, aslot, present_part, mol_c);
+                     int* bad, const int* slot_of_z, int* aslot, unsigned long long* present_part, const CellSetupRider* cell_setup) {
+  CellSetupRider cs{};
+  if (cell_setup) cs = *cell_setup;
+  hipLaunchKernelGGL(mol_start_kernel, dim3(ceil_div(n_atoms, 256) + (cs.sys ? 1 : 0)), dim3(256), 0, s, mol_idx, numbers, n_atoms, n_mol,
+                     mol_start, bad, (numbers && aslot) ? slot_of_z : nullptr, aslot, present_part, mol_c, cs);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }
@@ -234,17 +244,26 @@ __global__ void wrap_kernel(const float* __restrict__ coord, const int* __restri
 }
 
 // (defined with the binning kernels below)
-__global__ void cell_bins_setup_kernel(const float* __restrict__ cell, int n_cell, int n_mol, int p0, int p1, int p2,
-                                       const int* __restrict__ pbc_sys, NlistSystem* __restrict__ sys,
-                                       const int* __restrict__ mol_start, float w, int* __restrict__ bin_count, int n_zero);
+__global__ void cell_bins_setup_kernel(CellSetupRider r, const int* __restrict__ mol_start, int n_mol);
 __global__ void wrap_bin_count_kernel(const float* __restrict__ coord, const int* __restrict__ mol_idx, int n_atoms,
                                       const NlistSystem* __restrict__ sys, float* __restrict__ xw, int* __restrict__ atom_bin,
                                       int* __restrict__ bin_count, int* __restrict__ slot);
 
 // bin_width > 0 (periodic systems only): the bins of the following launch_bins(width = bin_width) are prepared on the way -
 // cell + bin-grid setup in one launch, wrapping + bin counting in one launch; launch_bins then starts at the scan.
+bool cell_setup_rides(int n_atoms, int n_mol) { return n_mol <= 4096 && n_atoms + 8 * n_mol + 9 <= 65536; }
+
+CellSetupRider cell_setup_rider(const float* cell, int n_cell, const int pbc[3], const int* pbc_sys, float bin_width, int n_atoms,
+                                int n_mol, NlistBuffers& b) {
+  CellSetupRider r;
+  r.cell = cell; r.n_cell = n_cell; r.p0 = pbc[0]; r.p1 = pbc[1]; r.p2 = pbc[2]; r.pbc_sys = pbc_sys; r.sys = b.sys; r.w = bin_width;
+  r.bin_count = b.bin_count;
+  r.n_zero = n_atoms + 8 * n_mol + 9;
+  return r;
+}
+
 int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
-                int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys, float bin_width) {
+                int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys, float bin_width, bool setup_done) {
   NlistSystem* sys = nullptr;
   b.prebinned_width = 0.0f;
   if (cell != nullptr && bin_width > 0.0f && n_mol <= 4096) {
@@ -252,14 +271,17 @@ int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_ato
     const int max_bins = n_atoms + 8 * n_mol + 8;
     // the single setup block also zeroes the bin counters - fine for the 10^4 entries of a 10 k-atom system (it saves a launch),
     // a serial tail on the critical path at 10^6: above 64 k counters a memset does it at full width
-    int n_zero = max_bins + 1;
-    if (n_zero > 65536) {
-      AIMNET_HIP_CHECK(hipMemsetAsync(b.bin_count, 0, (size_t)n_zero * sizeof(int), s));
-      n_zero = 0;
+    if (!setup_done) {  // (setup_done: the setup block rode on launch_mol_start, CellSetupRider)
+      int n_zero = max_bins + 1;
+      if (n_zero > 65536) {
+        AIMNET_HIP_CHECK(hipMemsetAsync(b.bin_count, 0, (size_t)n_zero * sizeof(int), s));
+        n_zero = 0;
+      }
+      CellSetupRider r = cell_setup_rider(cell, n_cell, pbc, pbc_sys, bin_width, n_atoms, n_mol, b);
+      r.n_zero = n_zero;
+      hipLaunchKernelGGL(cell_bins_setup_kernel, dim3(1), dim3(256), 0, s, r, b.mol_start, n_mol);
+      AIMNET_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(cell_bins_setup_kernel, dim3(1), dim3(256), 0, s, cell, n_cell, n_mol, pbc[0], pbc[1], pbc[2], pbc_sys, sys,
-                       b.mol_start, bin_width, b.bin_count, n_zero);
-    AIMNET_LAUNCH_CHECK();
     hipLaunchKernelGGL(wrap_bin_count_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, coord, mol_idx, n_atoms, sys, b.xw,
                        b.atom_bin, b.bin_count, b.bin_fill);
     AIMNET_LAUNCH_CHECK();
@@ -336,10 +358,24 @@ __global__ __launch_bounds__(256) void nlist_brute_kernel(const float* __restric
 // (the launcher of this kernel is launch_nlist below)
 
 // periodic: choose the bin grid of every system for this cutoff, then a serial prefix of bin offsets
-__device__ void bins_setup_block(NlistSystem* __restrict__ sys, const int* __restrict__ mol_start, int n_mol, float w) {
+// first atom whose (clamped) molecule index is >= m, in a sorted mol_idx (what mol_start[m] holds once launch_mol_start has run)
+__device__ __forceinline__ int first_atom_of(const int* __restrict__ mol_idx, int n_atoms, int n_mol, int m) {
+  int lo = 0, hi = n_atoms;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (min(max(mol_idx[mid], 0), n_mol - 1) < m) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// mol_start == NULL: the atom counts come from a binary search in the caller's (sorted) mol_idx - the form that rides on the
+// launch that is still writing mol_start
+__device__ void bins_setup_block(NlistSystem* __restrict__ sys, const int* __restrict__ mol_start, int n_mol, float w,
+                                 const int* __restrict__ mol_idx = nullptr, int n_atoms = 0) {
   for (int s = threadIdx.x; s < n_mol; s += blockDim.x) {
     NlistSystem S = sys[s];
-    const int ns = mol_start[s + 1] - mol_start[s];
+    const int ns = mol_start ? mol_start[s + 1] - mol_start[s]
+                             : (s + 1 < n_mol ? first_atom_of(mol_idx, n_atoms, n_mol, s + 1) : n_atoms) - first_atom_of(mol_idx, n_atoms, n_mol, s);
     const long cap_bins = (long)ns + 8;
     int nb[3];
     for (int k = 0; k < 3; ++k) nb[k] = max(1, min(1024, (int)floorf(S.h[k] / w)));
@@ -374,15 +410,17 @@ __global__ void bins_setup_kernel(NlistSystem* __restrict__ sys, const int* __re
 
 // periodic fast path (launch_wrap with a bin width): cell setup, bin grids and the zeroing of the bin counters in ONE
 // single-block launch (these are a few microseconds of work each; as separate kernels they cost a launch latency apiece)
-__global__ void cell_bins_setup_kernel(const float* __restrict__ cell, int n_cell, int n_mol, int p0,
-                                                             int p1, int p2, const int* __restrict__ pbc_sys,
-                                                             NlistSystem* __restrict__ sys,
-                                                             const int* __restrict__ mol_start, float w,
-                                                             int* __restrict__ bin_count, int n_zero) {
-  for (int s = threadIdx.x; s < n_mol; s += blockDim.x) cell_setup_one(cell, n_cell, s, p0, p1, p2, pbc_sys, sys);
-  for (int k = threadIdx.x; k < n_zero; k += blockDim.x) bin_count[k] = 0;
+__device__ void cell_bins_setup_block(const CellSetupRider& r, const int* __restrict__ mol_start, int n_mol, const int* __restrict__ mol_idx,
+                                      int n_atoms) {
+  NlistSystem* sys = (NlistSystem*)r.sys;
+  for (int s = threadIdx.x; s < n_mol; s += blockDim.x) cell_setup_one(r.cell, r.n_cell, s, r.p0, r.p1, r.p2, r.pbc_sys, sys);
+  for (int k = threadIdx.x; k < r.n_zero; k += blockDim.x) r.bin_count[k] = 0;
   __syncthreads();
-  bins_setup_block(sys, mol_start, n_mol, w);
+  bins_setup_block(sys, mol_start, n_mol, r.w, mol_idx, n_atoms);
+}
+
+__global__ void cell_bins_setup_kernel(CellSetupRider r, const int* __restrict__ mol_start, int n_mol) {
+  cell_bins_setup_block(r, mol_start, n_mol, nullptr, 0);
 }
 
 // slot[i] = arrival rank of atom i inside its bin (any order: bin_sort_kernel orders every bin by atom id afterwards)

@@ -128,6 +128,40 @@ def test_energy_sums_riding_on_the_stress_launches_bitwise(hip_engine, reps):
     assert np.isfinite(a["energy"]).all() and a["energy"][0] < 0
 
 
+@pytest.mark.parametrize("option", ["setup_rides", "status_rides"])
+@pytest.mark.parametrize("seed", [1, 5, 9])
+def test_rider_forms_bitwise(hip_engine, option, seed):
+    """The cell + bin-grid setup as a rider block of the molecule-offset launch (atom counts by binary search in mol_idx), and the
+    list's status words as rider blocks of the SR-Coulomb launch: identical results on strained cells, one or two systems of
+    different sizes; the separate preparation kernels are the ones that run (prep_fused = 0)."""
+    import test_gpu_fuzz as Z
+
+    case = Z.make_case(seed)
+    hip_engine.set_option("prep_fused", 0)
+    try:
+        a, b = both(hip_engine, lambda: Z.run_case(hip_engine, case), option)
+    finally:
+        hip_engine.set_option("prep_fused", 1)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), (k, case[-1])
+    assert np.array_equal(hip_engine.last_status[:7], hip_engine.last_status[:7])
+
+
+def test_status_words_identical_with_and_without_riders(hip_engine):
+    """Longest row and overflow flag arrive the same whichever launch reduces them; an overflowing capacity still grows."""
+    g = golden("pbc96_dsf15")
+    st = []
+    for v in (1, 0):
+        hip_engine.set_option("status_rides", v)
+        try:
+            hip_engine.max_nb = 16  # too small: the first evaluation overflows, the engine grows the rows and repeats
+            P.run(hip_engine, g, "dsf", dsf_rc=9.0)
+            st.append((hip_engine.last_status.copy(), hip_engine.max_nb))
+        finally:
+            hip_engine.set_option("status_rides", 1)
+    assert np.array_equal(st[0][0], st[1][0]) and st[0][1] == st[1][1] and st[0][0][2] == 0 and st[0][0][0] > 16
+
+
 def test_bad_inputs_are_flagged_the_same(hip_engine):
     g = golden("pbc96_dsf15")
     dev = hip_engine.device

@@ -70,6 +70,43 @@ __device__ __forceinline__ void nlist_status_block(const int* __restrict__ cnt_t
   }
 }
 
+// The same for a status array that nobody has zeroed: ONE block reduces all row counts and the per-wave sanity flags of
+// launch_mol_start and stores all eight words (0 longest row, 2 overflow, 6 sanity flags, the others 0; word 7 untouched if keep7).
+__device__ __forceinline__ void nlist_status_owned_block(const int* __restrict__ cnt_true, int n_atoms, int cap,
+                                                         const int* __restrict__ bad_part, int* __restrict__ status, int keep7) {
+  __shared__ int s_max[16], s_bad[16];
+  int v = 0, f = 0;
+  for (int i0 = (int)threadIdx.x; i0 < n_atoms; i0 += 8 * blockDim.x) {  // eight independent loads in flight (one block, 10^4 rows)
+    int c[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * (int)blockDim.x;
+      c[k] = i < n_atoms ? cnt_true[i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v = max(v, c[k]);
+  }
+  for (int w = (int)threadIdx.x; w < (n_atoms + 63) / 64; w += blockDim.x) f |= bad_part[w];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v = max(v, __shfl_xor(v, off, 64));
+    f |= __shfl_xor(f, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_max[threadIdx.x >> 6] = v;
+    s_bad[threadIdx.x >> 6] = f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+      v = max(v, s_max[w]);
+      f |= s_bad[w];
+    }
+    status[0] = v; status[1] = 0; status[2] = v > cap ? 1 : 0; status[3] = 0; status[4] = 0; status[5] = 0; status[6] = f;
+    if (!keep7) status[7] = 0;
+  }
+}
+
 // Visit every (neighbour image) candidate of atom i (one wave per atom) whose bin lies within the
 // search range of `cutoff`.  f(w, rx, ry, rz, ok, code) is called convergently by all 64 lanes once
 // per 64-candidate chunk; w = 4th component of the candidate's stream entry (atom id bits when

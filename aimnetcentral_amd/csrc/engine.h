@@ -76,6 +76,9 @@ struct aimnet_engine {
   // AIMNET_SETUP_RIDES / set_option("setup_rides"): periodic batches - the cell + bin-grid setup block rides on the molecule-offset
   // launch (atom counts by binary search in mol_idx) instead of following it as a launch of its own
   int setup_rides = 1;
+  // AIMNET_STATUS_OWNED / set_option("status_owned"): evaluations with one list of up to 32 768 atoms do not zero the status array in
+  // front: the status rider stores all eight words (cellwalk.h, nlist_status_owned_block) - the memset launch goes
+  int status_owned = 1;
   double* sae;
   // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row

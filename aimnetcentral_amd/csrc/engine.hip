@@ -192,6 +192,7 @@ struct Workspace {
   float *d3w, *dEdcn;                // per-atom D3 reference weights (12 floats) and dE/dCN
   float4* d3xs;                      // (x, y, z, species slot) per atom: one 16 B gather per D3 neighbour
   EwaldBuffers ew;                   // Ewald: per-system parameters, fractional coordinates, k entries (ewald.hip)
+  int* bad_part;                     // per-wave input sanity flags of launch_mol_start (status array not zeroed, SrRiders::status_all)
   int* aslot;                        // species slot of every atom (pass-0 moments, DFT-D3)
   unsigned long long* present_part;  // per-block masks of the slots present
   int n_part;
@@ -322,6 +323,7 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   W.rev_tab = c.take<unsigned long long>(W.xe ? pair_hash_bytes(N) / sizeof(unsigned long long) : 0);
   W.n_part = (N + 255) / 256;
   W.aslot = c.take<int>(n);
+  W.bad_part = c.take<int>((n + 63) / 64);
   W.present_part = c.take<unsigned long long>((size_t)W.n_part);
   W.total = align_up(c.off, 256);
 }
@@ -405,6 +407,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->status_rides = atoi(env) != 0;
     env = getenv("AIMNET_SETUP_RIDES");
     if (env) e->setup_rides = atoi(env) != 0;
+    env = getenv("AIMNET_STATUS_OWNED");
+    if (env) e->status_owned = atoi(env) != 0;
     env = getenv("AIMNET_CONV_XE");
     if (env) e->conv_xe = atoi(env);
     env = getenv("AIMNET_SPLIT_MAX");
@@ -544,6 +548,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "energy_rides") e->energy_rides = value != 0;
   else if (n == "status_rides") e->status_rides = value != 0;
   else if (n == "setup_rides") e->setup_rides = value != 0;
+  else if (n == "status_owned") e->status_owned = value != 0;
   else if (n == "split_max") e->split_max = value < 0 ? conv_split_max_default() : value;
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -568,6 +573,7 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
   else if (n == "energy_rides") *value = e->energy_rides;
   else if (n == "status_rides") *value = e->status_rides;
   else if (n == "setup_rides") *value = e->setup_rides;
+  else if (n == "status_owned") *value = e->status_owned;
   else if (n == "split_max") *value = e->split_max;
   else if (n == "p0_moments") *value = e->p0_moments ? 1 : 0;
   else if (n == "overlap_coulomb") *value = e->overlap_coulomb ? 1 : 0;
@@ -761,20 +767,24 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const bool want_species = (e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS))) || opt->dftd3 != 0;
   // small periodic batches: status zeroing, molecule offsets / sanity / species, cell + bin setup, wrapping and binning in one launch
   const bool prep1 = e->prep_fused && !ext && prep_small_applies(N, n_mol, pbc);
-  bool setup_rides = false;
+  bool setup_rides = false, status_owned = false;
   if (prep1) {
     RC(launch_prep_small(s, in->coord, in->mol_idx, in->numbers, N, n_mol, pbc ? in->cell : nullptr, n_cell, in->pbc, in->pbc_sys, ar.rc,
                          out->status,
                          want_species ? e->slot_of_z : nullptr, W.aslot, W.present_part, W.nl));
   } else {
-    AIMNET_HIP_CHECK(hipMemsetAsync(out->status, 0, 8 * sizeof(int), s));
+    // One list, its status words reduced by a rider of the SR-Coulomb launch: that rider can just as well STORE all eight status
+    // words (with the sanity flags of the launch below collected per wave), and nothing has to be zeroed in front of the evaluation.
+    const bool one_list = !ext && !(coulomb == AIMNET_COULOMB_DSF && !pbc) && opt->dftd3 == 0;
+    status_owned = e->status_rides && e->status_owned && one_list && N <= 32768;
+    if (!status_owned) AIMNET_HIP_CHECK(hipMemsetAsync(out->status, 0, 8 * sizeof(int), s));
     // periodic fast path: the cell + bin-grid setup block rides on this launch (it needs none of its output)
     setup_rides = e->setup_rides && !ext && pbc && cell_setup_rides(N, n_mol);
     CellSetupRider csr{};
     if (setup_rides) csr = cell_setup_rider(in->cell, n_cell, in->pbc, in->pbc_sys, ar.rc, N, n_mol, W.nl);
     RC(launch_mol_start(s, in->mol_idx, N, n_mol, W.nl.mol_start, W.nl.mol_c, in->numbers, out->status + 6,
                         want_species ? e->slot_of_z : nullptr, W.aslot, W.present_part,  // + aslot / present species
-                        setup_rides ? &csr : nullptr));
+                        setup_rides ? &csr : nullptr, status_owned ? W.bad_part : nullptr));
   }
   const int* mol_c = W.nl.mol_c;  // clamped to [0, n_mol): memory-safe whatever the caller passed (status[6] reports it)
   const bool d3 = opt->dftd3 != 0;
@@ -910,6 +920,12 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       rd.status_max = out->status + 0;
       rd.status_ovf = out->status + 2;
       rd.n_status_blocks = ceil_div(N, 1024);
+      if (status_owned) {
+        rd.n_status_blocks = 1;
+        rd.status_all = out->status;
+        rd.bad_part = W.bad_part;
+        rd.keep7 = ewald ? 1 : 0;
+      }
     }
     RC(launch_coulomb_sr(cs, grad, want_s, ar.sr_coulomb != 0, q_fin, W.nb_idx, W.nb_cnt, W.pg, cap, cp, N, W.ecoul, W.qbar,
                          W.fgrad, W.virial_atom, &rd));

@@ -102,7 +102,10 @@ CellSetupRider cell_setup_rider(const float* cell, int n_cell, const int pbc[3],
                                 int n_mol, NlistBuffers& b);
 int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start, int* mol_c,
                      const int* numbers = nullptr, int* bad = nullptr, const int* slot_of_z = nullptr, int* aslot = nullptr,
-                     unsigned long long* present_part = nullptr, const CellSetupRider* cell_setup = nullptr);
+                     unsigned long long* present_part = nullptr, const CellSetupRider* cell_setup = nullptr,
+                     // != NULL: the sanity flags go to bad_part[ceil(n_atoms / 64)] (one plain store per wave) instead of atomics
+                     // into *bad - for a status array that nobody has zeroed (nlist_status_owned_block combines them)
+                     int* bad_part = nullptr);
 // wrap coordinates (periodic) or copy them (non-periodic) into b.xw
 int launch_wrap(hipStream_t s, const float* coord, const int* mol_idx, int n_atoms, int n_mol, const float* cell,
                 int n_cell, const int pbc[3], NlistBuffers& b, const int* pbc_sys = nullptr, float bin_width = 0.0f,  // pbc_sys: device [n_cell][3] or NULL
@@ -298,6 +301,9 @@ struct SrRiders {
   PairMapRider hash;  // the hash build of the reverse-pair map (its lookup rides on a later launch)
   // the status words of the short-range list (nlist_status_block, cellwalk.h): n_status_blocks = ceil(n_atoms / 1024), 0 = none
   const int* cnt_true; int status_cap; int* status_max; int* status_ovf; int n_status_blocks;
+  // status_all != NULL ("owned" form, ONE rider block): nobody zeroed the status array - the block reduces the row counts and the
+  // sanity flags of launch_mol_start (bad_part) and STORES all eight words (word 7 is left alone when keep7: Ewald wrote it)
+  int* status_all; const int* bad_part; int keep7;
 };
 // embedded SRCoulomb subtraction over the rc list (sets ecoul/qbar/fgrad/virial_atom)
 int launch_coulomb_sr(hipStream_t s, bool grad, bool stress, bool enabled, const float* q, const int* nb_idx,

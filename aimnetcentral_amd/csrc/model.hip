@@ -408,7 +408,9 @@ __global__ __launch_bounds__(256) void coulomb_sr_kernel(bool enabled, const flo
       __shared__ unsigned long long s_tab[4][RH_SLOTS];
       pair_hash_block(rd.hash.nb_idx, rd.hash.nb_shift, rd.hash.nb_cnt, rd.hash.cap, n_atoms, rd.hash.tab, rd.hash.rev,
                       b - rd.n_head_blocks - rd.n_stream_blocks, s_tab);
-    } else {  // status words of the short-range list (max row length, overflow flag)
+    } else if (rd.status_all) {  // status words of the evaluation, stored by this one block (nothing was zeroed)
+      nlist_status_owned_block(rd.cnt_true, n_atoms, rd.status_cap, rd.bad_part, rd.status_all, rd.keep7);
+    } else {  // status words of the short-range list (max row length, overflow flag) into the zeroed array
       nlist_status_block(rd.cnt_true, n_atoms, rd.status_cap, rd.status_max, rd.status_ovf,
                          b - rd.n_head_blocks - rd.n_stream_blocks - rd.hash.n_blocks);
     }

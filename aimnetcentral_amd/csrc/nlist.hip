@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void mol_start_kernel(const int* __restrict__ 
                                                         int n_atoms, int n_mol, int* __restrict__ mol_start,
                                                         int* __restrict__ bad, const int* __restrict__ slot_of_z,
                                                         int* __restrict__ aslot, unsigned long long* __restrict__ present_part,
-                                                        int* __restrict__ mol_c, CellSetupRider cs) {
+                                                        int* __restrict__ mol_c, CellSetupRider cs, int* __restrict__ bad_part) {
   if (cs.sys && blockIdx.x == gridDim.x - 1) {  // rider: cell + bin-grid setup of the periodic fast path (cell_bins_setup_kernel),
     // independent of this launch's output (the atom counts come from a binary search in mol_idx): a kernel boundary less
     cell_bins_setup_block(cs, nullptr, n_mol, mol_idx, n_atoms);
@@ -104,7 +104,13 @@ __global__ __launch_bounds__(256) void mol_start_kernel(const int* __restrict__ 
       const int z = numbers[i];
       if (z < 0 || z > 63) f |= 1;
     }
-    if (f) atomicOr(bad, f);
+    if (bad_part) {  // one plain store per wave instead of atomics into a zeroed word: nothing has to be zeroed beforehand
+      // (the reader, nlist_status_owned_block, ORs the ceil(n_atoms / 64) slots)
+      const int wf = (__ballot(f & 1) ? 1 : 0) | (__ballot(f & 2) ? 2 : 0) | (__ballot(f & 4) ? 4 : 0);
+      if ((threadIdx.x & 63) == 0) bad_part[i >> 6] = wf;
+    } else if (f) {
+      atomicOr(bad, f);
+    }
   }
   for (int m = prev + 1; m <= cur && m <= n_mol; ++m) mol_start[m] = i;
   if (i == n_atoms - 1)
@@ -112,11 +118,12 @@ __global__ __launch_bounds__(256) void mol_start_kernel(const int* __restrict__ 
 }
 
 int launch_mol_start(hipStream_t s, const int* mol_idx, int n_atoms, int n_mol, int* mol_start, int* mol_c, const int* numbers,
-                     int* bad, const int* slot_of_z, int* aslot, unsigned long long* present_part, const CellSetupRider* cell_setup) {
+                     int* bad, const int* slot_of_z, int* aslot, unsigned long long* present_part, const CellSetupRider* cell_setup,
+                     int* bad_part) {
   CellSetupRider cs{};
   if (cell_setup) cs = *cell_setup;
   hipLaunchKernelGGL(mol_start_kernel, dim3(ceil_div(n_atoms, 256) + (cs.sys ? 1 : 0)), dim3(256), 0, s, mol_idx, numbers, n_atoms, n_mol,
-                     mol_start, bad, (numbers && aslot) ? slot_of_z : nullptr, aslot, present_part, mol_c, cs);
+                     mol_start, bad, (numbers && aslot) ? slot_of_z : nullptr, aslot, present_part, mol_c, cs, bad ? bad_part : nullptr);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

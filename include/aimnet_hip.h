@@ -272,6 +272,8 @@ int aimnet_debug_gemm_bf3a(int cfg, int epi, int out3, const void* A3, int lda3,
  *   "status_rides"  1 (default): when the short-range list is the only list built, status[0] / status[2] are reduced by rider blocks
  *                   of the SR-Coulomb launch instead of a launch of their own; 0: separate launch
  *   "setup_rides"   1 (default): periodic batches - the cell + bin-grid setup block rides on the molecule-offset launch; 0: its own launch
+ *   "status_owned"  1 (default): with "status_rides", up to 32 768 atoms: the status array is not zeroed in front of the evaluation,
+ *                   the rider block stores all eight words; 0: memset + atomics
  *   "emb_bias"      1 (default): pass 0's first GEMM runs over the conv columns, the embedding block is a per-element bias table
  *   "conv_mfma"     bit 0: conv forward, bit 1: conv backward on the v_mfma_f32_4x4x1_16B_f32 kernels (csrc/conv_mfma.hip)
  *                   instead of the packed-FMA VALU kernels (default 0; systems above the split threshold only)

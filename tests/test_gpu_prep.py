@@ -162,6 +162,39 @@ def test_status_words_identical_with_and_without_riders(hip_engine):
     assert np.array_equal(st[0][0], st[1][0]) and st[0][1] == st[1][1] and st[0][0][2] == 0 and st[0][0][0] > 16
 
 
+def test_status_array_without_a_memset(hip_engine):
+    """Option "status_owned": nothing zeroes the status words in front of the evaluation, one rider block stores all eight - the same
+    words arrive, bad inputs are still flagged (their flags travel per wave), an overflowing row capacity still grows.  4 608 atoms:
+    above the single-launch preparation, so the separate kernels and their riders are what runs."""
+    from aimnetcentral_amd import workloads
+
+    c, z, cell = workloads.glucose_supercell((4, 3, 4))
+    dev = hip_engine.device
+    args = [torch.from_numpy(c.astype(np.float32)).to(dev), torch.from_numpy(z).to(dev), torch.zeros(len(z), dtype=torch.int64, device=dev),
+            torch.zeros(1, device=dev)]
+    kw = dict(cell=torch.from_numpy(cell.astype(np.float32)).to(dev), forces=True, stress=True, coulomb="dsf", dsf_rc=9.0)
+    out = []
+    for v in (1, 0):
+        hip_engine.set_option("status_owned", v)
+        try:
+            hip_engine.max_nb = 16
+            r = hip_engine.eval(*args, **kw)
+            out.append(({k: t.cpu().numpy() for k, t in r.items()}, hip_engine.last_status.copy(), hip_engine.max_nb))
+            zb = z.copy()
+            zb[4000] = 99
+            with pytest.raises(ValueError, match="atomic number"):
+                hip_engine.eval(args[0], torch.from_numpy(zb).to(dev), args[2], args[3], **kw)
+            mb = np.zeros(len(z), dtype=np.int64)
+            mb[100] = 1
+            with pytest.raises(ValueError):
+                hip_engine.eval(args[0], args[1], torch.from_numpy(mb).to(dev), args[3], **kw)
+        finally:
+            hip_engine.set_option("status_owned", 1)
+    for k in out[0][0]:
+        assert np.array_equal(out[0][0][k], out[1][0][k]), k
+    assert np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2] and out[0][1][0] > 16 and not out[0][1][1:].any()
+
+
 def test_bad_inputs_are_flagged_the_same(hip_engine):
     g = golden("pbc96_dsf15")
     dev = hip_engine.device

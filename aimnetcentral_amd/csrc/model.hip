@@ -398,25 +398,29 @@ __global__ __launch_bounds__(256) void coulomb_sr_kernel(bool enabled, const flo
   // independent work that rides on this launch (a kernel boundary costs 4-5 us on the device): the last energy-head layer with
   // its backward seed, and the charge stream of the list-free DSF walk
   const int n_sr = (n_atoms + 3) >> 2;
-  if ((int)blockIdx.x >= n_sr) {
-    const int b = blockIdx.x - n_sr;
+  // the status riders come FIRST in the grid: the one-block form reads 10^4 row counts and would otherwise start last and end last
+  if ((int)blockIdx.x < rd.n_status_blocks) {
+    if (rd.status_all)  // status words of the evaluation, stored by this one block (nothing was zeroed)
+      nlist_status_owned_block(rd.cnt_true, n_atoms, rd.status_cap, rd.bad_part, rd.status_all, rd.keep7);
+    else  // status words of the short-range list (max row length, overflow flag) into the zeroed array
+      nlist_status_block(rd.cnt_true, n_atoms, rd.status_cap, rd.status_max, rd.status_ovf, blockIdx.x);
+    return;
+  }
+  const int bx = (int)blockIdx.x - rd.n_status_blocks;
+  if (bx >= n_sr) {
+    const int b = bx - n_sr;
     if (b < rd.n_head_blocks) {
       head_last_block(rd.h, rd.ldh, rd.w, rd.b, rd.k, n_atoms, rd.e_atom, rd.d, rd.zbar, b);
     } else if (b < rd.n_head_blocks + rd.n_stream_blocks) {
       charge_stream_block(rd.xs, q, n_atoms, rd.xq, rd.charges_out, b - rd.n_head_blocks);
-    } else if (b < rd.n_head_blocks + rd.n_stream_blocks + rd.hash.n_blocks) {  // hash build of the reverse-pair map (pairmap.h)
+    } else {  // hash build of the reverse-pair map (pairmap.h)
       __shared__ unsigned long long s_tab[4][RH_SLOTS];
       pair_hash_block(rd.hash.nb_idx, rd.hash.nb_shift, rd.hash.nb_cnt, rd.hash.cap, n_atoms, rd.hash.tab, rd.hash.rev,
                       b - rd.n_head_blocks - rd.n_stream_blocks, s_tab);
-    } else if (rd.status_all) {  // status words of the evaluation, stored by this one block (nothing was zeroed)
-      nlist_status_owned_block(rd.cnt_true, n_atoms, rd.status_cap, rd.bad_part, rd.status_all, rd.keep7);
-    } else {  // status words of the short-range list (max row length, overflow flag) into the zeroed array
-      nlist_status_block(rd.cnt_true, n_atoms, rd.status_cap, rd.status_max, rd.status_ovf,
-                         b - rd.n_head_blocks - rd.n_stream_blocks - rd.hash.n_blocks);
     }
     return;
   }
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int i = bx * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
   PairAcc A;

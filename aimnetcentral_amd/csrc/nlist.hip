@@ -70,12 +70,14 @@ __global__ __launch_bounds__(256) void mol_start_kernel(const int* __restrict__ 
                                                         int* __restrict__ bad, const int* __restrict__ slot_of_z,
                                                         int* __restrict__ aslot, unsigned long long* __restrict__ present_part,
                                                         int* __restrict__ mol_c, CellSetupRider cs, int* __restrict__ bad_part) {
-  if (cs.sys && blockIdx.x == gridDim.x - 1) {  // rider: cell + bin-grid setup of the periodic fast path (cell_bins_setup_kernel),
-    // independent of this launch's output (the atom counts come from a binary search in mol_idx): a kernel boundary less
+  if (cs.sys && blockIdx.x == 0) {  // rider: cell + bin-grid setup of the periodic fast path (cell_bins_setup_kernel),
+    // independent of this launch's output (the atom counts come from a binary search in mol_idx): a kernel boundary less.  FIRST
+    // block of the grid: it is the longest one (fp64 cell inverse, zeroing of the bin counters)
     cell_bins_setup_block(cs, nullptr, n_mol, mol_idx, n_atoms);
     return;
   }
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int blk = (int)blockIdx.x - (cs.sys ? 1 : 0);
+  const int i = blk * blockDim.x + threadIdx.x;
   if (slot_of_z) {  // (block-uniform)
     __shared__ unsigned long long s_mask;
     if (threadIdx.x == 0) s_mask = 0ull;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void mol_start_kernel(const int* __restrict__ 
     for (int off = 32; off > 0; off >>= 1) m |= __shfl_xor(m, off, 64);
     if ((threadIdx.x & 63) == 0) atomicOr(&s_mask, m);
     __syncthreads();
-    if (threadIdx.x == 0) present_part[blockIdx.x] = s_mask;
+    if (threadIdx.x == 0) present_part[blk] = s_mask;
   }
   if (i >= n_atoms) return;
   const int prev = (i == 0) ? -1 : min(max(mol_idx[i - 1], -1), n_mol - 1);
@@ -367,6 +369,7 @@ __global__ __launch_bounds__(256) void nlist_brute_kernel(const float* __restric
 // periodic: choose the bin grid of every system for this cutoff, then a serial prefix of bin offsets
 // first atom whose (clamped) molecule index is >= m, in a sorted mol_idx (what mol_start[m] holds once launch_mol_start has run)
 __device__ __forceinline__ int first_atom_of(const int* __restrict__ mol_idx, int n_atoms, int n_mol, int m) {
+  if (m <= 0) return 0;  // (a single system never searches: 14 dependent loads would be the longest thing in the launch)
   int lo = 0, hi = n_atoms;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;

@@ -1070,12 +1070,19 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   // the first conv backward (see `join` below)
   // The molecule energies are outputs only: with a stress request (and nothing else riding on the energy launch) their sums ride
   // on the two stress launches at the end of the evaluation instead of standing as two launches of their own here.
-  bool energy_deferred = false;
+  bool energy_deferred = false, copy_deferred = false;
   auto join = [&]() -> int {
     if (overlap) AIMNET_HIP_CHECK(hipStreamWaitEvent(s, e->ev_join, 0));
     RC(prof_mark(e, s, FAM_POINTWISE));
     if (e->energy_rides && grad && want_s && pbc && charges_written && rev_done) {
       energy_deferred = true;
+      return 0;
+    }
+    // forces only, one slice per molecule, the force-negation launch at the end (not the reverse-pair gather): the sums and the
+    // copy of the charges ride there
+    if (e->energy_rides && grad && want_f && !(want_s && pbc) && !W.xe && W.S == 1 && rev_done) {
+      energy_deferred = true;
+      copy_deferred = !charges_written;
       return 0;
     }
     RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, W.S, W.part, out->energy,
@@ -1189,7 +1196,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   // (with a stress request the force gather rides on the launch of the virial sums: independent work, one kernel boundary less)
   const bool pf_rides = W.xe && want_f && want_s && pbc;
   const PairForceRider pfr{W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, out->forces, ceil_div(N, 4)};
-  const EnergyRider erd{W.e_atom, W.ecoul, in->numbers, e->sae, W.part_e, out->energy, n_mol};
+  const EnergyRider erd{W.e_atom, W.ecoul, in->numbers, e->sae, W.part_e, out->energy, n_mol,
+                        q_fin, copy_deferred ? out->charges : nullptr, N};
   if (W.xe && want_f && !pf_rides) RC(launch_pair_force(s, W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, N, W.fgrad, out->forces));
   RC(launch_finalize(s, W.fgrad, W.virial_atom, W.nl.mol_start, in->cell, n_cell, n_mol, N, W.S, W.part,
                      (want_f && !W.xe) ? out->forces : nullptr, want_s ? out->stress : nullptr, pf_rides ? &pfr : nullptr,

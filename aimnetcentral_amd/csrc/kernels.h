@@ -336,6 +336,9 @@ struct PairForceRider {
 // finish): they are only needed at the end, and two launch boundaries go.  part: its own [n_mol][S] partial sums.
 struct EnergyRider {
   const float* e_atom; const double* ecoul; const int* numbers; const double* sae; double* part; double* energy; int n_mol;
+  // forces-only evaluations (no stress launches): with one slice per molecule (S == 1) the sums ride on the force-negation launch,
+  // together with the copy of the charges into the output (copy_dst != NULL) that the energy launch would have carried
+  const float* copy_src; float* copy_dst; int copy_n;
 };
 int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
                     const float* cell, int n_cell, int n_mol, int n_atoms, int S, double* part, float* forces,

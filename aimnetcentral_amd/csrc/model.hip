@@ -834,7 +834,20 @@ int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const
 }
 
 // ---- outputs -------------------------------------------------------------------------------------
-__global__ void forces_kernel(const float* __restrict__ fgrad, int n3, float* __restrict__ forces) {
+// riders (er.energy != NULL, S == 1): the molecule energy sums and the copy of the charges into the output - outputs only, so they
+// need no launch of their own in front of the backward pass
+__global__ __launch_bounds__(256) void forces_kernel(const float* __restrict__ fgrad, int n3, float* __restrict__ forces,
+                                                     const int* __restrict__ mol_start, EnergyRider er, int n_force_blocks) {
+  if ((int)blockIdx.x >= n_force_blocks) {
+    const int b = blockIdx.x - n_force_blocks;
+    if (b < er.n_mol) {
+      energy_partial_block(er.e_atom, er.ecoul, er.numbers, er.sae, mol_start, 1, er.energy, b);
+    } else {
+      const int e = (b - er.n_mol) * 256 + threadIdx.x;
+      if (e < er.copy_n) er.copy_dst[e] = er.copy_src[e];
+    }
+    return;
+  }
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n3) forces[e] = -fgrad[e];
 }
@@ -895,8 +908,11 @@ int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom,
   if (pair_force) pf = *pair_force;
   EnergyRider er{};
   if (energy) er = *energy;
+  const bool er_on_forces = energy && forces && !(stress && cell);  // (the engine only asks for this with S == 1)
   if (forces) {
-    hipLaunchKernelGGL(forces_kernel, dim3(ceil_div(3 * n_atoms, 256)), dim3(256), 0, s, fgrad, 3 * n_atoms, forces);
+    const int nfb = ceil_div(3 * n_atoms, 256);
+    const int n_rider = er_on_forces ? er.n_mol + (er.copy_dst ? ceil_div(er.copy_n, 256) : 0) : 0;
+    hipLaunchKernelGGL(forces_kernel, dim3(nfb + n_rider), dim3(256), 0, s, fgrad, 3 * n_atoms, forces, mol_start, er, nfb);
     AIMNET_LAUNCH_CHECK();
   }
   if (stress && cell) {

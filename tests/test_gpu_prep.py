@@ -162,6 +162,18 @@ def test_status_words_identical_with_and_without_riders(hip_engine):
     assert np.array_equal(st[0][0], st[1][0]) and st[0][1] == st[1][1] and st[0][0][2] == 0 and st[0][0][0] > 16
 
 
+@pytest.mark.parametrize("name,coulomb", [("taxol", "simple"), ("batch5", "simple"), ("batch5", "dsf")])
+def test_energy_sums_and_charge_copy_riding_on_the_force_launch_bitwise(hip_engine, name, coulomb):
+    """Forces-only evaluations of small molecules: the molecule energy sums and the copy of the charges into the output ride on the
+    force-negation launch at the end (option "energy_rides")."""
+    g = golden(name)
+    a, b = both(hip_engine, lambda: P.run(hip_engine, g, coulomb)[0], "energy_rides")
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    if name == "taxol":
+        P.compare(a, g, 113, "taxol/reference golden (riders)")
+
+
 def test_status_array_without_a_memset(hip_engine):
     """Option "status_owned": nothing zeroes the status words in front of the evaluation, one rider block stores all eight - the same
     words arrive, bad inputs are still flagged (their flags travel per wave), an overflowing row capacity still grows.  4 608 atoms:

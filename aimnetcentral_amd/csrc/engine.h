@@ -79,6 +79,9 @@ struct aimnet_engine {
   // AIMNET_STATUS_OWNED / set_option("status_owned"): evaluations with one list of up to 32 768 atoms do not zero the status array in
   // front: the status rider stores all eight words (cellwalk.h, nlist_status_owned_block) - the memset launch goes
   int status_owned = 1;
+  // AIMNET_SUMS_WHOLE / set_option("sums_whole"): up to 16 384 atoms, with the energy sums riding on the stress launch and the force
+  // gather beside them: one block per cell / per molecule sums everything (no slices, no finish launch)
+  int sums_whole = 1;
   double* sae;
   // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row

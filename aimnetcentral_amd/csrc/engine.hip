@@ -409,6 +409,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->setup_rides = atoi(env) != 0;
     env = getenv("AIMNET_STATUS_OWNED");
     if (env) e->status_owned = atoi(env) != 0;
+    env = getenv("AIMNET_SUMS_WHOLE");
+    if (env) e->sums_whole = atoi(env) != 0;
     env = getenv("AIMNET_CONV_XE");
     if (env) e->conv_xe = atoi(env);
     env = getenv("AIMNET_SPLIT_MAX");
@@ -549,6 +551,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "status_rides") e->status_rides = value != 0;
   else if (n == "setup_rides") e->setup_rides = value != 0;
   else if (n == "status_owned") e->status_owned = value != 0;
+  else if (n == "sums_whole") e->sums_whole = value != 0;
   else if (n == "split_max") e->split_max = value < 0 ? conv_split_max_default() : value;
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -574,6 +577,7 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
   else if (n == "status_rides") *value = e->status_rides;
   else if (n == "setup_rides") *value = e->setup_rides;
   else if (n == "status_owned") *value = e->status_owned;
+  else if (n == "sums_whole") *value = e->sums_whole;
   else if (n == "split_max") *value = e->split_max;
   else if (n == "p0_moments") *value = e->p0_moments ? 1 : 0;
   else if (n == "overlap_coulomb") *value = e->overlap_coulomb ? 1 : 0;
@@ -1201,7 +1205,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   if (W.xe && want_f && !pf_rides) RC(launch_pair_force(s, W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, N, W.fgrad, out->forces));
   RC(launch_finalize(s, W.fgrad, W.virial_atom, W.nl.mol_start, in->cell, n_cell, n_mol, N, W.S, W.part,
                      (want_f && !W.xe) ? out->forces : nullptr, want_s ? out->stress : nullptr, pf_rides ? &pfr : nullptr,
-                     energy_deferred ? &erd : nullptr));
+                     energy_deferred ? &erd : nullptr, e->sums_whole != 0));
   RC(prof_mark(e, s, -1));
   return AIMNET_OK;
 }

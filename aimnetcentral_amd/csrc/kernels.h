@@ -342,7 +342,8 @@ struct EnergyRider {
 };
 int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
                     const float* cell, int n_cell, int n_mol, int n_atoms, int S, double* part, float* forces,
-                    float* stress, const PairForceRider* pair_force = nullptr, const EnergyRider* energy = nullptr);
+                    float* stress, const PairForceRider* pair_force = nullptr, const EnergyRider* energy = nullptr,
+                    bool whole_ok = false);  // the sums may run as whole-cell / whole-molecule blocks without a finish launch
 int launch_copy_f32(hipStream_t s, const float* src, float* dst, size_t n);
 
 }  // namespace aimnet

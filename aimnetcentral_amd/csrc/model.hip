@@ -277,6 +277,33 @@ __device__ __forceinline__ void energy_partial_block(const float* __restrict__ e
   if (threadIdx.x == 0) part[(size_t)m * S + sl] = r;
 }
 
+// the whole molecule in ONE block (S == 1 on a few 10^4 atoms, as a rider beside a longer launch): eight atoms per thread and
+// round, their loads issued together - the slice form's two dependent loads per atom and round would take 40 round trips
+__device__ __forceinline__ void energy_whole_block(const float* __restrict__ e_atom, const double* __restrict__ ecoul,
+                                                   const int* __restrict__ numbers, const double* __restrict__ sae,
+                                                   const int* __restrict__ mol_start, double* __restrict__ energy, int m) {
+  __shared__ double sh[4];
+  const int lo = mol_start[m], hi = mol_start[m + 1];
+  double acc = 0.0;
+  for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += 8 * (int)blockDim.x) {
+    int z[8];
+    float ea[8];
+    double ec[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * (int)blockDim.x, ii = i < hi ? i : lo;
+      z[k] = min(63, max(0, numbers[ii]));
+      ea[k] = e_atom[ii];
+      ec[k] = ecoul[ii];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i0 + k * (int)blockDim.x < hi) acc += (double)ea[k] + sae[z[k]] + ec[k];
+  }
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) energy[m] = r;
+}
+
 __global__ __launch_bounds__(256) void energy_partial_kernel(const float* __restrict__ e_atom,
                                                             const double* __restrict__ ecoul,
                                                             const int* __restrict__ numbers,
@@ -856,9 +883,17 @@ __global__ __launch_bounds__(256) void forces_kernel(const float* __restrict__ f
 __global__ __launch_bounds__(256) void stress_partial_kernel(const float* __restrict__ virial_atom,
                                                             const int* __restrict__ mol_start, int n_cell, int n_mol,
                                                             int S, double* __restrict__ part, const float* __restrict__ fgrad,
-                                                            int n_atoms, PairForceRider pf, EnergyRider er) {
-  if ((int)blockIdx.x >= S * n_cell) {  // riders (independent of the virial sums; a kernel boundary less each)
-    const int b = blockIdx.x - S * n_cell;
+                                                            int n_atoms, PairForceRider pf, EnergyRider er,
+                                                            const float* __restrict__ cell, float* __restrict__ stress_whole) {
+  // whole form (stress_whole != NULL, S == 1): ONE block per cell sums all of its atoms and writes the stress itself, one block
+  // per molecule the energy - no finish launch; they come first in the grid and run beside the force-gather riders
+  const int n_first = S * n_cell + (stress_whole ? er.n_mol : 0);
+  if (stress_whole && (int)blockIdx.x >= n_cell && (int)blockIdx.x < n_first) {
+    energy_whole_block(er.e_atom, er.ecoul, er.numbers, er.sae, mol_start, er.energy, blockIdx.x - n_cell);
+    return;
+  }
+  if ((int)blockIdx.x >= n_first) {  // riders (independent of the virial sums; a kernel boundary less each)
+    const int b = blockIdx.x - n_first;
     if (b < pf.n_blocks)  // the force gather of the reverse-pair form
       pair_force_block(pf.nb_idx, pf.nb_cnt, pf.rev, pf.pairbuf, pf.cap, n_atoms, fgrad, pf.forces, b);
     else  // the molecule energies' partial sums (S == 1: the energies themselves)
@@ -869,6 +904,36 @@ __global__ __launch_bounds__(256) void stress_partial_kernel(const float* __rest
   const int sidx = blockIdx.x / S, sl = blockIdx.x % S;
   const int i0 = (n_cell == 1) ? mol_start[0] : mol_start[sidx];
   const int i1 = (n_cell == 1) ? mol_start[n_mol] : mol_start[sidx + 1];
+  if (stress_whole) {  // four atoms (36 floats) per thread and round in flight
+    double a9[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a9[k] = 0.0;
+    for (int j0 = i0 + (int)threadIdx.x; j0 < i1; j0 += 4 * (int)blockDim.x) {
+      float v[4][9];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u * (int)blockDim.x, jj = j < i1 ? j : i0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[u][k] = virial_atom[(size_t)jj * 9 + k];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + u * (int)blockDim.x < i1) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) a9[k] += (double)v[u][k];
+        }
+    }
+    const float* c = cell + (size_t)sidx * 9;
+    const double det = (double)c[0] * ((double)c[4] * c[8] - (double)c[5] * c[7]) -
+                       (double)c[1] * ((double)c[3] * c[8] - (double)c[5] * c[6]) +
+                       (double)c[2] * ((double)c[3] * c[7] - (double)c[4] * c[6]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double r = block_sum(a9[k], sh);
+      if (threadIdx.x == 0) stress_whole[sidx * 9 + k] = (float)(r / fabs(det));
+    }
+    return;
+  }
   const int L = (i1 - i0 + S - 1) / S;
   const int lo = min(i1, i0 + sl * L), hi = min(i1, lo + L);
   for (int k = 0; k < 9; ++k) {
@@ -903,7 +968,7 @@ __global__ void stress_finish_kernel(const double* __restrict__ part, int S, int
 
 int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
                     const float* cell, int n_cell, int n_mol, int n_atoms, int S, double* part, float* forces,
-                    float* stress, const PairForceRider* pair_force, const EnergyRider* energy) {
+                    float* stress, const PairForceRider* pair_force, const EnergyRider* energy, bool whole_ok) {
   PairForceRider pf{};
   if (pair_force) pf = *pair_force;
   EnergyRider er{};
@@ -917,9 +982,18 @@ int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom,
   }
   if (stress && cell) {
     S = S < 1 ? 1 : S;
+    // whole form: up to 16 384 atoms per launch with the energy riders and the force gather beside them (that gather is what the
+    // single blocks hide behind) - the sums need no slices and no finish launch
+    const bool whole = energy && pf.n_blocks > 0 && n_atoms <= 16384 && whole_ok;
+    if (whole) {
+      hipLaunchKernelGGL(stress_partial_kernel, dim3(n_cell + er.n_mol + pf.n_blocks), dim3(256), 0, s, virial_atom, mol_start, n_cell, n_mol,
+                         1, part, fgrad, n_atoms, pf, er, cell, stress);
+      AIMNET_LAUNCH_CHECK();
+      return 0;
+    }
     const int n_er = energy ? S * er.n_mol : 0;
     hipLaunchKernelGGL(stress_partial_kernel, dim3(S * n_cell + pf.n_blocks + n_er), dim3(256), 0, s, virial_atom, mol_start, n_cell, n_mol,
-                       S, part, fgrad, n_atoms, pf, er);
+                       S, part, fgrad, n_atoms, pf, er, cell, nullptr);
     AIMNET_LAUNCH_CHECK();
     hipLaunchKernelGGL(stress_finish_kernel, dim3(ceil_div(n_cell * 9 + (energy && S > 1 ? er.n_mol : 0), 64)), dim3(64), 0, s, part, S,
                        n_cell, cell, stress, er);

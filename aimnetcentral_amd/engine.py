@@ -142,7 +142,7 @@ class HipEngine:
 
     # ------------------------------------------------------------------------------------------
     def set_option(self, name: str, value: int) -> None:
-        """Engine switch for A/B and parity runs (include/aimnet_hip.h, aimnet_engine_set_option): "gemm_bf3", "gemm_presplit", "head_fused", "prep_fused", "energy_rides", "status_rides", "setup_rides", "status_owned", "conv_mfma",
+        """Engine switch for A/B and parity runs (include/aimnet_hip.h, aimnet_engine_set_option): "gemm_bf3", "gemm_presplit", "head_fused", "prep_fused", "energy_rides", "status_rides", "setup_rides", "status_owned", "sums_whole", "conv_mfma",
         "conv_xe", "split_max", "p0_moments", "spatial_order", "overlap_coulomb"."""
         _lib.check(self.lib.aimnet_engine_set_option(self._h, name.encode(), int(value)), "aimnet_engine_set_option")
         self._ws = None  # the workspace layout depends on the switches

@@ -274,6 +274,8 @@ int aimnet_debug_gemm_bf3a(int cfg, int epi, int out3, const void* A3, int lda3,
  *   "setup_rides"   1 (default): periodic batches - the cell + bin-grid setup block rides on the molecule-offset launch; 0: its own launch
  *   "status_owned"  1 (default): with "status_rides", up to 32 768 atoms: the status array is not zeroed in front of the evaluation,
  *                   the rider block stores all eight words; 0: memset + atomics
+ *   "sums_whole"    1 (default): up to 16 384 atoms, energy sums riding on the stress launch beside the force gather: one block per
+ *                   cell / molecule sums everything, no finish launch; 0: sliced sums + finish launch
  *   "emb_bias"      1 (default): pass 0's first GEMM runs over the conv columns, the embedding block is a per-element bias table
  *   "conv_mfma"     bit 0: conv forward, bit 1: conv backward on the v_mfma_f32_4x4x1_16B_f32 kernels (csrc/conv_mfma.hip)
  *                   instead of the packed-FMA VALU kernels (default 0; systems above the split threshold only)

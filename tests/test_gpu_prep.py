@@ -174,6 +174,35 @@ def test_energy_sums_and_charge_copy_riding_on_the_force_launch_bitwise(hip_engi
         P.compare(a, g, 113, "taxol/reference golden (riders)")
 
 
+@pytest.mark.parametrize("name", ["pbc96_dsf15", "pbc2x96_dsf9"])
+def test_whole_cell_sums_agree_with_the_sliced_ones(hip_engine, name):
+    """Option "sums_whole": one block per cell / per molecule sums the virial / the energy and writes the result (no slices, no finish
+    launch) when the sums ride beside the force gather.  A different association of fp64 sums: energies to 1e-13 relative, stress
+    to the last float bit or two; forces and charges untouched."""
+    from aimnetcentral_amd import workloads
+
+    if name == "pbc96_dsf15":  # above split_max, so that the reverse-pair force gather (the launch the sums ride on) is what runs
+        c, z, cell = workloads.glucose_supercell((2, 3, 4))
+        mol, q = np.zeros(len(z), dtype=np.int64), np.zeros(1, np.float32)
+    else:
+        g = golden(name)
+        c, z, cell, mol, q = g["coord"], g["numbers"], g["cell"], g["mol_idx"], np.atleast_1d(g["charge"]).astype(np.float32)
+        c, z, mol = np.tile(c, (8, 1)), np.tile(z, 8), np.repeat(np.arange(16), 96)  # 16 systems of 96 atoms: 1 536 atoms
+        cell, q = np.tile(cell, (8, 1, 1)), np.tile(q, 8)
+    dev = hip_engine.device
+
+    def go():
+        r = hip_engine.eval(torch.from_numpy(c.astype(np.float32)).to(dev), torch.from_numpy(z).to(dev), torch.from_numpy(mol).to(dev),
+                            torch.from_numpy(q).to(dev), cell=torch.from_numpy(cell.astype(np.float32)).to(dev), forces=True, stress=True,
+                            coulomb="dsf", dsf_rc=9.0)
+        return {k: v.cpu().numpy() for k, v in r.items()}
+
+    a, b = both(hip_engine, go, "sums_whole")
+    assert np.array_equal(a["forces"], b["forces"]) and np.array_equal(a["charges"], b["charges"])
+    assert np.abs(a["energy"] - b["energy"]).max() <= 1e-13 * np.abs(b["energy"]).max()
+    assert np.abs(a["stress"] - b["stress"]).max() <= 3e-7 * np.abs(b["stress"]).max()
+
+
 def test_status_array_without_a_memset(hip_engine):
     """Option "status_owned": nothing zeroes the status words in front of the evaluation, one rider block stores all eight - the same
     words arrive, bad inputs are still flagged (their flags travel per wave), an overflowing row capacity still grows.  4 608 atoms:

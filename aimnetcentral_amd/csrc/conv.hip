@@ -605,6 +605,7 @@ int launch_unconcat(hipStream_t s, int nq, const float* xbar, int ldx, const flo
 
 // ------------------------------------------------------------------------------------------------
 constexpr int CHB = 48;  // chunk of the backward kernels: 8.1 KiB of LDS per wave -> four blocks per CU
+static_assert(CHB % 16 == 0, "the basis table of a chunk is filled 16 pairs per trip: other sizes write past the LDS arrays");
 struct BwdWaveLds {
   float gs[CHB][G_];
   float dgs[CHB][G_];

@@ -1,7 +1,7 @@
 // Ewald summation for periodic point charges (LRCoulomb "ewald", reference aimnet/modules/lr.py:617-720, parameters and the
 // per-call real-space list calculator.py:1560-1603).  The reference delegates the arithmetic to nvalchemiops.ewald_summation
-// (un-vendored, 0.4.0): restated from the published method, see oracle/aimnet2_oracle.py (ewald_*), PARITY UNPINNED against
-// the reference itself.
+// (un-vendored, 0.4.0; unpinned against that kernel).  Restated from the published method and from the reference's in-tree
+// pure-PyTorch Ewald (ops.py:196-276), to whose golden matrices the oracle is pinned: oracle/aimnet2_oracle.py (ewald_*).
 //
 //   E / k_e = 1/2 sum'_{i,j,n} q_i q_j erfc(alpha r) / r                         real space, r < rc      (model.hip: the cell-grid walk)
 //           + (2 pi / V) sum_{k != 0} exp(-k^2 / 4 alpha^2) / k^2 |S(k)|^2       reciprocal space, |k| <= kc   (here)

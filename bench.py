@@ -507,8 +507,8 @@ def main():
         ewald = {"ms_per_step": ew_ms, "value": n_atoms / (ew_ms * 1e-3), "unit": "atoms*steps/s", "ewald_accuracy": 1e-6,
                  "k_box_entries": k_entries, "energy_eV": float(r_ew["energy"][0]),
                  "note": "set_lrcoulomb_method('ewald'): real space on the cell-grid walk, exact structure-factor sum in reciprocal space; "
-                         "parity against the oracle's restatement in tests/test_gpu_ewald.py (unpinned against the reference: its "
-                         "arithmetic is nvalchemiops')"}
+                         "parity against the oracle's restatement in tests/test_gpu_ewald.py; the oracle is pinned to the reference's "
+                         "in-tree pure-PyTorch Ewald (ops.py:196) and to Madelung constants, not to nvalchemiops' kernel (absent)"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

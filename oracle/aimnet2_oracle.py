@@ -16,11 +16,14 @@ It restates, op for op, the PyTorch eager sequence of the reference (all paths r
   * AIMNet2.forward models/aimnet2.py:141-187 (_update_q :122-139), ops.nse ops.py:99-145
   * Output/AtomicShift/AtomicSum modules/core.py:71-132, SRCoulomb lr.py:986-1032 (_calc_coulomb_sr :21-62)
   * LRCoulomb.coul_simple lr.py:311-331, _coul_dsf_torch lr.py:559-615
-  * LRCoulomb "ewald" (lr.py:617-720, calculator.py:1560-1603): PARITY UNPINNED against the reference - the arithmetic and the
-    parameter estimate live in nvalchemi-toolkit-ops 0.4.0 (ewald_summation / estimate_ewald_parameters), which is not in the
-    reference tree.  Restated here from the published method (Ewald 1921; the cost-balanced parameter choice
-    eta = (V^2 / N)^(1/6) / sqrt(2 pi), rc = sqrt(-2 ln eps) eta, kc = sqrt(-2 ln eps) / eta, alpha = 1 / (sqrt(2) eta)) and
-    pinned to published Madelung constants and to an fp64 direct lattice sum (tests/test_oracle_ewald.py).
+  * LRCoulomb "ewald" (lr.py:617-720, calculator.py:1560-1603): the production arithmetic and parameter estimate live in
+    nvalchemi-toolkit-ops 0.4.0 (ewald_summation / estimate_ewald_parameters), which is not in the reference tree - against THAT the
+    parity is unpinned.  What the tree does hold is its own pure-PyTorch Ewald, `aimnet.ops.coulomb_matrix_ewald` (ops.py:196-276,
+    "kept for ... regression cross-checks"), with the same parameter formula (eta = (V^2 / N)^(1/6) / sqrt(2 pi),
+    rc = sqrt(-2 ln eps) eta, kc = sqrt(-2 ln eps) / eta, alpha = 1 / (sqrt(2) eta); also calculator.py:660-667): the restatement
+    here is PINNED to golden matrices of that function (tests/golden/ewald_matrix.npz, energies and potentials to its fp32 rounding)
+    and, beyond fp32, to published Madelung constants, independence of the splitting and finite differences
+    (tests/test_oracle_ewald.py).
   * derivatives: calculators/derivatives.py:47-146 (autograd forces; row-vector strain stress)
 Forces/stress come from torch.autograd exactly as in the reference; oracle/aimnet2_analytic.py
 holds the hand-derived backward that the HIP kernels implement and is itself checked against

@@ -392,9 +392,39 @@ def check_hf_layout() -> None:
     print(f"hf layout: reference load_from_hf_repo and loader.load_hf_dir agree on {n} tensors and the metadata")
 
 
+def make_ewald() -> None:
+    """Golden Ewald Coulomb matrices from the reference's in-tree pure-PyTorch twin, `aimnet.ops.coulomb_matrix_ewald` (ops.py:196-
+    276; deprecated in favour of nvalchemiops but "kept for ... regression cross-checks"): J with E = k_e/2 q^T J q for a NEUTRAL
+    cell (no background term in J), fp32 (the function builds its lattice shifts in fp32), for a triclinic cell of 12 point charges at
+    two accuracies and for rock salt.  The
+    oracle's Ewald restatement (oracle/aimnet2_oracle.py, ewald_*) is held against these in tests/test_oracle_ewald.py."""
+    from aimnet import ops
+
+    rng = np.random.default_rng(0)
+    cell = np.array([[7.0, 0.3, -0.2], [0.5, 6.0, 0.4], [-0.3, 0.2, 8.0]])
+    coord = rng.random((12, 3)) @ cell
+    q = rng.normal(size=12)
+    q -= q.mean()
+    out = {"cell": cell, "coord": coord, "q": q}
+    for acc in (1e-6, 1e-8):
+        J = ops.coulomb_matrix_ewald(torch.tensor(coord, dtype=torch.float32), torch.tensor(cell, dtype=torch.float32), accuracy=acc).numpy()
+        out[f"J_{acc:g}"] = J
+        out[f"E_{acc:g}"] = np.float64(0.5 * q @ J.astype(np.float64) @ q)
+    nacl = np.array([[i, j, k] for i in range(2) for j in range(2) for k in range(2)], float)
+    qn = np.array([1.0 if (i + j + k) % 2 == 0 else -1.0 for i in range(2) for j in range(2) for k in range(2)])
+    Jn = ops.coulomb_matrix_ewald(torch.tensor(nacl, dtype=torch.float32), torch.tensor(2.0 * np.eye(3), dtype=torch.float32),
+                                  accuracy=1e-8).numpy()
+    out.update(nacl_coord=nacl, nacl_q=qn, nacl_cell=2.0 * np.eye(3), nacl_E=np.float64(0.5 * qn @ Jn.astype(np.float64) @ qn))
+    np.savez_compressed(os.path.join(HERE, "ewald_matrix.npz"), **out)
+    print("ewald_matrix.npz: E(1e-6) %.10f  E(1e-8) %.10f  Madelung/pair %.10f" % (out["E_1e-06"], out["E_1e-08"], out["nacl_E"] / 4.0))
+
+
 def main() -> None:
     if "--check-hf" in sys.argv:
         check_hf_layout()
+        return
+    if "--only-ewald" in sys.argv:
+        make_ewald()
         return
     if "--only-nse" in sys.argv:
         make_nse()

@@ -1,6 +1,7 @@
 """Ewald summation (engine method "ewald", csrc/ewald.hip + the real-space term on the cell-grid walk) against the oracle's
-restatement (oracle/aimnet2_oracle.py, ewald_*: pinned to Madelung constants and a direct lattice sum in tests/test_oracle_ewald.py;
-PARITY UNPINNED against the reference itself - its arithmetic is nvalchemiops', not in the reference tree).  Gates: the ones the
+restatement (oracle/aimnet2_oracle.py, ewald_*: pinned in tests/test_oracle_ewald.py to golden matrices of the reference's in-tree
+pure-PyTorch Ewald `ops.coulomb_matrix_ewald`, to Madelung constants and to a direct lattice sum; unpinned against nvalchemiops'
+kernel, which is not in the reference tree).  Gates: the ones the
 periodic DSF fixtures use (tests/test_gpu_parity.py), energies additionally against the fp64 oracle."""
 from __future__ import annotations
 

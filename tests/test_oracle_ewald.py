@@ -100,3 +100,39 @@ def test_evaluate_ewald_runs_and_rejects_open_boundaries(oracle64):
 
     with pytest.raises(ValueError):
         O.evaluate(oracle64, g["coord"], g["numbers"], np.zeros(1, np.float32), cell=g["cell"], pbc=(True, True, False), coulomb="ewald")
+
+
+def test_against_the_references_in_tree_ewald_twin():
+    """tests/golden/ewald_matrix.npz: Coulomb matrices of `aimnet.ops.coulomb_matrix_ewald` (ops.py:196-276, the reference's own
+    pure-PyTorch Ewald, fp32; generated by tests/golden/make_golden.py --only-ewald): E = 1/2 q^T J q of a neutral triclinic cell of
+    12 charges and of rock salt, and the potential J q, against this oracle's pieces.  Same splitting parameters by construction
+    (the formula of calculator.py:660-667 is the one of ops.py:207-214); agreement to the fp32 rounding of the reference's matrix."""
+    from conftest import golden
+
+    g = golden("ewald_matrix")
+    for acc, key in ((1e-6, "1e-06"), (1e-8, "1e-08")):
+        e = _ewald_point_charges(g["coord"], g["q"], g["cell"], accuracy=acc)
+        assert abs(e - float(g["E_" + key])) < 3e-6 * abs(e), (acc, e, float(g["E_" + key]))
+    e = _ewald_point_charges(g["nacl_coord"], g["nacl_q"], g["nacl_cell"], accuracy=1e-8)
+    assert abs(e - float(g["nacl_E"])) < 3e-6 * abs(e)
+    # the potential phi = dE/dq = J q (neutral cell: no background term): reciprocal part by autograd + real part + self term
+    al, rc, kc = O.ewald_parameters(12, abs(np.linalg.det(g["cell"])), 1e-8)
+    nh = O.ewald_kvectors(g["cell"], kc)
+    q = torch.tensor(g["q"], requires_grad=True)
+    x, cell = torch.tensor(g["coord"]), torch.tensor(g["cell"])
+    e_rec = O.ewald_reciprocal(x, q, cell, nh, al)
+    (phi_rec,) = torch.autograd.grad(e_rec, q)
+    heights = abs(np.linalg.det(g["cell"])) / np.array([np.linalg.norm(np.cross(g["cell"][(a + 1) % 3], g["cell"][(a + 2) % 3])) for a in range(3)])
+    R = [int(math.ceil(rc / h)) for h in heights]
+    phi_real = np.zeros(12)
+    for sx in range(-R[0], R[0] + 1):
+        for sy in range(-R[1], R[1] + 1):
+            for sz in range(-R[2], R[2] + 1):
+                d = g["coord"][None, :, :] + np.array([sx, sy, sz]) @ g["cell"] - g["coord"][:, None, :]
+                r = np.sqrt((d * d).sum(-1))
+                m = (r > 1e-9) & (r < rc)
+                rr = np.where(m, r, 1.0)
+                phi_real += (np.where(m, torch.erfc(torch.tensor(al * rr)).numpy() / rr, 0.0) * g["q"][None, :]).sum(-1)
+    phi = phi_rec.detach().numpy() + phi_real - 2.0 * al / math.sqrt(math.pi) * g["q"]
+    ref = g["J_1e-08"].astype(np.float64) @ g["q"]
+    assert np.abs(phi - ref).max() < 5e-6 * np.abs(ref).max()

@@ -38,6 +38,8 @@ EXPORTED_SYMBOLS = (
     "aimnet_debug_split_bf3",
     "aimnet_debug_gemm_bf3",
     "aimnet_debug_gemm_bf3a",
+    "aimnet_debug_split_h2",
+    "aimnet_debug_gemm_h2",
     "aimnet_debug_mfma4_probe",
     "aimnet_engine_set_option",
     "aimnet_engine_get_option",
@@ -214,6 +216,10 @@ def load() -> C.CDLL:
     lib.aimnet_engine_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.aimnet_engine_get_option.restype = C.c_int
     lib.aimnet_engine_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
+    lib.aimnet_debug_split_h2.restype = C.c_int
+    lib.aimnet_debug_split_h2.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
+    lib.aimnet_debug_gemm_h2.restype = C.c_int
+    lib.aimnet_debug_gemm_h2.argtypes = list(lib.aimnet_debug_gemm_bf3a.argtypes)
     lib.aimnet_debug_mfma4_probe.restype = C.c_int
     lib.aimnet_debug_mfma4_probe.argtypes = [vp, vp]
     lib.aimnet_neighbor_list_workspace_bytes.restype = sz

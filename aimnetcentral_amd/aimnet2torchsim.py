@@ -137,8 +137,8 @@ class AIMNet2TorchSim(_Base):
         if bool(pbc.any()):
             # "(cell != 0).any()" is a device read: done once per cell tensor (identity + version), not once per MD step
             key = (cell.data_ptr(), getattr(cell, "_version", None), tuple(cell.shape))
-            if self._cell_key is None or self._cell_key[0] != key:
-                self._cell_key = (key, bool((cell != 0).any()))
+            if self._cell_key is None or self._cell_key[0] != key or self._cell_key[2] is not cell:
+                self._cell_key = (key, bool((cell != 0).any()), cell)  # (holds the tensor: see _converted)
             nonzero = self._cell_key[1]
         if bool(pbc.any()) and nonzero:
             data["cell"] = cell.contiguous()
@@ -155,10 +155,13 @@ class AIMNet2TorchSim(_Base):
         cache = self.__dict__.setdefault("_conv_cache", {})
         key = (src.data_ptr(), getattr(src, "_version", None), tuple(src.shape), src.dtype, src.device)
         hit = cache.get(name)
-        if hit is None or hit[0] != key:
-            hit = (key, src.to(dtype))
+        # the entry HOLDS the source tensor: its storage cannot be recycled for another state's numbers while the entry lives, so
+        # an equal (address, version) key can only come from the very same tensor (a freed tensor's address is reused at once by
+        # the caching allocator, with _version 0 again)
+        if hit is None or hit[0] != key or hit[1] is not src:
+            hit = (key, src, src.to(dtype))
             cache[name] = hit
-        return hit[1]
+        return hit[2]
 
     @staticmethod
     def _per_system(state, names: tuple[str, ...], default: float, n_sys: int):

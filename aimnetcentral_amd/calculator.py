@@ -279,6 +279,12 @@ class AIMNet2Calculator:
             # to the requested accuracy.
             self._ewald_accuracy = float(ewald_accuracy)
             self._coulomb_cutoff = None
+            if method == "pme":
+                # honesty about the one unbuilt piece (aimnet/modules/lr.py:752, calculator.py:1566-1586): no particle mesh here
+                warnings.warn("set_lrcoulomb_method('pme'): this engine has no particle-mesh kernel; the request is served by the "
+                              "exact Ewald structure-factor sum at the same accuracy (O(N*K) instead of O(N log N): equal energies, "
+                              "slower above ~1e5 atoms).  PME mesh parameters (mesh spacing / spline order) do not apply and are ignored.",
+                              UserWarning, stacklevel=2)
         else:
             self._coulomb_cutoff = float("inf")
         if self._coulomb_cutoff is not None:

@@ -20,7 +20,7 @@
 #include <stdlib.h>
 
 #include "conv_common.h"
-#include "gemm_bf3_common.h"
+#include "gemm_h2_common.h"
 #include "pairmap.h"
 
 namespace aimnet {
@@ -60,9 +60,10 @@ struct FwdWaveLds {
 #ifndef AIMNET_PROBE_FWD_OCC
 #define AIMNET_PROBE_FWD_OCC 4
 #endif
-// X3: the MLP input row is written pre-split for gemm_bf3a.hip ("bf3" layout: per 32 columns [plane 0][plane 1][plane 2] x 32 bf16,
-// fp32 == p0 + p1 + p2 exactly; `x` then points at bf16 elements, 3 * ldx per row) instead of fp32.
-template <int NQ, bool SPLIT, bool P0M = false, bool X3 = false>
+// X3: the MLP input row is written pre-split instead of fp32 - 1: for gemm_bf3a.hip ("bf3" layout: per 32 columns [plane 0][plane 1]
+// [plane 2] x 32 bf16, fp32 == p0 + p1 + p2 exactly; `x` then points at bf16 elements, 3 * ldx per row); 2: for gemm_h2.hip ("h2"
+// layout, activation form: per 32 columns [hi][lo] x 32 fp16, 2 * ldx elements per row; gemm_h2_common.h).
+template <int NQ, bool SPLIT, bool P0M = false, int X3 = 0>
 __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fwd_kernel(const float* __restrict__ a, const int* __restrict__ row_of,
                                                       const float* __restrict__ q,
                                                       const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
@@ -333,9 +334,9 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
       const int ri = row_of ? min(63, max(0, row_of[i])) : i;
       const float4 av = reinterpret_cast<const float4*>(a + (size_t)ri * NF)[lane];
       if (X3) {
-        unsigned short* x3 = reinterpret_cast<unsigned short*>(x) + (size_t)i * 3 * ldx;
-        store_bf3_x4(x3, 4 * lane, f32x4{av.x, av.y, av.z, av.w});
-        store_bf3_x4(x3, NF + 4 * lane, f32x4{acc[0][0].x, acc[0][0].y, acc[0][1].x, acc[0][1].y});
+        unsigned short* x3 = reinterpret_cast<unsigned short*>(x) + (size_t)i * (X3 == 2 ? 2 : 3) * ldx;
+        store_split_x4<X3>(x3, 4 * lane, f32x4{av.x, av.y, av.z, av.w});
+        store_split_x4<X3>(x3, NF + 4 * lane, f32x4{acc[0][0].x, acc[0][0].y, acc[0][1].x, acc[0][1].y});
       } else {
         float* xr = x + (size_t)i * ldx;
         reinterpret_cast<float4*>(xr)[lane] = av;
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
     lds_sync<SPLIT>();
     if (live) {
       float* xr = x + (size_t)i * ldx;
-      unsigned short* x3 = reinterpret_cast<unsigned short*>(x) + (size_t)i * 3 * ldx;
+      unsigned short* x3 = reinterpret_cast<unsigned short*>(x) + (size_t)i * (X3 == 2 ? 2 : 3) * ldx;
       // X3: the columns from 2 NF on are staged in the wave's LDS scratch (behind the 864 floats of sv; the chunk arrays that follow
       // gs are idle in the epilogue) and leave as 8-byte plane pieces, four consecutive columns per lane
       float* xt = sv + 864;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
       if (X3) {
         lds_sync<false>();
         const int c = 4 * lane;
-        if (c < ldx - 2 * NF) store_bf3_x4(x3, 2 * NF + c, f32x4{xt[c], xt[c + 1], xt[c + 2], xt[c + 3]});
+        if (c < ldx - 2 * NF) store_split_x4<X3>(x3, 2 * NF + c, f32x4{xt[c], xt[c + 1], xt[c + 2], xt[c + 3]});
       }
     }
   }
@@ -420,15 +421,18 @@ int conv_split_max_default() { return SPLIT_MAX_ATOMS; }
 int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, const float* q, const int* nb_idx,
                     const int* nb_cnt, const float4* pg, int cap, const float* agh_a, const float* agh_q, BasisParams bp,
                     float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order, bool species_moments,
-                    int split_max, bool x_bf3) {
+                    int split_max, int x_split) {
   const bool split = n_atoms <= split_max;
 
   // (one-wave-per-atom form: exactly the 4 blocks per CU that are resident - with twice as many the second half only queues
   // behind the first and pays the block prologue again: 0.217 -> 0.207 ms/step over the three launches)
   const int grid = split ? n_atoms : min(ceil_div(n_atoms, APB), device_cus() * AIMNET_PROBE_FWD_OCC);
   if (species_moments && row_of && nq == 0 && !split) {  // pass 0 of a large system: per-element moments instead of row gathers
-    if (x_bf3)
-      hipLaunchKernelGGL((conv_fwd_kernel<0, false, true, true>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap,
+    if (x_split == 2)
+      hipLaunchKernelGGL((conv_fwd_kernel<0, false, true, 2>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap,
+                         agh_a, agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order);
+    else if (x_split)
+      hipLaunchKernelGGL((conv_fwd_kernel<0, false, true, 1>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap,
                          agh_a, agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order);
     else
       hipLaunchKernelGGL((conv_fwd_kernel<0, false, true>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, agh_a,
@@ -436,13 +440,16 @@ int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, co
     AIMNET_LAUNCH_CHECK();
     return 0;
   }
-  if (x_bf3) {
-#define AIMNET_FWD3(HQ, SP)                                                                                                       \
-  hipLaunchKernelGGL((conv_fwd_kernel<HQ, SP, false, true>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, \
+  if (x_split) {
+#define AIMNET_FWD3(HQ, SP, F)                                                                                                 \
+  hipLaunchKernelGGL((conv_fwd_kernel<HQ, SP, false, F>), dim3(grid), dim3(256), 0, s, a, row_of, q, nb_idx, nb_cnt, pg, cap, \
                      agh_a, agh_q, bp, x, ldx, Vsave, Vqsave, n_atoms, order)
-    if (nq == 2) { if (split) AIMNET_FWD3(2, true); else AIMNET_FWD3(2, false); }
-    else if (nq == 1) { if (split) AIMNET_FWD3(1, true); else AIMNET_FWD3(1, false); }
-    else { if (split) AIMNET_FWD3(0, true); else AIMNET_FWD3(0, false); }
+#define AIMNET_FWD3F(HQ, SP) \
+  do { if (x_split == 2) AIMNET_FWD3(HQ, SP, 2); else AIMNET_FWD3(HQ, SP, 1); } while (0)
+    if (nq == 2) { if (split) AIMNET_FWD3F(2, true); else AIMNET_FWD3F(2, false); }
+    else if (nq == 1) { if (split) AIMNET_FWD3F(1, true); else AIMNET_FWD3F(1, false); }
+    else { if (split) AIMNET_FWD3F(0, true); else AIMNET_FWD3F(0, false); }
+#undef AIMNET_FWD3F
 #undef AIMNET_FWD3
     AIMNET_LAUNCH_CHECK();
     return 0;

@@ -24,6 +24,8 @@ struct Layer {
   int neg_w3 = 0, neg_wt3 = 0;   // k-block (of 32) from which w3 / wt3 are stored negated (sign-flipped accumulation phase)
   unsigned short* w3a = nullptr;   // the same two operands with every ODD k-block negated (BF3_ALT): gemm_bf3a.hip / gemm_head.hip,
   unsigned short* wt3a = nullptr;  // which accumulate even / odd k-steps separately and subtract (no data-dependent split point)
+  unsigned short* w2a = nullptr;   // the same two operands in the fp16x2-split form of gemm_h2.hip ("h2", H2_WEIGHT: hi planes of the
+  unsigned short* wt2a = nullptr;  // odd k-blocks negated; 2 * k_in resp. 2 * k_out 16-bit elements per row); NULL: out of fp16's range
 };
 
 struct View {
@@ -61,6 +63,12 @@ struct aimnet_engine {
   // vector work in its main loop.  0 = fp32 activations, split inside gemm_bf3.hip's loop (round 3; also what the tangent sweep of
   // hvp.hip, small batches and AIMNET_KEEP_INTERMEDIATES use).
   int gemm_presplit = 1;
+  // AIMNET_GEMM_H2 / set_option("gemm_h2"): wherever the activations are pre-split, they and the weights take the fp16x2-split form
+  // (gemm_h2_common.h: fp32 == hi + lo / 4096 to 2^-24, three matrix instructions per tile and k-step, 4 bytes per element) instead
+  // of the bf16x3 form (six instructions, 6 bytes).  0 = bf16x3 (gemm_bf3a.hip).  Needs every weight inside fp16's range
+  // (h2_fits; activations beyond it surface as non-finite outputs and the Python layer repeats the call with gemm_h2 = 0).
+  int gemm_h2 = 1;
+  bool h2_fits = true;
   // AIMNET_HEAD_FUSED / set_option("head_fused"): with pre-split activations, the energy head 256 -> 128 -> 128 -> 1 runs forward
   // and backward in ONE launch (gemm_head.hip) instead of four N = 128 GEMM launches and the last-layer rider
   int head_fused = 1;
@@ -140,7 +148,9 @@ int mlp_gemm(const aimnet_engine* e, hipStream_t s, int epi, const float* A, int
              int N, int K, const float* bias, float* C, float* D, int ldc, const int* brow = nullptr, int ldbias = 0);
 // the same with the activation operand pre-split (A3, lda3 = 3 x its padded width in bf16 elements; gemm_bf3a.hip); out3: C is
 // written in bf3 form into C3 (ldc3 bf16 elements per row) instead of fp32 into C; D is fp32 [M][ldc]
-int mlp_gemm3(const aimnet_engine* e, hipStream_t s, int epi, bool out3, const unsigned short* A3, int lda3, const Layer& L, bool fwd,
-              int k0, int n0, int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
+// fmt: 1 = bf16x3 planes (gemm_bf3a.hip, lda3 / ldc3 = 3 x the padded width), 2 = fp16x2 planes (gemm_h2.hip, 2 x)
+int mlp_gemm3(const aimnet_engine* e, hipStream_t s, int fmt, int epi, bool out3, const unsigned short* A3, int lda3, const Layer& L,
+              bool fwd, int k0, int n0, int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
               const int* brow = nullptr, int ldbias = 0);
+int split_format(const aimnet_engine* e, int n_rows);  // 0: fp32 activations, 1: bf3, 2: h2 (engine.hip)
 }  // namespace aimnet

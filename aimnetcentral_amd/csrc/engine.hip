@@ -98,6 +98,13 @@ int upload_layer(aimnet_engine* e, const float* w, const float* b, int n_in, int
     if ((rc = dev_upload(e, s3.data(), s3.size(), &L->w3a))) return rc;
     split_bf3_host(wtp.data(), L->k_in, L->k_out, s3.data(), BF3_ALT);
     if ((rc = dev_upload(e, s3.data(), s3.size(), &L->wt3a))) return rc;
+    // the operand form of gemm_h2.hip: fp16 hi + scaled fp16 lo, hi planes of the odd k-blocks negated
+    std::vector<unsigned short> s2(wp.size() * 2);
+    bool fits = split_h2_host(wp.data(), L->k_out, L->k_in, s2.data(), H2_WEIGHT);
+    if ((rc = dev_upload(e, s2.data(), s2.size(), &L->w2a))) return rc;
+    fits = split_h2_host(wtp.data(), L->k_in, L->k_out, s2.data(), H2_WEIGHT) && fits;
+    if ((rc = dev_upload(e, s2.data(), s2.size(), &L->wt2a))) return rc;
+    if (!fits) e->h2_fits = false;
   }
   return 0;
 }
@@ -120,13 +127,19 @@ int mlp_gemm(const aimnet_engine* e, hipStream_t s, int epi, const float* A, int
   const float* w = (fwd ? L.w : L.wt) + (size_t)n0 * ldw + k0;
   return launch_gemm_nt(s, epi, A, lda, w, ldw, M, N, K, bias, C, D, ldc, brow, ldbias);
 }
-int mlp_gemm3(const aimnet_engine* e, hipStream_t s, int epi, bool out3, const unsigned short* A3, int lda3, const Layer& L, bool fwd,
-              int k0, int n0, int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
+int mlp_gemm3(const aimnet_engine* e, hipStream_t s, int fmt, int epi, bool out3, const unsigned short* A3, int lda3, const Layer& L,
+              bool fwd, int k0, int n0, int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
               const int* brow, int ldbias) {
   const int ldw = fwd ? L.k_in : L.k_out;
+  const int alt = ((k0 / 32) & 1) ? 2 : 1;
+  if (fmt == 2) {
+    const unsigned short* w2 = (fwd ? L.w2a : L.wt2a) + (size_t)n0 * 2 * ldw + (size_t)(k0 / 32) * 64;
+    return launch_gemm_h2_cfg(s, 0, epi, out3, A3 + (size_t)(k0 / 32) * 64, lda3, w2, 2 * ldw, M, N, K, bias, C, C3, ldc3, D, ldc, brow,
+                              ldbias, alt);
+  }
   const unsigned short* w3 = (fwd ? L.w3a : L.wt3a) + (size_t)n0 * 3 * ldw + (size_t)(k0 / 32) * 96;
   return launch_gemm_bf3a_cfg(s, 0, epi, out3, A3 + (size_t)(k0 / 32) * 96, lda3, w3, 3 * ldw, M, N, K, bias, C, C3, ldc3, D, ldc, brow,
-                              ldbias, ((k0 / 32) & 1) ? 2 : 1);
+                              ldbias, alt);
 }
 // the one-launch energy head of gemm_head.hip covers the shipped architecture (256 -> 128 -> 128 -> 1)
 bool head_fusable(const aimnet_engine* e) {
@@ -138,6 +151,10 @@ bool head_fusable(const aimnet_engine* e) {
 bool presplit_active(const aimnet_engine* e, int N) {
   const bool bf3 = e->gemm_bf3 == 2 || (e->gemm_bf3 == 1 && N > 256);  // the batches that take the split GEMMs at all (mlp_gemm)
   return e->gemm_presplit != 0 && bf3 && !e->keep_intermediates && !(e->conv_mfma & 1);
+}
+int split_format(const aimnet_engine* e, int n_rows) {
+  if (!presplit_active(e, n_rows)) return 0;
+  return (e->gemm_h2 && e->h2_fits) ? 2 : 1;
 }
 }  // namespace aimnet
 
@@ -397,6 +414,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->gemm_bf3 = std::min(2, std::max(0, atoi(env)));
     env = getenv("AIMNET_GEMM_PRESPLIT");
     if (env) e->gemm_presplit = atoi(env) != 0;
+    env = getenv("AIMNET_GEMM_H2");
+    if (env) e->gemm_h2 = atoi(env) != 0;
     env = getenv("AIMNET_HEAD_FUSED");
     if (env) e->head_fused = atoi(env) != 0;
     env = getenv("AIMNET_PREP_FUSED");
@@ -545,6 +564,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "emb_bias") e->emb_bias = value != 0;
   else if (n == "gemm_bf3") e->gemm_bf3 = std::min(2, std::max(0, value));
   else if (n == "gemm_presplit") e->gemm_presplit = value != 0;
+  else if (n == "gemm_h2") e->gemm_h2 = value != 0;
   else if (n == "head_fused") e->head_fused = value != 0;
   else if (n == "prep_fused") e->prep_fused = value != 0;
   else if (n == "energy_rides") e->energy_rides = value != 0;
@@ -571,6 +591,7 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
   else if (n == "emb_bias") *value = e->emb_bias ? 1 : 0;
   else if (n == "gemm_bf3") *value = e->gemm_bf3;
   else if (n == "gemm_presplit") *value = e->gemm_presplit;
+  else if (n == "gemm_h2") *value = e->gemm_h2 && e->h2_fits;
   else if (n == "head_fused") *value = e->head_fused;
   else if (n == "prep_fused") *value = e->prep_fused;
   else if (n == "energy_rides") *value = e->energy_rides;
@@ -864,7 +885,9 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const int* order = (!ext && W.nl.binned && e->spatial_order) ? W.nl.sorted : nullptr;
   // a^0 = afv[Z] is never materialised: pass 0 gathers the embedding rows directly (conv_fwd / conv_bwd row_of, update_a)
   const bool p0m = e->p0_moments && (opt->flags & (AIMNET_FORCES | AIMNET_STRESS));
-  const bool ps = presplit_active(e, N);  // GEMM activations in split form (gemm_bf3a.hip)
+  const int sfmt = split_format(e, N);  // GEMM activations in split form: 1 bf16x3 (gemm_bf3a.hip), 2 fp16x2 (gemm_h2.hip)
+  const bool ps = sfmt != 0;
+  const int pm = sfmt == 2 ? 2 : 3;  // 16-bit elements per fp32 value of a split row
   const bool hfused = ps && head_fusable(e);  // energy head forward + backward in one launch (gemm_head.hip)
   const bool mfma_fwd = (e->conv_mfma & 1) && N > e->split_max;
   const bool mfma_bwd = (e->conv_mfma & 2) && N > e->split_max;
@@ -977,13 +1000,13 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     else
       RC(launch_conv_fwd(s, p > 0 ? nq : 0, p == 0 ? e->afv : W.a[p], p == 0 ? in->numbers : nullptr, p > 0 ? W.q[p - 1] : nullptr,
                          W.nb_idx, W.nb_cnt, W.pg, cap, e->agh_a, e->agh_q, e->bp, W.x[p], Ls[0].k_in, W.V[p], W.Vq[p], N, order,
-                         p == 0 && e->p0_moments, e->split_max, ps));
+                         p == 0 && e->p0_moments, e->split_max, sfmt));
     const float* hin = W.x[p];
     int ld_in = Ls[0].k_in;
     RC(prof_mark(e, s, FAM_GEMM));
     if (ps) {  // activations in split form: rows from conv_fwd, hidden layers from the GELU epilogues; the last layer's output is fp32
       const unsigned short* a3 = reinterpret_cast<const unsigned short*>(W.x[p]);
-      int lda3 = 3 * Ls[0].k_in;
+      int lda3 = pm * Ls[0].k_in;
       for (int l = 0; l < nl; ++l) {
         const bool last = l == nl - 1, linear = last && ar.last_linear[p];
         const bool f32out = last && !(hfused && p == np - 1);  // the last layer's output is read by pointwise kernels - or by the fused head
@@ -992,12 +1015,12 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
         unsigned short* C3 = f32out ? nullptr : reinterpret_cast<unsigned short*>(W.H[p][l]);
         float* Dl = linear ? nullptr : W.D[p][l];
         if (p == 0 && l == 0 && e->emb_bias && e->emb_bias0)
-          RC(mlp_gemm3(e, s, epi, !f32out, a3, lda3, Ls[l], true, 256, 0, N, ko, Ls[l].k_in - 256, e->emb_bias0, Cf, C3, 3 * ko, Dl, ko,
+          RC(mlp_gemm3(e, s, sfmt, epi, !f32out, a3, lda3, Ls[l], true, 256, 0, N, ko, Ls[l].k_in - 256, e->emb_bias0, Cf, C3, pm * ko, Dl, ko,
                        in->numbers, ko));
         else
-          RC(mlp_gemm3(e, s, epi, !f32out, a3, lda3, Ls[l], true, 0, 0, N, ko, Ls[l].k_in, Ls[l].b, Cf, C3, 3 * ko, Dl, ko));
+          RC(mlp_gemm3(e, s, sfmt, epi, !f32out, a3, lda3, Ls[l], true, 0, 0, N, ko, Ls[l].k_in, Ls[l].b, Cf, C3, pm * ko, Dl, ko));
         a3 = C3;
-        lda3 = 3 * ko;
+        lda3 = pm * ko;
       }
     } else
     for (int l = 0; l < nl; ++l) {
@@ -1034,14 +1057,16 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     if (hfused) {
       HeadFusedArgs ha{};
       ha.aim3 = reinterpret_cast<const unsigned short*>(hin);
-      ha.lda3 = 3 * ld_in;
-      ha.w1 = e->head[0].w3a; ha.w2 = e->head[1].w3a; ha.w2t = e->head[1].wt3a; ha.w1t = e->head[0].wt3a;
+      ha.lda3 = pm * ld_in;
+      ha.fmt = sfmt;
+      if (sfmt == 2) { ha.w1 = e->head[0].w2a; ha.w2 = e->head[1].w2a; ha.w2t = e->head[1].wt2a; ha.w1t = e->head[0].wt2a; }
+      else { ha.w1 = e->head[0].w3a; ha.w2 = e->head[1].w3a; ha.w2t = e->head[1].wt3a; ha.w1t = e->head[0].wt3a; }
       ha.b1 = e->head[0].b; ha.b2 = e->head[1].b; ha.w3 = e->head_w_last; ha.b3 = e->head_b_last;
       ha.dlast = grad ? W.D[np - 1][nlp - 1] : nullptr;
       ha.ldd = ld_in;
       ha.e_atom = W.e_atom;
       ha.zbar3 = grad ? reinterpret_cast<unsigned short*>(W.zb0) : nullptr;
-      ha.ldz3 = 3 * ld_in;
+      ha.ldz3 = pm * ld_in;
       ha.M = N;
       ha.grad = grad ? 1 : 0;
       RC(launch_head_fused(s, ha));
@@ -1120,7 +1145,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       ld = L.k_in;
     }
     if (ps) {  // (interim: the head still runs on fp32 operands; its adjoint is split for the MLP backward)
-      RC(launch_split_bf3(s, zcur, ld, N, ld, reinterpret_cast<unsigned short*>(znext), 3 * ld));
+      if (sfmt == 2) RC(launch_split_h2(s, zcur, ld, N, ld, reinterpret_cast<unsigned short*>(znext), 2 * ld, H2_ACT));
+      else RC(launch_split_bf3(s, zcur, ld, N, ld, reinterpret_cast<unsigned short*>(znext), 3 * ld));
       std::swap(zcur, znext);
     }
   }
@@ -1134,13 +1160,13 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
         const Layer& L = Ls[l];
         const unsigned short* z3 = reinterpret_cast<const unsigned short*>(zcur);
         if (l > 0)
-          RC(mlp_gemm3(e, s, EPI_MUL, true, z3, 3 * ld, L, false, 0, 0, N, L.k_in, L.k_out, nullptr, nullptr,
-                       reinterpret_cast<unsigned short*>(znext), 3 * L.k_in, W.D[p][l - 1], L.k_in));
+          RC(mlp_gemm3(e, s, sfmt, EPI_MUL, true, z3, pm * ld, L, false, 0, 0, N, L.k_in, L.k_out, nullptr, nullptr,
+                       reinterpret_cast<unsigned short*>(znext), pm * L.k_in, W.D[p][l - 1], L.k_in));
         else if (p == 0 && p0m)
-          RC(mlp_gemm3(e, s, EPI_NONE, false, z3, 3 * ld, L, false, 0, 256, N, L.k_in - 256, L.k_out, nullptr, znext + 256, nullptr, 0,
+          RC(mlp_gemm3(e, s, sfmt, EPI_NONE, false, z3, pm * ld, L, false, 0, 256, N, L.k_in - 256, L.k_out, nullptr, znext + 256, nullptr, 0,
                        nullptr, L.k_in));
         else
-          RC(mlp_gemm3(e, s, EPI_NONE, false, z3, 3 * ld, L, false, 0, 0, N, L.k_in, L.k_out, nullptr, znext, nullptr, 0, nullptr,
+          RC(mlp_gemm3(e, s, sfmt, EPI_NONE, false, z3, pm * ld, L, false, 0, 0, N, L.k_in, L.k_out, nullptr, znext, nullptr, 0, nullptr,
                        L.k_in));
         std::swap(zcur, znext);
         ld = L.k_in;
@@ -1192,7 +1218,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     RC(prof_mark(e, s, FAM_POINTWISE));
     RC(launch_nse_bwd_reduce(s, W.qbar, y, ldy, nq, W.nl.mol_start, n_mol, N, W.S, (float*)W.part));
     RC(launch_build_zbar(s, W.qbar, W.abar, y, ldy, ar.last_linear[p - 1] ? nullptr : W.D[p - 1][nlq - 1], W.Fm[p - 1],
-                         W.Dm[p - 1], (const float*)W.part, W.S, mol_c, N, n_mol, 256, nq, p - 1 > 0, znext, W.qbar, ps));
+                         W.Dm[p - 1], (const float*)W.part, W.S, mol_c, N, n_mol, 256, nq, p - 1 > 0, znext, W.qbar, sfmt));
     std::swap(zcur, znext);
   }
   RC(prof_mark(e, s, FAM_POINTWISE));
@@ -1310,11 +1336,30 @@ int aimnet_debug_gemm_bf3a(int cfg, int epi, int out3, const void* A3, int lda3,
   return launch_gemm_bf3a_cfg((hipStream_t)hip_stream, cfg, epi, out3 != 0, (const unsigned short*)A3, lda3, (const unsigned short*)Bt3,
                               ldb, M, N, K, bias, C, (unsigned short*)C3, ldc3, D, ldc, nullptr, 0, alt);
 }
+int aimnet_debug_split_h2(const float* src, int ld, int M, int K, void* dst, int ldd, int mode, void* hip_stream) {
+  if (!src || !dst || M <= 0 || K <= 0 || ldd < 2 * pad32(K) || ldd % 64 || mode < 0 || mode > 2) return AIMNET_E_INVALID;
+  return aimnet::launch_split_h2((hipStream_t)hip_stream, src, ld, M, K, (unsigned short*)dst, ldd, mode);
+}
+
+int aimnet_debug_gemm_h2(int cfg, int epi, int out2, const void* A2, int lda2, const void* Bt2, int ldb, int M, int N, int K,
+                         const float* bias, float* C, void* C2, int ldc2, float* D, int ldc, int alt, void* hip_stream) {
+  using namespace aimnet;
+  if (alt < 0 || alt > 2) return AIMNET_E_INVALID;
+  static bool once = false;
+  if (!once) {
+    int rc = gemm_h2_set_attributes();
+    if (rc) return rc;
+    once = true;
+  }
+  return launch_gemm_h2_cfg((hipStream_t)hip_stream, cfg, epi, out2 != 0, (const unsigned short*)A2, lda2, (const unsigned short*)Bt2,
+                            ldb, M, N, K, bias, C, (unsigned short*)C2, ldc2, D, ldc, nullptr, 0, alt);
+}
 #ifdef AIMNET_PREP_TIMING
 int aimnet_debug_prep_stamps(unsigned long long* host16) { return aimnet::prep_read_stamps(host16); }
 #endif
 #ifdef AIMNET_BF3_TIMING
 int aimnet_debug_bf3a_stamps(unsigned long long* host1024) { return aimnet::gemm_bf3a_read_stamps(host1024); }
+int aimnet_debug_h2_stamps(unsigned long long* host1024) { return aimnet::gemm_h2_read_stamps(host1024); }
 int aimnet_debug_bf3_stamps(unsigned long long* host1024) { return aimnet::gemm_bf3_read_stamps(host1024); }
 #endif
 

@@ -49,6 +49,22 @@ int launch_gemm_bf3a_cfg(hipStream_t stream, int cfg, int epi, bool out3, const 
 // on an even k-block (result = even - odd), 2 = BF3_ALT weights, odd first k-block (result = odd - even)
 int gemm_bf3a_set_attributes();
 
+// ---- gemm_h2.hip: the same product on fp16x2-split operands ("h2", gemm_h2_common.h: fp32 == hi + lo / 4096 to 2^-24; per row,
+// K/32 blocks of [hi: 32 fp16][lo: 32 fp16] = 128 B; ld counts 16-bit elements = 2 x the padded K): three matrix instructions per
+// tile and k-step instead of six.  out2: the GELU / chain-rule epilogues write C in h2 form (C2, ldc2 >= 2 * pad32(N)).
+// alt as launch_gemm_bf3a_cfg (1 / 2: weights in the H2_WEIGHT form and activations in the H2_ACT form; 0: both plain).
+int launch_gemm_h2_cfg(hipStream_t stream, int cfg, int epi, bool out2, const unsigned short* A2, int lda2, const unsigned short* Bt,
+                       int ldb, int M, int N, int K, const float* bias, float* C, unsigned short* C2, int ldc2, float* D, int ldc,
+                       const int* brow = nullptr, int ldbias = 0, int alt = 0);
+int gemm_h2_set_attributes();
+// mode: 0 plain, 1 activation form (lo of the odd k-blocks negated), 2 weight form (hi of the odd k-blocks negated)
+enum { H2_PLAIN = 0, H2_ACT = 1, H2_WEIGHT = 2 };
+bool split_h2_host(const float* w, int rows, int K, unsigned short* out, int mode);  // false: an entry does not fit fp16's range
+int launch_split_h2(hipStream_t s, const float* src, int ld, int M, int K, unsigned short* dst, int ldd, int mode, int* ovf = nullptr);
+#ifdef AIMNET_BF3_TIMING
+int gemm_h2_read_stamps(unsigned long long* host1024);
+#endif
+
 // ---- gemm_head.hip: the energy head 256 -> 128 -> 128 -> 1 forward and backward in one launch (operands of gemm_bf3a.hip)
 struct HeadFusedArgs {
   const unsigned short* aim3;  // [M][lda3] head input in bf3 form (written by the last MLP layer's epilogue)
@@ -62,6 +78,7 @@ struct HeadFusedArgs {
   unsigned short* zbar3;                      // [M][ldz3] adjoint of that layer's pre-activation, bf3 form (grad only)
   int ldz3;
   int M, grad;
+  int fmt = 1;  // 1: operands in the bf16x3 form (BF3_ALT weights), 2: in the fp16x2 form (H2_WEIGHT weights, H2_ACT activations)
 };
 int launch_head_fused(hipStream_t s, const HeadFusedArgs& a);
 #ifdef AIMNET_BF3_TIMING
@@ -155,7 +172,7 @@ int launch_conv_fwd(hipStream_t s, int nq, const float* a, const int* row_of, co
                     float* x, int ldx, float* Vsave, float* Vqsave, int n_atoms, const int* order,
                     bool species_moments = false,  // pass 0 (row_of given, nq = 0): per-element moments, no row gathers
                     int split_max = 1024,          // atoms up to which the 4-waves-per-atom form is used
-                    bool x_bf3 = false);           // rows pre-split for gemm_bf3a.hip (x: bf16 elements, 3 * ldx per row)
+                    int x_split = 0);              // rows pre-split: 1 for gemm_bf3a.hip (x: bf16 elements, 3 * ldx per row), 2 for gemm_h2.hip (fp16 hi / lo, 2 * ldx)
 int launch_unconcat(hipStream_t s, int nq, const float* xbar, int ldx, const float* Vsave, const float* Vqsave,
                     const float* agh_a, const float* agh_q, float* Sbar, float* Sqbar, int n_atoms);
 int launch_conv_bwd(hipStream_t s, int nq, bool need_abar, bool stress, const float* a, const int* row_of,
@@ -327,7 +344,7 @@ int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int 
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
                       const float* Fm, const float* Dm, const float* wpart, int S, const int* mol_idx, int n_atoms, int n_mol,
                       int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next,
-                      bool zbar_bf3 = false);  // zbar_bf3: rows in the split form of gemm_bf3a.hip (bf16 elements, 3 * ldy per row)
+                      int zbar_split = 0);  // 1: rows in the split form of gemm_bf3a.hip (bf16 elements, 3 * ldy per row), 2: of gemm_h2.hip (2 * ldy)
 // launch_pair_force's arguments as a rider of the stress reduction (launch_finalize): n_blocks = ceil(n_atoms / 4), 0 = none
 struct PairForceRider {
   const int* nb_idx; const int* nb_cnt; const int* rev; const float4* pairbuf; int cap; float* forces; int n_blocks;

@@ -12,7 +12,7 @@
 // energies are accumulated in fp64 exactly where the reference does (lr.py:61,326,602,611).
 #include "cellwalk.h"
 #include "common.h"
-#include "gemm_bf3_common.h"
+#include "gemm_h2_common.h"
 #include "kernels.h"
 #include "pairmap.h"
 
@@ -807,7 +807,7 @@ __global__ void build_zbar_kernel(const float* __restrict__ qbar, const float* _
                                   const float* __restrict__ Fm, const float* __restrict__ Dm,
                                   const float* __restrict__ wpart, int S, const int* __restrict__ mol_idx, int n_atoms,
                                   int n_mol, int n_feat, int nq, int carry_q, float* __restrict__ zbar,
-                                  float* __restrict__ qbar_next, unsigned short* __restrict__ zbar3) {
+                                  float* __restrict__ qbar_next, unsigned short* __restrict__ zbar3, int fmt) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
@@ -838,24 +838,30 @@ __global__ void build_zbar_kernel(const float* __restrict__ qbar, const float* _
     else v = 0.0f;
     if (dr && c < 2 * nq + n_feat) v *= dr[c];
     if (to_lds) st[c] = v;
-    else if (zbar3) store_bf3_1(zbar3 + (size_t)i * 3 * ldy, c, v);
+    else if (zbar3) {
+      if (fmt == 2) store_h2_1(zbar3 + (size_t)i * 2 * ldy, c, v);
+      else store_bf3_1(zbar3 + (size_t)i * 3 * ldy, c, v);
+    }
     else zr[c] = v;
   }
   if (to_lds) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    unsigned short* zr3 = zbar3 + (size_t)i * 3 * ldy;
-    for (int c = 4 * lane; c < ldy; c += 256) store_bf3_x4(zr3, c, f32x4{st[c], st[c + 1], st[c + 2], st[c + 3]});
+    unsigned short* zr3 = zbar3 + (size_t)i * (fmt == 2 ? 2 : 3) * ldy;
+    if (fmt == 2)
+      for (int c = 4 * lane; c < ldy; c += 256) store_h2_x4(zr3, c, f32x4{st[c], st[c + 1], st[c + 2], st[c + 3]});
+    else
+      for (int c = 4 * lane; c < ldy; c += 256) store_bf3_x4(zr3, c, f32x4{st[c], st[c + 1], st[c + 2], st[c + 3]});
   }
   if (lane < nq) qbar_next[(size_t)lane * n_atoms + i] = carry_q ? (lane == 0 ? qr[0] : qr[1]) : 0.0f;
 }
 
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
                       const float* Fm, const float* Dm, const float* wpart, int S, const int* mol_idx, int n_atoms, int n_mol,
-                      int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next, bool zbar_bf3) {
+                      int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next, int zbar_split) {
   hipLaunchKernelGGL(build_zbar_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, qbar, abar, y, ldy, dlast, Fm, Dm, wpart,
                      S < 1 ? 1 : S, mol_idx, n_atoms, n_mol, n_feat, nq, carry_q ? 1 : 0, zbar, qbar_next,
-                     zbar_bf3 ? reinterpret_cast<unsigned short*>(zbar) : nullptr);
+                     zbar_split ? reinterpret_cast<unsigned short*>(zbar) : nullptr, zbar_split);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

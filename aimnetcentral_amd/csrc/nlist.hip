@@ -386,7 +386,9 @@ __device__ void bins_setup_block(NlistSystem* __restrict__ sys, const int* __res
     NlistSystem S = sys[s];
     const int ns = mol_start ? mol_start[s + 1] - mol_start[s]
                              : (s + 1 < n_mol ? first_atom_of(mol_idx, n_atoms, n_mol, s + 1) : n_atoms) - first_atom_of(mol_idx, n_atoms, n_mol, s);
-    const long cap_bins = (long)ns + 8;
+    // (an unsorted mol_idx can make the racing mol_start differences negative: the clamp keeps the loop below finite - every nb
+    // reaches 1 - and the input-sanity status bit reports the batch as unusable)
+    const long cap_bins = ns + 8 > 1 ? (long)ns + 8 : 1;
     int nb[3];
     for (int k = 0; k < 3; ++k) nb[k] = max(1, min(1024, (int)floorf(S.h[k] / w)));
     while ((long)nb[0] * nb[1] * nb[2] > cap_bins) {

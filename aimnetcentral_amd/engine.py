@@ -142,7 +142,7 @@ class HipEngine:
 
     # ------------------------------------------------------------------------------------------
     def set_option(self, name: str, value: int) -> None:
-        """Engine switch for A/B and parity runs (include/aimnet_hip.h, aimnet_engine_set_option): "gemm_bf3", "gemm_presplit", "head_fused", "prep_fused", "energy_rides", "status_rides", "setup_rides", "status_owned", "sums_whole", "conv_mfma",
+        """Engine switch for A/B and parity runs (include/aimnet_hip.h, aimnet_engine_set_option): "gemm_bf3", "gemm_presplit", "gemm_h2", "head_fused", "prep_fused", "energy_rides", "status_rides", "setup_rides", "status_owned", "sums_whole", "conv_mfma",
         "conv_xe", "split_max", "p0_moments", "spatial_order", "overlap_coulomb"."""
         _lib.check(self.lib.aimnet_engine_set_option(self._h, name.encode(), int(value)), "aimnet_engine_set_option")
         self._ws = None  # the workspace layout depends on the switches
@@ -326,6 +326,7 @@ class HipEngine:
         spin, f_out, s_out = dv.get("spin_charges"), dv.get("forces"), dv.get("stress")
         stream = torch.cuda.current_stream(dev).cuda_stream
         host = None
+        h2_on, h2_retry = bool(self.get_option("gemm_h2")) and bool(self.get_option("gemm_presplit")), False
         while True:
             opt = _lib.EvalOptions()
             opt.flags = (_lib.FORCES if forces else 0) | (_lib.STRESS if stress else 0)
@@ -401,12 +402,34 @@ class HipEngine:
                 # it took 1.4 ms, and the evaluation as a whole 15 ms instead of 2.2, tests/tools/ase_prof2.py.)
                 host = outbuf.cpu()
                 st = host[:32].view(torch.int32).numpy()
+                finite = all(bool(torch.isfinite(v).all()) for k, v in views(host).items() if k != "status") if (h2_on or h2_retry) else True
             else:
-                st = status.cpu().numpy()
+                # the status words and the molecule energies (adjacent sections) in one copy: the energies are the fp16-range
+                # sentinel of the h2 GEMM operands (below)
+                head = outbuf[: offs[1] + nbytes[1]].cpu()
+                st = head[:32].view(torch.int32).numpy()
+                finite = bool(torch.isfinite(head[offs[1]:].view(torch.float64)).all()) if (h2_on or h2_retry) else True
             self.last_status = st
             if st[6]:  # input sanity flags raised by the engine (it clamps for memory safety, the results are meaningless)
                 raise ValueError("HipEngine.eval: invalid input: " + describe_input_flags(int(st[6]), n_mol))
             retry = False
+            rows_overflowed = bool(st[2] or st[3] or st[5] or (method == _lib.COULOMB_EWALD and st[7] > opt.ewald_max_k))
+            if not finite and h2_on and not rows_overflowed:
+                # fp16x2-split GEMM operands (csrc/gemm_h2_common.h) hold |x| < 65504: an activation beyond that turns into inf / NaN
+                # and surfaces in the outputs.  Repeat the call with the bf16x3 operands (fp32's range); if THAT is finite the
+                # engine stays on them.
+                self.set_option("gemm_h2", 0)
+                h2_on, h2_retry = False, True
+                continue
+            if h2_retry and not rows_overflowed:
+                h2_retry = False
+                if finite:
+                    import warnings
+                    warnings.warn("HipEngine: an MLP activation of this model exceeded fp16's range (|x| >= 65504); the engine has "
+                                  "switched from the fp16x2-split to the bf16x3-split GEMM operands (set_option('gemm_h2', 0)) for "
+                                  "this and all later evaluations", RuntimeWarning, stacklevel=2)
+                else:  # non-finite with either operand form: not a range problem of the h2 form
+                    self.set_option("gemm_h2", 1)
             if ext:  # caller-supplied rows cannot overflow, and say nothing about the capacities of the engine's own lists
                 break
             if st[2]:
@@ -453,9 +476,10 @@ class HipEngine:
     # ------------------------------------------------------------------------------------------
     HVP_BYTES_BUDGET = 6 << 30  # workspace of one tangent sweep; more directions than fit are processed in several sweeps
     HVP_MAX_DIRECTIONS = 65535  # the tangent kernels put the direction index in grid.y (HIP limit 65535; 4 K with DFT-D3: 16383)
-    # one direction costs ~3/4 us per atom (7.5 ms on 10 080 atoms, profiles/r3_hvp.md): refuse calls that would run for more than
-    # this many seconds unless the caller raises the limit (a dense Hessian of a 10 k-atom crystal is 30 240 directions = minutes)
+    # one direction costs ~3/4 us per atom (7.5 ms on 10 080 atoms, profiles/r3_hvp.md): calls that would run for more than
+    # this many seconds are announced (or refused, HVP_ON_LONG) (a dense Hessian of a 10 k-atom crystal is 30 240 directions = minutes)
     HVP_MAX_SECONDS = 120.0
+    HVP_ON_LONG = "warn"  # "warn": say so and run (the reference runs such requests too, slowly); "raise": refuse with a ValueError
 
     def hvp(self, coord, numbers, mol_idx, charge, vectors, cell=None, pbc=(True, True, True), coulomb: str = "simple",
             dsf_rc: float = 15.0, dsf_alpha: float = 0.2, want_forces: bool = False,
@@ -484,10 +508,13 @@ class HipEngine:
         if n == 0 or n_mol == 0 or K == 0:
             raise ValueError("HipEngine.hvp: empty input")
         est = 0.75e-6 * n * K if n > 2000 else 0.0  # (small systems are launch-bound: ~0.04 force evaluations per direction)
-        if est > self.HVP_MAX_SECONDS:
-            raise ValueError(f"HipEngine.hvp: {K} directions on {n} atoms would take ~{est:.0f} s (~0.75 us per atom and direction); "
-                             f"pass fewer vectors per call (a Krylov / Davidson solver needs tens, not 3N) or raise "
-                             f"HipEngine.HVP_MAX_SECONDS (now {self.HVP_MAX_SECONDS:.0f} s)")
+        if est > self.HVP_MAX_SECONDS and self.HVP_ON_LONG == "raise":
+            raise ValueError(f"HipEngine.hvp: {K} directions on {n} atoms would take ~{est:.0f} s (HVP_ON_LONG = 'raise')")
+        if est > self.HVP_MAX_SECONDS:  # the reference computes such requests (slowly): warn, do not refuse
+            import warnings
+            warnings.warn(f"HipEngine.hvp: {K} directions on {n} atoms will take ~{est:.0f} s (~0.75 us per atom and direction on one "
+                          f"MI355X, more with DFT-D3); a Krylov / Davidson solver needs tens of directions, not 3N "
+                          f"(threshold: HipEngine.HVP_MAX_SECONDS = {self.HVP_MAX_SECONDS:.0f} s)", RuntimeWarning, stacklevel=2)
         vectors = vectors.to(device=dev, dtype=torch.float32).reshape(-1, n, 3).contiguous()
         n_cell = 0
         if cell is not None:

@@ -542,12 +542,12 @@ def load_dftd3_tables(source: Any = None) -> dict[str, np.ndarray]:
 
 
 def synthetic_spec(seed: int = 0, num_charge_channels: int = 1, rxn: bool = False, sr_envelope: str = "exp",
-                   sr_rc: float = 4.6) -> ModelSpec:
+                   sr_rc: float = 4.6, cold: bool = False) -> ModelSpec:
     """ModelSpec of the deterministic synthetic aimnet2 artifact (aimnetcentral_amd/synth.py); num_charge_channels = 2
     gives the open-shell NSE shape, rxn = True the `aimnet2_rxn` YAML (Dipole / Quadrupole output modules), sr_envelope / sr_rc
-    the SRCoulomb block's envelope ("exp" or "cosine") and radius."""
+    the SRCoulomb block's envelope ("exp" or "cosine") and radius, cold the low-force variant of the seed (synth._COLD_GAINS)."""
     from . import synth
 
     return spec_from_artifact(synth.synthetic_artifact(seed, num_charge_channels=num_charge_channels, rxn=rxn,
-                                                       sr_envelope=sr_envelope, sr_rc=sr_rc),
-                              source=f"<synthetic seed {seed}>")
+                                                       sr_envelope=sr_envelope, sr_rc=sr_rc, cold=cold),
+                              source=f"<synthetic seed {seed}{' cold' if cold else ''}>")

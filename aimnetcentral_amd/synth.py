@@ -117,9 +117,29 @@ def core_yaml(num_charge_channels: int = 1, rxn: bool = False) -> str:
     return AIMNET2_CORE_YAML.replace("kwargs:\n  nfeature: 16\n", f"kwargs:\n  num_charge_channels: {int(num_charge_channels)}\n  nfeature: 16\n", 1)
 
 
-def synthetic_state_dict(seed: int = 0, species: list[int] | None = None, num_charge_channels: int = 1) -> dict[str, np.ndarray]:
+# "Cold" variant of a seed (parity at the reference's LITERAL gates): the same random tensors with the hidden MLP layers
+# scaled to a gain of 1.1 (hot: 1.4), the (q~, f~, delta_a) layers to 0.3 (0.5) and the energy head's last layer to 0.8 (1.2): random
+# organics with 0.9 A contacts then have max|F| ~ 5 eV/A (hot: 50 - 800), taxol 3 eV/A, |q| <= 0.4 e - the force scale of real
+# molecules near equilibrium, where |dE| < 1e-5 eV and allclose(rtol 1e-4, atol 1e-5) on every force component
+# (tests/test_calculator_gpu.py:137,445,464 of the reference) can be asked of fp32 arithmetic without fp64 anchoring.
+_COLD_GAINS = {"hidden": 1.1 / 1.4, "charge_out": 0.3 / 0.5, "head_last": 0.8 / 1.2}
+
+
+def synthetic_state_dict(seed: int = 0, species: list[int] | None = None, num_charge_channels: int = 1,
+                         cold: bool = False) -> dict[str, np.ndarray]:
     """All 37 tensors of the aimnet2 core state dict as NumPy arrays (fp32; SAE fp64).  num_charge_channels = 2 gives the
-    shapes of an NSE model (conv_q.agh (2,G,H), MLP inputs 704 / 762, outputs 260; aimnet2.py:53-85)."""
+    shapes of an NSE model (conv_q.agh (2,G,H), MLP inputs 704 / 762, outputs 260; aimnet2.py:53-85).  cold: see _COLD_GAINS."""
+    if cold:
+        sd = synthetic_state_dict(seed, species, num_charge_channels)
+        for p in range(3):
+            nl = 3 if p < 2 else 4
+            for li in range(nl):
+                k = f"mlps.{p}.{2 * li}.weight"
+                g = _COLD_GAINS["charge_out"] if (li == nl - 1 and p < 2) else _COLD_GAINS["hidden"]
+                sd[k] = (sd[k] * np.float32(g)).astype(np.float32)
+        k = "outputs.energy_mlp.mlp.4.weight"
+        sd[k] = (sd[k] * np.float32(_COLD_GAINS["head_last"])).astype(np.float32)
+        return sd
     species = list(AIMNET2_SPECIES if species is None else species)
     rng = np.random.Generator(np.random.PCG64(seed))
 
@@ -190,13 +210,13 @@ def state_dict_digest(sd: dict[str, Any]) -> str:
 
 
 def synthetic_artifact(seed: int = 0, species: list[int] | None = None, num_charge_channels: int = 1,
-                       rxn: bool = False, sr_envelope: str = "exp", sr_rc: float = 4.6) -> dict[str, Any]:
+                       rxn: bool = False, sr_envelope: str = "exp", sr_rc: float = 4.6, cold: bool = False) -> dict[str, Any]:
     """A v2 artifact dict (torch tensors) as `torch.save` would hold it.  sr_envelope / sr_rc: the SRCoulomb block's
     `envelope` ("exp" mollifier or "cosine", lr.py:986-1032) and radius - same weights, another short-range subtraction."""
     import torch
 
     species = list(AIMNET2_SPECIES if species is None else species)
-    sd = {k: torch.from_numpy(np.array(v)) for k, v in synthetic_state_dict(seed, species, num_charge_channels).items()}
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synthetic_state_dict(seed, species, num_charge_channels, cold).items()}
     if rxn:
         # Dipole / Quadrupole register a `mass` buffer (119 atomic masses, core.py:163) that the reference loader insists on;
         # it is only read with center_coord=True, which the rxn YAML does not set - the synthetic artifact carries zeros

@@ -253,6 +253,15 @@ int aimnet_debug_gemm_bf3(int cfg, int epi, const float* A, int lda, const void*
 int aimnet_debug_gemm_bf3a(int cfg, int epi, int out3, const void* A3, int lda3, const void* Bt3, int ldb, int M, int N, int K,
                            const float* bias, float* C, void* C3, int ldc3, float* D, int ldc, int alt, void* hip_stream);
 
+/* aimnet_debug_split_h2 / aimnet_debug_gemm_h2 (csrc/gemm_h2.hip): the same product on fp16x2-split operands ("h2" layout: per row,
+ * K/32 blocks of [hi: 32 fp16][lo: 32 fp16] = 128 bytes, fp32 value == hi + lo / 4096 to 2^-24; ld* count 16-bit elements,
+ * >= 2 * pad32(K), multiples of 64): three matrix instructions per tile and k-step instead of six.  mode of the split: 0 plain,
+ * 1 activation form (lo planes of the odd k-blocks negated), 2 weight form (hi planes of the odd k-blocks negated); alt as in
+ * aimnet_debug_gemm_bf3a (1 / 2 want A2 in form 1 and Bt2 in form 2; 0 wants both plain); out2 != 0: C is written in h2 form 1. */
+int aimnet_debug_split_h2(const float* src, int ld, int M, int K, void* dst, int ldd, int mode, void* hip_stream);
+int aimnet_debug_gemm_h2(int cfg, int epi, int out2, const void* A2, int lda2, const void* Bt2, int ldb, int M, int N, int K,
+                         const float* bias, float* C, void* C2, int ldc2, float* D, int ldc, int alt, void* hip_stream);
+
 /* Engine switches for A/B and parity runs (all have an AIMNET_* environment twin read at create time):
  *   "conv_xe"       1 (default): reverse-pair form of the conv backward for systems above the split threshold, 0: combined form
  *   "gemm_bf3"      1 (default): MLP GEMMs of batches above 256 rows with bf16x3-split operands on the bf16 matrix pipe
@@ -261,6 +270,11 @@ int aimnet_debug_gemm_bf3a(int cfg, int epi, int out3, const void* A3, int lda3,
  *   "gemm_presplit" 1 (default): wherever the split GEMMs run, every GEMM activation operand is kept in the
  *                   split "bf3" form in memory (written by its producer; csrc/gemm_bf3a.hip streams both operands by DMA), 0: fp32
  *                   activations split inside the GEMM's main loop (csrc/gemm_bf3.hip)
+ *   "gemm_h2"       1 (default): wherever the activations are pre-split, they and the weights take the fp16x2-split form "h2"
+ *                   (csrc/gemm_h2.hip: fp32 == hi + lo / 4096 to 2^-24, three matrix instructions per tile and k-step instead of six,
+ *                   4 instead of 6 bytes per element; rms error below the bf16x3 form's, profiles/r5_gemm_h2.md), 0: the bf16x3 form
+ *                   (csrc/gemm_bf3a.hip).  fp16 holds |x| < 65504: weights beyond it switch the option off at create time,
+ *                   activations beyond it surface as non-finite outputs (the Python layer then repeats the call with 0 and stays there)
  *   "head_fused"    1 (default): with pre-split activations the energy head 256 -> 128 -> 128 -> 1 runs forward and backward in one
  *                   launch (csrc/gemm_head.hip), 0: four GEMM launches + the last-layer rider
  *   "prep_fused"    1 (default): periodic batches of <= 4 096 atoms / 64 systems prepare their cell grid (status zeroing, molecule

@@ -40,6 +40,51 @@ def assert_forces_close(got, ref, what=""):
     assert err <= tol, f"{what} forces: max|d|={err:.3e} > {tol:.3e}"
 
 
+def elementwise_violations(got, ref, rtol: float = FORCE_RTOL, atol: float = FORCE_ATOL) -> tuple[int, int, float]:
+    """The reference's LITERAL force gate, torch.allclose / np.testing.assert_allclose(rtol=1e-4, atol=1e-5)
+    (tests/test_calculator_gpu.py:137,464): (number of elements with |got - ref| > atol + rtol |ref|, number of elements, the
+    largest |got - ref| / (atol + rtol |ref|))."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    ratio = np.abs(got - ref) / (atol + rtol * np.abs(ref))
+    return int((ratio > 1.0).sum()), int(ratio.size), float(ratio.max()) if ratio.size else 0.0
+
+
+def golden_section(g, prefix: str) -> dict:
+    """The arrays `prefix_*` of a multi-fixture golden file (coldw.npz) as a dict keyed without the prefix."""
+    return {k[len(prefix) + 1:]: g[k] for k in g.files if k.startswith(prefix + "_")}
+
+
+COLDW_SECTIONS = ("taxol", "batch5", "rand8", "pbc96")
+
+
+@pytest.fixture(scope="session")
+def synth_sd_cold():
+    from aimnetcentral_amd import synth
+
+    return synth.synthetic_state_dict(0, cold=True)
+
+
+@pytest.fixture(scope="session")
+def oracle32_cold(synth_sd_cold):
+    import torch
+
+    from oracle import aimnet2_oracle as O
+
+    return O.OracleModel(synth_sd_cold, torch.float32)
+
+
+@pytest.fixture(scope="session")
+def hip_engine_cold():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from aimnetcentral_amd import loader
+    from aimnetcentral_amd.engine import HipEngine
+
+    return HipEngine(loader.synthetic_spec(0, cold=True), "cuda:0")
+
+
 @pytest.fixture(scope="session")
 def synth_sd():
     from aimnetcentral_amd import synth

@@ -419,6 +419,47 @@ def make_ewald() -> None:
     print("ewald_matrix.npz: E(1e-6) %.10f  E(1e-8) %.10f  Madelung/pair %.10f" % (out["E_1e-06"], out["E_1e-08"], out["nacl_E"] / 4.0))
 
 
+def make_coldw() -> None:
+    """G13: the COLD variant of the seed-0 weights (synth._COLD_GAINS: max|F| ~ 3 - 5 eV/A, |q| <= 0.4 e) through the unmodified
+    reference on the geometries of G1 (taxol), G2 (ragged charged batch), G3 (periodic cell, DSF 15 A, stress) and on eight random
+    organics of 20 - 60 atoms: the fixtures on which the engine is held to the reference's LITERAL gates - |dE| < 1e-5 eV and
+    allclose(rtol 1e-4, atol 1e-5) on every force component (tests/test_calculator_gpu.py:137,445,464) - without fp64 anchoring."""
+    art = synth.synthetic_artifact(SEED, cold=True)
+    digest = synth.state_dict_digest({k: v.numpy() for k, v in art["state_dict"].items()})
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "aimnet2_synth_cold.pt")
+    torch.save(art, path)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        load_model(path)
+    res: dict[str, np.ndarray] = {"weights_seed": np.int64(SEED), "weights_cold": np.int64(1), "weights_digest": np.array(digest)}
+    coord, numbers = read_taxol()
+    o = to_np(make_calc(path)({"coord": coord.astype(np.float32), "numbers": numbers, "charge": 0.0}, forces=True))
+    res.update(taxol_coord=coord.astype(np.float32), taxol_numbers=numbers, taxol_charge=np.float32(0.0), taxol_energy=o["energy"],
+               taxol_forces=o["forces"], taxol_charges=o["charges"])
+    print("coldw taxol  E=%.6f max|F|=%.3f max|q|=%.3f" % (o["energy"][0], np.abs(o["forces"]).max(), np.abs(o["charges"]).max()))
+    c, z, mol, q = workloads.random_batch(5, 9, 30, seed=11)
+    q = np.array([0.0, 1.0, -1.0, 0.0, 2.0], dtype=np.float32)
+    o = to_np(make_calc(path)({"coord": c, "numbers": z, "mol_idx": mol, "charge": q}, forces=True))
+    res.update(batch5_coord=c, batch5_numbers=z, batch5_mol_idx=mol, batch5_charge=q, batch5_energy=o["energy"], batch5_forces=o["forces"],
+               batch5_charges=o["charges"])
+    print("coldw batch5 max|F|=%.3f" % np.abs(o["forces"]).max())
+    c, z, mol, q = workloads.random_batch(8, 20, 60, seed=5)
+    o = to_np(make_calc(path)({"coord": c, "numbers": z, "mol_idx": mol, "charge": q}, forces=True))
+    res.update(rand8_coord=c, rand8_numbers=z, rand8_mol_idx=mol, rand8_charge=q, rand8_energy=o["energy"], rand8_forces=o["forces"],
+               rand8_charges=o["charges"])
+    print("coldw rand8  max|F|=%.3f" % np.abs(o["forces"]).max())
+    pc, pz, cell = workloads.glucose_cell()
+    calc = make_calc(path)
+    calc.set_lrcoulomb_method("dsf")
+    o = to_np(calc({"coord": pc.astype(np.float32), "numbers": pz, "charge": 0.0, "cell": cell.astype(np.float32)}, forces=True, stress=True))
+    res.update(pbc96_coord=pc.astype(np.float32), pbc96_numbers=pz, pbc96_charge=np.float32(0.0), pbc96_cell=cell.astype(np.float32),
+               pbc96_dsf_rc=np.float64(15.0), pbc96_dsf_alpha=np.float64(0.2), pbc96_energy=o["energy"], pbc96_forces=o["forces"],
+               pbc96_charges=o["charges"], pbc96_stress=o["stress"])
+    print("coldw pbc96  E=%.6f max|F|=%.3f" % (o["energy"][0], np.abs(o["forces"]).max()))
+    np.savez_compressed(os.path.join(HERE, "coldw.npz"), **res)
+
+
 def main() -> None:
     if "--check-hf" in sys.argv:
         check_hf_layout()
@@ -428,6 +469,9 @@ def main() -> None:
         return
     if "--only-nse" in sys.argv:
         make_nse()
+        return
+    if "--only-coldw" in sys.argv:
+        make_coldw()
         return
     art = synth.synthetic_artifact(SEED)
     digest = synth.state_dict_digest({k: v.numpy() for k, v in art["state_dict"].items()})

@@ -1,9 +1,9 @@
 """The parity fixtures under the two non-default GEMM modes (engine option "gemm_bf3", csrc/gemm_bf3.hip).
 
-Default (1): MLP GEMMs of batches above 256 rows run with bf16x3-split operands on the bf16 matrix pipe, smaller ones on the
-exact-fp32 skinny kernel - so the small golden fixtures never see the split kernels in the other test modules.  Here every parity
-check runs with mode 2 (split kernels for EVERY batch size; with pre-split activations = gemm_bf3a.hip + gemm_head.hip, and with
-the in-loop split of gemm_bf3.hip) and mode 0 (exact-fp32 MFMA kernels everywhere, the fallback the
+Default (1): MLP GEMMs of batches above 256 rows run with split operands on the 16-bit matrix pipe (fp16x2, gemm_h2.hip), smaller
+ones on the exact-fp32 skinny kernel - so the small golden fixtures never see the split kernels in the other test modules.  Here
+every parity check runs with mode 2 (split kernels for EVERY batch size; pre-split activations in the fp16x2 form = gemm_h2.hip
++ gemm_head.hip, in the bf16x3 form = gemm_bf3a.hip, and the in-loop split of gemm_bf3.hip) and mode 0 (exact-fp32 MFMA kernels everywhere, the fallback the
 bench reports as `exact_f32`), at the same, unchanged gates: goldens of the unmodified reference, the un-widened 1e-5 eV gate on
 the cold fixture, the 32-seed randomised sweep, both charge-channel families."""
 from __future__ import annotations
@@ -19,18 +19,22 @@ from oracle import aimnet2_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[(2, 1), (2, 0), (0, 1)], ids=["bf3_every_size", "bf3_split_in_loop", "exact_f32"])
-def gemm_mode(request, hip_engine, hip_engine_nse):
-    """(gemm_bf3, gemm_presplit): split kernels for every batch size with pre-split activations (gemm_bf3a.hip + the fused head:
-    what large systems run by default), the same with fp32 activations split inside the GEMM loop (gemm_bf3.hip, the tangent
-    sweep's kernels), and the exact-fp32 kernels."""
-    for e in (hip_engine, hip_engine_nse):
+@pytest.fixture(params=[(2, 1, 1), (2, 1, 0), (2, 0, 1), (0, 1, 1)], ids=["h2_every_size", "bf3_every_size", "bf3_split_in_loop", "exact_f32"])
+def gemm_mode(request, hip_engine, hip_engine_nse, hip_engine_cold):
+    """(gemm_bf3, gemm_presplit, gemm_h2): split kernels for every batch size with pre-split activations in the fp16x2 form
+    (gemm_h2.hip + the fused head: what large systems run by default) and in the bf16x3 form (gemm_bf3a.hip, the fallback for
+    activations beyond fp16's range), the same with fp32 activations split inside the GEMM loop (gemm_bf3.hip, the tangent sweep's
+    kernels), and the exact-fp32 kernels."""
+    engines = (hip_engine, hip_engine_nse, hip_engine_cold)
+    for e in engines:
         e.set_option("gemm_bf3", request.param[0])
         e.set_option("gemm_presplit", request.param[1])
+        e.set_option("gemm_h2", request.param[2])
     yield request.param
-    for e in (hip_engine, hip_engine_nse):
+    for e in engines:
         e.set_option("gemm_bf3", 1)
         e.set_option("gemm_presplit", 1)
+        e.set_option("gemm_h2", 1)
 
 
 def test_taxol(gemm_mode, hip_engine, oracle32):
@@ -55,6 +59,13 @@ def test_cold_fixture_unwidened_gate(gemm_mode, hip_engine):
     g = golden("cold24")
     res, _ = P.run(hip_engine, g, "simple")
     P.compare(res, g, 24, "cold24/reference golden")
+
+
+@pytest.mark.parametrize("name", ["taxol", "batch5", "rand8", "pbc96"])
+def test_cold_weights_at_the_reference_literal_gates(gemm_mode, hip_engine_cold, name):
+    """|dE| < 1e-5 eV and zero force components outside allclose(1e-4, 1e-5) against the reference's cold-weight goldens, with the
+    split kernels forced onto these small batches."""
+    P.test_cold_weights_at_the_reference_literal_gates(hip_engine_cold, name)
 
 
 def test_nse_molecule_and_batch(gemm_mode, hip_engine_nse, oracle32_nse, oracle64_nse):
@@ -84,17 +95,49 @@ def test_modes_agree_on_a_large_batch(hip_engine, oracle32):
     dev = hip_engine.device
     out = {}
     try:
-        for mode in (0, 1):
-            hip_engine.set_option("gemm_bf3", mode)
+        for mode in (0, 1, 2):  # exact fp32, fp16x2-split (default), bf16x3-split
+            hip_engine.set_option("gemm_bf3", min(mode, 1))
+            hip_engine.set_option("gemm_h2", 0 if mode == 2 else 1)
             r = hip_engine.eval(torch.from_numpy(c).to(dev), torch.from_numpy(z).to(dev), torch.zeros(len(z), dtype=torch.int64, device=dev),
                                 torch.zeros(1, device=dev), cell=torch.from_numpy(cell.astype(np.float32)).to(dev), forces=True, stress=True,
                                 coulomb="dsf", dsf_rc=9.0)
             out[mode] = {k: v.cpu().numpy() for k, v in r.items()}
     finally:
         hip_engine.set_option("gemm_bf3", 1)
+        hip_engine.set_option("gemm_h2", 1)
     n = len(z)
-    assert abs(out[0]["energy"][0] - out[1]["energy"][0]) <= max(1e-5, 5e-7 * n)
-    fmax = np.abs(out[0]["forces"]).max()
-    assert np.abs(out[0]["forces"] - out[1]["forces"]).max() <= 1e-5 + 1e-4 * fmax
-    assert np.abs(out[0]["charges"] - out[1]["charges"]).max() <= 1e-4
-    assert np.abs(out[0]["stress"] - out[1]["stress"]).max() <= 1e-5
+    for m in (1, 2):
+        assert abs(out[0]["energy"][0] - out[m]["energy"][0]) <= max(1e-5, 5e-7 * n)
+        fmax = np.abs(out[0]["forces"]).max()
+        assert np.abs(out[0]["forces"] - out[m]["forces"]).max() <= 1e-5 + 1e-4 * fmax
+        assert np.abs(out[0]["charges"] - out[m]["charges"]).max() <= 1e-4
+        assert np.abs(out[0]["stress"] - out[m]["stress"]).max() <= 1e-5
+
+
+def test_fp16_range_fallback():
+    """An activation beyond fp16's range (|x| >= 65504) cannot be held by the fp16x2-split operands: the outputs turn non-finite,
+    `HipEngine.eval` repeats the call with the bf16x3-split operands, warns, and stays there.  Weights: seed 0 with the first layer of
+    pass 0 scaled by 2e4 (the weights themselves stay inside fp16's range - otherwise the engine would not start in the h2 form at
+    all - its pre-activations do not; finite garbage in fp32 arithmetic)."""
+    import copy
+
+    import torch
+
+    from aimnetcentral_amd import loader, workloads
+    from aimnetcentral_amd.engine import HipEngine
+
+    spec = copy.deepcopy(loader.synthetic_spec(0))
+    spec.weights["mlps.0.0.weight"] = (spec.weights["mlps.0.0.weight"] * np.float32(2e4)).astype(np.float32)
+    c, z, mol, q = workloads.random_batch(12, 30, 40, seed=1)  # > 256 atoms: the split kernels run by default
+    dev = torch.device("cuda:0")
+    args = (torch.from_numpy(c).to(dev), torch.from_numpy(z).to(dev), torch.from_numpy(mol).to(dev), torch.from_numpy(q).to(dev))
+    ref_eng = HipEngine(spec, "cuda:0")
+    ref_eng.set_option("gemm_h2", 0)
+    ref = ref_eng.eval(*args, forces=True)
+    assert torch.isfinite(ref["energy"]).all() and torch.isfinite(ref["forces"]).all()
+    eng = HipEngine(spec, "cuda:0")
+    assert eng.get_option("gemm_h2") == 1
+    with pytest.warns(RuntimeWarning, match="exceeded fp16's range"):
+        res = eng.eval(*args, forces=True)
+    assert eng.get_option("gemm_h2") == 0
+    assert torch.equal(res["energy"], ref["energy"]) and torch.equal(res["forces"], ref["forces"])

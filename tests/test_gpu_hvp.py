@@ -248,15 +248,29 @@ def test_cosine_srcoulomb_envelope_eval_and_hvp():
     assert_forces_close(res["forces"].cpu().numpy(), g["forces40"], "40 atoms, cosine SR envelope")
 
 
-def test_hvp_refuses_calls_that_would_run_for_minutes(hip_engine):
-    """A dense Hessian of a 10 k-atom crystal is 30 240 directions x 7.5 ms: `HipEngine.hvp` says so instead of starting (VERDICT r3);
-    the limit is a class attribute the caller can raise.  (The direction tensor is a stride-0 view: nothing is materialised.)"""
+def test_hvp_announces_calls_that_would_run_for_minutes(hip_engine):
+    """A dense Hessian of a 10 k-atom crystal is 30 240 directions x 7.5 ms: `HipEngine.hvp` warns (the reference runs such requests
+    too, slowly - ADVICE r4) and refuses only with HVP_ON_LONG = 'raise'; the threshold is a class attribute.  (The direction tensor
+    of the refused call is a stride-0 view: nothing is materialised.)"""
     from aimnetcentral_amd import workloads
 
     c, z, cell = workloads.glucose_supercell((7, 3, 5))
     dev = hip_engine.device
     n = len(z)
     v = torch.zeros(1, n, 3, device=dev).expand(3 * n, n, 3)
-    with pytest.raises(ValueError, match="would take"):
-        hip_engine.hvp(torch.from_numpy(c.astype(np.float32)).to(dev), torch.from_numpy(z).to(dev), torch.zeros(n, dtype=torch.int32, device=dev),
-                       torch.zeros(1, device=dev), v, cell=torch.from_numpy(cell.astype(np.float32)).to(dev), coulomb="dsf")
+    args = (torch.from_numpy(c.astype(np.float32)).to(dev), torch.from_numpy(z).to(dev), torch.zeros(n, dtype=torch.int32, device=dev),
+            torch.zeros(1, device=dev))
+    kw = dict(cell=torch.from_numpy(cell.astype(np.float32)).to(dev), coulomb="dsf")
+    hip_engine.HVP_ON_LONG = "raise"
+    try:
+        with pytest.raises(ValueError, match="would take"):
+            hip_engine.hvp(*args, v, **kw)
+    finally:
+        del hip_engine.HVP_ON_LONG
+    hip_engine.HVP_MAX_SECONDS = 1e-9  # one direction on 10 080 atoms: announced, and computed
+    try:
+        with pytest.warns(RuntimeWarning, match="will take"):
+            out = hip_engine.hvp(*args, torch.ones(1, n, 3, device=dev), **kw)
+    finally:
+        del hip_engine.HVP_MAX_SECONDS
+    assert torch.isfinite(out["hv"]).all()

@@ -207,3 +207,26 @@ def test_cosine_srcoulomb_envelope_matches_reference(synth_sd):
     r = AN.evaluate_hvp(m64, c40.astype(np.float64), z40, 0.0, mol, ref["nbmat"], g["v4"].astype(np.float64), nbmat_lr=nbl)
     assert np.abs(r["hv"].reshape(4, 120) - g["v4"].reshape(4, 120).astype(np.float64) @ H64).max() < 1e-9
     assert np.abs(r["forces"] - ref["forces"]).max() < 1e-10
+
+
+@pytest.mark.parametrize("name", ["taxol", "batch5", "rand8", "pbc96"])
+def test_cold_weights_at_the_literal_gates(oracle32_cold, synth_sd_cold, name):
+    """coldw.npz: the COLD variant of the seed-0 weights (synth._COLD_GAINS, max|F| 1 - 6 eV/A) through the unmodified reference.
+    Here the oracle is held to the reference's LITERAL gates: |dE| < 1e-5 eV per molecule and no force component outside
+    allclose(rtol 1e-4, atol 1e-5) (tests/test_calculator_gpu.py:137,445,464)."""
+    from conftest import elementwise_violations, golden_section
+
+    from aimnetcentral_amd import synth
+
+    gf = golden("coldw")
+    assert synth.state_dict_digest(synth_sd_cold) == str(gf["weights_digest"])
+    g = golden_section(gf, name)
+    mol = g.get("mol_idx", np.zeros(len(g["numbers"]), dtype=np.int64))
+    kw = dict(cell=g["cell"], coulomb="dsf", stress=True, dsf_rc=float(g["dsf_rc"]), dsf_alpha=float(g["dsf_alpha"])) if "cell" in g else {}
+    res = O.evaluate(oracle32_cold, g["coord"], g["numbers"], g["charge"], mol, **kw)
+    assert np.abs(res["energy"] - g["energy"]).max() < 1e-5, np.abs(res["energy"] - g["energy"]).max()
+    bad, n, worst = elementwise_violations(res["forces"], g["forces"])
+    assert bad == 0, f"{bad} of {n} force components outside allclose(1e-4, 1e-5), worst {worst:.2f} x the gate"
+    assert np.abs(res["charges"] - g["charges"]).max() <= CHARGE_ATOL
+    if "stress" in g:
+        assert np.abs(res["stress"] - g["stress"]).max() <= STRESS_ATOL

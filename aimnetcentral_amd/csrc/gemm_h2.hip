@@ -26,16 +26,13 @@
 namespace aimnet {
 
 constexpr int h2_passes(int rows) { return (rows + 31) / 32; }  // DMA wave-instructions per wave of the issuing group (a pass = 4 KiB = 2 strips)
-// DMAC (the default schedule): the DMA requests are issued among the matrix instructions of the COMPUTE segments (a request costs
-// ~60 cycles there against 100 - 185 in a LOAD segment next to the fragment reads, MI355X_MICROARCH.md) one step further ahead -
-// three activation stages, four weight stages; the LOAD segments are fragment reads only.
-constexpr int h2_lds_bytes(int TM, int TN, bool dmac) { return (dmac ? 3 : 2) * h2_passes(TM) * 4096 + (dmac ? 4 : 3) * h2_passes(TN) * 4096; }
+constexpr int h2_lds_bytes(int TM, int TN, int sched) { return (sched == 1 ? 3 : 2) * h2_passes(TM) * 4096 + 3 * h2_passes(TN) * 4096; }
 
 #ifdef AIMNET_BF3_TIMING
 __device__ unsigned long long g_h2_stamps[1024];
 #endif
 
-template <int EPI, int SM, int SN, int WN, bool OUT3, bool DMAC>
+template <int EPI, int SM, int SN, int WN, bool OUT3, int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* __restrict__ A3, int lda3,
                                                            const unsigned short* __restrict__ Bt, int ldb, int M, int N, int K,
                                                            const float* __restrict__ bias, float* __restrict__ C,
@@ -75,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
       for (int j = 0; j < SN; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_a;
-  constexpr int NSA = DMAC ? 3 : 2, NSB = DMAC ? 4 : 3;  // ring depths
+  constexpr int NSA = SCHED == 1 ? 3 : 2, NSB = 3;  // ring depths
   const unsigned ldsB = lds0 + NSA * SA_BYTES;
 
   // DMA of the issuing group: pass p, wave w4 -> KiB q = 4 p + w4 of the stage = plane q & 1 of the 16-row strip q >> 1; lane ->
@@ -112,9 +109,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
     for (int p = decltype(p0_c)::value; p < decltype(p1_c)::value; ++p) glds16b(g + goff[p], base + p * 4096);
   };
   using PZ = std::integral_constant<int, 0>;
-  using PAH = std::integral_constant<int, NPA / 2>;
   using PAE = std::integral_constant<int, NPA>;
-  using PBH = std::integral_constant<int, NPB / 2>;
   using PBE = std::integral_constant<int, NPB>;
 
   // fragment addresses: row r, plane P, k-chunk c = lane >> 4 -> (r >> 4) * 2048 + P * 1024 + (r & 15) * 64 + (c ^ swz(r)) * 16
@@ -141,32 +136,113 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
 #else
   auto TS = [&]() __attribute__((always_inline)) {};
 #endif
+  f16x8 fa[SM][2], fb[SN][2];
+#define AIMNET_H2_PRODUCT(SET, PA, PB)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < SM; ++i) _Pragma("unroll") for (int jj = 0; jj < SN; ++jj) acc[SET][i][jj] = \
+      __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[jj][PB], fa[i][PA], acc[SET][i][jj], 0, 0, 0);
   TS();
-  // ---- prologue: A(0) by group 0; B(0), B(1) by group 1
+  if constexpr (SCHED == 1) {
+    // ---- one instruction stream per wave (AIMNET_H2_SCHED=1): every wave runs  [10 MFMAs | reads]  x 3  per k-step, fetching the
+    // fragments of step j+1 into the registers the products of step j have just released (fb.lo after the first cross product,
+    // fa.hi after the hi x hi product, fa.lo / fb.hi after the second cross product), ONE barrier per step.  The two waves of a
+    // SIMD are not held in opposite phases: whichever has operands feeds the matrix pipe, so its 60 instructions per step are
+    // the only serial resource (the alternating LOAD / COMPUTE segments left it idle for a third of every step:
+    // profiles/r5_gemm_h2.md).  Tiles: three ring stages each; tile j+3 is requested in step j (its stage held tile j, whose
+    // fragments every wave fetched before the barrier that ended step j-1), tile j+2 is waited for at the end of step j by the
+    // waves that requested it, in front of the barrier that publishes it.  Waves 0-3 request activations, waves 4-7 weights.
+    auto dma_tile = [&](int stage, int kt) __attribute__((always_inline)) {
+      if (!late) dma_a(stage, kt, PZ{}, PAE{});
+      else dma_b(stage, kt, PZ{}, PBE{});
+    };
+    auto wait_own = [&]() __attribute__((always_inline)) {  // all but the newest tile this wave requested have landed
+      if (!late) wait_vm<NPA>();
+      else wait_vm<NPB>();
+    };
+    dma_tile(0, 0);
+    dma_tile(1, kc(1));
+    dma_tile(2, kc(2));
+    wait_own();  // tiles 0 and 1
+    __builtin_amdgcn_sched_barrier(0);
+    TS();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_strips_h<0, SN, 1>(fb, adB);
+    read_strips_h<0, SM, 0>(fa, adA);
+    read_strips_h<0, SN, 0>(fb, adB);
+    read_strips_h<0, SM, 1>(fa, adA);
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();  // every wave holds the fragments of tile 0: its stage may receive tile 3
+    __builtin_amdgcn_sched_barrier(0);
+    TS();
+    // s1: stage of tile j+1 (read in this step); s0: stage of tile j = of tile j+3 (requested in this step)
+    // LAST: the step after which nothing follows - no fragment reads.  (Reads whose results are statically dead must not be
+    // issued at all: the compiler counts an asm load's destination as written at the statement and hands the registers of a
+    // dead value to the next instruction that needs some - here the DMA addresses - while the LDS data is still on its way.)
+    auto body = [&](int j, int s0, int s1, auto par_c, auto last_c) __attribute__((always_inline)) {
+      constexpr int PAR = decltype(par_c)::value;  // parity of the k-step = accumulator set of the hi x hi products
+      constexpr bool LAST = decltype(last_c)::value != 0;
+      const unsigned oa = adA + s1 * SA_BYTES, ob = adB + s1 * SB_BYTES;
+      __builtin_amdgcn_sched_barrier(0);
+      AIMNET_H2_PRODUCT(2, 0, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!LAST) read_strips_h<0, SN, 1>(fb, ob);
+      __builtin_amdgcn_sched_barrier(0);
+      AIMNET_H2_PRODUCT(PAR, 0, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!LAST) {
+        read_strips_h<0, SM, 0>(fa, oa);
+#if defined(AIMNET_H2_PROBE) && (AIMNET_H2_PROBE & 4)
+        // measurement only (wrong results): the tile requests of the loop dropped - bit 0 the activation tiles, bit 1 the weight tiles
+        if (!((AIMNET_H2_PROBE & 1) && !late) && !((AIMNET_H2_PROBE & 2) && late)) dma_tile(s0, kc(j + 3));
+#else
+        dma_tile(s0, kc(j + 3));
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      AIMNET_H2_PRODUCT(2, 1, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!LAST) {
+        read_strips_h<0, SN, 0>(fb, ob);
+        read_strips_h<0, SM, 1>(fa, oa);
+        wait_own();  // tile j+2
+        wait_lgkm<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        TS();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      TS();
+    };
+    int s0 = 0, s1 = 1, j = 0;
+    auto next = [&]() __attribute__((always_inline)) {
+      s0 = s1;
+      s1 = s1 == 2 ? 0 : s1 + 1;
+    };
+    // (an even number of steps ends inside the loop: the fragments its last step fetches are dead only dynamically - they keep
+    // their registers - and the wave waits for them before it leaves the loop)
+    for (; j + 1 < nk; j += 2) {
+      body(j, s0, s1, I0{}, I0{});
+      next();
+      body(j + 1, s0, s1, I1{}, I0{});
+      next();
+    }
+    if (j < nk) body(j, s0, s1, I0{}, I1{});
+  } else {
+  // ---- ping-pong (the default; the schedule of gemm_bf3a.hip): prologue A(0) by group 0; B(0), B(1) by group 1
   if (!late) {
     dma_a(0, 0, PZ{}, PAE{});
-    if constexpr (DMAC) {
-      dma_a(1, kc(1), PZ{}, PAE{});
-      wait_vm<NPA>();
-    } else {
-      wait_vm<0>();
-    }
+    wait_vm<0>();
   } else {
     dma_b(0, 0, PZ{}, PBE{});
     dma_b(1, kc(1), PZ{}, PBE{});
-    if constexpr (DMAC) {
-      dma_b(2, kc(2), PZ{}, PBE{});
-      wait_vm<2 * NPB>();
-    } else {
-      wait_vm<NPB>();
-    }
+    wait_vm<NPB>();
   }
   __builtin_amdgcn_sched_barrier(0);
   TS();
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
-  f16x8 fa[SM][2], fb[SN][2];
   // sa / sb: ring stages of this step's activation / weight tile
   auto seg_load = [&](int j, int sa, int sb, auto g_c) __attribute__((always_inline)) {
     constexpr int G = decltype(g_c)::value;
@@ -175,12 +251,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
     read_strips_h<0, SM, 0>(fa, oa);
     read_strips_h<0, SN, 0>(fb, ob);
     read_strips_h<0, SM, 1>(fa, oa);
-    if constexpr (DMAC) {
-      // group 1: the weight tile of step j+1 must be complete before group 0's next LOAD (a no-op after the first step: the wait
-      // at the end of the previous COMPUTE segment covers it)
-      if constexpr (G == 1) wait_vm<NPB>();
-      wait_lgkm<0>();
-    } else if constexpr (G == 0) {
+    if constexpr (G == 0) {
       dma_a(sa ^ 1, kc(j + 1), PZ{}, PAE{});
       wait_lgkm<0>();
     } else {
@@ -190,35 +261,14 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto seg_compute = [&](int j, int sa, int sb, auto par_c, auto g_c) __attribute__((always_inline)) {
+  auto seg_compute = [&](auto par_c, auto g_c) __attribute__((always_inline)) {
     constexpr int G = decltype(g_c)::value, PAR = decltype(par_c)::value;  // PAR: parity of the k-step = accumulator set
     __builtin_amdgcn_sched_barrier(0);
-#define AIMNET_H2_PRODUCT(SET, PA, PB)                                                                                      \
-  _Pragma("unroll") for (int i = 0; i < SM; ++i) _Pragma("unroll") for (int jj = 0; jj < SN; ++jj) acc[SET][i][jj] = \
-      __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[jj][PB], fa[i][PA], acc[SET][i][jj], 0, 0, 0);
     AIMNET_H2_PRODUCT(2, 0, 1)
-    if constexpr (DMAC) {  // activation tile of step j+2 -> stage (sa + 2) % 3; weight tile of step j+3 -> stage (sb + 3) % 4
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (G == 0) dma_a(sa == 0 ? 2 : sa - 1, kc(j + 2), PZ{}, PAH{});
-      else dma_b(sb == 0 ? 3 : sb - 1, kc(j + 3), PZ{}, PBH{});
-      __builtin_amdgcn_sched_barrier(0);
-    }
     AIMNET_H2_PRODUCT(PAR, 0, 0)
-    if constexpr (DMAC) {
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (G == 0) dma_a(sa == 0 ? 2 : sa - 1, kc(j + 2), PAH{}, PAE{});
-      else dma_b(sb == 0 ? 3 : sb - 1, kc(j + 3), PBH{}, PBE{});
-      __builtin_amdgcn_sched_barrier(0);
-    }
     AIMNET_H2_PRODUCT(2, 1, 0)
-#undef AIMNET_H2_PRODUCT
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DMAC) {
-      if constexpr (G == 0) wait_vm<NPA>();  // the activation tile of step j+1 (requested one COMPUTE segment earlier)
-      else wait_vm<NPB>();                   // the weight tile of step j+2
-    } else if constexpr (G == 0) {
-      wait_vm<0>();  // the activation tile of step j+1, requested in L(j)
-    }
+    if constexpr (G == 0) wait_vm<0>();  // the activation tile of step j+1, requested in L(j)
     __builtin_amdgcn_sched_barrier(0);
   };
   auto bar = [&]() __attribute__((always_inline)) {
@@ -230,25 +280,25 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
   auto run = [&](auto g_c) __attribute__((always_inline)) {
     int sa = 0, sb = 0, j = 0;
     auto next = [&]() __attribute__((always_inline)) {
-      sa = sa == NSA - 1 ? 0 : sa + 1;
-      sb = sb == NSB - 1 ? 0 : sb + 1;
+      sa ^= 1;
+      sb = sb == 2 ? 0 : sb + 1;
     };
     for (; j + 1 < nk; j += 2) {
       seg_load(j, sa, sb, g_c);
       bar();
-      seg_compute(j, sa, sb, I0{}, g_c);
+      seg_compute(I0{}, g_c);
       next();
       bar();
       seg_load(j + 1, sa, sb, g_c);
       bar();
-      seg_compute(j + 1, sa, sb, I1{}, g_c);
+      seg_compute(I1{}, g_c);
       next();
       if (j + 2 < nk) bar();
     }
     if (j < nk) {  // odd number of steps
       seg_load(j, sa, sb, g_c);
       bar();
-      seg_compute(j, sa, sb, I0{}, g_c);
+      seg_compute(I0{}, g_c);
     }
   };
   if (late) {
@@ -258,6 +308,8 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
     run(I0{});
     bar();  // group 0 has 2 nk segments, group 1 an empty one in front: both pass 2 nk barriers
   }
+  }
+#undef AIMNET_H2_PRODUCT
   wait_vm<0>();  // the clamped look-ahead of the last steps: the wave must not end (LDS released) under its DMA
   __builtin_amdgcn_sched_barrier(0);
   TS();
@@ -335,24 +387,28 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
 #endif
 }
 
-static int g_h2_sched = 1;  // AIMNET_H2_SCHED=0: DMA requests in the LOAD segments (the schedule of gemm_bf3a.hip)
+// AIMNET_H2_SCHED=1: one instruction stream per wave instead of the ping-pong of gemm_bf3a.hip.  Measured EQUAL (step 1.3452 vs
+// 1.3456 ms, profiles/r5_gemm_h2.md): with the tile requests dropped altogether a k-step still takes ~1 450 cycles - 60 matrix
+// instructions per SIMD at the 16x16x32 shape's own rate (19.4 cycles: 2 075 of 2 500 TFLOP/s in MI355X_MICROARCH.md's table) are
+// 1 164 of them; neither schedule has much left to hide.  The ping-pong keeps 88 instead of 108 KiB of LDS and is the default.
+static int g_h2_sched = 0;
 
-template <int SM, int SN, int WN, bool DMAC>
+template <int SM, int SN, int WN, int SCHED>
 static int launch_h2(hipStream_t stream, int epi, bool out3, const unsigned short* A3, int lda3, const unsigned short* Bt, int ldb,
                        int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
                        const int* brow, int ldbias, int alt) {
   constexpr int WM = 8 / WN, TM = 16 * SM * WM, TN = 16 * SN * WN;
   const int tiles = ceil_div(M, TM) * ceil_div(N, TN);
-  constexpr size_t lds = (size_t)h2_lds_bytes(TM, TN, DMAC);
+  constexpr size_t lds = (size_t)h2_lds_bytes(TM, TN, SCHED);
   static_assert(lds <= 160 * 1024, "LDS");
   dim3 grid(tiles), block(512);
 #define AIMNET_H2_LAUNCH(E, O3)                                                                                            \
   {                                                                                                                          \
     static PerDeviceOnce once;                                                                                               \
     if (once.first())                                                                                                        \
-      AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_h2_kernel<E, SM, SN, WN, O3, DMAC>,                                \
+      AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_h2_kernel<E, SM, SN, WN, O3, SCHED>,                                \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
-    hipLaunchKernelGGL((gemm_h2_kernel<E, SM, SN, WN, O3, DMAC>), grid, block, lds, stream, A3, lda3, Bt, ldb, M, N, K, bias, C, \
+    hipLaunchKernelGGL((gemm_h2_kernel<E, SM, SN, WN, O3, SCHED>), grid, block, lds, stream, A3, lda3, Bt, ldb, M, N, K, bias, C, \
                        C3, ldc3, D, ldc, brow, ldbias, alt);                                                                \
   }
   if (out3) {
@@ -413,9 +469,9 @@ int launch_gemm_h2_cfg(hipStream_t stream, int cfg, int epi, bool out3, const un
   switch (cfg) {
 #define AIMNET_H2_CASE(ID, SM_, SN_, WN_)                                                                                    \
     case ID:                                                                                                                   \
-      return g_h2_sched ? launch_h2<SM_, SN_, WN_, true>(stream, epi, out3, A3, lda3, Bt, ldb, M, N, K, bias, C, C3, ldc3, D, ldc, brow, \
+      return g_h2_sched ? launch_h2<SM_, SN_, WN_, 1>(stream, epi, out3, A3, lda3, Bt, ldb, M, N, K, bias, C, C3, ldc3, D, ldc, brow, \
                                                          ldbias, alt)                                                          \
-                        : launch_h2<SM_, SN_, WN_, false>(stream, epi, out3, A3, lda3, Bt, ldb, M, N, K, bias, C, C3, ldc3, D, ldc,   \
+                        : launch_h2<SM_, SN_, WN_, 0>(stream, epi, out3, A3, lda3, Bt, ldb, M, N, K, bias, C, C3, ldc3, D, ldc,   \
                                                           brow, ldbias, alt);
     AIMNET_H2_CASE(452, 5, 2, 4)  // 160 x 128 (2 x 4 waves of 80 x 32; 136 KiB of LDS)
     AIMNET_H2_CASE(432, 3, 2, 4)  //  96 x 128
@@ -506,7 +562,7 @@ int gemm_h2_set_attributes() {
   const char* env = getenv("AIMNET_H2_TILE");
   g_h2_force_tile = env ? atoi(env) : 0;
   env = getenv("AIMNET_H2_SCHED");
-  g_h2_sched = env ? atoi(env) : 1;
+  g_h2_sched = env ? atoi(env) : 0;
   return 0;
 }
 

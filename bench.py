@@ -47,6 +47,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_BF16_DENSE_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16 MFMA
 PEAK_BF16X3_TFLOPS = PEAK_BF16_DENSE_TFLOPS / 6.0  # six bf16 products per fp32 product
+PEAK_F16X2_TFLOPS = PEAK_BF16_DENSE_TFLOPS / 3.0   # three fp16 products per fp32 product (fp16 MFMA = the bf16 rate)
 
 
 def build_workload(name: str, rank: int, world: int):
@@ -381,6 +382,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pbc10k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-repeat", action="store_true", help="skip the four extra repeats of the timed region (timed_region_repeat)")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the extra pass with the exact-fp32 GEMM kernels (profiling runs)")
     ap.add_argument("--no-hessian", action="store_true", help="skip the hessian_config4 record (profiling runs: keeps the kernel trace "
                     "and the counter passes to the kernels of the timed workload)")
@@ -488,6 +490,14 @@ def main():
     elapsed, total_atoms, n_atoms, frames, prof, wl, local_step = (run[k] for k in ("elapsed", "total_atoms", "n_atoms", "frames", "prof",
                                                                                    "wl", "local_step"))
 
+    # the line's own noise bar: four more repeats of the identical timed region (untouched `value` = the FIRST region, as the driver
+    # clocks it); min / median / max of the five regions' ms per step
+    repeats = [elapsed / args.steps * 1e3]
+    if not args.no_repeat:
+        for _ in range(4):
+            rr = timed_run(args.workload, args.steps, 1, profile=False)
+            repeats.append(rr["elapsed"] / args.steps * 1e3)
+
     # BASELINE configs[4] in the same run (N > 1): 128 frames x 50 atoms per GPU, per-frame energies all-gathered every step
     md = None
     if distributed and args.workload != "md1024":
@@ -530,6 +540,19 @@ def main():
                               "kernel": "gemm_nt_panel_kernel (fp32 MFMA MLP GEMMs)"}}
         eng.set_option("gemm_bf3", 1)
 
+    bf16x3 = None
+    if world == 1 and not args.no_exact_f32 and eng.get_option("gemm_h2"):  # the bf16x3-split operands (round 4's default; the range fallback)
+        eng.set_option("gemm_h2", 0)
+        r = timed_run(args.workload, args.steps, 2)
+        g_ms = r["prof"]["gemm"] / max(1.0, r["prof"]["evals"])
+        fl = eng.gemm_flops_per_atom(True) * n_atoms
+        bf16x3 = {"value": r["total_atoms"] * args.steps / r["elapsed"], "unit": "atoms*steps/s", "ms_per_step": r["elapsed"] / args.steps * 1e3,
+                  "dtype": "f32 (bf16x3-split MFMA operands, six products, fp32 accumulate)", "option": "aimnet_engine_set_option(\"gemm_h2\", 0)",
+                  "roofline": {"bound": "mfma", "achieved": fl / (g_ms * 1e-3) / 1e12, "peak": PEAK_BF16X3_TFLOPS, "unit": "TFLOP/s",
+                               "frac": fl / (g_ms * 1e-3) / 1e12 / PEAK_BF16X3_TFLOPS, "gemm_ms_per_step": g_ms,
+                               "kernel": "gemm_bf3a_kernel + head_fused_kernel"}}
+        eng.set_option("gemm_h2", 1)
+
     ewald = None
     if world == 1 and args.workload == "pbc10k" and not args.no_exact_f32:
         # the same frame with Ewald summation instead of DSF (csrc/ewald.hip): its own record, after the timed region
@@ -564,6 +587,8 @@ def main():
         traffic, traffic_commit = pmc_traffic(args.workload)
         pmc = pmc_record(args.workload)
         presplit = eng.get_option("gemm_presplit") != 0 and eng.get_option("gemm_bf3") != 0 and n_atoms > max(256, eng.get_option("split_max"))
+        h2 = presplit and eng.get_option("gemm_h2") != 0  # fp16x2-split operands (csrc/gemm_h2.hip): three products per fp32 product
+        peak_split = PEAK_F16X2_TFLOPS if h2 else PEAK_BF16X3_TFLOPS
         n_lay = sum(len(d) - 1 for d in eng.spec.mlp_dims)
         fused = presplit and eng.get_option("head_fused") != 0
         gemm_launches = 2 * n_lay + (1 if fused else 2 * (len(eng.spec.head_dims) - 2))
@@ -580,7 +605,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (bf16x3-split MFMA operands, fp32 accumulate)",
+            "dtype": ("f32 (fp16x2-split MFMA operands: fp32 == hi + lo / 4096 to 2^-24, three fp16 products per fp32 product, fp32 accumulate; "
+                      "rms error against fp64 below the fp32 MFMA chain and the bf16x3 split, profiles/r5_gemm_h2.md)") if h2 else
+                     "f32 (bf16x3-split MFMA operands, fp32 accumulate)",
+            "timed_region_repeat": {"ms_per_step": repeats, "min": float(np.min(repeats)), "median": float(np.median(repeats)),
+                                    "max": float(np.max(repeats)), "regions": len(repeats), "steps_per_region": args.steps,
+                                    "note": "region 0 is the line's `value`; the others repeat it after one re-warming evaluation"},
             "data": "synthetic (seeded weights of the real aimnet2 architecture; " + (
                 "crystal from 2019828.cif + 0.02 A jitter)" if args.workload == "pbc10k" else
                 "taxol.xyz frame 0)" if args.workload == "taxol" else "seeded random organic geometries)"),
@@ -588,12 +618,18 @@ def main():
                        "parallelism": f"batch-shard x{world} (independent frames, RCCL all-gather of energies)" if world > 1 else "single GPU"},
             # algorithmic fp32 FLOPs of the MLP GEMMs / their time: against the roof of the kernel that runs them (six bf16 MFMA
             # products per fp32 product: 2.5 PFLOP/s / 6) and against the fp32-matrix peak the exact kernels are bound by
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16X3_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16X3_TFLOPS, "peak_note": "2.5 PFLOP/s dense bf16 / 6 products per fp32 product",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak_split, "unit": "TFLOP/s",
+                         "frac": achieved / peak_split,
+                         "peak_note": "2.5 PFLOP/s dense fp16 / 3 products per fp32 product" if h2 else "2.5 PFLOP/s dense bf16 / 6 products per fp32 product",
+                         # continuity with rounds 3-4, whose kernels needed six products per fp32 product: the same algorithmic FLOPs
+                         # against THAT roof (VERDICT r4's target was >= 0.38 of it)
+                         "frac_vs_bf16x3_roof": achieved / PEAK_BF16X3_TFLOPS,
                          "peak_fp32_matrix": PEAK_FP32_MATRIX_TFLOPS, "frac_fp32_matrix": achieved / PEAK_FP32_MATRIX_TFLOPS,
                          "traffic": traffic, "traffic_measured_at_commit": traffic_commit,
                          "mfma_busy_frac_in_kernel": pmc.get("mfma_busy_frac_in_kernel"),
-                         "kernel": ("gemm_bf3a_kernel + head_fused_kernel (bf16x3-split MFMA MLP GEMMs, operands pre-split by their producers, "
+                         "kernel": ("gemm_h2_kernel + head_fused_h2_kernel (fp16x2-split MFMA MLP GEMMs, operands pre-split by their producers, "
+                                    "fp32 accumulate; all launches of a step)") if h2 else
+                                   ("gemm_bf3a_kernel + head_fused_kernel (bf16x3-split MFMA MLP GEMMs, operands pre-split by their producers, "
                                     "fp32 accumulate; all launches of a step)") if presplit else
                                    "gemm_bf3_kernel (bf16x3-split MFMA MLP GEMMs, fp32 accumulate; all launches of a step)",
                          "gemm_launches_per_step": gemm_launches,
@@ -607,9 +643,9 @@ def main():
                              "mean_neighbours": n_pairs / n_atoms, "target_frac": 0.5,
                              # the same step against the pipes it actually runs on: the GEMM FLOPs at the bf16x3 roof (416.7), the
                              # rest (conv / AEV / agh, vector pipe) at 157.3: ideal time of both parts / measured time
-                             "frac_mixed": (flops_step / (PEAK_BF16X3_TFLOPS * 1e12) + (e2e_flops - flops_step) / (PEAK_FP32_MATRIX_TFLOPS * 1e12))
+                             "frac_mixed": (flops_step / (peak_split * 1e12) + (e2e_flops - flops_step) / (PEAK_FP32_MATRIX_TFLOPS * 1e12))
                                            / (ms_per_step * 1e-3),
-                             "frac_mixed_note": "GEMM FLOPs / 416.7 TFLOP/s + the rest / 157.3 TFLOP/s, over ms_per_step"},
+                             "frac_mixed_note": "GEMM FLOPs / the split kernels' roof (roofline.peak) + the rest / 157.3 TFLOP/s, over ms_per_step"},
             # second kernel class (SURVEY 8d ii): the gather-contract backward.  Algorithmic gathered bytes per ordered pair:
             # reverse-pair form (default above 1 024 atoms): passes 1, 2 read Sbar_j (4 KiB) + Sqbar_j (256 B) and write F1 into
             # the pair buffer (16 B, read back once when the passes are summed); combined form (AIMNET_CONV_XE=0): a_j (1 KiB) more;
@@ -624,6 +660,8 @@ def main():
         }
         if exact is not None:
             out["exact_f32"] = exact
+        if bf16x3 is not None:
+            out["bf16x3_split"] = bf16x3
         if ewald is not None:
             out["ewald_config3"] = ewald
         if md is not None:

@@ -122,10 +122,23 @@ def test_energy_sums_riding_on_the_stress_launches_bitwise(hip_engine, reps):
                             cell=torch.from_numpy(cell.astype(np.float32)).to(dev), forces=True, stress=True, coulomb="dsf", dsf_rc=9.0)
         return {k: v.cpu().numpy() for k, v in r.items()}
 
-    a, b = both(hip_engine, go, "energy_rides")
+    # (the whole-molecule form of the riding sums, "sums_whole", adds the same fp64 terms in another association - equal to 1e-13
+    # relative, checked below; the bitwise claim is about the sliced sums)
+    hip_engine.set_option("sums_whole", 0)
+    try:
+        a, b = both(hip_engine, go, "energy_rides")
+    finally:
+        hip_engine.set_option("sums_whole", 1)
     for k in a:
         assert np.array_equal(a[k], b[k]), k
     assert np.isfinite(a["energy"]).all() and a["energy"][0] < 0
+    w = go()  # defaults: energy sums riding, whole-molecule blocks
+    assert np.abs(w["energy"] - a["energy"]).max() <= 1e-13 * np.abs(a["energy"]).max()
+    for k in a:
+        if k == "stress":  # (its sums change association too: the last float bit)
+            assert np.allclose(w[k], a[k], rtol=1e-6, atol=1e-12), k
+        elif k != "energy":
+            assert np.array_equal(w[k], a[k]), k
 
 
 @pytest.mark.parametrize("option", ["setup_rides", "status_rides"])

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kseq
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kseq -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-f32 --no-hessian $KSEQ_ARGS > /tmp/kseq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kseq -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-f32 --no-hessian --no-repeat $KSEQ_ARGS > /tmp/kseq.log 2>&1
 python - <<PY > $R/gpurun_out/kseq.txt
 import csv, glob
 rows = list(csv.DictReader(open(glob.glob("/tmp/kseq/*/*kernel_trace.csv")[0])))

@@ -4,10 +4,10 @@ out=$1
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$out
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$out/trace -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-exact-f32 --no-hessian > $R/gpurun_out/$out/bench_traced.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$out/trace -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-exact-f32 --no-hessian --no-repeat > $R/gpurun_out/$out/bench_traced.log 2>&1
 for pass in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/$out/$tag -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-hessian > $R/gpurun_out/$out/$tag.log 2>&1
+  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/$out/$tag -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-hessian --no-repeat > $R/gpurun_out/$out/$tag.log 2>&1
 done
 cd $R
 python tests/tools/prof_summary.py $(ls gpurun_out/$out/trace/*/*kernel_trace.csv | head -1) 17 > gpurun_out/$out/kernel_summary.txt
@@ -30,7 +30,7 @@ import csv, glob, collections, json, os
 tot = collections.defaultdict(float); n = collections.defaultdict(int)
 for f in sorted(glob.glob("gpurun_out/$out/*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if not any(k in r["Kernel_Name"] for k in ("gemm_nt", "gemm_bf3", "head_fused")): continue
+        if not any(k in r["Kernel_Name"] for k in ("gemm_nt", "gemm_bf3", "gemm_h2", "head_fused")): continue
         tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 launches = max(1, n["TCC_EA0_RDREQ_sum"])
 rd, wr = tot["TCC_EA0_RDREQ_sum"] * 128 / launches, tot["TCC_EA0_WRREQ_sum"] * 64 / launches

@@ -34,7 +34,13 @@ def test_single_gpu_json_contract():
     assert abs(d["value"] - d["config"]["atoms_per_gpu"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     # the record of the exact-fp32 kernels rides on the same line (measured after the timed region)
     ex = d["exact_f32"]
-    assert ex["value"] > 0 and ex["roofline"]["peak"] == 157.3 and "bf16x3" in d["dtype"] and d["roofline"]["peak_fp32_matrix"] == 157.3
+    assert ex["value"] > 0 and ex["roofline"]["peak"] == 157.3 and d["dtype"].startswith("f32 (fp16x2-split") and d["roofline"]["peak_fp32_matrix"] == 157.3
+    # ... and so does the record of round 4's bf16x3-split operands (the range fallback); the line's own roof is the fp16x2 kernels'
+    b3 = d["bf16x3_split"]
+    assert b3["value"] > 0 and abs(b3["roofline"]["peak"] - 2500.0 / 6) < 1e-6 and abs(d["roofline"]["peak"] - 2500.0 / 3) < 1e-6
+    assert abs(d["roofline"]["frac_vs_bf16x3_roof"] - 2 * d["roofline"]["frac"]) < 1e-9
+    rep = d["timed_region_repeat"]
+    assert rep["regions"] == 5 and rep["min"] <= rep["median"] <= rep["max"] and abs(rep["ms_per_step"][0] - d["ms_per_step"]) < 1e-9
     # BASELINE config 4 in the same run: the analytic Hessian at the reference's own gate, and well inside it
     h4 = d["hessian_config4"]
     assert h4["ok"] is True and h4["dH_max"] <= 1e-4 and h4["dHv4_max"] <= 4e-4 and h4["force_evals_per_direction"]["dense"] < 0.2
@@ -51,11 +57,19 @@ def test_default_workload_carries_the_parity_gate():
     assert p["ok"] is True and set(p) >= {"pbc2304", "md48x50", "ok"}
     for k in ("pbc2304", "md48x50"):
         assert p[k]["ok"] and p[k]["dF_max"] <= p[k]["gates"]["dF_max"] and p[k]["dq_max"] <= 1e-4
-    assert p["pbc2304"]["dE"] <= p["pbc2304"]["gates"]["dE"] and p["pbc2304"]["gates"]["dE_gate_slack_fp64"] == 0.0
+    # the crystal's energy is held against the fp64 oracle (the fp32 oracle itself sits 1.3e-3 eV from it, more than the plain gate:
+    # tests/tools/pbc2304_margin.py) - and the engine is INSIDE the plain gate there, an order of magnitude closer than the fp32 oracle
+    assert p["pbc2304"]["dE_vs"] == "fp64 oracle" and p["pbc2304"]["dE"] <= p["pbc2304"]["gates"]["dE"] and p["pbc2304"]["rms_ratio"] < 0.5
+    for k in ("pbc2304", "md48x50"):
+        v = p[k]["dF_elementwise_violations"]
+        assert v["of"] == 3 * p[k]["atoms"] and 0 <= v["count"] < 0.02 * v["of"]
+    # the cold-weight goldens of the unmodified reference at its LITERAL gates: zero force components outside allclose(1e-4, 1e-5)
+    cg = d["parity_cold_goldens"]
+    assert cg["ok"] is True and all(cg[k]["dF_elementwise_violations"]["count"] == 0 and cg[k]["dE"] < 1e-5 for k in ("taxol", "batch5", "rand8", "pbc96"))
     # the honest fractions and the engine-reported configuration ride on the same line
     assert 0.0 < d["roofline_e2e"]["frac_mixed"] < d["roofline_e2e"]["frac"] < 1.0
     assert d["roofline"]["gemm_launches_per_step"] == 21 and "mfma_busy_frac_in_kernel" in d["roofline"]
-    assert d["roofline_gather"]["form"] == "reverse-pair" and "gemm_bf3a_kernel" in d["roofline"]["kernel"]
+    assert d["roofline_gather"]["form"] == "reverse-pair" and "gemm_h2_kernel" in d["roofline"]["kernel"]
     # the same frame with Ewald summation (its own record): slower than DSF by the reciprocal-space kernels, not by a factor
     ew = d["ewald_config3"]
     assert d["ms_per_step"] < ew["ms_per_step"] < 1.5 * d["ms_per_step"] and ew["k_box_entries"] > 1000 and np.isfinite(ew["energy_eV"])

@@ -120,7 +120,11 @@ def _metrics(eng, inputs):
     m["cfg5_shard"] = dict(dE_over_gate=float(np.max(err / gate)), rms_hip_vs_fp64=rms, rms_fp32_oracle_vs_fp64=rms_ref,
                            rms_ratio=rms / rms_ref, rms_gate_ok=bool(rms <= 1.5 * rms_ref + 1e-5),
                            dF_over_gate=float(np.abs(r["forces"] - ref["forces"]).max() / (1e-5 + 1e-4 * np.abs(ref["forces"]).max())),
-                           dq=float(np.abs(r["charges"] - ref["charges"]).max()))
+                           dq=float(np.abs(r["charges"] - ref["charges"]).max()),
+                           # charges against the fp64 oracle: the engine's distance and the fp32 oracle's own (on the hot seeds the
+                           # fp32 reference path itself sits ~1e-4 e from the fp64 charges of atoms in 0.9 A contacts)
+                           dq64=float(np.abs(r["charges"] - ref64["charges"]).max()),
+                           dq64_fp32_oracle=float(np.abs(ref["charges"] - ref64["charges"]).max()))
     return m
 
 
@@ -149,6 +153,8 @@ def test_fixtures_on_other_weight_seeds(seeded):
                     ok = d[key] / norm <= max(1.0, 1.5 * ex[key] / norm)
                     if key == "dE_over_gate" and "d64" in d:  # ... or as close to the fp64 energy as the fp32 reference path (x 1.5)
                         ok = ok or d["d64"] <= 1.5
+                    if key == "dq" and "dq64" in d:  # ... or as close to the fp64 charges as the fp32 reference path (x 1.5)
+                        ok = ok or d["dq64"] <= max(CHARGE_ATOL, 1.5 * d["dq64_fp32_oracle"])
                     assert ok, (seed, mode, fx, key, d, ex)
             if fx == "cfg5_shard":
                 assert d["rms_gate_ok"] or d["rms_ratio"] <= 1.5 * ex["rms_ratio"], (seed, mode, d, ex)

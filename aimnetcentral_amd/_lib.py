@@ -40,8 +40,6 @@ EXPORTED_SYMBOLS = (
     "aimnet_debug_gemm_bf3a",
     "aimnet_debug_split_h2",
     "aimnet_debug_gemm_h2",
-    "aimnet_debug_gemm_h2_chain",
-    "aimnet_debug_gemm_h2_chain_sync_words",
     "aimnet_debug_mfma4_probe",
     "aimnet_engine_set_option",
     "aimnet_engine_get_option",
@@ -56,14 +54,6 @@ EXPORTED_SYMBOLS = (
 
 class HipLibraryError(RuntimeError):
     pass
-
-
-class DebugChainLayer(C.Structure):
-    """aimnet_debug_chain_layer (include/aimnet_hip.h): one layer of aimnet_debug_gemm_h2_chain."""
-
-    _fields_ = [("A2", C.c_void_p), ("lda2", C.c_int32), ("Bt2", C.c_void_p), ("ldb", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
-                ("bias", C.c_void_p), ("C", C.c_void_p), ("C2", C.c_void_p), ("ldc2", C.c_int32), ("D", C.c_void_p), ("ldc", C.c_int32),
-                ("epi", C.c_int32), ("out2", C.c_int32), ("alt", C.c_int32)]
 
 
 class Arch(C.Structure):
@@ -230,10 +220,6 @@ def load() -> C.CDLL:
     lib.aimnet_debug_split_h2.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
     lib.aimnet_debug_gemm_h2.restype = C.c_int
     lib.aimnet_debug_gemm_h2.argtypes = list(lib.aimnet_debug_gemm_bf3a.argtypes)
-    lib.aimnet_debug_gemm_h2_chain.restype = C.c_int
-    lib.aimnet_debug_gemm_h2_chain.argtypes = [C.POINTER(DebugChainLayer), C.c_int, C.c_int, vp, C.c_size_t, vp]
-    lib.aimnet_debug_gemm_h2_chain_sync_words.restype = C.c_size_t
-    lib.aimnet_debug_gemm_h2_chain_sync_words.argtypes = [C.c_int, C.c_int]
     lib.aimnet_debug_mfma4_probe.restype = C.c_int
     lib.aimnet_debug_mfma4_probe.argtypes = [vp, vp]
     lib.aimnet_neighbor_list_workspace_bytes.restype = sz

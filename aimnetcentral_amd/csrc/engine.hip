@@ -1354,22 +1354,6 @@ int aimnet_debug_gemm_h2(int cfg, int epi, int out2, const void* A2, int lda2, c
   return launch_gemm_h2_cfg((hipStream_t)hip_stream, cfg, epi, out2 != 0, (const unsigned short*)A2, lda2, (const unsigned short*)Bt2,
                             ldb, M, N, K, bias, C, (unsigned short*)C2, ldc2, D, ldc, nullptr, 0, alt);
 }
-int aimnet_debug_gemm_h2_chain(const aimnet_debug_chain_layer* layers, int n_layers, int M, void* sync, size_t sync_words, void* hip_stream) {
-  using namespace aimnet;
-  if (!layers || n_layers < 1 || n_layers > 4 || M <= 0 || !sync) return AIMNET_E_INVALID;
-  H2ChainLayer L[4];
-  for (int l = 0; l < n_layers; ++l) {
-    const aimnet_debug_chain_layer& d = layers[l];
-    L[l] = H2ChainLayer{};
-    L[l].A = (const unsigned short*)d.A2; L[l].lda = d.lda2; L[l].W = (const unsigned short*)d.Bt2; L[l].ldb = d.ldb;
-    L[l].N = d.N; L[l].K = d.K; L[l].bias = d.bias; L[l].brow = nullptr; L[l].ldbias = 0;
-    L[l].C = d.C; L[l].C2 = (unsigned short*)d.C2; L[l].ldc2 = d.ldc2; L[l].D = d.D; L[l].ldc = d.ldc;
-    L[l].epi = d.epi; L[l].out2 = d.out2; L[l].alt = d.alt;
-  }
-  return launch_gemm_h2_chain((hipStream_t)hip_stream, L, n_layers, M, (unsigned*)sync, sync_words);
-}
-size_t aimnet_debug_gemm_h2_chain_sync_words(int n_layers, int M) { return aimnet::gemm_h2_chain_sync_words(n_layers, M); }
-
 #ifdef AIMNET_PREP_TIMING
 int aimnet_debug_prep_stamps(unsigned long long* host16) { return aimnet::prep_read_stamps(host16); }
 #endif

@@ -72,10 +72,6 @@ __device__ __forceinline__ void store_h2_1(unsigned short* __restrict__ row, int
 // Two horizontally adjacent 16x16 accumulator tiles of an MFMA epilogue -> h2 row (the contract of store_bf3_tile_pair: lane
 // (l16, lc) holds columns 4 lc .. 4 lc + 3 of row l16 of each tile, col0 = first column of tile j, a multiple of 16; after the
 // v_permlane16_swap exchange a lane owns 8 consecutive columns and stores 16 B per plane).  All 64 lanes must call it.
-// WT: write-through stores (sc0 sc1: the bytes go to memory and drop out of this XCD's L2) - the publish form of a tile that another
-// workgroup of the SAME launch reads (gemm_h2_chain.hip; cdna_hip_programming.md Guideline 16, R1); the storing wave drains them with
-// s_waitcnt vmcnt(0) before its workgroup's flag is raised.
-template <bool WT = false>
 __device__ __forceinline__ void store_h2_tile_pair(unsigned short* __restrict__ crow, int col0, int lc, f32x4 v0, f32x4 v1) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   unsigned x[2][2], y[2][2];
@@ -90,12 +86,7 @@ __device__ __forceinline__ void store_h2_tile_pair(unsigned short* __restrict__ 
   for (int pl = 0; pl < 2; ++pl) {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
                  : "+v"(x[pl][0]), "+v"(y[pl][0]), "+v"(x[pl][1]), "+v"(y[pl][1]));
-    const u32x4 val = {x[pl][0], x[pl][1], y[pl][0], y[pl][1]};
-    if constexpr (WT) {
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(pc + pl * 32), "v"(val) : "memory");
-    } else {
-      *reinterpret_cast<u32x4*>(pc + pl * 32) = val;
-    }
+    *reinterpret_cast<u32x4*>(pc + pl * 32) = u32x4{x[pl][0], x[pl][1], y[pl][0], y[pl][1]};
   }
 }
 

@@ -65,25 +65,6 @@ int launch_split_h2(hipStream_t s, const float* src, int ld, int M, int K, unsig
 int gemm_h2_read_stamps(unsigned long long* host1024);
 #endif
 
-// ---- gemm_h2_chain.hip: the layers of one MLP as ONE persistent launch of the h2 GEMM (tiles of all layers drawn in order from a
-// device queue, per-row-panel arrival counters between the layers, write-through stores for the activations a later layer reads)
-struct H2ChainLayer {
-  const unsigned short* A; int lda;   // h2 activation operand (layer l > 0: the C2 of layer l - 1)
-  const unsigned short* W; int ldb;   // h2 weight operand [N][K]
-  int N, K;
-  const float* bias; const int* brow; int ldbias;
-  float* C; unsigned short* C2; int ldc2; float* D; int ldc;
-  int epi, out2, alt;                 // as launch_gemm_h2_cfg
-  int tiles_n, tile0, dep, publish;   // filled by the launcher
-};
-struct H2ChainArgs {
-  H2ChainLayer L[4];
-  int n_layers, M, tiles_m, n_tiles;
-  unsigned *queue, *done, *err;
-};
-size_t gemm_h2_chain_sync_words(int n_layers, int M);
-int launch_gemm_h2_chain(hipStream_t stream, const H2ChainLayer* layers, int n_layers, int M, unsigned* sync, size_t sync_words);
-
 // ---- gemm_head.hip: the energy head 256 -> 128 -> 128 -> 1 forward and backward in one launch (operands of gemm_bf3a.hip)
 struct HeadFusedArgs {
   const unsigned short* aim3;  // [M][lda3] head input in bf3 form (written by the last MLP layer's epilogue)

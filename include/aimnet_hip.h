@@ -262,22 +262,6 @@ int aimnet_debug_split_h2(const float* src, int ld, int M, int K, void* dst, int
 int aimnet_debug_gemm_h2(int cfg, int epi, int out2, const void* A2, int lda2, const void* Bt2, int ldb, int M, int N, int K,
                          const float* bias, float* C, void* C2, int ldc2, float* D, int ldc, int alt, void* hip_stream);
 
-/* aimnet_debug_gemm_h2_chain (csrc/gemm_h2_chain.hip): up to four layers of one MLP - layer l reads the h2 output C2 of layer l - 1 - as
- * ONE persistent launch; every field as in aimnet_debug_gemm_h2 (alt 1 or 2).  sync: aimnet_debug_gemm_h2_chain_sync_words(n_layers, M)
- * 32-bit words of device memory (queue head, error word, per-row-panel arrival counters; zeroed by the call).  Results are bitwise
- * those of the per-layer launches. */
-typedef struct aimnet_debug_chain_layer {
-  const void* A2; int32_t lda2;
-  const void* Bt2; int32_t ldb;
-  int32_t N, K;
-  const float* bias;
-  float* C; void* C2; int32_t ldc2;
-  float* D; int32_t ldc;
-  int32_t epi, out2, alt;
-} aimnet_debug_chain_layer;
-int aimnet_debug_gemm_h2_chain(const aimnet_debug_chain_layer* layers, int n_layers, int M, void* sync, size_t sync_words, void* hip_stream);
-size_t aimnet_debug_gemm_h2_chain_sync_words(int n_layers, int M);
-
 /* Engine switches for A/B and parity runs (all have an AIMNET_* environment twin read at create time):
  *   "conv_xe"       1 (default): reverse-pair form of the conv backward for systems above the split threshold, 0: combined form
  *   "gemm_bf3"      1 (default): MLP GEMMs of batches above 256 rows with bf16x3-split operands on the bf16 matrix pipe

@@ -8,6 +8,11 @@
 //           - alpha / sqrt(pi) sum_i q_i^2                                        self term               (the walk's self term)
 //           - pi Q^2 / (2 V alpha^2)                                              neutralising background (here)
 //
+// UNPINNED against the reference's production kernel: three conventions follow the textbook form and the in-tree torch
+// Ewald, not nvalchemiops (absent from the reference tree) - the background term for CHARGED cells (a constant energy / stress
+// offset if the production kernel omits or scales it), the inclusive cut k^2 <= kc^2 (ops.py uses <), and "pme" requests being
+// served by this exact sum (calculator.set_lrcoulomb_method warns).  Neutral cells are pinned (golden matrices, Madelung constants).
+//
 // Per system: eta = (V^2 / N)^(1/6) / sqrt(2 pi), alpha = 1 / (sqrt(2) eta), rc = f eta, kc = f / eta, f = sqrt(-2 ln accuracy) -
 // both sums cost O(N^1.5).  Everything is decided on the device from the cell (no host round trip, NPT-safe); the host only
 // provides the capacity of the k arrays.

@@ -44,6 +44,12 @@ class ModelSpec:
     num_charge_channels: int = 1       # 2 = open-shell NSE family (aimnet2.py:21-28)
 
 
+class ActivationRangeError(RuntimeError):
+    """A DEFERRED evaluation produced non-finite energies while the fp16x2-split GEMM operands were in use: an MLP activation left
+    fp16's range (|x| >= 65504, csrc/gemm_h2_common.h).  The engine has switched to the bf16x3 operands; repeat the evaluations
+    since the last check (the synchronous path does this by itself)."""
+
+
 class NeighborOverflowError(RuntimeError):
     """A neighbour row overflowed in a DEFERRED evaluation (the synchronous path retries by itself; nvalchemiops raises the
     exception of this name, neighbors.py:127-130)."""
@@ -124,6 +130,7 @@ class HipEngine:
         self._ws = None
         self._ws_stream = None  # stream of the last launch (the workspace is tied to it)
         self.pending_status: list = []  # status words of evaluations run with sync=False and defer=True (check_deferred)
+        self._pending_energy: list = []  # their energies, while the h2 operand form is on (the fp16-range sentinel, check_deferred)
         # AdaptiveNeighborList policy (neighbors.py:49-63): density 0.2 -> 112 @ 5 A, 2832 @ 15 A
         self.max_nb = _round16(int(0.2 * 4.0 / 3.0 * math.pi * spec.rc**3))
         self._max_nb_lr: dict[float, int] = {}
@@ -184,6 +191,12 @@ class HipEngine:
         st = torch.stack(self.pending_status).cpu().numpy()
         self.pending_status.clear()
         self.last_status = st[-1]
+        energies, self._pending_energy = self._pending_energy, []
+        rows_ok = not (st[:, 2].any() or st[:, 3].any() or st[:, 5].any() or st[:, 6].any())
+        if rows_ok and energies and self.get_option("gemm_h2") and not all(bool(torch.isfinite(e).all()) for e in energies):
+            self.set_option("gemm_h2", 0)
+            raise ActivationRangeError("non-finite energies in one of the last %d deferred evaluations with fp16x2-split GEMM operands: an "
+                                       "activation left fp16's range; the engine now uses the bf16x3 operands - repeat them" % len(st))
         if st[:, 6].any():
             raise ValueError("HipEngine: invalid input in a deferred evaluation: " + describe_input_flags(int(np.bitwise_or.reduce(st[:, 6]))))
         grown = False
@@ -465,6 +478,8 @@ class HipEngine:
             res["status"] = status
             if defer:
                 self.pending_status.append(status)  # verified in one go by check_deferred()
+                if h2_on:
+                    self._pending_energy.append(energy)
         if spin is not None:
             res["spin_charges"] = spin
         if forces:

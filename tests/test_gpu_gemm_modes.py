@@ -141,3 +141,14 @@ def test_fp16_range_fallback():
         res = eng.eval(*args, forces=True)
     assert eng.get_option("gemm_h2") == 0
     assert torch.equal(res["energy"], ref["energy"]) and torch.equal(res["forces"], ref["forces"])
+    # the deferred path (no host read per step): the check every K steps finds the non-finite energies, switches and asks for a repeat
+    from aimnetcentral_amd.engine import ActivationRangeError
+
+    eng2 = HipEngine(spec, "cuda:0")
+    for _ in range(3):
+        eng2.eval(*args, forces=True, sync=False, defer=True)
+    with pytest.raises(ActivationRangeError, match="repeat them"):
+        eng2.check_deferred()
+    assert eng2.get_option("gemm_h2") == 0
+    again = eng2.eval(*args, forces=True)
+    assert torch.equal(again["energy"], ref["energy"])

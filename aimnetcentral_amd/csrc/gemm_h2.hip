@@ -26,13 +26,13 @@
 namespace aimnet {
 
 constexpr int h2_passes(int rows) { return (rows + 31) / 32; }  // DMA wave-instructions per wave of the issuing group (a pass = 4 KiB = 2 strips)
-constexpr int h2_lds_bytes(int TM, int TN, int sched) { return (sched == 1 ? 3 : 2) * h2_passes(TM) * 4096 + 3 * h2_passes(TN) * 4096; }
+constexpr int h2_lds_bytes(int TM, int TN) { return 2 * h2_passes(TM) * 4096 + 3 * h2_passes(TN) * 4096; }
 
 #ifdef AIMNET_BF3_TIMING
 __device__ unsigned long long g_h2_stamps[1024];
 #endif
 
-template <int EPI, int SM, int SN, int WN, bool OUT3, int SCHED>
+template <int EPI, int SM, int SN, int WN, bool OUT3>
 __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* __restrict__ A3, int lda3,
                                                            const unsigned short* __restrict__ Bt, int ldb, int M, int N, int K,
                                                            const float* __restrict__ bias, float* __restrict__ C,
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
       for (int j = 0; j < SN; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_a;
-  constexpr int NSA = SCHED == 1 ? 3 : 2, NSB = 3;  // ring depths
+  constexpr int NSA = 2;  // activation ring depth (weights: 3)
   const unsigned ldsB = lds0 + NSA * SA_BYTES;
 
   // DMA of the issuing group: pass p, wave w4 -> KiB q = 4 p + w4 of the stage = plane q & 1 of the 16-row strip q >> 1; lane ->
@@ -141,95 +141,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
   _Pragma("unroll") for (int i = 0; i < SM; ++i) _Pragma("unroll") for (int jj = 0; jj < SN; ++jj) acc[SET][i][jj] = \
       __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[jj][PB], fa[i][PA], acc[SET][i][jj], 0, 0, 0);
   TS();
-  if constexpr (SCHED == 1) {
-    // ---- one instruction stream per wave (AIMNET_H2_SCHED=1): every wave runs  [10 MFMAs | reads]  x 3  per k-step, fetching the
-    // fragments of step j+1 into the registers the products of step j have just released (fb.lo after the first cross product,
-    // fa.hi after the hi x hi product, fa.lo / fb.hi after the second cross product), ONE barrier per step.  The two waves of a
-    // SIMD are not held in opposite phases: whichever has operands feeds the matrix pipe, so its 60 instructions per step are
-    // the only serial resource (the alternating LOAD / COMPUTE segments left it idle for a third of every step:
-    // profiles/r5_gemm_h2.md).  Tiles: three ring stages each; tile j+3 is requested in step j (its stage held tile j, whose
-    // fragments every wave fetched before the barrier that ended step j-1), tile j+2 is waited for at the end of step j by the
-    // waves that requested it, in front of the barrier that publishes it.  Waves 0-3 request activations, waves 4-7 weights.
-    auto dma_tile = [&](int stage, int kt) __attribute__((always_inline)) {
-      if (!late) dma_a(stage, kt, PZ{}, PAE{});
-      else dma_b(stage, kt, PZ{}, PBE{});
-    };
-    auto wait_own = [&]() __attribute__((always_inline)) {  // all but the newest tile this wave requested have landed
-      if (!late) wait_vm<NPA>();
-      else wait_vm<NPB>();
-    };
-    dma_tile(0, 0);
-    dma_tile(1, kc(1));
-    dma_tile(2, kc(2));
-    wait_own();  // tiles 0 and 1
-    __builtin_amdgcn_sched_barrier(0);
-    TS();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    read_strips_h<0, SN, 1>(fb, adB);
-    read_strips_h<0, SM, 0>(fa, adA);
-    read_strips_h<0, SN, 0>(fb, adB);
-    read_strips_h<0, SM, 1>(fa, adA);
-    wait_lgkm<0>();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();  // every wave holds the fragments of tile 0: its stage may receive tile 3
-    __builtin_amdgcn_sched_barrier(0);
-    TS();
-    // s1: stage of tile j+1 (read in this step); s0: stage of tile j = of tile j+3 (requested in this step)
-    // LAST: the step after which nothing follows - no fragment reads.  (Reads whose results are statically dead must not be
-    // issued at all: the compiler counts an asm load's destination as written at the statement and hands the registers of a
-    // dead value to the next instruction that needs some - here the DMA addresses - while the LDS data is still on its way.)
-    auto body = [&](int j, int s0, int s1, auto par_c, auto last_c) __attribute__((always_inline)) {
-      constexpr int PAR = decltype(par_c)::value;  // parity of the k-step = accumulator set of the hi x hi products
-      constexpr bool LAST = decltype(last_c)::value != 0;
-      const unsigned oa = adA + s1 * SA_BYTES, ob = adB + s1 * SB_BYTES;
-      __builtin_amdgcn_sched_barrier(0);
-      AIMNET_H2_PRODUCT(2, 0, 1)
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!LAST) read_strips_h<0, SN, 1>(fb, ob);
-      __builtin_amdgcn_sched_barrier(0);
-      AIMNET_H2_PRODUCT(PAR, 0, 0)
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!LAST) {
-        read_strips_h<0, SM, 0>(fa, oa);
-#if defined(AIMNET_H2_PROBE) && (AIMNET_H2_PROBE & 4)
-        // measurement only (wrong results): the tile requests of the loop dropped - bit 0 the activation tiles, bit 1 the weight tiles
-        if (!((AIMNET_H2_PROBE & 1) && !late) && !((AIMNET_H2_PROBE & 2) && late)) dma_tile(s0, kc(j + 3));
-#else
-        dma_tile(s0, kc(j + 3));
-#endif
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      AIMNET_H2_PRODUCT(2, 1, 0)
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!LAST) {
-        read_strips_h<0, SN, 0>(fb, ob);
-        read_strips_h<0, SM, 1>(fa, oa);
-        wait_own();  // tile j+2
-        wait_lgkm<0>();
-        __builtin_amdgcn_sched_barrier(0);
-        TS();
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      TS();
-    };
-    int s0 = 0, s1 = 1, j = 0;
-    auto next = [&]() __attribute__((always_inline)) {
-      s0 = s1;
-      s1 = s1 == 2 ? 0 : s1 + 1;
-    };
-    // (an even number of steps ends inside the loop: the fragments its last step fetches are dead only dynamically - they keep
-    // their registers - and the wave waits for them before it leaves the loop)
-    for (; j + 1 < nk; j += 2) {
-      body(j, s0, s1, I0{}, I0{});
-      next();
-      body(j + 1, s0, s1, I1{}, I0{});
-      next();
-    }
-    if (j < nk) body(j, s0, s1, I0{}, I1{});
-  } else {
-  // ---- ping-pong (the default; the schedule of gemm_bf3a.hip): prologue A(0) by group 0; B(0), B(1) by group 1
+  // ---- prologue: A(0) by group 0; B(0), B(1) by group 1
   if (!late) {
     dma_a(0, 0, PZ{}, PAE{});
     wait_vm<0>();
@@ -307,7 +219,6 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
   } else {
     run(I0{});
     bar();  // group 0 has 2 nk segments, group 1 an empty one in front: both pass 2 nk barriers
-  }
   }
 #undef AIMNET_H2_PRODUCT
   wait_vm<0>();  // the clamped look-ahead of the last steps: the wave must not end (LDS released) under its DMA
@@ -387,28 +298,25 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
 #endif
 }
 
-// AIMNET_H2_SCHED=1: one instruction stream per wave instead of the ping-pong of gemm_bf3a.hip.  Measured EQUAL (step 1.3452 vs
-// 1.3456 ms, profiles/r5_gemm_h2.md): with the tile requests dropped altogether a k-step still takes ~1 450 cycles - 60 matrix
-// instructions per SIMD at the 16x16x32 shape's own rate (19.4 cycles: 2 075 of 2 500 TFLOP/s in MI355X_MICROARCH.md's table) are
-// 1 164 of them; neither schedule has much left to hide.  The ping-pong keeps 88 instead of 108 KiB of LDS and is the default.
-static int g_h2_sched = 0;
-
-template <int SM, int SN, int WN, int SCHED>
+// (A one-instruction-stream-per-wave schedule - fragments of step j+1 fetched into the registers step j's products release, one
+// barrier per step - was built and measured EQUAL, step 1.3452 vs 1.3456 ms: 60 matrix instructions per SIMD and step at the
+// 16x16x32 shape's own rate are 1 164 of the ~1 500 cycles either schedule takes; profiles/r5_gemm_h2.md.  Removed; commit d9e6536.)
+template <int SM, int SN, int WN>
 static int launch_h2(hipStream_t stream, int epi, bool out3, const unsigned short* A3, int lda3, const unsigned short* Bt, int ldb,
                        int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
                        const int* brow, int ldbias, int alt) {
   constexpr int WM = 8 / WN, TM = 16 * SM * WM, TN = 16 * SN * WN;
   const int tiles = ceil_div(M, TM) * ceil_div(N, TN);
-  constexpr size_t lds = (size_t)h2_lds_bytes(TM, TN, SCHED);
+  constexpr size_t lds = (size_t)h2_lds_bytes(TM, TN);
   static_assert(lds <= 160 * 1024, "LDS");
   dim3 grid(tiles), block(512);
 #define AIMNET_H2_LAUNCH(E, O3)                                                                                            \
   {                                                                                                                          \
     static PerDeviceOnce once;                                                                                               \
     if (once.first())                                                                                                        \
-      AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_h2_kernel<E, SM, SN, WN, O3, SCHED>,                                \
+      AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_h2_kernel<E, SM, SN, WN, O3>,                                \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
-    hipLaunchKernelGGL((gemm_h2_kernel<E, SM, SN, WN, O3, SCHED>), grid, block, lds, stream, A3, lda3, Bt, ldb, M, N, K, bias, C, \
+    hipLaunchKernelGGL((gemm_h2_kernel<E, SM, SN, WN, O3>), grid, block, lds, stream, A3, lda3, Bt, ldb, M, N, K, bias, C, \
                        C3, ldc3, D, ldc, brow, ldbias, alt);                                                                \
   }
   if (out3) {
@@ -468,11 +376,8 @@ int launch_gemm_h2_cfg(hipStream_t stream, int cfg, int epi, bool out3, const un
   if (cfg == 0) cfg = choose_h2_tile(M, N);
   switch (cfg) {
 #define AIMNET_H2_CASE(ID, SM_, SN_, WN_)                                                                                    \
-    case ID:                                                                                                                   \
-      return g_h2_sched ? launch_h2<SM_, SN_, WN_, 1>(stream, epi, out3, A3, lda3, Bt, ldb, M, N, K, bias, C, C3, ldc3, D, ldc, brow, \
-                                                         ldbias, alt)                                                          \
-                        : launch_h2<SM_, SN_, WN_, 0>(stream, epi, out3, A3, lda3, Bt, ldb, M, N, K, bias, C, C3, ldc3, D, ldc,   \
-                                                          brow, ldbias, alt);
+    case ID: return launch_h2<SM_, SN_, WN_>(stream, epi, out3, A3, lda3, Bt, ldb, M, N, K, bias, C, C3, ldc3, D, ldc, brow, \
+                                             ldbias, alt);
     AIMNET_H2_CASE(452, 5, 2, 4)  // 160 x 128 (2 x 4 waves of 80 x 32; 136 KiB of LDS)
     AIMNET_H2_CASE(432, 3, 2, 4)  //  96 x 128
     AIMNET_H2_CASE(422, 2, 2, 4)  //  64 x 128
@@ -561,8 +466,6 @@ bool split_h2_host(const float* w, int rows, int K, unsigned short* out, int mod
 int gemm_h2_set_attributes() {
   const char* env = getenv("AIMNET_H2_TILE");
   g_h2_force_tile = env ? atoi(env) : 0;
-  env = getenv("AIMNET_H2_SCHED");
-  g_h2_sched = env ? atoi(env) : 0;
   return 0;
 }
 

@@ -11,7 +11,6 @@ python bench.py > gpurun_out/r5/bench.json 2> gpurun_out/r5/bench.err
 rm -f gpurun_out/r5/bench_other_workloads.jsonl
 for w in batch256 md1024 taxol; do python bench.py --workload $w --no-hessian 2>/dev/null | tail -1 >> gpurun_out/r5/bench_other_workloads.jsonl; done
 bash tests/tools/ab_env.sh AIMNET_GEMM_H2=0 --no-exact-f32 --no-hessian --no-repeat > gpurun_out/r5/h2_ab.txt 2>&1
-bash tests/tools/ab_env.sh AIMNET_H2_SCHED=1 --no-exact-f32 --no-hessian --no-repeat > gpurun_out/r5/h2_sched_ab.txt 2>&1
 python tests/tools/md_throughput.py 2>/dev/null | tail -1 > gpurun_out/r5/md_throughput.json
 python tests/tools/h2_bench.py 2>&1 | grep -v amdgpu > gpurun_out/r5/gemm_h2_shapes_gelu.txt
 EPI=3 python tests/tools/h2_bench.py 2>&1 | grep -v amdgpu > gpurun_out/r5/gemm_h2_shapes_mul.txt

@@ -11,9 +11,9 @@ import os
 from functools import lru_cache
 
 MAX_PASS, MAX_LAYERS, MAX_SHIFTS = 4, 6, 32
-ABI_VERSION = 9  # AIMNET_ABI_VERSION of include/aimnet_hip.h this binding was written against
+ABI_VERSION = 10  # AIMNET_ABI_VERSION of include/aimnet_hip.h this binding was written against
 FORCES, STRESS = 1, 2
-COULOMB_NONE, COULOMB_SIMPLE, COULOMB_DSF, COULOMB_EWALD = 0, 1, 2, 3
+COULOMB_NONE, COULOMB_SIMPLE, COULOMB_DSF, COULOMB_EWALD, COULOMB_PME = 0, 1, 2, 3, 4
 E_INVALID, E_HIP, E_WORKSPACE = -1, -2, -3
 PROF_FAMILIES = ("nlist", "geom", "conv_fwd", "gemm", "pointwise", "coulomb", "unconcat", "conv_bwd", "other")
 
@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = (
     "aimnet_debug_gemm_bf3a",
     "aimnet_debug_split_h2",
     "aimnet_debug_gemm_h2",
+    "aimnet_debug_pme_recip",
     "aimnet_debug_mfma4_probe",
     "aimnet_engine_set_option",
     "aimnet_engine_get_option",
@@ -133,6 +134,7 @@ class EvalOptions(C.Structure):
         ("max_nb_d3", C.c_int32),
         ("ewald_accuracy", C.c_float),
         ("ewald_max_k", C.c_int32),
+        ("pme_max_mesh", C.c_int32),
     ]
 
 
@@ -220,6 +222,8 @@ def load() -> C.CDLL:
     lib.aimnet_debug_split_h2.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
     lib.aimnet_debug_gemm_h2.restype = C.c_int
     lib.aimnet_debug_gemm_h2.argtypes = list(lib.aimnet_debug_gemm_bf3a.argtypes)
+    lib.aimnet_debug_pme_recip.restype = C.c_int
+    lib.aimnet_debug_pme_recip.argtypes = [vp, vp, vp, C.c_float, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, C.POINTER(C.c_double), vp]
     lib.aimnet_debug_mfma4_probe.restype = C.c_int
     lib.aimnet_debug_mfma4_probe.argtypes = [vp, vp]
     lib.aimnet_neighbor_list_workspace_bytes.restype = sz

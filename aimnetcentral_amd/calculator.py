@@ -275,16 +275,11 @@ class AIMNet2Calculator:
         elif method in ("ewald", "pme"):
             # calculator.py:704-720: `cutoff` is ignored, the real- and reciprocal-space cutoffs follow from the accuracy per call
             # (eta = (V^2 / N)^(1/6) / sqrt(2 pi), rc = sqrt(-2 ln acc) eta, kc = sqrt(-2 ln acc) / eta, calculator.py:660-667 - on the
-            # device, csrc/ewald.hip).  "pme" requests are served by the same exact structure-factor sum (no mesh): the same energy
-            # to the requested accuracy.
+            # device, csrc/ewald.hip).  "pme": the same splitting with the real-space cutoff capped at 10 A and the reciprocal sum on
+            # an order-8 B-spline mesh sized from the accuracy (csrc/pme.hip; the reference's estimate_pme_parameters lives in the
+            # un-vendored nvalchemiops, so the mesh rule is this engine's own, calibrated against the exact sum).
             self._ewald_accuracy = float(ewald_accuracy)
             self._coulomb_cutoff = None
-            if method == "pme":
-                # honesty about the one unbuilt piece (aimnet/modules/lr.py:752, calculator.py:1566-1586): no particle mesh here
-                warnings.warn("set_lrcoulomb_method('pme'): this engine has no particle-mesh kernel; the request is served by the "
-                              "exact Ewald structure-factor sum at the same accuracy (O(N*K) instead of O(N log N): equal energies, "
-                              "slower above ~1e5 atoms).  PME mesh parameters (mesh spacing / spline order) do not apply and are ignored.",
-                              UserWarning, stacklevel=2)
         else:
             self._coulomb_cutoff = float("inf")
         if self._coulomb_cutoff is not None:

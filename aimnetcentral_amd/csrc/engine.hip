@@ -263,11 +263,20 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
     W.d3xs = c.take<float4>(d3 ? n : 0);
   }
   {
+    const bool pme = opt->coulomb == AIMNET_COULOMB_PME;
     const bool ew = opt->coulomb == AIMNET_COULOMB_EWALD;
     W.ew.max_k = ew ? std::max(EWALD_KB, opt->ewald_max_k / EWALD_KB * EWALD_KB) : 0;
-    W.ew.sys = c.take<EwaldSystem>(ew ? (size_t)n_mol : 0);
-    W.ew.frac = c.take<double>(ew ? n * 3 : 0);
+    W.ew.sys = c.take<EwaldSystem>(ew || pme ? (size_t)n_mol : 0);
+    W.ew.frac = c.take<double>(ew || pme ? n * 3 : 0);
     W.ew.k = c.take<EwaldK>(ew ? (size_t)W.ew.max_k : 0);
+    W.ew.max_mesh = pme ? std::max(512, opt->pme_max_mesh) : 0;
+    W.ew.max_parts = pme ? ceil_div(W.ew.max_mesh, PME_PART) : 0;
+    const size_t mesh_all = (size_t)W.ew.max_mesh * (pme ? (size_t)n_mol : 0);
+    W.ew.meshq = c.take<long long>(mesh_all);
+    W.ew.ma = c.take<double>(2 * mesh_all);
+    W.ew.mb = c.take<double>(2 * mesh_all);
+    W.ew.bmod = c.take<double>(pme ? (size_t)n_mol * 3 * PME_MAX_AXIS : 0);
+    W.ew.vpart = c.take<double>(pme ? (size_t)n_mol * W.ew.max_parts * 8 : 0);
   }
   W.pg = c.take<float4>(n * cap, "pair_geom", cap);
   char name[32];
@@ -722,7 +731,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     set_last_error("eval: 'simple' Coulomb is undefined for periodic input (host must switch to DSF, calculator.py:1044)");
     return AIMNET_E_INVALID;
   }
-  if (coulomb == AIMNET_COULOMB_EWALD) {
+  if (coulomb == AIMNET_COULOMB_EWALD || coulomb == AIMNET_COULOMB_PME) {
     if (!pbc || in->pbc_sys || !(in->pbc[0] && in->pbc[1] && in->pbc[2])) {
       set_last_error("eval: Ewald summation needs a cell that is periodic along all three axes (lr.py:655-657)");
       return AIMNET_E_INVALID;
@@ -732,8 +741,9 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
                      "(the reference builds its own per-call list for this method too, calculator.py:1560-1603)");
       return AIMNET_E_INVALID;
     }
-    if (!(opt->ewald_accuracy > 0.0f && opt->ewald_accuracy < 1.0f) || opt->ewald_max_k < EWALD_KB) {
-      set_last_error("eval: Ewald summation needs 0 < ewald_accuracy < 1 and ewald_max_k >= %d", EWALD_KB);
+    if (!(opt->ewald_accuracy > 0.0f && opt->ewald_accuracy < 1.0f) ||
+        (coulomb == AIMNET_COULOMB_EWALD ? opt->ewald_max_k < EWALD_KB : opt->pme_max_mesh < 512)) {
+      set_last_error("eval: Ewald summation needs 0 < ewald_accuracy < 1 and ewald_max_k >= %d (PME: pme_max_mesh >= 512)", EWALD_KB);
       return AIMNET_E_INVALID;
     }
   }
@@ -919,8 +929,13 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     cp.sr_envelope = ar.sr_envelope;
     cp.dsf_rc = opt->dsf_rc;
     cp.dsf_alpha = opt->dsf_alpha;
-    const bool ewald = coulomb == AIMNET_COULOMB_EWALD;
-    if (ewald) {  // per-system (alpha, rc, kc) and k boxes from the cell, fractional coordinates in double (ewald.hip)
+    const bool pme = coulomb == AIMNET_COULOMB_PME;
+    const bool ewald = coulomb == AIMNET_COULOMB_EWALD || pme;  // (the real-space walk and the self term are the same)
+    if (pme) {  // per-system (alpha, rc, mesh) from the cell, fractional coordinates in double (pme.hip)
+      RC(launch_pme_setup(cs, in->cell, n_cell, W.nl.mol_start, mol_c, W.nl.xw, in->charge, nq, N, n_mol, opt->ewald_accuracy, W.ew,
+                          out->status + 7));
+      cp.ewald = W.ew.sys;
+    } else if (ewald) {  // per-system (alpha, rc, kc) and k boxes from the cell, fractional coordinates in double (ewald.hip)
       RC(launch_ewald_setup(cs, in->cell, n_cell, W.nl.mol_start, mol_c, W.nl.xw, in->charge, nq, N, n_mol, opt->ewald_accuracy, W.ew,
                             out->status + 7));
       cp.ewald = W.ew.sys;
@@ -970,7 +985,10 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
                                  out->charges, true, rev_done ? nullptr : &pmap));
       rev_done = true;
       charges_written = true;
-      if (ewald)  // reciprocal space + neutralising background, accumulated onto what the pair kernels have stored
+      if (pme)  // reciprocal space on the mesh + neutralising background (pme.hip)
+        RC(launch_pme_recip(cs, grad, want_s, q_fin, mol_c, W.nl.mol_start, N, n_mol, W.ew, cp.factor, W.ecoul, W.qbar, W.fgrad,
+                            W.virial_atom));
+      else if (ewald)  // reciprocal space + neutralising background, accumulated onto what the pair kernels have stored
         RC(launch_ewald_recip(cs, grad, want_s, q_fin, mol_c, W.nl.mol_start, N, n_mol, W.ew, cp.factor, W.ecoul, W.qbar, W.fgrad,
                               W.virial_atom));
     } else if (coulomb == AIMNET_COULOMB_DSF)
@@ -1362,6 +1380,58 @@ int aimnet_debug_bf3a_stamps(unsigned long long* host1024) { return aimnet::gemm
 int aimnet_debug_h2_stamps(unsigned long long* host1024) { return aimnet::gemm_h2_read_stamps(host1024); }
 int aimnet_debug_bf3_stamps(unsigned long long* host1024) { return aimnet::gemm_bf3_read_stamps(host1024); }
 #endif
+
+int aimnet_debug_pme_recip(const float* xw, const float* q, const float* cell, float total_charge, int n_atoms, float accuracy,
+                           int max_mesh, double* e_atom, float* qbar, float* fgrad, float* virial_atom, double* host_info,
+                           void* hip_stream) {
+  using namespace aimnet;
+  if (!xw || !q || !cell || !e_atom || !qbar || !fgrad || !virial_atom || !host_info || n_atoms <= 0 || max_mesh < 512)
+    return AIMNET_E_INVALID;
+  hipStream_t st = (hipStream_t)hip_stream;
+  EwaldBuffers b{};
+  b.max_mesh = max_mesh;
+  b.max_parts = ceil_div(max_mesh, PME_PART);
+  int *mol_idx = nullptr, *mol_start = nullptr, *status = nullptr;
+  float* charge = nullptr;
+  const int ms[2] = {0, n_atoms};
+  int rc = 0;
+#define PME_DBG(x)            \
+  if ((x) != hipSuccess) {    \
+    rc = AIMNET_E_HIP;        \
+    goto done;                \
+  }
+  PME_DBG(hipMalloc(&b.sys, sizeof(EwaldSystem)));
+  PME_DBG(hipMalloc(&b.frac, sizeof(double) * 3 * n_atoms));
+  PME_DBG(hipMalloc(&b.meshq, sizeof(long long) * (size_t)max_mesh));
+  PME_DBG(hipMalloc(&b.ma, sizeof(double) * 2 * (size_t)max_mesh));
+  PME_DBG(hipMalloc(&b.mb, sizeof(double) * 2 * (size_t)max_mesh));
+  PME_DBG(hipMalloc(&b.bmod, sizeof(double) * 3 * PME_MAX_AXIS));
+  PME_DBG(hipMalloc(&b.vpart, sizeof(double) * 8 * (size_t)b.max_parts));
+  PME_DBG(hipMalloc(&mol_idx, sizeof(int) * n_atoms));
+  PME_DBG(hipMalloc(&mol_start, sizeof(int) * 2));
+  PME_DBG(hipMalloc(&status, sizeof(int)));
+  PME_DBG(hipMalloc(&charge, sizeof(float)));
+  PME_DBG(hipMemsetAsync(mol_idx, 0, sizeof(int) * n_atoms, st));
+  PME_DBG(hipMemcpyAsync(mol_start, ms, sizeof(ms), hipMemcpyHostToDevice, st));
+  PME_DBG(hipMemcpyAsync(charge, &total_charge, sizeof(float), hipMemcpyHostToDevice, st));
+  rc = launch_pme_setup(st, cell, 1, mol_start, mol_idx, xw, charge, 1, n_atoms, 1, accuracy, b, status);
+  if (!rc) rc = launch_pme_recip(st, true, true, q, mol_idx, mol_start, n_atoms, 1, b, 1.0f, e_atom, qbar, fgrad, virial_atom);
+  if (!rc) {
+    EwaldSystem E;
+    int need = 0;
+    PME_DBG(hipMemcpyAsync(&E, b.sys, sizeof(E), hipMemcpyDeviceToHost, st));
+    PME_DBG(hipMemcpyAsync(&need, status, sizeof(int), hipMemcpyDeviceToHost, st));
+    PME_DBG(hipStreamSynchronize(st));
+    host_info[0] = E.alpha; host_info[1] = E.rc; host_info[2] = E.mesh[0]; host_info[3] = E.mesh[1]; host_info[4] = E.mesh[2];
+    host_info[5] = need; host_info[6] = E.phi_bg; host_info[7] = 0.0;
+  }
+done:
+#undef PME_DBG
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(b.sys); (void)hipFree(b.frac); (void)hipFree(b.meshq); (void)hipFree(b.ma); (void)hipFree(b.mb); (void)hipFree(b.bmod);
+  (void)hipFree(b.vpart); (void)hipFree(mol_idx); (void)hipFree(mol_start); (void)hipFree(status); (void)hipFree(charge);
+  return rc;
+}
 
 int aimnet_debug_mfma4_probe(float* out, void* hip_stream) {
   if (!out) return AIMNET_E_INVALID;

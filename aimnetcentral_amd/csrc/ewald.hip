@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "ewald_common.h"
 #include "kernels.h"
 
 namespace aimnet {
@@ -38,19 +39,8 @@ __global__ void ewald_setup_kernel(const float* __restrict__ cell, int n_cell, c
   for (int s = threadIdx.x; s < n_mol; s += blockDim.x) {
     const float* c = cell + (n_cell == 1 ? 0 : (size_t)s * 9);
     double m[9];
-    for (int k = 0; k < 9; ++k) m[k] = c[k];
-    const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
-    const double id = 1.0 / det;
     EwaldSystem E;
-    E.inv[0] = (m[4] * m[8] - m[5] * m[7]) * id;
-    E.inv[1] = (m[2] * m[7] - m[1] * m[8]) * id;
-    E.inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-    E.inv[3] = (m[5] * m[6] - m[3] * m[8]) * id;
-    E.inv[4] = (m[0] * m[8] - m[2] * m[6]) * id;
-    E.inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-    E.inv[6] = (m[3] * m[7] - m[4] * m[6]) * id;
-    E.inv[7] = (m[1] * m[6] - m[0] * m[7]) * id;
-    E.inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    const double det = ewald_cell_geometry(c, m, E);
     const double vol = fabs(det);
     const int ns = max(1, mol_start[s + 1] - mol_start[s]);
     const double eta = cbrt(sqrt(vol * vol / (double)ns)) / sqrt(EW_TWO_PI);
@@ -275,6 +265,10 @@ int launch_ewald_setup(hipStream_t s, const float* cell, int n_cell, const int* 
   hipLaunchKernelGGL(ewald_setup_kernel, dim3(1), dim3(256), 0, s, cell, n_cell, mol_start, charge, nq, n_mol, accuracy, b.max_k, b.sys,
                      status_k);
   AIMNET_LAUNCH_CHECK();
+  return launch_ewald_frac(s, xw, mol_idx, n_atoms, b);
+}
+
+int launch_ewald_frac(hipStream_t s, const float* xw, const int* mol_idx, int n_atoms, const EwaldBuffers& b) {
   hipLaunchKernelGGL(ewald_frac_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, xw, mol_idx, n_atoms, b.sys, b.frac);
   AIMNET_LAUNCH_CHECK();
   return 0;

@@ -1108,7 +1108,7 @@ int aimnet_engine_hvp(aimnet_engine* e, const aimnet_inputs* in, const aimnet_ev
     set_last_error("hvp: DSF Coulomb needs max_nb_lr > 0 (the tangent sweep runs on the neighbour list, also for periodic input)");
     return AIMNET_E_INVALID;
   }
-  if (coulomb == AIMNET_COULOMB_EWALD) {
+  if (coulomb == AIMNET_COULOMB_EWALD || coulomb == AIMNET_COULOMB_PME) {
     set_last_error("hvp: the analytic tangent sweep does not cover Ewald summation (use DSF, or differences of forces as the reference "
                    "does for its PME block, lr.py:903-926)");
     return AIMNET_E_INVALID;

@@ -260,6 +260,8 @@ struct EwaldSystem {   // per periodic system, written by ewald_setup_kernel fro
   double pref;         // 8 pi / V (the potential's prefactor, half space doubled)
   double b[9];         // k_c = sum_a n_a b[a * 3 + c]
   double inv[9];       // fractional coordinate a = sum_c x_c inv[c * 3 + a]
+  int mesh[3];         // pme.hip: mesh points along the three cell vectors (0: this system's mesh did not fit the capacity)
+  int mesh_pts;        // mesh[0] mesh[1] mesh[2]
 };
 struct EwaldK {        // one entry of the k box (P = Q = 0: outside the half-space sphere)
   double P, Q;         // A(k) Re S(k), A(k) Im S(k);  A = pref exp(-k^2 / 4 alpha^2) / k^2
@@ -272,10 +274,28 @@ struct EwaldBuffers {  // device pointers carved from the workspace
   double* frac;        // [n_atoms][3] fractional coordinates in double
   EwaldK* k;           // [max_k]
   int max_k;
+  // pme.hip (AIMNET_COULOMB_PME): per system a slice of max_mesh points
+  long long* meshq;    // [n_mol][max_mesh] charge mesh in 2^-44 fixed point (integer atomics: order-independent sums), later the
+                       // potential mesh as doubles
+  double* ma;          // [n_mol][max_mesh][2] complex work meshes (ping-pong of the axis transforms)
+  double* mb;
+  double* bmod;        // [n_mol][3][PME_MAX_AXIS] inverse squared moduli of the spline's Fourier coefficients
+  double* vpart;       // [n_mol][max_parts][8] per-block sums of theta |Q^|^2 (k_a k_b vfac, 1)
+  int max_mesh, max_parts;
 };
+constexpr int PME_MAX_AXIS = 512;   // mesh points per axis at most (direct axis transforms in LDS)
+constexpr int PME_PART = 1024;      // mesh points per block of the influence-function kernel
 // parameters + k boxes of every system; *status_k = k entries the batch needs (> max_k: the boxes were truncated, results meaningless)
 int launch_ewald_setup(hipStream_t s, const float* cell, int n_cell, const int* mol_start, const int* mol_idx, const float* xw,
                        const float* charge, int nq, int n_atoms, int n_mol, float accuracy, EwaldBuffers& b, int* status_k);
+int launch_ewald_frac(hipStream_t s, const float* xw, const int* mol_idx, int n_atoms, const EwaldBuffers& b);
+// ---- pme.hip: smooth particle-mesh Ewald (LRCoulomb "pme", lr.py:752-775): the reciprocal-space sum on a mesh --------------
+// per-system (alpha, rc, mesh) + fractional coordinates; *status = mesh points the largest system needs (> max_mesh: its mesh
+// was skipped, results meaningless; INT32_MAX: an axis beyond PME_MAX_AXIS)
+int launch_pme_setup(hipStream_t s, const float* cell, int n_cell, const int* mol_start, const int* mol_idx, const float* xw,
+                     const float* charge, int nq, int n_atoms, int n_mol, float accuracy, EwaldBuffers& b, int* status);
+int launch_pme_recip(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, const int* mol_start, int n_atoms,
+                     int n_mol, const EwaldBuffers& b, float factor, double* ecoul, float* qbar, float* fgrad, float* virial_atom);
 // reciprocal-space sum + neutralising background, ACCUMULATED onto the per-atom energies / adjoints the pair kernels have stored
 int launch_ewald_recip(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, const int* mol_start, int n_atoms,
                        int n_mol, const EwaldBuffers& b, float factor, double* ecoul, float* qbar, float* fgrad, float* virial_atom);

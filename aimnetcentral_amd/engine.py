@@ -137,6 +137,8 @@ class HipEngine:
         self.last_status: np.ndarray | None = None
         self.has_dftd3 = False
         self._ewald_max_k = 8192  # capacity of the Ewald k arrays (entries; grows to what status[7] reports)
+        self._pme_max_mesh = 32768  # capacity of one system's PME mesh (points; grows to what status[7] reports)
+        self._status7_pme = False  # what status[7] of the pending deferred evaluations counts (mesh points or k entries)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -179,6 +181,12 @@ class HipEngine:
             return max(16, _round16(int(actual_max / target_utilization)))
         return capacity
 
+    def _grow_pme_mesh(self, need: int) -> None:
+        if need >= 2**31 - 1:
+            raise ValueError("HipEngine: a cell vector of this system needs more than 512 PME mesh points (csrc/pme.hip PME_MAX_AXIS); "
+                             "use coulomb='dsf' or a looser ewald_accuracy")
+        self._pme_max_mesh = need * 9 // 8 + 64
+
     def check_deferred(self) -> None:
         """Synchronise once and verify the status words of every evaluation run with `sync=False, defer=True` since the last
         check: a device-resident MD driver calls this every K steps instead of paying one host read per step.  On a neighbour
@@ -207,7 +215,11 @@ class HipEngine:
             for rc in list(self._max_nb_lr):
                 self._max_nb_lr[rc] = _round16(int(max(self._max_nb_lr[rc] * 1.5, st[:, 1].max(), st[:, 4].max())))
             grown = True
-        if st[:, 7].max() > self._ewald_max_k:  # Ewald k arrays (status[7] is 0 for the other methods)
+        if self._status7_pme:
+            if st[:, 7].max() > self._pme_max_mesh:  # PME mesh of the largest system
+                self._grow_pme_mesh(int(st[:, 7].max()))
+                grown = True
+        elif st[:, 7].max() > self._ewald_max_k:  # Ewald k arrays (status[7] is 0 for the other methods)
             self._ewald_max_k = (int(st[:, 7].max()) * 5 // 4 + 7) // 8 * 8
             grown = True
         if grown:
@@ -286,10 +298,12 @@ class HipEngine:
                 raise ValueError(f"pbc must have shape (3,) or ({n_cell}, 3), got {tuple(pbc_sys.shape)}")
         elif not isinstance(pbc, (tuple, list)):
             pbc = tuple(bool(x) for x in torch.as_tensor(pbc).reshape(-1).tolist())
-        # "pme" requests take the exact structure-factor sum too: the same energy to the requested accuracy (csrc/ewald.hip)
+        # "ewald": the exact structure-factor sum (csrc/ewald.hip); "pme": the same splitting with the reciprocal sum on a mesh
+        # (csrc/pme.hip)
         method = {"none": _lib.COULOMB_NONE, "simple": _lib.COULOMB_SIMPLE, "dsf": _lib.COULOMB_DSF, "ewald": _lib.COULOMB_EWALD,
-                  "pme": _lib.COULOMB_EWALD}[coulomb]
-        if method == _lib.COULOMB_EWALD:
+                  "pme": _lib.COULOMB_PME}[coulomb]
+        is_pme = method == _lib.COULOMB_PME
+        if method in (_lib.COULOMB_EWALD, _lib.COULOMB_PME):
             if cell is None:
                 raise ValueError(f"HipEngine.eval: coulomb={coulomb!r} needs a periodic cell (lr.py:655-657)")
             if nbmat is not None:
@@ -348,9 +362,10 @@ class HipEngine:
             opt.max_nb = self.max_nb
             # periodic DSF walks the cell grid (no list); only non-periodic DSF materialises a long-range list
             opt.max_nb_lr = self._lr_capacity(float(dsf_rc)) if (method == _lib.COULOMB_DSF and cell is None) else 0
-            if method == _lib.COULOMB_EWALD:
+            if method in (_lib.COULOMB_EWALD, _lib.COULOMB_PME):
                 opt.ewald_accuracy = float(ewald_accuracy)
                 opt.ewald_max_k = self._ewald_max_k
+                opt.pme_max_mesh = self._pme_max_mesh
             if ext:  # caller-supplied matrices: the row capacities are their widths (nothing can overflow)
                 opt.max_nb = _round16(ext["nbmat"][0].shape[1])
                 opt.max_nb_lr = _round16(ext["nbmat_lr"][0].shape[1]) if "nbmat_lr" in ext else 0
@@ -426,7 +441,8 @@ class HipEngine:
             if st[6]:  # input sanity flags raised by the engine (it clamps for memory safety, the results are meaningless)
                 raise ValueError("HipEngine.eval: invalid input: " + describe_input_flags(int(st[6]), n_mol))
             retry = False
-            rows_overflowed = bool(st[2] or st[3] or st[5] or (method == _lib.COULOMB_EWALD and st[7] > opt.ewald_max_k))
+            rows_overflowed = bool(st[2] or st[3] or st[5] or (method == _lib.COULOMB_EWALD and st[7] > opt.ewald_max_k) or
+                                   (is_pme and st[7] > opt.pme_max_mesh))
             if not finite and h2_on and not rows_overflowed:
                 # fp16x2-split GEMM operands (csrc/gemm_h2_common.h) hold |x| < 65504: an activation beyond that turns into inf / NaN
                 # and surfaces in the outputs.  Repeat the call with the bf16x3 operands (fp32's range); if THAT is finite the
@@ -454,6 +470,9 @@ class HipEngine:
             if method == _lib.COULOMB_EWALD and st[7] > opt.ewald_max_k:  # the k boxes did not fit: their size is now known
                 self._ewald_max_k = (int(st[7]) * 5 // 4 + 7) // 8 * 8
                 retry = True
+            if is_pme and st[7] > opt.pme_max_mesh:  # the mesh did not fit: its size is now known
+                self._grow_pme_mesh(int(st[7]))
+                retry = True
             if st[5]:  # D3 list (it may be stored in the LR buffers: grow both capacities)
                 d3_rc = float(dftd3.get("cutoff", 15.0))
                 self._max_nb_lr[d3_rc] = _round16(int(max(max(opt.max_nb_d3, opt.max_nb_lr) * 1.5, st[4])))
@@ -478,6 +497,7 @@ class HipEngine:
             res["status"] = status
             if defer:
                 self.pending_status.append(status)  # verified in one go by check_deferred()
+                self._status7_pme = is_pme
                 if h2_on:
                     self._pending_energy.append(energy)
         if spin is not None:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define AIMNET_ABI_VERSION 9
+#define AIMNET_ABI_VERSION 10
 
 #define AIMNET_OK 0
 #define AIMNET_E_INVALID (-1)   /* bad argument / unsupported architecture */
@@ -52,8 +52,10 @@ extern "C" {
 #define AIMNET_COULOMB_NONE 0
 #define AIMNET_COULOMB_SIMPLE 1 /* all pairs inside a molecule, lr.py:311-331 */
 #define AIMNET_COULOMB_DSF 2    /* damped shifted force, lr.py:559-615 */
-#define AIMNET_COULOMB_EWALD 3  /* Ewald summation of a fully periodic system, lr.py:617-720 (`ewald`; `pme` requests take the same
-                                   exact structure-factor sum): options.ewald_accuracy, options.ewald_max_k */
+#define AIMNET_COULOMB_EWALD 3  /* Ewald summation of a fully periodic system, lr.py:617-720 (`ewald`): the exact structure-factor
+                                   sum; options.ewald_accuracy, options.ewald_max_k */
+#define AIMNET_COULOMB_PME 4    /* smooth particle-mesh Ewald, lr.py:752-775 (`pme`): the reciprocal-space sum on a mesh (order-8
+                                   B-splines, csrc/pme.hip); options.ewald_accuracy, options.pme_max_mesh */
 
 /* Architecture of one AIMNet2 core model (aimnet/models/aimnet2.py:12-106 hyper-parameters). */
 typedef struct aimnet_arch {
@@ -147,6 +149,11 @@ typedef struct aimnet_eval_options {
    * truncated - evaluate again with at least that capacity. */
   float ewald_accuracy;
   int32_t ewald_max_k;
+  /* AIMNET_COULOMB_PME: capacity of the mesh of ONE system in points (every system of the batch gets a slice of that size; 40
+   * bytes per point).  The mesh dimensions follow from ewald_accuracy and the cell on the device; status[7] reports the points the
+   * largest system needs: > pme_max_mesh means its mesh was skipped - evaluate again with at least that capacity; INT32_MAX means
+   * a cell vector needs more than 512 mesh points (not supported). */
+  int32_t pme_max_mesh;
 } aimnet_eval_options;
 
 typedef struct aimnet_outputs {
@@ -162,7 +169,8 @@ typedef struct aimnet_outputs {
                                 or an unshifted self pair, bit 4 the caller-supplied short-range matrix is not symmetric.  The first kernel writes clamped copies (atomic number
                                 slots, mol_idx) into the workspace and every later kernel indexes through those, so any device
                                 array is memory-safe; with a flag raised the results are meaningless.
-                              7 Ewald: k-array entries the batch needs (compare with options.ewald_max_k; 0 for other methods) */
+                              7 Ewald: k-array entries the batch needs (compare with options.ewald_max_k); PME: mesh points the
+                                largest system needs (compare with options.pme_max_mesh); 0 for other methods */
   float* spin_charges; /* [n_atoms] alpha - beta of an NSE model (aimnet2.py:103), or NULL; must be NULL for 1-channel models */
 } aimnet_outputs;
 
@@ -303,6 +311,14 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
 
 /* Test hook: lane layout of v_mfma_f32_4x4x1_16B_f32 as the conv kernels assume it.  out: f32[64][4][64] (device),
  * out[lb][r][l] = VGPR r, lane l of D = A x B with A[l] = l + 1 and B = one-hot(lb), C = 0. */
+/* aimnet_debug_pme_recip (csrc/pme.hip): the reciprocal-space part of AIMNET_COULOMB_PME alone, for ONE system - what
+ * particle_mesh_ewald's mesh half computes (aimnet/modules/lr.py:752-775) - with unit prefactor: device xw [n][3] (any image of
+ * the atoms), q [n], cell [9] row vectors; ACCUMULATES onto device e_atom [n] (double: q_i phi_i), qbar [n] (2 phi_i), fgrad [n][3]
+ * (2 q_i grad phi_i), virial_atom [n][9] (per-atom shares of 2 dE/d eps; the mesh term on atom 0) - zero them first.  host_info[8]:
+ * alpha, rc, mesh[3], mesh points needed (> max_mesh: nothing was computed), phi_bg.  Allocates its own scratch; synchronises. */
+int aimnet_debug_pme_recip(const float* xw, const float* q, const float* cell, float total_charge, int n_atoms, float accuracy,
+                           int max_mesh, double* e_atom, float* qbar, float* fgrad, float* virial_atom, double* host_info,
+                           void* hip_stream);
 int aimnet_debug_mfma4_probe(float* out, void* hip_stream);
 
 /* Stand-alone neighbour list with the nvalchemiops contract.  nbmat [n_atoms, max_nb] int32 is

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/aimnet_hip.h but not exported"
     assert set(declared) == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.aimnet_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.aimnet_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_struct_layouts_match_header():
@@ -35,7 +35,7 @@ def test_struct_layouts_match_header():
 
     from aimnetcentral_amd import _lib
 
-    assert C.sizeof(_lib.EvalOptions) == 24 + 8 * 4 + 2 * 4  # + dftd3, s6, s8, a1, a2, cutoff, smoothing_on, max_nb_d3; + ewald_accuracy, ewald_max_k
+    assert C.sizeof(_lib.EvalOptions) == 24 + 8 * 4 + 3 * 4  # + dftd3, s6, s8, a1, a2, cutoff, smoothing_on, max_nb_d3; + ewald_accuracy, ewald_max_k, pme_max_mesh
     assert C.sizeof(_lib.DftD3Tables) == 8 + 4 * 8
     assert C.sizeof(_lib.Inputs) == 8 + 5 * 8 + 4 + 12 + 8 + 3 * 24  # + pbc_sys; + three optional caller-supplied matrices
     assert C.sizeof(_lib.Outputs) == 6 * 8      # + spin_charges

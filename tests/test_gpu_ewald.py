@@ -55,7 +55,8 @@ def test_two_systems_with_different_cells(hip_engine, oracle32, oracle64):
 
 
 def test_accuracy_parameter_moves_the_split_not_the_energy(hip_engine):
-    """Converged sums do not depend on the splitting: 1e-6 and 1e-9 agree to the looser accuracy; "pme" is served by the same sum."""
+    """Converged sums do not depend on the splitting: 1e-6 and 1e-9 agree to the looser accuracy; "pme" (the mesh, test_gpu_pme.py)
+    lands on the same energy to that accuracy."""
     g = golden("pbc96_dsf15")
     mol = np.zeros(96, dtype=np.int64)
     q = np.zeros(1, dtype=np.float32)
@@ -68,7 +69,7 @@ def test_accuracy_parameter_moves_the_split_not_the_energy(hip_engine):
     dev = hip_engine.device
     c = hip_engine.eval(torch.from_numpy(g["coord"]).to(dev), torch.from_numpy(g["numbers"]).to(dev), torch.from_numpy(mol).to(dev),
                         torch.from_numpy(q).to(dev), cell=torch.from_numpy(g["cell"]).to(dev), forces=True, stress=True, coulomb="pme")
-    assert c["energy"].cpu().numpy()[0] == a["energy"][0]
+    assert abs(c["energy"].cpu().numpy()[0] - a["energy"][0]) < 5e-5
 
 
 def test_supercell_vs_oracle_and_k_capacity(hip_engine, oracle32, oracle64):

@@ -149,8 +149,8 @@ def test_ewald_methods_need_a_cell_and_carry_their_accuracy(calc):
     calc(dict(WATER, cell=cell), forces=True)
     call = calc.engine.calls[-1]
     assert call["coulomb"] == "ewald" and call["ewald_accuracy"] == 1e-7
-    with pytest.warns(UserWarning, match="no particle-mesh kernel"):  # the one unbuilt piece says so
-        calc.set_lrcoulomb_method("pme")
+    calc.set_lrcoulomb_method("pme")  # served by the mesh kernels of csrc/pme.hip (round 5); no fixed cutoff either
+    assert calc.coulomb_method == "pme" and calc.coulomb_cutoff is None
     calc(dict(WATER, cell=cell))
     assert calc.engine.calls[-1]["coulomb"] == "pme" and calc.engine.calls[-1]["ewald_accuracy"] == 1e-6
     calc.set_lrcoulomb_method("simple")

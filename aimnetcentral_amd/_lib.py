@@ -223,7 +223,7 @@ def load() -> C.CDLL:
     lib.aimnet_debug_gemm_h2.restype = C.c_int
     lib.aimnet_debug_gemm_h2.argtypes = list(lib.aimnet_debug_gemm_bf3a.argtypes)
     lib.aimnet_debug_pme_recip.restype = C.c_int
-    lib.aimnet_debug_pme_recip.argtypes = [vp, vp, vp, C.c_float, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, C.POINTER(C.c_double), vp]
+    lib.aimnet_debug_pme_recip.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, C.POINTER(C.c_double), vp]
     lib.aimnet_debug_mfma4_probe.restype = C.c_int
     lib.aimnet_debug_mfma4_probe.argtypes = [vp, vp]
     lib.aimnet_neighbor_list_workspace_bytes.restype = sz

@@ -267,7 +267,7 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
     const bool ew = opt->coulomb == AIMNET_COULOMB_EWALD;
     W.ew.max_k = ew ? std::max(EWALD_KB, opt->ewald_max_k / EWALD_KB * EWALD_KB) : 0;
     W.ew.sys = c.take<EwaldSystem>(ew || pme ? (size_t)n_mol : 0);
-    W.ew.frac = c.take<double>(ew || pme ? n * 3 : 0);
+    W.ew.frac = c.take<double>(ew ? n * 3 : 0);
     W.ew.k = c.take<EwaldK>(ew ? (size_t)W.ew.max_k : 0);
     W.ew.max_mesh = pme ? std::max(512, opt->pme_max_mesh) : 0;
     W.ew.max_parts = pme ? ceil_div(W.ew.max_mesh, PME_PART) : 0;
@@ -932,8 +932,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const bool pme = coulomb == AIMNET_COULOMB_PME;
     const bool ewald = coulomb == AIMNET_COULOMB_EWALD || pme;  // (the real-space walk and the self term are the same)
     if (pme) {  // per-system (alpha, rc, mesh) from the cell, fractional coordinates in double (pme.hip)
-      RC(launch_pme_setup(cs, in->cell, n_cell, W.nl.mol_start, mol_c, W.nl.xw, in->charge, nq, N, n_mol, opt->ewald_accuracy, W.ew,
-                          out->status + 7));
+      RC(launch_pme_setup(cs, in->cell, n_cell, W.nl.mol_start, in->charge, nq, n_mol, opt->ewald_accuracy, W.ew, out->status + 7));
       cp.ewald = W.ew.sys;
     } else if (ewald) {  // per-system (alpha, rc, kc) and k boxes from the cell, fractional coordinates in double (ewald.hip)
       RC(launch_ewald_setup(cs, in->cell, n_cell, W.nl.mol_start, mol_c, W.nl.xw, in->charge, nq, N, n_mol, opt->ewald_accuracy, W.ew,
@@ -986,7 +985,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       rev_done = true;
       charges_written = true;
       if (pme)  // reciprocal space on the mesh + neutralising background (pme.hip)
-        RC(launch_pme_recip(cs, grad, want_s, q_fin, mol_c, W.nl.mol_start, N, n_mol, W.ew, cp.factor, W.ecoul, W.qbar, W.fgrad,
+        RC(launch_pme_recip(cs, grad, want_s, W.nl.xw, q_fin, mol_c, W.nl.mol_start, order, N, n_mol, W.ew, cp.factor, W.ecoul, W.qbar, W.fgrad,
                             W.virial_atom));
       else if (ewald)  // reciprocal space + neutralising background, accumulated onto what the pair kernels have stored
         RC(launch_ewald_recip(cs, grad, want_s, q_fin, mol_c, W.nl.mol_start, N, n_mol, W.ew, cp.factor, W.ecoul, W.qbar, W.fgrad,
@@ -1381,7 +1380,8 @@ int aimnet_debug_h2_stamps(unsigned long long* host1024) { return aimnet::gemm_h
 int aimnet_debug_bf3_stamps(unsigned long long* host1024) { return aimnet::gemm_bf3_read_stamps(host1024); }
 #endif
 
-int aimnet_debug_pme_recip(const float* xw, const float* q, const float* cell, float total_charge, int n_atoms, float accuracy,
+int aimnet_debug_pme_recip(const float* xw, const float* q, const int* order, const float* cell, float total_charge, int n_atoms,
+                           float accuracy,
                            int max_mesh, double* e_atom, float* qbar, float* fgrad, float* virial_atom, double* host_info,
                            void* hip_stream) {
   using namespace aimnet;
@@ -1401,7 +1401,6 @@ int aimnet_debug_pme_recip(const float* xw, const float* q, const float* cell, f
     goto done;                \
   }
   PME_DBG(hipMalloc(&b.sys, sizeof(EwaldSystem)));
-  PME_DBG(hipMalloc(&b.frac, sizeof(double) * 3 * n_atoms));
   PME_DBG(hipMalloc(&b.meshq, sizeof(long long) * (size_t)max_mesh));
   PME_DBG(hipMalloc(&b.ma, sizeof(double) * 2 * (size_t)max_mesh));
   PME_DBG(hipMalloc(&b.mb, sizeof(double) * 2 * (size_t)max_mesh));
@@ -1414,8 +1413,8 @@ int aimnet_debug_pme_recip(const float* xw, const float* q, const float* cell, f
   PME_DBG(hipMemsetAsync(mol_idx, 0, sizeof(int) * n_atoms, st));
   PME_DBG(hipMemcpyAsync(mol_start, ms, sizeof(ms), hipMemcpyHostToDevice, st));
   PME_DBG(hipMemcpyAsync(charge, &total_charge, sizeof(float), hipMemcpyHostToDevice, st));
-  rc = launch_pme_setup(st, cell, 1, mol_start, mol_idx, xw, charge, 1, n_atoms, 1, accuracy, b, status);
-  if (!rc) rc = launch_pme_recip(st, true, true, q, mol_idx, mol_start, n_atoms, 1, b, 1.0f, e_atom, qbar, fgrad, virial_atom);
+  rc = launch_pme_setup(st, cell, 1, mol_start, charge, 1, 1, accuracy, b, status);
+  if (!rc) rc = launch_pme_recip(st, true, true, xw, q, mol_idx, mol_start, order, n_atoms, 1, b, 1.0f, e_atom, qbar, fgrad, virial_atom);
   if (!rc) {
     EwaldSystem E;
     int need = 0;

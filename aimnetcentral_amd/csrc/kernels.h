@@ -290,12 +290,13 @@ int launch_ewald_setup(hipStream_t s, const float* cell, int n_cell, const int* 
                        const float* charge, int nq, int n_atoms, int n_mol, float accuracy, EwaldBuffers& b, int* status_k);
 int launch_ewald_frac(hipStream_t s, const float* xw, const int* mol_idx, int n_atoms, const EwaldBuffers& b);
 // ---- pme.hip: smooth particle-mesh Ewald (LRCoulomb "pme", lr.py:752-775): the reciprocal-space sum on a mesh --------------
-// per-system (alpha, rc, mesh) + fractional coordinates; *status = mesh points the largest system needs (> max_mesh: its mesh
+// per-system (alpha, rc, mesh), the charge mesh zeroed, the spline moduli; *status = mesh points the largest system needs (> max_mesh: its mesh
 // was skipped, results meaningless; INT32_MAX: an axis beyond PME_MAX_AXIS)
-int launch_pme_setup(hipStream_t s, const float* cell, int n_cell, const int* mol_start, const int* mol_idx, const float* xw,
-                     const float* charge, int nq, int n_atoms, int n_mol, float accuracy, EwaldBuffers& b, int* status);
-int launch_pme_recip(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, const int* mol_start, int n_atoms,
-                     int n_mol, const EwaldBuffers& b, float factor, double* ecoul, float* qbar, float* fgrad, float* virial_atom);
+int launch_pme_setup(hipStream_t s, const float* cell, int n_cell, const int* mol_start, const float* charge, int nq, int n_mol,
+                     float accuracy, EwaldBuffers& b, int* status);
+// order: the engine's bin order of the atoms (a permutation of 0 .. n_atoms-1) or NULL - the charge assignment groups atoms by it
+int launch_pme_recip(hipStream_t s, bool grad, bool stress, const float* xw, const float* q, const int* mol_idx, const int* mol_start,
+                     const int* order, int n_atoms, int n_mol, const EwaldBuffers& b, float factor, double* ecoul, float* qbar, float* fgrad, float* virial_atom);
 // reciprocal-space sum + neutralising background, ACCUMULATED onto the per-atom energies / adjoints the pair kernels have stored
 int launch_ewald_recip(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, const int* mol_start, int n_atoms,
                        int n_mol, const EwaldBuffers& b, float factor, double* ecoul, float* qbar, float* fgrad, float* virial_atom);

@@ -313,10 +313,12 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
  * out[lb][r][l] = VGPR r, lane l of D = A x B with A[l] = l + 1 and B = one-hot(lb), C = 0. */
 /* aimnet_debug_pme_recip (csrc/pme.hip): the reciprocal-space part of AIMNET_COULOMB_PME alone, for ONE system - what
  * particle_mesh_ewald's mesh half computes (aimnet/modules/lr.py:752-775) - with unit prefactor: device xw [n][3] (any image of
- * the atoms), q [n], cell [9] row vectors; ACCUMULATES onto device e_atom [n] (double: q_i phi_i), qbar [n] (2 phi_i), fgrad [n][3]
+ * the atoms), q [n], order [n] (device, a permutation: the sequence in which the charge assignment groups the atoms; NULL = as
+ * given - the results do not depend on it, bit for bit), cell [9] row vectors; ACCUMULATES onto device e_atom [n] (double: q_i phi_i), qbar [n] (2 phi_i), fgrad [n][3]
  * (2 q_i grad phi_i), virial_atom [n][9] (per-atom shares of 2 dE/d eps; the mesh term on atom 0) - zero them first.  host_info[8]:
  * alpha, rc, mesh[3], mesh points needed (> max_mesh: nothing was computed), phi_bg.  Allocates its own scratch; synchronises. */
-int aimnet_debug_pme_recip(const float* xw, const float* q, const float* cell, float total_charge, int n_atoms, float accuracy,
+int aimnet_debug_pme_recip(const float* xw, const float* q, const int* order, const float* cell, float total_charge, int n_atoms,
+                           float accuracy,
                            int max_mesh, double* e_atom, float* qbar, float* fgrad, float* virial_atom, double* host_info,
                            void* hip_stream);
 int aimnet_debug_mfma4_probe(float* out, void* hip_stream);

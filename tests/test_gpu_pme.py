@@ -30,7 +30,7 @@ def _run(eng, coord, numbers, mol, charge, cell, method="pme", **kw):
     return {k: v.cpu().numpy() for k, v in r.items()}
 
 
-def _recip(eng, x, q, cell, acc, max_mesh=1 << 20):
+def _recip(eng, x, q, cell, acc, max_mesh=1 << 20, order=None):
     lib, dev = eng.lib, eng.device
     n = len(x)
     xd = torch.from_numpy(x.astype(np.float32)).to(dev).contiguous()
@@ -41,8 +41,9 @@ def _recip(eng, x, q, cell, acc, max_mesh=1 << 20):
     fg = torch.zeros(n, 3, dtype=torch.float32, device=dev)
     va = torch.zeros(n, 9, dtype=torch.float32, device=dev)
     info = (C.c_double * 8)()
+    od = None if order is None else torch.from_numpy(np.ascontiguousarray(order, dtype=np.int32)).to(dev)
     torch.cuda.synchronize()
-    rc = lib.aimnet_debug_pme_recip(xd.data_ptr(), qd.data_ptr(), cd.data_ptr(), float(q.astype(np.float32).sum(dtype=np.float64)), n, acc,
+    rc = lib.aimnet_debug_pme_recip(xd.data_ptr(), qd.data_ptr(), None if od is None else od.data_ptr(), cd.data_ptr(), float(q.astype(np.float32).sum(dtype=np.float64)), n, acc,
                                     max_mesh, e.data_ptr(), qb.data_ptr(), fg.data_ptr(), va.data_ptr(), info, None)
     assert rc == 0
     return e.cpu().numpy(), qb.cpu().numpy(), fg.cpu().numpy(), va.cpu().numpy(), list(info)
@@ -87,6 +88,13 @@ def test_mesh_kernels_repeat_bitwise_and_report_their_capacity(hip_engine):
     b = _recip(hip_engine, x, q, cell, 1e-6)
     for u, v in zip(a[:4], b[:4]):
         assert np.array_equal(u, v)  # integer charge assignment, fixed-order sums
+    # atoms grouped by 4 A boxes: the charge assignment sums each group in an LDS tile first - the same integers, the same bits
+    frac = (x.astype(np.float64) @ np.linalg.inv(cell.astype(np.float64))) % 1.0
+    box = np.floor(frac * np.maximum(1, np.floor(np.linalg.norm(cell, axis=1) / 4.0))).astype(np.int64)
+    order = np.lexsort((box[:, 2], box[:, 1], box[:, 0]))
+    c = _recip(hip_engine, x, q, cell, 1e-6, order=order)
+    for u, v in zip(a[:4], c[:4]):
+        assert np.array_equal(u, v)
     e, qb, fg, va, info = _recip(hip_engine, x, q, cell, 1e-6, max_mesh=512)
     assert int(info[5]) > 512 and not e.any() and not fg.any()  # too small: nothing computed, the need reported
 

@@ -7,7 +7,9 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from aimnetcentral_amd import loader, workloads  # noqa: E402
 from aimnetcentral_amd.engine import HipEngine  # noqa: E402
 

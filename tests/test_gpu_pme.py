@@ -175,3 +175,52 @@ def test_through_the_calculator_with_forces_as_the_energy_gradient():
     assert abs(-(ep - em) / (2 * h) - (f * v).sum()) < 2e-3 * max(1.0, abs((f * v).sum()))
     with pytest.raises(ValueError, match="requires a periodic 'cell'"):
         calc(dict(coord=g["coord"], numbers=g["numbers"], charge=0.0))
+
+
+def test_with_dftd3_and_with_two_charge_channels(hip_engine, hip_engine_nse):
+    """The mesh beside the other long-range pieces: external DFT-D3 (its own 15 A list) and an open-shell NSE model (two charge
+    channels, the Coulomb sum sees their total) - each against the same evaluation with the exact Ewald sum at 1e-8."""
+    g = golden("dftd3")
+    par, tables = P._d3(12.0)
+    hip_engine.set_dftd3_tables(tables)
+    mol = np.zeros(96, dtype=np.int64)
+    a, a0 = P._run_d3(hip_engine, g["pbc_coord"], g["pbc_numbers"], mol, "pme", par, cell=g["pbc_cell"], stress=True, ewald_accuracy=1e-8)
+    b, b0 = P._run_d3(hip_engine, g["pbc_coord"], g["pbc_numbers"], mol, "ewald", par, cell=g["pbc_cell"], stress=True, ewald_accuracy=1e-8)
+    assert abs(a["energy"][0] - a0["energy"][0]) > 1e-3  # the dispersion term is there
+    for x, y in ((a, b), (a0, b0)):
+        assert abs(x["energy"][0] - y["energy"][0]) < 2e-6
+        assert np.abs(x["forces"] - y["forces"]).max() < 2e-6 * max(1.0, np.abs(y["forces"]).max())
+        assert np.abs(x["stress"] - y["stress"]).max() < 1e-7  # (fp32 outputs: one ulp at 0.18 is 1.5e-8)
+    p = golden("nse")
+    dev = hip_engine_nse.device
+    args = (torch.from_numpy(p["pbc_coord"]).to(dev), torch.from_numpy(p["pbc_numbers"]).to(dev), torch.zeros(96, dtype=torch.int64, device=dev),
+            torch.from_numpy(P._nse_charge(1.0, np.array([2.0], dtype=np.float32))).to(dev))  # a doublet cation
+    kw = dict(cell=torch.from_numpy(p["pbc_cell"]).to(dev), forces=True, stress=True, ewald_accuracy=1e-8)
+    u = {k: v.cpu().numpy() for k, v in hip_engine_nse.eval(*args, coulomb="pme", **kw).items()}
+    v = {k: v.cpu().numpy() for k, v in hip_engine_nse.eval(*args, coulomb="ewald", **kw).items()}
+    assert abs(u["energy"][0] - v["energy"][0]) < 5e-6
+    assert np.abs(u["forces"] - v["forces"]).max() < 3e-6 * max(1.0, np.abs(v["forces"]).max())
+    assert np.abs(u["spin_charges"] - v["spin_charges"]).max() < 1e-6 and np.abs(u["charges"] - v["charges"]).max() < 1e-6
+
+
+def test_deferred_status_grows_the_mesh_capacity():
+    """Device-resident stepping with the mesh method: a capacity that is too small is noticed by check_status(), grown to what the
+    engine reported, and the repeated evaluation is the synchronous one's."""
+    from aimnetcentral_amd import AIMNet2Calculator, loader
+    from aimnetcentral_amd.engine import NeighborOverflowError
+
+    calc = AIMNet2Calculator(loader.synthetic_spec(0, cold=True), device="cuda:0")
+    calc.set_lrcoulomb_method("pme")
+    g = golden("pbc96_dsf15")
+    data = dict(coord=g["coord"], numbers=g["numbers"], charge=0.0, cell=g["cell"])
+    ref = calc(data, forces=True)
+    need = int(calc.engine.last_status[7])
+    calc.engine._pme_max_mesh = 512
+    assert need > 512
+    calc.eval(data, forces=True, defer_status=True)
+    with pytest.raises(NeighborOverflowError):
+        calc.check_status()
+    assert calc.engine._pme_max_mesh >= need
+    out = calc.eval(data, forces=True, defer_status=True)
+    calc.check_status()
+    assert float(out["energy"]) == float(ref["energy"]) and torch.equal(out["forces"], ref["forces"])

@@ -90,6 +90,9 @@ struct aimnet_engine {
   // AIMNET_SUMS_WHOLE / set_option("sums_whole"): up to 16 384 atoms, with the energy sums riding on the stress launch and the force
   // gather beside them: one block per cell / per molecule sums everything (no slices, no finish launch)
   int sums_whole = 1;
+  // AIMNET_NSE_MERGED / set_option("nse_merged"): systems of up to 1 024 atoms form the molecule sums of the NSE adjoint inside
+  // build_zbar_kernel instead of by a partial-sum launch in front of it (two launches fewer per evaluation)
+  int nse_merged = 1;
   double* sae;
   // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row

@@ -194,7 +194,7 @@ struct Workspace {
   float* hD[AIMNET_MAX_LAYERS];
   float* e_atom;
   double* ecoul;
-  float *qbar, *fgrad, *virial_atom, *abar;
+  float *qbar, *qbar2, *fgrad, *virial_atom, *abar;
   float* qtot;   // NSE models: alpha + beta charges (the Coulomb kernels and the `charges` output see these)
   double* part;  // per-(system, slice) partial sums of the molecule reductions
   double* part_e;  // [n_mol][S] energy partial sums when the energy reduction rides on the stress launches
@@ -327,6 +327,7 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
   W.e_atom = c.take<float>(n, "e_atom", 1);
   W.ecoul = c.take<double>(n, "ecoul", 1);
   W.qbar = c.take<float>(n * e->nq, "qbar", 1);
+  W.qbar2 = c.take<float>(n * e->nq, "qbar2", 1);  // (the merged NSE adjoint writes the next pass' qbar beside the one it sums over)
   W.qtot = c.take<float>(e->nq > 1 ? n : 0, "qtot", 1);
   W.fgrad = c.take<float>(n * 3, "fgrad", 3);
   W.virial_atom = c.take<float>(n * 9);
@@ -439,6 +440,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->status_owned = atoi(env) != 0;
     env = getenv("AIMNET_SUMS_WHOLE");
     if (env) e->sums_whole = atoi(env) != 0;
+    env = getenv("AIMNET_NSE_MERGED");
+    if (env) e->nse_merged = atoi(env) != 0;
     env = getenv("AIMNET_CONV_XE");
     if (env) e->conv_xe = atoi(env);
     env = getenv("AIMNET_SPLIT_MAX");
@@ -581,6 +584,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "setup_rides") e->setup_rides = value != 0;
   else if (n == "status_owned") e->status_owned = value != 0;
   else if (n == "sums_whole") e->sums_whole = value != 0;
+  else if (n == "nse_merged") e->nse_merged = value != 0;
   else if (n == "split_max") e->split_max = value < 0 ? conv_split_max_default() : value;
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -608,6 +612,7 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
   else if (n == "setup_rides") *value = e->setup_rides;
   else if (n == "status_owned") *value = e->status_owned;
   else if (n == "sums_whole") *value = e->sums_whole;
+  else if (n == "nse_merged") *value = e->nse_merged;
   else if (n == "split_max") *value = e->split_max;
   else if (n == "p0_moments") *value = e->p0_moments ? 1 : 0;
   else if (n == "overlap_coulomb") *value = e->overlap_coulomb ? 1 : 0;
@@ -1233,9 +1238,15 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const float* y = W.H[p - 1][nlq - 1];
     const int ldy = Lq[nlq - 1].k_out;
     RC(prof_mark(e, s, FAM_POINTWISE));
-    RC(launch_nse_bwd_reduce(s, W.qbar, y, ldy, nq, W.nl.mol_start, n_mol, N, W.S, (float*)W.part));
-    RC(launch_build_zbar(s, W.qbar, W.abar, y, ldy, ar.last_linear[p - 1] ? nullptr : W.D[p - 1][nlq - 1], W.Fm[p - 1],
-                         W.Dm[p - 1], (const float*)W.part, W.S, mol_c, N, n_mol, 256, nq, p - 1 > 0, znext, W.qbar, sfmt));
+    if (e->nse_merged && N <= 1024) {  // small systems: the molecule sums inside build_zbar, one launch instead of two
+      RC(launch_build_zbar(s, W.qbar, W.abar, y, ldy, ar.last_linear[p - 1] ? nullptr : W.D[p - 1][nlq - 1], W.Fm[p - 1],
+                           W.Dm[p - 1], nullptr, 1, mol_c, N, n_mol, 256, nq, p - 1 > 0, znext, W.qbar2, sfmt, W.nl.mol_start));
+      std::swap(W.qbar, W.qbar2);
+    } else {
+      RC(launch_nse_bwd_reduce(s, W.qbar, y, ldy, nq, W.nl.mol_start, n_mol, N, W.S, (float*)W.part));
+      RC(launch_build_zbar(s, W.qbar, W.abar, y, ldy, ar.last_linear[p - 1] ? nullptr : W.D[p - 1][nlq - 1], W.Fm[p - 1],
+                           W.Dm[p - 1], (const float*)W.part, W.S, mol_c, N, n_mol, 256, nq, p - 1 > 0, znext, W.qbar, sfmt));
+    }
     std::swap(zcur, znext);
   }
   RC(prof_mark(e, s, FAM_POINTWISE));

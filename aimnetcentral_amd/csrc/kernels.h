@@ -365,7 +365,10 @@ int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int 
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
                       const float* Fm, const float* Dm, const float* wpart, int S, const int* mol_idx, int n_atoms, int n_mol,
                       int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next,
-                      int zbar_split = 0);  // 1: rows in the split form of gemm_bf3a.hip (bf16 elements, 3 * ldy per row), 2: of gemm_h2.hip (2 * ldy)
+                      int zbar_split = 0,
+                      // wpart == NULL: the blocks form the molecule sums themselves (no launch_nse_bwd_reduce in front: small systems);
+                      // needs mol_start and qbar_next != qbar
+                      const int* mol_start = nullptr);  // 1: rows in the split form of gemm_bf3a.hip (bf16 elements, 3 * ldy per row), 2: of gemm_h2.hip (2 * ldy)
 // launch_pair_force's arguments as a rider of the stress reduction (launch_finalize): n_blocks = ceil(n_atoms / 4), 0 = none
 struct PairForceRider {
   const int* nb_idx; const int* nb_cnt; const int* rev; const float4* pairbuf; int cap; float* forces; int n_blocks;

@@ -802,25 +802,56 @@ int launch_nse_bwd_reduce(hipStream_t s, const float* qbar, const float* y, int 
 // zbar[i] = adjoint of the LAST linear layer's pre-activation of this pass' MLP:
 //   ybar = [q~bar (nq), f~bar (nq), delta_a bar(n_feat)], times GELU'(z_last) when the MLP ends with GELU.
 // qbar / qbar_next: nq planes of [n_atoms]; Fm, Dm: nq planes of [n_mol]; wpart: launch_nse_bwd_reduce's partial sums.
-__global__ void build_zbar_kernel(const float* __restrict__ qbar, const float* __restrict__ abar,
+__global__ __launch_bounds__(256) void build_zbar_kernel(const float* __restrict__ qbar, const float* __restrict__ abar,
                                   const float* __restrict__ y, int ldy, const float* __restrict__ dlast,
                                   const float* __restrict__ Fm, const float* __restrict__ Dm,
                                   const float* __restrict__ wpart, int S, const int* __restrict__ mol_idx, int n_atoms,
                                   int n_mol, int n_feat, int nq, int carry_q, float* __restrict__ zbar,
-                                  float* __restrict__ qbar_next, unsigned short* __restrict__ zbar3, int fmt) {
+                                  float* __restrict__ qbar_next, unsigned short* __restrict__ zbar3, int fmt,
+                                  const int* __restrict__ mol_start) {
+  // wpart == NULL (small systems, launch_build_zbar): the block forms sum_i qbar_i f_i of the molecules of its four atoms itself
+  // (same code and order in every block that needs a molecule: the same bits) - what nse_bwd_partial_kernel and a kernel boundary
+  // did.  Pays while a molecule is a few hundred atoms (a 113-atom molecule: -6 us per pass); for 10^4 atoms the redundant sums cost
+  // more than the launch (profiles/r5_nse_merged_ab.txt).
+  __shared__ float s_w[2][4];
+  __shared__ float sh[4];
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
+  int m_lo = 0;
+  if (wpart == nullptr) {
+    const int a_lo = blockIdx.x * 4, a_hi = min(n_atoms, a_lo + 4);
+    m_lo = mol_idx[a_lo];
+    const int m_hi = mol_idx[a_hi - 1];
+    for (int m = m_lo; m <= m_hi; ++m) {  // (<= 4 molecules: mol_idx is sorted)
+      const int i0 = mol_start[m], i1 = mol_start[m + 1];
+      for (int ch = 0; ch < nq; ++ch) {
+        float acc = 0.f;
+        for (int k = i0 + threadIdx.x; k < i1; k += 256) {
+          const float ft = y[(size_t)k * ldy + nq + ch];
+          acc += qbar[(size_t)ch * n_atoms + k] * (ft * ft);
+        }
+        const float r = block_sum(acc, sh);
+        if (threadIdx.x == 0) s_w[ch][m - m_lo] = r;
+      }
+    }
+    __syncthreads();
+  }
+  if (i >= n_atoms) return;
   const int m = mol_idx[i];
   // every lane reads both channels' qbar before anything is written: qbar_next may alias qbar
   float qr[2] = {0.f, 0.f}, fsc[2] = {0.f, 0.f};
   for (int ch = 0; ch < nq; ++ch) {
     const float F = Fm[(size_t)ch * n_mol + m];
-    // Wbar_m = (sum_i qbar_i f_i) / F_m: the S slice sums, one per lane, added by the wave's fixed reduction tree (S dependent
-    // wave-uniform loads in a row were half of this kernel's time on a 10 k-atom system, S = 20)
-    float wl = 0.f;
-    for (int k = lane; k < S; k += 64) wl += wpart[((size_t)ch * n_mol + m) * S + k];
-    const float wsum = wave_sum(wl);
+    float wsum;
+    if (wpart) {
+      // Wbar_m = (sum_i qbar_i f_i) / F_m: the S slice sums, one per lane, added by the wave's fixed reduction tree (S dependent
+      // wave-uniform loads in a row were half of this kernel's time on a 10 k-atom system, S = 20)
+      float wl = 0.f;
+      for (int k = lane; k < S; k += 64) wl += wpart[((size_t)ch * n_mol + m) * S + k];
+      wsum = wave_sum(wl);
+    } else {
+      wsum = s_w[ch][m - m_lo];
+    }
     qr[ch] = qbar[(size_t)ch * n_atoms + i] - wsum / F;
     fsc[ch] = Dm[(size_t)ch * n_mol + m] / F;
   }
@@ -858,10 +889,14 @@ __global__ void build_zbar_kernel(const float* __restrict__ qbar, const float* _
 
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
                       const float* Fm, const float* Dm, const float* wpart, int S, const int* mol_idx, int n_atoms, int n_mol,
-                      int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next, int zbar_split) {
+                      int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next, int zbar_split, const int* mol_start) {
+  if (!wpart && (!mol_start || qbar_next == qbar)) {  // (the blocks re-read qbar of whole molecules: it must not change under them)
+    set_last_error("build_zbar: the merged form needs mol_start and a qbar_next that is not qbar");
+    return -1;
+  }
   hipLaunchKernelGGL(build_zbar_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, qbar, abar, y, ldy, dlast, Fm, Dm, wpart,
                      S < 1 ? 1 : S, mol_idx, n_atoms, n_mol, n_feat, nq, carry_q ? 1 : 0, zbar, qbar_next,
-                     zbar_split ? reinterpret_cast<unsigned short*>(zbar) : nullptr, zbar_split);
+                     zbar_split ? reinterpret_cast<unsigned short*>(zbar) : nullptr, zbar_split, mol_start);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

@@ -271,3 +271,40 @@ def test_bad_inputs_are_flagged_the_same(hip_engine):
             finally:
                 hip_engine.set_option("prep_fused", 1)
         assert msgs[0] == msgs[1]
+
+
+@pytest.mark.parametrize("case", ["taxol", "batch5", "pbc2x96", "nse_batch5"])
+def test_molecule_sums_inside_build_zbar_agree_with_the_partial_sum_launch(hip_engine, hip_engine_nse, case):
+    """Option "nse_merged" (systems of up to 1 024 atoms): build_zbar's blocks form sum_i qbar_i f_i of their molecules themselves
+    instead of reading the result of a launch in front.  The same terms in another association: everything to fp32 rounding of the
+    evaluation, charges untouched (the adjoint only), and the merged form repeats bit for bit."""
+    eng = hip_engine_nse if case == "nse_batch5" else hip_engine
+    dev = eng.device
+    kw = dict(forces=True, coulomb="simple")
+    if case == "taxol":
+        g = golden("taxol")
+        c, z, mol, q = g["coord"], g["numbers"], np.zeros(113, dtype=np.int64), np.zeros(1, np.float32)
+    elif case == "batch5":
+        g = golden("batch5")
+        c, z, mol, q = g["coord"], g["numbers"], g["mol_idx"], np.atleast_1d(g["charge"]).astype(np.float32)
+    elif case == "pbc2x96":
+        g = golden("pbc2x96_dsf9")
+        c, z, mol, q = g["coord"], g["numbers"], g["mol_idx"], np.atleast_1d(g["charge"]).astype(np.float32)
+        kw.update(cell=torch.from_numpy(g["cell"]).to(dev), stress=True, coulomb="dsf", dsf_rc=9.0)
+    else:
+        g = golden("nse")
+        c, z, mol, q = g["b5_coord"], g["b5_numbers"], g["b5_mol_idx"], P._nse_charge(g["b5_charge"], g["b5_mult"])
+
+    def go():
+        r = eng.eval(torch.from_numpy(np.asarray(c, np.float32)).to(dev), torch.from_numpy(np.asarray(z)).to(dev),
+                     torch.from_numpy(np.asarray(mol)).to(dev), torch.from_numpy(np.asarray(q, np.float32)).to(dev), **kw)
+        return {k: v.cpu().numpy() for k, v in r.items()}
+
+    a, b = both(eng, go, "nse_merged")
+    a2 = go()
+    for k in a:
+        assert np.array_equal(a[k], a2[k]), k
+    assert np.array_equal(a["charges"], b["charges"]) and np.array_equal(a["energy"], b["energy"])
+    assert np.abs(a["forces"] - b["forces"]).max() < 2e-5 * max(1.0, np.abs(b["forces"]).max())
+    if "stress" in a:
+        assert np.abs(a["stress"] - b["stress"]).max() < 2e-6 * max(1e-2, np.abs(b["stress"]).max())

@@ -425,24 +425,26 @@ static int launch_panel(hipStream_t stream, int epi, const float* A, int lda, co
 // ------------------------------------------------------------------------------------------------
 // Skinny kernel for small M (single molecules: M ~ 100 rows).  There the MFMA work is ~1 us and the tiled kernels
 // are pure latency: 46 dependent K steps of DMA -> barrier -> read.  Here every 16x16 output tile gets a block of
-// 4 waves that split K four ways; a wave issues ALL of its operand loads (<= 12 + 12 dwordx4 straight from L2,
-// no LDS) before its first MFMA, so the critical path is one memory round trip + ~48 MFMAs + a 4-way LDS
+// SKINNY_KS waves that split K; a wave issues ALL of its operand loads (<= 3 + 3 dwordx4 straight from L2,
+// no LDS) before its first MFMA, so the critical path is one memory round trip + ~12 MFMAs + a 16-way LDS
 // reduction.  L2 traffic is M*N*K/2 bytes (each tile re-reads its panels), which is why this is only chosen for
 // M <= 256.
+constexpr int SKINNY_KS = 16;  // waves of a block = K slices of its tile.  4 -> 8 -> 16 slices: taxol 0.2890 -> 0.2849 -> 0.2745 ms (every wave's
+                                // dependent chain of loads and MFMAs shrinks; the 16-way LDS reduction costs less than it saves)
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bt,
+__global__ __launch_bounds__(64 * SKINNY_KS) void gemm_nt_skinny_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bt,
                                                             int ldb, int M, int N, int K, const float* __restrict__ bias,
                                                             float* __restrict__ C, float* __restrict__ D, int ldc,
                                                             const int* __restrict__ brow, int ldbias) {
-  constexpr int MAXC = 12;  // 16-wide k chunks in flight per wave
-  __shared__ f32x4 part[4][64];
+  constexpr int MAXC = 48 / SKINNY_KS;  // 16-wide k chunks in flight per wave (K <= 768 in one round)
+  __shared__ f32x4 part[SKINNY_KS][64];
   const int lane = threadIdx.x & 63;
   const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tiles_n = (N + 15) >> 4;
   const int m0 = (blockIdx.x / tiles_n) * 16, n0 = (blockIdx.x % tiles_n) * 16;
   const int l16 = lane & 15, lc = lane >> 4;
   const int nch = K >> 4;                                   // chunks of 16 along K
-  const int c_lo = (nch * ks) >> 2, c_hi = (nch * (ks + 1)) >> 2;  // this wave's chunk range
+  const int c_lo = (nch * ks) / SKINNY_KS, c_hi = (nch * (ks + 1)) / SKINNY_KS;  // this wave's chunk range
   const float* pa = A + (size_t)min(m0 + l16, M - 1) * lda + lc * 4;
   const float* pb = Bt + (size_t)min(n0 + l16, N - 1) * ldb + lc * 4;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -465,7 +467,9 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const float* __rest
   part[ks][lane] = acc;
   __syncthreads();
   if (ks != 0) return;
-  f32x4 v = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+  f32x4 v = part[0][lane];
+#pragma unroll
+  for (int w = 1; w < SKINNY_KS; ++w) v = v + part[w][lane];
   // v[r] = C[m0 + (lane & 15)][n0 + 4 (lane >> 4) + r]
   const int row = m0 + l16, col = n0 + 4 * lc;
   if (row >= M) return;
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const float* __rest
 
 static int launch_skinny(hipStream_t stream, int epi, const float* A, int lda, const float* Bt, int ldb, int M, int N, int K,
                          const float* bias, float* C, float* D, int ldc, const int* brow, int ldbias) {
-  dim3 grid(ceil_div(M, 16) * ceil_div(N, 16)), block(256);
+  dim3 grid(ceil_div(M, 16) * ceil_div(N, 16)), block(64 * SKINNY_KS);
   switch (epi) {
     case EPI_NONE:
       hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI_NONE>, grid, block, 0, stream, A, lda, Bt, ldb, M, N, K, bias, C, D, ldc, brow, ldbias);

@@ -26,13 +26,17 @@
 namespace aimnet {
 
 constexpr int h2_passes(int rows) { return (rows + 31) / 32; }  // DMA wave-instructions per wave of the issuing group (a pass = 4 KiB = 2 strips)
-constexpr int h2_lds_bytes(int TM, int TN) { return 2 * h2_passes(TM) * 4096 + 3 * h2_passes(TN) * 4096; }
+// NSA = activation ring depth.  2: the activation tile is requested ONE step ahead (weights: two).  3: two steps ahead as well -
+// for launches that leave CUs idle (a few hundred to ~2 000 rows): there a step is as long as the request's latency whatever the
+// tile (~0.6 us; the GEMM family costs the same 0.25 ms from 384 to 2 304 atoms), and the second step of lead takes 8 % off it;
+// on full grids the extra 20 KB of LDS cost 0.6 % (profiles/r5_size_sweep.jsonl).
+constexpr int h2_lds_bytes(int TM, int TN, int NSA) { return NSA * h2_passes(TM) * 4096 + 3 * h2_passes(TN) * 4096; }
 
 #ifdef AIMNET_BF3_TIMING
 __device__ unsigned long long g_h2_stamps[1024];
 #endif
 
-template <int EPI, int SM, int SN, int WN, bool OUT3>
+template <int EPI, int SM, int SN, int WN, bool OUT3, int NSA>
 __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* __restrict__ A3, int lda3,
                                                            const unsigned short* __restrict__ Bt, int ldb, int M, int N, int K,
                                                            const float* __restrict__ bias, float* __restrict__ C,
@@ -72,7 +76,6 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
       for (int j = 0; j < SN; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_a;
-  constexpr int NSA = 2;  // activation ring depth (weights: 3)
   const unsigned ldsB = lds0 + NSA * SA_BYTES;
 
   // DMA of the issuing group: pass p, wave w4 -> KiB q = 4 p + w4 of the stage = plane q & 1 of the 16-row strip q >> 1; lane ->
@@ -144,7 +147,12 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
   // ---- prologue: A(0) by group 0; B(0), B(1) by group 1
   if (!late) {
     dma_a(0, 0, PZ{}, PAE{});
-    wait_vm<0>();
+    if (NSA == 3) {
+      dma_a(1, kc(1), PZ{}, PAE{});
+      wait_vm<NPA>();
+    } else {
+      wait_vm<0>();
+    }
   } else {
     dma_b(0, 0, PZ{}, PBE{});
     dma_b(1, kc(1), PZ{}, PBE{});
@@ -164,7 +172,8 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
     read_strips_h<0, SN, 0>(fb, ob);
     read_strips_h<0, SM, 1>(fa, oa);
     if constexpr (G == 0) {
-      dma_a(sa ^ 1, kc(j + 1), PZ{}, PAE{});
+      if (NSA == 3) dma_a(sa == 0 ? 2 : sa - 1, kc(j + 2), PZ{}, PAE{});  // (sa + 2) % 3: two steps ahead, as the weights
+      else dma_a(sa ^ 1, kc(j + 1), PZ{}, PAE{});
       wait_lgkm<0>();
     } else {
       dma_b(sb == 0 ? 2 : sb - 1, kc(j + 2), PZ{}, PBE{});  // (sb + 2) % 3
@@ -180,7 +189,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
     AIMNET_H2_PRODUCT(PAR, 0, 0)
     AIMNET_H2_PRODUCT(2, 1, 0)
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (G == 0) wait_vm<0>();  // the activation tile of step j+1, requested in L(j)
+    if constexpr (G == 0) {  // the activation tile of step j+1 has landed (requested in L(j-1); NSA = 2: in L(j))
+      if (NSA == 3) wait_vm<NPA>();
+      else wait_vm<0>();
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
   auto bar = [&]() __attribute__((always_inline)) {
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
   auto run = [&](auto g_c) __attribute__((always_inline)) {
     int sa = 0, sb = 0, j = 0;
     auto next = [&]() __attribute__((always_inline)) {
-      sa ^= 1;
+      sa = NSA == 3 ? (sa == 2 ? 0 : sa + 1) : sa ^ 1;
       sb = sb == 2 ? 0 : sb + 1;
     };
     for (; j + 1 < nk; j += 2) {
@@ -307,17 +319,25 @@ static int launch_h2(hipStream_t stream, int epi, bool out3, const unsigned shor
                        const int* brow, int ldbias, int alt) {
   constexpr int WM = 8 / WN, TM = 16 * SM * WM, TN = 16 * SN * WN;
   const int tiles = ceil_div(M, TM) * ceil_div(N, TN);
-  constexpr size_t lds = (size_t)h2_lds_bytes(TM, TN);
-  static_assert(lds <= 160 * 1024, "LDS");
+  static_assert(h2_lds_bytes(TM, TN, 3) <= 160 * 1024, "LDS");
+  const bool deep = 2 * tiles <= device_cus();  // at most half of the CUs busy (see NSA)
+  const size_t lds = (size_t)(deep ? h2_lds_bytes(TM, TN, 3) : h2_lds_bytes(TM, TN, 2));
   dim3 grid(tiles), block(512);
 #define AIMNET_H2_LAUNCH(E, O3)                                                                                            \
   {                                                                                                                          \
     static PerDeviceOnce once;                                                                                               \
-    if (once.first())                                                                                                        \
-      AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_h2_kernel<E, SM, SN, WN, O3>,                                \
+    if (once.first()) {                                                                                                      \
+      AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_h2_kernel<E, SM, SN, WN, O3, 2>,                             \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
-    hipLaunchKernelGGL((gemm_h2_kernel<E, SM, SN, WN, O3>), grid, block, lds, stream, A3, lda3, Bt, ldb, M, N, K, bias, C, \
-                       C3, ldc3, D, ldc, brow, ldbias, alt);                                                                \
+      AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_h2_kernel<E, SM, SN, WN, O3, 3>,                             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
+    }                                                                                                                        \
+    if (deep)                                                                                                                \
+      hipLaunchKernelGGL((gemm_h2_kernel<E, SM, SN, WN, O3, 3>), grid, block, lds, stream, A3, lda3, Bt, ldb, M, N, K,    \
+                         bias, C, C3, ldc3, D, ldc, brow, ldbias, alt);                                                      \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((gemm_h2_kernel<E, SM, SN, WN, O3, 2>), grid, block, lds, stream, A3, lda3, Bt, ldb, M, N, K,    \
+                         bias, C, C3, ldc3, D, ldc, brow, ldbias, alt);                                                      \
   }
   if (out3) {
     switch (epi) {

@@ -41,6 +41,7 @@ struct FwdWaveLds {
   float fc[CH];       // cutoff envelope fc(d) of the chunk (one sincos per pair)
   float qj[2][CH];    // neighbour charges, one row per charge channel
   float mt[64];       // P0M: one species' moments M[g][c], handed from the (g,c) lane map to the (a, 4 shifts) one
+  int rz[CH], re[CH]; // P0M: the chunk's runs of equal elements: element, end slot
 };
 
 // `row_of` (may be NULL): feature row of atom j inside `a`.  Pass 0 gathers straight from the
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
 #pragma unroll
     for (int ch = 0; ch < NQC; ++ch) accq[ch] = 0.0f;
 
+    int p0_runs = 0;  // P0M: runs of equal elements in the staged chunk (wave-uniform)
     for (int c0 = 0; c0 < cmax; c0 += CH) {
       const int nch = max(0, min(CH, cnt - c0));
       lds_sync<SPLIT>();  // previous chunk fully consumed
@@ -153,12 +155,18 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
         unsigned long long rem = __ballot(valid);
         const unsigned long long lt = (1ull << lane) - 1ull;
         int base = 0, pos = lane;
+        p0_runs = 0;
         while (rem) {  // wave-uniform
           const int zs = __shfl(zj, __ffsll((long long)rem) - 1, 64);
           const bool mine = valid && zj == zs;
           const unsigned long long m = __ballot(mine);
           if (mine) pos = base + __popcll(m & lt);
           base += __popcll(m);
+          if (lane == 0) {
+            L.rz[p0_runs] = zs;
+            L.re[p0_runs] = base;
+          }
+          ++p0_runs;
           rem &= ~m;
         }
         if (!valid) pos = lane;  // slots nch..63 keep a defined (zero-weight) entry
@@ -241,19 +249,21 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
           }
           lds_sync<false>();
         };
-        int cur = -1;
-        float accm = 0.f;
-        for (int mm = 0; mm < nch; ++mm) {
-          const int zs = __builtin_amdgcn_readfirstlane(L.j[mm]);
-          if (zs != cur) {
-            if (cur >= 0) flush(cur, accm);
-            accm = 0.f;
-            cur = zs;
+        // one run of equal elements after the other (the staging recorded them): the pair loop has no branch and no scalar
+        // round trip per pair - two 4-byte LDS reads and one FMA, which the compiler can keep several of in flight
+        const int cidx = max(qc_f - 1, 0);
+        int start = 0;
+        for (int r = 0; r < p0_runs; ++r) {
+          const int z = __builtin_amdgcn_readfirstlane(L.rz[r]), end = __builtin_amdgcn_readfirstlane(L.re[r]);
+          float accm = 0.f;
+          for (int mm = start; mm < end; ++mm) {
+            float uc = reinterpret_cast<const float*>(&L.ud[mm])[cidx];
+            uc = qc_f == 0 ? 1.f : uc;
+            accm += L.gs[mm][gq] * uc;
           }
-          const float4 u = L.ud[mm];
-          accm += L.gs[mm][gq] * (fm0 + fm1 * u.x + fm2 * u.y + fm3 * u.z);
+          flush(z, accm);
+          start = end;
         }
-        if (cur >= 0) flush(cur, accm);
       } else {
 #ifdef AIMNET_PROBE_FWD_DEEP  // measurement builds only: eight row loads in flight per wave instead of four
         const int nch8 = (nch + 7) & ~7;

@@ -1258,6 +1258,7 @@ int launch_unconcat_p0(hipStream_t s, const float* xbar, int ldx, const float* V
 
 struct P0WaveLds {
   float4 ud[64];
+  float4 du[64];  // per pair: (D, U0, U1, U2), handed from the (pair-of-four, g) lane map of the radial sums to the lane = pair map
   float fc[64], dfc[64];
   int j[64], sj[64];
 };
@@ -1308,18 +1309,20 @@ __global__ __launch_bounds__(256) void conv_bwd_p0_kernel(const float4* __restri
     for (int c0 = 0; c0 < cnt; c0 += 64) {
       const int nch = min(64, cnt - c0);
       __builtin_amdgcn_wave_barrier();
+      float4 ud_own = make_float4(0.f, 0.f, 0.f, 1.f);
       if (lane < nch) {  // lane = pair: one sincos per pair
         const size_t p = (size_t)i * cap + c0 + lane;
         const int j = nb_idx[p];
-        const float4 ud = pg[p];
+        ud_own = pg[p];
         L.j[lane] = j;
         L.sj[lane] = aslot[j];
-        L.ud[lane] = ud;
+        L.ud[lane] = ud_own;
         float dfc;
-        L.fc[lane] = basis_fc(bp, ud.w, dfc);
+        L.fc[lane] = basis_fc(bp, ud_own.w, dfc);
         L.dfc[lane] = dfc;
       }
       __builtin_amdgcn_wave_barrier();
+      // phase 1, lanes = (pair of the step, g): the radial sums D and U of four pairs per step
       for (int m0 = 0; m0 < nch; m0 += 4) {
         const int m = min(m0 + pq, nch - 1);
         const bool valid = m0 + pq < nch;
@@ -1335,15 +1338,23 @@ __global__ __launch_bounds__(256) void conv_bwd_p0_kernel(const float4* __restri
         float D = dg * ((Ti.x + Tj.x) + u.x * (Ti.y - Tj.y) + u.y * (Ti.z - Tj.z) + u.z * (Ti.w - Tj.w));
         float U0 = gs * (Tj.y - Ti.y), U1 = gs * (Tj.z - Ti.z), U2 = gs * (Tj.w - Ti.w);
         D = row16_sum(D); U0 = row16_sum(U0); U1 = row16_sum(U1); U2 = row16_sum(U2);
-        const float keep = (valid && g == 0) ? 1.0f : 0.0f;
+        if (valid && g == 0) L.du[m] = make_float4(D, U0, U1, U2);
+      }
+      __builtin_amdgcn_wave_barrier();
+      // phase 2, lane = pair: the projection onto the pair's geometry, the pair-buffer entry (one coalesced 16-byte access per
+      // lane instead of four scattered ones per step) and the virial terms - once per pair, not once per (pair, g)
+      if (lane < nch) {
+        const float4 u = ud_own;
+        const float4 du = L.du[lane];
+        const float D = du.x, U0 = du.y, U1 = du.z, U2 = du.w;
         const float inv_d = __builtin_amdgcn_rcpf(u.w);
         const float dot = U0 * u.x + U1 * u.y + U2 * u.z;
-        const float f0 = keep * ((U0 - dot * u.x) * inv_d - D * u.x);
-        const float f1 = keep * ((U1 - dot * u.y) * inv_d - D * u.y);
-        const float f2 = keep * ((U2 - dot * u.z) * inv_d - D * u.z);
+        const float f0 = (U0 - dot * u.x) * inv_d - D * u.x;
+        const float f1 = (U1 - dot * u.y) * inv_d - D * u.y;
+        const float f2 = (U2 - dot * u.z) * inv_d - D * u.z;
         xa0 += f0; xa1 += f1; xa2 += f2;
-        if (XE && valid && g == 0) {  // the passes before this one left their F1 here
-          float4* pb = pairbuf + (size_t)i * cap + c0 + m;
+        if (XE) {  // the passes before this one left their F1 here
+          float4* pb = pairbuf + (size_t)i * cap + c0 + lane;
           const float4 o = *pb;
           *pb = make_float4(o.x + f0, o.y + f1, o.z + f2, 0.f);
         }

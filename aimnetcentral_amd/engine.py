@@ -137,7 +137,7 @@ class HipEngine:
         self.last_status: np.ndarray | None = None
         self.has_dftd3 = False
         self._ewald_max_k = 8192  # capacity of the Ewald k arrays (entries; grows to what status[7] reports)
-        self._pme_max_mesh = 32768  # capacity of one system's PME mesh (points; grows to what status[7] reports)
+        self._pme_max_mesh = 8192  # capacity of one system's PME mesh (points; every system of a batch gets a slice: grows to what status[7] reports)
         self._status7_pme = False  # what status[7] of the pending deferred evaluations counts (mesh points or k entries)
 
     def __del__(self):

@@ -224,3 +224,45 @@ def test_deferred_status_grows_the_mesh_capacity():
     out = calc.eval(data, forces=True, defer_status=True)
     calc.check_status()
     assert float(out["energy"]) == float(ref["energy"]) and torch.equal(out["forces"], ref["forces"])
+
+
+def test_sheared_cell_and_tiny_cell_mesh_kernels(hip_engine):
+    """A strongly sheared triclinic cell (60 degree angles) and a cell smaller than the spline support (5 A: every atom's 8 x 8 x 8
+    stencil wraps around the 8-point minimum mesh) against the CPU twin."""
+    rng = np.random.default_rng(21)
+    for cell, n in ((np.array([[9.0, 0.0, 0.0], [4.5, 7.794, 0.0], [4.5, 2.598, 7.348]], np.float32), 150),
+                    (np.eye(3, dtype=np.float32) * 5.0, 12)):
+        x = ((rng.random((n, 3)) * 2.0 - 0.5) @ cell).astype(np.float32)
+        q = rng.normal(0.0, 0.4, n).astype(np.float32)
+        e, qb, fg, va, info = _recip(hip_engine, x, q, cell, 1e-6)
+        alpha, rc, mesh = OP.pme_parameters(n, cell.astype(np.float64), 1e-6)
+        assert [int(v) for v in info[2:5]] == list(mesh)
+        alpha_eff = math.sqrt(1.0 / (4.0 * float(np.float32(1.0 / (4.0 * alpha * alpha)))))
+        ref = OP.pme_reciprocal(x.astype(np.float64), q.astype(np.float64), cell.astype(np.float64), alpha_eff, mesh)
+        scale = max(1.0, np.abs(ref["phi"]).max())
+        assert np.abs(e - q.astype(np.float64) * ref["phi"]).max() < (1e-10 * scale + 2e-7 * abs(info[6])) * np.abs(q).max()
+        gref = 2.0 * q[:, None].astype(np.float64) * ref["grad"]
+        assert np.abs(fg - gref).max() < 3e-7 * max(1.0, np.abs(gref).max())
+        assert np.abs(va.sum(0).reshape(3, 3) - 2.0 * ref["strain"]).max() < 2e-6 * max(1.0, np.abs(ref["strain"]).max())
+
+
+def test_batch_of_many_cells_each_with_its_own_mesh(hip_engine):
+    """24 periodic systems of 96 atoms with cells scaled 0.97 ... 1.20 (different alpha, mesh and capacity needs) in one batch:
+    every system equals its single-system evaluation (to the difference between the split-operand GEMMs of the batch and the exact-fp32
+    ones a 96-atom system takes), and the batch lands on the Ewald method."""
+    g = golden("pbc96_dsf15")
+    nsys = 24
+    rng = np.random.default_rng(8)
+    scale = np.linspace(0.97, 1.20, nsys).astype(np.float32)
+    coords = [(g["coord"] * s + rng.normal(0.0, 0.01, g["coord"].shape)).astype(np.float32) for s in scale]
+    cells = np.stack([g["cell"] * s for s in scale]).astype(np.float32)
+    c, z = np.concatenate(coords), np.tile(g["numbers"], nsys)
+    mol, q = np.repeat(np.arange(nsys), 96), np.zeros(nsys, np.float32)
+    a = _run(hip_engine, c, z, mol, q, cells)
+    b = _run(hip_engine, c, z, mol, q, cells, method="ewald")
+    assert np.abs(a["energy"] - b["energy"]).max() < 5e-5
+    assert np.abs(a["forces"] - b["forces"]).max() < 2e-5 + 1e-4 * np.abs(b["forces"]).max()
+    for k in (0, 11, 23):
+        s1 = _run(hip_engine, coords[k], g["numbers"], np.zeros(96, np.int64), np.zeros(1, np.float32), cells[k])
+        assert abs(s1["energy"][0] - a["energy"][k]) < 1e-4
+        assert np.abs(s1["forces"] - a["forces"][96 * k:96 * (k + 1)]).max() < 2e-5 + 1e-4 * np.abs(s1["forces"]).max()

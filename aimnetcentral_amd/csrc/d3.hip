@@ -256,7 +256,9 @@ __global__ __launch_bounds__(256) void d3_pair_kernel(const float4* __restrict__
     float N = 0.f, D = 0.f, G = 0.f, H = 0.f;
 #pragma unroll
     for (int a = 0; a < 5; ++a) {
-      if (a < nref_i) {
+      // (a reference of the CENTRE whose log-weight is below the -12 cut on its own fails the pair cut s_i[a] + s_j[b] >= -12 for
+      // every b, s_j <= 0: skipped for the whole wave - typically three or four of the five)
+      if (a < nref_i && s_i[a] >= -12.0f) {
         float sb = 0.f, tb = 0.f;
 #pragma unroll
         for (int b = 0; b < 5; ++b) {

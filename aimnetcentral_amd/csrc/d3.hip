@@ -408,13 +408,15 @@ __global__ __launch_bounds__(256) void d3_cnforce_kernel(const float4* __restric
 int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const int* mol_idx, const float* cell, int n_cell,
                  const int* aslot, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, D3Tables T, D3Params P,
                  float cutoff, int n_atoms, float4* xs4, float* d3w, float* dEdcn, double* ecoul, float* fgrad,
-                 float* virial_atom, bool with_dsf, CoulombParams cp, const float* q, float* qbar) {
+                 float* virial_atom, bool with_dsf, CoulombParams cp, const float* q, float* qbar, bool cn_done) {
   hipLaunchKernelGGL(d3_pack_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, xw, aslot, n_atoms, xs4);
   AIMNET_LAUNCH_CHECK();
   dim3 grid(ceil_div(n_atoms, 4)), block(256);
-  hipLaunchKernelGGL(d3_cn_kernel, grid, block, 0, s, xs4, mol_idx, cell, n_cell, nb_idx, nb_shift, nb_cnt, cap, T, cutoff, n_atoms,
-                     d3w);
-  AIMNET_LAUNCH_CHECK();
+  if (!cn_done) {  // (otherwise the list build left cn_i and the weights in d3w: kernels.h, D3CnRider)
+    hipLaunchKernelGGL(d3_cn_kernel, grid, block, 0, s, xs4, mol_idx, cell, n_cell, nb_idx, nb_shift, nb_cnt, cap, T, cutoff, n_atoms,
+                       d3w);
+    AIMNET_LAUNCH_CHECK();
+  }
   const size_t lds = (size_t)4 * T.ns * 25 * sizeof(float);
 #define AIMNET_D3_PAIR(G_, S_, C_)                                                                                             \
   hipLaunchKernelGGL((d3_pair_kernel<G_, S_, C_>), grid, block, lds, s, xs4, mol_idx, cell, n_cell, nb_idx, nb_shift, nb_cnt, cap, \

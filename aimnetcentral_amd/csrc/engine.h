@@ -93,6 +93,9 @@ struct aimnet_engine {
   // AIMNET_NSE_MERGED / set_option("nse_merged"): systems of up to 1 024 atoms form the molecule sums of the NSE adjoint inside
   // build_zbar_kernel instead of by a partial-sum launch in front of it (two launches fewer per evaluation)
   int nse_merged = 1;
+  // AIMNET_D3_CN_RIDES / set_option("d3_cn_rides"): the DFT-D3 coordination numbers are formed by the cell-grid list build that serves
+  // D3 (kernels.h, D3CnRider) instead of by a pass over the finished matrix
+  int d3_cn_rides = 1;
   double* sae;
   // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row

@@ -442,6 +442,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->sums_whole = atoi(env) != 0;
     env = getenv("AIMNET_NSE_MERGED");
     if (env) e->nse_merged = atoi(env) != 0;
+    env = getenv("AIMNET_D3_CN_RIDES");
+    if (env) e->d3_cn_rides = atoi(env) != 0;
     env = getenv("AIMNET_CONV_XE");
     if (env) e->conv_xe = atoi(env);
     env = getenv("AIMNET_SPLIT_MAX");
@@ -585,6 +587,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "status_owned") e->status_owned = value != 0;
   else if (n == "sums_whole") e->sums_whole = value != 0;
   else if (n == "nse_merged") e->nse_merged = value != 0;
+  else if (n == "d3_cn_rides") e->d3_cn_rides = value != 0;
   else if (n == "split_max") e->split_max = value < 0 ? conv_split_max_default() : value;
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -613,6 +616,7 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
   else if (n == "status_owned") *value = e->status_owned;
   else if (n == "sums_whole") *value = e->sums_whole;
   else if (n == "nse_merged") *value = e->nse_merged;
+  else if (n == "d3_cn_rides") *value = e->d3_cn_rides;
   else if (n == "split_max") *value = e->split_max;
   else if (n == "p0_moments") *value = e->p0_moments ? 1 : 0;
   else if (n == "overlap_coulomb") *value = e->overlap_coulomb ? 1 : 0;
@@ -833,7 +837,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     return AIMNET_E_INVALID;
   }
   int cap_d3 = cap_lr;
-  bool d3_shared = false;
+  bool d3_shared = false, d3_cn_done = false;
   const int* sr_cnt_true = nullptr;  // != NULL: the short-range list's status words are still to be reduced (SrRiders)
   if (ext) {
     // the reference hands a caller's matrices to the model as they are (calculator.py:1069-1071): import them into the row format
@@ -882,13 +886,17 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
                     W.lr_shift, W.lr_cnt, out->status + 1, out->status + 3));
   d3_shared = d3 && d3_shares_lr_list(opt, cap_lr) && !pbc;
   if (d3 && !d3_shared) {
+    D3CnRider cnr;  // the coordination numbers ride on the (cell-grid) build of the D3 matrix
+    if (e->d3_cn_rides) {
+      cnr.aslot = W.aslot; cnr.rcov = e->d3.rcov; cnr.nref = e->d3.nref; cnr.cnref = e->d3.cnref; cnr.d3w = W.d3w;
+    }
     if (d3_shares_lr_list(opt, cap_lr)) {  // periodic DSF walks the grid: the shared buffers are free for the D3 list
       RC(launch_nlist(s, N, n_mol, mol_c, in->cell, n_cell, in->pbc, opt->d3_cutoff, -1.0f, cap_lr, N, 0, W.nl, W.d3_idx,
-                      W.d3_shift, W.d3_cnt, out->status + 4, out->status + 5));
+                      W.d3_shift, W.d3_cnt, out->status + 4, out->status + 5, nullptr, nullptr, &cnr, &d3_cn_done));
     } else {
       cap_d3 = std::max(1, opt->max_nb_d3);
       RC(launch_nlist(s, N, n_mol, mol_c, in->cell, n_cell, in->pbc, opt->d3_cutoff, -1.0f, cap_d3, N, 0, W.nl, W.d3_idx,
-                      W.d3_shift, W.d3_cnt, out->status + 4, out->status + 5));
+                      W.d3_shift, W.d3_cnt, out->status + 4, out->status + 5, nullptr, nullptr, &cnr, &d3_cn_done));
     }
   }
   }
@@ -1005,7 +1013,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       dp.r_off = opt->d3_cutoff * 1.8897261258369282f;
       RC(launch_dftd3(cs, grad, want_s, W.nl.xw, mol_c, in->cell, n_cell, W.aslot, W.d3_idx, W.d3_shift, W.d3_cnt, cap_d3,
                       e->d3, dp, opt->d3_cutoff, N, W.d3xs, W.d3w, W.dEdcn, W.ecoul, W.fgrad, W.virial_atom, dsf_in_d3, cp, q_fin,
-                      W.qbar));
+                      W.qbar, d3_cn_done));
     }
     if (grad && nq == 2) RC(launch_copy_f32(cs, W.qbar, W.qbar + N, (size_t)N));  // dE/dq_alpha = dE/dq_beta = dE/dq at this point
     return 0;

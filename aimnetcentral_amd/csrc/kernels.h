@@ -142,13 +142,25 @@ int launch_bbox(hipStream_t s, int n_mol, NlistBuffers& b);
 // build one full neighbour matrix for `cutoff` from b.xw; rows real-first; entries beyond the row
 // count are set to `fill_value` when fill_rows != 0; status[0] = max count (atomicMax), status[1] = overflow
 // bin_width > 0: (re)bin the periodic systems into slabs >= bin_width thick first; <= 0: reuse the last bins
+// DFT-D3 coordination numbers as a rider of the (cell-grid) list build that serves D3: the builder has every pair's distance in
+// hand, so cn_i and the atom's five reference weights (d3.hip, d3_cn_kernel's outputs) cost a few instructions per hit there
+// instead of a pass over the finished matrix.  d3w == NULL: none.
+struct D3CnRider {
+  const int* aslot = nullptr;    // [n_atoms] species slot
+  const float* rcov = nullptr;   // [ns]
+  const int* nref = nullptr;     // [ns]
+  const float* cnref = nullptr;  // [ns][5]
+  float* d3w = nullptr;          // [n_atoms][12]
+};
 int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, const float* cell, int n_cell,
                  const int pbc[3], float cutoff, float bin_width, int cap, int fill_value, int fill_rows,
                  NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf,
                  float4* pg = nullptr,
                  // != NULL: the status reduction is NOT launched; *status_later = the per-row counts for nlist_status_block
                  // (cellwalk.h) as riders of a later launch - valid until the next list build
-                 const int** status_later = nullptr);  // pg [n_atoms, cap] (may be NULL): also emit the pair geometry (u, d) of every entry
+                 const int** status_later = nullptr,  // pg [n_atoms, cap] (may be NULL): also emit the pair geometry (u, d) of every entry
+                 // cn != NULL and the batch is binned: the D3 coordination numbers ride (then *cn_done = true)
+                 const D3CnRider* cn = nullptr, bool* cn_done = nullptr);
 int launch_bins(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, float width, NlistBuffers& b);
 // caller-supplied neighbour matrix [n_atoms][width] (+ integer shifts [n_atoms][width][3] or NULL) -> the engine's row format
 // (valid entries compacted in order, shifts packed, optional pair geometry from the coordinates as given in b.xw); status as
@@ -326,7 +338,8 @@ struct D3Tables {  // device pointers, indexed by species SLOT (engine.hip: slot
 int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const int* mol_idx, const float* cell, int n_cell,
                  const int* aslot, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, D3Tables T, D3Params P,
                  float cutoff, int n_atoms, float4* xs4, float* d3w, float* dEdcn, double* ecoul, float* fgrad,
-                 float* virial_atom, bool with_dsf, CoulombParams cp, const float* q, float* qbar);
+                 float* virial_atom, bool with_dsf, CoulombParams cp, const float* q, float* qbar,
+                 bool cn_done = false);  // cn_done: d3w was filled by the list build (D3CnRider): no d3_cn_kernel launch
 // with_dsf: the DSF Coulomb pair sum (cutoff == cp.dsf_rc) is evaluated in the same pair pass; adds to ecoul / qbar too
 // Independent work that rides on the SR-Coulomb launch (role-dispatched blocks behind the pair blocks; a kernel boundary costs
 // 4-5 us on the device): launch_head_last's arguments (n_head_blocks = ceil(n_atoms / 4), 0 = none) and the charge stream of the

@@ -781,7 +781,7 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
                                                         int n_atoms, float cutoff, int cap, int fill_value,
                                                         int fill_rows, int* __restrict__ nb_idx,
                                                         int* __restrict__ nb_shift, int* __restrict__ nb_cnt,
-                                                        int* __restrict__ cnt_true, float4* __restrict__ pg) {
+                                                        int* __restrict__ cnt_true, float4* __restrict__ pg, D3CnRider cn) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
@@ -789,6 +789,10 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
   int* row = nb_idx + (size_t)i * cap;
   int* rsh = nb_shift + (size_t)i * cap;
   int count = 0;
+  // D3CnRider: cn_i = sum_j 1 / (1 + exp(-16 ((rcov_i + rcov_j) / d_ij [Bohr] - 1))) over the hits (d3.hip, d3_cn_kernel)
+  const int si = cn.d3w ? cn.aslot[i] : 0;
+  const float rci = cn.d3w ? cn.rcov[si] : 0.0f;
+  float cnv = 0.0f;
   __shared__ int s_runs[4][CELLWALK_RUN_INTS];
   cell_walk<true>(sys[mol_idx[i]], i, xi, yi, zi, cutoff, bin_start, xs, lane, s_runs[threadIdx.x >> 6],
             [&](float w, float rx, float ry, float rz, bool ok, int code) {
@@ -799,8 +803,36 @@ __global__ __launch_bounds__(256) void nlist_cell_kernel(const float* __restrict
                 rsh[pos] = code;
                 if (pg) pg[(size_t)i * cap + pos] = unit_and_norm(rx, ry, rz);
               }
+              if (cn.d3w && ok) {  // (wave-uniform pointer test)
+                const float d2 = fmaxf(rx * rx + ry * ry + rz * rz, 1e-24f);
+                const float d = d2 * __builtin_amdgcn_rsqf(d2);
+                const float rcj = cn.rcov[cn.aslot[__float_as_int(w)]];
+                const float arg = -16.0f * ((rci + rcj) * __builtin_amdgcn_rcpf(fmaxf(d * 1.8897261258369282f, 1e-12f)) - 1.0f);
+                cnv += __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg * 1.4426950408889634f));
+              }
               count += __popcll(mask);
             });
+  if (cn.d3w) {  // the five shifted exponents / weights of atom i (as d3_cn_kernel leaves them)
+    cnv = wave_sum(cnv);
+    const int nref = cn.nref[si];
+    float e[5], mx = -1e30f;
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+      const float dc = cnv - cn.cnref[si * 5 + a];
+      e[a] = a < nref ? -4.0f * dc * dc : -1e30f;
+      mx = fmaxf(mx, e[a]);
+    }
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+      if (lane == a) {
+        const float sa = a < nref ? e[a] - mx : -1e30f;
+        cn.d3w[(size_t)i * 12 + a] = sa;
+        cn.d3w[(size_t)i * 12 + 5 + a] = a < nref ? expf(sa) : 0.0f;
+      }
+    }
+    if (lane == 5) cn.d3w[(size_t)i * 12 + 10] = cnv;
+    if (lane == 6) cn.d3w[(size_t)i * 12 + 11] = 0.0f;
+  }
   if (fill_rows)
     for (int p = min(count, cap) + lane; p < cap; p += 64) {
       row[p] = fill_value;
@@ -913,7 +945,8 @@ __global__ __launch_bounds__(1024) void nlist_status_kernel(const int* __restric
 int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, const float* cell, int n_cell,
                  const int pbc[3], float cutoff, float bin_width, int cap, int fill_value, int fill_rows,
                  NlistBuffers& b, int* nb_idx, int* nb_shift, int* nb_cnt, int* status_max, int* status_ovf, float4* pg,
-                 const int** status_later) {
+                 const int** status_later, const D3CnRider* cn, bool* cn_done) {
+  if (cn_done) *cn_done = false;
   (void)n_cell;
   (void)pbc;
   (void)cell;
@@ -928,8 +961,10 @@ int launch_nlist(hipStream_t s, int n_atoms, int n_mol, const int* mol_idx, cons
       if (rc) return rc;
     }
     hipLaunchKernelGGL(nlist_cell_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, b.xw, mol_idx, (NlistSystem*)b.sys,
-                       b.bin_start, b.xs, n_atoms, cutoff, cap, fill_value, fill_rows, nb_idx, nb_shift, nb_cnt, cnt_true, pg);
+                       b.bin_start, b.xs, n_atoms, cutoff, cap, fill_value, fill_rows, nb_idx, nb_shift, nb_cnt, cnt_true, pg,
+                       cn ? *cn : D3CnRider{});
     AIMNET_LAUNCH_CHECK();
+    if (cn && cn->d3w && cn_done) *cn_done = true;
   }
   if (status_later) {  // the caller runs nlist_status_block over these counts as riders of a later launch (no list build in between)
     *status_later = cnt_true;

@@ -308,3 +308,21 @@ def test_molecule_sums_inside_build_zbar_agree_with_the_partial_sum_launch(hip_e
     assert np.abs(a["forces"] - b["forces"]).max() < 2e-5 * max(1.0, np.abs(b["forces"]).max())
     if "stress" in a:
         assert np.abs(a["stress"] - b["stress"]).max() < 2e-6 * max(1e-2, np.abs(b["stress"]).max())
+
+
+def test_d3_coordination_numbers_riding_on_the_matrix_build(hip_engine):
+    """Option "d3_cn_rides": cn_i and the reference weights of DFT-D3 formed inside the cell-grid build of the D3 matrix instead of by a
+    pass over it - the same terms, summed per lane in the builder's candidate order instead of the matrix' slot order."""
+    g = golden("dftd3")
+    par, tables = P._d3(12.0)
+    hip_engine.set_dftd3_tables(tables)
+    mol = np.zeros(96, dtype=np.int64)
+
+    def go():
+        return P._run_d3(hip_engine, g["pbc_coord"], g["pbc_numbers"], mol, "dsf", par, cell=g["pbc_cell"], stress=True, dsf_rc=9.0)[0]
+
+    a, b = both(hip_engine, go, "d3_cn_rides")
+    assert abs(a["energy"][0] - b["energy"][0]) < 1e-6
+    assert np.abs(a["forces"] - b["forces"]).max() < 1e-5 * max(1.0, np.abs(b["forces"]).max())
+    assert np.abs(a["stress"] - b["stress"]).max() < 1e-7
+    assert np.array_equal(a["charges"], b["charges"])

@@ -442,6 +442,7 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->sums_whole = atoi(env) != 0;
     env = getenv("AIMNET_NSE_MERGED");
     if (env) e->nse_merged = atoi(env) != 0;
+    (void)gemm_h2_set_attributes();  // AIMNET_H2_TILE / AIMNET_H2_DEEP (gemm_h2.hip)
     env = getenv("AIMNET_D3_CN_RIDES");
     if (env) e->d3_cn_rides = atoi(env) != 0;
     env = getenv("AIMNET_CONV_XE");

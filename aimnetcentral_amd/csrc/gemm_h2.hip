@@ -26,11 +26,13 @@
 namespace aimnet {
 
 constexpr int h2_passes(int rows) { return (rows + 31) / 32; }  // DMA wave-instructions per wave of the issuing group (a pass = 4 KiB = 2 strips)
-// NSA = activation ring depth.  2: the activation tile is requested ONE step ahead (weights: two).  3: two steps ahead as well -
+// NSA = activation ring depth (weights: h2_nsb).  2: the activation tile is requested ONE step ahead (weights: two).  3: two steps
+// ahead as well; 4: both three steps ahead -
 // for launches that leave CUs idle (a few hundred to ~2 000 rows): there a step is as long as the request's latency whatever the
 // tile (~0.6 us; the GEMM family costs the same 0.25 ms from 384 to 2 304 atoms), and the second step of lead takes 8 % off it;
 // on full grids the extra 20 KB of LDS cost 0.6 % (profiles/r5_size_sweep.jsonl).
-constexpr int h2_lds_bytes(int TM, int TN, int NSA) { return NSA * h2_passes(TM) * 4096 + 3 * h2_passes(TN) * 4096; }
+constexpr int h2_nsb(int NSA) { return NSA == 4 ? 4 : 3; }  // weight ring depth that goes with an activation ring depth
+constexpr int h2_lds_bytes(int TM, int TN, int NSA) { return NSA * h2_passes(TM) * 4096 + h2_nsb(NSA) * h2_passes(TN) * 4096; }
 
 #ifdef AIMNET_BF3_TIMING
 __device__ unsigned long long g_h2_stamps[1024];
@@ -145,18 +147,15 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
       __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[jj][PB], fa[i][PA], acc[SET][i][jj], 0, 0, 0);
   TS();
   // ---- prologue: A(0) by group 0; B(0), B(1) by group 1
+  constexpr int NSB = h2_nsb(NSA);  // lead of the requests: NSA - 1 steps for activation tiles, NSB - 1 for weight tiles
   if (!late) {
-    dma_a(0, 0, PZ{}, PAE{});
-    if (NSA == 3) {
-      dma_a(1, kc(1), PZ{}, PAE{});
-      wait_vm<NPA>();
-    } else {
-      wait_vm<0>();
-    }
+#pragma unroll
+    for (int t = 0; t < NSA - 1; ++t) dma_a(t, kc(t), PZ{}, PAE{});
+    wait_vm<(NSA - 2) * NPA>();  // A(0) has landed
   } else {
-    dma_b(0, 0, PZ{}, PBE{});
-    dma_b(1, kc(1), PZ{}, PBE{});
-    wait_vm<NPB>();
+#pragma unroll
+    for (int t = 0; t < NSB - 1; ++t) dma_b(t, kc(t), PZ{}, PBE{});
+    wait_vm<(NSB - 2) * NPB>();  // B(0) has landed
   }
   __builtin_amdgcn_sched_barrier(0);
   TS();
@@ -172,12 +171,11 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
     read_strips_h<0, SN, 0>(fb, ob);
     read_strips_h<0, SM, 1>(fa, oa);
     if constexpr (G == 0) {
-      if (NSA == 3) dma_a(sa == 0 ? 2 : sa - 1, kc(j + 2), PZ{}, PAE{});  // (sa + 2) % 3: two steps ahead, as the weights
-      else dma_a(sa ^ 1, kc(j + 1), PZ{}, PAE{});
+      dma_a(sa == 0 ? NSA - 1 : sa - 1, kc(j + NSA - 1), PZ{}, PAE{});  // stage (sa + NSA - 1) % NSA held A(j - 1)
       wait_lgkm<0>();
     } else {
-      dma_b(sb == 0 ? 2 : sb - 1, kc(j + 2), PZ{}, PBE{});  // (sb + 2) % 3
-      wait_vm<NPB>();  // the weight tile of step j+1 (requested one L earlier) has landed
+      dma_b(sb == 0 ? NSB - 1 : sb - 1, kc(j + NSB - 1), PZ{}, PBE{});  // stage (sb + NSB - 1) % NSB
+      wait_vm<(NSB - 2) * NPB>();  // the weight tile of step j+1 has landed (the later requests may be outstanding)
       wait_lgkm<0>();
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -189,10 +187,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
     AIMNET_H2_PRODUCT(PAR, 0, 0)
     AIMNET_H2_PRODUCT(2, 1, 0)
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (G == 0) {  // the activation tile of step j+1 has landed (requested in L(j-1); NSA = 2: in L(j))
-      if (NSA == 3) wait_vm<NPA>();
-      else wait_vm<0>();
-    }
+    if constexpr (G == 0) wait_vm<(NSA - 2) * NPA>();  // the activation tile of step j+1 has landed
     __builtin_amdgcn_sched_barrier(0);
   };
   auto bar = [&]() __attribute__((always_inline)) {
@@ -204,8 +199,8 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
   auto run = [&](auto g_c) __attribute__((always_inline)) {
     int sa = 0, sb = 0, j = 0;
     auto next = [&]() __attribute__((always_inline)) {
-      sa = NSA == 3 ? (sa == 2 ? 0 : sa + 1) : sa ^ 1;
-      sb = sb == 2 ? 0 : sb + 1;
+      sa = sa == NSA - 1 ? 0 : sa + 1;
+      sb = sb == NSB - 1 ? 0 : sb + 1;
     };
     for (; j + 1 < nk; j += 2) {
       seg_load(j, sa, sb, g_c);
@@ -313,15 +308,16 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const unsigned short* _
 // (A one-instruction-stream-per-wave schedule - fragments of step j+1 fetched into the registers step j's products release, one
 // barrier per step - was built and measured EQUAL, step 1.3452 vs 1.3456 ms: 60 matrix instructions per SIMD and step at the
 // 16x16x32 shape's own rate are 1 164 of the ~1 500 cycles either schedule takes; profiles/r5_gemm_h2.md.  Removed; commit d9e6536.)
+static int g_h2_deep = 4;  // AIMNET_H2_DEEP: ring depth (2, 3 or 4) of launches that fill at most half of the CUs
 template <int SM, int SN, int WN>
 static int launch_h2(hipStream_t stream, int epi, bool out3, const unsigned short* A3, int lda3, const unsigned short* Bt, int ldb,
                        int M, int N, int K, const float* bias, float* C, unsigned short* C3, int ldc3, float* D, int ldc,
                        const int* brow, int ldbias, int alt) {
   constexpr int WM = 8 / WN, TM = 16 * SM * WM, TN = 16 * SN * WN;
   const int tiles = ceil_div(M, TM) * ceil_div(N, TN);
-  static_assert(h2_lds_bytes(TM, TN, 3) <= 160 * 1024, "LDS");
-  const bool deep = 2 * tiles <= device_cus();  // at most half of the CUs busy (see NSA)
-  const size_t lds = (size_t)(deep ? h2_lds_bytes(TM, TN, 3) : h2_lds_bytes(TM, TN, 2));
+  static_assert(h2_lds_bytes(TM, TN, 4) <= 160 * 1024, "LDS");
+  const int deep = 2 * tiles <= device_cus() ? g_h2_deep : 2;  // at most half of the CUs busy: longer request lead (see NSA)
+  const size_t lds = (size_t)(deep == 4 ? h2_lds_bytes(TM, TN, 4) : deep == 3 ? h2_lds_bytes(TM, TN, 3) : h2_lds_bytes(TM, TN, 2));
   dim3 grid(tiles), block(512);
 #define AIMNET_H2_LAUNCH(E, O3)                                                                                            \
   {                                                                                                                          \
@@ -331,8 +327,13 @@ static int launch_h2(hipStream_t stream, int epi, bool out3, const unsigned shor
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
       AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_h2_kernel<E, SM, SN, WN, O3, 3>,                             \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
+      AIMNET_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_h2_kernel<E, SM, SN, WN, O3, 4>,                             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
     }                                                                                                                        \
-    if (deep)                                                                                                                \
+    if (deep == 4)                                                                                                           \
+      hipLaunchKernelGGL((gemm_h2_kernel<E, SM, SN, WN, O3, 4>), grid, block, lds, stream, A3, lda3, Bt, ldb, M, N, K,    \
+                         bias, C, C3, ldc3, D, ldc, brow, ldbias, alt);                                                      \
+    else if (deep == 3)                                                                                                      \
       hipLaunchKernelGGL((gemm_h2_kernel<E, SM, SN, WN, O3, 3>), grid, block, lds, stream, A3, lda3, Bt, ldb, M, N, K,    \
                          bias, C, C3, ldc3, D, ldc, brow, ldbias, alt);                                                      \
     else                                                                                                                     \
@@ -486,6 +487,8 @@ bool split_h2_host(const float* w, int rows, int K, unsigned short* out, int mod
 int gemm_h2_set_attributes() {
   const char* env = getenv("AIMNET_H2_TILE");
   g_h2_force_tile = env ? atoi(env) : 0;
+  env = getenv("AIMNET_H2_DEEP");
+  if (env) g_h2_deep = atoi(env) == 3 ? 3 : atoi(env) == 2 ? 2 : 4;
   return 0;
 }
 

@@ -409,7 +409,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=60,
+                    help="untimed steps in front of the timed region (default 60 = ~80 ms: the five regions of timed_region_repeat show the "
+                         "first ~40 steps after an idle phase running 2 - 3 % slower than the following ones)")
     ap.add_argument("--workload", default="pbc10k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-repeat", action="store_true", help="skip the four extra repeats of the timed region (timed_region_repeat)")

@@ -7,15 +7,16 @@ from aimnetcentral_amd.engine import HipEngine
 eng = HipEngine(loader.synthetic_spec(0), "cuda:0")
 dev = eng.device
 ref = None
+METHOD = os.environ.get("COULOMB", "dsf")
 for rep in ((7, 3, 5), (14, 6, 10), (21, 9, 15)):
     c, z, cell = workloads.glucose_supercell(rep)
     n = len(z)
     args = (torch.from_numpy(c.astype(np.float32)).to(dev), torch.from_numpy(z).to(dev), torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(1, device=dev))
     cl = torch.from_numpy(cell.astype(np.float32)).to(dev)
-    r = eng.eval(*args, cell=cl, forces=True, stress=True, coulomb="dsf")
+    r = eng.eval(*args, cell=cl, forces=True, stress=True, coulomb=METHOD)
     torch.cuda.synchronize()
     t0 = time.time()
-    for _ in range(3): r = eng.eval(*args, cell=cl, forces=True, stress=True, coulomb="dsf")
+    for _ in range(3): r = eng.eval(*args, cell=cl, forces=True, stress=True, coulomb=METHOD)
     torch.cuda.synchronize(); dt = (time.time() - t0) / 3
     e_cell = float(r["energy"][0]) / (n / 96)
     f = r["forces"].cpu().numpy()

@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = (
     "aimnet_debug_gemm_bf3a",
     "aimnet_debug_split_h2",
     "aimnet_debug_gemm_h2",
+    "aimnet_engine_debug_mlp_sweep",
     "aimnet_debug_pme_recip",
     "aimnet_debug_mfma4_probe",
     "aimnet_engine_set_option",
@@ -222,6 +223,9 @@ def load() -> C.CDLL:
     lib.aimnet_debug_split_h2.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
     lib.aimnet_debug_gemm_h2.restype = C.c_int
     lib.aimnet_debug_gemm_h2.argtypes = list(lib.aimnet_debug_gemm_bf3a.argtypes)
+    lib.aimnet_engine_debug_mlp_sweep.restype = C.c_int
+    lib.aimnet_engine_debug_mlp_sweep.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.POINTER(vp), C.POINTER(vp),
+                                                  C.POINTER(vp), C.POINTER(C.c_int), vp]
     lib.aimnet_debug_pme_recip.restype = C.c_int
     lib.aimnet_debug_pme_recip.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, C.POINTER(C.c_double), vp]
     lib.aimnet_debug_mfma4_probe.restype = C.c_int

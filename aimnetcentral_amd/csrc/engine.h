@@ -26,6 +26,19 @@ struct Layer {
   unsigned short* wt3a = nullptr;  // which accumulate even / odd k-steps separately and subtract (no data-dependent split point)
   unsigned short* w2a = nullptr;   // the same two operands in the fp16x2-split form of gemm_h2.hip ("h2", H2_WEIGHT: hi planes of the
   unsigned short* wt2a = nullptr;  // odd k-blocks negated; 2 * k_in resp. 2 * k_out 16-bit elements per row); NULL: out of fp16's range
+  std::vector<unsigned short> h_w2a, h_wt2a;  // host copies of the two, kept until the chain plans are packed (engine create)
+};
+
+// One MLP sweep as a single launch of gemm_chain.hip: the instantiated shape and, per pass, the packed weight stream
+struct ChainPlan {
+  int shape = -1;  // -1: this sweep takes the per-layer launches
+  int n_pass = 0;
+  struct Pass {
+    void* w;     // packed stream (device)
+    int layer;   // MLP layer this pass belongs to
+    int n0;      // first output column of the pass inside the layer's output
+    int ncols;   // output columns of the pass
+  } pass[CHAIN_MAX_PASS];
 };
 
 struct View {
@@ -36,6 +49,7 @@ struct View {
 }  // namespace aimnet
 
 using aimnet::BasisParams;
+using aimnet::ChainPlan;
 using aimnet::D3Tables;
 using aimnet::Layer;
 using aimnet::View;
@@ -93,6 +107,12 @@ struct aimnet_engine {
   // AIMNET_NSE_MERGED / set_option("nse_merged"): systems of up to 1 024 atoms form the molecule sums of the NSE adjoint inside
   // build_zbar_kernel instead of by a partial-sum launch in front of it (two launches fewer per evaluation)
   int nse_merged = 1;
+  // AIMNET_GEMM_CHAIN / set_option("gemm_chain"): with fp16x2-split activations every MLP sweep (forward or backward, one per pass)
+  // is ONE launch of gemm_chain.hip - a block owns 48 rows and the full width of every layer, the hidden activations stay in LDS -
+  // instead of one GEMM launch per layer (bitwise-equal results).  0 = the per-layer launches.  chain_fwd[p][e]: e = 1 with the
+  // embedding block of pass 0 folded into the bias table; chain_bwd[p][m]: m = 1 when only the conv columns of xbar_0 are formed.
+  int gemm_chain = 1;
+  ChainPlan chain_fwd[AIMNET_MAX_PASS][2], chain_bwd[AIMNET_MAX_PASS][2];
   // AIMNET_D3_CN_RIDES / set_option("d3_cn_rides"): the DFT-D3 coordination numbers are formed by the cell-grid list build that serves
   // D3 (kernels.h, D3CnRider) instead of by a pass over the finished matrix
   int d3_cn_rides = 1;

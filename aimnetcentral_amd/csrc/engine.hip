@@ -102,11 +102,70 @@ int upload_layer(aimnet_engine* e, const float* w, const float* b, int n_in, int
     std::vector<unsigned short> s2(wp.size() * 2);
     bool fits = split_h2_host(wp.data(), L->k_out, L->k_in, s2.data(), H2_WEIGHT);
     if ((rc = dev_upload(e, s2.data(), s2.size(), &L->w2a))) return rc;
+    L->h_w2a = s2;
     fits = split_h2_host(wtp.data(), L->k_in, L->k_out, s2.data(), H2_WEIGHT) && fits;
     if ((rc = dev_upload(e, s2.data(), s2.size(), &L->wt2a))) return rc;
+    L->h_wt2a = s2;
     if (!fits) e->h2_fits = false;
   }
   return 0;
+}
+
+
+// ---- chain plans (gemm_chain.hip): match an MLP sweep against the instantiated shapes and pack its weight streams ----------------
+constexpr int CHAIN_NW = 8;  // waves per block of the instantiated shapes
+struct PassDesc { int layer, n0, ncols, nk, nt, kb0; bool fwd; };
+int chain_build(aimnet_engine* e, const std::vector<Layer>& Ls, const std::vector<PassDesc>& ps, bool bwd, int n_hidden, ChainPlan* plan) {
+  plan->shape = -1;
+  if (ps.empty() || (int)ps.size() > CHAIN_MAX_PASS) return 0;
+  int nk[CHAIN_MAX_PASS] = {}, nt[CHAIN_MAX_PASS] = {};
+  for (size_t i = 0; i < ps.size(); ++i) { nk[i] = ps[i].nk; nt[i] = ps[i].nt; }
+  if (ps[0].nk > CHAIN_MAX_KB) return 0;
+  const int shape = chain_find_shape(CHAIN_NW, bwd, (int)ps.size(), nk, nt, n_hidden);
+  if (shape < 0) return 0;
+  std::vector<unsigned short> packed;
+  for (size_t i = 0; i < ps.size(); ++i) {
+    const PassDesc& d = ps[i];
+    const Layer& L = Ls[d.layer];
+    // forward: rows of W [k_out][k_in]; backward: rows of W^T [k_in][k_out]
+    const std::vector<unsigned short>& w2 = d.fwd ? L.h_w2a : L.h_wt2a;
+    const int n_rows = d.fwd ? L.k_out : L.k_in, ldk = d.fwd ? L.k_in : L.k_out;
+    if (w2.empty()) return 0;
+    chain_pack_weights(w2.data(), std::min(n_rows, d.n0 + d.ncols), ldk, d.n0, CHAIN_NW, d.nt, d.kb0, d.nk, packed);
+    unsigned short* dev = nullptr;
+    int rc = dev_upload(e, packed.data(), packed.size(), &dev);
+    if (rc) return rc;
+    plan->pass[i].w = dev;
+    plan->pass[i].layer = d.layer;
+    plan->pass[i].n0 = d.n0;
+    plan->pass[i].ncols = d.ncols;
+  }
+  plan->n_pass = (int)ps.size();
+  plan->shape = shape;
+  return 0;
+}
+// forward sweep of one MLP; k0: leading input columns of the first layer that are skipped (the embedding block behind the bias table)
+int chain_plan_fwd(aimnet_engine* e, const std::vector<Layer>& Ls, int k0, ChainPlan* plan) {
+  std::vector<PassDesc> ps;
+  const int nl = (int)Ls.size();
+  for (int l = 0; l < nl; ++l) {
+    const int K = Ls[l].k_in - (l == 0 ? k0 : 0), N = Ls[l].k_out;
+    if (l > 0 && Ls[l].k_in != Ls[l - 1].k_out) return 0;
+    ps.push_back(PassDesc{l, 0, N, K / 32, ceil_div(N / 16, CHAIN_NW), l == 0 ? k0 / 32 : 0, true});
+  }
+  return chain_build(e, Ls, ps, false, nl - 1, plan);
+}
+// backward sweep: zbar (k_out of the last layer) -> ... -> xbar (k_in of the first layer from column n0 on; wide outputs in column passes)
+int chain_plan_bwd(aimnet_engine* e, const std::vector<Layer>& Ls, int n0, ChainPlan* plan) {
+  std::vector<PassDesc> ps;
+  const int nl = (int)Ls.size();
+  for (int l = nl - 1; l >= 1; --l) ps.push_back(PassDesc{l, 0, Ls[l].k_in, Ls[l].k_out / 32, ceil_div(Ls[l].k_in / 16, CHAIN_NW), 0, false});
+  const int N = Ls[0].k_in - n0, tiles = N / 16;
+  const int n_col = ceil_div(tiles, 4 * CHAIN_NW);  // column passes of the last product (<= 4 tile slots per wave)
+  if (tiles % n_col) return 0;
+  for (int c = 0; c < n_col; ++c)
+    ps.push_back(PassDesc{0, n0 + c * (N / n_col), N / n_col, Ls[0].k_out / 32, ceil_div(tiles / n_col, CHAIN_NW), 0, false});
+  return chain_build(e, Ls, ps, true, nl - 1, plan);
 }
 
 }  // namespace
@@ -155,6 +214,114 @@ bool presplit_active(const aimnet_engine* e, int N) {
 int split_format(const aimnet_engine* e, int n_rows) {
   if (!presplit_active(e, n_rows)) return 0;
   return (e->gemm_h2 && e->h2_fits) ? 2 : 1;
+}
+
+// ---- one MLP sweep on split activations (fmt 1 = bf16x3, 2 = fp16x2): ONE launch of gemm_chain.hip where the pass has a plan
+// (fp16x2 form only), else one launch per layer.  x: the input rows in split form; H[l]: layer outputs (hidden ones in split form -
+// the chain does not write them -, the last in fp32, or in split form for the fused energy head: `split_last`); D[l]: GELU' (fp32).
+int mlp_sweep_fwd(const aimnet_engine* e, hipStream_t s, int sfmt, int p, int N, const int* numbers, const float* x, float* const* H,
+                  float* const* D, bool split_last, bool chain) {
+  const aimnet_arch& ar = e->arch;
+  const std::vector<Layer>& Ls = e->mlp[p];
+  const int nl = (int)Ls.size(), pm = sfmt == 2 ? 2 : 3;
+  const bool emb0 = p == 0 && e->emb_bias && e->emb_bias0;
+  const ChainPlan& cf = e->chain_fwd[p][emb0 ? 1 : 0];
+  if (sfmt == 2 && chain && cf.shape >= 0) {
+    ChainArgs ca{};
+    ca.x = reinterpret_cast<const unsigned short*>(x) + (emb0 ? (256 / 32) * 64 : 0);
+    ca.ldx = 2 * Ls[0].k_in;
+    ca.M = N;
+    for (int i = 0; i < cf.n_pass; ++i) {
+      const int l = cf.pass[i].layer, ko = Ls[l].k_out;
+      const bool last = l == nl - 1, linear = last && ar.last_linear[p];
+      ChainPass& cp = ca.p[i];
+      cp.w = cf.pass[i].w;
+      cp.kb0 = 0;
+      cp.ncols = cf.pass[i].ncols;
+      cp.epi = linear ? CH_BIAS_F32 : (last && split_last) ? CH_GELU_H2G : CH_GELU_F32;
+      cp.bias = (l == 0 && emb0) ? e->emb_bias0 : Ls[l].b;
+      cp.brow = (l == 0 && emb0) ? numbers : nullptr;
+      cp.ldbias = ko;
+      cp.D = linear ? nullptr : D[l];
+      cp.ldd = ko;
+      cp.C = H[l];
+      cp.ldc = ko;
+      static const bool dump = getenv("AIMNET_CHAIN_DUMP") != nullptr;  // debug: hidden activations are copied out of LDS too
+      cp.C2 = (last || dump) ? reinterpret_cast<unsigned short*>(H[l]) : nullptr;
+      cp.ldc2 = 2 * ko;
+    }
+    return launch_gemm_chain(s, cf.shape, ca);
+  }
+  const unsigned short* a3 = reinterpret_cast<const unsigned short*>(x);
+  int lda3 = pm * Ls[0].k_in;
+  for (int l = 0; l < nl; ++l) {
+    const bool last = l == nl - 1, linear = last && ar.last_linear[p];
+    const bool f32out = last && !split_last;  // the last layer's output is read by pointwise kernels - or by the fused head
+    const int epi = linear ? EPI_BIAS : EPI_BIAS_GELU, ko = Ls[l].k_out;
+    float* Cf = f32out ? H[l] : nullptr;
+    unsigned short* C3 = f32out ? nullptr : reinterpret_cast<unsigned short*>(H[l]);
+    float* Dl = linear ? nullptr : D[l];
+    int rc;
+    if (l == 0 && emb0)
+      rc = mlp_gemm3(e, s, sfmt, epi, !f32out, a3, lda3, Ls[l], true, 256, 0, N, ko, Ls[l].k_in - 256, e->emb_bias0, Cf, C3, pm * ko, Dl, ko,
+                     numbers, ko);
+    else
+      rc = mlp_gemm3(e, s, sfmt, epi, !f32out, a3, lda3, Ls[l], true, 0, 0, N, ko, Ls[l].k_in, Ls[l].b, Cf, C3, pm * ko, Dl, ko);
+    if (rc) return rc;
+    a3 = C3;
+    lda3 = pm * ko;
+  }
+  return 0;
+}
+// adjoint sweep: zcur = adjoint of the last layer's pre-activation (split form, GELU' applied) -> zcur = xbar (fp32, row stride
+// k_in of the first layer; conv_only: only its columns 256.. are formed).  zcur / znext are the ping-pong buffers.
+int mlp_sweep_bwd(const aimnet_engine* e, hipStream_t s, int sfmt, int p, int N, bool conv_only, float*& zcur, float*& znext,
+                  float* const* D, bool chain) {
+  const std::vector<Layer>& Ls = e->mlp[p];
+  const int nl = (int)Ls.size(), pm = sfmt == 2 ? 2 : 3;
+  int ld = Ls[nl - 1].k_out;
+  const ChainPlan& cb = e->chain_bwd[p][(p == 0 && conv_only) ? 1 : 0];
+  if (sfmt == 2 && chain && cb.shape >= 0 && !(conv_only && p != 0)) {
+    ChainArgs ca{};
+    ca.x = reinterpret_cast<const unsigned short*>(zcur);
+    ca.ldx = 2 * ld;
+    ca.M = N;
+    for (int i = 0; i < cb.n_pass; ++i) {
+      const int l = cb.pass[i].layer;
+      ChainPass& cp = ca.p[i];
+      cp.w = cb.pass[i].w;
+      cp.kb0 = 0;
+      cp.ncols = cb.pass[i].ncols;
+      if (l > 0) {  // adjoint of a hidden activation: x GELU'(z_{l-1}), stays in LDS
+        cp.D = D[l - 1];
+        cp.ldd = Ls[l].k_in;
+      } else {  // xbar (fp32), in column passes
+        cp.C = znext + cb.pass[i].n0;
+        cp.ldc = Ls[0].k_in;
+      }
+    }
+    int rc = launch_gemm_chain(s, cb.shape, ca);
+    std::swap(zcur, znext);
+    return rc;
+  }
+  for (int l = nl - 1; l >= 0; --l) {
+    const Layer& L = Ls[l];
+    const unsigned short* z3 = reinterpret_cast<const unsigned short*>(zcur);
+    int rc;
+    if (l > 0)
+      rc = mlp_gemm3(e, s, sfmt, EPI_MUL, true, z3, pm * ld, L, false, 0, 0, N, L.k_in, L.k_out, nullptr, nullptr,
+                     reinterpret_cast<unsigned short*>(znext), pm * L.k_in, D[l - 1], L.k_in);
+    else if (conv_only)
+      rc = mlp_gemm3(e, s, sfmt, EPI_NONE, false, z3, pm * ld, L, false, 0, 256, N, L.k_in - 256, L.k_out, nullptr, znext + 256, nullptr, 0,
+                     nullptr, L.k_in);
+    else
+      rc = mlp_gemm3(e, s, sfmt, EPI_NONE, false, z3, pm * ld, L, false, 0, 0, N, L.k_in, L.k_out, nullptr, znext, nullptr, 0, nullptr,
+                     L.k_in);
+    if (rc) return rc;
+    std::swap(zcur, znext);
+    ld = L.k_in;
+  }
+  return 0;
 }
 }  // namespace aimnet
 
@@ -314,7 +481,8 @@ void layout(const aimnet_engine* e, int N, int n_mol, const aimnet_eval_options*
       // (pre-split activations: the last pass' output feeds the fused head in split form - 6 bytes per element)
       const size_t own = (!hidden && p == np - 1) ? n * ld * ps_num / 2 : n * ld;
       W.H[p][l] = (hidden && share) ? h_shared[l & 1] : c.take<float>(own, name, ld);
-      W.D[p][l] = grad ? c.take<float>(n * ld) : nullptr;
+      snprintf(name, sizeof name, "d%d_%d", p, (int)l);
+      W.D[p][l] = grad ? c.take<float>(n * ld, name, ld) : nullptr;
     }
     W.Fm[p] = c.take<float>((size_t)n_mol * e->nq);
     W.Dm[p] = c.take<float>((size_t)n_mol * e->nq);
@@ -442,6 +610,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->sums_whole = atoi(env) != 0;
     env = getenv("AIMNET_NSE_MERGED");
     if (env) e->nse_merged = atoi(env) != 0;
+    env = getenv("AIMNET_GEMM_CHAIN");
+    if (env) e->gemm_chain = atoi(env) != 0;
     (void)gemm_h2_set_attributes();  // AIMNET_H2_TILE / AIMNET_H2_DEEP (gemm_h2.hip)
     env = getenv("AIMNET_D3_CN_RIDES");
     if (env) e->d3_cn_rides = atoi(env) != 0;
@@ -505,6 +675,23 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     e->head.push_back(L);
     if ((rc = dev_upload(e, w->head_w[l], (size_t)L.n_in, &e->head_w_last))) goto fail;
     if ((rc = dev_upload(e, w->head_b[l], (size_t)1, &e->head_b_last))) goto fail;
+  }
+  if (e->h2_fits) {  // one-launch MLP sweeps (gemm_chain.hip) where the layer sizes match an instantiated shape
+    for (int p = 0; p < arch->n_pass; ++p) {
+      if ((rc = chain_plan_fwd(e, e->mlp[p], 0, &e->chain_fwd[p][0]))) goto fail;
+      if ((rc = chain_plan_bwd(e, e->mlp[p], 0, &e->chain_bwd[p][0]))) goto fail;
+      if (p == 0 && e->emb_bias0 && (rc = chain_plan_fwd(e, e->mlp[p], AG, &e->chain_fwd[p][1]))) goto fail;
+      if (p == 0 && (rc = chain_plan_bwd(e, e->mlp[p], AG, &e->chain_bwd[p][1]))) goto fail;
+    }
+  }
+  for (int p = 0; p < arch->n_pass; ++p)
+    for (Layer& L : e->mlp[p]) {
+      std::vector<unsigned short>().swap(L.h_w2a);
+      std::vector<unsigned short>().swap(L.h_wt2a);
+    }
+  for (Layer& L : e->head) {
+    std::vector<unsigned short>().swap(L.h_w2a);
+    std::vector<unsigned short>().swap(L.h_wt2a);
   }
   e->bp.rc = arch->rc;
   e->bp.eta = arch->eta;
@@ -588,6 +775,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "status_owned") e->status_owned = value != 0;
   else if (n == "sums_whole") e->sums_whole = value != 0;
   else if (n == "nse_merged") e->nse_merged = value != 0;
+  else if (n == "gemm_chain") e->gemm_chain = value != 0;
   else if (n == "d3_cn_rides") e->d3_cn_rides = value != 0;
   else if (n == "split_max") e->split_max = value < 0 ? conv_split_max_default() : value;
   else if (n == "p0_moments") e->p0_moments = value != 0;
@@ -617,6 +805,7 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
   else if (n == "status_owned") *value = e->status_owned;
   else if (n == "sums_whole") *value = e->sums_whole;
   else if (n == "nse_merged") *value = e->nse_merged;
+  else if (n == "gemm_chain") *value = e->gemm_chain;
   else if (n == "d3_cn_rides") *value = e->d3_cn_rides;
   else if (n == "split_max") *value = e->split_max;
   else if (n == "p0_moments") *value = e->p0_moments ? 1 : 0;
@@ -1035,24 +1224,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const float* hin = W.x[p];
     int ld_in = Ls[0].k_in;
     RC(prof_mark(e, s, FAM_GEMM));
-    if (ps) {  // activations in split form: rows from conv_fwd, hidden layers from the GELU epilogues; the last layer's output is fp32
-      const unsigned short* a3 = reinterpret_cast<const unsigned short*>(W.x[p]);
-      int lda3 = pm * Ls[0].k_in;
-      for (int l = 0; l < nl; ++l) {
-        const bool last = l == nl - 1, linear = last && ar.last_linear[p];
-        const bool f32out = last && !(hfused && p == np - 1);  // the last layer's output is read by pointwise kernels - or by the fused head
-        const int epi = linear ? EPI_BIAS : EPI_BIAS_GELU, ko = Ls[l].k_out;
-        float* Cf = f32out ? W.H[p][l] : nullptr;
-        unsigned short* C3 = f32out ? nullptr : reinterpret_cast<unsigned short*>(W.H[p][l]);
-        float* Dl = linear ? nullptr : W.D[p][l];
-        if (p == 0 && l == 0 && e->emb_bias && e->emb_bias0)
-          RC(mlp_gemm3(e, s, sfmt, epi, !f32out, a3, lda3, Ls[l], true, 256, 0, N, ko, Ls[l].k_in - 256, e->emb_bias0, Cf, C3, pm * ko, Dl, ko,
-                       in->numbers, ko));
-        else
-          RC(mlp_gemm3(e, s, sfmt, epi, !f32out, a3, lda3, Ls[l], true, 0, 0, N, ko, Ls[l].k_in, Ls[l].b, Cf, C3, pm * ko, Dl, ko));
-        a3 = C3;
-        lda3 = pm * ko;
-      }
+    if (ps) {  // activations in split form: one launch per MLP (gemm_chain.hip) or one per layer
+      RC(mlp_sweep_fwd(e, s, sfmt, p, N, in->numbers, W.x[p], W.H[p], W.D[p], hfused && p == np - 1, e->gemm_chain != 0));
     } else
     for (int l = 0; l < nl; ++l) {
       const bool linear = (l == nl - 1) && ar.last_linear[p];
@@ -1186,22 +1359,9 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const int nl = (int)Ls.size();
     int ld = Ls[nl - 1].k_out;  // zcur = adjoint of the last layer's pre-activation (GELU' already applied)
     RC(prof_mark(e, s, FAM_GEMM));
-    if (ps) {  // zcur holds the adjoint in split form; every layer but the first hands a split adjoint on, the first writes xbar (fp32)
-      for (int l = nl - 1; l >= 0; --l) {
-        const Layer& L = Ls[l];
-        const unsigned short* z3 = reinterpret_cast<const unsigned short*>(zcur);
-        if (l > 0)
-          RC(mlp_gemm3(e, s, sfmt, EPI_MUL, true, z3, pm * ld, L, false, 0, 0, N, L.k_in, L.k_out, nullptr, nullptr,
-                       reinterpret_cast<unsigned short*>(znext), pm * L.k_in, W.D[p][l - 1], L.k_in));
-        else if (p == 0 && p0m)
-          RC(mlp_gemm3(e, s, sfmt, EPI_NONE, false, z3, pm * ld, L, false, 0, 256, N, L.k_in - 256, L.k_out, nullptr, znext + 256, nullptr, 0,
-                       nullptr, L.k_in));
-        else
-          RC(mlp_gemm3(e, s, sfmt, EPI_NONE, false, z3, pm * ld, L, false, 0, 0, N, L.k_in, L.k_out, nullptr, znext, nullptr, 0, nullptr,
-                       L.k_in));
-        std::swap(zcur, znext);
-        ld = L.k_in;
-      }
+    if (ps) {  // zcur holds the adjoint in split form; the sweep leaves xbar (fp32) in zcur
+      RC(mlp_sweep_bwd(e, s, sfmt, p, N, p == 0 && p0m, zcur, znext, W.D[p], e->gemm_chain != 0));
+      ld = Ls[0].k_in;
     } else
     for (int l = nl - 1; l >= 0; --l) {
       const Layer& L = Ls[l];
@@ -1391,6 +1551,27 @@ int aimnet_debug_gemm_h2(int cfg, int epi, int out2, const void* A2, int lda2, c
   return launch_gemm_h2_cfg((hipStream_t)hip_stream, cfg, epi, out2 != 0, (const unsigned short*)A2, lda2, (const unsigned short*)Bt2,
                             ldb, M, N, K, bias, C, (unsigned short*)C2, ldc2, D, ldc, nullptr, 0, alt);
 }
+int aimnet_engine_debug_mlp_sweep(aimnet_engine* e, int pass, int backward, int chain, int flag, const void* x2, int M,
+                                  const int32_t* numbers, float* const* H, float* const* D, float* const* zb, int* which,
+                                  void* hip_stream) {
+  using namespace aimnet;
+  if (!e || pass < 0 || pass >= e->arch.n_pass || M <= 0 || !D) return AIMNET_E_INVALID;
+  if (!(e->gemm_h2 && e->h2_fits)) {
+    set_last_error("debug_mlp_sweep: the fp16x2 operand form is off");
+    return AIMNET_E_INVALID;
+  }
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (!backward) {
+    if (!x2 || !H) return AIMNET_E_INVALID;
+    return mlp_sweep_fwd(e, s, 2, pass, M, numbers, reinterpret_cast<const float*>(x2), H, D, flag != 0, chain != 0);
+  }
+  if (!zb || !zb[0] || !zb[1] || !which) return AIMNET_E_INVALID;
+  float *zcur = zb[0], *znext = zb[1];
+  const int rc = mlp_sweep_bwd(e, s, 2, pass, M, flag != 0, zcur, znext, D, chain != 0);
+  *which = zcur == zb[0] ? 0 : 1;
+  return rc;
+}
+
 #ifdef AIMNET_PREP_TIMING
 int aimnet_debug_prep_stamps(unsigned long long* host16) { return aimnet::prep_read_stamps(host16); }
 #endif

@@ -35,6 +35,10 @@ constexpr float H2_MAX = 65504.0f;
 
 // two fp32 -> packed hi pair, packed (scaled) lo pair; lo_scale = +-4096 (the sign of the k-block for activations)
 __device__ __forceinline__ void split2_pair(float a, float b, float lo_scale, unsigned& hi, unsigned& lo) {
+  // (no contraction: with a producer `a = p * q` inlined in front, `a - hi` would become fma(p, q, -hi) - the residual of the UNROUNDED
+  // product - in one kernel and not in another; the split is defined on the fp32 value, so that kernels that compute the same value
+  // write the same two planes: gemm_chain.hip is bitwise gemm_h2.hip)
+#pragma clang fp contract(off)
   const f32x2 x = {a, b};
   const f16x2 h = __builtin_convertvector(x, f16x2);
   const f32x2 r = (x - __builtin_convertvector(h, f32x2)) * lo_scale;

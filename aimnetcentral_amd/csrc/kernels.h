@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace aimnet {
 
 // ---- gemm.hip ---------------------------------------------------------------------------------
@@ -64,6 +66,38 @@ int launch_split_h2(hipStream_t s, const float* src, int ld, int M, int K, unsig
 #ifdef AIMNET_BF3_TIMING
 int gemm_h2_read_stamps(unsigned long long* host1024);
 #endif
+
+// ---- gemm_chain.hip: one MLP (forward or backward sweep) as ONE launch.  A block owns a panel of CHAIN_ROWS rows and the full width
+// of every layer; hidden activations stay in LDS (h2 form), weights stream L2 -> registers in a host-packed fragment order
+// (chain_pack_weights).  Same products and accumulation order as gemm_h2.hip: bitwise-equal results.
+constexpr int CHAIN_ROWS = 48, CHAIN_MAX_KB = 23, CHAIN_MAX_PASS = 5;
+enum { CH_BIAS_F32 = 0, CH_GELU_F32 = 1, CH_GELU_H2G = 2 };  // epilogue of a forward chain's LAST pass (hidden passes: GELU -> LDS)
+struct ChainPass {          // a layer, or a column range of a wide layer
+  const void* w;            // packed weight stream of this pass (chain_pack_weights)
+  int kb0;                  // first k-block of the LDS operand this pass reads (0)
+  int ncols;                // real output columns (a multiple of 16; of 32 when the output is the next pass' operand)
+  int epi;                  // CH_* (last forward pass only)
+  const float* bias;        // forward: [ncols], or a [64][ldbias] table indexed by brow[row]
+  const int* brow;
+  int ldbias;
+  float* D;                 // forward: GELU' out (may be NULL); backward hidden passes: GELU' in; [M][ldd] at this pass' first column
+  int ldd;
+  float* C;                 // fp32 output of a non-LDS pass, at this pass' first column
+  int ldc;
+  unsigned short* C2;       // CH_GELU_H2G: the output in h2 form [M][ldc2]
+  int ldc2;
+};
+struct ChainArgs {
+  const unsigned short* x;  // input rows, h2 form, at the first k-block pass 0 reads; ldx 16-bit elements per row
+  int ldx, M;
+  ChainPass p[CHAIN_MAX_PASS];
+};
+// id of the instantiated shape that has these k-steps / tile slots per pass (-1: none - use the per-layer launches)
+int chain_find_shape(int n_waves, bool bwd, int n_pass, const int* nk, const int* nt, int n_hidden);
+int launch_gemm_chain(hipStream_t stream, int shape, const ChainArgs& a);
+// columns n0 .. n0 + 16 nw nt - 1 (= rows of the h2 weight matrix w2 [n_rows][2 ldk], H2_WEIGHT form; rows >= n_rows: zeros), k-blocks
+// kb0 .. kb0 + nk - 1, in the order the kernel consumes them
+void chain_pack_weights(const unsigned short* w2, int n_rows, int ldk, int n0, int nw, int nt, int kb0, int nk, std::vector<unsigned short>& out);
 
 // ---- gemm_head.hip: the energy head 256 -> 128 -> 128 -> 1 forward and backward in one launch (operands of gemm_bf3a.hip)
 struct HeadFusedArgs {

@@ -270,6 +270,18 @@ int aimnet_debug_split_h2(const float* src, int ld, int M, int K, void* dst, int
 int aimnet_debug_gemm_h2(int cfg, int epi, int out2, const void* A2, int lda2, const void* Bt2, int ldb, int M, int N, int K,
                          const float* bias, float* C, void* C2, int ldc2, float* D, int ldc, int alt, void* hip_stream);
 
+/* aimnet_engine_debug_mlp_sweep (csrc/gemm_chain.hip against csrc/gemm_h2.hip): ONE sweep of the MLP of `pass` on fp16x2-split
+ * activations, as the evaluation runs it - `chain` != 0: the single launch of gemm_chain.hip (a block owns 48 rows and the full width
+ * of every layer; hidden activations stay in LDS), 0: one launch per layer.  Forward (`backward` == 0): x2 = the input rows in h2 form 1
+ * [M][2 * k_in]; H[l] / D[l] (host arrays of device pointers, one per layer): the layer outputs (hidden ones in h2 form - the chain does
+ * not write them -, the last one fp32 [M][k_out], or h2 when `flag` != 0) and GELU' (fp32 [M][k_out]; NULL entries allowed for a linear last
+ * layer).  Backward: x2 = zb[0] holds the adjoint of the last pre-activation in h2 form and is OVERWRITTEN; zb[0] / zb[1] are the two
+ * ping-pong buffers ([M][2 * widest layer] 16-bit elements each); D[l] are inputs; `flag` != 0 forms only the conv columns 256.. of
+ * xbar (pass 0); *which = index of the buffer that holds xbar (fp32 [M][k_in]) afterwards.  Test / measurement hook. */
+int aimnet_engine_debug_mlp_sweep(aimnet_engine* engine, int pass, int backward, int chain, int flag, const void* x2, int M,
+                                  const int32_t* numbers, float* const* H, float* const* D, float* const* zb, int* which,
+                                  void* hip_stream);
+
 /* Engine switches for A/B and parity runs (all have an AIMNET_* environment twin read at create time):
  *   "conv_xe"       1 (default): reverse-pair form of the conv backward for systems above the split threshold, 0: combined form
  *   "gemm_bf3"      1 (default): MLP GEMMs of batches above 256 rows with bf16x3-split operands on the bf16 matrix pipe

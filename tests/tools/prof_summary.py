@@ -4,7 +4,7 @@ import collections, csv, sys
 path, steps = sys.argv[1], int(sys.argv[2])
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(path)):
-    n = r["Kernel_Name"].replace("aimnet::", "").split("(")[0].replace("void ", "")
+    n = r["Kernel_Name"].replace("aimnet::", "").replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
     agg[n[:60]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tot = sum(sum(v) for v in agg.values())
 print(f"total kernel time {tot/1e3:.2f} ms over {steps} steps = {tot/1e3/steps:.3f} ms/step")

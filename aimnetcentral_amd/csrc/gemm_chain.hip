@@ -90,6 +90,10 @@ constexpr int item_pass(int i, int qi) {  // pass that holds item qi counted fro
 }
 }  // namespace
 
+#ifdef CH_TIMING
+__device__ unsigned long long g_chain_stamps[4 * 64];  // [block 0 / last block][wave 0 / wave 4][stamp]
+#endif
+
 template <class S>
 __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) {
   constexpr int NW = S::NW, NTH = 64 * NW;
@@ -99,6 +103,21 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
   const int l16 = lane & 15, lc = lane >> 4;
   const int m0 = blockIdx.x * CHAIN_ROWS;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_c;
+#ifdef CH_TIMING
+  int n_ts = 0;
+  auto TS = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && (wid & 3) == 0 && n_ts < 64) {
+      const unsigned long long t = __builtin_readcyclecounter();
+      if (lane == 0) g_chain_stamps[((blockIdx.x != 0) * 2 + (wid >> 2)) * 64 + n_ts] = t;
+      ++n_ts;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#else
+  auto TS = [&]() __attribute__((always_inline)) {};
+#endif
+  TS();
 
   // ---- input panel: k-blocks 0 .. nk0 - 1 of rows m0 .. m0 + 47 -> LDS.  Piece q = plane (q & 1) of strip (q >> 1) % 3 of
   // k-block (q / 6); wave w takes the pieces q = w, w + NW, ...; lane -> row lane >> 2 of the strip, slot lane & 3 holding k-chunk
@@ -148,10 +167,13 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
 
   // ---- prologue of the ring: the first R items
   static_for<0, R>([&](auto q_c) __attribute__((always_inline)) { load_item(I0{}, q_c, q_c); });
+  TS();
   wait_vm<0>();  // the panel has landed (the DMA requests are older than the ring's)
   __builtin_amdgcn_sched_barrier(0);
+  TS();
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
+  TS();
 
   // ---- one pass ------------------------------------------------------------------------------------------------------------
   auto run_pass = [&](auto i_c) __attribute__((always_inline)) {
@@ -171,13 +193,23 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
     // vmcnt(0) in front of the first product - it would wait for the refills it has just issued)
     static_for<0, NK>([&](auto j_c) __attribute__((always_inline)) {
       constexpr int J = decltype(j_c)::value, PAR = J & 1;  // PAR: the accumulator set of this k-step
+      if constexpr (J == 2 || J == NK / 2) TS();
       const unsigned oa = adA + (unsigned)(P.kb0 + J) * CH_KB;
+#ifdef CH_PROBE_NO_LDSREAD
+      if (J == 0) {
+#endif
       read_strips_h<0, CH_SM, 0>(fa, oa);
       read_strips_h<0, CH_SM, 1>(fa, oa);
       wait_lgkm<0>();
+#ifdef CH_PROBE_NO_LDSREAD
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, NT>([&](auto sl_c) __attribute__((always_inline)) {
         constexpr int SL = decltype(sl_c)::value, QI = J * NT + SL, POS = (Q0 + QI) % R;
+#ifdef CH_PROBE_NO_MFMA
+        acc[2][0][SL][0] += (float)ring[POS][0][0] + (float)ring[POS][1][0] + (float)fa[0][0][0] + (float)fa[1][1][0] + (float)fa[2][0][0];
+#else
 #pragma unroll
         for (int i = 0; i < CH_SM; ++i)
           acc[2][i][SL] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[POS][1], fa[i][0], acc[2][i][SL], 0, 0, 0);
@@ -187,12 +219,16 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
 #pragma unroll
         for (int i = 0; i < CH_SM; ++i)
           acc[2][i][SL] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[POS][0], fa[i][1], acc[2][i][SL], 0, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
+#ifndef CH_PROBE_NO_LOAD
         load_item(i_c, std::integral_constant<int, QI + R>{}, std::integral_constant<int, POS>{});
+#endif
         __builtin_amdgcn_sched_barrier(0);
       });
     });
 
+    TS();
     // ---- epilogue.  Tile of slot s: t = NW s + wid, columns c0 = 16 t + 4 lc .. + 3 (relative to the pass), rows 16 i + l16.
     constexpr bool TO_LDS = I < S::NH;
     const int epi = P.epi;
@@ -222,7 +258,11 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float hh, dd;
+#ifdef CH_PROBE_NO_EPI
+              hh = v[r], dd = 1.0f;
+#else
               gelu_and_grad(v[r], hh, dd);
+#endif
               v[r] = hh;
               d[r] = dd;
             }
@@ -237,12 +277,14 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
         val[i][s] = v;
       }
     }
+    TS();
     const bool to_lds = TO_LDS || (!S::BWD && epi == CH_GELU_H2G);
     if (to_lds) {
       // every wave has read the operand this overwrites
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      TS();
 #pragma unroll
       for (int s = 0; s < NT; ++s) {
         const int t = NW * s + wid;  // tile = columns 16 t .. 16 t + 15 of the pass = half of k-block t >> 1 of the next operand
@@ -263,6 +305,7 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      TS();
     }
     if constexpr (!S::BWD) {
       if (TO_LDS ? (P.C2 != nullptr) : (epi == CH_GELU_H2G)) {  // (hidden passes: debug dump of the LDS operand, AIMNET_CHAIN_DUMP)
@@ -315,6 +358,14 @@ void chain_pack_weights(const unsigned short* w2, int n_rows, int ldk, int n0, i
             memcpy(dst, src, 16);
           }
 }
+
+#ifdef CH_TIMING
+int gemm_chain_read_stamps(unsigned long long* host256) {
+  AIMNET_HIP_CHECK(hipMemcpyFromSymbol(host256, HIP_SYMBOL(g_chain_stamps), 256 * sizeof(unsigned long long)));
+  return 0;
+}
+extern "C" int aimnet_debug_chain_stamps(unsigned long long* host256) { return gemm_chain_read_stamps(host256); }
+#endif
 
 int launch_gemm_chain(hipStream_t stream, int shape, const ChainArgs& a) {
   if (a.M <= 0) return 0;

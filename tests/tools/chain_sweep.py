@@ -92,6 +92,17 @@ for p in passes:
     ne = (a != b)
     line += f" out: {'bitwise' if not ne.any() else f'{int(ne.sum())} differ max {(a - b).abs().max().item():.2e}'}"
     print(line, flush=True)
+    if os.environ.get("STAMPS") and hasattr(lib, "aimnet_debug_chain_stamps"):
+        import numpy as np
+        buf = (C.c_ulonglong * 256)()
+        lib.aimnet_debug_chain_stamps.argtypes = [C.c_void_p]
+        assert lib.aimnet_debug_chain_stamps(buf) == 0
+        t = np.array(buf[:], dtype=np.int64).reshape(4, 64)
+        for g, nm in enumerate(("block 0 wave 0", "block 0 wave 4", "last block wave 0", "last block wave 4")):
+            n = int((t[g] > 0).sum())
+            if n:
+                rel = t[g][:n] - t[0][0]
+                print(f"   stamps {nm}: first {rel[0]} last {rel[-1]} | deltas:", " ".join(str(int(v)) for v in np.diff(rel)))
     # ---- backward (GELU' of the forward as the chain-rule factors)
     Dv = res[0][1]
     zbar = torch.randn(M, d[nl], device=dev)

@@ -34,7 +34,7 @@ struct ChainPlan {
   int shape = -1;  // -1: this sweep takes the per-layer launches
   int n_pass = 0;
   struct Pass {
-    void* w;     // packed stream (device)
+    void* w[2];  // packed streams of the column groups A / B (device; w[0] NULL: no group A)
     int layer;   // MLP layer this pass belongs to
     int n0;      // first output column of the pass inside the layer's output
     int ncols;   // output columns of the pass

@@ -131,11 +131,17 @@ int chain_build(aimnet_engine* e, const std::vector<Layer>& Ls, const std::vecto
     const std::vector<unsigned short>& w2 = d.fwd ? L.h_w2a : L.h_wt2a;
     const int n_rows = d.fwd ? L.k_out : L.k_in, ldk = d.fwd ? L.k_in : L.k_out;
     if (w2.empty()) return 0;
-    chain_pack_weights(w2.data(), std::min(n_rows, d.n0 + d.ncols), ldk, d.n0, CHAIN_NW, d.nt, d.kb0, d.nk, packed);
-    unsigned short* dev = nullptr;
-    int rc = dev_upload(e, packed.data(), packed.size(), &dev);
-    if (rc) return rc;
-    plan->pass[i].w = dev;
+    const int nta = chain_group_a(d.nt);
+    for (int g = 0; g < 2; ++g) {  // column group A: the first nta tile slots of every wave, B: the rest
+      const int ntg = g == 0 ? nta : d.nt - nta, s0 = g == 0 ? 0 : nta;
+      plan->pass[i].w[g] = nullptr;
+      if (ntg == 0) continue;
+      chain_pack_weights(w2.data(), std::min(n_rows, d.n0 + d.ncols), ldk, d.n0 + 16 * CHAIN_NW * s0, CHAIN_NW, ntg, d.kb0, d.nk, packed);
+      unsigned short* dev = nullptr;
+      int rc = dev_upload(e, packed.data(), packed.size(), &dev);
+      if (rc) return rc;
+      plan->pass[i].w[g] = dev;
+    }
     plan->pass[i].layer = d.layer;
     plan->pass[i].n0 = d.n0;
     plan->pass[i].ncols = d.ncols;
@@ -235,7 +241,8 @@ int mlp_sweep_fwd(const aimnet_engine* e, hipStream_t s, int sfmt, int p, int N,
       const int l = cf.pass[i].layer, ko = Ls[l].k_out;
       const bool last = l == nl - 1, linear = last && ar.last_linear[p];
       ChainPass& cp = ca.p[i];
-      cp.w = cf.pass[i].w;
+      cp.w[0] = cf.pass[i].w[0];
+      cp.w[1] = cf.pass[i].w[1];
       cp.kb0 = 0;
       cp.ncols = cf.pass[i].ncols;
       cp.epi = linear ? CH_BIAS_F32 : (last && split_last) ? CH_GELU_H2G : CH_GELU_F32;
@@ -246,8 +253,7 @@ int mlp_sweep_fwd(const aimnet_engine* e, hipStream_t s, int sfmt, int p, int N,
       cp.ldd = ko;
       cp.C = H[l];
       cp.ldc = ko;
-      static const bool dump = getenv("AIMNET_CHAIN_DUMP") != nullptr;  // debug: hidden activations are copied out of LDS too
-      cp.C2 = (last || dump) ? reinterpret_cast<unsigned short*>(H[l]) : nullptr;
+      cp.C2 = last ? reinterpret_cast<unsigned short*>(H[l]) : nullptr;
       cp.ldc2 = 2 * ko;
     }
     return launch_gemm_chain(s, cf.shape, ca);
@@ -289,7 +295,8 @@ int mlp_sweep_bwd(const aimnet_engine* e, hipStream_t s, int sfmt, int p, int N,
     for (int i = 0; i < cb.n_pass; ++i) {
       const int l = cb.pass[i].layer;
       ChainPass& cp = ca.p[i];
-      cp.w = cb.pass[i].w;
+      cp.w[0] = cb.pass[i].w[0];
+      cp.w[1] = cb.pass[i].w[1];
       cp.kb0 = 0;
       cp.ncols = cb.pass[i].ncols;
       if (l > 0) {  // adjoint of a hidden activation: x GELU'(z_{l-1}), stays in LDS

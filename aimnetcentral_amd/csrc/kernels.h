@@ -71,9 +71,11 @@ int gemm_h2_read_stamps(unsigned long long* host1024);
 // of every layer; hidden activations stay in LDS (h2 form), weights stream L2 -> registers in a host-packed fragment order
 // (chain_pack_weights).  Same products and accumulation order as gemm_h2.hip: bitwise-equal results.
 constexpr int CHAIN_ROWS = 48, CHAIN_MAX_KB = 23, CHAIN_MAX_PASS = 5;
+// tile slots per wave of a pass' column group A (group B takes the rest; gemm_chain.hip)
+constexpr int chain_group_a(int nt) { return nt >= 3 ? 2 : 0; }
 enum { CH_BIAS_F32 = 0, CH_GELU_F32 = 1, CH_GELU_H2G = 2 };  // epilogue of a forward chain's LAST pass (hidden passes: GELU -> LDS)
 struct ChainPass {          // a layer, or a column range of a wide layer
-  const void* w;            // packed weight stream of this pass (chain_pack_weights)
+  const void* w[2];         // packed weight streams of the pass' column groups A and B (chain_pack_weights; w[0] NULL: no group A)
   int kb0;                  // first k-block of the LDS operand this pass reads (0)
   int ncols;                // real output columns (a multiple of 16; of 32 when the output is the next pass' operand)
   int epi;                  // CH_* (last forward pass only)

@@ -30,9 +30,7 @@
 namespace aimnet {
 
 namespace {
-constexpr int CH_SM = 3;                   // 16-row strips per panel
-constexpr int CH_KB = CH_SM * H2_STRIP;    // LDS bytes per k-block (32 columns) of the resident operand
-constexpr int CH_LDS = CHAIN_MAX_KB * CH_KB;
+constexpr int CH_MAX_SM = 3;               // 16-row strips per panel: 3 (48 rows) when the batch fills the chip, fewer below
 #ifndef CH_RING8
 #define CH_RING8 4
 #endif
@@ -131,9 +129,11 @@ constexpr int item_unit(int u, int qi) {  // unit that holds item qi counted fro
 __device__ unsigned long long g_chain_stamps[4 * 64];  // [block 0 / last block][wave 0 / wave 4][stamp]
 #endif
 
-template <class S>
+template <class S, int CH_SM>
 __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) {
   constexpr int NW = S::NW, NTH = 64 * NW, NU = n_units<S>();
+  constexpr int CH_KB = CH_SM * H2_STRIP;  // LDS bytes per k-block (32 columns) of the resident operand
+  constexpr int CHAIN_ROWS = 16 * CH_SM;   // rows of the panel
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,16 +156,16 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
 #endif
   TS();
 
-  // ---- input panel: k-blocks of rows m0 .. m0 + 47 -> LDS.  Piece q = plane (q & 1) of strip (q >> 1) % 3 of k-block (q / 6) = 16 rows
+  // ---- input panel: k-blocks of rows m0 .. m0 + 16 CH_SM - 1 -> LDS.  Piece q = plane (q & 1) of strip (q >> 1) % CH_SM of k-block q / (2 CH_SM) = 16 rows
   // x 64 B; lane -> row lane >> 2 of the strip, 16-byte chunk lane & 3, which sits in slot chunk ^ swz(row).  Rows beyond the matrix
   // re-read its last row (their results are never stored).  The first XC0 k-blocks arrive by LDS-DMA in front of the first product;
   // the rest in chunks of XCH k-blocks through registers (ordinary loads: the compiler's wait counts stay exact - with an LDS-DMA request
   // pending beside ordinary loads it treats the memory counter as out of order and waits with vmcnt(0) for every ring refill), requested
   // XCH k-steps ahead and written to LDS, with a barrier, one k-step in front of their first use.
-  constexpr int NK0 = S::nk(0), XC0 = NK0 < 7 ? NK0 : 7, XCH = 8, XP = (6 * XCH + NW - 1) / NW;
+  constexpr int NK0 = S::nk(0), XC0 = NK0 < 7 ? NK0 : 7, XCH = 8, PPK = 2 * CH_SM /* pieces per k-block */, XP = (PPK * XCH + NW - 1) / NW;
   const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
   auto piece_src = [&](int q) __attribute__((always_inline)) {
-    const int kb = q / 6, st = (q % 6) >> 1, pl = q & 1;
+    const int kb = q / PPK, st = (q % PPK) >> 1, pl = q & 1;
     const int row = min(m0 + st * 16 + (lane >> 2), a.M - 1);
     return xb + (size_t)row * 2u * (unsigned)a.ldx + kb * H2_ROWB + pl * 64;
   };
@@ -173,9 +173,9 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
     const int r16 = lane >> 2;
     const unsigned in_row = (((lane & 3) ^ swz_h2(r16)) << 4);
 #pragma unroll
-    for (int q0 = 0; q0 < XC0 * 6; q0 += NW) {
+    for (int q0 = 0; q0 < XC0 * PPK; q0 += NW) {
       const int q = q0 + wid;
-      if (q < XC0 * 6) glds16b(piece_src(q) + in_row, smem_c + (q / 6) * CH_KB + ((q % 6) >> 1) * H2_STRIP + (q & 1) * 1024);
+      if (q < XC0 * PPK) glds16b(piece_src(q) + in_row, smem_c + (q / PPK) * CH_KB + ((q % PPK) >> 1) * H2_STRIP + (q & 1) * 1024);
     }
   }
   u32x4 xr[XP];  // pieces of the chunk in flight (this wave's)
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
     constexpr int KB0 = decltype(kb0_c)::value, KB1 = KB0 + XCH < NK0 ? KB0 + XCH : NK0;
 #pragma unroll
     for (int e = 0; e < XP; ++e) {
-      const int q = KB0 * 6 + e * NW + wid;
-      if (q < KB1 * 6) xr[e] = *reinterpret_cast<const u32x4*>(piece_src(q) + (lane & 3) * 16);
+      const int q = KB0 * PPK + e * NW + wid;
+      if (q < KB1 * PPK) xr[e] = *reinterpret_cast<const u32x4*>(piece_src(q) + (lane & 3) * 16);
     }
   };
   auto x_chunk_store = [&](auto kb0_c) __attribute__((always_inline)) {
@@ -192,9 +192,9 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
     const int r16 = lane >> 2;
 #pragma unroll
     for (int e = 0; e < XP; ++e) {
-      const int q = KB0 * 6 + e * NW + wid;
-      if (q < KB1 * 6)
-        *reinterpret_cast<u32x4*>(smem_c + (q / 6) * CH_KB + ((q % 6) >> 1) * H2_STRIP + (q & 1) * 1024 + r16 * 64 + (((lane & 3) ^ swz_h2(r16)) << 4)) = xr[e];
+      const int q = KB0 * PPK + e * NW + wid;
+      if (q < KB1 * PPK)
+        *reinterpret_cast<u32x4*>(smem_c + (q / PPK) * CH_KB + ((q % PPK) >> 1) * H2_STRIP + (q & 1) * 1024 + r16 * 64 + (((lane & 3) ^ swz_h2(r16)) << 4)) = xr[e];
     }
   };
 
@@ -595,25 +595,42 @@ int gemm_chain_read_stamps(unsigned long long* host256) {
 extern "C" int aimnet_debug_chain_stamps(unsigned long long* host256) { return gemm_chain_read_stamps(host256); }
 #endif
 
+// strips per panel: the fewest that keep the grid inside one round of the chip (a block streams the chain's weights once whatever its
+// rows: below ~200 panels of 48 rows, narrower panels on more CUs are faster), 3 beyond
+int chain_strips(int M) {
+  const int cus = device_cus();
+  for (int sm = 1; sm < CH_MAX_SM; ++sm)
+    if (ceil_div(M, 16 * sm) <= cus) return sm;
+  return CH_MAX_SM;
+}
+static int g_chain_sm = 0;  // AIMNET_CHAIN_SM forces the strip count (A/B runs)
+
 int launch_gemm_chain(hipStream_t stream, int shape, const ChainArgs& a) {
   if (a.M <= 0) return 0;
   if (shape < 0 || shape >= N_SHAPES || (a.ldx % 64) || (((size_t)a.x) & 15)) {
     set_last_error("gemm_chain: bad shape id %d / operand alignment", shape);
     return -1;
   }
-  const dim3 grid(ceil_div(a.M, CHAIN_ROWS));
+  static const bool env_read = [] {
+    const char* env = getenv("AIMNET_CHAIN_SM");
+    if (env) g_chain_sm = atoi(env);
+    return true;
+  }();
+  (void)env_read;
+  const int sm = (g_chain_sm >= 1 && g_chain_sm <= CH_MAX_SM) ? g_chain_sm : chain_strips(a.M);
   int rc = 0;
-  static_for<0, N_SHAPES>([&](auto s_c) {
-    constexpr int ID = decltype(s_c)::value;
-    if (ID != shape) return;
+  static_for<0, N_SHAPES * CH_MAX_SM>([&](auto c_c) {
+    constexpr int ID = decltype(c_c)::value / CH_MAX_SM, SM = decltype(c_c)::value % CH_MAX_SM + 1;
+    if (ID != shape || SM != sm) return;
     static PerDeviceOnce once;
-    if (once.first() && hipFuncSetAttribute((const void*)gemm_chain_kernel<Shape<ID>>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (once.first() && hipFuncSetAttribute((const void*)gemm_chain_kernel<Shape<ID>, SM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             160 * 1024) != hipSuccess) {
       set_last_error("gemm_chain: cannot raise the dynamic LDS limit");
       rc = -2;
       return;
     }
-    hipLaunchKernelGGL((gemm_chain_kernel<Shape<ID>>), grid, dim3(64 * Shape<ID>::NW), CH_LDS, stream, a);
+    hipLaunchKernelGGL((gemm_chain_kernel<Shape<ID>, SM>), dim3(ceil_div(a.M, 16 * SM)), dim3(64 * Shape<ID>::NW), CHAIN_MAX_KB * SM * H2_STRIP,
+                       stream, a);
   });
   if (rc) return rc;
   AIMNET_LAUNCH_CHECK();

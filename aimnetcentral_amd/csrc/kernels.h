@@ -67,10 +67,10 @@ int launch_split_h2(hipStream_t s, const float* src, int ld, int M, int K, unsig
 int gemm_h2_read_stamps(unsigned long long* host1024);
 #endif
 
-// ---- gemm_chain.hip: one MLP (forward or backward sweep) as ONE launch.  A block owns a panel of CHAIN_ROWS rows and the full width
+// ---- gemm_chain.hip: one MLP (forward or backward sweep) as ONE launch.  A block owns a panel of 16 / 32 / 48 rows and the full width
 // of every layer; hidden activations stay in LDS (h2 form), weights stream L2 -> registers in a host-packed fragment order
 // (chain_pack_weights).  Same products and accumulation order as gemm_h2.hip: bitwise-equal results.
-constexpr int CHAIN_ROWS = 48, CHAIN_MAX_KB = 23, CHAIN_MAX_PASS = 5;
+constexpr int CHAIN_MAX_KB = 23, CHAIN_MAX_PASS = 5;
 // tile slots per wave of a pass' column group A (group B takes the rest; gemm_chain.hip)
 constexpr int chain_group_a(int nt) { return nt >= 3 ? 2 : 0; }
 enum { CH_BIAS_F32 = 0, CH_GELU_F32 = 1, CH_GELU_H2G = 2 };  // epilogue of a forward chain's LAST pass (hidden passes: GELU -> LDS)

@@ -460,6 +460,40 @@ def make_coldw() -> None:
     np.savez_compressed(os.path.join(HERE, "coldw.npz"), **res)
 
 
+def make_coldw_big() -> None:
+    """G14: the cold weights at HEADLINE size through the unmodified reference: the (2,3,4) supercell of the config-3
+    crystal with 0.02 A jitter (2 304 atoms, DSF 15 A, forces + stress: the sample bench.py's CPU baseline runs on) and the 256-molecule
+    batch of config 2 (random neutral organics of 20 - 60 atoms, 10 205 atoms).  Outputs as the reference returns them (energy f64,
+    forces / charges f32).  The engine's DEFAULT GEMM path (fp16x2-split large tiles / one-launch sweeps) is held to the reference's
+    literal gates on these, with no fp64 anchor."""
+    import time
+
+    art = synth.synthetic_artifact(SEED, cold=True)
+    digest = synth.state_dict_digest({k: v.numpy() for k, v in art["state_dict"].items()})
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "aimnet2_synth_cold.pt")
+    torch.save(art, path)
+    res: dict[str, np.ndarray] = {"weights_seed": np.int64(SEED), "weights_cold": np.int64(1), "weights_digest": np.array(digest)}
+    c, z, cell = workloads.glucose_supercell((2, 3, 4))
+    c = (c + np.random.default_rng(1).normal(0, 0.02, c.shape)).astype(np.float32)
+    calc = make_calc(path)
+    calc.set_lrcoulomb_method("dsf")
+    t0 = time.time()
+    o = to_np(calc({"coord": c, "numbers": z, "charge": 0.0, "cell": cell.astype(np.float32)}, forces=True, stress=True))
+    res.update(pbc2304_coord=c, pbc2304_numbers=z, pbc2304_charge=np.float32(0.0), pbc2304_cell=cell.astype(np.float32),
+               pbc2304_dsf_rc=np.float64(15.0), pbc2304_dsf_alpha=np.float64(0.2), pbc2304_energy=o["energy"],
+               pbc2304_forces=o["forces"].astype(np.float32), pbc2304_charges=o["charges"].astype(np.float32), pbc2304_stress=o["stress"])
+    print("coldw_big pbc2304  E=%.6f max|F|=%.3f (%.1f s)" % (o["energy"][0], np.abs(o["forces"]).max(), time.time() - t0))
+    c, z, mol, q = workloads.random_batch(256, 20, 60, seed=2)
+    t0 = time.time()
+    o = to_np(make_calc(path)({"coord": c, "numbers": z, "mol_idx": mol, "charge": q}, forces=True))
+    res.update(batch256_coord=c, batch256_numbers=z.astype(np.int16), batch256_mol_idx=mol.astype(np.int16), batch256_charge=q,
+               batch256_energy=o["energy"], batch256_forces=o["forces"].astype(np.float32), batch256_charges=o["charges"].astype(np.float32))
+    print("coldw_big batch256 atoms=%d max|F|=%.3f max|E|=%.3f (%.1f s)" % (len(z), np.abs(o["forces"]).max(), np.abs(o["energy"]).max(),
+                                                                              time.time() - t0))
+    np.savez_compressed(os.path.join(HERE, "coldw_big.npz"), **res)
+
+
 def main() -> None:
     if "--check-hf" in sys.argv:
         check_hf_layout()
@@ -469,6 +503,9 @@ def main() -> None:
         return
     if "--only-nse" in sys.argv:
         make_nse()
+        return
+    if "--only-coldw-big" in sys.argv:
+        make_coldw_big()
         return
     if "--only-coldw" in sys.argv:
         make_coldw()

@@ -371,3 +371,32 @@ def test_cold_weights_at_the_reference_literal_gates(hip_engine_cold, name):
     assert np.abs(res["charges"] - g["charges"]).max() <= CHARGE_ATOL
     if "stress" in g:
         assert np.abs(res["stress"] - g["stress"]).max() <= STRESS_ATOL
+
+
+@pytest.mark.parametrize("name", ["pbc2304", "batch256"])
+def test_cold_weights_at_headline_size_literal_gates(hip_engine_cold, name):
+    """The DEFAULT GEMM path (fp16x2-split operands, one-launch MLP sweeps - what batches above 256 rows run) against goldens of the
+    unmodified reference at the sizes the headline is quoted on (tests/golden/coldw_big.npz: the 2 304-atom jittered supercell with
+    DSF 15 A + stress, the 256-molecule batch of config 2; cold weights), at the reference's literal gates with no fp64 anchor:
+    |dE| < max(1e-5, 5e-7 n) eV per system, zero force components outside allclose(rtol 1e-4, atol 1e-5)
+    (tests/test_calculator_gpu.py:137,445,464)."""
+    from conftest import elementwise_violations, golden_section
+
+    g = golden_section(golden("coldw_big"), name)
+    eng, dev = hip_engine_cold, hip_engine_cold.device
+    numbers = g["numbers"].astype(np.int64)
+    mol = g["mol_idx"].astype(np.int64) if "mol_idx" in g else np.zeros(len(numbers), dtype=np.int64)
+    charge = np.atleast_1d(g["charge"]).astype(np.float32)
+    kw = dict(cell=torch.from_numpy(g["cell"]).to(dev), coulomb="dsf", stress=True, dsf_rc=float(g["dsf_rc"]),
+              dsf_alpha=float(g["dsf_alpha"])) if "cell" in g else dict(coulomb="simple")
+    res = eng.eval(torch.from_numpy(g["coord"]).to(dev), torch.from_numpy(numbers).to(dev), torch.from_numpy(mol).to(dev),
+                   torch.from_numpy(charge).to(dev), forces=True, **kw)
+    res = {k: v.cpu().numpy() for k, v in res.items()}
+    gate = np.maximum(1e-5, 5e-7 * np.bincount(mol))
+    de = np.abs(res["energy"] - g["energy"])
+    assert (de < gate).all(), f"{name}: |dE| up to {(de / gate).max():.2f} x the gate"
+    bad, n, worst = elementwise_violations(res["forces"], g["forces"])
+    assert bad == 0, f"{name}: {bad} of {n} force components outside allclose(1e-4, 1e-5), worst {worst:.2f} x the gate"
+    assert np.abs(res["charges"] - g["charges"]).max() <= CHARGE_ATOL
+    if "stress" in g:
+        assert np.abs(res["stress"] - g["stress"]).max() <= STRESS_ATOL

@@ -230,3 +230,29 @@ def test_cold_weights_at_the_literal_gates(oracle32_cold, synth_sd_cold, name):
     assert np.abs(res["charges"] - g["charges"]).max() <= CHARGE_ATOL
     if "stress" in g:
         assert np.abs(res["stress"] - g["stress"]).max() <= STRESS_ATOL
+
+
+@pytest.mark.parametrize("name", ["pbc2304", "batch256"])
+def test_cold_weights_at_headline_size(oracle32_cold, synth_sd_cold, name):
+    """coldw_big.npz (make_golden.py --only-coldw-big): the unmodified reference on the cold weights at the sizes the headline is quoted
+    on - the 2 304-atom jittered supercell (DSF 15 A, stress) and the 256-molecule batch of config 2.  The oracle at the reference's
+    literal gates: |dE| < max(1e-5, 5e-7 n) eV per system, no force component outside allclose(rtol 1e-4, atol 1e-5)."""
+    from conftest import elementwise_violations, golden_section
+
+    from aimnetcentral_amd import synth
+
+    gf = golden("coldw_big")
+    assert synth.state_dict_digest(synth_sd_cold) == str(gf["weights_digest"])
+    g = golden_section(gf, name)
+    numbers = g["numbers"].astype(np.int64)
+    mol = g["mol_idx"].astype(np.int64) if "mol_idx" in g else np.zeros(len(numbers), dtype=np.int64)
+    kw = dict(cell=g["cell"], coulomb="dsf", stress=True, dsf_rc=float(g["dsf_rc"]), dsf_alpha=float(g["dsf_alpha"])) if "cell" in g else {}
+    res = O.evaluate(oracle32_cold, g["coord"], numbers, g["charge"], mol, **kw)
+    n_per = np.bincount(mol)
+    de = np.abs(res["energy"] - g["energy"])
+    assert (de < np.maximum(1e-5, 5e-7 * n_per)).all(), (de / np.maximum(1e-5, 5e-7 * n_per)).max()
+    bad, n, worst = elementwise_violations(res["forces"], g["forces"])
+    assert bad == 0, f"{bad} of {n} force components outside allclose(1e-4, 1e-5), worst {worst:.2f} x the gate"
+    assert np.abs(res["charges"] - g["charges"]).max() <= CHARGE_ATOL
+    if "stress" in g:
+        assert np.abs(res["stress"] - g["stress"]).max() <= STRESS_ATOL

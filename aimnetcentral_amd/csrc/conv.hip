@@ -1076,14 +1076,15 @@ int launch_pair_rev_hash(hipStream_t s, const int* nb_idx, const int* nb_shift, 
 // kernel of the backward, it writes the force output itself
 __global__ __launch_bounds__(256) void pair_force_kernel(const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
                                                          const int* __restrict__ rev, const float4* __restrict__ pairbuf, int cap,
-                                                         int n_atoms, const float* __restrict__ fgrad, float* __restrict__ forces) {
-  pair_force_block(nb_idx, nb_cnt, rev, pairbuf, cap, n_atoms, fgrad, forces, blockIdx.x);  // (pairmap.h)
+                                                         int n_atoms, const float* __restrict__ fgrad, float* __restrict__ forces,
+                                                         int* __restrict__ nf) {
+  pair_force_block(nb_idx, nb_cnt, rev, pairbuf, cap, n_atoms, fgrad, forces, blockIdx.x, nf);  // (pairmap.h)
 }
 
 int launch_pair_force(hipStream_t s, const int* nb_idx, const int* nb_cnt, const int* rev, const float4* pairbuf, int cap,
-                      int n_atoms, const float* fgrad, float* forces) {
+                      int n_atoms, const float* fgrad, float* forces, int* nf) {
   hipLaunchKernelGGL(pair_force_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, nb_idx, nb_cnt, rev, pairbuf, cap, n_atoms,
-                     fgrad, forces);
+                     fgrad, forces, nf);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

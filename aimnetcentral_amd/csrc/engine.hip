@@ -1327,7 +1327,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     }
     RC(launch_energy_reduce(s, W.e_atom, W.ecoul, in->numbers, e->sae, W.nl.mol_start, n_mol, W.S, W.part, out->energy,
                             q_fin, charges_written ? nullptr : out->charges, N,  // + the charges output, unless the DSF walk wrote it
-                            rev_done ? nullptr : &pmap));                        // + the lookup of the reverse-pair map, unless the walk ran it
+                            rev_done ? nullptr : &pmap,                          // + the lookup of the reverse-pair map, unless the walk ran it
+                            out->status + 6));
     rev_done = true;
     return 0;
   };
@@ -1432,10 +1433,10 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const PairForceRider pfr{W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, out->forces, ceil_div(N, 4)};
   const EnergyRider erd{W.e_atom, W.ecoul, in->numbers, e->sae, W.part_e, out->energy, n_mol,
                         q_fin, copy_deferred ? out->charges : nullptr, N};
-  if (W.xe && want_f && !pf_rides) RC(launch_pair_force(s, W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, N, W.fgrad, out->forces));
+  if (W.xe && want_f && !pf_rides) RC(launch_pair_force(s, W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, N, W.fgrad, out->forces, out->status + 6));
   RC(launch_finalize(s, W.fgrad, W.virial_atom, W.nl.mol_start, in->cell, n_cell, n_mol, N, W.S, W.part,
                      (want_f && !W.xe) ? out->forces : nullptr, want_s ? out->stress : nullptr, pf_rides ? &pfr : nullptr,
-                     energy_deferred ? &erd : nullptr, e->sums_whole != 0));
+                     energy_deferred ? &erd : nullptr, e->sums_whole != 0, out->status + 6));
   RC(prof_mark(e, s, -1));
   return AIMNET_OK;
 }

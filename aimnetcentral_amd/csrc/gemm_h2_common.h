@@ -15,8 +15,11 @@
 //   activations : hi plain, lo of every ODD k-block negated           (the producers below, H2_ACT)
 // so that ah (-bh) lands in the odd set with a minus sign (epilogue: even - odd) and both cross terms ah bl, (-al)(-bh) keep
 // their sign in the single cross accumulator.
-// Range: |x| >= 65520 does not fit hi.  Producers report it (h2_flag_overflow) and the engine repeats the evaluation with the
-// bf16x3 kernels (engine.hip, `gemm_h2` fallback).
+// Range: |x| >= 65520 does not fit hi: it becomes inf, the products inf / NaN, and the energies / forces non-finite.  The kernels that
+// write those raise status[6] bit 5 (kernels.h STATUS_NONFINITE, include/aimnet_hip.h) - visible to every consumer of the C ABI, also
+// for an overflow in the adjoint sweep alone; the Python layer (engine.py) then repeats the evaluation with the bf16x3 operands
+// (set_option("gemm_h2", 0)) and stays on them if that is finite.  Weights are checked at create time (h2_fits).
+// (h2_flag_overflow below is the per-element form for the stand-alone split kernel of the tests.)
 #pragma once
 
 #include <hip/hip_runtime.h>

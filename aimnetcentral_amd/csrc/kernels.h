@@ -236,7 +236,7 @@ size_t pair_hash_bytes(int n_atoms);
 int launch_pair_rev_hash(hipStream_t s, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, int n_atoms,
                          unsigned long long* tab, int* rev);
 int launch_pair_force(hipStream_t s, const int* nb_idx, const int* nb_cnt, const int* rev, const float4* pairbuf, int cap,
-                      int n_atoms, const float* fgrad, float* forces);  // forces = -(fgrad + pair terms)
+                      int n_atoms, const float* fgrad, float* forces, int* nf = nullptr);  // forces = -(fgrad + pair terms)
 // `order` (conv_fwd / conv_bwd / conv_bwd_p0): optional permutation of the atoms giving the PROCESSING order - the
 // bin-sorted order of the cell list for periodic systems - so that an XCD's centres and the rows they gather stay
 // spatially coherent (and L2-resident) whatever the order of the input file; NULL = input order.
@@ -296,7 +296,8 @@ int launch_energy_reduce(hipStream_t s, const float* e_atom, const double* ecoul
                          const double* sae, const int* mol_start, int n_mol, int S, double* part, double* energy,
                          // copy_dst != NULL: copy_n floats copy_src -> copy_dst ride on the same launch (the charges output)
                          const float* copy_src = nullptr, float* copy_dst = nullptr, int copy_n = 0,
-                         const PairMapRider* rev_rider = nullptr);  // the lookup of the reverse-pair map rides on this launch
+                         const PairMapRider* rev_rider = nullptr,  // the lookup of the reverse-pair map rides on this launch
+                         int* nf = nullptr);                       // status word that takes STATUS_NONFINITE
 // ---- ewald.hip: Ewald summation of a periodic system (LRCoulomb "ewald", lr.py:617-720) ------------------------------------
 struct EwaldSystem {   // per periodic system, written by ewald_setup_kernel from the cell, the atom count and the accuracy
   float alpha, rc;     // splitting parameter, real-space cutoff
@@ -422,6 +423,9 @@ int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const
 struct PairForceRider {
   const int* nb_idx; const int* nb_cnt; const int* rev; const float4* pairbuf; int cap; float* forces; int n_blocks;
 };
+// bit of status[6] that the kernels writing the energies and forces raise when a value is not finite: an MLP activation beyond
+// fp16's range with the fp16x2-split GEMM operands (gemm_h2_common.h) surfaces there (or a genuine blow-up of the input geometry)
+constexpr int STATUS_NONFINITE = 32;
 // the molecule energy sums as riders of the stress launches (partial sums beside the virial sums, the slice sums beside the stress
 // finish): they are only needed at the end, and two launch boundaries go.  part: its own [n_mol][S] partial sums.
 struct EnergyRider {
@@ -430,10 +434,12 @@ struct EnergyRider {
   // together with the copy of the charges into the output (copy_dst != NULL) that the energy launch would have carried
   const float* copy_src; float* copy_dst; int copy_n;
 };
+// nf: status word that takes STATUS_NONFINITE (NULL: not reported)
 int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
                     const float* cell, int n_cell, int n_mol, int n_atoms, int S, double* part, float* forces,
                     float* stress, const PairForceRider* pair_force = nullptr, const EnergyRider* energy = nullptr,
-                    bool whole_ok = false);  // the sums may run as whole-cell / whole-molecule blocks without a finish launch
+                    bool whole_ok = false,  // the sums may run as whole-cell / whole-molecule blocks without a finish launch
+                    int* nf = nullptr);
 int launch_copy_f32(hipStream_t s, const float* src, float* dst, size_t n);
 
 }  // namespace aimnet

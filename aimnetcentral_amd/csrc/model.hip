@@ -263,7 +263,8 @@ int launch_head_last(hipStream_t s, const float* h, int ldh, const float* w, con
 // partial sum number b = (molecule, slice) of E_m = sum_i e_i + SAE[Z_i] + pair energies (fp64)
 __device__ __forceinline__ void energy_partial_block(const float* __restrict__ e_atom, const double* __restrict__ ecoul,
                                                      const int* __restrict__ numbers, const double* __restrict__ sae,
-                                                     const int* __restrict__ mol_start, int S, double* __restrict__ part, int b) {
+                                                     const int* __restrict__ mol_start, int S, double* __restrict__ part, int b,
+                                                     int* __restrict__ nf = nullptr) {
   __shared__ double sh[4];
   const int m = b / S, sl = b % S;
   int lo, hi;
@@ -274,14 +275,18 @@ __device__ __forceinline__ void energy_partial_block(const float* __restrict__ e
     acc += (double)e_atom[i] + sae[z] + ecoul[i];
   }
   const double r = block_sum(acc, sh);
-  if (threadIdx.x == 0) part[(size_t)m * S + sl] = r;
+  if (threadIdx.x == 0) {
+    part[(size_t)m * S + sl] = r;
+    if (nf && !isfinite(r)) atomicOr(nf, STATUS_NONFINITE);
+  }
 }
 
 // the whole molecule in ONE block (S == 1 on a few 10^4 atoms, as a rider beside a longer launch): eight atoms per thread and
 // round, their loads issued together - the slice form's two dependent loads per atom and round would take 40 round trips
 __device__ __forceinline__ void energy_whole_block(const float* __restrict__ e_atom, const double* __restrict__ ecoul,
                                                    const int* __restrict__ numbers, const double* __restrict__ sae,
-                                                   const int* __restrict__ mol_start, double* __restrict__ energy, int m) {
+                                                   const int* __restrict__ mol_start, double* __restrict__ energy, int m,
+                                                   int* __restrict__ nf = nullptr) {
   __shared__ double sh[4];
   const int lo = mol_start[m], hi = mol_start[m + 1];
   double acc = 0.0;
@@ -301,7 +306,10 @@ __device__ __forceinline__ void energy_whole_block(const float* __restrict__ e_a
       if (i0 + k * (int)blockDim.x < hi) acc += (double)ea[k] + sae[z[k]] + ec[k];
   }
   const double r = block_sum(acc, sh);
-  if (threadIdx.x == 0) energy[m] = r;
+  if (threadIdx.x == 0) {
+    energy[m] = r;
+    if (nf && !isfinite(r)) atomicOr(nf, STATUS_NONFINITE);
+  }
 }
 
 __global__ __launch_bounds__(256) void energy_partial_kernel(const float* __restrict__ e_atom,
@@ -310,7 +318,8 @@ __global__ __launch_bounds__(256) void energy_partial_kernel(const float* __rest
                                                             const double* __restrict__ sae,
                                                             const int* __restrict__ mol_start, int S,
                                                             double* __restrict__ part, int n_red, const float* __restrict__ cp_src,
-                                                            float* __restrict__ cp_dst, int cp_n, int n_cp, PairMapRider pm) {
+                                                            float* __restrict__ cp_dst, int cp_n, int n_cp, PairMapRider pm,
+                                                            int* __restrict__ nf) {
   if ((int)blockIdx.x >= n_red) {  // riders (independent work; one kernel boundary less each)
     const int b = blockIdx.x - n_red;
     if (b < n_cp) {  // the copy of the charges into the output
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(256) void energy_partial_kernel(const float* __rest
     }
     return;
   }
-  energy_partial_block(e_atom, ecoul, numbers, sae, mol_start, S, part, blockIdx.x);
+  energy_partial_block(e_atom, ecoul, numbers, sae, mol_start, S, part, blockIdx.x, nf);
 }
 
 __global__ void energy_finish_kernel(const double* __restrict__ part, int S, int n_mol, double* __restrict__ energy) {
@@ -334,13 +343,13 @@ __global__ void energy_finish_kernel(const double* __restrict__ part, int S, int
 
 int launch_energy_reduce(hipStream_t s, const float* e_atom, const double* ecoul, const int* numbers,
                          const double* sae, const int* mol_start, int n_mol, int S, double* part, double* energy,
-                         const float* copy_src, float* copy_dst, int copy_n, const PairMapRider* rev_rider) {
+                         const float* copy_src, float* copy_dst, int copy_n, const PairMapRider* rev_rider, int* nf) {
   S = S < 1 ? 1 : S;
   const int n_red = S * n_mol, n_cp = copy_dst ? ceil_div(copy_n, 256) : 0;
   PairMapRider pm{};
   if (rev_rider) pm = *rev_rider;
   hipLaunchKernelGGL(energy_partial_kernel, dim3(n_red + n_cp + pm.n_blocks), dim3(256), 0, s, e_atom, ecoul, numbers, sae, mol_start, S,
-                     S == 1 ? energy : part, n_red, copy_src, copy_dst, copy_n, n_cp, pm);
+                     S == 1 ? energy : part, n_red, copy_src, copy_dst, copy_n, n_cp, pm, nf);
   AIMNET_LAUNCH_CHECK();
   if (S > 1) {
     hipLaunchKernelGGL(energy_finish_kernel, dim3(ceil_div(n_mol, 64)), dim3(64), 0, s, part, S, n_mol, energy);
@@ -817,21 +826,26 @@ __global__ __launch_bounds__(256) void build_zbar_kernel(const float* __restrict
   __shared__ float sh[4];
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  int m_lo = 0;
   if (wpart == nullptr) {
+    // one sum per ATOM SLOT of the block (not per molecule id: sorted mol_idx may skip ids - empty molecules - so the ids of four
+    // consecutive atoms can span any range); a slot whose molecule is the previous slot's copies that slot's sums
     const int a_lo = blockIdx.x * 4, a_hi = min(n_atoms, a_lo + 4);
-    m_lo = mol_idx[a_lo];
-    const int m_hi = mol_idx[a_hi - 1];
-    for (int m = m_lo; m <= m_hi; ++m) {  // (<= 4 molecules: mol_idx is sorted)
+    for (int k = 0; k < a_hi - a_lo; ++k) {
+      const int m = mol_idx[a_lo + k];
+      if (k > 0 && m == mol_idx[a_lo + k - 1]) {
+        if (threadIdx.x == 0)
+          for (int ch = 0; ch < nq; ++ch) s_w[ch][k] = s_w[ch][k - 1];
+        continue;
+      }
       const int i0 = mol_start[m], i1 = mol_start[m + 1];
       for (int ch = 0; ch < nq; ++ch) {
         float acc = 0.f;
-        for (int k = i0 + threadIdx.x; k < i1; k += 256) {
-          const float ft = y[(size_t)k * ldy + nq + ch];
-          acc += qbar[(size_t)ch * n_atoms + k] * (ft * ft);
+        for (int q = i0 + threadIdx.x; q < i1; q += 256) {
+          const float ft = y[(size_t)q * ldy + nq + ch];
+          acc += qbar[(size_t)ch * n_atoms + q] * (ft * ft);
         }
         const float r = block_sum(acc, sh);
-        if (threadIdx.x == 0) s_w[ch][m - m_lo] = r;
+        if (threadIdx.x == 0) s_w[ch][k] = r;
       }
     }
     __syncthreads();
@@ -850,7 +864,7 @@ __global__ __launch_bounds__(256) void build_zbar_kernel(const float* __restrict
       for (int k = lane; k < S; k += 64) wl += wpart[((size_t)ch * n_mol + m) * S + k];
       wsum = wave_sum(wl);
     } else {
-      wsum = s_w[ch][m - m_lo];
+      wsum = s_w[ch][threadIdx.x >> 6];
     }
     qr[ch] = qbar[(size_t)ch * n_atoms + i] - wsum / F;
     fsc[ch] = Dm[(size_t)ch * n_mol + m] / F;
@@ -905,11 +919,12 @@ int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const
 // riders (er.energy != NULL, S == 1): the molecule energy sums and the copy of the charges into the output - outputs only, so they
 // need no launch of their own in front of the backward pass
 __global__ __launch_bounds__(256) void forces_kernel(const float* __restrict__ fgrad, int n3, float* __restrict__ forces,
-                                                     const int* __restrict__ mol_start, EnergyRider er, int n_force_blocks) {
+                                                     const int* __restrict__ mol_start, EnergyRider er, int n_force_blocks,
+                                                     int* __restrict__ nf) {
   if ((int)blockIdx.x >= n_force_blocks) {
     const int b = blockIdx.x - n_force_blocks;
     if (b < er.n_mol) {
-      energy_partial_block(er.e_atom, er.ecoul, er.numbers, er.sae, mol_start, 1, er.energy, b);
+      energy_partial_block(er.e_atom, er.ecoul, er.numbers, er.sae, mol_start, 1, er.energy, b, nf);
     } else {
       const int e = (b - er.n_mol) * 256 + threadIdx.x;
       if (e < er.copy_n) er.copy_dst[e] = er.copy_src[e];
@@ -917,7 +932,11 @@ __global__ __launch_bounds__(256) void forces_kernel(const float* __restrict__ f
     return;
   }
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n3) forces[e] = -fgrad[e];
+  if (e < n3) {
+    const float f = fgrad[e];
+    forces[e] = -f;
+    if (nf && !isfinite(f)) atomicOr(nf, STATUS_NONFINITE);
+  }
 }
 
 // stage 1: 9 partial sums per (system, slice); a single shared cell (n_cell == 1) spans all molecules
@@ -925,20 +944,21 @@ __global__ __launch_bounds__(256) void stress_partial_kernel(const float* __rest
                                                             const int* __restrict__ mol_start, int n_cell, int n_mol,
                                                             int S, double* __restrict__ part, const float* __restrict__ fgrad,
                                                             int n_atoms, PairForceRider pf, EnergyRider er,
-                                                            const float* __restrict__ cell, float* __restrict__ stress_whole) {
+                                                            const float* __restrict__ cell, float* __restrict__ stress_whole,
+                                                            int* __restrict__ nf) {
   // whole form (stress_whole != NULL, S == 1): ONE block per cell sums all of its atoms and writes the stress itself, one block
   // per molecule the energy - no finish launch; they come first in the grid and run beside the force-gather riders
   const int n_first = S * n_cell + (stress_whole ? er.n_mol : 0);
   if (stress_whole && (int)blockIdx.x >= n_cell && (int)blockIdx.x < n_first) {
-    energy_whole_block(er.e_atom, er.ecoul, er.numbers, er.sae, mol_start, er.energy, blockIdx.x - n_cell);
+    energy_whole_block(er.e_atom, er.ecoul, er.numbers, er.sae, mol_start, er.energy, blockIdx.x - n_cell, nf);
     return;
   }
   if ((int)blockIdx.x >= n_first) {  // riders (independent of the virial sums; a kernel boundary less each)
     const int b = blockIdx.x - n_first;
     if (b < pf.n_blocks)  // the force gather of the reverse-pair form
-      pair_force_block(pf.nb_idx, pf.nb_cnt, pf.rev, pf.pairbuf, pf.cap, n_atoms, fgrad, pf.forces, b);
+      pair_force_block(pf.nb_idx, pf.nb_cnt, pf.rev, pf.pairbuf, pf.cap, n_atoms, fgrad, pf.forces, b, nf);
     else  // the molecule energies' partial sums (S == 1: the energies themselves)
-      energy_partial_block(er.e_atom, er.ecoul, er.numbers, er.sae, mol_start, S, S == 1 ? er.energy : er.part, b - pf.n_blocks);
+      energy_partial_block(er.e_atom, er.ecoul, er.numbers, er.sae, mol_start, S, S == 1 ? er.energy : er.part, b - pf.n_blocks, nf);
     return;
   }
   __shared__ double sh[4];
@@ -1009,7 +1029,7 @@ __global__ void stress_finish_kernel(const double* __restrict__ part, int S, int
 
 int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom, const int* mol_start,
                     const float* cell, int n_cell, int n_mol, int n_atoms, int S, double* part, float* forces,
-                    float* stress, const PairForceRider* pair_force, const EnergyRider* energy, bool whole_ok) {
+                    float* stress, const PairForceRider* pair_force, const EnergyRider* energy, bool whole_ok, int* nf) {
   PairForceRider pf{};
   if (pair_force) pf = *pair_force;
   EnergyRider er{};
@@ -1018,7 +1038,7 @@ int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom,
   if (forces) {
     const int nfb = ceil_div(3 * n_atoms, 256);
     const int n_rider = er_on_forces ? er.n_mol + (er.copy_dst ? ceil_div(er.copy_n, 256) : 0) : 0;
-    hipLaunchKernelGGL(forces_kernel, dim3(nfb + n_rider), dim3(256), 0, s, fgrad, 3 * n_atoms, forces, mol_start, er, nfb);
+    hipLaunchKernelGGL(forces_kernel, dim3(nfb + n_rider), dim3(256), 0, s, fgrad, 3 * n_atoms, forces, mol_start, er, nfb, nf);
     AIMNET_LAUNCH_CHECK();
   }
   if (stress && cell) {
@@ -1028,13 +1048,13 @@ int launch_finalize(hipStream_t s, const float* fgrad, const float* virial_atom,
     const bool whole = energy && pf.n_blocks > 0 && n_atoms <= 16384 && whole_ok;
     if (whole) {
       hipLaunchKernelGGL(stress_partial_kernel, dim3(n_cell + er.n_mol + pf.n_blocks), dim3(256), 0, s, virial_atom, mol_start, n_cell, n_mol,
-                         1, part, fgrad, n_atoms, pf, er, cell, stress);
+                         1, part, fgrad, n_atoms, pf, er, cell, stress, nf);
       AIMNET_LAUNCH_CHECK();
       return 0;
     }
     const int n_er = energy ? S * er.n_mol : 0;
     hipLaunchKernelGGL(stress_partial_kernel, dim3(S * n_cell + pf.n_blocks + n_er), dim3(256), 0, s, virial_atom, mol_start, n_cell, n_mol,
-                       S, part, fgrad, n_atoms, pf, er, cell, nullptr);
+                       S, part, fgrad, n_atoms, pf, er, cell, nullptr, nf);
     AIMNET_LAUNCH_CHECK();
     hipLaunchKernelGGL(stress_finish_kernel, dim3(ceil_div(n_cell * 9 + (energy && S > 1 ? er.n_mol : 0), 64)), dim3(64), 0, s, part, S,
                        n_cell, cell, stress, er);

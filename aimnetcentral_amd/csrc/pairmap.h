@@ -80,7 +80,8 @@ __device__ __forceinline__ void pair_rev_hash_block(const int* __restrict__ nb_i
 // forces_i = -(fgrad_i + sum_m F1(i -> j_m) - F1(j_m -> i))  (conv_bwd_kernel XE form; one wave per atom, lane = pair)
 __device__ __forceinline__ void pair_force_block(const int* __restrict__ nb_idx, const int* __restrict__ nb_cnt,
                                                  const int* __restrict__ rev, const float4* __restrict__ pairbuf, int cap,
-                                                 int n_atoms, const float* __restrict__ fgrad, float* __restrict__ forces, int block) {
+                                                 int n_atoms, const float* __restrict__ fgrad, float* __restrict__ forces, int block,
+                                                 int* __restrict__ nf = nullptr) {
   const int lane = threadIdx.x & 63;
   const int i = block * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
@@ -101,6 +102,7 @@ __device__ __forceinline__ void pair_force_block(const int* __restrict__ nb_idx,
     forces[3 * i + 0] = -(fgrad[3 * i + 0] + f0);
     forces[3 * i + 1] = -(fgrad[3 * i + 1] + f1);
     forces[3 * i + 2] = -(fgrad[3 * i + 2] + f2);
+    if (nf && !(isfinite(f0 + fgrad[3 * i]) && isfinite(f1 + fgrad[3 * i + 1]) && isfinite(f2 + fgrad[3 * i + 2]))) atomicOr(nf, 32);
   }
 }
 

@@ -55,6 +55,9 @@ class NeighborOverflowError(RuntimeError):
     exception of this name, neighbors.py:127-130)."""
 
 
+NONFINITE_FLAG = 32  # status[6] bit 5 (csrc/kernels.h STATUS_NONFINITE): a non-finite energy or force was written - not an input flag
+
+
 def describe_input_flags(flags: int, n_mol: int | None = None) -> str:
     """Text of the input sanity flags the engine raises in status[6] (it clamps for memory safety; the results are meaningless)."""
     what = []
@@ -200,13 +203,18 @@ class HipEngine:
         self.pending_status.clear()
         self.last_status = st[-1]
         energies, self._pending_energy = self._pending_energy, []
-        rows_ok = not (st[:, 2].any() or st[:, 3].any() or st[:, 5].any() or st[:, 6].any())
-        if rows_ok and energies and self.get_option("gemm_h2") and not all(bool(torch.isfinite(e).all()) for e in energies):
+        if (st[:, 6] & ~NONFINITE_FLAG).any():  # (first: invalid input also produces non-finite outputs)
+            raise ValueError("HipEngine: invalid input in a deferred evaluation: " +
+                             describe_input_flags(int(np.bitwise_or.reduce(st[:, 6])) & ~NONFINITE_FLAG))
+        rows_ok = not (st[:, 2].any() or st[:, 3].any() or st[:, 5].any())
+        # status[6] bit 5: the kernels that write the energies / forces saw a non-finite value (covers the adjoint sweep too, which
+        # the energies alone would not)
+        nonfinite = bool((st[:, 6] & NONFINITE_FLAG).any()) or not all(bool(torch.isfinite(e).all()) for e in energies)
+        if rows_ok and nonfinite and self.get_option("gemm_h2"):
             self.set_option("gemm_h2", 0)
-            raise ActivationRangeError("non-finite energies in one of the last %d deferred evaluations with fp16x2-split GEMM operands: an "
-                                       "activation left fp16's range; the engine now uses the bf16x3 operands - repeat them" % len(st))
-        if st[:, 6].any():
-            raise ValueError("HipEngine: invalid input in a deferred evaluation: " + describe_input_flags(int(np.bitwise_or.reduce(st[:, 6]))))
+            raise ActivationRangeError("non-finite energies or forces in one of the last %d deferred evaluations with fp16x2-split GEMM "
+                                       "operands: an activation may have left fp16's range; the engine now uses the bf16x3 operands - "
+                                       "repeat them (if they stay non-finite the input itself is the cause)" % len(st))
         grown = False
         if st[:, 2].any():
             self.max_nb = _round16(int(max(self.max_nb * 1.5, st[:, 0].max())))
@@ -430,16 +438,19 @@ class HipEngine:
                 # it took 1.4 ms, and the evaluation as a whole 15 ms instead of 2.2, tests/tools/ase_prof2.py.)
                 host = outbuf.cpu()
                 st = host[:32].view(torch.int32).numpy()
-                finite = all(bool(torch.isfinite(v).all()) for k, v in views(host).items() if k != "status") if (h2_on or h2_retry) else True
+                finite = (all(bool(torch.isfinite(v).all()) for k, v in views(host).items() if k != "status") and
+                          not (int(st[6]) & NONFINITE_FLAG)) if (h2_on or h2_retry) else True
             else:
                 # the status words and the molecule energies (adjacent sections) in one copy: the energies are the fp16-range
                 # sentinel of the h2 GEMM operands (below)
                 head = outbuf[: offs[1] + nbytes[1]].cpu()
                 st = head[:32].view(torch.int32).numpy()
-                finite = bool(torch.isfinite(head[offs[1]:].view(torch.float64)).all()) if (h2_on or h2_retry) else True
+                # (status[6] bit 5 = a non-finite energy or FORCE seen on the device: an overflow in the adjoint sweep leaves the energies finite)
+                finite = (bool(torch.isfinite(head[offs[1]:].view(torch.float64)).all()) and
+                          not (int(st[6]) & NONFINITE_FLAG)) if (h2_on or h2_retry) else True
             self.last_status = st
-            if st[6]:  # input sanity flags raised by the engine (it clamps for memory safety, the results are meaningless)
-                raise ValueError("HipEngine.eval: invalid input: " + describe_input_flags(int(st[6]), n_mol))
+            if int(st[6]) & ~NONFINITE_FLAG:  # input sanity flags raised by the engine (it clamps for memory safety, the results are meaningless)
+                raise ValueError("HipEngine.eval: invalid input: " + describe_input_flags(int(st[6]) & ~NONFINITE_FLAG, n_mol))
             retry = False
             rows_overflowed = bool(st[2] or st[3] or st[5] or (method == _lib.COULOMB_EWALD and st[7] > opt.ewald_max_k) or
                                    (is_pme and st[7] > opt.pme_max_mesh))

@@ -169,6 +169,10 @@ typedef struct aimnet_outputs {
                                 or an unshifted self pair, bit 4 the caller-supplied short-range matrix is not symmetric.  The first kernel writes clamped copies (atomic number
                                 slots, mol_idx) into the workspace and every later kernel indexes through those, so any device
                                 array is memory-safe; with a flag raised the results are meaningless.
+                                Bit 5 (32) is NOT an input flag: the kernels that write the energies / forces saw a non-finite value.
+                                With the fp16x2-split GEMM operands ("gemm_h2", the default above 256 rows) that is how an MLP
+                                activation or adjoint beyond fp16's range (|x| >= 65504) surfaces: set_option("gemm_h2", 0) and
+                                repeat the evaluation (the bf16x3 operands have fp32's range); still raised, the input is the cause.
                               7 Ewald: k-array entries the batch needs (compare with options.ewald_max_k); PME: mesh points the
                                 largest system needs (compare with options.pme_max_mesh); 0 for other methods */
   float* spin_charges; /* [n_atoms] alpha - beta of an NSE model (aimnet2.py:103), or NULL; must be NULL for 1-channel models */

@@ -150,5 +150,7 @@ def test_fp16_range_fallback():
     with pytest.raises(ActivationRangeError, match="repeat them"):
         eng2.check_deferred()
     assert eng2.get_option("gemm_h2") == 0
+    assert int(eng2.last_status[6]) & 32  # raised on the device by the kernels that write the energies / forces (include/aimnet_hip.h)
     again = eng2.eval(*args, forces=True)
+    assert not int(eng2.last_status[6]) & 32
     assert torch.equal(again["energy"], ref["energy"])

@@ -248,6 +248,22 @@ def test_nse_ragged_batch_mixed_multiplicities(hip_engine_nse, oracle32_nse, ora
     assert np.abs(spin - (g["b5_mult"] - 1.0)).max() < 5e-4  # NSE conserves N_alpha - N_beta per molecule
 
 
+def test_nse_batch_with_empty_molecules(hip_engine_nse):
+    """Sorted mol_idx may skip ids (empty molecules): the molecule ids of four consecutive atoms then span more than four values -
+    the merged NSE adjoint of small systems (model.hip, build_zbar_kernel without partial sums) once indexed its per-block sums by
+    molecule id and wrote past them.  The batch with its molecules renumbered 0, 7, 14, ... must give the same bits."""
+    g = golden("nse")
+    mol = g["b5_mol_idx"]
+    res = _run_nse(hip_engine_nse, g["b5_coord"], g["b5_numbers"], mol, g["b5_charge"], g["b5_mult"], coulomb="simple")
+    n_mol = 7 * 4 + 1
+    charge, mult = np.zeros(n_mol, dtype=np.float32), np.ones(n_mol, dtype=np.float32)
+    charge[::7], mult[::7] = g["b5_charge"], g["b5_mult"]
+    gap = _run_nse(hip_engine_nse, g["b5_coord"], g["b5_numbers"], 7 * mol, charge, mult, coulomb="simple")
+    for k in ("forces", "charges", "spin_charges"):
+        assert np.array_equal(res[k], gap[k]), k
+    assert np.array_equal(res["energy"], gap["energy"][::7])
+
+
 def test_nse_periodic_dsf_stress(hip_engine_nse, oracle32_nse):
     g = golden("nse")
     dev = hip_engine_nse.device

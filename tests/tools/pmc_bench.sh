@@ -17,7 +17,7 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in sorted(glob.glob("gpurun_out/$out/*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].replace("aimnet::", "").replace("void ", "").split("(")[0][:48]
+        k = r["Kernel_Name"].replace("aimnet::", "").replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]
         a = agg[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 names = sorted({c for k in agg for c in agg[k]})
 print("per-dispatch averages; kernel | " + " | ".join(names))
@@ -30,7 +30,7 @@ import csv, glob, collections, json, os
 tot = collections.defaultdict(float); n = collections.defaultdict(int)
 for f in sorted(glob.glob("gpurun_out/$out/*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if not any(k in r["Kernel_Name"] for k in ("gemm_nt", "gemm_bf3", "gemm_h2", "head_fused")): continue
+        if not any(k in r["Kernel_Name"] for k in ("gemm_nt", "gemm_bf3", "gemm_h2", "gemm_chain", "head_fused")): continue
         tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 launches = max(1, n["TCC_EA0_RDREQ_sum"])
 rd, wr = tot["TCC_EA0_RDREQ_sum"] * 128 / launches, tot["TCC_EA0_WRREQ_sum"] * 64 / launches

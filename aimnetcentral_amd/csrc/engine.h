@@ -112,11 +112,6 @@ struct aimnet_engine {
   // instead of one GEMM launch per layer (bitwise-equal results).  0 = the per-layer launches.  chain_fwd[p][e]: e = 1 with the
   // embedding block of pass 0 folded into the bias table; chain_bwd[p][m]: m = 1 when only the conv columns of xbar_0 are formed.
   int gemm_chain = 1;
-  // AIMNET_DSF_TABLE / set_option("dsf_table"): the list-free periodic DSF walk takes its pair term w(d), w'(d) / d from per-interval
-  // cubics (kernels.h dsf_pair_table; rebuilt on the host when (alpha, rc) change) instead of evaluating erfc / exp per pair
-  int dsf_table = 1;
-  float* dsf_tab = nullptr;           // [DSF_TAB_N][8] on the device
-  float dsf_tab_alpha = -1.f, dsf_tab_rc = -1.f;
   ChainPlan chain_fwd[AIMNET_MAX_PASS][2], chain_bwd[AIMNET_MAX_PASS][2];
   // AIMNET_D3_CN_RIDES / set_option("d3_cn_rides"): the DFT-D3 coordination numbers are formed by the cell-grid list build that serves
   // D3 (kernels.h, D3CnRider) instead of by a pass over the finished matrix

@@ -619,8 +619,6 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     if (env) e->nse_merged = atoi(env) != 0;
     env = getenv("AIMNET_GEMM_CHAIN");
     if (env) e->gemm_chain = atoi(env) != 0;
-    env = getenv("AIMNET_DSF_TABLE");
-    if (env) e->dsf_table = atoi(env) != 0;
     (void)gemm_h2_set_attributes();  // AIMNET_H2_TILE / AIMNET_H2_DEEP (gemm_h2.hip)
     env = getenv("AIMNET_D3_CN_RIDES");
     if (env) e->d3_cn_rides = atoi(env) != 0;
@@ -684,10 +682,6 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     e->head.push_back(L);
     if ((rc = dev_upload(e, w->head_w[l], (size_t)L.n_in, &e->head_w_last))) goto fail;
     if ((rc = dev_upload(e, w->head_b[l], (size_t)1, &e->head_b_last))) goto fail;
-  }
-  {
-    std::vector<float> zeros((size_t)DSF_TAB_N * 8, 0.0f);
-    if ((rc = dev_upload(e, zeros.data(), zeros.size(), &e->dsf_tab))) goto fail;
   }
   if (e->h2_fits) {  // one-launch MLP sweeps (gemm_chain.hip) where the layer sizes match an instantiated shape
     for (int p = 0; p < arch->n_pass; ++p) {
@@ -789,7 +783,6 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "sums_whole") e->sums_whole = value != 0;
   else if (n == "nse_merged") e->nse_merged = value != 0;
   else if (n == "gemm_chain") e->gemm_chain = value != 0;
-  else if (n == "dsf_table") e->dsf_table = value != 0;
   else if (n == "d3_cn_rides") e->d3_cn_rides = value != 0;
   else if (n == "split_max") e->split_max = value < 0 ? conv_split_max_default() : value;
   else if (n == "p0_moments") e->p0_moments = value != 0;
@@ -820,7 +813,6 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
   else if (n == "sums_whole") *value = e->sums_whole;
   else if (n == "nse_merged") *value = e->nse_merged;
   else if (n == "gemm_chain") *value = e->gemm_chain;
-  else if (n == "dsf_table") *value = e->dsf_table;
   else if (n == "d3_cn_rides") *value = e->d3_cn_rides;
   else if (n == "split_max") *value = e->split_max;
   else if (n == "p0_moments") *value = e->p0_moments ? 1 : 0;
@@ -1147,17 +1139,6 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     cp.sr_envelope = ar.sr_envelope;
     cp.dsf_rc = opt->dsf_rc;
     cp.dsf_alpha = opt->dsf_alpha;
-    if (e->dsf_table && coulomb == AIMNET_COULOMB_DSF && pbc && !ext && e->dsf_tab) {
-      if (e->dsf_tab_alpha != opt->dsf_alpha || e->dsf_tab_rc != opt->dsf_rc) {  // (rare: the parameters are calculator settings)
-        std::vector<float> t((size_t)DSF_TAB_N * 8);
-        dsf_pair_table(opt->dsf_alpha, opt->dsf_rc, t.data());
-        AIMNET_HIP_CHECK(hipStreamSynchronize(cs));  // no evaluation in flight may still read the old table
-        AIMNET_HIP_CHECK(hipMemcpy(e->dsf_tab, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
-        e->dsf_tab_alpha = opt->dsf_alpha;
-        e->dsf_tab_rc = opt->dsf_rc;
-      }
-      cp.dsf_tab = reinterpret_cast<const float4*>(e->dsf_tab);
-    }
     const bool pme = coulomb == AIMNET_COULOMB_PME;
     const bool ewald = coulomb == AIMNET_COULOMB_EWALD || pme;  // (the real-space walk and the self term are the same)
     if (pme) {  // per-system (alpha, rc, mesh) from the cell, fractional coordinates in double (pme.hip)

@@ -357,14 +357,7 @@ struct CoulombParams {
   float dsf_rc, dsf_alpha;
   const EwaldSystem* ewald = nullptr;  // != NULL: the list-free walk sums the REAL-space Ewald term erfc(alpha d) / d with the
                                        // system's own (alpha, rc) instead of the shifted DSF pair term
-  // DSF pair term as a table (dsf_pair_table below; NULL: evaluated analytically): interval k of [0, dsf_rc] holds the cubics of
-  // w(d) (entry 2k) and w'(d) / d (entry 2k + 1) in t = d DSF_TAB_N / dsf_rc - k
-  const float4* dsf_tab = nullptr;
 };
-constexpr int DSF_TAB_N = 512;  // intervals (16 KiB of LDS in the walk kernel)
-// cubics (monomial coefficients in t, fitted in double through four points of each interval) of the damped-shifted-force pair term
-// w(d) = erfc(a d) / d - erfc(a Rc) / Rc + (d - Rc) slope and of w'(d) / d (aimnet/modules/lr.py:559-615), for the list-free walk
-void dsf_pair_table(float alpha, float rc, float* tab8 /* [DSF_TAB_N][8] */);
 
 // ---- d3.hip: DFT-D3(BJ) two-body dispersion on a full neighbour list ------------------------------
 struct D3Params {

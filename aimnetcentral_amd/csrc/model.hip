@@ -645,7 +645,7 @@ int launch_coulomb_dsf(hipStream_t s, bool grad, bool stress, const float* q, co
 // periodic DSF without a neighbour matrix: the wave walks the bins of the short-range cell grid out to
 // Rc and accumulates the pair terms directly (no 8 B x ~1800 per atom list write + re-read, no row
 // capacity / overflow handling for the long-range cutoff)
-template <bool GRAD, bool STRESS, bool TAB = false>  // TAB: the DSF pair term from cp.dsf_tab (never with cp.ewald)
+template <bool GRAD, bool STRESS>
 __global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __restrict__ q, const float* __restrict__ xw,
                                                               const int* __restrict__ mol_idx,
                                                               const NlistSystem* __restrict__ sys,
@@ -663,11 +663,6 @@ __global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __re
   // instructions (erfc, exp, fp64 energy sum, virial).  So the walk only COMPACTS the hits (r, q_j) into a
   // per-wave LDS queue, and the expensive math runs on full 64-lane batches popped from that queue.
   __shared__ float4 queue[4][128];
-  __shared__ float4 s_tab[TAB ? 2 * DSF_TAB_N : 1];
-  if (TAB) {  // the pair-term table (16 KiB, L2-resident) -> LDS
-    for (int k = threadIdx.x; k < 2 * DSF_TAB_N; k += 256) s_tab[k] = cp.dsf_tab[k];
-    __syncthreads();
-  }
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
@@ -682,37 +677,11 @@ __global__ __launch_bounds__(256) void coulomb_dsf_walk_kernel(const float* __re
   const float slope = ewald ? 0.0f : erfc_rc / (Rc * Rc) + two_a_sqrtpi * expf(-al * al * Rc * Rc) / Rc;
   const float xi = xw[3 * i], yi = xw[3 * i + 1], zi = xw[3 * i + 2], qi = q[i];
   PairAcc A;
-  const float tab_scale = (float)DSF_TAB_N / Rc;
   auto pair_term = [&](const float4& e) {
     // single-instruction rsq / exp2 (1 ulp): the kernel is VALU-issue bound and the pair sums are fp64 anyway
     const float d2 = e.x * e.x + e.y * e.y + e.z * e.z;
     const float inv = __builtin_amdgcn_rsqf(d2);
     const float d = d2 * inv;
-    if (TAB) {
-      // w(d) and w'(d) / d from per-interval cubics (dsf_pair_table: fitted in double, 5e-8 relative at 1 A, better beyond): two
-      // LDS reads and six FMAs instead of exp2 + rcp + a degree-9 polynomial + the assembly of w and w' (~30 instructions)
-      if (d < Rc) {
-        const float sd = d * tab_scale;
-        const int k = min((int)sd, DSF_TAB_N - 1);
-        const float t = sd - (float)k;
-        const float4 cw = s_tab[2 * k], cg = s_tab[2 * k + 1];
-        const float w = fmaf(fmaf(fmaf(cw.w, t, cw.z), t, cw.y), t, cw.x);
-        const float gd = fmaf(fmaf(fmaf(cg.w, t, cg.z), t, cg.y), t, cg.x);
-        const float qq = qi * e.w;
-        A.e += (double)(w * qq);
-        if (GRAD) {
-          A.qb += w * e.w;
-          const float sc = gd * qq;
-          const float px = sc * e.x, py = sc * e.y, pz = sc * e.z;
-          A.f0 += px; A.f1 += py; A.f2 += pz;
-          if (STRESS) {
-            A.W[0] += px * e.x; A.W[1] += px * e.y; A.W[2] += px * e.z;
-            A.W[4] += py * e.y; A.W[5] += py * e.z; A.W[8] += pz * e.z;
-          }
-        }
-      }
-      return;
-    }
     if (d < Rc) {  // the walk tests the squared distance; the reference tests d < Rc on the root (a pair at Rc weighs 0)
       // erfc(x) = exp(-x^2) t P(t), t = 1 / (1 + x/2): degree-9 fit of erfcx(x) / t on x in [0, 6.5] (6.5e-9 relative; the fp32
       // Horner evaluation adds 2.5e-7, the class of erfcf itself) - the exponential is the one the derivative needs anyway
@@ -784,39 +753,6 @@ __global__ void charge_stream_kernel(const float4* __restrict__ xs, const float*
   charge_stream_block(xs, q, n_atoms, xq, charges_out, blockIdx.x);
 }
 
-void dsf_pair_table(float alpha, float rc, float* tab8) {
-  const double a = alpha, Rc = rc, PI = 3.14159265358979323846;
-  const double erfc_rc = erfc(a * Rc), sv = erfc_rc / Rc;
-  const double slope = erfc_rc / (Rc * Rc) + 2.0 * a / sqrt(PI) * exp(-a * a * Rc * Rc) / Rc;
-  auto w = [&](double d) { return erfc(a * d) / d - sv + (d - Rc) * slope; };
-  auto g = [&](double d) { return (-erfc(a * d) / (d * d) - 2.0 * a / sqrt(PI) * exp(-a * a * d * d) / d + slope) / d; };
-  const double h = Rc / DSF_TAB_N;
-  for (int k = 0; k < DSF_TAB_N; ++k) {
-    // cubic through t = 0, 1/3, 2/3, 1 (Lagrange -> monomial); the first interval starts at d = 0, where the term diverges: its
-    // nodes are moved inside (no pair is that close; the walk clamps)
-    const double d0 = k == 0 ? 0.25 * h : k * h, d1 = (k + 1) * h, hh = d1 - d0;
-    for (int f = 0; f < 2; ++f) {
-      double y[4];
-      for (int q = 0; q < 4; ++q) y[q] = f == 0 ? w(d0 + hh * q / 3.0) : g(d0 + hh * q / 3.0);
-      // p(t) = c0 + c1 t + c2 t^2 + c3 t^3 through (0, y0), (1/3, y1), (2/3, y2), (1, y3)
-      const double c0 = y[0];
-      const double c1 = (-11.0 * y[0] + 18.0 * y[1] - 9.0 * y[2] + 2.0 * y[3]) / 2.0;
-      const double c2 = (18.0 * y[0] - 45.0 * y[1] + 36.0 * y[2] - 9.0 * y[3]) / 2.0;
-      const double c3 = (-9.0 * y[0] + 27.0 * y[1] - 27.0 * y[2] + 9.0 * y[3]) / 2.0;
-      double c[4] = {c0, c1, c2, c3};
-      if (k == 0) {  // re-express in t over [0, h] (t' = (d - d0) / hh = (t h - d0) / hh): only evaluated for d >= d0 in practice
-        const double s0 = -d0 / hh, s1 = h / hh;  // t' = s0 + s1 t
-        const double e0 = c0 + c1 * s0 + c2 * s0 * s0 + c3 * s0 * s0 * s0;
-        const double e1 = (c1 + 2.0 * c2 * s0 + 3.0 * c3 * s0 * s0) * s1;
-        const double e2 = (c2 + 3.0 * c3 * s0) * s1 * s1;
-        const double e3 = c3 * s1 * s1 * s1;
-        c[0] = e0; c[1] = e1; c[2] = e2; c[3] = e3;
-      }
-      for (int q = 0; q < 4; ++q) tab8[(size_t)k * 8 + f * 4 + q] = (float)c[q];
-    }
-  }
-}
-
 int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* q, const int* mol_idx, NlistBuffers& b,
                             CoulombParams cp, int n_atoms, double* ecoul, float* qbar, float* fgrad, float* virial_atom,
                             float* charges_out, bool stream_done, const PairMapRider* rev_rider) {
@@ -829,14 +765,7 @@ int launch_coulomb_dsf_walk(hipStream_t s, bool grad, bool stress, const float* 
     hipLaunchKernelGGL(charge_stream_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, b.xs, q, n_atoms, xq, charges_out);
     AIMNET_LAUNCH_CHECK();
   }
-  if (cp.ewald) cp.dsf_tab = nullptr;
-  if (grad && stress && cp.dsf_tab)
-    hipLaunchKernelGGL((coulomb_dsf_walk_kernel<true, true, true>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, xq, cp,
-                       n_atoms, ecoul, qbar, fgrad, virial_atom, pm);
-  else if (grad && cp.dsf_tab)
-    hipLaunchKernelGGL((coulomb_dsf_walk_kernel<true, false, true>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, xq, cp,
-                       n_atoms, ecoul, qbar, fgrad, virial_atom, pm);
-  else if (grad && stress)
+  if (grad && stress)
     hipLaunchKernelGGL((coulomb_dsf_walk_kernel<true, true>), grid, block, 0, s, q, b.xw, mol_idx, sys, b.bin_start, xq, cp,
                        n_atoms, ecoul, qbar, fgrad, virial_atom, pm);
   else if (grad)

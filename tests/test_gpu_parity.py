@@ -416,29 +416,3 @@ def test_cold_weights_at_headline_size_literal_gates(hip_engine_cold, name):
     assert np.abs(res["charges"] - g["charges"]).max() <= CHARGE_ATOL
     if "stress" in g:
         assert np.abs(res["stress"] - g["stress"]).max() <= STRESS_ATOL
-
-
-@pytest.mark.parametrize("rc, alpha", [(15.0, 0.2), (9.0, 0.25)])
-def test_dsf_pair_term_table_against_the_analytic_pair_term(hip_engine, rc, alpha):
-    """The list-free periodic DSF walk takes w(d), w'(d) / d from per-interval cubics (engine option "dsf_table", csrc/model.hip
-    dsf_pair_table; lr.py:559-615) - against the same walk with erfc / exp evaluated per pair: the fit is 5e-8 relative at 1 A and
-    better beyond, so energies, forces and stress agree far inside the parity gates.  Also: a change of (alpha, rc) rebuilds it."""
-    from aimnetcentral_amd import workloads
-
-    eng, dev = hip_engine, hip_engine.device
-    c, z, cell = workloads.glucose_supercell((2, 2, 2))
-    c = torch.from_numpy((c + np.random.default_rng(5).normal(0, 0.03, c.shape)).astype(np.float32)).to(dev)
-    args = (c, torch.from_numpy(z).to(dev), torch.zeros(len(z), dtype=torch.int64, device=dev), torch.zeros(1, device=dev))
-    kw = dict(cell=torch.from_numpy(cell.astype(np.float32)).to(dev), forces=True, stress=True, coulomb="dsf", dsf_rc=rc, dsf_alpha=alpha)
-    res = {}
-    try:
-        for mode in (0, 1):
-            eng.set_option("dsf_table", mode)
-            res[mode] = {k: v.cpu().numpy() for k, v in eng.eval(*args, **kw).items()}
-    finally:
-        eng.set_option("dsf_table", 1)
-    n = len(z)
-    assert abs(res[0]["energy"][0] - res[1]["energy"][0]) < 2e-7 * n
-    assert np.abs(res[0]["forces"] - res[1]["forces"]).max() < 3e-6
-    assert np.abs(res[0]["stress"] - res[1]["stress"]).max() < 2e-8
-    assert np.abs(res[0]["charges"] - res[1]["charges"]).max() < 1e-7

@@ -551,7 +551,10 @@ class AIMNet2Calculator:
 
     def check_status(self) -> None:
         """Verify every evaluation enqueued with `defer_status=True` since the last call (one synchronisation); raises
-        `engine.NeighborOverflowError` after growing the row capacity if one of them overflowed."""
+        `engine.NeighborOverflowError` after growing the row capacity if one of them overflowed, `ValueError` for invalid inputs,
+        and `engine.ActivationRangeError` - after switching the engine to the bf16x3 GEMM operands - when an energy or a force of
+        one of them was not finite (status[6] bit 5, raised on the device): in every case the evaluations since the last check are
+        invalid and have to be repeated."""
         self.engine.check_deferred()
 
     # ---- second derivatives (calculator.py:904-910,1247-1450,1753-1989; derivatives.py:149-192) -------------

@@ -576,6 +576,9 @@ __global__ __launch_bounds__(256) void unconcat_kernel(const float* __restrict__
           v1 += w * v3[1];
           v2 += w * v3[2];
         }
+#ifdef AIMNET_PROBE_SBAR16  // measurement builds only: what storing the vector planes of Sbar in fp16 would do to the forces
+        v0 = (float)(_Float16)v0; v1 = (float)(_Float16)v1; v2 = (float)(_Float16)v2;
+#endif
         vv[0][gi] = v0; vv[1][gi] = v1; vv[2][gi] = v2;
       }
       // (plane 0, the scalar part of xbar, is not stored: conv_bwd_kernel reads it from the xbar row itself)

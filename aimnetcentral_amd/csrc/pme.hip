@@ -244,8 +244,10 @@ __global__ __launch_bounds__(256) void pme_spread_kernel(const float* __restrict
   __syncthreads();
   unsigned long long* mq = reinterpret_cast<unsigned long long*>(meshq);
   const int j1 = lane >> 3, j2 = lane & 7;
-  const int e0 = smax[0] - smin[0] + PME_P, e1 = smax[1] - smin[1] + PME_P, e2 = smax[2] - smin[2] + PME_P;
-  const bool tiled = one_system && E.mesh_pts != 0 && (long)e0 * e1 * e2 <= (long)PME_TILE;
+  // (extents only where the min / max were formed: with mixed systems they still hold INT_MAX / INT_MIN - signed overflow)
+  const bool spans = one_system && E.mesh_pts != 0;
+  const int e0 = spans ? smax[0] - smin[0] + PME_P : 0, e1 = spans ? smax[1] - smin[1] + PME_P : 0, e2 = spans ? smax[2] - smin[2] + PME_P : 0;
+  const bool tiled = spans && (long)e0 * e1 * e2 <= (long)PME_TILE;
   if (!tiled) {  // direct form, one wave per atom in turn
     for (int a = wv; a < na; a += 4) {
       const int sa = mol_idx[satom[a]];

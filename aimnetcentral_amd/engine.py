@@ -362,6 +362,7 @@ class HipEngine:
         stream = torch.cuda.current_stream(dev).cuda_stream
         host = None
         h2_on, h2_retry = bool(self.get_option("gemm_h2")) and bool(self.get_option("gemm_presplit")), False
+        pme_shrunk = False
         while True:
             opt = _lib.EvalOptions()
             opt.flags = (_lib.FORCES if forces else 0) | (_lib.STRESS if stress else 0)
@@ -374,6 +375,18 @@ class HipEngine:
                 opt.ewald_accuracy = float(ewald_accuracy)
                 opt.ewald_max_k = self._ewald_max_k
                 opt.pme_max_mesh = self._pme_max_mesh
+                # the mesh workspace is n_mol slices of the LARGEST system's mesh this engine has seen (40 B per point): after one big
+                # cell, a batch of many small ones would ask for n_mol x that.  Shrink to the starting capacity once (status[7] grows
+                # it back to what THIS batch needs); if the batch itself is beyond the limit, say so instead of running out of memory.
+                # (the PME kernels index the systems through grid.y: <= 65 535)
+                if method == _lib.COULOMB_PME and (n_mol > 65535 or n_mol * self._pme_max_mesh * 40 > 64 << 30):
+                    if n_mol <= 65535 and not pme_shrunk and self._pme_max_mesh > 8192:
+                        pme_shrunk = True
+                        self._pme_max_mesh = opt.pme_max_mesh = 8192
+                    else:
+                        raise ValueError(f"HipEngine.eval(coulomb='pme'): {n_mol} systems x a mesh of {self._pme_max_mesh} points for the "
+                                         "largest of them exceeds the PME workspace limit (64 GiB, 65 535 systems); split the batch, or use "
+                                         "coulomb='ewald' / 'dsf'")
             if ext:  # caller-supplied matrices: the row capacities are their widths (nothing can overflow)
                 opt.max_nb = _round16(ext["nbmat"][0].shape[1])
                 opt.max_nb_lr = _round16(ext["nbmat_lr"][0].shape[1]) if "nbmat_lr" in ext else 0

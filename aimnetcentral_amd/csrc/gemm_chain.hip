@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
   f32x4 PA[CH_SM][CH_NTG];      // group A of the current pass: pre-activation -> activation (until the LDS write); GELU' of the previous pass' group B
   f32x4 PB[CH_SM][CH_NTG];      // group B: GELU' of group A (forward) / prefetched GELU' (backward); then the pre-activations of group B, whose
                                 // GELU runs under the next pass' first k-loop
-  f32x4 bb[CH_NTG], dtmp[2];    // bias of the group's slots (layers with ONE bias vector); GELU' tiles in flight (backward)
+  f32x4 bb[CH_NTG];             // bias of the group's slots (layers with ONE bias vector)
   f16x8 fa[2][CH_SM][2];        // the operand fragments of this k-step and of the next one (requested in front of this one's products)
   const unsigned adA = lds0 + l16 * 64 + ((lc ^ swz_h2(l16)) << 4);
 
@@ -296,13 +296,15 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
     //         by element (PB in place, GELU' into PA); in front of k-step KS - the first that reads their k-blocks - GELU' is stored and
     //         the activations enter the LDS operand (group A's were written at the end of the previous pass)
     // kind 2 (forward, group B's loop): GELU of group A element by element (PA in place, GELU' into PB)
-    // kind 3 (backward hidden, group B's loop): PA *= GELU' (tiles requested two jobs ahead)
+    // (backward: no jobs - GELU' of a group is requested as ONE batch half a k-loop / a whole k-loop ahead of the group's end, into PB:
+    // it was written by the forward sweep long ago and comes from HBM; the memory counter is in order, so every slow load holds the
+    // ring's waits behind it once - one batch per group instead of one tile at a time)
     constexpr int NT_PREV = I > 0 ? S::nt(I > 0 ? I - 1 : 0) : 0, NTA_PREV = chain_nta(NT_PREV), NTB_PREV = NT_PREV - NTA_PREV;
     constexpr bool GELU_PREV = !S::BWD && FIRST && I > 0 && I - 1 < S::NH && NTA_PREV > 0;
-    constexpr int KIND = GELU_PREV ? 1 : (G == 1 && NTA > 0) ? (!S::BWD ? 2 : TO_LDS ? 3 : 0) : 0;
+    constexpr int KIND = GELU_PREV ? 1 : (G == 1 && NTA > 0 && !S::BWD) ? 2 : 0;
     constexpr int KS = GELU_PREV ? NW * NTA_PREV / 2 : 0;
     static_assert(!GELU_PREV || (KS >= 3 && KS < NK), "group B of the previous pass must start behind k-block 2");
-    constexpr int NJOB = KIND == 1 ? CH_SM * NTB_PREV * 4 : KIND == 2 ? CH_SM * NTA * 4 : KIND == 3 ? 2 * CH_SM * NTA : 0;
+    constexpr int NJOB = KIND == 1 ? CH_SM * NTB_PREV * 4 : KIND == 2 ? CH_SM * NTA * 4 : 0;
     constexpr int NPOS = (GELU_PREV ? KS - 1 : NK - 1) * NTG;  // positions that take jobs
     const bool gelu_here = TO_LDS || (!S::BWD && P.epi != CH_BIAS_F32);  // this pass' outputs go through GELU
     auto job = [&](auto q_c) __attribute__((always_inline)) {
@@ -329,18 +331,6 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
           PA[i][s][r] = hh;
           PB[i][s][r] = dd;
         }
-      } else if constexpr (KIND == 3) {
-        constexpr int NTILE = CH_SM * NTA;
-        // order: L0 L1 M0 L2 M1 ... L(n-1) M(n-2) M(n-1): two GELU' tiles in flight
-        constexpr bool IS_LOAD = Q == 0 || (Q != 2 * NTILE - 1 && (Q & 1));
-        constexpr int n = Q == 0 ? 0 : Q == 2 * NTILE - 1 ? NTILE - 1 : (Q & 1) ? (Q + 1) / 2 : (Q - 2) / 2;
-        constexpr int i = n % CH_SM, s = n / CH_SM;
-        if constexpr (IS_LOAD) {
-          const int cc = min(col0(s), P.ncols - 4), rowc = min(row_of(i), a.M - 1);
-          dtmp[n & 1] = *reinterpret_cast<const f32x4*>(P.D + (size_t)rowc * P.ldd + cc);
-        } else {
-          PA[i][s] = PA[i][s] * dtmp[n & 1];
-        }
       }
     };
     // loads that the end of this k-loop consumes, requested behind slot SL of the last k-step: the bias of the slot (forward, layers with
@@ -350,12 +340,19 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
       const int cc = min(col0(SG + SL), P.ncols - 4);
       if constexpr (!S::BWD) {
         if (!P.brow) bb[SL] = *reinterpret_cast<const f32x4*>(P.bias + cc);
-      } else if constexpr (TO_LDS && G == 1) {
-#pragma unroll
-        for (int i = 0; i < CH_SM; ++i)
-          PB[i][SL] = *reinterpret_cast<const f32x4*>(P.D + (size_t)min(row_of(i), a.M - 1) * P.ldd + cc);
       }
     };
+    // backward hidden passes: GELU' of this group's tiles -> PB, one batch
+    auto prefetch_gelu_grad = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int sl = 0; sl < NTG; ++sl) {
+        const int cc = min(col0(SG + sl), P.ncols - 4);
+#pragma unroll
+        for (int i = 0; i < CH_SM; ++i)
+          PB[i][sl] = *reinterpret_cast<const f32x4*>(P.D + (size_t)min(row_of(i), a.M - 1) * P.ldd + cc);
+      }
+    };
+    constexpr int J_DGRAD = (S::BWD && TO_LDS) ? (G == 0 ? NK / 2 : 0) : -1;  // k-step in front of which that batch is requested
     // product sums of tile (i, s of the group) (+ bias, forward)
     auto combined = [&](int i, int s) __attribute__((always_inline)) -> f32x4 {
       f32x4 v = (acc[0][i][s] - acc[1][i][s]) + acc[2][i][s] * H2_INV_SCALE;
@@ -396,6 +393,10 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
         wait_lgkm<0>();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (J == J_DGRAD) {
+        prefetch_gelu_grad();
         __builtin_amdgcn_sched_barrier(0);
       }
       // fragments: this k-step's were requested one step ahead; request the next step's in front of this step's products
@@ -450,6 +451,7 @@ __global__ __launch_bounds__(64 * S::NW, 1) void gemm_chain_kernel(ChainArgs a) 
 #pragma unroll
         for (int i = 0; i < CH_SM; ++i) {
           PA[i][s] = combined(i, s);
+          if constexpr (S::BWD && TO_LDS) PA[i][s] = PA[i][s] * PB[i][s];  // x GELU'(z) of the layer below (requested half a k-loop ago)
           asm volatile("" : "+v"(PA[i][s]));  // (formed HERE: the compiler otherwise sinks this into the side jobs and keeps - spills - the raw accumulators)
         }
     } else if constexpr (!S::BWD && TO_LDS && NTA > 0) {

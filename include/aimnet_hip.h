@@ -299,6 +299,10 @@ int aimnet_engine_debug_mlp_sweep(aimnet_engine* engine, int pass, int backward,
  *                   4 instead of 6 bytes per element; rms error below the bf16x3 form's, profiles/r5_gemm_h2.md), 0: the bf16x3 form
  *                   (csrc/gemm_bf3a.hip).  fp16 holds |x| < 65504: weights beyond it switch the option off at create time,
  *                   activations beyond it surface as non-finite outputs (the Python layer then repeats the call with 0 and stays there)
+ *   "gemm_chain"    1 (default): with fp16x2-split activations every MLP sweep (forward or backward, one per pass) whose layer sizes
+ *                   match an instantiated shape is ONE launch (csrc/gemm_chain.hip: a block owns 16 / 32 / 48 rows and the full width
+ *                   of every layer, hidden activations stay in LDS, weights stream L2 -> registers in a packed fragment order); 0: one
+ *                   launch per layer (csrc/gemm_h2.hip).  Bitwise-identical results (tests/test_gpu_chain.py)
  *   "head_fused"    1 (default): with pre-split activations the energy head 256 -> 128 -> 128 -> 1 runs forward and backward in one
  *                   launch (csrc/gemm_head.hip), 0: four GEMM launches + the last-layer rider
  *   "prep_fused"    1 (default): periodic batches of <= 4 096 atoms / 64 systems prepare their cell grid (status zeroing, molecule

@@ -11,7 +11,7 @@ import os
 from functools import lru_cache
 
 MAX_PASS, MAX_LAYERS, MAX_SHIFTS = 4, 6, 32
-ABI_VERSION = 10  # AIMNET_ABI_VERSION of include/aimnet_hip.h this binding was written against
+ABI_VERSION = 11  # AIMNET_ABI_VERSION of include/aimnet_hip.h this binding was written against
 FORCES, STRESS = 1, 2
 COULOMB_NONE, COULOMB_SIMPLE, COULOMB_DSF, COULOMB_EWALD, COULOMB_PME = 0, 1, 2, 3, 4
 E_INVALID, E_HIP, E_WORKSPACE = -1, -2, -3
@@ -46,12 +46,17 @@ EXPORTED_SYMBOLS = (
     "aimnet_engine_set_option",
     "aimnet_engine_get_option",
     "aimnet_engine_set_dftd3",
+    "aimnet_engine_set_dd",
     "aimnet_neighbor_list",
     "aimnet_neighbor_list_workspace_bytes",
     "aimnet_conv_sv_2d_sp_fwd",
     "aimnet_conv_sv_2d_sp_bwd",
     "aimnet_conv_sv_2d_sp_bwd_bwd",
 )
+
+
+# aimnet_dd_exchange_fn of include/aimnet_hip.h (domain decomposition, aimnetcentral_amd/dd.py)
+DD_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p)
 
 
 class HipLibraryError(RuntimeError):
@@ -206,6 +211,8 @@ def load() -> C.CDLL:
     lib.aimnet_engine_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.c_int]
     lib.aimnet_engine_set_dftd3.restype = C.c_int
     lib.aimnet_engine_set_dftd3.argtypes = [vp, C.POINTER(DftD3Tables)]
+    lib.aimnet_engine_set_dd.restype = C.c_int
+    lib.aimnet_engine_set_dd.argtypes = [vp, vp, DD_EXCHANGE_FN, vp]
     lib.aimnet_debug_gemm.restype = C.c_int
     lib.aimnet_debug_gemm.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
     lib.aimnet_debug_split_bf3.restype = C.c_int

@@ -116,6 +116,9 @@ struct aimnet_engine {
   // AIMNET_D3_CN_RIDES / set_option("d3_cn_rides"): the DFT-D3 coordination numbers are formed by the cell-grid list build that serves
   // D3 (kernels.h, D3CnRider) instead of by a pass over the finished matrix
   int d3_cn_rides = 1;
+  // aimnet_engine_set_dd: spatial domain decomposition of one system over ranks - owned-atom mask of the local cluster and the
+  // caller's exchange function (dd.owned == NULL: off)
+  aimnet::DdLink dd{nullptr, nullptr, nullptr};
   double* sae;
   // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row

@@ -825,6 +825,15 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
   return AIMNET_OK;
 }
 
+int aimnet_engine_set_dd(aimnet_engine* e, const float* owned, aimnet_dd_exchange_fn fn, void* ctx) {
+  if (!e || (owned && !fn)) {
+    set_last_error("set_dd: an owned-atom mask needs an exchange function");
+    return AIMNET_E_INVALID;
+  }
+  e->dd = aimnet::DdLink{owned, owned ? fn : nullptr, owned ? ctx : nullptr};
+  return AIMNET_OK;
+}
+
 int aimnet_engine_set_dftd3(aimnet_engine* e, const aimnet_dftd3_tables* t) {
   if (!e || !t || t->n_z <= 0 || !t->c6ab || !t->cn_ref || !t->rcov || !t->r4r2) {
     set_last_error("set_dftd3: null argument");
@@ -987,6 +996,13 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     set_last_error("eval: nbmat_lr / nbmat_d3 are only read together with nbmat");
     return AIMNET_E_INVALID;
   }
+  // spatial domain decomposition (aimnet_engine_set_dd): the local cluster of owned + halo atoms is a non-periodic system
+  const aimnet::DdLink* dd = e->dd.owned ? &e->dd : nullptr;
+  if (dd && (pbc || ext || want_s || opt->dftd3 != 0 || !(coulomb == AIMNET_COULOMB_NONE || coulomb == AIMNET_COULOMB_DSF))) {
+    set_last_error("eval: a domain-decomposed evaluation takes a non-periodic cluster (no cell, no caller-supplied lists), Coulomb "
+                   "'none' or 'dsf', no DFT-D3 and no stress request");
+    return AIMNET_E_INVALID;
+  }
   hipStream_t s = (hipStream_t)hip_stream;
   AIMNET_HIP_CHECK(hipSetDevice(e->device));
   Workspace W;
@@ -1116,7 +1132,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   // launches instead of standing in front of the forward pass: the hash build on the SR-Coulomb launch, the lookup on the DSF walk
   // (VALU-bound, the lookup is latency-bound) or else on the energy reduction - kernels.h PairMapRider)
   PairMapRider pmap{};
-  const bool overlap_early = e->overlap_coulomb && e->prof_level < 2;
+  const bool overlap_early = e->overlap_coulomb && e->prof_level < 2 && !dd;
   if (W.xe && want_f) {
     if (overlap_early) {
       RC(launch_pair_rev_hash(s, W.nb_idx, n_cell > 0 ? W.nb_shift : nullptr, W.nb_cnt, cap, N, W.rev_tab, W.rev));
@@ -1127,7 +1143,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   bool rev_done = pmap.n_blocks == 0;
   // ---- Coulomb: energies, and the seeds of qbar / dE/dx / virial (a closure: it runs on the eval stream or on the side one) ----
   const float* q_fin = nq == 2 ? W.qtot : W.q[np - 2];
-  const bool overlap = e->overlap_coulomb && e->prof_level < 2;  // per-family profiling wants one stream
+  const bool overlap = e->overlap_coulomb && e->prof_level < 2 && !dd;  // per-family profiling wants one stream
   bool charges_written = false;  // the DSF walk's charge stream kernel copies q to the `charges` output on its way
   SrRiders head_rider{};  // the last energy-head layer rides on the SR-Coulomb launch (filled in below when both run on one stream)
   auto coulomb_block = [&](hipStream_t cs) -> int {
@@ -1250,7 +1266,13 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       // (the feature update a^{p+1} = a^p + delta_a rides on the NSE launch: independent work, one kernel boundary less)
       RC(launch_nse_fwd(s, W.H[p][nl - 1], Ls[nl - 1].k_out, nq, p > 0 ? W.q[p - 1] : nullptr, W.nl.mol_start, in->charge,
                         n_mol, N, W.S, (float*)W.part, W.q[p], W.Fm[p], W.Dm[p], p == 0 ? e->afv : W.a[p],
-                        p == 0 ? in->numbers : nullptr, W.a[p + 1], W.at[p + 1]));
+                        p == 0 ? in->numbers : nullptr, W.a[p + 1], W.at[p + 1], dd));
+      // domain decomposition: the final charges of halo copies are exact only within one cutoff of the owned region, the Coulomb
+      // sums reach further - the owners' values come in through the exchange function
+      if (dd && p == np - 2 && dd->fn(dd->ctx, AIMNET_DD_CHARGES, W.q[p], (int64_t)nq * N, (void*)s) != 0) {
+        set_last_error("eval: the domain-decomposition exchange function failed (charges)");
+        return AIMNET_E_INVALID;
+      }
       if (p == np - 2 && overlap) {  // the final charges exist: the Coulomb block starts on the side stream
         AIMNET_HIP_CHECK(hipEventRecord(e->ev_fork, s));
         AIMNET_HIP_CHECK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
@@ -1305,6 +1327,12 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   if (!overlap) {
     RC(prof_mark(e, s, FAM_COULOMB));
     RC(coulomb_block(s));
+  }
+  if (dd) {  // halo copies: no energy, no Coulomb adjoint / direct force, no backward seed (model.hip, dd_mask_kernel)
+    const int nlp = (int)e->mlp[np - 1].size();
+    const int seed_bytes = hfused ? pm * e->mlp[np - 1][nlp - 1].k_out * 2 : e->head[e->head.size() - 2].k_out * 4;
+    RC(launch_dd_mask(s, dd->owned, in->numbers, e->sae, W.e_atom, W.ecoul, grad ? W.qbar : nullptr, nq, grad ? W.fgrad : nullptr,
+                      nullptr, grad ? W.zb0 : nullptr, seed_bytes, N));
   }
   // results of the Coulomb block (ecoul, qbar / fgrad / virial seeds, qtot) are first needed here (energy only) or in front of
   // the first conv backward (see `join` below)
@@ -1415,7 +1443,16 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const float* y = W.H[p - 1][nlq - 1];
     const int ldy = Lq[nlq - 1].k_out;
     RC(prof_mark(e, s, FAM_POINTWISE));
-    if (e->nse_merged && N <= 1024) {  // small systems: the molecule sums inside build_zbar, one launch instead of two
+    if (dd) {  // domain decomposition: the adjoint sums run over every local atom and are all-reduced over the ranks
+      RC(launch_nse_bwd_reduce(s, W.qbar, y, ldy, nq, W.nl.mol_start, n_mol, N, 1, (float*)W.part));
+      if (dd->fn(dd->ctx, AIMNET_DD_SUM, W.part, (int64_t)nq * n_mol, (void*)s) != 0) {
+        set_last_error("eval: the domain-decomposition exchange function failed (NSE adjoint sums)");
+        return AIMNET_E_INVALID;
+      }
+      RC(launch_build_zbar(s, W.qbar, W.abar, y, ldy, ar.last_linear[p - 1] ? nullptr : W.D[p - 1][nlq - 1], W.Fm[p - 1],
+                           W.Dm[p - 1], (const float*)W.part, 1, mol_c, N, n_mol, 256, nq, p - 1 > 0, znext, W.qbar, sfmt, nullptr,
+                           dd->owned));
+    } else if (e->nse_merged && N <= 1024) {  // small systems: the molecule sums inside build_zbar, one launch instead of two
       RC(launch_build_zbar(s, W.qbar, W.abar, y, ldy, ar.last_linear[p - 1] ? nullptr : W.D[p - 1][nlq - 1], W.Fm[p - 1],
                            W.Dm[p - 1], nullptr, 1, mol_c, N, n_mol, 256, nq, p - 1 > 0, znext, W.qbar2, sfmt, W.nl.mol_start));
       std::swap(W.qbar, W.qbar2);

@@ -281,11 +281,22 @@ struct PairMapRider {
 // S = slices (blocks) per molecule for the per-molecule reductions; `part` = scratch [n_sys * S * 9] doubles
 // nq = charge channels (1, or 2 for NSE models): q planes [nq][n_atoms], charge / Fm / Dm / Wbar planes [nq][n_mol];
 // the MLP output row is [q~ (nq) | f~ (nq) | delta_a (256)] (aimnet2.py:123-130)
+// Domain decomposition of one system over ranks (include/aimnet_hip.h, aimnet_engine_set_dd): the rank's owned-atom mask and the
+// caller's exchange function (what = 0: all-reduce n floats in place, 1: fill the halo entries of the charge planes)
+struct DdLink {
+  const float* owned;
+  int (*fn)(void* ctx, int32_t what, void* dev_ptr, int64_t n_float, void* hip_stream);
+  void* ctx;
+};
+// halo rows leave the energy sums, the Coulomb adjoints / direct forces and the backward seed (model.hip, dd_mask_kernel)
+int launch_dd_mask(hipStream_t s, const float* owned, const int* numbers, const double* sae, float* e_atom, double* ecoul,
+                   float* qbar, int nq, float* fgrad, float* virial_atom, void* seed, int seed_row_bytes, int n_atoms);
 int launch_nse_fwd(hipStream_t s, const float* y, int ldy, int nq, const float* q_prev, const int* mol_start,
                    const float* charge, int n_mol, int n_atoms, int S, float* part, float* q_new, float* Fm, float* Dm,
                    // upd_a_new != NULL: a_new = a + delta_a (launch_update_a with these arguments) rides on the same launch
                    const float* upd_a = nullptr, const int* upd_row_of = nullptr, float* upd_a_new = nullptr,
-                   float* upd_a_t = nullptr);
+                   float* upd_a_t = nullptr,
+                   const DdLink* dd = nullptr);  // != NULL: sums over owned atoms, all-reduced by dd->fn between the two launches
 int launch_charge_sum(hipStream_t s, const float* q2, int n_atoms, float* q_tot, float* q_spin);
 int launch_update_a(hipStream_t s, const float* a, const int* row_of, const float* y, int ldy, int nq, int n_atoms, float* a_new,
                     float* a_t = nullptr);  // a_t: optional copy in the operand layout of the MFMA conv kernels
@@ -418,7 +429,8 @@ int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const
                       int zbar_split = 0,
                       // wpart == NULL: the blocks form the molecule sums themselves (no launch_nse_bwd_reduce in front: small systems);
                       // needs mol_start and qbar_next != qbar
-                      const int* mol_start = nullptr);  // 1: rows in the split form of gemm_bf3a.hip (bf16 elements, 3 * ldy per row), 2: of gemm_h2.hip (2 * ldy)
+                      const int* mol_start = nullptr,
+                      const float* owned = nullptr);  // (domain decomposition: halo rows take no share of the sums' adjoint)  1: rows in the split form of gemm_bf3a.hip (bf16 elements, 3 * ldy per row), 2: of gemm_h2.hip (2 * ldy)
 // launch_pair_force's arguments as a rider of the stress reduction (launch_finalize): n_blocks = ceil(n_atoms / 4), 0 = none
 struct PairForceRider {
   const int* nb_idx; const int* nb_cnt; const int* rev; const float4* pairbuf; int cap; float* forces; int n_blocks;

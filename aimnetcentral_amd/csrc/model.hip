@@ -103,13 +103,16 @@ __device__ __forceinline__ void slice_bounds(const int* __restrict__ mol_start, 
 __global__ __launch_bounds__(256) void nse_fwd_partial_kernel(const float* __restrict__ y, int ldy, int qcol, int fcol,
                                                              const float* __restrict__ q_prev,
                                                              const int* __restrict__ mol_start, int S,
-                                                             float* __restrict__ part) {
+                                                             float* __restrict__ part,
+                                                             const float* __restrict__ owned = nullptr) {
+  // owned != NULL (domain decomposition, DdLink): halo copies carry weight 0 - their owners' ranks count them
   __shared__ float sh[4];
   const int m = blockIdx.y, sl = blockIdx.x;
   int lo, hi;
   slice_bounds(mol_start, m, sl, S, lo, hi);
   float sf = 0.f, sq = 0.f;
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    if (owned && owned[i] == 0.0f) continue;
     const float ft = y[(size_t)i * ldy + fcol];
     sf += ft * ft;
     sq += (q_prev ? q_prev[i] : 0.0f) + y[(size_t)i * ldy + qcol];
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void nse_fwd_apply_kernel(const float* __restr
 
 int launch_nse_fwd(hipStream_t s, const float* y, int ldy, int nq, const float* q_prev, const int* mol_start,
                    const float* charge, int n_mol, int n_atoms, int S, float* part, float* q_new, float* Fm, float* Dm,
-                   const float* upd_a, const int* upd_row_of, float* upd_a_new, float* upd_a_t) {
+                   const float* upd_a, const int* upd_row_of, float* upd_a_new, float* upd_a_t, const DdLink* dd) {
   // upd_a_new != NULL: the feature update a_new = a + delta_a (launch_update_a) rides on the launch of channel 0
   const UpdateA none{nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
   const UpdateA upd{upd_a, upd_row_of, y, ldy, 2 * nq, n_atoms, upd_a_new, upd_a_t};
@@ -172,6 +175,20 @@ int launch_nse_fwd(hipStream_t s, const float* y, int ldy, int nq, const float* 
     float* qn = q_new + (size_t)ch * n_atoms;
     float *F = Fm + (size_t)ch * n_mol, *D = Dm + (size_t)ch * n_mol;
     const int extra = ch == 0 ? n_upd : 0;
+    if (dd) {
+      // domain decomposition: one slice per molecule summed over the OWNED atoms, all-reduced over the ranks by the caller's
+      // exchange function, then applied to every local atom (halo copies included: the convolutions of the next pass read them)
+      hipLaunchKernelGGL(nse_fwd_partial_kernel, dim3(1, n_mol), dim3(256), 0, s, y, ldy, ch, nq + ch, qp, mol_start, 1, part, dd->owned);
+      AIMNET_LAUNCH_CHECK();
+      if (dd->fn(dd->ctx, 0 /* AIMNET_DD_SUM */, part, 2 * (int64_t)n_mol, (void*)s) != 0) {
+        set_last_error("eval: the domain-decomposition exchange function failed (NSE sums)");
+        return -1;
+      }
+      hipLaunchKernelGGL(nse_fwd_apply_kernel, dim3(n_mol + extra), dim3(256), 0, s, y, ldy, ch, nq + ch, qp, mol_start, Q, 1, part,
+                         qn, F, D, n_mol, ch == 0 ? upd : none);
+      AIMNET_LAUNCH_CHECK();
+      continue;
+    }
     if (S <= 1) {
       hipLaunchKernelGGL(nse_fwd_kernel, dim3(n_mol + extra), dim3(256), 0, s, y, ldy, ch, nq + ch, qp, mol_start, Q, qn, F, D, n_mol,
                          ch == 0 ? upd : none);
@@ -817,7 +834,7 @@ __global__ __launch_bounds__(256) void build_zbar_kernel(const float* __restrict
                                   const float* __restrict__ wpart, int S, const int* __restrict__ mol_idx, int n_atoms,
                                   int n_mol, int n_feat, int nq, int carry_q, float* __restrict__ zbar,
                                   float* __restrict__ qbar_next, unsigned short* __restrict__ zbar3, int fmt,
-                                  const int* __restrict__ mol_start) {
+                                  const int* __restrict__ mol_start, const float* __restrict__ owned) {
   // wpart == NULL (small systems, launch_build_zbar): the block forms sum_i qbar_i f_i of the molecules of its four atoms itself
   // (same code and order in every block that needs a molecule: the same bits) - what nse_bwd_partial_kernel and a kernel boundary
   // did.  Pays while a molecule is a few hundred atoms (a 113-atom molecule: -6 us per pass); for 10^4 atoms the redundant sums cost
@@ -866,7 +883,9 @@ __global__ __launch_bounds__(256) void build_zbar_kernel(const float* __restrict
     } else {
       wsum = s_w[ch][threadIdx.x >> 6];
     }
-    qr[ch] = qbar[(size_t)ch * n_atoms + i] - wsum / F;
+    // (domain decomposition: the molecule sums ran over owned atoms only, so only they receive the sums' adjoint; wsum is the
+    // all-reduced sum over every rank's local atoms)
+    qr[ch] = (owned && owned[i] == 0.0f) ? qbar[(size_t)ch * n_atoms + i] : qbar[(size_t)ch * n_atoms + i] - wsum / F;
     fsc[ch] = Dm[(size_t)ch * n_mol + m] / F;
   }
   float* zr = zbar + (size_t)i * ldy;
@@ -903,14 +922,45 @@ __global__ __launch_bounds__(256) void build_zbar_kernel(const float* __restrict
 
 int launch_build_zbar(hipStream_t s, const float* qbar, const float* abar, const float* y, int ldy, const float* dlast,
                       const float* Fm, const float* Dm, const float* wpart, int S, const int* mol_idx, int n_atoms, int n_mol,
-                      int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next, int zbar_split, const int* mol_start) {
+                      int n_feat, int nq, bool carry_q, float* zbar, float* qbar_next, int zbar_split, const int* mol_start,
+                      const float* owned) {
   if (!wpart && (!mol_start || qbar_next == qbar)) {  // (the blocks re-read qbar of whole molecules: it must not change under them)
     set_last_error("build_zbar: the merged form needs mol_start and a qbar_next that is not qbar");
     return -1;
   }
   hipLaunchKernelGGL(build_zbar_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, qbar, abar, y, ldy, dlast, Fm, Dm, wpart,
                      S < 1 ? 1 : S, mol_idx, n_atoms, n_mol, n_feat, nq, carry_q ? 1 : 0, zbar, qbar_next,
-                     zbar_split ? reinterpret_cast<unsigned short*>(zbar) : nullptr, zbar_split, mol_start);
+                     zbar_split ? reinterpret_cast<unsigned short*>(zbar) : nullptr, zbar_split, mol_start, owned);
+  AIMNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- domain decomposition: halo rows leave the sums --------------------------------------------------
+// After the energy head and the Coulomb block: a halo copy contributes no energy (its pair-energy slot takes -SAE[Z], in double,
+// so that e + SAE + pair sums to exactly 0), no Coulomb adjoint, no direct Coulomb force / virial, and seeds no backward sweep
+// (its seed row is zeroed: zero is zero in every operand format).  One wave per atom.
+__global__ __launch_bounds__(256) void dd_mask_kernel(const float* __restrict__ owned, const int* __restrict__ numbers,
+                                                      const double* __restrict__ sae, float* __restrict__ e_atom,
+                                                      double* __restrict__ ecoul, float* __restrict__ qbar, int nq,
+                                                      float* __restrict__ fgrad, float* __restrict__ virial_atom,
+                                                      unsigned int* __restrict__ seed, int seed_row_words, int n_atoms) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n_atoms || owned[i] != 0.0f) return;
+  if (lane == 0) {
+    e_atom[i] = 0.0f;
+    ecoul[i] = -sae[min(63, max(0, numbers[i]))];
+  }
+  if (qbar && lane < nq) qbar[(size_t)lane * n_atoms + i] = 0.0f;
+  if (fgrad && lane < 3) fgrad[(size_t)i * 3 + lane] = 0.0f;
+  if (virial_atom && lane < 9) virial_atom[(size_t)i * 9 + lane] = 0.0f;
+  if (seed)
+    for (int c = lane; c < seed_row_words; c += 64) seed[(size_t)i * seed_row_words + c] = 0u;
+}
+
+int launch_dd_mask(hipStream_t s, const float* owned, const int* numbers, const double* sae, float* e_atom, double* ecoul,
+                   float* qbar, int nq, float* fgrad, float* virial_atom, void* seed, int seed_row_bytes, int n_atoms) {
+  hipLaunchKernelGGL(dd_mask_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, owned, numbers, sae, e_atom, ecoul, qbar, nq,
+                     fgrad, virial_atom, (unsigned int*)seed, seed_row_bytes / 4, n_atoms);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,282 @@
+"""Spatial domain decomposition of ONE periodic system over the GPUs of a node.
+
+The reference has no counterpart: it evaluates a system on one device and points users with several GPUs at independent
+processes (docs/tutorials/performance.md:275-285).  What the model's structure implies (aimnet/models/aimnet2.py:135-206:
+three message-passing passes of radius rc, the NSE charge normalisation aimnet/ops.py:99-145 per molecule, the external
+Coulomb term aimnet/modules/lr.py:559-615 over 15 A):
+
+* a rank OWNS the atoms of one slab of the cell (fractional coordinate along the widest axis) and holds HALO copies - periodic
+  images resolved here, on the host - of every atom within `halo` = max(3 rc, Coulomb cutoff) of the slab.  Owned + halo atoms
+  go to the engine as ONE NON-PERIODIC cluster (`slab_partition`);
+* the energy of an owned atom is exact inside that cluster except for two things that are global: the NSE sums (two scalars per
+  molecule, charge channel and pass: all-reduced through the engine's exchange function, include/aimnet_hip.h
+  aimnet_engine_set_dd) and the final charges of halo copies further than one cutoff from the slab (taken from their owners in
+  front of the Coulomb block, same function);
+* the backward sweep differentiates E_rank = sum of the owned atoms' energies with respect to EVERY local position (the adjoint
+  sums of the NSE steps are all-reduced, mirror image of the forward); the direct Coulomb force and dE/dq are formed at the owned
+  centre for both directions of a pair, so no charge adjoint crosses ranks; at the end the partial forces of halo copies are
+  added onto their owners (one reverse halo exchange) and the rank energies are summed.
+
+The exchanges here are the simple form - global-size arrays all-reduced over the group (40 KB of charges, 120 KB of forces at
+10^4 atoms): correct for any number of ranks on `nccl` (= RCCL) and `gloo`; the scalable form (neighbour-to-neighbour halo
+messages) changes `_Exchange` only.  No performance claim is attached to this module: at 10^4 atoms one MI355X
+evaluates the whole system in 1.2 ms; decomposition is for systems beyond one GPU's memory or time budget.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Any
+
+import numpy as np
+
+from . import _lib
+from .engine import NONFINITE_FLAG, _round16, describe_input_flags
+
+DD_SUM, DD_CHARGES = 0, 1  # AIMNET_DD_* of include/aimnet_hip.h
+EXCHANGE_FN = _lib.DD_EXCHANGE_FN
+
+
+@dataclass
+class SlabDomain:
+    """One rank's cluster: the first `n_owned` local atoms are owned (wrapped into the cell), the rest are halo copies."""
+
+    rank: int
+    world: int
+    axis: int
+    n_owned: int
+    gid: np.ndarray  # [n_loc] global index of every local atom
+    coord: np.ndarray  # [n_loc, 3] Cartesian positions with the periodic images resolved (float64)
+    shift: np.ndarray  # [n_loc, 3] integer lattice shift of every local atom relative to its wrapped position
+
+    @property
+    def n_local(self) -> int:
+        return int(self.gid.shape[0])
+
+    @property
+    def owned_mask(self) -> np.ndarray:
+        m = np.zeros(self.n_local, dtype=np.float32)
+        m[: self.n_owned] = 1.0
+        return m
+
+
+def perpendicular_widths(cell: np.ndarray) -> np.ndarray:
+    """Distance between the two faces of the cell (row vectors) that bound fractional coordinate d, for d = 0, 1, 2."""
+    cell = np.asarray(cell, dtype=np.float64)
+    inv = np.linalg.inv(cell)  # columns = reciprocal vectors (coord = frac @ cell)
+    return 1.0 / np.linalg.norm(inv, axis=0)
+
+
+def wrapped_fractional(coord: np.ndarray, cell: np.ndarray) -> np.ndarray:
+    f = np.asarray(coord, dtype=np.float64) @ np.linalg.inv(np.asarray(cell, dtype=np.float64))
+    f = f - np.floor(f)
+    f[f >= 1.0] = 0.0  # (x - floor(x) rounds to 1.0 for tiny negative x)
+    return f
+
+
+def owners(coord: np.ndarray, cell: np.ndarray, world: int, axis: int | None = None) -> tuple[np.ndarray, int]:
+    """Owner rank of every atom (equal-width slabs of the fractional coordinate along `axis`; default: the widest axis)."""
+    if axis is None:
+        axis = int(np.argmax(perpendicular_widths(cell)))
+    f = wrapped_fractional(coord, cell)
+    return np.minimum((f[:, axis] * world).astype(np.int64), world - 1), axis
+
+
+def slab_partition(coord: np.ndarray, cell: np.ndarray, world: int, rank: int, halo: float, axis: int | None = None) -> SlabDomain:
+    """Owned atoms of slab `rank` plus every periodic image of every atom inside the slab's box padded by `halo` along all three
+    cell axes (a superset of the points within `halo` of the slab: a point at Euclidean distance <= h from the region is at most
+    h / w_d outside it in fractional coordinate d, w_d the perpendicular width)."""
+    cell = np.asarray(cell, dtype=np.float64)
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("slab_partition: need 0 <= rank < world")
+    own, axis = owners(coord, cell, world, axis)
+    f = wrapped_fractional(coord, cell)
+    w = perpendicular_widths(cell)
+    lo = np.zeros(3)
+    hi = np.ones(3)
+    lo[axis], hi[axis] = rank / world, (rank + 1) / world
+    pad = halo / w
+    n_lo = np.floor(lo - pad).astype(int)
+    n_hi = np.floor(hi + pad).astype(int)
+    idx_owned = np.nonzero(own == rank)[0]
+    gids, shifts = [idx_owned], [np.zeros((idx_owned.shape[0], 3), dtype=np.int64)]
+    for nx in range(n_lo[0], n_hi[0] + 1):
+        for ny in range(n_lo[1], n_hi[1] + 1):
+            for nz in range(n_lo[2], n_hi[2] + 1):
+                n = np.array([nx, ny, nz])
+                g = f + n
+                inside = np.all((g >= lo - pad) & (g < hi + pad), axis=1)
+                if nx == 0 and ny == 0 and nz == 0:
+                    inside &= own != rank  # (the owned atoms themselves)
+                k = np.nonzero(inside)[0]
+                if k.size:
+                    gids.append(k)
+                    shifts.append(np.broadcast_to(n, (k.size, 3)).astype(np.int64))
+    gid = np.concatenate(gids)
+    shift = np.concatenate(shifts)
+    pos = (f[gid] + shift) @ cell
+    return SlabDomain(rank=rank, world=world, axis=axis, n_owned=int(idx_owned.shape[0]), gid=gid, coord=pos, shift=shift)
+
+
+class _Exchange:
+    """The engine's exchange function for one evaluation: all-reduce of the NSE sums, owner values for the halo charges."""
+
+    def __init__(self, dde: "DomainDecomposedEngine", dom: SlabDomain, gid_t, n_global: int):
+        self.dde, self.dom, self.gid, self.n_global = dde, dom, gid_t, n_global
+        self.error: BaseException | None = None
+        self.calls = {DD_SUM: 0, DD_CHARGES: 0}
+        self.cb = EXCHANGE_FN(self._call)
+
+    def _view(self, ptr: int, n: int):
+        import torch
+
+        ws = self.dde.engine._ws
+        off = ptr - ws.data_ptr()
+        if off < 0 or off + 4 * n > ws.numel():
+            raise RuntimeError("domain decomposition: the engine handed out a pointer outside its workspace")
+        return ws[off : off + 4 * n].view(torch.float32)
+
+    def _call(self, _ctx, what, ptr, n, _stream) -> int:
+        import torch
+
+        try:
+            t = self._view(int(ptr), int(n))
+            self.calls[int(what)] += 1
+            if what == DD_SUM:
+                self.dde.all_reduce_(t)
+            else:
+                nq = self.dde.engine.nq
+                planes = t.view(nq, self.dom.n_local)
+                glob = torch.zeros((nq, self.n_global), dtype=torch.float32, device=t.device)
+                glob[:, self.gid[: self.dom.n_owned]] = planes[:, : self.dom.n_owned]
+                self.dde.all_reduce_(glob)  # every entry has exactly one non-zero contribution: exact
+                planes[:, self.dom.n_owned :] = glob[:, self.gid[self.dom.n_owned :]]
+            return 0
+        except BaseException as exc:  # noqa: BLE001 - must not propagate through the C frame
+            self.error = exc
+            return 1
+
+
+class DomainDecomposedEngine:
+    """`HipEngine.eval` for one periodic system cut into slabs over the ranks of a torch.distributed group.
+
+    Every rank calls `eval` with the SAME full system (coord [N,3], numbers [N], cell [3,3]); every rank gets the same result:
+    energy (float64 scalar tensor), forces [N,3], charges [N] in the caller's atom order."""
+
+    def __init__(self, engine, group=None):
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            raise RuntimeError("DomainDecomposedEngine needs an initialised torch.distributed process group")
+        self.engine, self.group = engine, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.last_domain: SlabDomain | None = None
+        self.last_calls: dict[int, int] | None = None
+
+    def all_reduce_(self, t, op=None):
+        """In-place sum (or `op`) over the group, ordered on torch's current stream.  `nccl` (= RCCL) reduces device memory
+        directly; `gloo` (CPU tests, two ranks sharing one GPU) goes through the host."""
+        import torch.distributed as dist
+
+        op = dist.ReduceOp.SUM if op is None else op
+        if self.backend == "nccl" or not t.is_cuda:
+            dist.all_reduce(t, op=op, group=self.group)
+        else:
+            h = t.cpu()  # synchronises the current stream: everything the engine has enqueued so far is done
+            dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+        return t
+
+    def eval(self, coord, numbers, cell, charge: float = 0.0, forces: bool = True, coulomb: str = "dsf", dsf_rc: float = 15.0,
+             dsf_alpha: float = 0.2, halo: float | None = None, axis: int | None = None) -> dict[str, Any]:
+        import torch
+
+        eng = self.engine
+        if coulomb not in ("none", "dsf"):
+            raise ValueError("DomainDecomposedEngine: coulomb must be 'none' or 'dsf' (Ewald / PME reciprocal sums and the all-pairs "
+                             "'simple' form are not decomposed)")
+        xyz = np.asarray(coord.detach().cpu() if hasattr(coord, "detach") else coord, dtype=np.float64)
+        cel = np.asarray(cell.detach().cpu() if hasattr(cell, "detach") else cell, dtype=np.float64)
+        z = np.asarray(numbers.detach().cpu() if hasattr(numbers, "detach") else numbers).astype(np.int64)
+        n_global = xyz.shape[0]
+        if halo is None:
+            halo = max(3.0 * float(eng.spec.rc), float(dsf_rc) if coulomb == "dsf" else 0.0) + 1e-3
+        dom = slab_partition(xyz, cel, self.world, self.rank, float(halo), axis)
+        self.last_domain = dom
+        if dom.n_owned == 0:
+            raise ValueError(f"DomainDecomposedEngine: rank {self.rank} owns no atom (world {self.world} is too large for this system)")
+        dev = eng.device
+        gid = torch.as_tensor(dom.gid, device=dev)
+        # (the cluster is centred on its owned atoms before it is rounded to fp32: the engine's results are translation invariant,
+        # and an image position of magnitude 50 A carries twice the rounding of one at 25 A)
+        x_loc = torch.as_tensor(dom.coord - dom.coord[: dom.n_owned].mean(axis=0), dtype=torch.float32, device=dev)
+        z_loc = torch.as_tensor(z[dom.gid], dtype=torch.int32, device=dev)
+        mol = torch.zeros(dom.n_local, dtype=torch.int32, device=dev)
+        if eng.nq == 2:
+            q_in = torch.as_tensor(np.asarray(charge, dtype=np.float32).reshape(1, 2), device=dev)
+        else:
+            q_in = torch.tensor([float(charge)], dtype=torch.float32, device=dev)
+        owned = torch.as_tensor(dom.owned_mask, device=dev)
+        ex = _Exchange(self, dom, gid, n_global)
+        try:
+            while True:
+                _lib.check(eng.lib.aimnet_engine_set_dd(eng._h, owned.data_ptr(), ex.cb, None), "aimnet_engine_set_dd")
+                try:
+                    res = eng.eval(x_loc, z_loc, mol, q_in, cell=None, forces=forces, coulomb=coulomb, dsf_rc=dsf_rc, dsf_alpha=dsf_alpha,
+                                   sync=False)
+                except _lib.HipLibraryError:
+                    if ex.error is not None:
+                        raise ex.error
+                    raise
+                # the row capacities must grow on EVERY rank together (a rank that repeated its evaluation alone would leave the
+                # others waiting in a collective): status words max-reduced over the group, then the engine's own growth rule
+                import torch.distributed as dist
+
+                st = self.all_reduce_(res["status"].clone(), op=dist.ReduceOp.MAX).cpu().numpy()
+                flags = int(st[6]) & ~NONFINITE_FLAG
+                if flags:
+                    raise ValueError("DomainDecomposedEngine: invalid input: " + describe_input_flags(flags, 1))
+                retry = False
+                if st[2]:
+                    eng.max_nb = _round16(int(max(eng.max_nb * 1.5, st[0])))
+                    retry = True
+                if st[3]:
+                    eng._max_nb_lr[float(dsf_rc)] = _round16(int(max(eng._max_nb_lr[float(dsf_rc)] * 1.5, st[1])))
+                    retry = True
+                if not retry:
+                    break
+        finally:
+            _lib.check(eng.lib.aimnet_engine_set_dd(eng._h, None, EXCHANGE_FN(), None), "aimnet_engine_set_dd")
+        self.last_calls = dict(ex.calls)
+        # one all-reduce for the outputs: [energy, forces of owned AND halo copies added onto their global rows, owned charges];
+        # float64 so that the sum over a row's copies does not depend on the order the device adds them in
+        nf = 3 * n_global if forces else 0
+        buf = torch.zeros(1 + nf + n_global, dtype=torch.float64, device=dev)
+        buf[0] = res["energy"][0]
+        if forces:
+            buf[1 : 1 + nf].view(n_global, 3).index_add_(0, gid, res["forces"].double())
+        buf[1 + nf :].index_add_(0, gid[: dom.n_owned], res["charges"][: dom.n_owned].double())
+        self.all_reduce_(buf)
+        if not bool(torch.isfinite(buf).all()):
+            raise FloatingPointError("DomainDecomposedEngine: non-finite energy / forces (for an fp16-range overflow of the GEMM "
+                                     "operands set engine.set_option('gemm_h2', 0) on every rank and repeat)")
+        out = {"energy": buf[0].clone(), "charges": buf[1 + nf :].float()}
+        if forces:
+            out["forces"] = buf[1 : 1 + nf].view(n_global, 3).float()
+        return out
+
+
+def halo_fraction(cell: np.ndarray, world: int, halo: float) -> float:
+    """Local atoms per owned atom for a homogeneous system (the cost model of DESIGN.md 6: form (a) pays this factor)."""
+    w = perpendicular_widths(cell)
+    axis = int(np.argmax(w))
+    f = 1.0
+    for d in range(3):
+        own = w[d] / world if d == axis else w[d]
+        f *= (own + 2.0 * halo) / own
+    return f
+
+
+__all__ = ["DomainDecomposedEngine", "SlabDomain", "slab_partition", "owners", "perpendicular_widths", "wrapped_fractional",
+           "halo_fraction"]

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define AIMNET_ABI_VERSION 10
+#define AIMNET_ABI_VERSION 11
 
 #define AIMNET_OK 0
 #define AIMNET_E_INVALID (-1)   /* bad argument / unsupported architecture */
@@ -196,6 +196,28 @@ typedef struct aimnet_dftd3_tables {
   const float* r4r2;
 } aimnet_dftd3_tables;
 int aimnet_engine_set_dftd3(aimnet_engine* e, const aimnet_dftd3_tables* t);
+
+/* Spatial domain decomposition of ONE large system over ranks (the reference has no counterpart and points
+ * its users at one GPU per system, docs/tutorials/performance.md:275-285).  A rank evaluates the atoms it OWNS together with halo
+ * copies of every atom (periodic images resolved by the host-side partitioner) within 3 x the model cutoff (and within the Coulomb
+ * cutoff) as ONE NON-PERIODIC cluster: `owned` is a device array [n_atoms] of 1.0f (owned) / 0.0f (halo) that must stay valid
+ * while evaluations run.  With it set, aimnet_engine_eval
+ *   - sums the NSE charge normalisation (ops.nse, aimnet/ops.py:99-145) over OWNED atoms only and hands the per-molecule partial
+ *     sums to `fn` (AIMNET_DD_SUM: all-reduce n floats in place) before it applies them - once per charge channel and pass, and
+ *     once more per pass for the adjoint sums of the backward sweep;
+ *   - hands the final charges to `fn` (AIMNET_DD_CHARGES: nq planes of n_atoms floats; overwrite the halo entries with their
+ *     owners' values) in front of the Coulomb block, whose 15 A sums reach beyond the shell where the local charges are exact;
+ *   - counts energies, Coulomb adjoints, direct Coulomb forces and the backward seed of OWNED atoms only.
+ * energy[m] is then the rank's share (sum over ranks = the system's energy); forces[] holds, for owned AND halo atoms, the rank's
+ * partial -dE_rank/dx: the caller adds the halo rows onto their owners (one reverse halo exchange; aimnetcentral_amd/dd.py).
+ * `fn` is called on the host from inside aimnet_engine_eval, between launches; the work it enqueues (or performs after a
+ * synchronisation) must be ordered on `hip_stream`.  A non-zero return aborts the evaluation with AIMNET_E_INVALID.
+ * Restrictions: no cell (the cluster is non-periodic), Coulomb NONE or DSF, no DFT-D3, no stress, no caller-supplied lists.
+ * owned == NULL switches the mode off. */
+#define AIMNET_DD_SUM 0
+#define AIMNET_DD_CHARGES 1
+typedef int (*aimnet_dd_exchange_fn)(void* ctx, int32_t what, void* dev_ptr, int64_t n_float, void* hip_stream);
+int aimnet_engine_set_dd(aimnet_engine* e, const float* owned, aimnet_dd_exchange_fn fn, void* ctx);
 
 /* Bytes of scratch `aimnet_engine_eval` needs for the given problem size. */
 size_t aimnet_engine_workspace_bytes(const aimnet_engine* e, int32_t n_atoms, int32_t n_mol, int32_t n_cell,

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/aimnet_hip.h but not exported"
     assert set(declared) == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.aimnet_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.aimnet_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_struct_layouts_match_header():

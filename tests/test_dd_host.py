@@ -1,0 +1,134 @@
+"""Host logic of the spatial domain decomposition (aimnetcentral_amd/dd.py): the slab partitioner against brute-force periodic
+images, and the engine's exchange function (all-reduce of the NSE sums, owner values for halo charges) over gloo with two CPU
+ranks and a stand-in for the engine's workspace.  No GPU."""
+from __future__ import annotations
+
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from aimnetcentral_amd import dd, workloads
+
+
+def _cell_and_atoms(seed: int, n: int = 60):
+    rng = np.random.default_rng(seed)
+    cell = np.array([[9.0, 0.0, 0.0], [2.5, 11.0, 0.0], [-1.5, 3.0, 14.0]]) + rng.normal(0.0, 0.2, (3, 3))
+    frac = rng.uniform(-1.5, 2.5, (n, 3))  # atoms up to two cells outside the box
+    return frac @ cell, cell
+
+
+def _periodic_neighbour_distances(x, cell, i, h):
+    """Sorted distances < h from atom i to every periodic image of every atom (excluding itself at shift 0)."""
+    reach = int(np.ceil(h / dd.perpendicular_widths(cell).min())) + 1
+    x = dd.wrapped_fractional(x, cell) @ cell  # (the input atoms sit up to two cells outside the box)
+    out = []
+    rng_ = range(-reach, reach + 1)
+    for a in rng_:
+        for b in rng_:
+            for c in rng_:
+                d = np.linalg.norm(x + np.array([a, b, c]) @ cell - x[i], axis=1)
+                if a == 0 and b == 0 and c == 0:
+                    d = np.delete(d, i)
+                out.append(d[d < h])
+    return np.sort(np.concatenate(out))
+
+
+def test_partition_covers_every_owned_neighbourhood():
+    h = 6.0
+    for seed, world in ((0, 2), (1, 3), (2, 1)):
+        x, cell = _cell_and_atoms(seed)
+        own, axis = dd.owners(x, cell, world)
+        seen = np.zeros(len(x), dtype=int)
+        for rank in range(world):
+            dom = dd.slab_partition(x, cell, world, rank, h)
+            assert dom.axis == axis and dom.n_owned == int((own == rank).sum())
+            assert np.array_equal(np.sort(dom.gid[: dom.n_owned]), np.nonzero(own == rank)[0])
+            assert np.all(dom.shift[: dom.n_owned] == 0) and dom.owned_mask.sum() == dom.n_owned
+            seen[dom.gid[: dom.n_owned]] += 1
+            # positions are periodic images of the input atoms
+            f_in = x @ np.linalg.inv(cell)
+            f_loc = dom.coord @ np.linalg.inv(cell)
+            delta = f_loc - f_in[dom.gid]
+            assert np.abs(delta - np.round(delta)).max() < 1e-9
+            # no (atom, image) twice
+            key = np.concatenate([dom.gid[:, None], np.round(delta).astype(int)], axis=1)
+            assert len(np.unique(key, axis=0)) == dom.n_local
+            # every owned atom sees inside the cluster exactly what it sees in the periodic system
+            for k in range(0, dom.n_owned, 3):
+                d = np.linalg.norm(dom.coord - dom.coord[k], axis=1)
+                d = np.sort(np.delete(d, k))
+                ref = _periodic_neighbour_distances(x, cell, int(dom.gid[k]), h)
+                got = d[d < h]
+                assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-9
+        assert np.all(seen == 1)  # every atom is owned by exactly one rank
+
+
+def test_widths_and_halo_fraction():
+    _, _, cell = workloads.glucose_supercell((7, 3, 5))
+    w = dd.perpendicular_widths(cell)
+    assert abs(w[1] - 37.6872) < 1e-3 and int(np.argmax(w)) == 2 and w[0] < np.linalg.norm(cell[0]) + 1e-9
+    assert dd.halo_fraction(cell, 2, 15.0) > dd.halo_fraction(cell * 10.0, 2, 15.0) > 1.0
+    f = dd.wrapped_fractional(np.array([[-1e-18, 0.0, 0.0]]), np.eye(3))
+    assert (f >= 0).all() and (f < 1).all()
+
+
+class _StubEngine:
+    nq = 1
+    _ws = None
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x, cell = _cell_and_atoms(3, 40)
+        dom = dd.slab_partition(x, cell, world, rank, 5.0)
+        eng = _StubEngine()
+        eng._ws = torch.zeros(64 + 4 * dom.n_local + 64, dtype=torch.uint8)  # stand-in for the engine's workspace
+        dde = dd.DomainDecomposedEngine(eng)
+        ex = dd._Exchange(dde, dom, torch.as_tensor(dom.gid), len(x))
+        base = eng._ws.data_ptr()
+        # AIMNET_DD_SUM: two floats summed over the ranks, in place
+        sums = eng._ws[16:24].view(torch.float32)
+        sums[:] = torch.tensor([1.0 + rank, 10.0 * (rank + 1)])
+        assert ex.cb(None, dd.DD_SUM, base + 16, 2, None) == 0
+        # AIMNET_DD_CHARGES: the charge of atom g is 0.5 + g on its owner, garbage on halo copies
+        q = eng._ws[64 : 64 + 4 * dom.n_local].view(torch.float32)
+        q[: dom.n_owned] = torch.as_tensor(0.5 + dom.gid[: dom.n_owned], dtype=torch.float32)
+        q[dom.n_owned :] = -777.0
+        assert ex.cb(None, dd.DD_CHARGES, base + 64, dom.n_local, None) == 0
+        # a pointer outside the workspace is refused (returns non-zero, the engine aborts the evaluation)
+        bad = ex.cb(None, dd.DD_SUM, base - 4096, 2, None)
+        ret[rank] = (sums.clone().numpy(), q.clone().numpy(), dom.gid.copy(), bad, dict(ex.calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_function_over_gloo_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [mp.get_context("spawn").Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    for r in range(world):
+        sums, q, gid, bad, calls = ret[r]
+        assert np.array_equal(sums, np.array([3.0, 30.0], dtype=np.float32))
+        assert np.array_equal(q, (0.5 + gid).astype(np.float32))  # halo copies carry their owners' values
+        assert bad != 0 and calls[dd.DD_SUM] == 1 and calls[dd.DD_CHARGES] == 1

@@ -1062,7 +1062,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     if (in->nbmat_lr && coulomb != AIMNET_COULOMB_NONE) {
       RC(launch_import_list(s, in->nbmat_lr, pbc ? in->shifts_lr : nullptr, in->nbmat_lr_width, N, mol_c, in->cell, n_cell, cap_lr, W.nl,
                             W.lr_idx, W.lr_shift, W.lr_cnt, out->status + 1, out->status + 3, nullptr, out->status + 6));
-      RC(launch_list_symmetry_check(s, W.lr_idx, pbc ? W.lr_shift : nullptr, W.lr_cnt, cap_lr, N, out->status + 6));
+      RC(launch_list_symmetry_check(s, W.lr_idx, pbc ? W.lr_shift : nullptr, W.lr_cnt, cap_lr, N, out->status + 6, 64));
     }
     if (d3) {
       d3_shared = d3_shares_lr_list(opt, cap_lr);  // one cutoff for both: the layout stores ONE matrix
@@ -1082,7 +1082,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
         }
         RC(launch_import_list(s, src, pbc ? src_sh : nullptr, src_w, N, mol_c, in->cell, n_cell, cap_d3, W.nl, W.d3_idx, W.d3_shift,
                               W.d3_cnt, out->status + 4, out->status + 5, nullptr, out->status + 6));
-        RC(launch_list_symmetry_check(s, W.d3_idx, pbc ? W.d3_shift : nullptr, W.d3_cnt, cap_d3, N, out->status + 6));
+        RC(launch_list_symmetry_check(s, W.d3_idx, pbc ? W.d3_shift : nullptr, W.d3_cnt, cap_d3, N, out->status + 6, 64));
       }
     }
   } else {

@@ -206,7 +206,8 @@ int launch_import_list(hipStream_t s, const int* ext_idx, const int* ext_shift, 
                        int* status_max, int* status_ovf, float4* pg, int* bad);
 // bad |= 16 unless every entry (i -> j, s) has its mirror (j -> i, -s) in the row of j (caller-supplied matrices)
 int launch_list_symmetry_check(hipStream_t s, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, int n_atoms,
-                               int* bad);
+                               int* bad,
+                               int max_check = 1 << 30);  // pairs per row that are verified (long-range matrices: a sample);
 
 // ---- conv.hip ---------------------------------------------------------------------------------
 struct BasisParams {  // radial basis of AEVSV (aev.py:66-81), passed by value

@@ -995,37 +995,54 @@ int launch_import_list(hipStream_t s, const int* ext_idx, const int* ext_shift, 
 // silently halve the Coulomb / dispersion energy.  bad: bit 4.
 __global__ __launch_bounds__(256) void list_symmetry_kernel(const int* __restrict__ nb_idx, const int* __restrict__ nb_shift,
                                                            const int* __restrict__ nb_cnt, int cap, int n_atoms,
-                                                           int* __restrict__ bad) {
+                                                           int* __restrict__ bad, int max_check) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
-  const int cnt = nb_cnt[i];
+  // max_check: pairs per row that are verified.  The short-range matrix is verified in full (the reverse-pair map needs EXACTLY one
+  // mirror per pair); of a long-range / D3 row (2 000 entries at 15 A) the first max_check pairs are - the test there is against a
+  // HALF list, which fails on the first pairs of almost every row, and the full scan is quadratic in the row length
+  const int cnt = min(nb_cnt[i], max_check);
+  // The wave takes the pairs of row i one after the other and scans row j with all 64 lanes (coalesced; a lane-per-pair scan of
+  // 64 different rows took 0.39 s on a 10 080 x 2 064 long-range matrix, this form a few ms)
   bool missing = false;
-  for (int m = lane; m < cnt; m += 64) {
-    const size_t p = (size_t)i * cap + m;
-    const int j = nb_idx[p];
-    int want = 0;
-    if (nb_shift) {
-      int sx, sy, sz;
-      unpack_shift(nb_shift[p], sx, sy, sz);
-      want = pack_shift(-sx, -sy, -sz);
+  for (int m0 = 0; m0 < cnt; m0 += 64) {
+    int jl = 0, wl = 0;
+    if (m0 + lane < cnt) {
+      const size_t p = (size_t)i * cap + m0 + lane;
+      jl = nb_idx[p];
+      if (nb_shift) {
+        int sx, sy, sz;
+        unpack_shift(nb_shift[p], sx, sy, sz);
+        wl = pack_shift(-sx, -sy, -sz);
+      }
     }
-    const int cj = nb_cnt[j];
-    // EXACTLY one mirror: a duplicated (j, shift) entry would give two entries of the reverse-pair map one slot, and the force
-    // gather would subtract one pair-buffer entry twice (silently wrong forces)
-    int found = 0;
-    for (int t = 0; t < cj; ++t) {
-      const size_t r = (size_t)j * cap + t;
-      found += (nb_idx[r] == i && (!nb_shift || (nb_shift[r] & 0xffffff) == (want & 0xffffff))) ? 1 : 0;
+    const int nm = min(64, cnt - m0);
+    for (int k = 0; k < nm; ++k) {
+      const int j = __shfl(jl, k), want = __shfl(wl, k);
+      const int cj = nb_cnt[j];
+      // EXACTLY one mirror: a duplicated (j, shift) entry would give two entries of the reverse-pair map one slot, and the force
+      // gather would subtract one pair-buffer entry twice (silently wrong forces)
+      int found = 0;
+      for (int t0 = 0; t0 < cj; t0 += 64) {
+        const int t = t0 + lane;
+        bool hit = false;
+        if (t < cj) {
+          const size_t r = (size_t)j * cap + t;
+          hit = nb_idx[r] == i && (!nb_shift || (nb_shift[r] & 0xffffff) == (want & 0xffffff));
+        }
+        found += __popcll(__ballot(hit));
+      }
+      missing = missing || found != 1;
     }
-    missing = missing || found != 1;
   }
   if (__ballot(missing) && lane == 0) atomicOr(bad, 16);
 }
 
 int launch_list_symmetry_check(hipStream_t s, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, int n_atoms,
-                               int* bad) {
-  hipLaunchKernelGGL(list_symmetry_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, nb_idx, nb_shift, nb_cnt, cap, n_atoms, bad);
+                               int* bad, int max_check) {
+  hipLaunchKernelGGL(list_symmetry_kernel, dim3(ceil_div(n_atoms, 4)), dim3(256), 0, s, nb_idx, nb_shift, nb_cnt, cap, n_atoms, bad,
+                     max_check);
   AIMNET_LAUNCH_CHECK();
   return 0;
 }

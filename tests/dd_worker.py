@@ -59,6 +59,19 @@ def main():
     rec = {"case": case, "world": world, "ranks_agree": bool((lo == hi).all()), "axis": dom.axis, "n_owned": dom.n_owned,
            "n_local": dom.n_local, "exchange_calls": {str(k): v for k, v in dde.last_calls.items()},
            "repeat_bitwise": bool(torch.equal(res["forces"], again["forces"]) and torch.equal(res["energy"], again["energy"]))}
+    # wall time of one decomposed evaluation (all ranks SHARE this GPU and the exchanges go through the host over gloo: an upper
+    # bound that says nothing about a multi-GPU run; recorded so that nobody has to guess)
+    import time
+
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        dde.eval(inp["coord"], inp["numbers"], inp["cell"], charge=inp["charge"], forces=True, coulomb=coulomb, dsf_rc=inp["dsf_rc"],
+                 dsf_alpha=inp["dsf_alpha"])
+    torch.cuda.synchronize()
+    dist.barrier()
+    rec["ms_per_decomposed_eval_shared_gpu_gloo"] = (time.perf_counter() - t0) / 3 * 1e3
     owned = torch.tensor([dom.n_owned], dtype=torch.int64)
     dist.all_reduce(owned)
     rec["owned_total"] = int(owned[0])
@@ -75,6 +88,15 @@ def main():
         one = eng.eval(torch.as_tensor(xw, device=dev), torch.as_tensor(inp["numbers"], device=dev).int(),
                        torch.zeros(n, dtype=torch.int32, device=dev), q_in, cell=torch.as_tensor(inp["cell"], device=dev), forces=True,
                        coulomb=coulomb, dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"])
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng.eval(torch.as_tensor(xw, device=dev), torch.as_tensor(inp["numbers"], device=dev).int(),
+                     torch.zeros(n, dtype=torch.int32, device=dev), q_in, cell=torch.as_tensor(inp["cell"], device=dev), forces=True,
+                     coulomb=coulomb, dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"])
+        torch.cuda.synchronize()
+        rec["ms_per_single_rank_eval"] = (time.perf_counter() - t0) / 3 * 1e3
 
         def cmp(ref_e, ref_f, ref_q, tag):
             f, fr = res["forces"].double().cpu().numpy(), np.asarray(ref_f, np.float64)

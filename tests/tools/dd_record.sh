@@ -1,0 +1,13 @@
+#!/bin/bash
+# Domain decomposition record (GPU box): every case of tests/dd_worker.py, 2 and 3 ranks sharing cuda:0 over gloo -> gpurun_out/dd/*.json
+set -u
+cd "$(dirname "$0")/../.."
+mkdir -p gpurun_out/dd
+port=29560
+for spec in "golden2304 2" "golden2304 3" "cube1536 2" "cube1536 3" "cube1536_nocoul 2" "cube1536_nse 2"; do
+  set -- $spec
+  port=$((port + 1))
+  DD_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$2" --master-addr 127.0.0.1 --master-port $port \
+    tests/dd_worker.py "$1" "gpurun_out/dd/$1_w$2.json" > "gpurun_out/dd/$1_w$2.log" 2>&1 || echo "FAILED $spec"
+done
+cat gpurun_out/dd/*.json

@@ -119,6 +119,7 @@ struct aimnet_engine {
   // aimnet_engine_set_dd: spatial domain decomposition of one system over ranks - owned-atom mask of the local cluster and the
   // caller's exchange function (dd.owned == NULL: off)
   aimnet::DdLink dd{nullptr, nullptr, nullptr};
+  float* unit_cell = nullptr;  // 3 x 3 identity (device): "cell" of the virial sums of a decomposed evaluation
   double* sae;
   // species slots of the pass-0 moment backward: slot = rank of the atomic number among the embedding rows that
   // are finite (supported elements); every other Z shares one extra slot that points at its NaN row

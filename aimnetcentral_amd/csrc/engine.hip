@@ -682,6 +682,10 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     e->head.push_back(L);
     if ((rc = dev_upload(e, w->head_w[l], (size_t)L.n_in, &e->head_w_last))) goto fail;
     if ((rc = dev_upload(e, w->head_b[l], (size_t)1, &e->head_b_last))) goto fail;
+    {
+      static const float unit[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+      if ((rc = dev_upload(e, unit, (size_t)9, &e->unit_cell))) goto fail;
+    }
   }
   if (e->h2_fits) {  // one-launch MLP sweeps (gemm_chain.hip) where the layer sizes match an instantiated shape
     for (int p = 0; p < arch->n_pass; ++p) {
@@ -920,7 +924,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const bool want_f = (opt->flags & AIMNET_FORCES) != 0, want_s = (opt->flags & AIMNET_STRESS) != 0;
   const bool grad = want_f || want_s;
   const bool pbc = in->cell != nullptr;
-  if (want_s && (!pbc || !out->stress)) {
+  if (want_s && ((!pbc && !e->dd.owned) || !out->stress)) {  // (domain decomposition: the rank's virial, see aimnet_engine_set_dd)
     set_last_error("eval: stress requires a cell and a stress buffer");
     return AIMNET_E_INVALID;
   }
@@ -998,9 +1002,9 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   }
   // spatial domain decomposition (aimnet_engine_set_dd): the local cluster of owned + halo atoms is a non-periodic system
   const aimnet::DdLink* dd = e->dd.owned ? &e->dd : nullptr;
-  if (dd && (pbc || ext || want_s || opt->dftd3 != 0 || !(coulomb == AIMNET_COULOMB_NONE || coulomb == AIMNET_COULOMB_DSF))) {
+  if (dd && (pbc || ext || opt->dftd3 != 0 || !(coulomb == AIMNET_COULOMB_NONE || coulomb == AIMNET_COULOMB_DSF))) {
     set_last_error("eval: a domain-decomposed evaluation takes a non-periodic cluster (no cell, no caller-supplied lists), Coulomb "
-                   "'none' or 'dsf', no DFT-D3 and no stress request");
+                   "'none' or 'dsf' and no DFT-D3");
     return AIMNET_E_INVALID;
   }
   hipStream_t s = (hipStream_t)hip_stream;
@@ -1332,7 +1336,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     const int nlp = (int)e->mlp[np - 1].size();
     const int seed_bytes = hfused ? pm * e->mlp[np - 1][nlp - 1].k_out * 2 : e->head[e->head.size() - 2].k_out * 4;
     RC(launch_dd_mask(s, dd->owned, in->numbers, e->sae, W.e_atom, W.ecoul, grad ? W.qbar : nullptr, nq, grad ? W.fgrad : nullptr,
-                      nullptr, grad ? W.zb0 : nullptr, seed_bytes, N));
+                      want_s ? W.virial_atom : nullptr, grad ? W.zb0 : nullptr, seed_bytes, N));
   }
   // results of the Coulomb block (ecoul, qbar / fgrad / virial seeds, qtot) are first needed here (energy only) or in front of
   // the first conv backward (see `join` below)
@@ -1471,7 +1475,9 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const EnergyRider erd{W.e_atom, W.ecoul, in->numbers, e->sae, W.part_e, out->energy, n_mol,
                         q_fin, copy_deferred ? out->charges : nullptr, N};
   if (W.xe && want_f && !pf_rides) RC(launch_pair_force(s, W.nb_idx, W.nb_cnt, W.rev, W.pairbuf, cap, N, W.fgrad, out->forces, out->status + 6));
-  RC(launch_finalize(s, W.fgrad, W.virial_atom, W.nl.mol_start, in->cell, n_cell, n_mol, N, W.S, W.part,
+  // (domain decomposition: no cell - the virial sums are divided by the volume of a unit cube, i.e. the `stress` output takes the
+  // rank's share of dE/d(strain) itself; the caller adds the ranks' shares and divides by the cell volume)
+  RC(launch_finalize(s, W.fgrad, W.virial_atom, W.nl.mol_start, dd ? e->unit_cell : in->cell, dd ? 1 : n_cell, n_mol, N, W.S, W.part,
                      (want_f && !W.xe) ? out->forces : nullptr, want_s ? out->stress : nullptr, pf_rides ? &pfr : nullptr,
                      energy_deferred ? &erd : nullptr, e->sums_whole != 0, out->status + 6));
   RC(prof_mark(e, s, -1));

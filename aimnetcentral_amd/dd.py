@@ -188,8 +188,8 @@ class DomainDecomposedEngine:
             t.copy_(h)
         return t
 
-    def eval(self, coord, numbers, cell, charge: float = 0.0, forces: bool = True, coulomb: str = "dsf", dsf_rc: float = 15.0,
-             dsf_alpha: float = 0.2, halo: float | None = None, axis: int | None = None) -> dict[str, Any]:
+    def eval(self, coord, numbers, cell, charge: float = 0.0, forces: bool = True, stress: bool = False, coulomb: str = "dsf",
+             dsf_rc: float = 15.0, dsf_alpha: float = 0.2, halo: float | None = None, axis: int | None = None) -> dict[str, Any]:
         import torch
 
         eng = self.engine
@@ -223,8 +223,9 @@ class DomainDecomposedEngine:
             while True:
                 _lib.check(eng.lib.aimnet_engine_set_dd(eng._h, owned.data_ptr(), ex.cb, None), "aimnet_engine_set_dd")
                 try:
-                    res = eng.eval(x_loc, z_loc, mol, q_in, cell=None, forces=forces, coulomb=coulomb, dsf_rc=dsf_rc, dsf_alpha=dsf_alpha,
-                                   sync=False)
+                    # (stress: the engine returns the rank's share of dE/d(strain), undivided - the cluster has no cell)
+                    res = eng.eval(x_loc, z_loc, mol, q_in, cell=None, forces=forces, stress=stress, coulomb=coulomb, dsf_rc=dsf_rc,
+                                   dsf_alpha=dsf_alpha, sync=False)
                 except _lib.HipLibraryError:
                     if ex.error is not None:
                         raise ex.error
@@ -252,16 +253,20 @@ class DomainDecomposedEngine:
         # one all-reduce for the outputs: [energy, forces of owned AND halo copies added onto their global rows, owned charges];
         # float64 so that the sum over a row's copies does not depend on the order the device adds them in
         nf = 3 * n_global if forces else 0
-        buf = torch.zeros(1 + nf + n_global, dtype=torch.float64, device=dev)
+        buf = torch.zeros(1 + nf + n_global + (9 if stress else 0), dtype=torch.float64, device=dev)
         buf[0] = res["energy"][0]
         if forces:
             buf[1 : 1 + nf].view(n_global, 3).index_add_(0, gid, res["forces"].double())
-        buf[1 + nf :].index_add_(0, gid[: dom.n_owned], res["charges"][: dom.n_owned].double())
+        buf[1 + nf : 1 + nf + n_global].index_add_(0, gid[: dom.n_owned], res["charges"][: dom.n_owned].double())
+        if stress:
+            buf[1 + nf + n_global :] = res["stress"].reshape(9).double()
         self.all_reduce_(buf)
         if not bool(torch.isfinite(buf).all()):
             raise FloatingPointError("DomainDecomposedEngine: non-finite energy / forces (for an fp16-range overflow of the GEMM "
                                      "operands set engine.set_option('gemm_h2', 0) on every rank and repeat)")
-        out = {"energy": buf[0].clone(), "charges": buf[1 + nf :].float()}
+        out = {"energy": buf[0].clone(), "charges": buf[1 + nf : 1 + nf + n_global].float()}
+        if stress:  # sum of the ranks' virial shares over the cell volume (model.hip, stress_partial_kernel: sum / |det cell|)
+            out["stress"] = (buf[1 + nf + n_global :] / abs(float(np.linalg.det(cel)))).view(3, 3).float()
         if forces:
             out["forces"] = buf[1 : 1 + nf].view(n_global, 3).float()
         return out

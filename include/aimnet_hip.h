@@ -212,7 +212,9 @@ int aimnet_engine_set_dftd3(aimnet_engine* e, const aimnet_dftd3_tables* t);
  * partial -dE_rank/dx: the caller adds the halo rows onto their owners (one reverse halo exchange; aimnetcentral_amd/dd.py).
  * `fn` is called on the host from inside aimnet_engine_eval, between launches; the work it enqueues (or performs after a
  * synchronisation) must be ordered on `hip_stream`.  A non-zero return aborts the evaluation with AIMNET_E_INVALID.
- * Restrictions: no cell (the cluster is non-periodic), Coulomb NONE or DSF, no DFT-D3, no stress, no caller-supplied lists.
+ * With AIMNET_STRESS the `stress` output [1][3][3] takes the rank's share of dE/d(strain) UNDIVIDED (there is no cell here): the sum
+ * over the ranks divided by the cell volume is the stress.
+ * Restrictions: no cell (the cluster is non-periodic), Coulomb NONE or DSF, no DFT-D3, no caller-supplied lists.
  * owned == NULL switches the mode off. */
 #define AIMNET_DD_SUM 0
 #define AIMNET_DD_CHARGES 1

@@ -25,7 +25,7 @@ def case_inputs(case: str):
         g = np.load(os.path.join(ROOT, "tests", "golden", "coldw_big.npz"))
         return dict(coord=g["pbc2304_coord"], numbers=g["pbc2304_numbers"], cell=g["pbc2304_cell"], charge=float(g["pbc2304_charge"]),
                     dsf_rc=float(g["pbc2304_dsf_rc"]), dsf_alpha=float(g["pbc2304_dsf_alpha"]), cold=True, nq=1,
-                    ref=dict(energy=g["pbc2304_energy"], forces=g["pbc2304_forces"], charges=g["pbc2304_charges"]))
+                    ref=dict(energy=g["pbc2304_energy"], forces=g["pbc2304_forces"], charges=g["pbc2304_charges"], stress=g["pbc2304_stress"]))
     if case in ("cube1536", "cube1536_nse", "cube1536_nocoul"):  # a near-cubic (4,2,2) supercell: 20 x 25 x 24 A, jittered, sheared outside the cell
         c, z, cell = workloads.glucose_supercell((4, 2, 2))
         rng = np.random.default_rng(5)
@@ -46,10 +46,10 @@ def main():
     spec = loader.synthetic_spec(0, cold=inp["cold"]) if inp["nq"] == 1 else loader.synthetic_spec(0, num_charge_channels=2)
     eng = HipEngine(spec, "cuda:0")
     dde = DomainDecomposedEngine(eng)
-    res = dde.eval(inp["coord"], inp["numbers"], inp["cell"], charge=inp["charge"], forces=True, coulomb=coulomb, dsf_rc=inp["dsf_rc"],
-                   dsf_alpha=inp["dsf_alpha"])
-    again = dde.eval(inp["coord"], inp["numbers"], inp["cell"], charge=inp["charge"], forces=True, coulomb=coulomb, dsf_rc=inp["dsf_rc"],
-                     dsf_alpha=inp["dsf_alpha"])
+    res = dde.eval(inp["coord"], inp["numbers"], inp["cell"], charge=inp["charge"], forces=True, stress=True, coulomb=coulomb,
+                   dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"])
+    again = dde.eval(inp["coord"], inp["numbers"], inp["cell"], charge=inp["charge"], forces=True, stress=True, coulomb=coulomb,
+                     dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"])
     dom = dde.last_domain
     # every rank holds the same result
     chk = torch.stack([res["energy"].double().cpu(), res["forces"].double().abs().sum().cpu()])
@@ -58,7 +58,8 @@ def main():
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     rec = {"case": case, "world": world, "ranks_agree": bool((lo == hi).all()), "axis": dom.axis, "n_owned": dom.n_owned,
            "n_local": dom.n_local, "exchange_calls": {str(k): v for k, v in dde.last_calls.items()},
-           "repeat_bitwise": bool(torch.equal(res["forces"], again["forces"]) and torch.equal(res["energy"], again["energy"]))}
+           "repeat_bitwise": bool(torch.equal(res["forces"], again["forces"]) and torch.equal(res["energy"], again["energy"]) and
+                                  torch.equal(res["stress"], again["stress"]))}
     # wall time of one decomposed evaluation (all ranks SHARE this GPU and the exchanges go through the host over gloo: an upper
     # bound that says nothing about a multi-GPU run; recorded so that nobody has to guess)
     import time
@@ -87,7 +88,7 @@ def main():
         xw = (wrapped_fractional(inp["coord"], inp["cell"]) @ np.asarray(inp["cell"], np.float64)).astype(np.float32)
         one = eng.eval(torch.as_tensor(xw, device=dev), torch.as_tensor(inp["numbers"], device=dev).int(),
                        torch.zeros(n, dtype=torch.int32, device=dev), q_in, cell=torch.as_tensor(inp["cell"], device=dev), forces=True,
-                       coulomb=coulomb, dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"])
+                       stress=True, coulomb=coulomb, dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"])
 
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -98,18 +99,20 @@ def main():
         torch.cuda.synchronize()
         rec["ms_per_single_rank_eval"] = (time.perf_counter() - t0) / 3 * 1e3
 
-        def cmp(ref_e, ref_f, ref_q, tag):
+        def cmp(ref_e, ref_f, ref_q, tag, ref_s=None):
             f, fr = res["forces"].double().cpu().numpy(), np.asarray(ref_f, np.float64)
             ratio = np.abs(f - fr) / (1e-5 + 1e-4 * np.abs(fr))  # the reference's literal gate, allclose(rtol 1e-4, atol 1e-5)
             rec[tag] = {"dE": float(abs(float(res["energy"]) - float(np.asarray(ref_e).reshape(-1)[0]))),
                         "dF_max": float(np.abs(f - fr).max()), "F_max": float(np.abs(fr).max()), "dF_violations": int((ratio > 1).sum()),
                         "dF_worst_ratio": float(ratio.max()),
                         "dq_max": float(np.abs(res["charges"].cpu().numpy() - np.asarray(ref_q, np.float64).reshape(-1)[:n]).max())}
+            if ref_s is not None:
+                rec[tag]["ds_max"] = float(np.abs(res["stress"].double().cpu().numpy() - np.asarray(ref_s, np.float64).reshape(3, 3)).max())
 
         q_one = one["charges"].cpu().numpy()
-        cmp(one["energy"].cpu().numpy(), one["forces"].cpu().numpy(), q_one, "vs_single_rank")
+        cmp(one["energy"].cpu().numpy(), one["forces"].cpu().numpy(), q_one, "vs_single_rank", one["stress"].cpu().numpy())
         if "ref" in inp:
-            cmp(inp["ref"]["energy"], inp["ref"]["forces"], inp["ref"]["charges"], "vs_reference_golden")
+            cmp(inp["ref"]["energy"], inp["ref"]["forces"], inp["ref"]["charges"], "vs_reference_golden", inp["ref"]["stress"])
             f1, fr = one["forces"].double().cpu().numpy(), np.asarray(inp["ref"]["forces"], np.float64)
             rec["single_rank_vs_reference_golden"] = {"dE": float(abs(float(one["energy"][0]) - float(inp["ref"]["energy"][0]))),
                                                       "dF_max": float(np.abs(f1 - fr).max())}

@@ -37,10 +37,12 @@ def _gates(rec: dict, key: str, n: int, dq: float = 1e-4, strict: bool = True):
     else:
         assert c["dF_violations"] <= 3e-3 * n and c["dF_worst_ratio"] <= 2.0, (key, c)
     assert c["dq_max"] <= dq, (key, c)
+    assert c["ds_max"] <= 1e-5, (key, c)  # stress: the ranks' virial shares summed, over the cell volume
 
 
 def test_two_slabs_reproduce_the_reference_golden_2304(tmp_path):
-    """The 2 304-atom jittered crystal of tests/golden/coldw_big.npz (outputs of the unmodified reference): two ranks, E + F + q."""
+    """The 2 304-atom jittered crystal of tests/golden/coldw_big.npz (outputs of the unmodified reference): two ranks, E + F + q +
+    stress."""
     rec = _run("golden2304", 2, 29541, tmp_path)
     assert rec["ranks_agree"] and rec["repeat_bitwise"] and rec["owned_total"] == rec["n_atoms"] == 2304
     assert rec["n_local"] > rec["n_owned"] > 0
@@ -69,4 +71,4 @@ def test_two_charge_channels_charged_cell(tmp_path):
     assert rec["exchange_calls"] == {"0": 6, "1": 1}
     c = rec["vs_single_rank"]
     # hot synthetic weights: two fp32 evaluations of the same surface in different summation orders (noise floor)
-    assert c["dE"] <= 5e-3 and c["dF_max"] <= 2e-4 * max(1.0, c["F_max"]) and c["dq_max"] <= 1e-4, c
+    assert c["dE"] <= 5e-3 and c["dF_max"] <= 2e-4 * max(1.0, c["F_max"]) and c["dq_max"] <= 1e-4 and c["ds_max"] <= 1e-4, c

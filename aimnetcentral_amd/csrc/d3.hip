@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void d3_cnforce_kernel(const float4* __restric
 int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const int* mol_idx, const float* cell, int n_cell,
                  const int* aslot, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, D3Tables T, D3Params P,
                  float cutoff, int n_atoms, float4* xs4, float* d3w, float* dEdcn, double* ecoul, float* fgrad,
-                 float* virial_atom, bool with_dsf, CoulombParams cp, const float* q, float* qbar, bool cn_done) {
+                 float* virial_atom, bool with_dsf, CoulombParams cp, const float* q, float* qbar, bool cn_done, const DdLink* dd) {
   hipLaunchKernelGGL(d3_pack_kernel, dim3(ceil_div(n_atoms, 256)), dim3(256), 0, s, xw, aslot, n_atoms, xs4);
   AIMNET_LAUNCH_CHECK();
   dim3 grid(ceil_div(n_atoms, 4)), block(256);
@@ -416,6 +416,13 @@ int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const i
     hipLaunchKernelGGL(d3_cn_kernel, grid, block, 0, s, xs4, mol_idx, cell, n_cell, nb_idx, nb_shift, nb_cnt, cap, T, cutoff, n_atoms,
                        d3w);
     AIMNET_LAUNCH_CHECK();
+  }
+  // domain decomposition: the coordination number (and with it the reference weights) of a halo copy is exact only if its own
+  // 15 A neighbourhood is inside the cluster - the owners' rows come in through the exchange function, and so does dE/dcn below
+  // (for an owned centre both are complete: the pair pass forms both directions of a pair at the centre)
+  if (dd && dd->fn(dd->ctx, 2 /* AIMNET_DD_ROWS */, d3w, (int64_t)D3W * n_atoms, (void*)s) != 0) {
+    set_last_error("eval: the domain-decomposition exchange function failed (DFT-D3 weights)");
+    return -1;
   }
   const size_t lds = (size_t)4 * T.ns * 25 * sizeof(float);
 #define AIMNET_D3_PAIR(G_, S_, C_)                                                                                             \
@@ -432,6 +439,10 @@ int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const i
   }
 #undef AIMNET_D3_PAIR
   AIMNET_LAUNCH_CHECK();
+  if (grad && dd && dd->fn(dd->ctx, 2 /* AIMNET_DD_ROWS */, dEdcn, (int64_t)n_atoms, (void*)s) != 0) {
+    set_last_error("eval: the domain-decomposition exchange function failed (DFT-D3 dE/dcn)");
+    return -1;
+  }
   if (grad) {
     if (stress)
       hipLaunchKernelGGL(d3_cnforce_kernel<true>, grid, block, 0, s, xs4, mol_idx, cell, n_cell, nb_idx, nb_shift, nb_cnt, cap, T,

@@ -1002,9 +1002,9 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   }
   // spatial domain decomposition (aimnet_engine_set_dd): the local cluster of owned + halo atoms is a non-periodic system
   const aimnet::DdLink* dd = e->dd.owned ? &e->dd : nullptr;
-  if (dd && (pbc || ext || opt->dftd3 != 0 || !(coulomb == AIMNET_COULOMB_NONE || coulomb == AIMNET_COULOMB_DSF))) {
+  if (dd && (pbc || ext || !(coulomb == AIMNET_COULOMB_NONE || coulomb == AIMNET_COULOMB_DSF))) {
     set_last_error("eval: a domain-decomposed evaluation takes a non-periodic cluster (no cell, no caller-supplied lists), Coulomb "
-                   "'none' or 'dsf' and no DFT-D3");
+                   "'none' or 'dsf'");
     return AIMNET_E_INVALID;
   }
   hipStream_t s = (hipStream_t)hip_stream;
@@ -1230,7 +1230,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       dp.r_off = opt->d3_cutoff * 1.8897261258369282f;
       RC(launch_dftd3(cs, grad, want_s, W.nl.xw, mol_c, in->cell, n_cell, W.aslot, W.d3_idx, W.d3_shift, W.d3_cnt, cap_d3,
                       e->d3, dp, opt->d3_cutoff, N, W.d3xs, W.d3w, W.dEdcn, W.ecoul, W.fgrad, W.virial_atom, dsf_in_d3, cp, q_fin,
-                      W.qbar, d3_cn_done));
+                      W.qbar, d3_cn_done, dd));
     }
     if (grad && nq == 2) RC(launch_copy_f32(cs, W.qbar, W.qbar + N, (size_t)N));  // dE/dq_alpha = dE/dq_beta = dE/dq at this point
     return 0;

@@ -9,6 +9,8 @@
 
 namespace aimnet {
 
+struct DdLink;  // domain decomposition of one system over ranks (below)
+
 // ---- gemm.hip ---------------------------------------------------------------------------------
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL = 3 };
 // C[M,N] = A[M,K] . Bt[N,K]^T with fused epilogue.  K % 32 == 0, lda/ldb % 4 == 0.
@@ -388,7 +390,8 @@ int launch_dftd3(hipStream_t s, bool grad, bool stress, const float* xw, const i
                  const int* aslot, const int* nb_idx, const int* nb_shift, const int* nb_cnt, int cap, D3Tables T, D3Params P,
                  float cutoff, int n_atoms, float4* xs4, float* d3w, float* dEdcn, double* ecoul, float* fgrad,
                  float* virial_atom, bool with_dsf, CoulombParams cp, const float* q, float* qbar,
-                 bool cn_done = false);  // cn_done: d3w was filled by the list build (D3CnRider): no d3_cn_kernel launch
+                 bool cn_done = false,
+                 const DdLink* dd = nullptr);  // domain decomposition: halo rows of d3w / dE/dcn come from their owners (dd->fn, what = 2)  // cn_done: d3w was filled by the list build (D3CnRider): no d3_cn_kernel launch
 // with_dsf: the DSF Coulomb pair sum (cutoff == cp.dsf_rc) is evaluated in the same pair pass; adds to ecoul / qbar too
 // Independent work that rides on the SR-Coulomb launch (role-dispatched blocks behind the pair blocks; a kernel boundary costs
 // 4-5 us on the device): launch_head_last's arguments (n_head_blocks = ceil(n_atoms / 4), 0 = none) and the charge stream of the

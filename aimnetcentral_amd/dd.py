@@ -15,7 +15,9 @@ Coulomb term aimnet/modules/lr.py:559-615 over 15 A):
 * the backward sweep differentiates E_rank = sum of the owned atoms' energies with respect to EVERY local position (the adjoint
   sums of the NSE steps are all-reduced, mirror image of the forward); the direct Coulomb force and dE/dq are formed at the owned
   centre for both directions of a pair, so no charge adjoint crosses ranks; at the end the partial forces of halo copies are
-  added onto their owners (one reverse halo exchange) and the rank energies are summed.
+  added onto their owners (one reverse halo exchange) and the rank energies (and, for the stress, virial shares) are summed;
+* external DFT-D3: the reference weights and dE/dcn of halo copies come from their owners (a coordination number needs the
+  atom's own 15 A neighbourhood) - two more exchanges of the same owner-to-halo kind.
 
 The exchanges here are the simple form - global-size arrays all-reduced over the group (40 KB of charges, 120 KB of forces at
 10^4 atoms): correct for any number of ranks on `nccl` (= RCCL) and `gloo`; the scalable form (neighbour-to-neighbour halo
@@ -33,7 +35,7 @@ import numpy as np
 from . import _lib
 from .engine import NONFINITE_FLAG, _round16, describe_input_flags
 
-DD_SUM, DD_CHARGES = 0, 1  # AIMNET_DD_* of include/aimnet_hip.h
+DD_SUM, DD_CHARGES, DD_ROWS = 0, 1, 2  # AIMNET_DD_* of include/aimnet_hip.h
 EXCHANGE_FN = _lib.DD_EXCHANGE_FN
 
 
@@ -124,7 +126,7 @@ class _Exchange:
     def __init__(self, dde: "DomainDecomposedEngine", dom: SlabDomain, gid_t, n_global: int):
         self.dde, self.dom, self.gid, self.n_global = dde, dom, gid_t, n_global
         self.error: BaseException | None = None
-        self.calls = {DD_SUM: 0, DD_CHARGES: 0}
+        self.calls = {DD_SUM: 0, DD_CHARGES: 0, DD_ROWS: 0}
         self.cb = EXCHANGE_FN(self._call)
 
     def _view(self, ptr: int, n: int):
@@ -144,6 +146,12 @@ class _Exchange:
             self.calls[int(what)] += 1
             if what == DD_SUM:
                 self.dde.all_reduce_(t)
+            elif what == DD_ROWS:  # per-atom records (DFT-D3 weights, dE/dcn): halo rows take their owners' rows
+                rows = t.view(self.dom.n_local, -1)
+                glob = torch.zeros((self.n_global, rows.shape[1]), dtype=torch.float32, device=t.device)
+                glob[self.gid[: self.dom.n_owned]] = rows[: self.dom.n_owned]
+                self.dde.all_reduce_(glob)  # exactly one non-zero contribution per row: exact
+                rows[self.dom.n_owned :] = glob[self.gid[self.dom.n_owned :]]
             else:
                 nq = self.dde.engine.nq
                 planes = t.view(nq, self.dom.n_local)
@@ -189,7 +197,8 @@ class DomainDecomposedEngine:
         return t
 
     def eval(self, coord, numbers, cell, charge: float = 0.0, forces: bool = True, stress: bool = False, coulomb: str = "dsf",
-             dsf_rc: float = 15.0, dsf_alpha: float = 0.2, halo: float | None = None, axis: int | None = None) -> dict[str, Any]:
+             dsf_rc: float = 15.0, dsf_alpha: float = 0.2, dftd3: dict[str, float] | None = None, halo: float | None = None,
+             axis: int | None = None) -> dict[str, Any]:
         import torch
 
         eng = self.engine
@@ -201,7 +210,8 @@ class DomainDecomposedEngine:
         z = np.asarray(numbers.detach().cpu() if hasattr(numbers, "detach") else numbers).astype(np.int64)
         n_global = xyz.shape[0]
         if halo is None:
-            halo = max(3.0 * float(eng.spec.rc), float(dsf_rc) if coulomb == "dsf" else 0.0) + 1e-3
+            halo = max(3.0 * float(eng.spec.rc), float(dsf_rc) if coulomb == "dsf" else 0.0,
+                       float(dftd3.get("cutoff", 15.0)) if dftd3 is not None else 0.0) + 1e-3
         dom = slab_partition(xyz, cel, self.world, self.rank, float(halo), axis)
         self.last_domain = dom
         if dom.n_owned == 0:
@@ -225,7 +235,7 @@ class DomainDecomposedEngine:
                 try:
                     # (stress: the engine returns the rank's share of dE/d(strain), undivided - the cluster has no cell)
                     res = eng.eval(x_loc, z_loc, mol, q_in, cell=None, forces=forces, stress=stress, coulomb=coulomb, dsf_rc=dsf_rc,
-                                   dsf_alpha=dsf_alpha, sync=False)
+                                   dsf_alpha=dsf_alpha, dftd3=dftd3, sync=False)
                 except _lib.HipLibraryError:
                     if ex.error is not None:
                         raise ex.error
@@ -244,6 +254,10 @@ class DomainDecomposedEngine:
                     retry = True
                 if st[3]:
                     eng._max_nb_lr[float(dsf_rc)] = _round16(int(max(eng._max_nb_lr[float(dsf_rc)] * 1.5, st[1])))
+                    retry = True
+                if st[5]:  # DFT-D3 matrix (it may live in the long-range buffers: grow both, as HipEngine.eval does)
+                    d3_rc = float(dftd3.get("cutoff", 15.0))
+                    eng._max_nb_lr[d3_rc] = _round16(int(max(eng._lr_capacity(d3_rc) * 1.5, st[4], st[1])))
                     retry = True
                 if not retry:
                     break

@@ -207,17 +207,21 @@ int aimnet_engine_set_dftd3(aimnet_engine* e, const aimnet_dftd3_tables* t);
  *     once more per pass for the adjoint sums of the backward sweep;
  *   - hands the final charges to `fn` (AIMNET_DD_CHARGES: nq planes of n_atoms floats; overwrite the halo entries with their
  *     owners' values) in front of the Coulomb block, whose 15 A sums reach beyond the shell where the local charges are exact;
- *   - counts energies, Coulomb adjoints, direct Coulomb forces and the backward seed of OWNED atoms only.
+ *   - with DFT-D3 hands the per-atom reference weights (12 floats per atom, coordination number included) and, with gradients,
+ *     dE/dcn (1 float per atom) to `fn` (AIMNET_DD_ROWS: [n_atoms][n_float / n_atoms] records; overwrite the halo rows with their
+ *     owners'): a halo copy's coordination number needs ITS 15 A neighbourhood, which the cluster does not hold;
+ *   - counts energies, Coulomb adjoints, direct Coulomb / dispersion forces and the backward seed of OWNED atoms only.
  * energy[m] is then the rank's share (sum over ranks = the system's energy); forces[] holds, for owned AND halo atoms, the rank's
  * partial -dE_rank/dx: the caller adds the halo rows onto their owners (one reverse halo exchange; aimnetcentral_amd/dd.py).
  * `fn` is called on the host from inside aimnet_engine_eval, between launches; the work it enqueues (or performs after a
  * synchronisation) must be ordered on `hip_stream`.  A non-zero return aborts the evaluation with AIMNET_E_INVALID.
  * With AIMNET_STRESS the `stress` output [1][3][3] takes the rank's share of dE/d(strain) UNDIVIDED (there is no cell here): the sum
  * over the ranks divided by the cell volume is the stress.
- * Restrictions: no cell (the cluster is non-periodic), Coulomb NONE or DSF, no DFT-D3, no caller-supplied lists.
+ * Restrictions: no cell (the cluster is non-periodic), Coulomb NONE or DSF, no caller-supplied lists.
  * owned == NULL switches the mode off. */
 #define AIMNET_DD_SUM 0
 #define AIMNET_DD_CHARGES 1
+#define AIMNET_DD_ROWS 2
 typedef int (*aimnet_dd_exchange_fn)(void* ctx, int32_t what, void* dev_ptr, int64_t n_float, void* hip_stream);
 int aimnet_engine_set_dd(aimnet_engine* e, const float* owned, aimnet_dd_exchange_fn fn, void* ctx);
 

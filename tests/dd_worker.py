@@ -26,12 +26,18 @@ def case_inputs(case: str):
         return dict(coord=g["pbc2304_coord"], numbers=g["pbc2304_numbers"], cell=g["pbc2304_cell"], charge=float(g["pbc2304_charge"]),
                     dsf_rc=float(g["pbc2304_dsf_rc"]), dsf_alpha=float(g["pbc2304_dsf_alpha"]), cold=True, nq=1,
                     ref=dict(energy=g["pbc2304_energy"], forces=g["pbc2304_forces"], charges=g["pbc2304_charges"], stress=g["pbc2304_stress"]))
-    if case in ("cube1536", "cube1536_nse", "cube1536_nocoul"):  # a near-cubic (4,2,2) supercell: 20 x 25 x 24 A, jittered, sheared outside the cell
+    if case in ("cube1536", "cube1536_nse", "cube1536_nocoul", "cube1536_d3", "cube1536_d3rc12"):  # a near-cubic (4,2,2) supercell: 20 x 25 x 24 A, jittered, sheared outside the cell
         c, z, cell = workloads.glucose_supercell((4, 2, 2))
         rng = np.random.default_rng(5)
         c = c + rng.normal(0.0, 0.03, c.shape) + np.array([37.0, -61.0, 13.0])  # (atoms start one or two cells outside the box)
         nse = case.endswith("_nse")
-        return dict(coord=c.astype(np.float32), numbers=z, cell=cell.astype(np.float32), charge=(np.array([1.0, 0.0]) if nse else 0.0),
+        d3 = None
+        if "_d3" in case:  # external DFT-D3(BJ): one matrix shared with DSF (cutoff 15 A) or its own (12 A, the list build forms cn)
+            g, t = (np.load(os.path.join(ROOT, "tests", "golden", f + ".npz")) for f in ("dftd3", "dftd3_subset"))
+            d3 = dict(par=dict(s6=float(g["s6"]), s8=float(g["s8"]), a1=float(g["a1"]), a2=float(g["a2"]),
+                               cutoff=12.0 if case.endswith("rc12") else 15.0, smoothing_fraction=0.2),
+                      tables={k: t[k] for k in ("c6ab", "cn_ref", "rcov", "r4r2")})
+        return dict(d3=d3, coord=c.astype(np.float32), numbers=z, cell=cell.astype(np.float32), charge=(np.array([1.0, 0.0]) if nse else 0.0),
                     dsf_rc=15.0, dsf_alpha=0.2, cold=not nse, nq=2 if nse else 1, coulomb="none" if case.endswith("_nocoul") else "dsf")
     raise SystemExit(f"unknown case {case}")
 
@@ -45,11 +51,15 @@ def main():
     coulomb = inp.get("coulomb", "dsf")
     spec = loader.synthetic_spec(0, cold=inp["cold"]) if inp["nq"] == 1 else loader.synthetic_spec(0, num_charge_channels=2)
     eng = HipEngine(spec, "cuda:0")
+    d3par = None
+    if inp.get("d3"):
+        eng.set_dftd3_tables(inp["d3"]["tables"])
+        d3par = inp["d3"]["par"]
     dde = DomainDecomposedEngine(eng)
     res = dde.eval(inp["coord"], inp["numbers"], inp["cell"], charge=inp["charge"], forces=True, stress=True, coulomb=coulomb,
-                   dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"])
+                   dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"], dftd3=d3par)
     again = dde.eval(inp["coord"], inp["numbers"], inp["cell"], charge=inp["charge"], forces=True, stress=True, coulomb=coulomb,
-                     dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"])
+                     dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"], dftd3=d3par)
     dom = dde.last_domain
     # every rank holds the same result
     chk = torch.stack([res["energy"].double().cpu(), res["forces"].double().abs().sum().cpu()])
@@ -69,7 +79,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(3):
         dde.eval(inp["coord"], inp["numbers"], inp["cell"], charge=inp["charge"], forces=True, coulomb=coulomb, dsf_rc=inp["dsf_rc"],
-                 dsf_alpha=inp["dsf_alpha"])
+                 dsf_alpha=inp["dsf_alpha"], dftd3=d3par)
     torch.cuda.synchronize()
     dist.barrier()
     rec["ms_per_decomposed_eval_shared_gpu_gloo"] = (time.perf_counter() - t0) / 3 * 1e3
@@ -88,14 +98,14 @@ def main():
         xw = (wrapped_fractional(inp["coord"], inp["cell"]) @ np.asarray(inp["cell"], np.float64)).astype(np.float32)
         one = eng.eval(torch.as_tensor(xw, device=dev), torch.as_tensor(inp["numbers"], device=dev).int(),
                        torch.zeros(n, dtype=torch.int32, device=dev), q_in, cell=torch.as_tensor(inp["cell"], device=dev), forces=True,
-                       stress=True, coulomb=coulomb, dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"])
+                       stress=True, coulomb=coulomb, dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"], dftd3=d3par)
 
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3):
             eng.eval(torch.as_tensor(xw, device=dev), torch.as_tensor(inp["numbers"], device=dev).int(),
                      torch.zeros(n, dtype=torch.int32, device=dev), q_in, cell=torch.as_tensor(inp["cell"], device=dev), forces=True,
-                     coulomb=coulomb, dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"])
+                     coulomb=coulomb, dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"], dftd3=d3par)
         torch.cuda.synchronize()
         rec["ms_per_single_rank_eval"] = (time.perf_counter() - t0) / 3 * 1e3
 

@@ -47,7 +47,7 @@ def test_two_slabs_reproduce_the_reference_golden_2304(tmp_path):
     assert rec["ranks_agree"] and rec["repeat_bitwise"] and rec["owned_total"] == rec["n_atoms"] == 2304
     assert rec["n_local"] > rec["n_owned"] > 0
     # per evaluation: NSE forward sums of passes 0, 1 + their adjoint sums = 4 all-reduces, one charge exchange
-    assert rec["exchange_calls"] == {"0": 4, "1": 1}
+    assert rec["exchange_calls"] == {"0": 4, "1": 1, "2": 0}
     _gates(rec, "vs_single_rank", 2304)
     _gates(rec, "vs_reference_golden", 2304)
 
@@ -68,7 +68,17 @@ def test_two_charge_channels_charged_cell(tmp_path):
     """Open-shell NSE model (two charge channels, hot weights), total charge +1: one forward all-reduce per channel and pass, one
     (both channels) per pass for the adjoint sums; two charge planes in the one charge exchange."""
     rec = _run("cube1536_nse", 2, 29545, tmp_path)
-    assert rec["exchange_calls"] == {"0": 6, "1": 1}
+    assert rec["exchange_calls"] == {"0": 6, "1": 1, "2": 0}
     c = rec["vs_single_rank"]
     # hot synthetic weights: two fp32 evaluations of the same surface in different summation orders (DESIGN.md 7, noise floor)
     assert c["dE"] <= 5e-3 and c["dF_max"] <= 2e-4 * max(1.0, c["F_max"]) and c["dq_max"] <= 1e-4 and c["ds_max"] <= 1e-4, c
+
+
+@pytest.mark.parametrize("case,port", [("cube1536_d3", 29546), ("cube1536_d3rc12", 29547)])
+def test_dftd3_weights_and_dEdcn_come_from_the_owners(case, port, tmp_path):
+    """External DFT-D3(BJ) (the shipped models run with it): a halo copy's coordination number needs ITS 15 A neighbourhood, so
+    the per-atom reference weights and dE/dcn of halo rows are taken from their owners (AIMNET_DD_ROWS, two more exchanges) - with
+    one matrix shared with DSF (cutoff 15 A) and with a D3 matrix of its own (12 A, coordination numbers formed by the list build)."""
+    rec = _run(case, 2, port, tmp_path)
+    assert rec["ranks_agree"] and rec["repeat_bitwise"] and rec["exchange_calls"] == {"0": 4, "1": 1, "2": 2}
+    _gates(rec, "vs_single_rank", 1536, strict=False)

@@ -4,7 +4,7 @@ set -u
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/dd
 port=29560
-for spec in "golden2304 2" "golden2304 3" "cube1536 2" "cube1536 3" "cube1536_nocoul 2" "cube1536_nse 2"; do
+for spec in "golden2304 2" "golden2304 3" "cube1536 2" "cube1536 3" "cube1536_nocoul 2" "cube1536_nse 2" "cube1536_d3 2" "cube1536_d3rc12 2"; do
   set -- $spec
   port=$((port + 1))
   DD_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$2" --master-addr 127.0.0.1 --master-port $port \

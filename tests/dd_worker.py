@@ -44,9 +44,11 @@ def case_inputs(case: str):
 
 def main():
     case, out_path = sys.argv[1], sys.argv[2]
-    dist.init_process_group(os.environ.get("DD_BACKEND", "gloo"))
-    rank, world = dist.get_rank(), dist.get_world_size()
+    backend = os.environ.get("DD_BACKEND", "gloo")
     torch.cuda.set_device(0)
+    dist.init_process_group(backend)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cdev = "cuda:0" if backend == "nccl" else "cpu"  # where the worker's own bookkeeping collectives live
     inp = case_inputs(case)
     coulomb = inp.get("coulomb", "dsf")
     spec = loader.synthetic_spec(0, cold=inp["cold"]) if inp["nq"] == 1 else loader.synthetic_spec(0, num_charge_channels=2)
@@ -62,11 +64,11 @@ def main():
                      dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"], dftd3=d3par)
     dom = dde.last_domain
     # every rank holds the same result
-    chk = torch.stack([res["energy"].double().cpu(), res["forces"].double().abs().sum().cpu()])
+    chk = torch.stack([res["energy"].double().cpu(), res["forces"].double().abs().sum().cpu()]).to(cdev)
     lo, hi = chk.clone(), chk.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    rec = {"case": case, "world": world, "ranks_agree": bool((lo == hi).all()), "axis": dom.axis, "n_owned": dom.n_owned,
+    rec = {"case": case, "world": world, "backend": backend, "ranks_agree": bool((lo == hi).all()), "axis": dom.axis, "n_owned": dom.n_owned,
            "n_local": dom.n_local, "exchange_calls": {str(k): v for k, v in dde.last_calls.items()},
            "repeat_bitwise": bool(torch.equal(res["forces"], again["forces"]) and torch.equal(res["energy"], again["energy"]) and
                                   torch.equal(res["stress"], again["stress"]))}
@@ -83,7 +85,7 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     rec["ms_per_decomposed_eval_shared_gpu_gloo"] = (time.perf_counter() - t0) / 3 * 1e3
-    owned = torch.tensor([dom.n_owned], dtype=torch.int64)
+    owned = torch.tensor([dom.n_owned], dtype=torch.int64, device=cdev)
     dist.all_reduce(owned)
     rec["owned_total"] = int(owned[0])
     if rank == 0:

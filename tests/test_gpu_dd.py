@@ -16,11 +16,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(case: str, world: int, port: int, tmp_path) -> dict:
+def _run(case: str, world: int, port: int, tmp_path, backend: str = "gloo") -> dict:
     out = os.path.join(str(tmp_path), f"dd_{case}_{world}.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dd_worker.py"), case, out]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, DD_BACKEND="gloo"))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, DD_BACKEND=backend))
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     with open(out) as fh:
         return json.load(fh)
@@ -81,4 +81,13 @@ def test_dftd3_weights_and_dEdcn_come_from_the_owners(case, port, tmp_path):
     one matrix shared with DSF (cutoff 15 A) and with a D3 matrix of its own (12 A, coordination numbers formed by the list build)."""
     rec = _run(case, 2, port, tmp_path)
     assert rec["ranks_agree"] and rec["repeat_bitwise"] and rec["exchange_calls"] == {"0": 4, "1": 1, "2": 2}
+    _gates(rec, "vs_single_rank", 1536, strict=False)
+
+
+def test_one_rank_over_rccl_exercises_the_device_side_exchanges(tmp_path):
+    """RCCL refuses two ranks on one device, so the `nccl` branch of the exchanges (all-reduce on views of the engine's workspace,
+    ordered on the engine's stream, no host copy) runs here with ONE rank: a single slab whose halo holds the cell's own images."""
+    rec = _run("cube1536", 1, 29548, tmp_path, backend="nccl")
+    assert rec["backend"] == "nccl" and rec["world"] == 1 and rec["owned_total"] == 1536 and rec["n_local"] > 1536
+    assert rec["exchange_calls"] == {"0": 4, "1": 1, "2": 0} and rec["repeat_bitwise"]
     _gates(rec, "vs_single_rank", 1536, strict=False)

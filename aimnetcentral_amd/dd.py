@@ -76,27 +76,60 @@ def wrapped_fractional(coord: np.ndarray, cell: np.ndarray) -> np.ndarray:
     return f
 
 
-def owners(coord: np.ndarray, cell: np.ndarray, world: int, axis: int | None = None) -> tuple[np.ndarray, int]:
-    """Owner rank of every atom (equal-width slabs of the fractional coordinate along `axis`; default: the widest axis)."""
+def brick_grid(cell: np.ndarray, world: int, halo: float = 15.0) -> tuple[int, int, int]:
+    """Ranks along the three cell axes (g0 g1 g2 = world) that evaluate the fewest local atoms per owned atom (`halo_fraction`)."""
+    w = perpendicular_widths(cell)
+    best, best_cost = (1, 1, world), None
+    for g0 in range(1, world + 1):
+        if world % g0:
+            continue
+        for g1 in range(1, world // g0 + 1):
+            if (world // g0) % g1:
+                continue
+            g = (g0, g1, world // (g0 * g1))
+            cost = float(np.prod([(w[d] / g[d] + 2.0 * halo) / (w[d] / g[d]) for d in range(3)]))
+            if best_cost is None or cost < best_cost - 1e-12:
+                best, best_cost = g, cost
+    return best
+
+
+def _grid_of(cell, world: int, grid, axis):
+    if grid is not None:
+        g = tuple(int(x) for x in grid)
+        if len(g) != 3 or min(g) < 1 or g[0] * g[1] * g[2] != world:
+            raise ValueError(f"domain decomposition: grid {grid} does not multiply to the {world} ranks of the group")
+        return g
     if axis is None:
         axis = int(np.argmax(perpendicular_widths(cell)))
+    g = [1, 1, 1]
+    g[axis] = world
+    return tuple(g)
+
+
+def owners(coord: np.ndarray, cell: np.ndarray, world: int, axis: int | None = None, grid=None) -> tuple[np.ndarray, tuple[int, int, int]]:
+    """Owner rank of every atom and the rank grid.  Default: `world` equal-width slabs of the fractional coordinate along `axis`
+    (the widest axis); `grid = (g0, g1, g2)`: bricks, rank = (i0 g1 + i1) g2 + i2."""
+    g = _grid_of(cell, world, grid, axis)
     f = wrapped_fractional(coord, cell)
-    return np.minimum((f[:, axis] * world).astype(np.int64), world - 1), axis
+    idx = [np.minimum((f[:, d] * g[d]).astype(np.int64), g[d] - 1) for d in range(3)]
+    return (idx[0] * g[1] + idx[1]) * g[2] + idx[2], g
 
 
-def slab_partition(coord: np.ndarray, cell: np.ndarray, world: int, rank: int, halo: float, axis: int | None = None) -> SlabDomain:
-    """Owned atoms of slab `rank` plus every periodic image of every atom inside the slab's box padded by `halo` along all three
-    cell axes (a superset of the points within `halo` of the slab: a point at Euclidean distance <= h from the region is at most
-    h / w_d outside it in fractional coordinate d, w_d the perpendicular width)."""
+def slab_partition(coord: np.ndarray, cell: np.ndarray, world: int, rank: int, halo: float, axis: int | None = None,
+                   grid=None) -> SlabDomain:
+    """Owned atoms of slab (or brick, `grid`) `rank` plus every periodic image of every atom inside the region's box padded by `halo`
+    along all three cell axes (a superset of the points within `halo` of the region: a point at Euclidean distance <= h from it is
+    at most h / w_d outside it in fractional coordinate d, w_d the perpendicular width)."""
     cell = np.asarray(cell, dtype=np.float64)
     if world < 1 or not (0 <= rank < world):
         raise ValueError("slab_partition: need 0 <= rank < world")
-    own, axis = owners(coord, cell, world, axis)
+    own, g = owners(coord, cell, world, axis, grid)
     f = wrapped_fractional(coord, cell)
     w = perpendicular_widths(cell)
-    lo = np.zeros(3)
-    hi = np.ones(3)
-    lo[axis], hi[axis] = rank / world, (rank + 1) / world
+    ri = (rank // (g[1] * g[2]), (rank // g[2]) % g[1], rank % g[2])
+    lo = np.array([ri[d] / g[d] for d in range(3)])
+    hi = np.array([(ri[d] + 1) / g[d] for d in range(3)])
+    axis = int(np.argmax(g))
     pad = halo / w
     n_lo = np.floor(lo - pad).astype(int)
     n_hi = np.floor(hi + pad).astype(int)
@@ -106,8 +139,8 @@ def slab_partition(coord: np.ndarray, cell: np.ndarray, world: int, rank: int, h
         for ny in range(n_lo[1], n_hi[1] + 1):
             for nz in range(n_lo[2], n_hi[2] + 1):
                 n = np.array([nx, ny, nz])
-                g = f + n
-                inside = np.all((g >= lo - pad) & (g < hi + pad), axis=1)
+                gg = f + n
+                inside = np.all((gg >= lo - pad) & (gg < hi + pad), axis=1)
                 if nx == 0 and ny == 0 and nz == 0:
                     inside &= own != rank  # (the owned atoms themselves)
                 k = np.nonzero(inside)[0]
@@ -198,7 +231,7 @@ class DomainDecomposedEngine:
 
     def eval(self, coord, numbers, cell, charge: float = 0.0, forces: bool = True, stress: bool = False, coulomb: str = "dsf",
              dsf_rc: float = 15.0, dsf_alpha: float = 0.2, dftd3: dict[str, float] | None = None, halo: float | None = None,
-             axis: int | None = None) -> dict[str, Any]:
+             axis: int | None = None, grid=None) -> dict[str, Any]:
         import torch
 
         eng = self.engine
@@ -212,7 +245,7 @@ class DomainDecomposedEngine:
         if halo is None:
             halo = max(3.0 * float(eng.spec.rc), float(dsf_rc) if coulomb == "dsf" else 0.0,
                        float(dftd3.get("cutoff", 15.0)) if dftd3 is not None else 0.0) + 1e-3
-        dom = slab_partition(xyz, cel, self.world, self.rank, float(halo), axis)
+        dom = slab_partition(xyz, cel, self.world, self.rank, float(halo), axis, grid)
         self.last_domain = dom
         if dom.n_owned == 0:
             raise ValueError(f"DomainDecomposedEngine: rank {self.rank} owns no atom (world {self.world} is too large for this system)")
@@ -286,16 +319,12 @@ class DomainDecomposedEngine:
         return out
 
 
-def halo_fraction(cell: np.ndarray, world: int, halo: float) -> float:
+def halo_fraction(cell: np.ndarray, world: int, halo: float, grid=None) -> float:
     """Local atoms per owned atom for a homogeneous system (the cost model of DESIGN.md 6: form (a) pays this factor)."""
     w = perpendicular_widths(cell)
-    axis = int(np.argmax(w))
-    f = 1.0
-    for d in range(3):
-        own = w[d] / world if d == axis else w[d]
-        f *= (own + 2.0 * halo) / own
-    return f
+    g = _grid_of(cell, world, grid, None)
+    return float(np.prod([(w[d] / g[d] + 2.0 * halo) / (w[d] / g[d]) for d in range(3)]))
 
 
-__all__ = ["DomainDecomposedEngine", "SlabDomain", "slab_partition", "owners", "perpendicular_widths", "wrapped_fractional",
+__all__ = ["DomainDecomposedEngine", "SlabDomain", "slab_partition", "owners", "brick_grid", "perpendicular_widths", "wrapped_fractional",
            "halo_fraction"]

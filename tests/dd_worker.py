@@ -44,6 +44,7 @@ def case_inputs(case: str):
 
 def main():
     case, out_path = sys.argv[1], sys.argv[2]
+    grid = tuple(int(v) for v in os.environ["DD_GRID"].split(",")) if os.environ.get("DD_GRID") else None  # bricks instead of slabs
     backend = os.environ.get("DD_BACKEND", "gloo")
     torch.cuda.set_device(0)
     dist.init_process_group(backend)
@@ -59,16 +60,16 @@ def main():
         d3par = inp["d3"]["par"]
     dde = DomainDecomposedEngine(eng)
     res = dde.eval(inp["coord"], inp["numbers"], inp["cell"], charge=inp["charge"], forces=True, stress=True, coulomb=coulomb,
-                   dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"], dftd3=d3par)
+                   dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"], dftd3=d3par, grid=grid)
     again = dde.eval(inp["coord"], inp["numbers"], inp["cell"], charge=inp["charge"], forces=True, stress=True, coulomb=coulomb,
-                     dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"], dftd3=d3par)
+                     dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"], dftd3=d3par, grid=grid)
     dom = dde.last_domain
     # every rank holds the same result
     chk = torch.stack([res["energy"].double().cpu(), res["forces"].double().abs().sum().cpu()]).to(cdev)
     lo, hi = chk.clone(), chk.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    rec = {"case": case, "world": world, "backend": backend, "ranks_agree": bool((lo == hi).all()), "axis": dom.axis, "n_owned": dom.n_owned,
+    rec = {"case": case, "world": world, "backend": backend, "ranks_agree": bool((lo == hi).all()), "axis": dom.axis, "grid": list(grid) if grid else None, "n_owned": dom.n_owned,
            "n_local": dom.n_local, "exchange_calls": {str(k): v for k, v in dde.last_calls.items()},
            "repeat_bitwise": bool(torch.equal(res["forces"], again["forces"]) and torch.equal(res["energy"], again["energy"]) and
                                   torch.equal(res["stress"], again["stress"]))}
@@ -81,7 +82,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(3):
         dde.eval(inp["coord"], inp["numbers"], inp["cell"], charge=inp["charge"], forces=True, coulomb=coulomb, dsf_rc=inp["dsf_rc"],
-                 dsf_alpha=inp["dsf_alpha"], dftd3=d3par)
+                 dsf_alpha=inp["dsf_alpha"], dftd3=d3par, grid=grid)
     torch.cuda.synchronize()
     dist.barrier()
     rec["ms_per_decomposed_eval_shared_gpu_gloo"] = (time.perf_counter() - t0) / 3 * 1e3

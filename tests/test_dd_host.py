@@ -38,13 +38,14 @@ def _periodic_neighbour_distances(x, cell, i, h):
 
 def test_partition_covers_every_owned_neighbourhood():
     h = 6.0
-    for seed, world in ((0, 2), (1, 3), (2, 1)):
+    for seed, world, grid in ((0, 2, None), (1, 3, None), (2, 1, None), (3, 4, (2, 1, 2)), (4, 8, (2, 2, 2))):
         x, cell = _cell_and_atoms(seed)
-        own, axis = dd.owners(x, cell, world)
+        own, g = dd.owners(x, cell, world, grid=grid)
+        assert g[0] * g[1] * g[2] == world and (grid is None or g == grid)
         seen = np.zeros(len(x), dtype=int)
         for rank in range(world):
-            dom = dd.slab_partition(x, cell, world, rank, h)
-            assert dom.axis == axis and dom.n_owned == int((own == rank).sum())
+            dom = dd.slab_partition(x, cell, world, rank, h, grid=grid)
+            assert dom.axis == int(np.argmax(g)) and dom.n_owned == int((own == rank).sum())
             assert np.array_equal(np.sort(dom.gid[: dom.n_owned]), np.nonzero(own == rank)[0])
             assert np.all(dom.shift[: dom.n_owned] == 0) and dom.owned_mask.sum() == dom.n_owned
             seen[dom.gid[: dom.n_owned]] += 1
@@ -71,6 +72,9 @@ def test_widths_and_halo_fraction():
     w = dd.perpendicular_widths(cell)
     assert abs(w[1] - 37.6872) < 1e-3 and int(np.argmax(w)) == 2 and w[0] < np.linalg.norm(cell[0]) + 1e-9
     assert dd.halo_fraction(cell, 2, 15.0) > dd.halo_fraction(cell * 10.0, 2, 15.0) > 1.0
+    cube = np.eye(3) * 200.0
+    assert dd.brick_grid(cube, 8) == (2, 2, 2) and dd.halo_fraction(cube, 8, 15.0, (2, 2, 2)) < dd.halo_fraction(cube, 8, 15.0)
+    assert dd.brick_grid(cell, 2) == (1, 1, 2)  # two ranks: slabs along the widest axis
     f = dd.wrapped_fractional(np.array([[-1e-18, 0.0, 0.0]]), np.eye(3))
     assert (f >= 0).all() and (f < 1).all()
 

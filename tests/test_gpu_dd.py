@@ -16,11 +16,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(case: str, world: int, port: int, tmp_path, backend: str = "gloo") -> dict:
+def _run(case: str, world: int, port: int, tmp_path, backend: str = "gloo", grid: str = "") -> dict:
     out = os.path.join(str(tmp_path), f"dd_{case}_{world}.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dd_worker.py"), case, out]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, DD_BACKEND=backend))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, DD_BACKEND=backend, DD_GRID=grid))
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     with open(out) as fh:
         return json.load(fh)
@@ -91,3 +91,12 @@ def test_one_rank_over_rccl_exercises_the_device_side_exchanges(tmp_path):
     assert rec["backend"] == "nccl" and rec["world"] == 1 and rec["owned_total"] == 1536 and rec["n_local"] > 1536
     assert rec["exchange_calls"] == {"0": 4, "1": 1, "2": 0} and rec["repeat_bitwise"]
     _gates(rec, "vs_single_rank", 1536, strict=False)
+
+
+def test_four_ranks_as_bricks(tmp_path):
+    """2 x 1 x 2 bricks instead of slabs (the form that keeps the halo fraction down on near-cubic cells): four ranks on the one
+    GPU, the reference's 2 304-atom golden at the literal gates."""
+    rec = _run("golden2304", 4, 29549, tmp_path, grid="2,1,2")
+    assert rec["ranks_agree"] and rec["owned_total"] == 2304 and rec["grid"] == [2, 1, 2]
+    _gates(rec, "vs_single_rank", 2304)
+    _gates(rec, "vs_reference_golden", 2304)

@@ -159,6 +159,8 @@ class AIMNet2Calculator:
         self._mult_ignored_checked = False
         self._species_cache: tuple[Any, Any] | None = None
         self._molidx_cache: tuple[Any, Any] | None = None
+        self._dd = None  # set_domain_decomposition: one periodic system over the ranks of a torch.distributed group
+        self._dd_grid = None
         family = (metadata or {}).get("family")
         self._maybe_warn_family_mix(family)
 
@@ -286,6 +288,20 @@ class AIMNet2Calculator:
             self.cutoff_lr = self._coulomb_cutoff
         else:
             self.cutoff_lr = self._dftd3_cutoff if self.external_dftd3 is not None else None
+
+    def set_domain_decomposition(self, enabled: bool = True, group=None, grid=None) -> None:
+        """Not in the reference (it evaluates a system on one device, docs/tutorials/performance.md:275-285): from now on a call with
+        ONE fully periodic system in the flat (N, 3) layout is cut into slabs - or `grid = (g0, g1, g2)` bricks - over the ranks of a
+        torch.distributed process group (default: the world).  Every rank calls `eval` with the same full input and receives the same
+        full result (aimnetcentral_amd/dd.py).  Coulomb method 'dsf' (or none); Ewald / PME, batches, caller-supplied
+        matrices and Hessians are not decomposed."""
+        if not enabled:
+            self._dd = None
+            return
+        from .dd import DomainDecomposedEngine
+
+        self._dd = DomainDecomposedEngine(self.engine, group)
+        self._dd_grid = grid
 
     def _dftd3_options(self) -> dict[str, float] | None:
         d3 = self.external_dftd3
@@ -518,13 +534,24 @@ class AIMNet2Calculator:
                 if p.ndim == 1 and p.shape != (3,):
                     raise ValueError("pbc must have shape (3,) or (B, 3)")
                 pbc3 = tuple(bool(x) for x in p) if p.ndim == 1 else pbc  # per-system flags: the engine uploads them as int32
-            res = self.engine.eval(
-                coord_f, numbers_f, mol_idx, self._engine_charge(charge, d.get("mult")), cell=cell, pbc=pbc3, forces=bool(forces),
-                stress=bool(stress),
-                coulomb=method or "none", dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, ewald_accuracy=self._ewald_accuracy,
-                dftd3=self._dftd3_options(),
-                **({"host_out": True} if host_out else {}), **({"sync": False, "defer": True} if defer_status else {}),
-                **self._check_caller_lists(ext_lists, method, cell))
+            if self._dd is not None:
+                if (coord.ndim != 2 or n_mol != 1 or cell is None or cell.ndim != 2 or pbc3 != (True, True, True) or ext_lists or
+                        method not in (None, "dsf") or host_out or defer_status):
+                    raise ValueError("domain decomposition (set_domain_decomposition) takes ONE fully periodic system in the flat (N, 3) "
+                                     "layout with Coulomb method 'dsf' or none, evaluated synchronously")
+                q_sys = self._engine_charge(charge, d.get("mult")).detach().cpu().numpy().reshape(-1)
+                res = self._dd.eval(coord_f, numbers_f, cell, charge=(q_sys if q_sys.size == 2 else float(q_sys[0])), forces=bool(forces),
+                                    stress=bool(stress), coulomb=method or "none", dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha,
+                                    dftd3=self._dftd3_options(), grid=self._dd_grid)
+                res["energy"] = res["energy"].reshape(1)
+            else:
+                res = self.engine.eval(
+                    coord_f, numbers_f, mol_idx, self._engine_charge(charge, d.get("mult")), cell=cell, pbc=pbc3, forces=bool(forces),
+                    stress=bool(stress),
+                    coulomb=method or "none", dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha, ewald_accuracy=self._ewald_accuracy,
+                    dftd3=self._dftd3_options(),
+                    **({"host_out": True} if host_out else {}), **({"sync": False, "defer": True} if defer_status else {}),
+                    **self._check_caller_lists(ext_lists, method, cell))
         finally:
             if restore is not None:
                 (self._coulomb_method, self._coulomb_cutoff, self.cutoff_lr, self._dsf_alpha, self._dsf_rc) = restore

@@ -100,3 +100,14 @@ def test_four_ranks_as_bricks(tmp_path):
     assert rec["ranks_agree"] and rec["owned_total"] == 2304 and rec["grid"] == [2, 1, 2]
     _gates(rec, "vs_single_rank", 2304)
     _gates(rec, "vs_reference_golden", 2304)
+
+
+def test_calculator_surface(tmp_path):
+    """`AIMNet2Calculator.set_domain_decomposition(True)`: the reference's dict-in / dict-out call on every rank returns the same
+    shapes and (at the gates) the same numbers as the undecomposed calculator; a batch is refused; switching it off restores the
+    single-rank path bit for bit."""
+    rec = _run("calculator", 2, 29550, tmp_path)
+    assert rec["shapes"] == rec["ref_shapes"] and rec["shapes"]["energy"] == [1] and rec["shapes"]["stress"] == [3, 3]
+    assert rec["dE"] <= max(1e-5, 5e-7 * 1536) and rec["dF_violations"] <= 4 and rec["dF_worst_ratio"] <= 2.0, rec
+    assert rec["dq_max"] <= 1e-4 and rec["ds_max"] <= 1e-5, rec
+    assert rec["batch_refused"] and "domain decomposition" in rec["batch_refused"] and rec["off_again_bitwise"]

@@ -153,6 +153,52 @@ def slab_partition(coord: np.ndarray, cell: np.ndarray, world: int, rank: int, h
     return SlabDomain(rank=rank, world=world, axis=axis, n_owned=int(idx_owned.shape[0]), gid=gid, coord=pos, shift=shift)
 
 
+def slab_partition_device(coord, cell, world: int, rank: int, halo: float, axis: int | None = None, grid=None):
+    """`slab_partition` in torch on the device that holds `coord` (float64 arithmetic, same region, same image set): for callers whose
+    positions live on the GPU - a 10^6-atom system costs the numpy form a second of host time per call.  Returns a `SlabDomain` whose
+    `gid` / `coord` / `shift` are torch tensors on that device (owned atoms first, in global order; the halo order is the shift loop's)."""
+    import torch
+
+    cel = np.asarray(cell.detach().cpu() if hasattr(cell, "detach") else cell, dtype=np.float64)
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("slab_partition: need 0 <= rank < world")
+    g = _grid_of(cel, world, grid, axis)
+    w = perpendicular_widths(cel)
+    dev = coord.device
+    cell_t = torch.as_tensor(cel, dtype=torch.float64, device=dev)
+    f = coord.to(torch.float64) @ torch.linalg.inv(cell_t)
+    f = f - torch.floor(f)
+    f = torch.where(f >= 1.0, torch.zeros_like(f), f)
+    g_t = torch.tensor(g, dtype=torch.float64, device=dev)
+    idx = torch.minimum((f * g_t).to(torch.int64), (g_t - 1).to(torch.int64))
+    own = (idx[:, 0] * g[1] + idx[:, 1]) * g[2] + idx[:, 2]
+    ri = (rank // (g[1] * g[2]), (rank // g[2]) % g[1], rank % g[2])
+    lo = np.array([ri[d] / g[d] for d in range(3)])
+    hi = np.array([(ri[d] + 1) / g[d] for d in range(3)])
+    pad = halo / w
+    n_lo, n_hi = np.floor(lo - pad).astype(int), np.floor(hi + pad).astype(int)
+    lo_t = torch.as_tensor(lo - pad, dtype=torch.float64, device=dev)
+    hi_t = torch.as_tensor(hi + pad, dtype=torch.float64, device=dev)
+    mine = own == rank
+    idx_owned = torch.nonzero(mine).reshape(-1)
+    gids, shifts = [idx_owned], [torch.zeros((idx_owned.shape[0], 3), dtype=torch.int64, device=dev)]
+    for nx in range(n_lo[0], n_hi[0] + 1):
+        for ny in range(n_lo[1], n_hi[1] + 1):
+            for nz in range(n_lo[2], n_hi[2] + 1):
+                n = torch.tensor([nx, ny, nz], dtype=torch.float64, device=dev)
+                gg = f + n
+                inside = ((gg >= lo_t) & (gg < hi_t)).all(dim=1)
+                if nx == 0 and ny == 0 and nz == 0:
+                    inside = inside & ~mine
+                k = torch.nonzero(inside).reshape(-1)
+                gids.append(k)
+                shifts.append(n.to(torch.int64).expand(k.shape[0], 3))
+    gid = torch.cat(gids)
+    shift = torch.cat(shifts)
+    pos = (f[gid] + shift.to(torch.float64)) @ cell_t
+    return SlabDomain(rank=rank, world=world, axis=int(np.argmax(g)), n_owned=int(idx_owned.shape[0]), gid=gid, coord=pos, shift=shift)
+
+
 class _Exchange:
     """The engine's exchange function for one evaluation: all-reduce of the NSE sums, owner values for the halo charges."""
 
@@ -238,29 +284,38 @@ class DomainDecomposedEngine:
         if coulomb not in ("none", "dsf"):
             raise ValueError("DomainDecomposedEngine: coulomb must be 'none' or 'dsf' (Ewald / PME reciprocal sums and the all-pairs "
                              "'simple' form are not decomposed)")
-        xyz = np.asarray(coord.detach().cpu() if hasattr(coord, "detach") else coord, dtype=np.float64)
         cel = np.asarray(cell.detach().cpu() if hasattr(cell, "detach") else cell, dtype=np.float64)
-        z = np.asarray(numbers.detach().cpu() if hasattr(numbers, "detach") else numbers).astype(np.int64)
-        n_global = xyz.shape[0]
+        dev = eng.device
+        n_global = int(coord.shape[0])
         if halo is None:
             halo = max(3.0 * float(eng.spec.rc), float(dsf_rc) if coulomb == "dsf" else 0.0,
                        float(dftd3.get("cutoff", 15.0)) if dftd3 is not None else 0.0) + 1e-3
-        dom = slab_partition(xyz, cel, self.world, self.rank, float(halo), axis, grid)
+        on_device = hasattr(coord, "is_cuda") and coord.is_cuda
+        if on_device:  # positions already on the GPU (an MD driver's state): partition there, nothing crosses to the host
+            dom = slab_partition_device(coord.to(dev), cel, self.world, self.rank, float(halo), axis, grid)
+            gid = dom.gid
+            xc = dom.coord
+            z_loc = torch.as_tensor(numbers, device=dev).to(torch.int32)[gid]
+        else:
+            xyz = np.asarray(coord.detach().cpu() if hasattr(coord, "detach") else coord, dtype=np.float64)
+            z = np.asarray(numbers.detach().cpu() if hasattr(numbers, "detach") else numbers).astype(np.int64)
+            dom = slab_partition(xyz, cel, self.world, self.rank, float(halo), axis, grid)
+            gid = torch.as_tensor(dom.gid, device=dev)
+            xc = torch.as_tensor(dom.coord, device=dev)
+            z_loc = torch.as_tensor(z[dom.gid], dtype=torch.int32, device=dev)
         self.last_domain = dom
         if dom.n_owned == 0:
             raise ValueError(f"DomainDecomposedEngine: rank {self.rank} owns no atom (world {self.world} is too large for this system)")
-        dev = eng.device
-        gid = torch.as_tensor(dom.gid, device=dev)
         # (the cluster is centred on its owned atoms before it is rounded to fp32: the engine's results are translation invariant,
         # and an image position of magnitude 50 A carries twice the rounding of one at 25 A)
-        x_loc = torch.as_tensor(dom.coord - dom.coord[: dom.n_owned].mean(axis=0), dtype=torch.float32, device=dev)
-        z_loc = torch.as_tensor(z[dom.gid], dtype=torch.int32, device=dev)
+        x_loc = (xc - xc[: dom.n_owned].mean(dim=0)).to(torch.float32)
         mol = torch.zeros(dom.n_local, dtype=torch.int32, device=dev)
         if eng.nq == 2:
             q_in = torch.as_tensor(np.asarray(charge, dtype=np.float32).reshape(1, 2), device=dev)
         else:
             q_in = torch.tensor([float(charge)], dtype=torch.float32, device=dev)
-        owned = torch.as_tensor(dom.owned_mask, device=dev)
+        owned = torch.zeros(dom.n_local, dtype=torch.float32, device=dev)
+        owned[: dom.n_owned] = 1.0
         ex = _Exchange(self, dom, gid, n_global)
         try:
             while True:
@@ -326,5 +381,5 @@ def halo_fraction(cell: np.ndarray, world: int, halo: float, grid=None) -> float
     return float(np.prod([(w[d] / g[d] + 2.0 * halo) / (w[d] / g[d]) for d in range(3)]))
 
 
-__all__ = ["DomainDecomposedEngine", "SlabDomain", "slab_partition", "owners", "brick_grid", "perpendicular_widths", "wrapped_fractional",
+__all__ = ["DomainDecomposedEngine", "SlabDomain", "slab_partition", "slab_partition_device", "owners", "brick_grid", "perpendicular_widths", "wrapped_fractional",
            "halo_fraction"]

@@ -67,6 +67,19 @@ def test_partition_covers_every_owned_neighbourhood():
         assert np.all(seen == 1)  # every atom is owned by exactly one rank
 
 
+def test_torch_partitioner_equals_the_numpy_one():
+    """`slab_partition_device` (what a caller with positions on the GPU gets) on CPU tensors: the same atoms, images, order and
+    positions as the numpy partitioner."""
+    for seed, world, grid in ((5, 2, None), (6, 3, None), (7, 4, (2, 1, 2)), (8, 8, (2, 2, 2))):
+        x, cell = _cell_and_atoms(seed, 80)
+        for rank in range(world):
+            a = dd.slab_partition(x, cell, world, rank, 6.0, grid=grid)
+            b = dd.slab_partition_device(torch.as_tensor(x), cell, world, rank, 6.0, grid=grid)
+            assert a.n_owned == b.n_owned and a.n_local == b.n_local and a.axis == b.axis
+            assert np.array_equal(a.gid, b.gid.numpy()) and np.array_equal(a.shift, b.shift.numpy())
+            assert np.abs(a.coord - b.coord.numpy()).max() < 1e-12
+
+
 def test_widths_and_halo_fraction():
     _, _, cell = workloads.glucose_supercell((7, 3, 5))
     w = dd.perpendicular_widths(cell)

@@ -104,6 +104,11 @@ def main():
         eng.set_dftd3_tables(inp["d3"]["tables"])
         d3par = inp["d3"]["par"]
     dde = DomainDecomposedEngine(eng)
+    if os.environ.get("DD_FORCE_OVERFLOW") and rank == 0:
+        # ONE rank starts with rows that are too short: its overflow has to make EVERY rank repeat the evaluation (a rank that
+        # retried alone would leave the others waiting in a collective)
+        eng.max_nb = 16
+        eng._max_nb_lr[float(inp["dsf_rc"])] = 64
     res = dde.eval(inp["coord"], inp["numbers"], inp["cell"], charge=inp["charge"], forces=True, stress=True, coulomb=coulomb,
                    dsf_rc=inp["dsf_rc"], dsf_alpha=inp["dsf_alpha"], dftd3=d3par, grid=grid)
     again = dde.eval(inp["coord"], inp["numbers"], inp["cell"], charge=inp["charge"], forces=True, stress=True, coulomb=coulomb,
@@ -114,7 +119,7 @@ def main():
     lo, hi = chk.clone(), chk.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    rec = {"case": case, "world": world, "backend": backend, "ranks_agree": bool((lo == hi).all()), "axis": dom.axis, "grid": list(grid) if grid else None, "n_owned": dom.n_owned,
+    rec = {"case": case, "world": world, "backend": backend, "max_nb_after": int(eng.max_nb), "ranks_agree": bool((lo == hi).all()), "axis": dom.axis, "grid": list(grid) if grid else None, "n_owned": dom.n_owned,
            "n_local": dom.n_local, "exchange_calls": {str(k): v for k, v in dde.last_calls.items()},
            "repeat_bitwise": bool(torch.equal(res["forces"], again["forces"]) and torch.equal(res["energy"], again["energy"]) and
                                   torch.equal(res["stress"], again["stress"]))}

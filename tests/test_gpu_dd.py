@@ -16,11 +16,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(case: str, world: int, port: int, tmp_path, backend: str = "gloo", grid: str = "") -> dict:
+def _run(case: str, world: int, port: int, tmp_path, backend: str = "gloo", grid: str = "", **env) -> dict:
     out = os.path.join(str(tmp_path), f"dd_{case}_{world}.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dd_worker.py"), case, out]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, DD_BACKEND=backend, DD_GRID=grid))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, DD_BACKEND=backend, DD_GRID=grid, **env))
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     with open(out) as fh:
         return json.load(fh)
@@ -111,3 +111,11 @@ def test_calculator_surface(tmp_path):
     assert rec["dE"] <= max(1e-5, 5e-7 * 1536) and rec["dF_violations"] <= 4 and rec["dF_worst_ratio"] <= 2.0, rec
     assert rec["dq_max"] <= 1e-4 and rec["ds_max"] <= 1e-5, rec
     assert rec["batch_refused"] and "domain decomposition" in rec["batch_refused"] and rec["off_again_bitwise"]
+
+
+def test_row_overflow_on_one_rank_is_repeated_by_all(tmp_path):
+    """Rank 0 starts with neighbour rows that are too short (16 short-range, 64 long-range entries): the status words are max-reduced
+    over the group, every rank grows its capacities and repeats the evaluation together - no rank is left in a collective."""
+    rec = _run("cube1536", 2, 29551, tmp_path, DD_FORCE_OVERFLOW="1")
+    assert rec["max_nb_after"] > 16 and rec["ranks_agree"]
+    _gates(rec, "vs_single_rank", 1536, strict=False)

@@ -106,6 +106,15 @@ def _grid_of(cell, world: int, grid, axis):
     return tuple(g)
 
 
+def _check_every_rank_owns(counts, g) -> None:
+    """Raised on EVERY rank alike (each rank sees the owner of every atom): a rank that stopped alone would leave the others waiting
+    in the first collective of the evaluation."""
+    empty = [int(r) for r in np.nonzero(np.asarray(counts) == 0)[0]]
+    if empty:
+        raise ValueError(f"domain decomposition: rank(s) {empty} of the {g[0]} x {g[1]} x {g[2]} rank grid own no atom - use fewer "
+                         "ranks or another grid for this system")
+
+
 def owners(coord: np.ndarray, cell: np.ndarray, world: int, axis: int | None = None, grid=None) -> tuple[np.ndarray, tuple[int, int, int]]:
     """Owner rank of every atom and the rank grid.  Default: `world` equal-width slabs of the fractional coordinate along `axis`
     (the widest axis); `grid = (g0, g1, g2)`: bricks, rank = (i0 g1 + i1) g2 + i2."""
@@ -124,6 +133,7 @@ def slab_partition(coord: np.ndarray, cell: np.ndarray, world: int, rank: int, h
     if world < 1 or not (0 <= rank < world):
         raise ValueError("slab_partition: need 0 <= rank < world")
     own, g = owners(coord, cell, world, axis, grid)
+    _check_every_rank_owns(np.bincount(own, minlength=world), g)
     f = wrapped_fractional(coord, cell)
     w = perpendicular_widths(cell)
     ri = (rank // (g[1] * g[2]), (rank // g[2]) % g[1], rank % g[2])
@@ -172,6 +182,7 @@ def slab_partition_device(coord, cell, world: int, rank: int, halo: float, axis:
     g_t = torch.tensor(g, dtype=torch.float64, device=dev)
     idx = torch.minimum((f * g_t).to(torch.int64), (g_t - 1).to(torch.int64))
     own = (idx[:, 0] * g[1] + idx[:, 1]) * g[2] + idx[:, 2]
+    _check_every_rank_owns(torch.bincount(own, minlength=world).cpu().numpy(), g)
     ri = (rank // (g[1] * g[2]), (rank // g[2]) % g[1], rank % g[2])
     lo = np.array([ri[d] / g[d] for d in range(3)])
     hi = np.array([(ri[d] + 1) / g[d] for d in range(3)])
@@ -304,8 +315,6 @@ class DomainDecomposedEngine:
             xc = torch.as_tensor(dom.coord, device=dev)
             z_loc = torch.as_tensor(z[dom.gid], dtype=torch.int32, device=dev)
         self.last_domain = dom
-        if dom.n_owned == 0:
-            raise ValueError(f"DomainDecomposedEngine: rank {self.rank} owns no atom (world {self.world} is too large for this system)")
         # (the cluster is centred on its owned atoms before it is rounded to fp32: the engine's results are translation invariant,
         # and an image position of magnitude 50 A carries twice the rounding of one at 25 A)
         x_loc = (xc - xc[: dom.n_owned].mean(dim=0)).to(torch.float32)

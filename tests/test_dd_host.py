@@ -80,6 +80,20 @@ def test_torch_partitioner_equals_the_numpy_one():
             assert np.abs(a.coord - b.coord.numpy()).max() < 1e-12
 
 
+def test_an_empty_rank_is_refused_on_every_rank():
+    """All atoms in one half of the cell: the rank that would own nothing is named by EVERY rank's partition call (a rank that
+    stopped alone would leave the others in a collective)."""
+    import pytest
+
+    cell = np.diag([10.0, 10.0, 20.0])
+    x = np.random.default_rng(0).uniform(0.0, 1.0, (30, 3)) * np.array([10.0, 10.0, 9.0])
+    for rank in (0, 1):
+        with pytest.raises(ValueError, match=r"rank\(s\) \[1\]"):
+            dd.slab_partition(x, cell, 2, rank, 5.0)
+        with pytest.raises(ValueError, match=r"rank\(s\) \[1\]"):
+            dd.slab_partition_device(torch.as_tensor(x), cell, 2, rank, 5.0)
+
+
 def test_widths_and_halo_fraction():
     _, _, cell = workloads.glucose_supercell((7, 3, 5))
     w = dd.perpendicular_widths(cell)

@@ -116,6 +116,11 @@ struct aimnet_engine {
   // AIMNET_D3_CN_RIDES / set_option("d3_cn_rides"): the DFT-D3 coordination numbers are formed by the cell-grid list build that serves
   // D3 (kernels.h, D3CnRider) instead of by a pass over the finished matrix
   int d3_cn_rides = 1;
+  // AIMNET_DSF_NP_WALK / set_option("dsf_np_walk"): non-periodic systems large enough for the bounding-box cell grid (>= 1 500 atoms per
+  // molecule on average) evaluate DSF Coulomb by the list-free walk over that grid, like periodic cells do - no 15 A neighbour matrix
+  // (N x ~2 000 entries built and read every step).  0 = the matrix form.  (With DFT-D3 at the same cutoff the pair terms ride on
+  // the D3 matrix pass either way.)  The clusters of a domain-decomposed evaluation are such systems.
+  int dsf_np_walk = 1;
   // aimnet_engine_set_dd: spatial domain decomposition of one system over ranks - owned-atom mask of the local cluster and the
   // caller's exchange function (dd.owned == NULL: off)
   aimnet::DdLink dd{nullptr, nullptr, nullptr};

@@ -622,6 +622,8 @@ int aimnet_engine_create(const aimnet_arch* arch, const aimnet_weights* w, int d
     (void)gemm_h2_set_attributes();  // AIMNET_H2_TILE / AIMNET_H2_DEEP (gemm_h2.hip)
     env = getenv("AIMNET_D3_CN_RIDES");
     if (env) e->d3_cn_rides = atoi(env) != 0;
+    env = getenv("AIMNET_DSF_NP_WALK");
+    if (env) e->dsf_np_walk = atoi(env) != 0;
     env = getenv("AIMNET_CONV_XE");
     if (env) e->conv_xe = atoi(env);
     env = getenv("AIMNET_SPLIT_MAX");
@@ -788,6 +790,7 @@ int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value) {
   else if (n == "nse_merged") e->nse_merged = value != 0;
   else if (n == "gemm_chain") e->gemm_chain = value != 0;
   else if (n == "d3_cn_rides") e->d3_cn_rides = value != 0;
+  else if (n == "dsf_np_walk") e->dsf_np_walk = value != 0;
   else if (n == "split_max") e->split_max = value < 0 ? conv_split_max_default() : value;
   else if (n == "p0_moments") e->p0_moments = value != 0;
   else if (n == "overlap_coulomb") e->overlap_coulomb = value != 0;
@@ -818,6 +821,7 @@ int aimnet_engine_get_option(const aimnet_engine* e, const char* name, int* valu
   else if (n == "nse_merged") *value = e->nse_merged;
   else if (n == "gemm_chain") *value = e->gemm_chain;
   else if (n == "d3_cn_rides") *value = e->d3_cn_rides;
+  else if (n == "dsf_np_walk") *value = e->dsf_np_walk;
   else if (n == "split_max") *value = e->split_max;
   else if (n == "p0_moments") *value = e->p0_moments ? 1 : 0;
   else if (n == "overlap_coulomb") *value = e->overlap_coulomb ? 1 : 0;
@@ -942,7 +946,10 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
     return AIMNET_E_INVALID;
   }
   int coulomb = opt->coulomb;
-  if (coulomb == AIMNET_COULOMB_DSF && !pbc && opt->max_nb_lr <= 0) {
+  // large non-periodic systems get a bounding-box cell grid (launch_bbox below): DSF walks it like a periodic cell's grid, no matrix
+  const bool np_walk = e->dsf_np_walk && !pbc && in->nbmat == nullptr && coulomb == AIMNET_COULOMB_DSF && (long)N >= 1500L * n_mol &&
+                       !(opt->dftd3 != 0 && opt->d3_cutoff == opt->dsf_rc);
+  if (coulomb == AIMNET_COULOMB_DSF && !pbc && opt->max_nb_lr <= 0 && !np_walk) {
     set_last_error("eval: non-periodic DSF Coulomb needs max_nb_lr > 0 (periodic DSF walks the cell grid, no list)");
     return AIMNET_E_INVALID;
   }
@@ -1098,7 +1105,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
   const bool status_rides = e->status_rides && !(coulomb == AIMNET_COULOMB_DSF && !pbc) && !d3;
   RC(launch_nlist(s, N, n_mol, mol_c, in->cell, n_cell, in->pbc, ar.rc, ar.rc, cap, N, 0, W.nl, W.nb_idx, W.nb_shift,
                   W.nb_cnt, out->status + 0, out->status + 2, W.pg, status_rides ? &sr_cnt_true : nullptr));
-  if (coulomb == AIMNET_COULOMB_DSF && !pbc)  // periodic DSF needs no list: it walks the short-range cell grid
+  if (coulomb == AIMNET_COULOMB_DSF && !pbc && !np_walk)  // periodic DSF (and large non-periodic systems) need no list: they walk the short-range cell grid
     RC(launch_nlist(s, N, n_mol, mol_c, in->cell, n_cell, in->pbc, opt->dsf_rc, -1.0f, cap_lr, N, 0, W.nl, W.lr_idx,
                     W.lr_shift, W.lr_cnt, out->status + 1, out->status + 3));
   d3_shared = d3 && d3_shares_lr_list(opt, cap_lr) && !pbc;
@@ -1169,8 +1176,8 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
                             out->status + 7));
       cp.ewald = W.ew.sys;
     }
-    const bool walk = ewald || (coulomb == AIMNET_COULOMB_DSF && pbc && !ext &&
-                                !(d3 && opt->d3_cutoff == opt->dsf_rc));  // the list-free walk runs below: its charge stream rides here
+    const bool walk = ewald || np_walk || (coulomb == AIMNET_COULOMB_DSF && pbc && !ext &&
+                                           !(d3 && opt->d3_cutoff == opt->dsf_rc));  // the list-free walk runs below: its charge stream rides here
     SrRiders rd = head_rider;
     if (walk) {
       rd.xs = W.nl.xs;
@@ -1209,7 +1216,7 @@ int aimnet_engine_eval(aimnet_engine* e, const aimnet_inputs* in, const aimnet_e
       ;  // ran inside the SR-Coulomb launch above (SrRiders::simple_xw)
     else if (dsf_in_d3)
       ;  // see launch_dftd3 below
-    else if (ewald || (coulomb == AIMNET_COULOMB_DSF && pbc && !ext)) {
+    else if (ewald || np_walk || (coulomb == AIMNET_COULOMB_DSF && pbc && !ext)) {
       RC(launch_coulomb_dsf_walk(cs, grad, want_s, q_fin, mol_c, W.nl, cp, N, W.ecoul, W.qbar, W.fgrad, W.virial_atom,
                                  out->charges, true, rev_done ? nullptr : &pmap));
       rev_done = true;

@@ -371,6 +371,10 @@ class HipEngine:
             opt.max_nb = self.max_nb
             # periodic DSF walks the cell grid (no list); only non-periodic DSF materialises a long-range list
             opt.max_nb_lr = self._lr_capacity(float(dsf_rc)) if (method == _lib.COULOMB_DSF and cell is None) else 0
+            # ... and neither do non-periodic systems large enough for the bounding-box cell grid (engine.hip `np_walk`: the same rule)
+            if (opt.max_nb_lr and n >= 1500 * n_mol and nbmat is None and self.get_option("dsf_np_walk") and
+                    not (dftd3 is not None and float(dftd3.get("cutoff", 15.0)) == float(dsf_rc))):
+                opt.max_nb_lr = 0
             if method in (_lib.COULOMB_EWALD, _lib.COULOMB_PME):
                 opt.ewald_accuracy = float(ewald_accuracy)
                 opt.ewald_max_k = self._ewald_max_k

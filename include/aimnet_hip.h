@@ -351,6 +351,8 @@ int aimnet_engine_debug_mlp_sweep(aimnet_engine* engine, int pass, int backward,
  *                   instead of the packed-FMA VALU kernels (default 0; systems above the split threshold only)
  *   "split_max"     atoms up to which the 4-waves-per-atom "split" conv kernels are used (default 1024; per engine; < 0 = default)
  *   "p0_moments"    0: generic row-gather conv kernels in pass 0 instead of the element-moment forward / species-moment backward
+ *   "dsf_np_walk" 0: non-periodic systems of >= 1 500 atoms per molecule evaluate DSF over a neighbour matrix (options.max_nb_lr) instead of
+ *                    walking their bounding-box cell grid (the default there, as for periodic cells: max_nb_lr may then be 0)
  *   "overlap_coulomb" 1: Coulomb / DFT-D3 pair kernels on a second HIP stream (default 0: measured slower)
  *   "spatial_order" 0: conv kernels walk the atoms in input order instead of cell-list bin order */
 int aimnet_engine_set_option(aimnet_engine* e, const char* name, int value);

@@ -298,12 +298,31 @@ __global__ __launch_bounds__(256) void d3_pair_kernel(const float4* __restrict__
     float tc = 0.0f;
     if (DSF) {
       const float inv = frcp(P.d);
+      // erfc(x) = exp(-x^2) t P(t), t = 1 / (1 + x / 2): the degree-9 fit of the list-free walk (model.hip, coulomb_dsf_walk_kernel:
+      // 6.5e-9 relative + 2.5e-7 of the fp32 Horner evaluation, the class of erfcf itself) - one exponential serves the value and
+      // the derivative, where erfcf() and a second exponential cost ~40 instructions more per list slot
+      const float ex = fexp(-al * al * P.d * P.d);
+      const float tt = frcp(fmaf(0.5f * al, P.d, 1.0f));
+      float pe = 2.672036890e-02f;
+      pe = fmaf(pe, tt, -2.020067459e-01f);
+      pe = fmaf(pe, tt, 6.150174393e-01f);
+      pe = fmaf(pe, tt, -9.195323909e-01f);
+      pe = fmaf(pe, tt, 6.300562657e-01f);
+      pe = fmaf(pe, tt, -2.111610618e-01f);
+      pe = fmaf(pe, tt, 2.648643249e-01f);
+      pe = fmaf(pe, tt, 2.301390953e-01f);
+      pe = fmaf(pe, tt, 2.838921720e-01f);
+      pe = fmaf(pe, tt, 2.820105286e-01f);
+#ifdef AIMNET_PROBE_D3_ERFCF  // measurement build: the library erfc of rounds 1 - 5 (tests/tools/d3prof.sh)
       const float ec = erfcf(al * P.d);
+#else
+      const float ec = pe * tt * ex;
+#endif
       const float w = ec * inv - sv + (P.d - Rc) * slope;
       A.ec += (double)(w * qc_i * qj);
       if (GRAD) {
         qb += w * qj;
-        tc = kratio * (-ec * inv * inv - two_a_sqrtpi * fexp(-al * al * P.d * P.d) * inv + slope) * qc_i * qj;
+        tc = kratio * (-ec * inv * inv - two_a_sqrtpi * ex * inv + slope) * qc_i * qj;
       }
     }
     if (GRAD) {

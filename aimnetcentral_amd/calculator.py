@@ -536,7 +536,7 @@ class AIMNet2Calculator:
                 pbc3 = tuple(bool(x) for x in p) if p.ndim == 1 else pbc  # per-system flags: the engine uploads them as int32
             if self._dd is not None:
                 if (coord.ndim != 2 or n_mol != 1 or cell is None or cell.ndim != 2 or pbc3 != (True, True, True) or ext_lists or
-                        method not in (None, "dsf") or host_out or defer_status):
+                        method not in (None, "dsf") or defer_status):
                     raise ValueError("domain decomposition (set_domain_decomposition) takes ONE fully periodic system in the flat (N, 3) "
                                      "layout with Coulomb method 'dsf' or none, evaluated synchronously")
                 q_sys = self._engine_charge(charge, d.get("mult")).detach().cpu().numpy().reshape(-1)
@@ -544,6 +544,8 @@ class AIMNet2Calculator:
                                     stress=bool(stress), coulomb=method or "none", dsf_rc=self._dsf_rc, dsf_alpha=self._dsf_alpha,
                                     dftd3=self._dftd3_options(), grid=self._dd_grid)
                 res["energy"] = res["energy"].reshape(1)
+                if host_out:  # (the ASE adapter's request: CPU tensors)
+                    res = {k: v.cpu() for k, v in res.items()}
             else:
                 res = self.engine.eval(
                     coord_f, numbers_f, mol_idx, self._engine_charge(charge, d.get("mult")), cell=cell, pbc=pbc3, forces=bool(forces),

@@ -62,6 +62,7 @@ def main_calculator(out_path: str):
     ref = calc(data, forces=True, stress=True)
     calc.set_domain_decomposition(True)
     out = calc(data, forces=True, stress=True)
+    out_h = calc.eval(data, forces=True, host_out=True)  # (what the ASE adapter asks for: CPU tensors)
     bad = None
     try:
         calc({"coord": inp["coord"][None], "numbers": inp["numbers"][None], "charge": [0.0], "cell": inp["cell"]}, forces=True)
@@ -76,7 +77,8 @@ def main_calculator(out_path: str):
                "ref_shapes": {k: list(v.shape) for k, v in ref.items()},
                "dE": float((out["energy"] - ref["energy"]).abs().max()), "dF_violations": int((ratio > 1).sum()),
                "dF_worst_ratio": float(ratio.max()), "dq_max": float((out["charges"] - ref["charges"]).abs().max()),
-               "ds_max": float((out["stress"] - ref["stress"]).abs().max()), "batch_refused": bad,
+               "ds_max": float((out["stress"] - ref["stress"]).abs().max()), "batch_refused": bad, "host_out_on_cpu": bool(all(not v.is_cuda for v in out_h.values()) and
+                                                                        torch.equal(out_h["forces"], out["forces"].cpu())),
                "off_again_bitwise": bool(torch.equal(back["forces"], ref["forces"]) and torch.equal(back["energy"], ref["energy"]))}
         with open(out_path, "w") as fh:
             json.dump(rec, fh)

@@ -110,7 +110,7 @@ def test_calculator_surface(tmp_path):
     assert rec["shapes"] == rec["ref_shapes"] and rec["shapes"]["energy"] == [1] and rec["shapes"]["stress"] == [3, 3]
     assert rec["dE"] <= max(1e-5, 5e-7 * 1536) and rec["dF_violations"] <= 4 and rec["dF_worst_ratio"] <= 2.0, rec
     assert rec["dq_max"] <= 1e-4 and rec["ds_max"] <= 1e-5, rec
-    assert rec["batch_refused"] and "domain decomposition" in rec["batch_refused"] and rec["off_again_bitwise"]
+    assert rec["batch_refused"] and "domain decomposition" in rec["batch_refused"] and rec["off_again_bitwise"] and rec["host_out_on_cpu"]
 
 
 def test_row_overflow_on_one_rank_is_repeated_by_all(tmp_path):

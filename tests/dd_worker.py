@@ -78,7 +78,7 @@ def main_calculator(out_path: str):
                "dE": float((out["energy"] - ref["energy"]).abs().max()), "dF_violations": int((ratio > 1).sum()),
                "dF_worst_ratio": float(ratio.max()), "dq_max": float((out["charges"] - ref["charges"]).abs().max()),
                "ds_max": float((out["stress"] - ref["stress"]).abs().max()), "batch_refused": bad, "host_out_on_cpu": bool(all(not v.is_cuda for v in out_h.values()) and
-                                                                        torch.equal(out_h["forces"], out["forces"].cpu())),
+                                                                        torch.allclose(out_h["forces"], out["forces"].cpu(), rtol=1e-4, atol=1e-5)),
                "off_again_bitwise": bool(torch.equal(back["forces"], ref["forces"]) and torch.equal(back["energy"], ref["energy"]))}
         with open(out_path, "w") as fh:
             json.dump(rec, fh)

@@ -213,6 +213,8 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
       // 4-deep software pipeline over the neighbour rows: the kernel is latency-bound (25 VALU
       // instructions per 1 KiB row), so keep four row loads in flight per wave
       const int qc_f = lane & 3;
+      const int qsel = max(qc_f - 1, 0);
+      (void)qsel;
       const float fm0 = qc_f == 0 ? 1.f : 0.f, fm1 = qc_f == 1 ? 1.f : 0.f, fm2 = qc_f == 2 ? 1.f : 0.f,
                   fm3 = qc_f == 3 ? 1.f : 0.f;
       auto rowj = [&](int j) {  // j wave-uniform -> scalar address
@@ -223,11 +225,26 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
         const float4 u = L.ud[mm];
         const f2 t0 = mk2(av.x, av.y) * mk2(gv.x, gv.y), t1 = mk2(av.z, av.w) * mk2(gv.z, gv.w);
         acc[0][0] += t0;       acc[0][1] += t1;
+#ifdef AIMNET_PROBE_FWD_SPLAT_MOV  // measurement build: the compiler's form (a v_mov pair per component builds the {u, u} splat)
         acc[1][0] += t0 * u.x; acc[1][1] += t1 * u.x;
         acc[2][0] += t0 * u.y; acc[2][1] += t1 * u.y;
         acc[3][0] += t0 * u.z; acc[3][1] += t1 * u.z;
+#else
+        const f2 uxy = mk2(u.x, u.y), uzw = mk2(u.z, u.w);  // (halves of the 16-byte LDS read: no instruction)
+        pk_fma_bcast<false>(acc[1][0], t0, uxy); pk_fma_bcast<false>(acc[1][1], t1, uxy);
+        pk_fma_bcast<true>(acc[2][0], t0, uxy);  pk_fma_bcast<true>(acc[2][1], t1, uxy);
+        pk_fma_bcast<false>(acc[3][0], t0, uzw); pk_fma_bcast<false>(acc[3][1], t1, uzw);
+#endif
         if (HAS_Q) {
+#ifdef AIMNET_PROBE_FWD_QSEL_FMA  // measurement build: the component selected by three FMAs with 0 / 1 weights (rounds 1 - 5)
           const float w = L.gs[mm][lane >> 2] * (fm0 + fm1 * u.x + fm2 * u.y + fm3 * u.z);
+#else
+          // the lane's component (1, ux, uy, uz)[lane & 3] read straight from the staged pair record: one 4-byte LDS read and a
+          // select instead of three FMAs with 0 / 1 weights
+          float uc = reinterpret_cast<const float*>(&L.ud[mm])[qsel];
+          uc = qc_f == 0 ? 1.0f : uc;
+          const float w = L.gs[mm][lane >> 2] * uc;
+#endif
 #pragma unroll
           for (int ch = 0; ch < NQ; ++ch) accq[ch] += L.qj[ch][mm] * w;
         }
@@ -287,6 +304,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
         // (the four ids of a group come with one uniform-address ds_read_b128; mm + 4 <= 60 inside the guard)
         int4 jj = *reinterpret_cast<const int4*>(&L.j[0]);
         float4 r0 = rowj(jj.x), r1 = rowj(jj.y), r2 = rowj(jj.z), r3 = rowj(jj.w);
+#ifndef AIMNET_PROBE_FWD_PINGPONG  // one register set, rotated by copies (two 64-bit moves per pair)
         for (int mm = 0; mm < nch4; mm += 4) {
           const float4 c0 = r0, c1 = r1, c2 = r2, c3 = r3;
           if (mm + 4 < nch4) {
@@ -295,6 +313,24 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : AIMNET_PROBE_FWD_OCC) void conv_fw
           }
           use(mm, c0); use(mm + 1, c1); use(mm + 2, c2); use(mm + 3, c3);
         }
+#else
+        // measurement build: two register sets in turn (r and s), no copies - 55 instead of 67 vector instructions per four pairs, but
+        // the kernel then needs 64 B of scratch at 128 VGPRs: 65.7 against 63.4 us per dispatch (profiles/r6_conv_fwd.md)
+        float4 s0 = r0, s1 = r1, s2 = r2, s3 = r3;
+        for (int mm = 0; mm < nch4; mm += 8) {
+          if (mm + 4 < nch4) {
+            jj = *reinterpret_cast<const int4*>(&L.j[mm + 4]);
+            s0 = rowj(jj.x); s1 = rowj(jj.y); s2 = rowj(jj.z); s3 = rowj(jj.w);
+          }
+          use(mm, r0); use(mm + 1, r1); use(mm + 2, r2); use(mm + 3, r3);
+          if (mm + 4 >= nch4) break;
+          if (mm + 8 < nch4) {
+            jj = *reinterpret_cast<const int4*>(&L.j[mm + 8]);
+            r0 = rowj(jj.x); r1 = rowj(jj.y); r2 = rowj(jj.z); r3 = rowj(jj.w);
+          }
+          use(mm + 4, s0); use(mm + 5, s1); use(mm + 6, s2); use(mm + 7, s3);
+        }
+#endif
 #endif
       }
     }
@@ -678,6 +714,8 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
   const int qg = lane >> 2, qc = lane & 3;
   const float qm0 = qc == 0 ? 1.f : 0.f, qm1 = qc == 1 ? 1.f : 0.f, qm2 = qc == 2 ? 1.f : 0.f, qm3 = qc == 3 ? 1.f : 0.f;
   const float qsgn = qc == 0 ? 1.f : -1.f;
+  const int qc_sel = max(qc - 1, 0);  // word of the staged (ux, uy, uz, d) record that holds the lane's component (qc == 0: 1)
+  (void)qc_sel;
 
   __shared__ float s_red[SPLIT ? 3 * (4 * 64 + 14) : 1];  // SPLIT: per-lane abar partials + 14 reduced scalars of waves 1..3
 
@@ -807,9 +845,21 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
         const f2 Sj[4][2] = {{mk2(R.s0.x, R.s0.y), mk2(R.s0.z, R.s0.w)}, {mk2(R.s1.x, R.s1.y), mk2(R.s1.z, R.s1.w)},
                              {mk2(R.s2.x, R.s2.y), mk2(R.s2.z, R.s2.w)}, {mk2(R.s3.x, R.s3.y), mk2(R.s3.z, R.s3.w)}};
         f2 Dv = mk2(0.f, 0.f), U0v = mk2(0.f, 0.f), U1v = mk2(0.f, 0.f), U2v = mk2(0.f, 0.f);
+        const f2 uxy = mk2(u.x, u.y), uzw = mk2(u.z, u.w);  // (halves of the 16-byte LDS read: no instruction)
+        (void)uxy; (void)uzw;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
+#ifdef AIMNET_PROBE_BWD_SPLAT_MOV  // measurement build: the compiler's form (v_mov pairs build the {u, u} splats)
           const f2 Pp = Sj[0][hf] - (u.x * Sj[1][hf] + u.y * Sj[2][hf] + u.z * Sj[3][hf]);
+#else
+          // the component of u taken from its register pair by the packed instructions' op_sel modifiers (conv_common.h,
+          // pk_fma_bcast): no splat moves.  (Not bit-identical to the compiler's form - it contracts the sums differently - but the
+          // same arithmetic to fp32 rounding: checksums differ in the last bits, every parity test unchanged.)
+          f2 Tj = pk_mul_bcast<false>(Sj[1][hf], uxy);
+          pk_fma_bcast<true>(Tj, Sj[2][hf], uxy);
+          pk_fma_bcast<false>(Tj, Sj[3][hf], uzw);
+          const f2 Pp = Sj[0][hf] - Tj;
+#endif
           if (NEED_ABAR) ab[hf] += gsv[hf] * Pp;
           const f2 tp = gsv[hf] * ai[hf];
           if (XE) {
@@ -818,7 +868,14 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
             U1v += tp * Sj[2][hf];
             U2v += tp * Sj[3][hf];
           } else {
+#ifdef AIMNET_PROBE_BWD_SPLAT_MOV
             const f2 P = Si[0][hf] + (u.x * Si[1][hf] + u.y * Si[2][hf] + u.z * Si[3][hf]);
+#else
+            f2 Ti = pk_mul_bcast<false>(Si[1][hf], uxy);
+            pk_fma_bcast<true>(Ti, Si[2][hf], uxy);
+            pk_fma_bcast<false>(Ti, Si[3][hf], uzw);
+            const f2 P = Si[0][hf] + Ti;
+#endif
             Dv += dg[hf] * (aj[hf] * P + ai[hf] * Pp);
             const f2 t = gsv[hf] * aj[hf];
             U0v += tp * Sj[1][hf] - t * Si[1][hf];
@@ -831,7 +888,13 @@ __global__ __launch_bounds__(256, 4) void conv_bwd_kernel(const float* __restric
           // lane (g, c) of the charge convolution Sq[g,c] = sum_m q_j gs_g (1,u)_c, branch-free:
           // qm0..qm3 are the lane's one-hot component selectors, qsgn = (1,-1,-1,-1)[c] for the reverse pair
           const float gq = L.gs[mm][qg], dgq = L.dgs[mm][qg];
+#ifdef AIMNET_PROBE_BWD_SPLAT_MOV
           const float uc = qm0 + qm1 * u.x + qm2 * u.y + qm3 * u.z;
+#else
+          // (1, ux, uy, uz)[c] read from the staged pair record and a select, instead of three FMAs with 0 / 1 weights
+          float uc = reinterpret_cast<const float*>(&L.ud[mm])[qc_sel];
+          uc = qc == 0 ? 1.0f : uc;
+#endif
 #pragma unroll
           for (int ch = 0; ch < NQ; ++ch) {
             const float sqj = R.sq[ch];

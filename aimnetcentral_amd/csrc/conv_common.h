@@ -23,6 +23,27 @@ __device__ __forceinline__ f2 mk2(float a, float b) {
   return r;
 }
 
+// acc += t * s for a 2-vector t and a scalar s that sits in one half of a register PAIR p: the packed FMA broadcasts that half to
+// both result lanes through its op_sel modifiers, so no v_mov builds the {s, s} splat (the compiler emits three moves per pair of
+// conv_fwd for the three components of u: 17 % of the loop's vector instructions).  HI: s = p.y, else p.x.
+template <bool HI>
+__device__ __forceinline__ void pk_fma_bcast(f2& acc, const f2& t, const f2& p) {
+  if (HI)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(t), "v"(p));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(t), "v"(p));
+}
+
+template <bool HI>
+__device__ __forceinline__ f2 pk_mul_bcast(const f2& t, const f2& p) {  // t * s, s = one half of the register pair p
+  f2 r;
+  if (HI)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(t), "v"(p));
+  else
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(t), "v"(p));
+  return r;
+}
+
 // Persistent-loop atom assignment.  Hardware places block b on XCD b % 8 (observed; speed only): give
 // each XCD one CONTIGUOUS range of atoms, processed in order, so that when the input is spatially
 // ordered (crystals, MD frames) the neighbour rows an XCD gathers were mostly produced / recently

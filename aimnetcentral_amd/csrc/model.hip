@@ -619,9 +619,23 @@ __global__ __launch_bounds__(256) void coulomb_dsf_kernel(const float* __restric
       w = inv;
       dw = -inv * inv;
     } else {
-      const float ec = erfcf(al * d);
+      // erfc(x) = exp(-x^2) t P(t), t = 1 / (1 + x / 2): the degree-9 fit of the list-free walk below (coulomb_dsf_walk_kernel) - one
+      // exponential serves the value and the derivative, and matrix and walk evaluate the same pair term
+      const float ex = __builtin_amdgcn_exp2f(-1.4426950408889634f * al * al * d * d);
+      const float tt = __builtin_amdgcn_rcpf(fmaf(0.5f * al, d, 1.0f));
+      float pe = 2.672036890e-02f;
+      pe = fmaf(pe, tt, -2.020067459e-01f);
+      pe = fmaf(pe, tt, 6.150174393e-01f);
+      pe = fmaf(pe, tt, -9.195323909e-01f);
+      pe = fmaf(pe, tt, 6.300562657e-01f);
+      pe = fmaf(pe, tt, -2.111610618e-01f);
+      pe = fmaf(pe, tt, 2.648643249e-01f);
+      pe = fmaf(pe, tt, 2.301390953e-01f);
+      pe = fmaf(pe, tt, 2.838921720e-01f);
+      pe = fmaf(pe, tt, 2.820105286e-01f);
+      const float ec = pe * tt * ex;
       w = ec * inv - sv + (d - Rc) * slope;
-      dw = -ec * inv * inv - two_a_sqrtpi * expf(-al * al * d * d) * inv + slope;
+      dw = -ec * inv * inv - two_a_sqrtpi * ex * inv + slope;
     }
     pair_add<GRAD, STRESS>(A, w, dw, qi, q[j], rx * inv, ry * inv, rz * inv, d);
   }
